@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+TEST INFRASTRUCTURE, build-container only (needs /root/reference).  The reference
+is imported in place through ``bootstrap.py``; this script only *drives* it (it
+builds the reference's own objects, calls ``rhs.full(Q)`` and reads the arrays it
+leaves behind) and stores inputs + expected outputs as compressed ``.npz``.
+No reference source text is stored - fixtures are data.
+
+    python oracle/refharness/gen_golden.py [case ...]
+
+Cases are listed in CASES below.  Every fixture holds, per stored panel ``pN/``:
+inputs (Q, operators' 1-D pieces, every metric array the path reads, the halo
+faces received from the 4 neighbour panels) and outputs (per-phase
+intermediates, final R), for real Q and for a complex-step perturbed Q.
+"""
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+from bootstrap import bootstrap, REF  # noqa: E402
+
+MPI = bootstrap(6)
+
+import numpy  # noqa: E402
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+SCHEMA_TEXT = open(os.path.join(REF, "config", "config-format.json")).read()
+
+
+def _config(ini, overrides):
+    from common import Configuration, ConfigurationSchema
+
+    cfg = Configuration(open(os.path.join(REF, "config", ini)).read(), ConfigurationSchema(SCHEMA_TEXT))
+    for k, v in overrides.items():
+        setattr(cfg, k, v)
+    if "num_elements_horizontal" in overrides:
+        cfg.num_elements_horizontal_total = overrides["num_elements_horizontal"]
+    if "num_solpts" in overrides:
+        cfg.initial_num_solpts = overrides["num_solpts"]
+    cfg.output_freq = 0
+    cfg.save_state_freq = 0
+    cfg.stat_freq = 0
+    cfg.output_dir = "/tmp/wx_golden_out"
+    return cfg
+
+
+def _ops_1d(ops, geom):
+    return {
+        "ops/solution_points": numpy.asarray(geom.solutionPoints, dtype=float),
+        "ops/glweights": numpy.asarray(geom.glweights, dtype=float),
+        "ops/extrap_neg": numpy.asarray(ops.extrap_west, dtype=float),
+        "ops/extrap_pos": numpy.asarray(ops.extrap_east, dtype=float),
+        "ops/diff_solpt": numpy.asarray(ops.diff_solpt, dtype=float),
+        "ops/correction": numpy.asarray(ops.correction, dtype=float),
+        "ops/highfilter": numpy.asarray(ops.highfilter, dtype=float),
+    }
+
+
+# ---------------------------------------------------------------------------------------------
+# 3-D Euler on the cubed sphere (rhs_dfr.py + pde_euler_cubesphere.py + fluxes.py)
+# ---------------------------------------------------------------------------------------------
+EULER_PHASE_ATTRS = [
+    "q_itf_x1", "q_itf_x2", "q_itf_x3",
+    "q_itf_s", "q_itf_n", "q_itf_w", "q_itf_e",
+    "f_x1", "f_x2", "f_x3", "pressure", "log_p",
+    "wflux_adv_x1", "wflux_adv_x2", "wflux_adv_x3",
+    "wflux_pres_x1", "wflux_pres_x2", "wflux_pres_x3",
+    "f_itf_x1", "f_itf_x2", "f_itf_x3",
+    "pressure_itf_x1", "pressure_itf_x2", "pressure_itf_x3",
+    "wflux_adv_itf_x1", "wflux_adv_itf_x2", "wflux_adv_itf_x3",
+    "wflux_pres_itf_x1", "wflux_pres_itf_x2", "wflux_pres_itf_x3",
+    "forcing",
+]
+# Small: kept for every stored panel.  Phases: only when ``phases`` is requested.
+EULER_LIGHT_ATTRS = ["q_itf_s", "q_itf_n", "q_itf_w", "q_itf_e"]
+
+EULER_METRIC_ATTRS = [
+    "sqrtG_new", "inv_sqrtG_new", "h_contra_new", "christoffel", "inv_dzdeta_new",
+    "sqrtG_itf_i_new", "sqrtG_itf_j_new", "sqrtG_itf_k_new",
+    "h_contra_itf_i_new", "h_contra_itf_j_new", "h_contra_itf_k_new",
+]
+
+
+def _damping_fields(geom, metric, case_number, shape):
+    """Static Rayleigh-damping fields of cases 21/22, obtained by probing the reference's
+    dcmip_schar_damping with unit states: forcing_i += coef*rho*(u_i - uref_i)."""
+    from init.dcmip import dcmip_schar_damping
+
+    shear = case_number == 22
+    ones = numpy.ones(shape)
+    zeros = numpy.zeros(shape)
+    f0 = numpy.zeros((5,) + shape)
+    dcmip_schar_damping(f0, ones, zeros, zeros, zeros, metric, geom, shear=shear, new_layout=True)
+    f1 = numpy.zeros((5,) + shape)
+    dcmip_schar_damping(f1, ones, ones, ones, ones, metric, geom, shear=shear, new_layout=True)
+    coef = f1[1] - f0[1]  # = coef * 1
+    uref = numpy.zeros((3,) + shape)
+    nz = coef != 0.0
+    for i in range(3):
+        uref[i][nz] = -f0[1 + i][nz] / coef[nz]
+    return coef, uref
+
+
+def euler_case(name, ini, overrides, metric_panels, phase_panels, perturb=0.0, seed=1234):
+    cfg_probe = _config(ini, overrides)
+    n = cfg_probe.num_solpts
+    print(f"[{name}] {ini} n={n} H={cfg_probe.num_elements_horizontal} V={cfg_probe.num_elements_vertical}",
+          flush=True)
+
+    def work(rank):
+        from device import CpuDevice
+        from process_topology import ProcessTopology
+        from geometry import CubedSphere3D, DFROperators
+        from init.init_state_vars import init_state_vars
+        from rhs.rhs_selector import RhsBundle
+
+        cfg = _config(ini, overrides)
+        comm = MPI.COMM_WORLD
+        dev = CpuDevice(comm)
+        pt = ProcessTopology(dev, comm=comm)
+        geom = CubedSphere3D(
+            cfg.num_elements_horizontal, cfg.num_elements_vertical, cfg.num_solpts,
+            cfg.lambda0, cfg.phi0, cfg.alpha0, cfg.ztop, pt, cfg, dev,
+        )
+        ops = DFROperators(geom, cfg, dev)
+        Q, topo, metric = init_state_vars(geom, ops, cfg)
+        rhs = RhsBundle(geom, ops, metric, topo, pt, cfg, Q.shape, False)
+
+        rng = numpy.random.default_rng(seed + rank)
+        if perturb > 0.0:
+            # O(1)-RHS state: seeded relative perturbation of the balanced initial condition
+            Q = Q * (1.0 + perturb * rng.uniform(-1.0, 1.0, Q.shape))
+            umag = numpy.abs(Q[1]).max() + 1e-12 * numpy.abs(Q[0]).max()
+            Q[3] = Q[3] + Q[0] * perturb * 1e-5 * rng.uniform(-1.0, 1.0, Q[0].shape)
+
+        out = {}
+        out["Q"] = Q.copy()
+        R = rhs.full(Q)
+        out["R"] = R.copy()
+        r = rhs.full
+        want = set(EULER_LIGHT_ATTRS)
+        if rank in phase_panels:
+            want |= set(EULER_PHASE_ATTRS)
+        for a in sorted(want):
+            out["phase/" + a] = numpy.array(getattr(r, a), copy=True)
+        if rank in phase_panels:
+            out["phase/df1_dx1"] = r.df1_dx1.copy()  # after corrections (phase 7)
+            out["phase/df2_dx2"] = r.df2_dx2.copy()
+            out["phase/df3_dx3"] = r.df3_dx3.copy()
+            out["phase/w_df1_dx1"] = r.w_df1_dx1.copy()
+            out["phase/w_df2_dx2"] = r.w_df2_dx2.copy()
+            out["phase/w_df3_dx3"] = numpy.array(r.w_df3_dx3, copy=True)
+
+        # complex-step perturbed evaluation (matvec_fun semantics: Q + i*eps*v)
+        v = rng.uniform(-1.0, 1.0, Q.shape) * numpy.abs(Q).max(axis=(1, 2, 3, 4), keepdims=True) * 1e-3
+        eps = numpy.sqrt(numpy.finfo(float).eps)
+        Qc = Q + 1j * eps * v
+        Rc = rhs.full(Qc)
+        if rank in metric_panels:  # complex inputs/outputs only where they can be checked
+            out["V"] = v
+            out["Rc"] = Rc.copy()
+        for a in EULER_LIGHT_ATTRS:
+            out["cphase/" + a] = numpy.array(getattr(r, a), copy=True)
+
+        if rank in metric_panels:
+            for a in EULER_METRIC_ATTRS:
+                out["metric/" + a] = numpy.array(getattr(metric, a), copy=True)
+            if cfg.case_number in (21, 22):
+                coef, uref = _damping_fields(geom, metric, cfg.case_number, Q.shape[1:])
+                out["metric/damp_coef"] = coef
+                out["metric/damp_uref"] = uref
+        out["geom/boundary_sn_new"] = numpy.array(geom.boundary_sn_new, copy=True)
+        out["geom/boundary_we_new"] = numpy.array(geom.boundary_we_new, copy=True)
+        if rank == 0:
+            out.update(_ops_1d(ops, geom))
+            out["meta/case_number"] = numpy.int64(cfg.case_number)
+            out["meta/n"] = numpy.int64(cfg.num_solpts)
+            out["meta/H"] = numpy.int64(cfg.num_elements_horizontal)
+            out["meta/V"] = numpy.int64(cfg.num_elements_vertical)
+            out["meta/eps"] = numpy.float64(eps)
+            # Kronecker-ordering pin: dense operators applied to a seeded element
+            u = numpy.random.default_rng(7).uniform(-1, 1, n**3)
+            out["kron/u"] = u
+            for opn in ("derivative_x", "derivative_y", "derivative_z", "extrap_x", "extrap_y", "extrap_z",
+                        "highfilter_k"):
+                out["kron/" + opn] = u @ getattr(ops, opn)
+            f = numpy.random.default_rng(8).uniform(-1, 1, 2 * n**2)
+            out["kron/f"] = f
+            for opn in ("correction_WE", "correction_SN", "correction_DU"):
+                out["kron/" + opn] = f @ getattr(ops, opn)
+        return out
+
+    t0 = time.time()
+    MPI.reset_world(6)
+    res, err = MPI.run_ranks(work, 6)
+    for e in err:
+        if e:
+            print(e)
+            raise SystemExit(1)
+    flat = {}
+    for p, d in enumerate(res):
+        for k, v in d.items():
+            if k.startswith(("ops/", "meta/", "kron/")):
+                flat[k] = v
+            else:
+                flat[f"p{p}/{k}"] = v
+    path = os.path.join(GOLDEN, name + ".npz")
+    numpy.savez_compressed(path, **flat)
+    print(f"   -> {path}  {os.path.getsize(path)/1e6:.2f} MB  ({time.time()-t0:.1f}s)  "
+          f"max|R| per var panel0 = {numpy.abs(res[0]['R']).max(axis=(1,2,3,4))}", flush=True)
+
+
+CASES = {
+    # balanced gravity-wave state, small n: all panels carry metrics + phases (exchange coverage)
+    "euler3d_c31_n3_h4_v2": lambda nm: euler_case(
+        nm, "dcmip31.ini", dict(num_solpts=3, num_elements_horizontal=4, num_elements_vertical=2),
+        metric_panels=range(6), phase_panels=(0, 4)),
+    # same with an O(1) RHS (1 % seeded perturbation): tolerance is meaningful without cancellation
+    "euler3d_c31p_n3_h4_v2": lambda nm: euler_case(
+        nm, "dcmip31.ini", dict(num_solpts=3, num_elements_horizontal=4, num_elements_vertical=2),
+        metric_panels=range(6), phase_panels=(), perturb=0.01),
+    # the benchmark order p=7
+    "euler3d_c31p_n8_h2_v2": lambda nm: euler_case(
+        nm, "dcmip31.ini", dict(num_solpts=8, num_elements_horizontal=2, num_elements_vertical=2),
+        metric_panels=(0, 4), phase_panels=(), perturb=0.01),
+    "euler3d_c31_n8_h2_v2": lambda nm: euler_case(
+        nm, "dcmip31.ini", dict(num_solpts=8, num_elements_horizontal=2, num_elements_vertical=2),
+        metric_panels=(0, 4), phase_panels=()),
+    # topography + Rayleigh damping (Schaer mountain), even n
+    "euler3d_c21_n4_h3_v4": lambda nm: euler_case(
+        nm, "dcmip21.ini", dict(num_solpts=4, num_elements_horizontal=3, num_elements_vertical=4),
+        metric_panels=(0, 3, 5), phase_panels=()),
+}
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLDEN, exist_ok=True)
+    names = sys.argv[1:] or list(CASES)
+    for nm in names:
+        CASES[nm](nm)
