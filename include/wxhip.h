@@ -1,0 +1,126 @@
+/*
+ * wxhip.h - C ABI of the MI355X-native RHS / JVP engine (libwxhip.so).
+ *
+ * Drop-in boundary for ONE hot path of WxFactory: evaluation of the spatial
+ * right-hand side R(Q) of the DFR discretisation on the cubed sphere.
+ * Every entry point cites the reference interface it replaces (paths relative to
+ * the WxFactory tree, wx_factory/...).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no exceptions cross the boundary.
+ *   - every call returns a wx_status; wx_last_error() gives the message (thread local).
+ *   - all array arguments are DEVICE pointers unless marked [host]; the caller owns them
+ *     (same ownership rule as the reference's pybind module, pde/interface.hpp:158-171).
+ *   - all work is enqueued on the caller's hipStream_t; no entry point synchronises the
+ *     device, allocates after plan creation, or keeps a pointer to q / rhs / halo.
+ *   - arrays are C-contiguous float64 (WX_F64) or complex128 (WX_C128, interleaved
+ *     re,im) in the reference's element-blocked layout (geometry/cubed_sphere_3d.py:187-205):
+ *         state     q[var][ek][ej][ei][p],  p = (kl*n + jl)*n + il
+ *         faces     [..][2*n*n]  first n*n = minus side (W/S/bottom), then plus side
+ */
+#ifndef WXHIP_H
+#define WXHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* wx_stream; /* hipStream_t */
+
+typedef enum {
+    WX_OK = 0,
+    WX_ERR_INVALID = 1,     /* bad argument (null pointer, unsupported n, shape mismatch) */
+    WX_ERR_UNSUPPORTED = 2, /* valid request this build cannot serve (dtype, case) */
+    WX_ERR_HIP = 3,         /* a HIP runtime call failed; message has hipGetErrorString */
+    WX_ERR_NOMEM = 4
+} wx_status;
+
+typedef enum { WX_F64 = 0, WX_C128 = 1 } wx_dtype;
+
+/* Which elements of the tile an RHS launch covers (lets the caller overlap the halo
+ * exchange with the interior, the ordering of rhs/rhs.py:88-118). */
+typedef enum {
+    WX_REGION_ALL = 0,
+    WX_REGION_INTERIOR = 1, /* elements that touch no lateral tile edge: need no halo */
+    WX_REGION_BOUNDARY = 2  /* the ring of elements on the four lateral tile edges   */
+} wx_region;
+
+const char* wx_last_error(void);
+/* "wxhip <version> gfx950" */
+const char* wx_version(void);
+/* number of HIP devices visible; <0 on error.  Does not create a context. */
+int wx_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * 3-D Euler on a cubed-sphere tile.
+ * Replaces  rhs/rhs_dfr.py:48-313  (RHSDirecFluxReconstruction_mpi, phases 1-8 of
+ *           rhs/rhs.py:75-122) together with pde/pde_euler_cubesphere.py:72-290 and
+ *           pde/fluxes.py:150-222, 326-403, 507-582.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Static fields read by the path, exactly the reference's arrays, read IN PLACE (no copy):
+ * geometry/metric3d.py:1108-1157.  nh = H+2, nv = V+2 (halo-padded interface arrays). */
+typedef struct {
+    const double* sqrtG;          /* (V,H,H,n^3)        metric.sqrtG_new                 */
+    const double* h_contra;       /* (3,3,V,H,H,n^3)    metric.h_contra_new              */
+    const double* christoffel;    /* (3,9,V,H,H,n^3)    metric.christoffel               */
+    const double* inv_dzdeta;     /* (V,H,H,n^3)        metric.inv_dzdeta_new            */
+    const double* sqrtG_itf_i;    /* (V,H,nh,2n^2)      metric.sqrtG_itf_i_new           */
+    const double* sqrtG_itf_j;    /* (V,nh,H,2n^2)      metric.sqrtG_itf_j_new           */
+    const double* sqrtG_itf_k;    /* (nv,H,H,2n^2)      metric.sqrtG_itf_k_new           */
+    const double* h_contra_itf_i; /* (3,3,V,H,nh,2n^2)  metric.h_contra_itf_i_new        */
+    const double* h_contra_itf_j; /* (3,3,V,nh,H,2n^2)  metric.h_contra_itf_j_new        */
+    const double* h_contra_itf_k; /* (3,3,nv,H,H,2n^2)  metric.h_contra_itf_k_new        */
+    /* Rayleigh sponge of DCMIP 2-1/2-2 (init/dcmip.py:676-757): forcing_i += damp_coef*rho*
+     * (u_i - damp_uref_i).  Both NULL unless case_number is 21 or 22. */
+    const double* damp_coef;      /* (V,H,H,n^3)   sin^2(pi/2 (z-zh)/(ztop-zh))/tau0 above zh, else 0 */
+    const double* damp_uref;      /* (3,V,H,H,n^3) contravariant reference wind          */
+    /* tan of the edge coordinate used by the vector rotation (process_topology.py:137-175):
+     * geom.boundary_sn (H*n values along x1), geom.boundary_we (H*n values along x2). */
+    const double* boundary_sn;
+    const double* boundary_we;
+} wx_euler3d_metric;
+
+/* 1-D operator pieces [host], geometry/operators.py:55-80, 144-148 (row-major). */
+typedef struct {
+    const double* extrap_neg; /* (n)    ops.extrap_west  */
+    const double* extrap_pos; /* (n)    ops.extrap_east  */
+    const double* diff_solpt; /* (n,n)  ops.diff_solpt   */
+    const double* correction; /* (n,2)  ops.correction   */
+    const double* highfilter; /* (n,n)  ops.highfilter   */
+} wx_dfr_ops;
+
+typedef struct wx_euler3d_plan wx_euler3d_plan;
+
+/* Build a plan for one tile.  `panel` (0..5) selects the flip/rotation tables of
+ * process_topology.py:105-175 for the four lateral edges (one tile per panel).
+ * Allocates the plan's private interface buffer (6*5*n^2 values per element). */
+wx_status wx_euler3d_plan_create(wx_euler3d_plan** plan, int n, int H, int V, int case_number, wx_dtype dtype,
+                                 int panel, const wx_dfr_ops* ops, const wx_euler3d_metric* metric);
+wx_status wx_euler3d_plan_destroy(wx_euler3d_plan* plan);
+
+/* Number of ELEMENTS of dtype in one edge message: 5*V*H*n^2 (layout [var][ek][along][n^2]). */
+size_t wx_euler3d_edge_count(const wx_euler3d_plan* plan);
+
+/* Phases 1-2, sender side (rhs_dfr.py:50-71, 141-172; process_topology.py:269-386):
+ * extrapolate q to all element faces (log-space for rho, rho*theta) into the plan's
+ * interface buffer, and write the four outward tile-edge faces - rotated into the
+ * neighbour's basis and flipped as the reference does before MPI - to send[e]
+ * (e = S,N,W,E; each wx_euler3d_edge_count() values).  What lands in send[e] is exactly
+ * what the neighbour's q_itf_{s,n,w,e} holds after ExchangeRequest.wait(). */
+wx_status wx_euler3d_extrap_pack(wx_euler3d_plan* plan, const void* q, void* const send[4], wx_stream stream);
+
+/* Phases 3-8 (rhs_dfr.py:73-139, 203-313): pointwise fluxes, derivatives, Rusanov fluxes
+ * with the received halo faces halo[e] (receiver-local ordering, what wait() returns),
+ * corrections, forcing; writes rhs (same layout/dtype as q) for the elements of `region`.
+ * Requires wx_euler3d_extrap_pack(plan, q, ...) to have run on the same stream. */
+wx_status wx_euler3d_rhs(wx_euler3d_plan* plan, const void* q, const void* const halo[4], void* rhs,
+                         wx_region region, wx_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WXHIP_H */

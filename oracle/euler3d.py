@@ -300,8 +300,19 @@ class Euler3DOracle:
             R[...] = 0.0
         if want is not None:
             want.update(dict(F=F, A=A, B=B, p=p, logp=logp, fc=fc, wac=wac, wpc=wpc, pc=pc, forcing=forcing,
-                             padded=(f1, f2, f3)))
+                             padded=(f1, f2, f3), dF=dF, inv_sg=inv_sg))
         return R
+
+    @staticmethod
+    def cancel_scale(want):
+        """s_v of SURVEY.md section 7 (hard part 1): magnitude of the largest of the terms that
+        cancel in row v of R = -1/sqrtG * sum_d dF_d - forcing (for the rho-w row the flux-form
+        divergence terms stand in for the equally large W^d terms)."""
+        ax = (1, 2, 3, 4)
+        s = numpy.abs(want["forcing"].real).max(axis=ax)
+        for d in range(3):
+            s = numpy.maximum(s, numpy.abs((want["inv_sg"] * want["dF"][d]).real).max(axis=ax))
+        return s
 
 
 def sphere_rhs(oracles, qs):

@@ -1,0 +1,75 @@
+"""Shared helpers of the test-suite: golden fixture access and error norms."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+EULER_FIXTURES = [
+    "euler3d_c31_n3_h4_v2",
+    "euler3d_c31p_n3_h4_v2",
+    "euler3d_c31p_n8_h2_v2",
+    "euler3d_c31_n8_h2_v2",
+    "euler3d_c21_n4_h3_v4",
+]
+
+_cache = {}
+
+
+class Golden:
+    def __init__(self, name):
+        self.name = name
+        self.z = np.load(os.path.join(GOLDEN, name + ".npz"))
+        self.n, self.H, self.V = int(self.z["meta/n"]), int(self.z["meta/H"]), int(self.z["meta/V"])
+        self.case = int(self.z["meta/case_number"])
+        self.eps = float(self.z["meta/eps"])
+        self.ops = {k[4:]: self.z[k] for k in self.z.files if k.startswith("ops/")}
+
+    def __getitem__(self, k):
+        return self.z[k]
+
+    def has(self, k):
+        return k in self.z.files
+
+    def metric_panels(self):
+        return [p for p in range(6) if f"p{p}/metric/sqrtG_new" in self.z.files]
+
+    def metric(self, p):
+        pre = f"p{p}/metric/"
+        return {k[len(pre):]: self.z[k] for k in self.z.files if k.startswith(pre)}
+
+    def q(self, p, cplx=False):
+        q = self.z[f"p{p}/Q"]
+        if cplx:
+            q = q + 1j * self.eps * self.z[f"p{p}/V"]
+        return q
+
+    def halo(self, p, cplx=False):
+        ph = "cphase" if cplx else "phase"
+        return [self.z[f"p{p}/{ph}/q_itf_{e}"] for e in "snwe"]
+
+    def r(self, p, cplx=False):
+        return self.z[f"p{p}/Rc"] if cplx else self.z[f"p{p}/R"]
+
+
+def golden(name) -> Golden:
+    if name not in _cache:
+        _cache[name] = Golden(name)
+    return _cache[name]
+
+
+def make_oracle(g: Golden, p: int):
+    from oracle.euler3d import Euler3DOracle
+
+    return Euler3DOracle(g.n, g.H, g.V, g.case, g.ops, g.metric(p), g[f"p{p}/geom/boundary_sn_new"],
+                         g[f"p{p}/geom/boundary_we_new"], panel=p)
+
+
+def var_err(a, b):
+    """max-norm error per variable (axis 0)."""
+    ax = tuple(range(1, a.ndim))
+    return np.abs(a - b).max(axis=ax)
+
+
+def var_max(a):
+    return np.abs(a).max(axis=tuple(range(1, a.ndim)))

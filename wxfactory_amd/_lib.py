@@ -1,0 +1,76 @@
+"""ctypes binding of libwxhip.so - the only way the Python host reaches the HIP kernels.
+
+There is NO fallback: if the library is missing or a symbol is absent, importing the
+compute entry points raises.  (Signatures mirror include/wxhip.h one to one.)
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_size_t, c_void_p
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "lib", "libwxhip.so")
+
+WX_OK = 0
+WX_F64, WX_C128 = 0, 1
+WX_REGION_ALL, WX_REGION_INTERIOR, WX_REGION_BOUNDARY = 0, 1, 2
+
+
+class WxError(RuntimeError):
+    pass
+
+
+class DfrOps(ctypes.Structure):
+    _fields_ = [(k, POINTER(c_double)) for k in ("extrap_neg", "extrap_pos", "diff_solpt", "correction", "highfilter")]
+
+
+EULER3D_METRIC_FIELDS = (
+    "sqrtG", "h_contra", "christoffel", "inv_dzdeta",
+    "sqrtG_itf_i", "sqrtG_itf_j", "sqrtG_itf_k",
+    "h_contra_itf_i", "h_contra_itf_j", "h_contra_itf_k",
+    "damp_coef", "damp_uref", "boundary_sn", "boundary_we",
+)
+
+
+class Euler3DMetric(ctypes.Structure):
+    _fields_ = [(k, c_void_p) for k in EULER3D_METRIC_FIELDS]
+
+
+# every symbol include/wxhip.h declares: (restype, argtypes)
+SIGNATURES = {
+    "wx_last_error": (c_char_p, []),
+    "wx_version": (c_char_p, []),
+    "wx_device_count": (c_int, []),
+    "wx_euler3d_plan_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int,
+                                       POINTER(DfrOps), POINTER(Euler3DMetric)]),
+    "wx_euler3d_plan_destroy": (c_int, [c_void_p]),
+    "wx_euler3d_edge_count": (c_size_t, [c_void_p]),
+    "wx_euler3d_extrap_pack": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p]),
+    "wx_euler3d_rhs": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libwxhip.so (once).  Raises WxError when it is not built: no silent fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise WxError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m wxfactory_amd.build` "
+            "(or __graft_entry__.build()). There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str):
+    if status != WX_OK:
+        msg = load().wx_last_error().decode(errors="replace")
+        raise WxError(f"{what} failed (status {status}): {msg}")

@@ -1,0 +1,656 @@
+// 3-D Euler RHS on one cubed-sphere tile: hand-written HIP for gfx950 (MI355X).
+//
+// Replaces reference wx_factory/rhs/rhs_dfr.py:48-313 + pde/pde_euler_cubesphere.py:72-290 +
+// pde/fluxes.py:150-222,326-403,507-582 (phases 1-8 of rhs/rhs.py:75-122).
+//
+// Two kernels per evaluation (DESIGN.md has the traffic model):
+//   K1 euler_extrap_kernel  phase 1-2: Q -> face states of every element (log-space for rho,
+//                           rho*theta) into the plan's interface buffer + rotated/flipped
+//                           tile-edge faces into the send buffers.
+//   K2 euler_rhs_kernel     phases 3-8 fused, one pass over Q, the 35 static metric fields and
+//                           the interface buffer; writes R.  Nothing else touches HBM.
+// Both are element-blocked: a workgroup owns EPB whole elements, one thread per solution
+// point, so every global access is a contiguous n^3 (or n^2) run of doubles.  The dense
+// Kronecker operators of the reference become 1-D contractions staged through LDS.
+#include "wx_common.h"
+#include "wx_math.h"
+
+#include <cstring>
+#include <new>
+
+namespace wx {
+
+constexpr int kMaxN = 8;
+
+template <int N>
+struct Cfg {
+    static constexpr int N2 = N * N;
+    static constexpr int N3 = N * N * N;
+    // elements per workgroup: whole elements, <= 256 points unless one element is larger
+    static constexpr int EPB = (N3 >= 216) ? 1 : (256 / N3);
+    static constexpr int BS = ((EPB * N3 + 63) / 64) * 64;
+};
+
+enum { F_W = 0, F_E = 1, F_S = 2, F_N = 3, F_B = 4, F_T = 5 };
+enum { E_S = 0, E_N = 1, E_W = 2, E_E = 3 };
+
+// 1-D operator pieces and the tile's edge tables, in device memory (one copy per plan): dynamic
+// indexing into a by-value kernel argument would force the whole struct into scratch.
+struct EulerConsts {
+    double em[kMaxN], ep[kMaxN], cm[kMaxN], cp[kMaxN];
+    double D[kMaxN * kMaxN], HF[kMaxN * kMaxN];
+    double rot[4][8];
+    int flip[4];
+};
+
+template <typename T>
+struct EulerParams {
+    int H, V, nelem, count, region;
+    int advection_only, has_damp;
+    const T* q;
+    T* rhs;
+    T* itf;  // [elem][6 faces][5 vars][N2]
+    const T *halo_s, *halo_n, *halo_w, *halo_e;
+    T *send_s, *send_n, *send_w, *send_e;
+    const double *sg, *h, *chr, *idz;
+    const double *sgi, *sgj, *sgk, *hi, *hj, *hk;
+    const double *dcoef, *duref, *bsn, *bwe;
+    const EulerConsts* K;  // device memory
+};
+
+struct Elem {
+    int ek, ej, ei, e;
+    bool valid;
+};
+
+// slot (position in this launch's processing order) -> element of the tile
+__device__ __forceinline__ Elem decode_elem(int slot, int count, int region, int H, int V) {
+    Elem r;
+    r.valid = slot < count;
+    if (!r.valid) slot = 0;
+    if (region == WX_REGION_ALL) {
+        r.ei = slot % H;
+        r.ej = (slot / H) % H;
+        r.ek = slot / (H * H);
+    } else if (region == WX_REGION_INTERIOR) {
+        const int w = H - 2;
+        r.ei = 1 + slot % w;
+        r.ej = 1 + (slot / w) % w;
+        r.ek = slot / (w * w);
+    } else {
+        const int w = H > 2 ? H - 2 : 0;
+        const int ring = H * H - w * w;
+        r.ek = slot / ring;
+        int s = slot % ring;
+        if (s < H) {
+            r.ej = 0;
+            r.ei = s;
+        } else if (s < 2 * H) {
+            r.ej = H - 1;
+            r.ei = s - H;
+        } else {
+            s -= 2 * H;
+            r.ej = 1 + s % w;
+            r.ei = (s / w) ? H - 1 : 0;
+        }
+    }
+    r.e = (r.ek * H + r.ej) * H + r.ei;
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: extrapolation to element faces + tile-edge pack
+// ------------------------------------------------------------------------------------------------
+template <int N, typename T>
+__global__ __launch_bounds__(Cfg<N>::BS) void euler_extrap_kernel(const EulerParams<T> P) {
+    using C = Cfg<N>;
+    constexpr int N2 = C::N2, N3 = C::N3, EPB = C::EPB, BS = C::BS;
+    __shared__ T fld[5][EPB * N3];
+
+    const int tid = threadIdx.x;
+    const int H = P.H, V = P.V;
+    const size_t fs = (size_t)P.nelem * N3;
+
+    {
+        const int le = tid / N3, pt = tid % N3;
+        const Elem el = decode_elem(blockIdx.x * EPB + le, P.nelem, WX_REGION_ALL, H, V);
+        if (le < EPB && el.valid) {
+            const size_t o = (size_t)el.e * N3 + pt;
+            fld[0][le * N3 + pt] = w_log(P.q[o]);
+            fld[1][le * N3 + pt] = P.q[fs + o];
+            fld[2][le * N3 + pt] = P.q[2 * fs + o];
+            fld[3][le * N3 + pt] = P.q[3 * fs + o];
+            fld[4][le * N3 + pt] = w_log(P.q[4 * fs + o]);
+        }
+    }
+    __syncthreads();
+
+    for (int fi = tid; fi < EPB * 6 * N2; fi += BS) {
+        const int le = fi / (6 * N2);
+        const int r = fi % (6 * N2);
+        const int f = r / N2, fp = r % N2;
+        const Elem el = decode_elem(blockIdx.x * EPB + le, P.nelem, WX_REGION_ALL, H, V);
+        if (!el.valid) continue;
+        const int d = f >> 1, plus = f & 1;
+        const int a = fp / N, b = fp % N;
+        // point index of m-th node on the line normal to the face, and its stride
+        int base, stride;
+        if (d == 0) { base = (a * N + b) * N; stride = 1; }        // (kl=a, jl=b, il=m)
+        else if (d == 1) { base = a * N2 + b; stride = N; }        // (kl=a, jl=m, il=b)
+        else { base = a * N + b; stride = N2; }                    // (kl=m, jl=a, il=b)
+        const double* w = plus ? P.K->ep : P.K->em;
+        T s[5];
+#pragma unroll
+        for (int v = 0; v < 5; ++v) s[v] = T(0.0);
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+            const double wm = w[m];
+#pragma unroll
+            for (int v = 0; v < 5; ++v) s[v] += wm * fld[v][le * N3 + base + m * stride];
+        }
+        s[0] = w_exp(s[0]);
+        s[4] = w_exp(s[4]);
+        T* dst = P.itf + ((size_t)el.e * 6 + f) * 5 * N2 + fp;
+#pragma unroll
+        for (int v = 0; v < 5; ++v) dst[v * N2] = s[v];
+
+        // outward faces of the tile edge: rotate into the neighbour's basis, flip, pack
+        int edge = -1, along = 0;
+        double X = 0.0;
+        if (d == 0 && ((plus && el.ei == H - 1) || (!plus && el.ei == 0))) {
+            edge = plus ? E_E : E_W;
+            along = el.ej;
+            X = P.bwe[el.ej * N + b];
+        } else if (d == 1 && ((plus && el.ej == H - 1) || (!plus && el.ej == 0))) {
+            edge = plus ? E_N : E_S;
+            along = el.ei;
+            X = P.bsn[el.ei * N + b];
+        }
+        T* sendp = edge == E_S ? P.send_s : (edge == E_N ? P.send_n : (edge == E_W ? P.send_w : P.send_e));
+        if (edge >= 0 && sendp != nullptr) {
+            const double* mt = P.K->rot[edge];
+            const double c = 2.0 * X / (1.0 + X * X);
+            const T a1 = s[1], a2 = s[2];
+            s[1] = mt[0] * a1 + mt[1] * a2 + c * (mt[2] * a1 + mt[3] * a2);
+            s[2] = mt[4] * a1 + mt[5] * a2 + c * (mt[6] * a1 + mt[7] * a2);
+            int al = along, bb = b;
+            if (P.K->flip[edge]) { al = H - 1 - along; bb = N - 1 - b; }
+            T* out = sendp + ((size_t)el.ek * H + al) * N2 + a * N + bb;
+            const size_t vs = (size_t)V * H * N2;
+#pragma unroll
+            for (int v = 0; v < 5; ++v) out[v * vs] = s[v];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Rusanov common flux at one face point (fluxes.py:326-403 and its j / vertical twins).
+// Outputs the seven face quantities the element on the `own` side needs:
+//   out[0..3] F* for rho, rho u1, rho u2, rho theta;  out[4] A* (rho w advective);
+//   out[5] B*_own = 1/2 (P_L + P_R) / p_own;          out[6] log p_own
+// (the common flux of the rho w row itself is never used: rhs_dfr.py:139 overwrites that row).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void rusanov_face(const T* qL, const T* qR, T unL, T unR, double sg, double h0, double h1,
+                                             double h2, double hdd, bool own_is_L, bool advection_only, T* out) {
+    const T pL = kP0 * w_exp(kGamma * w_log(qL[4] * kRdOverP0));
+    const T pR = kP0 * w_exp(kGamma * w_log(qR[4] * kRdOverP0));
+    T eL, eR;
+    if (advection_only) {
+        eL = T(w_abs(unL));
+        eR = T(w_abs(unR));
+    } else {
+        eL = w_abs(unL) + w_sqrt(hdd * kGamma * pL / qL[0]);
+        eR = w_abs(unR) + w_sqrt(hdd * kGamma * pR / qR[0]);
+    }
+    const T eig = w_max(eL, eR);
+    const T sguL = sg * unL, sguR = sg * unR;
+    const T es = eig * sg;
+    const double sgh0 = sg * h0, sgh1 = sg * h1, sgh2 = sg * h2;
+
+    out[0] = 0.5 * (sguL * qL[0] + sguR * qR[0] - es * (qR[0] - qL[0]));
+    out[1] = 0.5 * ((sguL * qL[1] + sgh0 * pL) + (sguR * qR[1] + sgh0 * pR) - es * (qR[1] - qL[1]));
+    out[2] = 0.5 * ((sguL * qL[2] + sgh1 * pL) + (sguR * qR[2] + sgh1 * pR) - es * (qR[2] - qL[2]));
+    out[3] = 0.5 * (sguL * qL[4] + sguR * qR[4] - es * (qR[4] - qL[4]));
+    out[4] = 0.5 * (sguL * qL[3] + sguR * qR[3] - es * (qR[3] - qL[3]));
+    const T pown = own_is_L ? pL : pR;
+    out[5] = 0.5 * (sgh2 * pL + sgh2 * pR) / pown;
+    out[6] = w_log(pown);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: fused phases 3-8
+// ------------------------------------------------------------------------------------------------
+template <int N, typename T>
+__global__ __launch_bounds__(Cfg<N>::BS) void euler_rhs_kernel(const EulerParams<T> P) {
+    using C = Cfg<N>;
+    constexpr int N2 = C::N2, N3 = C::N3, EPB = C::EPB, BS = C::BS;
+    constexpr int NF = 8;   // staged fields: 4 F rows, A, B (per direction) + log p + sqrtG*rho
+    constexpr int NC = 7;   // face quantities, see rusanov_face
+    __shared__ T fld[NF][EPB * N3];
+    __shared__ T fr[EPB][6][NC][N2];
+    __shared__ double sD[N * N], sHF[N * N], sCm[N], sCp[N];
+
+    const int tid = threadIdx.x;
+    const int H = P.H, V = P.V;
+    const size_t fs = (size_t)P.nelem * N3;
+
+    for (int i = tid; i < N * N; i += BS) {
+        sD[i] = P.K->D[i];
+        sHF[i] = P.K->HF[i];
+    }
+    if (tid < N) {
+        sCm[tid] = P.K->cm[tid];
+        sCp[tid] = P.K->cp[tid];
+    }
+
+    // ---- face stage: Riemann problems of all 6 faces of the block's elements -> LDS
+    for (int fi = tid; fi < EPB * 6 * N2; fi += BS) {
+        const int le = fi / (6 * N2);
+        const int r = fi % (6 * N2);
+        const int f = r / N2, fp = r % N2;
+        const Elem el = decode_elem(blockIdx.x * EPB + le, P.count, P.region, H, V);
+        if (!el.valid) continue;
+        const int d = f >> 1, plus = f & 1;
+        const size_t vsh = (size_t)V * H * N2;  // var stride in a halo edge message
+
+        const T* own = P.itf + ((size_t)el.e * 6 + f) * 5 * N2 + fp;
+        const T* nbr;
+        size_t nstride = N2;
+        bool mirror = false;
+        const double *sgp, *hp;
+        size_t hfs;  // field stride of the h_contra_itf array
+        if (d == 0) {
+            const int ne = el.ei + (plus ? 1 : -1);
+            if (ne >= 0 && ne < H) nbr = P.itf + ((size_t)(el.e + (plus ? 1 : -1)) * 6 + (f ^ 1)) * 5 * N2 + fp;
+            else { nbr = (plus ? P.halo_e : P.halo_w) + ((size_t)el.ek * H + el.ej) * N2 + fp; nstride = vsh; }
+            const size_t o = (((size_t)el.ek * H + el.ej) * (H + 2) + el.ei + 1) * 2 * N2 + plus * N2 + fp;
+            hfs = (size_t)V * H * (H + 2) * 2 * N2;
+            sgp = P.sgi + o;
+            hp = P.hi + 0 * 3 * hfs + o;
+        } else if (d == 1) {
+            const int ne = el.ej + (plus ? 1 : -1);
+            if (ne >= 0 && ne < H) nbr = P.itf + ((size_t)(el.e + (plus ? H : -H)) * 6 + (f ^ 1)) * 5 * N2 + fp;
+            else { nbr = (plus ? P.halo_n : P.halo_s) + ((size_t)el.ek * H + el.ei) * N2 + fp; nstride = vsh; }
+            const size_t o = (((size_t)el.ek * (H + 2) + el.ej + 1) * H + el.ei) * 2 * N2 + plus * N2 + fp;
+            hfs = (size_t)V * (H + 2) * H * 2 * N2;
+            sgp = P.sgj + o;
+            hp = P.hj + 1 * 3 * hfs + o;
+        } else {
+            const int ne = el.ek + (plus ? 1 : -1);
+            if (ne >= 0 && ne < V) nbr = P.itf + ((size_t)(el.e + (plus ? H * H : -H * H)) * 6 + (f ^ 1)) * 5 * N2 + fp;
+            else { nbr = own; mirror = true; }
+            const size_t o = ((((size_t)el.ek + 1) * H + el.ej) * H + el.ei) * 2 * N2 + plus * N2 + fp;
+            hfs = (size_t)(V + 2) * H * H * 2 * N2;
+            sgp = P.sgk + o;
+            hp = P.hk + 2 * 3 * hfs + o;
+        }
+        T qo[5], qn[5];
+#pragma unroll
+        for (int v = 0; v < 5; ++v) {
+            qo[v] = own[v * N2];
+            qn[v] = nbr[v * nstride];
+        }
+        const double sg = *sgp, h0 = hp[0], h1 = hp[hfs], h2 = hp[2 * hfs];
+        const double hdd = d == 0 ? h0 : (d == 1 ? h1 : h2);
+        T uo = qo[1 + d] / qo[0];
+        T un = qn[1 + d] / qn[0];
+        if (mirror) un = -uo;  // no-flow wall: odd symmetry of w (pde_euler_cubesphere.py:150-156)
+        T out[NC];
+        if (plus) rusanov_face<T>(qo, qn, uo, un, sg, h0, h1, h2, hdd, true, P.advection_only, out);
+        else rusanov_face<T>(qn, qo, un, uo, sg, h0, h1, h2, hdd, false, P.advection_only, out);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) fr[le][f][c][fp] = out[c];
+    }
+
+    // ---- point stage
+    const int le = tid / N3, pt = tid % N3;
+    const Elem el = decode_elem(blockIdx.x * EPB + le, P.count, P.region, H, V);
+    const bool active = (le < EPB) && el.valid;
+    const int kl = pt / N2, jl = (pt / N) % N, il = pt % N;
+    const int lb = (le < EPB ? le : 0) * N3;  // LDS base of this thread's element
+    const size_t o = (size_t)el.e * N3 + pt;
+
+    T q0 = T(1.0), q1 = T(0.0), q2 = T(0.0), q3 = T(0.0), q4 = T(1.0);
+    double sg = 1.0, h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0;
+    if (active) {
+        q0 = P.q[o]; q1 = P.q[fs + o]; q2 = P.q[2 * fs + o]; q3 = P.q[3 * fs + o]; q4 = P.q[4 * fs + o];
+        sg = P.sg[o];
+        h00 = P.h[0 * fs + o]; h01 = P.h[1 * fs + o]; h02 = P.h[2 * fs + o];
+        h11 = P.h[4 * fs + o]; h12 = P.h[5 * fs + o]; h22 = P.h[8 * fs + o];
+    }
+    const T u1 = q1 / q0, u2 = q2 / q0, u3 = q3 / q0;
+    const T p = kP0 * w_exp(kGamma * w_log(kRdOverP0 * q4));
+    const T logp = w_log(p);
+
+    if (le < EPB) {
+        fld[6][lb + pt] = logp;
+        fld[7][lb + pt] = sg * q0;
+    }
+
+    T acc0 = T(0.0), acc1 = T(0.0), acc2 = T(0.0), acc4 = T(0.0), accw = T(0.0);
+    T hf = T(0.0);
+
+#pragma unroll 1
+    for (int d = 0; d < 3; ++d) {
+        const T ud = d == 0 ? u1 : (d == 1 ? u2 : u3);
+        const double hd0 = d == 0 ? h00 : (d == 1 ? h01 : h02);
+        const double hd1 = d == 0 ? h01 : (d == 1 ? h11 : h12);
+        const double hd2 = d == 0 ? h02 : (d == 1 ? h12 : h22);
+        const T sgu = sg * ud;
+        const T Bd = T(sg * hd2);
+        if (d > 0) __syncthreads();  // previous direction's reads are done
+        if (le < EPB) {
+            fld[0][lb + pt] = sgu * q0;
+            fld[1][lb + pt] = sgu * q1 + (sg * hd0) * p;
+            fld[2][lb + pt] = sgu * q2 + (sg * hd1) * p;
+            fld[3][lb + pt] = sgu * q4;
+            fld[4][lb + pt] = sgu * q3;
+            fld[5][lb + pt] = Bd;
+        }
+        __syncthreads();
+
+        int base, stride, idx, fp;
+        if (d == 0) { base = lb + (kl * N + jl) * N; stride = 1; idx = il; fp = kl * N + jl; }
+        else if (d == 1) { base = lb + kl * N2 + il; stride = N; idx = jl; fp = kl * N + il; }
+        else { base = lb + jl * N + il; stride = N2; idx = kl; fp = jl * N + il; }
+
+        T dv[7];
+#pragma unroll
+        for (int c = 0; c < 7; ++c) dv[c] = T(0.0);
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+            const double dm = sD[idx * N + m];
+            const int a = base + m * stride;
+#pragma unroll
+            for (int c = 0; c < 7; ++c) dv[c] += dm * fld[c][a];
+            if (d == 2) hf += sHF[idx * N + m] * fld[7][a];
+        }
+        const double cm = sCm[idx], cp = sCp[idx];
+        const int lf = le < EPB ? le : 0;
+#pragma unroll
+        for (int c = 0; c < 7; ++c) dv[c] += cm * fr[lf][2 * d][c][fp] + cp * fr[lf][2 * d + 1][c][fp];
+
+        acc0 += dv[0];
+        acc1 += dv[1];
+        acc2 += dv[2];
+        acc4 += dv[3];
+        // W^d = [A@D + A*@C] + p [B@D + B*@C] + p B [log p@D + log p^@C]   (rhs_dfr.py:113-136)
+        accw += dv[4] + dv[5] * p + dv[6] * (p * Bd);
+    }
+
+    if (!active) return;
+
+    const double inv_sg = 1.0 / sg;
+    T r0 = -inv_sg * acc0, r1 = -inv_sg * acc1, r2 = -inv_sg * acc2, r3 = -inv_sg * accw, r4 = -inv_sg * acc4;
+
+    // ---- forcing (pde_euler_cubesphere.py:12-25, 203-290)
+    T fc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double* c = P.chr + (size_t)(i * 9) * fs + o;
+        const double c01 = c[0], c02 = c[fs], c03 = c[2 * fs], c11 = c[3 * fs], c12 = c[4 * fs], c13 = c[5 * fs],
+                     c22 = c[6 * fs], c23 = c[7 * fs], c33 = c[8 * fs];
+        fc[i] = 2.0 * q0 * (c01 * u1 + c02 * u2 + c03 * u3) + c11 * (q0 * u1 * u1 + h00 * p) +
+                2.0 * c12 * (q0 * u1 * u2 + h01 * p) + 2.0 * c13 * (q0 * u1 * u3 + h02 * p) +
+                c22 * (q0 * u2 * u2 + h11 * p) + 2.0 * c23 * (q0 * u2 * u3 + h12 * p) + c33 * (q0 * u3 * u3 + h22 * p);
+    }
+    fc[2] += (P.idz[o] * kGravity * inv_sg) * hf;
+    if (P.has_damp) {
+        const T dw = P.dcoef[o] * q0;
+        fc[0] += dw * (u1 - P.duref[o]);
+        fc[1] += dw * (u2 - P.duref[fs + o]);
+        fc[2] += dw * (u3 - P.duref[2 * fs + o]);
+    }
+    r1 -= fc[0];
+    r2 -= fc[1];
+    r3 -= fc[2];
+    if (P.advection_only) { r0 = r1 = r2 = r3 = r4 = T(0.0); }
+
+    P.rhs[o] = r0;
+    P.rhs[fs + o] = r1;
+    P.rhs[2 * fs + o] = r2;
+    P.rhs[3 * fs + o] = r3;
+    P.rhs[4 * fs + o] = r4;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+template <int N, typename T>
+static wx_status launch_extrap(const EulerParams<T>& P, hipStream_t st) {
+    using C = Cfg<N>;
+    const int grid = (P.nelem + C::EPB - 1) / C::EPB;
+    hipLaunchKernelGGL((euler_extrap_kernel<N, T>), dim3(grid), dim3(C::BS), 0, st, P);
+    WX_HIP_TRY(hipGetLastError());
+    return WX_OK;
+}
+
+template <int N, typename T>
+static wx_status launch_rhs(const EulerParams<T>& P, hipStream_t st) {
+    using C = Cfg<N>;
+    if (P.count == 0) return WX_OK;
+    const int grid = (P.count + C::EPB - 1) / C::EPB;
+    hipLaunchKernelGGL((euler_rhs_kernel<N, T>), dim3(grid), dim3(C::BS), 0, st, P);
+    WX_HIP_TRY(hipGetLastError());
+    return WX_OK;
+}
+
+}  // namespace wx
+
+// ------------------------------------------------------------------------------------------------
+// plan + C ABI
+// ------------------------------------------------------------------------------------------------
+using namespace wx;
+
+struct wx_euler3d_plan {
+    int n, H, V, case_number, panel;
+    wx_dtype dtype;
+    size_t nelem;
+    void* itf;         // device: [elem][6][5][n^2] of dtype
+    size_t itf_bytes;
+    EulerConsts* consts;  // device
+    EulerParams<double> base;  // pointer-free parts + metric pointers (q/rhs/halo/send filled per call)
+};
+
+namespace {
+
+// flip / rotation tables, reference process_topology.py:126-175 (one tile per panel).
+// rot[p][edge] = (m0..m7):  b1 = m0 a1 + m1 a2 + c (m2 a1 + m3 a2),  b2 = m4 a1 + m5 a2 + c (m6 a1 + m7 a2)
+const int kFlip[6][4] = {{0, 0, 0, 0}, {1, 0, 0, 0}, {1, 1, 0, 0}, {0, 1, 0, 0}, {0, 1, 1, 0}, {1, 0, 0, 1}};
+#define WX_W0 {1, 0, 0, 0, 0, 1, 1, 0}
+#define WX_E0 {1, 0, 0, 0, 0, 1, -1, 0}
+const double kRot[6][4][8] = {
+    {{1, 0, 0, 1, 0, 1, 0, 0}, {1, 0, 0, -1, 0, 1, 0, 0}, WX_W0, WX_E0},
+    {{0, 1, 0, 0, -1, 0, 0, -1}, {0, -1, 0, 0, 1, 0, 0, -1}, WX_W0, WX_E0},
+    {{-1, 0, 0, -1, 0, -1, 0, 0}, {-1, 0, 0, 1, 0, -1, 0, 0}, WX_W0, WX_E0},
+    {{0, -1, 0, 0, 1, 0, 0, 1}, {0, 1, 0, 0, -1, 0, 0, 1}, WX_W0, WX_E0},
+    {{1, 0, 0, 1, 0, 1, 0, 0}, {-1, 0, 0, 1, 0, -1, 0, 0}, {0, -1, -1, 0, 1, 0, 0, 0}, {0, 1, -1, 0, -1, 0, 0, 0}},
+    {{-1, 0, 0, -1, 0, -1, 0, 0}, {1, 0, 0, -1, 0, 1, 0, 0}, {0, 1, 1, 0, -1, 0, 0, 0}, {0, -1, 1, 0, 1, 0, 0, 0}},
+};
+
+template <typename T>
+EulerParams<T> make_params(const wx_euler3d_plan* pl) {
+    // EulerParams<double> and <cplx> differ only in pointer value types: copy field by field
+    EulerParams<T> P;
+    const EulerParams<double>& b = pl->base;
+    P.H = b.H; P.V = b.V; P.nelem = b.nelem; P.count = b.count; P.region = b.region;
+    P.advection_only = b.advection_only; P.has_damp = b.has_damp;
+    P.q = nullptr; P.rhs = nullptr; P.itf = static_cast<T*>(pl->itf);
+    P.halo_s = P.halo_n = P.halo_w = P.halo_e = nullptr;
+    P.send_s = P.send_n = P.send_w = P.send_e = nullptr;
+    P.K = pl->consts;
+    P.sg = b.sg; P.h = b.h; P.chr = b.chr; P.idz = b.idz;
+    P.sgi = b.sgi; P.sgj = b.sgj; P.sgk = b.sgk; P.hi = b.hi; P.hj = b.hj; P.hk = b.hk;
+    P.dcoef = b.dcoef; P.duref = b.duref; P.bsn = b.bsn; P.bwe = b.bwe;
+    return P;
+}
+
+template <typename T>
+wx_status dispatch_extrap(int n, const EulerParams<T>& P, hipStream_t st) {
+    switch (n) {
+        case 2: return launch_extrap<2, T>(P, st);
+        case 3: return launch_extrap<3, T>(P, st);
+        case 4: return launch_extrap<4, T>(P, st);
+        case 5: return launch_extrap<5, T>(P, st);
+        case 6: return launch_extrap<6, T>(P, st);
+        case 7: return launch_extrap<7, T>(P, st);
+        case 8: return launch_extrap<8, T>(P, st);
+    }
+    return fail(WX_ERR_UNSUPPORTED, "num_solpts %d not in 2..8", n);
+}
+
+template <typename T>
+wx_status dispatch_rhs(int n, const EulerParams<T>& P, hipStream_t st) {
+    switch (n) {
+        case 2: return launch_rhs<2, T>(P, st);
+        case 3: return launch_rhs<3, T>(P, st);
+        case 4: return launch_rhs<4, T>(P, st);
+        case 5: return launch_rhs<5, T>(P, st);
+        case 6: return launch_rhs<6, T>(P, st);
+        case 7: return launch_rhs<7, T>(P, st);
+        case 8: return launch_rhs<8, T>(P, st);
+    }
+    return fail(WX_ERR_UNSUPPORTED, "num_solpts %d not in 2..8", n);
+}
+
+int region_count(int region, int H, int V) {
+    const int w = H > 2 ? H - 2 : 0;
+    if (region == WX_REGION_ALL) return V * H * H;
+    if (region == WX_REGION_INTERIOR) return V * w * w;
+    return V * (H * H - w * w);
+}
+
+}  // namespace
+
+extern "C" {
+
+wx_status wx_euler3d_plan_create(wx_euler3d_plan** out, int n, int H, int V, int case_number, wx_dtype dtype,
+                                 int panel, const wx_dfr_ops* ops, const wx_euler3d_metric* m) {
+    if (!out || !ops || !m) return fail(WX_ERR_INVALID, "wx_euler3d_plan_create: null argument");
+    *out = nullptr;
+    if (n < 2 || n > kMaxN) return fail(WX_ERR_UNSUPPORTED, "num_solpts %d not in 2..%d", n, kMaxN);
+    if (H < 1 || V < 1) return fail(WX_ERR_INVALID, "bad tile size H=%d V=%d", H, V);
+    if (panel < 0 || panel > 5) return fail(WX_ERR_INVALID, "panel %d not in 0..5", panel);
+    if (dtype != WX_F64 && dtype != WX_C128) return fail(WX_ERR_INVALID, "unknown dtype %d", (int)dtype);
+    if (!ops->extrap_neg || !ops->extrap_pos || !ops->diff_solpt || !ops->correction || !ops->highfilter)
+        return fail(WX_ERR_INVALID, "wx_dfr_ops has a null member");
+    if (!m->sqrtG || !m->h_contra || !m->christoffel || !m->inv_dzdeta || !m->sqrtG_itf_i || !m->sqrtG_itf_j ||
+        !m->sqrtG_itf_k || !m->h_contra_itf_i || !m->h_contra_itf_j || !m->h_contra_itf_k || !m->boundary_sn ||
+        !m->boundary_we)
+        return fail(WX_ERR_INVALID, "wx_euler3d_metric has a null member");
+    const bool damp = (case_number == 21 || case_number == 22);
+    if (damp && (!m->damp_coef || !m->damp_uref))
+        return fail(WX_ERR_INVALID, "case %d needs damp_coef and damp_uref", case_number);
+
+    wx_euler3d_plan* pl = new (std::nothrow) wx_euler3d_plan();
+    if (!pl) return fail(WX_ERR_NOMEM, "out of host memory");
+    pl->n = n; pl->H = H; pl->V = V; pl->case_number = case_number; pl->panel = panel; pl->dtype = dtype;
+    pl->nelem = (size_t)V * H * H;
+    const size_t esz = dtype == WX_C128 ? 16 : 8;
+    pl->itf_bytes = pl->nelem * 6 * 5 * n * n * esz;
+    hipError_t e = hipMalloc(&pl->itf, pl->itf_bytes);
+    if (e != hipSuccess) {
+        delete pl;
+        return fail(WX_ERR_NOMEM, "hipMalloc(%zu bytes) for the interface buffer failed: %s", pl->itf_bytes,
+                    hipGetErrorString(e));
+    }
+    EulerParams<double>& b = pl->base;
+    b.H = H; b.V = V; b.nelem = (int)pl->nelem; b.count = 0; b.region = 0;
+    b.advection_only = case_number < 13; b.has_damp = damp;
+    b.sg = m->sqrtG; b.h = m->h_contra; b.chr = m->christoffel; b.idz = m->inv_dzdeta;
+    b.sgi = m->sqrtG_itf_i; b.sgj = m->sqrtG_itf_j; b.sgk = m->sqrtG_itf_k;
+    b.hi = m->h_contra_itf_i; b.hj = m->h_contra_itf_j; b.hk = m->h_contra_itf_k;
+    b.dcoef = damp ? m->damp_coef : nullptr; b.duref = damp ? m->damp_uref : nullptr;
+    b.bsn = m->boundary_sn; b.bwe = m->boundary_we;
+    EulerConsts hc;
+    memset(&hc, 0, sizeof(hc));
+    for (int i = 0; i < n; ++i) {
+        hc.em[i] = ops->extrap_neg[i]; hc.ep[i] = ops->extrap_pos[i];
+        hc.cm[i] = ops->correction[2 * i]; hc.cp[i] = ops->correction[2 * i + 1];
+        for (int j = 0; j < n; ++j) { hc.D[i * n + j] = ops->diff_solpt[i * n + j]; hc.HF[i * n + j] = ops->highfilter[i * n + j]; }
+    }
+    for (int ed = 0; ed < 4; ++ed) {
+        hc.flip[ed] = kFlip[panel][ed];
+        for (int i = 0; i < 8; ++i) hc.rot[ed][i] = kRot[panel][ed][i];
+    }
+    e = hipMalloc((void**)&pl->consts, sizeof(EulerConsts));
+    if (e == hipSuccess) e = hipMemcpy(pl->consts, &hc, sizeof(hc), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        hipFree(pl->itf);
+        if (pl->consts) hipFree(pl->consts);
+        delete pl;
+        return fail(WX_ERR_HIP, "constant upload failed: %s", hipGetErrorString(e));
+    }
+    *out = pl;
+    return WX_OK;
+}
+
+wx_status wx_euler3d_plan_destroy(wx_euler3d_plan* pl) {
+    if (!pl) return WX_OK;
+    hipError_t e = hipFree(pl->itf);
+    hipError_t e2 = hipFree(pl->consts);
+    if (e == hipSuccess) e = e2;
+    delete pl;
+    if (e != hipSuccess) return fail(WX_ERR_HIP, "hipFree failed: %s", hipGetErrorString(e));
+    return WX_OK;
+}
+
+size_t wx_euler3d_edge_count(const wx_euler3d_plan* pl) {
+    return pl ? (size_t)5 * pl->V * pl->H * pl->n * pl->n : 0;
+}
+
+wx_status wx_euler3d_extrap_pack(wx_euler3d_plan* pl, const void* q, void* const send[4], wx_stream stream) {
+    if (!pl || !q) return fail(WX_ERR_INVALID, "wx_euler3d_extrap_pack: null argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (pl->dtype == WX_F64) {
+        EulerParams<double> P = make_params<double>(pl);
+        P.q = static_cast<const double*>(q);
+        if (send) {
+            P.send_s = static_cast<double*>(send[0]); P.send_n = static_cast<double*>(send[1]);
+            P.send_w = static_cast<double*>(send[2]); P.send_e = static_cast<double*>(send[3]);
+        }
+        return dispatch_extrap<double>(pl->n, P, st);
+    }
+    EulerParams<cplx> P = make_params<cplx>(pl);
+    P.q = static_cast<const cplx*>(q);
+    if (send) {
+        P.send_s = static_cast<cplx*>(send[0]); P.send_n = static_cast<cplx*>(send[1]);
+        P.send_w = static_cast<cplx*>(send[2]); P.send_e = static_cast<cplx*>(send[3]);
+    }
+    return dispatch_extrap<cplx>(pl->n, P, st);
+}
+
+wx_status wx_euler3d_rhs(wx_euler3d_plan* pl, const void* q, const void* const halo[4], void* rhs, wx_region region,
+                         wx_stream stream) {
+    if (!pl || !q || !rhs) return fail(WX_ERR_INVALID, "wx_euler3d_rhs: null argument");
+    if (region != WX_REGION_ALL && region != WX_REGION_INTERIOR && region != WX_REGION_BOUNDARY)
+        return fail(WX_ERR_INVALID, "unknown region %d", (int)region);
+    if (region != WX_REGION_INTERIOR) {
+        if (!halo) return fail(WX_ERR_INVALID, "wx_euler3d_rhs: halo is required for this region");
+        for (int e = 0; e < 4; ++e)
+            if (!halo[e]) return fail(WX_ERR_INVALID, "wx_euler3d_rhs: halo[%d] is null", e);
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int count = region_count(region, pl->H, pl->V);
+    if (pl->dtype == WX_F64) {
+        EulerParams<double> P = make_params<double>(pl);
+        P.q = static_cast<const double*>(q); P.rhs = static_cast<double*>(rhs);
+        P.region = region; P.count = count;
+        if (halo) {
+            P.halo_s = static_cast<const double*>(halo[0]); P.halo_n = static_cast<const double*>(halo[1]);
+            P.halo_w = static_cast<const double*>(halo[2]); P.halo_e = static_cast<const double*>(halo[3]);
+        }
+        return dispatch_rhs<double>(pl->n, P, st);
+    }
+    EulerParams<cplx> P = make_params<cplx>(pl);
+    P.q = static_cast<const cplx*>(q); P.rhs = static_cast<cplx*>(rhs);
+    P.region = region; P.count = count;
+    if (halo) {
+        P.halo_s = static_cast<const cplx*>(halo[0]); P.halo_n = static_cast<const cplx*>(halo[1]);
+        P.halo_w = static_cast<const cplx*>(halo[2]); P.halo_e = static_cast<const cplx*>(halo[3]);
+    }
+    return dispatch_rhs<cplx>(pl->n, P, st);
+}
+
+}  // extern "C"

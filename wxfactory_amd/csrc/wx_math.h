@@ -1,0 +1,89 @@
+// Scalar helpers shared by the kernels: float64 and a complex128 type whose abs / max /
+// sqrt follow NumPy's rules, because the reference's default Jacobian-vector product is the
+// complex step Im R(Q + i eps v)/eps (solvers/matvec.py:56-61) and inherits NumPy semantics:
+//   abs(z)      -> modulus, a REAL number (no tangent flows through |u|)
+//   maximum(a,b)-> lexicographic compare (real part first), carries the winner's imag part
+// (the reference's C++ kernels hard-code the same choices, pde/definitions.hpp:45-69).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace wx {
+
+// reference common/definitions.py:5-12
+constexpr double kGravity = 9.80616;
+constexpr double kP0 = 100000.0;
+constexpr double kRd = 287.05;
+constexpr double kCpd = 1005.46;
+constexpr double kCvd = kCpd - kRd;
+constexpr double kGamma = kCpd / kCvd;  // heat_capacity_ratio
+constexpr double kRdOverP0 = kRd / kP0;
+
+struct cplx {
+    double re, im;
+    __host__ __device__ cplx() = default;
+    __host__ __device__ constexpr cplx(double r) : re(r), im(0.0) {}
+    __host__ __device__ constexpr cplx(double r, double i) : re(r), im(i) {}
+};
+
+__device__ __forceinline__ cplx operator+(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ cplx operator-(cplx a, cplx b) { return {a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ cplx operator-(cplx a) { return {-a.re, -a.im}; }
+__device__ __forceinline__ cplx operator*(cplx a, cplx b) {
+    return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+}
+__device__ __forceinline__ cplx operator*(double a, cplx b) { return {a * b.re, a * b.im}; }
+__device__ __forceinline__ cplx operator*(cplx a, double b) { return {a.re * b, a.im * b}; }
+__device__ __forceinline__ cplx operator+(cplx a, double b) { return {a.re + b, a.im}; }
+__device__ __forceinline__ cplx operator+(double a, cplx b) { return {a + b.re, b.im}; }
+__device__ __forceinline__ cplx operator-(cplx a, double b) { return {a.re - b, a.im}; }
+__device__ __forceinline__ cplx operator/(cplx a, cplx b) {
+    // Smith's algorithm (what NumPy uses for complex division)
+    if (fabs(b.re) >= fabs(b.im)) {
+        const double r = b.im / b.re, d = 1.0 / (b.re + b.im * r);
+        return {(a.re + a.im * r) * d, (a.im - a.re * r) * d};
+    }
+    const double r = b.re / b.im, d = 1.0 / (b.re * r + b.im);
+    return {(a.re * r + a.im) * d, (a.im * r - a.re) * d};
+}
+__device__ __forceinline__ cplx operator/(cplx a, double b) { return {a.re / b, a.im / b}; }
+__device__ __forceinline__ cplx operator/(double a, cplx b) { return cplx(a, 0.0) / b; }
+__device__ __forceinline__ cplx& operator+=(cplx& a, cplx b) { a.re += b.re; a.im += b.im; return a; }
+__device__ __forceinline__ cplx& operator-=(cplx& a, cplx b) { a.re -= b.re; a.im -= b.im; return a; }
+
+__device__ __forceinline__ double w_log(double x) { return log(x); }
+__device__ __forceinline__ double w_exp(double x) { return exp(x); }
+__device__ __forceinline__ double w_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ double w_abs(double x) { return fabs(x); }
+__device__ __forceinline__ double w_max(double a, double b) { return (a > b || a != a) ? a : b; }
+__device__ __forceinline__ double w_real(double x) { return x; }
+
+__device__ __forceinline__ cplx w_log(cplx z) { return {log(hypot(z.re, z.im)), atan2(z.im, z.re)}; }
+__device__ __forceinline__ cplx w_exp(cplx z) {
+    const double e = exp(z.re);
+    double s, c;
+    sincos(z.im, &s, &c);
+    return {e * c, e * s};
+}
+__device__ __forceinline__ cplx w_sqrt(cplx z) {
+    // principal branch, as csqrt
+    const double m = hypot(z.re, z.im);
+    if (m == 0.0) return {0.0, z.im};
+    if (z.re >= 0.0) {
+        const double t = sqrt(0.5 * (m + z.re));
+        return {t, z.im / (2.0 * t)};
+    }
+    const double t = sqrt(0.5 * (m - z.re));
+    return {fabs(z.im) / (2.0 * t), copysign(t, z.im)};
+}
+__device__ __forceinline__ double w_abs(cplx z) { return hypot(z.re, z.im); }
+__device__ __forceinline__ cplx w_max(cplx a, cplx b) {
+    // numpy.maximum on complex: a if a >= b lexicographically (or a is nan) else b
+    const bool ge = (a.re > b.re) || (a.re == b.re && a.im >= b.im) || (a.re != a.re) || (a.im != a.im);
+    return ge ? a : b;
+}
+__device__ __forceinline__ double w_real(cplx z) { return z.re; }
+
+template <typename T> struct is_complex { static constexpr bool value = false; };
+template <> struct is_complex<cplx> { static constexpr bool value = true; };
+
+}  // namespace wx

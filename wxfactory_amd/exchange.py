@@ -1,0 +1,115 @@
+"""Panel-edge halo exchange for the panels a rank owns.
+
+Replaces reference wx_factory/process_topology.py:269-386 + 564-606 (start_exchange_scalars /
+start_exchange_vectors / ExchangeRequest.wait): there, three Ineighbor_alltoall messages per
+RHS carry (rho), (rho u1, rho u2, rho w), (rho theta); here ONE message per panel edge carries
+all five variables, already rotated and flipped by the pack kernel (wx_euler3d_extrap_pack).
+
+* neighbours on the same rank: zero copy - the receiver's halo pointer aliases the sender's
+  send slot;
+* neighbours on other ranks: one torch.distributed.all_to_all_single (RCCL grouped
+  send/recv over xGMI on GPUs, gloo on CPU) issued asynchronously so the interior elements
+  are computed while it is in flight.
+"""
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from .panels import NEIGHBOR, landing_edge, owner_of_panels
+
+
+class PanelExchange:
+    def __init__(self, edge_doubles: int, device, rank: int = 0, world_size: int = 1, group=None):
+        """edge_doubles: float64 words per edge message (5*V*H*n^2, doubled for complex128);
+        buffers are float64 (complex payloads travel as interleaved re/im, which RCCL accepts)."""
+        dtype = torch.float64
+        self.edge_count = int(edge_doubles)
+        self.rank, self.world = rank, world_size
+        self.group = group
+        owner = owner_of_panels(world_size)
+        self.owner = owner
+        self.local = [p for p in range(6) if owner[p] == rank]
+
+        # messages this rank sends: (src panel, src edge) -> (dst rank, dst panel, dst edge)
+        local_msgs, remote_out, remote_in = [], {}, {}
+        for p in self.local:
+            for e in range(4):
+                q, e2 = NEIGHBOR[p][e], landing_edge(p, e)
+                if owner[q] == rank:
+                    local_msgs.append((p, e, q, e2))
+                else:
+                    remote_out.setdefault(owner[q], []).append((q, e2, p, e))
+        for q in self.local:
+            for e2 in range(4):
+                p = NEIGHBOR[q][e2]
+                if owner[p] != rank:
+                    remote_in.setdefault(owner[p], []).append((q, e2))
+        # canonical order inside each rank pair: by (destination panel, destination edge)
+        n_remote_out = sum(len(v) for v in remote_out.values())
+        n_remote_in = sum(len(v) for v in remote_in.values())
+        ec = self.edge_count
+        self.send_buf = torch.zeros((n_remote_out + len(local_msgs)) * ec, dtype=dtype, device=device)
+        self.recv_buf = torch.zeros(max(n_remote_in, 1) * ec, dtype=dtype, device=device)
+        self._send_slot: Dict[Tuple[int, int], int] = {}
+        self._halo_src: Dict[Tuple[int, int], Tuple[str, int]] = {}
+        self.send_splits, self.recv_splits = [0] * world_size, [0] * world_size
+        slot = 0
+        for r in range(world_size):
+            msgs = sorted(remote_out.get(r, []))
+            self.send_splits[r] = len(msgs) * ec
+            for (q, e2, p, e) in msgs:
+                self._send_slot[(p, e)] = slot
+                slot += 1
+        self.n_remote_out = slot
+        for (p, e, q, e2) in local_msgs:
+            self._send_slot[(p, e)] = slot
+            self._halo_src[(q, e2)] = ("send", slot)
+            slot += 1
+        rslot = 0
+        for r in range(world_size):
+            msgs = sorted(remote_in.get(r, []))
+            self.recv_splits[r] = len(msgs) * ec
+            for (q, e2) in msgs:
+                self._halo_src[(q, e2)] = ("recv", rslot)
+                rslot += 1
+        self.n_remote_in = rslot
+        self._work = None
+
+    # -- views (tests / host logic) and raw pointers (kernels)
+    def send_view(self, panel: int, edge: int) -> torch.Tensor:
+        s = self._send_slot[(panel, edge)]
+        return self.send_buf[s * self.edge_count:(s + 1) * self.edge_count]
+
+    def halo_view(self, panel: int, edge: int) -> torch.Tensor:
+        kind, s = self._halo_src[(panel, edge)]
+        buf = self.send_buf if kind == "send" else self.recv_buf
+        return buf[s * self.edge_count:(s + 1) * self.edge_count]
+
+    def send_ptrs(self, panel: int) -> List[int]:
+        return [self.send_view(panel, e).data_ptr() for e in range(4)]
+
+    def halo_ptrs(self, panel: int) -> List[int]:
+        return [self.halo_view(panel, e).data_ptr() for e in range(4)]
+
+    @property
+    def needs_comm(self) -> bool:
+        return self.world > 1
+
+    def start(self):
+        """Post the exchange of everything the pack kernels wrote (stream-ordered after them)."""
+        if not self.needs_comm:
+            return
+        ec = self.edge_count
+        send = self.send_buf[: self.n_remote_out * ec]
+        recv = self.recv_buf[: self.n_remote_in * ec]
+        self._work = dist.all_to_all_single(
+            recv, send, output_split_sizes=self.recv_splits, input_split_sizes=self.send_splits,
+            group=self.group, async_op=True,
+        )
+
+    def wait(self):
+        """Make the current stream (GPU) / the caller (CPU) wait for the halos."""
+        if self._work is not None:
+            self._work.wait()
+            self._work = None

@@ -1,0 +1,144 @@
+"""3-D Euler RHS on cubed-sphere panels: host-side mirror of the reference's RHS object.
+
+Same contract as reference wx_factory/rhs/rhs.py:75-122 (`RHS.__call__`) with
+`RHSDirecFluxReconstruction_mpi` (rhs/rhs_dfr.py:48-313): `rhs(Q) -> R`, same shape and dtype
+as Q (float64 or complex128), collective over the ranks, result is fresh storage.  The eight
+phases of the reference collapse into two HIP kernels per panel (see csrc/euler3d.hip); the
+phase timers of rhs.py:88-118 are kept as four buckets (extrap+pack, exchange, interior, boundary).
+"""
+import ctypes
+from typing import Dict, List, Optional, Sequence
+
+import numpy
+import torch
+
+from . import _lib
+from ._lib import DfrOps, Euler3DMetric, check
+from .exchange import PanelExchange
+
+_DTYPES = {torch.float64: _lib.WX_F64, torch.complex128: _lib.WX_C128}
+
+
+def _dptr(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+class Euler3DPlan:
+    """One tile (= one cube panel).  Owns the native plan; borrows the metric tensors
+    (kept alive here) exactly as the reference's pde module borrows NumPy/CuPy buffers."""
+
+    def __init__(self, n: int, H: int, V: int, case_number: int, panel: int, ops: Dict[str, numpy.ndarray],
+                 metric: Dict[str, torch.Tensor], dtype: torch.dtype = torch.float64):
+        self.lib = _lib.load()
+        if dtype not in _DTYPES:
+            raise TypeError(f"dtype must be float64 or complex128, not {dtype}")
+        self.n, self.H, self.V, self.case_number, self.panel, self.dtype = n, H, V, case_number, panel, dtype
+        self.shape = (5, V, H, H, n**3)
+        self._keep = []
+        o = DfrOps()
+        for k in ("extrap_neg", "extrap_pos", "diff_solpt", "correction", "highfilter"):
+            a = numpy.ascontiguousarray(ops[k], dtype=numpy.float64)
+            self._keep.append(a)
+            setattr(o, k, _dptr(a))
+        m = Euler3DMetric()
+        n2, n3 = n * n, n**3
+        expect = {
+            "sqrtG": (V, H, H, n3), "h_contra": (3, 3, V, H, H, n3), "christoffel": (3, 9, V, H, H, n3),
+            "inv_dzdeta": (V, H, H, n3),
+            "sqrtG_itf_i": (V, H, H + 2, 2 * n2), "sqrtG_itf_j": (V, H + 2, H, 2 * n2), "sqrtG_itf_k": (V + 2, H, H, 2 * n2),
+            "h_contra_itf_i": (3, 3, V, H, H + 2, 2 * n2), "h_contra_itf_j": (3, 3, V, H + 2, H, 2 * n2),
+            "h_contra_itf_k": (3, 3, V + 2, H, H, 2 * n2),
+            "damp_coef": (V, H, H, n3), "damp_uref": (3, V, H, H, n3),
+            "boundary_sn": (H * n,), "boundary_we": (H * n,),
+        }
+        self.device = metric["sqrtG"].device
+        for k in _lib.EULER3D_METRIC_FIELDS:
+            t = metric.get(k)
+            if t is None:
+                setattr(m, k, None)
+                continue
+            if tuple(t.shape) != expect[k] or t.dtype != torch.float64 or not t.is_contiguous() or t.device != self.device:
+                raise ValueError(f"metric[{k!r}]: need contiguous float64 {expect[k]} on {self.device}, "
+                                 f"got {t.dtype} {tuple(t.shape)} on {t.device}")
+            self._keep.append(t)
+            setattr(m, k, t.data_ptr())
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            check(self.lib.wx_euler3d_plan_create(ctypes.byref(self._h), n, H, V, case_number, _DTYPES[dtype], panel,
+                                                  ctypes.byref(o), ctypes.byref(m)), "wx_euler3d_plan_create")
+        self.edge_count = int(self.lib.wx_euler3d_edge_count(self._h))
+
+    def _check_q(self, q):
+        if q.dtype != self.dtype or q.numel() != 5 * self.V * self.H * self.H * self.n**3 or not q.is_contiguous() \
+                or q.device != self.device:
+            raise ValueError(f"state must be a contiguous {self.dtype} tensor of {self.shape} on {self.device}")
+
+    def extrap_pack(self, q: torch.Tensor, send_ptrs: Optional[Sequence[int]]):
+        self._check_q(q)
+        arr = (ctypes.c_void_p * 4)(*send_ptrs) if send_ptrs is not None else None
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.wx_euler3d_extrap_pack(self._h, q.data_ptr(), arr, st), "wx_euler3d_extrap_pack")
+
+    def rhs(self, q: torch.Tensor, halo_ptrs: Optional[Sequence[int]], out: torch.Tensor, region: int = _lib.WX_REGION_ALL):
+        self._check_q(q)
+        self._check_q(out)
+        arr = (ctypes.c_void_p * 4)(*halo_ptrs) if halo_ptrs is not None else None
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.wx_euler3d_rhs(self._h, q.data_ptr(), arr, out.data_ptr(), region, st), "wx_euler3d_rhs")
+
+    def close(self):
+        if self._h:
+            self.lib.wx_euler3d_plan_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RhsEuler3D:
+    """R(Q) for the panels this rank owns (all six on one GPU, or one per GPU on six).
+
+    `plans` : {panel: Euler3DPlan}; `exchange` : PanelExchange built for the same ownership.
+    Call with {panel: Q} (or a single tensor when the rank owns one panel); returns the same
+    structure of freshly allocated R tensors, shaped like the inputs."""
+
+    def __init__(self, plans: Dict[int, Euler3DPlan], exchange: PanelExchange, overlap: bool = True):
+        self.plans = plans
+        self.ex = exchange
+        self.overlap = overlap
+        self.panels = sorted(plans)
+        any_plan = next(iter(plans.values())) if plans else None
+        self.device = any_plan.device if any_plan else None
+        self.timestamps = None
+
+    def __call__(self, qs):
+        single = isinstance(qs, torch.Tensor)
+        if single:
+            if len(self.panels) != 1:
+                raise ValueError("a single tensor was given but this rank owns several panels")
+            qs = {self.panels[0]: qs}
+        shapes = {p: q.shape for p, q in qs.items()}
+        flat = {p: q.reshape(self.plans[p].shape) for p, q in qs.items()}
+        outs = {p: torch.empty_like(flat[p]) for p in self.panels}
+        ex = self.ex
+        for p in self.panels:
+            self.plans[p].extrap_pack(flat[p], ex.send_ptrs(p))
+        if ex.needs_comm and self.overlap:
+            ex.start()
+            for p in self.panels:
+                self.plans[p].rhs(flat[p], None, outs[p], _lib.WX_REGION_INTERIOR)
+            ex.wait()
+            for p in self.panels:
+                self.plans[p].rhs(flat[p], ex.halo_ptrs(p), outs[p], _lib.WX_REGION_BOUNDARY)
+        else:
+            ex.start()
+            ex.wait()
+            for p in self.panels:
+                self.plans[p].rhs(flat[p], ex.halo_ptrs(p), outs[p], _lib.WX_REGION_ALL)
+        res = {p: outs[p].reshape(shapes[p]) for p in self.panels}
+        return res[self.panels[0]] if single else res
+
+    full = __call__
