@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Headline benchmark: whole-sphere 3-D Euler RHS evaluations (E7 of SURVEY.md section 8d).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one complete collective R(Q) on the WHOLE cubed sphere (6 panels, n=8 (p=7),
+60x60 elements per panel, V vertical elements), inputs resident in HBM, result left in HBM,
+halo exchange included.  STRONG scaling: the same sphere is split over min(N,6) GPUs
+(panel p on rank p % min(N,6); at N=1 all six panels live on one GPU and exchange by
+aliasing; ranks >= 6 idle).  value = DOF-updates/s = 5 vars * points * 6 panels * evals/s.
+
+Prints ONE JSON line (rank 0) with `roofline` for the dominant kernel (euler_rhs_kernel,
+timed live with HIP events on its launch stream) and `cpu_baseline` (the NumPy oracle on a
+bounded sample of the same workload, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_POINT = 384.0  # 360 B/point fields + 24 B/point interface metric
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(n, V, sample_H, reps, seed):
+    """Time the CPU oracle (oracle/euler3d.py, NumPy, 1 thread) on one tile of the same
+    workload with sample_H x sample_H x V elements.  Checker used as a *reported* baseline."""
+    import numpy as np
+
+    from oracle.euler3d import Euler3DOracle
+    from wxfactory_amd import synthetic
+
+    m = synthetic.euler3d_metric(n, sample_H, V, 0, "cpu", seed)
+    q = synthetic.euler3d_state(n, sample_H, V, 0, "cpu", seed).numpy()
+    om = {
+        "sqrtG_new": m["sqrtG"].numpy(), "inv_sqrtG_new": (1.0 / m["sqrtG"]).numpy(),
+        "h_contra_new": m["h_contra"].numpy(), "christoffel": m["christoffel"].numpy(),
+        "inv_dzdeta_new": m["inv_dzdeta"].numpy(),
+    }
+    for d in "ijk":
+        om[f"sqrtG_itf_{d}_new"] = m[f"sqrtG_itf_{d}"].numpy()
+        om[f"h_contra_itf_{d}_new"] = m[f"h_contra_itf_{d}"].numpy()
+    bsn = np.tile(m["boundary_sn"].numpy().reshape(sample_H, 1, n), (1, n, 1))
+    o = Euler3DOracle(n, sample_H, V, 31, synthetic.dfr_ops(n), om, bsn, bsn, panel=0)
+    itf = o.extrapolate(q)
+    halo = o.pack_edges(itf)  # any finite halo: timing only
+    o.rhs(q, halo)  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        itf = o.extrapolate(q)
+        o.pack_edges(itf)
+        o.rhs(q, halo, itf=itf)
+    dt = (time.perf_counter() - t0) / reps
+    dof = 5 * V * sample_H * sample_H * n**3
+    return dof / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=8, help="num_solpts (p = n-1)")
+    ap.add_argument("--H", type=int, default=60, help="elements per panel side")
+    ap.add_argument("--V", type=int, default=8, help="vertical elements")
+    ap.add_argument("--seed", type=int, default=20250824)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from wxfactory_amd import _lib, synthetic
+    from wxfactory_amd.exchange import PanelExchange
+    from wxfactory_amd.panels import panels_of_rank
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D
+
+    _lib.load()
+    n, H, V = args.n, args.H, args.V
+    ops = synthetic.dfr_ops(n)
+    mine = panels_of_rank(rank, world)
+    plans, qs = {}, {}
+    for p in mine:
+        metric = synthetic.euler3d_metric(n, H, V, p, dev, args.seed)
+        plans[p] = Euler3DPlan(n, H, V, 31, p, ops, metric)
+        qs[p] = synthetic.euler3d_state(n, H, V, p, dev, args.seed)
+    edge_doubles = 5 * V * H * n * n
+    ex = PanelExchange(edge_doubles, dev, rank=rank, world_size=world)
+    rhs = RhsEuler3D(plans, ex, overlap=not args.no_overlap)
+
+    # live timing of the dominant kernel: HIP events on the launch stream around every K2 launch
+    ev = []
+    orig_rhs = Euler3DPlan.rhs
+
+    def timed_rhs(self, q, halo, out, region=_lib.WX_REGION_ALL):
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        orig_rhs(self, q, halo, out, region)
+        b.record()
+        if recording[0]:
+            ev.append((a, b, region))
+
+    recording = [False]
+    Euler3DPlan.rhs = timed_rhs
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    out = None
+    for _ in range(args.warmup):
+        out = rhs(qs)
+    torch.cuda.synchronize()
+    barrier()
+    recording[0] = True
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = rhs(qs)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    recording[0] = False
+    if mine:
+        chk = float(sum(o.abs().max() for o in out.values()))
+        if not (chk == chk and chk < float("inf")):
+            raise SystemExit("non-finite RHS in the benchmark")
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    pts_panel = V * H * H * n**3
+    evals_per_s = args.steps / dt
+    dof_per_s = 5 * pts_panel * 6 * evals_per_s
+
+    # dominant-kernel roofline (rank 0's launches)
+    roof = None
+    if ev:
+        by_region = {}
+        for a, b, region in ev:
+            by_region.setdefault(region, []).append(a.elapsed_time(b) * 1e-3)
+        w = H - 2 if H > 2 else 0
+        frac_of_panel = {_lib.WX_REGION_ALL: 1.0, _lib.WX_REGION_INTERIOR: (w * w) / (H * H),
+                         _lib.WX_REGION_BOUNDARY: 1.0 - (w * w) / (H * H)}
+        # the dominant launch shape: ALL at N=1, INTERIOR when the exchange is overlapped
+        region = max(by_region, key=lambda r: sum(by_region[r]))
+        tk = sum(by_region[region]) / len(by_region[region])
+        bytes_launch = ALGO_BYTES_PER_POINT * pts_panel * frac_of_panel[region]
+        achieved = bytes_launch / tk / 1e9
+        roof = {"bound": "hbm", "kernel": "euler_rhs_kernel<8,double>", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None, "launch_ms": round(tk * 1e3, 4),
+                "algorithmic_bytes_per_launch": bytes_launch,
+                "region": {0: "all", 1: "interior", 2: "boundary"}[region]}
+
+    if rank == 0:
+        line = {
+            "metric": "DOF-updates/s (whole-sphere 3-D Euler RHS evals, cubed sphere p=7, 60x60 elem/panel)",
+            "value": dof_per_s, "unit": "DOF-updates/s", "n_gpus": args.gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "rhs_evals_per_s": evals_per_s,
+            "config": {"workload": f"E7: 3-D Euler RHS, n={n} (p={n-1}), H={H}x{H} elem/panel, V={V}, 6 panels "
+                                   f"({5*pts_panel*6} DOF), halo exchange included",
+                       "n": n, "H": H, "V": V, "panels_per_gpu": len(mine), "parallelism": f"panel-dd{min(world,6)}",
+                       "overlap": not args.no_overlap},
+            "roofline": roof,
+        }
+        if args.gpus == 1 and not args.no_cpu_baseline:
+            sample_H = 30
+            v, secs = cpu_baseline(n, V, sample_H, reps=3, seed=args.seed)
+            line["cpu_baseline"] = {
+                "value": v, "unit": "DOF-updates/s", "cores": 1, "kind": "port",
+                "sample": f"oracle/euler3d.py (NumPy, 1 thread) on one {sample_H}x{sample_H}x{V}-element tile of the "
+                          f"same n={n} workload, 3 evals, {secs:.2f} s/eval",
+            }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,143 @@
+"""Seeded synthetic cubed-sphere states and metric fields with physical magnitudes.
+
+The reference's geometry / initial-condition generators are setup code outside the hot path
+and cannot travel to the GPU box, so timing runs use these fields (SURVEY.md section 8d gives
+the recipe: magnitudes only - values do not affect speed).  Parity uses the golden fixtures.
+Arrays come out in the reference's layouts (geometry/cubed_sphere_3d.py:187-205, metric3d.py:1108-1157),
+interface metric single-valued per face with the outermost slots zero as cubed_sphere_3d.py:825-826.
+"""
+import math
+from typing import Dict
+
+import torch
+
+
+def _u(shape, gen, device):
+    """xi ~ U(-1, 1)"""
+    return torch.rand(shape, generator=gen, device=device, dtype=torch.float64) * 2.0 - 1.0
+
+
+def _pad_itf(face: torch.Tensor, axis: int, n2: int) -> torch.Tensor:
+    """(…, faces=E+1 along `axis`, n2) single-valued face field -> halo-padded (…, E+2, 2*n2) layout."""
+    E = face.shape[axis] - 1
+    shape = list(face.shape)
+    shape[axis] = E + 2
+    shape[-1] = 2 * n2
+    out = torch.zeros(shape, dtype=face.dtype, device=face.device)
+    idx_minus = [slice(None)] * face.ndim
+    idx_plus = [slice(None)] * face.ndim
+    idx_minus[axis] = slice(1, None)   # minus slot of padded index f+1 = face f
+    idx_minus[-1] = slice(0, n2)
+    idx_plus[axis] = slice(0, E + 1)   # plus slot of padded index f = face f
+    idx_plus[-1] = slice(n2, None)
+    out[tuple(idx_minus)] = face
+    out[tuple(idx_plus)] = face
+    # outermost slots (never read) are zero like the reference's
+    z0 = [slice(None)] * face.ndim
+    z0[axis] = 0
+    z0[-1] = slice(0, n2)
+    out[tuple(z0)] = 0.0
+    z1 = [slice(None)] * face.ndim
+    z1[axis] = E + 1
+    z1[-1] = slice(n2, None)
+    out[tuple(z1)] = 0.0
+    return out
+
+
+def euler3d_metric(n: int, H: int, V: int, panel: int, device, seed: int = 20250824, damping: bool = False
+                   ) -> Dict[str, torch.Tensor]:
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed + 1000 * panel + 1)
+    n2, n3 = n * n, n**3
+    pts = (V, H, H, n3)
+    m = {}
+    m["sqrtG"] = 1e9 * (1.0 + 0.1 * _u(pts, gen, device))
+    h = torch.empty((3, 3) + pts, dtype=torch.float64, device=device)
+    diag = (4e-10, 4e-10, 6e-7)
+    for a in range(3):
+        h[a, a] = diag[a] * (1.0 + 0.1 * _u(pts, gen, device))
+    for a, b in ((0, 1), (0, 2), (1, 2)):
+        h[a, b] = 1e-11 * _u(pts, gen, device)
+        h[b, a] = h[a, b]
+    m["h_contra"] = h
+    m["christoffel"] = 1e-3 * _u((3, 9) + pts, gen, device)
+    m["inv_dzdeta"] = torch.full(pts, 1.6e-3, dtype=torch.float64, device=device)
+    for name, axis, fshape, pshape in (
+        ("i", 2, (V, H, H + 1, n2), None),
+        ("j", 1, (V, H + 1, H, n2), None),
+        ("k", 0, (V + 1, H, H, n2), None),
+    ):
+        sg = 1e9 * (1.0 + 0.1 * _u(fshape, gen, device))
+        m[f"sqrtG_itf_{name}"] = _pad_itf(sg, axis, n2).contiguous()
+        hf = torch.empty((3, 3) + fshape, dtype=torch.float64, device=device)
+        for a in range(3):
+            hf[a, a] = diag[a] * (1.0 + 0.1 * _u(fshape, gen, device))
+        for a, b in ((0, 1), (0, 2), (1, 2)):
+            hf[a, b] = 1e-11 * _u(fshape, gen, device)
+            hf[b, a] = hf[a, b]
+        m[f"h_contra_itf_{name}"] = _pad_itf(hf, axis + 2, n2).contiguous()
+    x = (torch.arange(H * n, dtype=torch.float64, device=device) + 0.5) / (H * n) * (math.pi / 2) - math.pi / 4
+    m["boundary_sn"] = torch.tan(x).contiguous()
+    m["boundary_we"] = torch.tan(x).contiguous()
+    if damping:
+        m["damp_coef"] = 0.02 * (_u(pts, gen, device) > 0.5).to(torch.float64)
+        m["damp_uref"] = 1e-6 * (20.0 + _u((3,) + pts, gen, device))
+    return m
+
+
+def euler3d_state(n: int, H: int, V: int, panel: int, device, seed: int = 20250824, ztop: float = 10000.0
+                  ) -> torch.Tensor:
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed + 1000 * panel + 2)
+    n3 = n**3
+    pts = (V, H, H, n3)
+    # height of each point: level index = ek*n + kl
+    ek = torch.arange(V, dtype=torch.float64, device=device).view(V, 1, 1, 1)
+    kl = (torch.arange(n3, device=device) // (n * n)).to(torch.float64).view(1, 1, 1, n3)
+    z = ztop * (ek * n + kl + 0.5) / (n * V)
+    q = torch.empty((5,) + pts, dtype=torch.float64, device=device)
+    rho = 1.2 * torch.exp(-z / 8000.0) * (1.0 + 0.01 * _u(pts, gen, device))
+    q[0] = rho
+    q[1] = rho * 1e-6 * (20.0 + _u(pts, gen, device))
+    q[2] = rho * 1e-6 * (20.0 + _u(pts, gen, device))
+    q[3] = rho * 1e-7 * _u(pts, gen, device)
+    q[4] = rho * 300.0 * (1.0 + 0.01 * _u(pts, gen, device))
+    return q
+
+
+def dfr_ops(n: int):
+    """1-D DFR operator pieces on Gauss-Legendre points, computed from their definitions
+    (reference geometry/operators.py:55-80, 86-99, 144-148 builds the same objects with sympy):
+    Lagrange extrapolation to -1/+1, the differentiation matrix on the extended point set
+    [-1, GL nodes, +1] restricted to solution points (diff_solpt) with its two boundary columns
+    (correction), and the modal filter removing the highest Legendre mode."""
+    import numpy as np
+    from numpy.polynomial import legendre as L
+
+    x, _ = L.leggauss(n)
+    ext = np.concatenate(([-1.0], x, [1.0]))
+
+    def bary_diff(pts):
+        m = len(pts)
+        w = np.array([1.0 / np.prod([pts[j] - pts[k] for k in range(m) if k != j]) for j in range(m)])
+        Dm = np.zeros((m, m))
+        for i in range(m):
+            for j in range(m):
+                if i != j:
+                    Dm[i, j] = (w[j] / w[i]) / (pts[i] - pts[j])
+            Dm[i, i] = -Dm[i].sum()
+        return Dm
+
+    Dext = bary_diff(ext)
+    Vd = L.legvander(x, n - 1)
+    invV = np.linalg.inv(Vd)
+    em = (L.legvander(np.array([-1.0]), n - 1) @ invV).reshape(-1)
+    ep = (L.legvander(np.array([1.0]), n - 1) @ invV).reshape(-1)
+    feye = np.eye(n)
+    feye[-1, -1] = 0.0
+    return {
+        "extrap_neg": em, "extrap_pos": ep,
+        "diff_solpt": np.ascontiguousarray(Dext[1:-1, 1:-1]),
+        "correction": np.ascontiguousarray(np.column_stack((Dext[1:-1, 0], Dext[1:-1, -1]))),
+        "highfilter": Vd @ (feye @ invV),
+    }
