@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import EULER_FIXTURES, golden, make_oracle, var_err, var_max
+from tests.util import EULER_FIXTURES, golden, halo7, make_oracle, var_err, var_max
 
 pytestmark = pytest.mark.gpu
 
@@ -50,11 +50,12 @@ def test_pack_matches_reference_halos(name):
             send = torch.zeros((4, plan.edge_count), dtype=dtype, device=DEV)
             plan.extrap_pack(q, [send[e].data_ptr() for e in range(4)])
             torch.cuda.synchronize()
-            got = send.cpu().numpy().reshape(4, 5, g.V, g.H, g.n**2)
+            got = send.cpu().numpy().reshape(4, 7, g.V, g.H, g.n**2)
             for e in range(4):
                 nb, e2 = NEIGHBOR[p][e], landing_edge(p, e)
-                ref = g.halo(nb, cplx)[e2]
-                assert np.abs(got[e] - ref).max() <= 1e-13 * np.abs(ref).max(), (name, p, e, cplx)
+                ref = halo7(g.halo(nb, cplx)[e2])
+                for v in range(7):  # 0-4: the reference's message; 5-6: derived pressure, log p
+                    assert np.abs(got[e][v] - ref[v]).max() <= 1e-13 * np.abs(ref[v]).max(), (name, p, e, v, cplx)
             plan.close()
 
 
@@ -68,7 +69,7 @@ def test_rhs_matches_reference(name, cplx):
     for p in g.metric_panels():
         plan = make_plan(g, p, dtype)
         q = to_dev(g.q(p, cplx))
-        halo = [to_dev(h) for h in g.halo(p, cplx)]
+        halo = [to_dev(halo7(h)) for h in g.halo(p, cplx)]
         out = torch.full_like(q, float("nan"))
         plan.extrap_pack(q, None)
         plan.rhs(q, [h.data_ptr() for h in halo], out)
@@ -97,7 +98,7 @@ def test_regions_compose(name):
     p = g.metric_panels()[-1]
     plan = make_plan(g, p)
     q = to_dev(g.q(p))
-    keep = [to_dev(h) for h in g.halo(p)]
+    keep = [to_dev(halo7(h)) for h in g.halo(p)]
     halo = [k.data_ptr() for k in keep]
     a = torch.full_like(q, float("nan"))
     b = torch.full_like(q, float("nan"))

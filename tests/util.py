@@ -73,3 +73,12 @@ def var_err(a, b):
 
 def var_max(a):
     return np.abs(a).max(axis=tuple(range(1, a.ndim)))
+
+
+def halo7(h5):
+    """Edge message of the HIP path from the reference's 5-variable halo face: append the face
+    pressure and its log (WX_EULER3D_EDGE_FIELDS = 7; pde_euler_cubesphere.py:158, rhs_dfr.py:113)."""
+    from oracle.euler3d import Rd, cpd, cvd, p0
+
+    p = p0 * np.exp((cpd / cvd) * np.log(h5[4] * (Rd / p0)))
+    return np.concatenate((h5, p[None], np.log(p)[None]), axis=0)

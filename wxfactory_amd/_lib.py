@@ -8,7 +8,7 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_int, c_size_t, c_void_p
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "lib", "libwxhip.so")
+LIB_PATH = os.environ.get("WXHIP_LIB") or os.path.join(PKG, "lib", "libwxhip.so")  # WXHIP_LIB: A/B variants
 
 WX_OK = 0
 WX_F64, WX_C128 = 0, 1

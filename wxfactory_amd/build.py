@@ -25,18 +25,22 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
+def build(force: bool = False, verbose: bool = False, defines=(), out: str = LIB) -> str:
+    """defines/out: build an experiment variant (e.g. defines=["WX_K2_WAVES=2"], out=".../libwxhip_w2.so");
+    pick it at run time with the WXHIP_LIB environment variable."""
+    if out == LIB and not force and not _stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
+    tag = os.path.basename(out).replace(".so", "")
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        obj = os.path.join(LIBDIR, tag + "_" + src.replace(".hip", ".o"))
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd += ["-D" + d for d in defines]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))
@@ -44,12 +48,15 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
+    outs = [a[6:] for a in sys.argv[1:] if a.startswith("--out=")]
+    print(build(force="--force" in sys.argv, verbose=True, defines=defs,
+                out=os.path.join(LIBDIR, outs[0]) if outs else LIB))

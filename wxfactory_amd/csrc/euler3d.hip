@@ -18,6 +18,29 @@
 #include <cstring>
 #include <new>
 
+// tuning knobs (A/B-tested on MI355X; defaults are the measured best)
+#ifndef WX_K2_WAVES
+#define WX_K2_WAVES 4   // min waves per SIMD requested for the fused kernel (real dtype)
+#endif
+#ifndef WX_K2_RELOAD_H
+#define WX_K2_RELOAD_H 0   // re-read h_contra rows per direction (L2 hits) instead of holding 6 values
+#endif
+#ifndef WX_K2_EARLY_GAMMA
+#define WX_K2_EARLY_GAMMA 0   // also issue the 27 Christoffel loads before the face stage
+#endif
+#ifndef WX_K2_GAMMA_ROLLED
+#define WX_K2_GAMMA_ROLLED 0  // forcing rows one at a time (9 Christoffel loads in flight, not 27)
+#endif
+#ifndef WX_K2_FIELD_BATCH
+#define WX_K2_FIELD_BATCH 3   // derivative fields contracted per (rolled) batch: 7 = fully unrolled
+#endif
+#ifndef WX_K2_STAMPS
+#define WX_K2_STAMPS 0   // diagnostic build: per-workgroup phase timestamps (never in the product build)
+#endif
+#ifndef WX_K2_EARLY_LOADS
+#define WX_K2_EARLY_LOADS 0   // issue the point loads before the face stage
+#endif
+
 namespace wx {
 
 constexpr int kMaxN = 8;
@@ -32,6 +55,11 @@ struct Cfg {
 };
 
 enum { F_W = 0, F_E = 1, F_S = 2, F_N = 3, F_B = 4, F_T = 5 };
+// values per face point in the interface buffer and in the edge messages: the five prognostic
+// variables (exactly the reference's q_itf) followed by the face pressure and its logarithm, so
+// that the two elements sharing a face do not both redo exp(gamma*log(.)) (fluxes.py evaluates it
+// once per face side as well: pde_euler_cubesphere.py:158-160).
+constexpr int NQ = 7;
 enum { E_S = 0, E_N = 1, E_W = 2, E_E = 3 };
 
 // 1-D operator pieces and the tile's edge tables, in device memory (one copy per plan): dynamic
@@ -49,13 +77,14 @@ struct EulerParams {
     int advection_only, has_damp;
     const T* q;
     T* rhs;
-    T* itf;  // [elem][6 faces][5 vars][N2]
+    T* itf;  // [elem][6 faces][NQ = 5 vars + pressure + log pressure][N2]
     const T *halo_s, *halo_n, *halo_w, *halo_e;
     T *send_s, *send_n, *send_w, *send_e;
     const double *sg, *h, *chr, *idz;
     const double *sgi, *sgj, *sgk, *hi, *hj, *hk;
     const double *dcoef, *duref, *bsn, *bwe;
     const EulerConsts* K;  // device memory
+    unsigned long long* stamps;  // diagnostic builds only (WX_K2_STAMPS), else null
 };
 
 struct Elem {
@@ -150,9 +179,13 @@ __global__ __launch_bounds__(Cfg<N>::BS) void euler_extrap_kernel(const EulerPar
         }
         s[0] = w_exp(s[0]);
         s[4] = w_exp(s[4]);
-        T* dst = P.itf + ((size_t)el.e * 6 + f) * 5 * N2 + fp;
+        const T pf = kP0 * w_exp(kGamma * w_log(s[4] * kRdOverP0));  // pde_euler_cubesphere.py:158
+        const T lpf = w_log(pf);                                     // rhs_dfr.py:113-115
+        T* dst = P.itf + ((size_t)el.e * 6 + f) * NQ * N2 + fp;
 #pragma unroll
         for (int v = 0; v < 5; ++v) dst[v * N2] = s[v];
+        dst[5 * N2] = pf;
+        dst[6 * N2] = lpf;
 
         // outward faces of the tile edge: rotate into the neighbour's basis, flip, pack
         int edge = -1, along = 0;
@@ -179,6 +212,8 @@ __global__ __launch_bounds__(Cfg<N>::BS) void euler_extrap_kernel(const EulerPar
             const size_t vs = (size_t)V * H * N2;
 #pragma unroll
             for (int v = 0; v < 5; ++v) out[v * vs] = s[v];
+            out[5 * vs] = pf;
+            out[6 * vs] = lpf;
         }
     }
 }
@@ -191,17 +226,18 @@ __global__ __launch_bounds__(Cfg<N>::BS) void euler_extrap_kernel(const EulerPar
 // (the common flux of the rho w row itself is never used: rhs_dfr.py:139 overwrites that row).
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ void rusanov_face(const T* qL, const T* qR, T unL, T unR, double sg, double h0, double h1,
-                                             double h2, double hdd, bool own_is_L, bool advection_only, T* out) {
-    const T pL = kP0 * w_exp(kGamma * w_log(qL[4] * kRdOverP0));
-    const T pR = kP0 * w_exp(kGamma * w_log(qR[4] * kRdOverP0));
+__device__ __forceinline__ void rusanov_face(const T* qL, const T* qR, T unL, T unR, T rL, T rR, double sg, double h0,
+                                             double h1, double h2, double hdd, bool own_is_L, bool advection_only,
+                                             T* out) {
+    // q[0..4] state, q[5] pressure, q[6] log pressure; rL, rR = 1/rho
+    const T pL = qL[5], pR = qR[5];
     T eL, eR;
     if (advection_only) {
         eL = T(w_abs(unL));
         eR = T(w_abs(unR));
     } else {
-        eL = w_abs(unL) + w_sqrt(hdd * kGamma * pL / qL[0]);
-        eR = w_abs(unR) + w_sqrt(hdd * kGamma * pR / qR[0]);
+        eL = w_abs(unL) + w_sqrt((hdd * kGamma) * pL * rL);
+        eR = w_abs(unR) + w_sqrt((hdd * kGamma) * pR * rR);
     }
     const T eig = w_max(eL, eR);
     const T sguL = sg * unL, sguR = sg * unR;
@@ -213,16 +249,15 @@ __device__ __forceinline__ void rusanov_face(const T* qL, const T* qR, T unL, T 
     out[2] = 0.5 * ((sguL * qL[2] + sgh1 * pL) + (sguR * qR[2] + sgh1 * pR) - es * (qR[2] - qL[2]));
     out[3] = 0.5 * (sguL * qL[4] + sguR * qR[4] - es * (qR[4] - qL[4]));
     out[4] = 0.5 * (sguL * qL[3] + sguR * qR[3] - es * (qR[3] - qL[3]));
-    const T pown = own_is_L ? pL : pR;
-    out[5] = 0.5 * (sgh2 * pL + sgh2 * pR) / pown;
-    out[6] = w_log(pown);
+    out[5] = 0.5 * (sgh2 * pL + sgh2 * pR) / (own_is_L ? pL : pR);
+    out[6] = own_is_L ? qL[6] : qR[6];
 }
 
 // ------------------------------------------------------------------------------------------------
 // K2: fused phases 3-8
 // ------------------------------------------------------------------------------------------------
 template <int N, typename T>
-__global__ __launch_bounds__(Cfg<N>::BS) void euler_rhs_kernel(const EulerParams<T> P) {
+__global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES)) void euler_rhs_kernel(const EulerParams<T> P) {
     using C = Cfg<N>;
     constexpr int N2 = C::N2, N3 = C::N3, EPB = C::EPB, BS = C::BS;
     constexpr int NF = 8;   // staged fields: 4 F rows, A, B (per direction) + log p + sqrtG*rho
@@ -234,6 +269,16 @@ __global__ __launch_bounds__(Cfg<N>::BS) void euler_rhs_kernel(const EulerParams
     const int tid = threadIdx.x;
     const int H = P.H, V = P.V;
     const size_t fs = (size_t)P.nelem * N3;
+#if WX_K2_STAMPS
+#define WX_STAMP(i)                                                                           \
+    do {                                                                                      \
+        __syncthreads();                                                                      \
+        if (tid == 0 && P.stamps) P.stamps[(size_t)blockIdx.x * 8 + (i)] = wall_clock64();    \
+    } while (0)
+#else
+#define WX_STAMP(i)
+#endif
+    WX_STAMP(0);
 
     for (int i = tid; i < N * N; i += BS) {
         sD[i] = P.K->D[i];
@@ -243,6 +288,40 @@ __global__ __launch_bounds__(Cfg<N>::BS) void euler_rhs_kernel(const EulerParams
         sCm[tid] = P.K->cm[tid];
         sCp[tid] = P.K->cp[tid];
     }
+
+    // ---- point loads first: in flight while the face stage computes
+    const int le = tid / N3, pt = tid % N3;
+    const Elem el = decode_elem(blockIdx.x * EPB + le, P.count, P.region, H, V);
+    const bool active = (le < EPB) && el.valid;
+    const int kl = pt / N2, jl = (pt / N) % N, il = pt % N;
+    const int lb = (le < EPB ? le : 0) * N3;  // LDS base of this thread's element
+    const size_t o = (size_t)el.e * N3 + pt;
+
+    T q0 = T(1.0), q1 = T(0.0), q2 = T(0.0), q3 = T(0.0), q4 = T(1.0);
+    double sg = 1.0, h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0;
+#define WX_POINT_LOADS()                                                                                   \
+    if (active) {                                                                                          \
+        q0 = P.q[o]; q1 = P.q[fs + o]; q2 = P.q[2 * fs + o]; q3 = P.q[3 * fs + o]; q4 = P.q[4 * fs + o];   \
+        sg = P.sg[o];                                                                                      \
+        h00 = P.h[0 * fs + o]; h01 = P.h[1 * fs + o]; h02 = P.h[2 * fs + o];                               \
+        h11 = P.h[4 * fs + o]; h12 = P.h[5 * fs + o]; h22 = P.h[8 * fs + o];                               \
+    }
+#if WX_K2_EARLY_LOADS
+    WX_POINT_LOADS()
+#endif
+#if !WX_K2_GAMMA_ROLLED
+    double cg[27], idzv = 0.0;
+#define WX_GAMMA_LOADS()                                                        \
+    if (active) {                                                               \
+        _Pragma("unroll") for (int i = 0; i < 27; ++i) cg[i] = P.chr[(size_t)i * fs + o]; \
+        idzv = P.idz[o];                                                        \
+    } else {                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 27; ++i) cg[i] = 0.0;             \
+    }
+#if WX_K2_EARLY_GAMMA
+    WX_GAMMA_LOADS()
+#endif
+#endif
 
     // ---- face stage: Riemann problems of all 6 faces of the block's elements -> LDS
     for (int fi = tid; fi < EPB * 6 * N2; fi += BS) {
@@ -254,7 +333,7 @@ __global__ __launch_bounds__(Cfg<N>::BS) void euler_rhs_kernel(const EulerParams
         const int d = f >> 1, plus = f & 1;
         const size_t vsh = (size_t)V * H * N2;  // var stride in a halo edge message
 
-        const T* own = P.itf + ((size_t)el.e * 6 + f) * 5 * N2 + fp;
+        const T* own = P.itf + ((size_t)el.e * 6 + f) * NQ * N2 + fp;
         const T* nbr;
         size_t nstride = N2;
         bool mirror = false;
@@ -262,7 +341,7 @@ __global__ __launch_bounds__(Cfg<N>::BS) void euler_rhs_kernel(const EulerParams
         size_t hfs;  // field stride of the h_contra_itf array
         if (d == 0) {
             const int ne = el.ei + (plus ? 1 : -1);
-            if (ne >= 0 && ne < H) nbr = P.itf + ((size_t)(el.e + (plus ? 1 : -1)) * 6 + (f ^ 1)) * 5 * N2 + fp;
+            if (ne >= 0 && ne < H) nbr = P.itf + ((size_t)(el.e + (plus ? 1 : -1)) * 6 + (f ^ 1)) * NQ * N2 + fp;
             else { nbr = (plus ? P.halo_e : P.halo_w) + ((size_t)el.ek * H + el.ej) * N2 + fp; nstride = vsh; }
             const size_t o = (((size_t)el.ek * H + el.ej) * (H + 2) + el.ei + 1) * 2 * N2 + plus * N2 + fp;
             hfs = (size_t)V * H * (H + 2) * 2 * N2;
@@ -270,7 +349,7 @@ __global__ __launch_bounds__(Cfg<N>::BS) void euler_rhs_kernel(const EulerParams
             hp = P.hi + 0 * 3 * hfs + o;
         } else if (d == 1) {
             const int ne = el.ej + (plus ? 1 : -1);
-            if (ne >= 0 && ne < H) nbr = P.itf + ((size_t)(el.e + (plus ? H : -H)) * 6 + (f ^ 1)) * 5 * N2 + fp;
+            if (ne >= 0 && ne < H) nbr = P.itf + ((size_t)(el.e + (plus ? H : -H)) * 6 + (f ^ 1)) * NQ * N2 + fp;
             else { nbr = (plus ? P.halo_n : P.halo_s) + ((size_t)el.ek * H + el.ei) * N2 + fp; nstride = vsh; }
             const size_t o = (((size_t)el.ek * (H + 2) + el.ej + 1) * H + el.ei) * 2 * N2 + plus * N2 + fp;
             hfs = (size_t)V * (H + 2) * H * 2 * N2;
@@ -278,65 +357,116 @@ __global__ __launch_bounds__(Cfg<N>::BS) void euler_rhs_kernel(const EulerParams
             hp = P.hj + 1 * 3 * hfs + o;
         } else {
             const int ne = el.ek + (plus ? 1 : -1);
-            if (ne >= 0 && ne < V) nbr = P.itf + ((size_t)(el.e + (plus ? H * H : -H * H)) * 6 + (f ^ 1)) * 5 * N2 + fp;
+            if (ne >= 0 && ne < V) nbr = P.itf + ((size_t)(el.e + (plus ? H * H : -H * H)) * 6 + (f ^ 1)) * NQ * N2 + fp;
             else { nbr = own; mirror = true; }
             const size_t o = ((((size_t)el.ek + 1) * H + el.ej) * H + el.ei) * 2 * N2 + plus * N2 + fp;
             hfs = (size_t)(V + 2) * H * H * 2 * N2;
             sgp = P.sgk + o;
             hp = P.hk + 2 * 3 * hfs + o;
         }
-        T qo[5], qn[5];
+        T qo[NQ], qn[NQ];
 #pragma unroll
-        for (int v = 0; v < 5; ++v) {
+        for (int v = 0; v < NQ; ++v) {
             qo[v] = own[v * N2];
             qn[v] = nbr[v * nstride];
         }
         const double sg = *sgp, h0 = hp[0], h1 = hp[hfs], h2 = hp[2 * hfs];
         const double hdd = d == 0 ? h0 : (d == 1 ? h1 : h2);
-        T uo = qo[1 + d] / qo[0];
-        T un = qn[1 + d] / qn[0];
+        const T ro = 1.0 / qo[0], rn = 1.0 / qn[0];
+        T uo = qo[1 + d] * ro;
+        T un = qn[1 + d] * rn;
         if (mirror) un = -uo;  // no-flow wall: odd symmetry of w (pde_euler_cubesphere.py:150-156)
         T out[NC];
-        if (plus) rusanov_face<T>(qo, qn, uo, un, sg, h0, h1, h2, hdd, true, P.advection_only, out);
-        else rusanov_face<T>(qn, qo, un, uo, sg, h0, h1, h2, hdd, false, P.advection_only, out);
+        if (plus) rusanov_face<T>(qo, qn, uo, un, ro, rn, sg, h0, h1, h2, hdd, true, P.advection_only, out);
+        else rusanov_face<T>(qn, qo, un, uo, rn, ro, sg, h0, h1, h2, hdd, false, P.advection_only, out);
 #pragma unroll
         for (int c = 0; c < NC; ++c) fr[le][f][c][fp] = out[c];
     }
 
-    // ---- point stage
-    const int le = tid / N3, pt = tid % N3;
-    const Elem el = decode_elem(blockIdx.x * EPB + le, P.count, P.region, H, V);
-    const bool active = (le < EPB) && el.valid;
-    const int kl = pt / N2, jl = (pt / N) % N, il = pt % N;
-    const int lb = (le < EPB ? le : 0) * N3;  // LDS base of this thread's element
-    const size_t o = (size_t)el.e * N3 + pt;
-
-    T q0 = T(1.0), q1 = T(0.0), q2 = T(0.0), q3 = T(0.0), q4 = T(1.0);
-    double sg = 1.0, h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0;
-    if (active) {
-        q0 = P.q[o]; q1 = P.q[fs + o]; q2 = P.q[2 * fs + o]; q3 = P.q[3 * fs + o]; q4 = P.q[4 * fs + o];
-        sg = P.sg[o];
-        h00 = P.h[0 * fs + o]; h01 = P.h[1 * fs + o]; h02 = P.h[2 * fs + o];
-        h11 = P.h[4 * fs + o]; h12 = P.h[5 * fs + o]; h22 = P.h[8 * fs + o];
-    }
-    const T u1 = q1 / q0, u2 = q2 / q0, u3 = q3 / q0;
-    const T p = kP0 * w_exp(kGamma * w_log(kRdOverP0 * q4));
-    const T logp = w_log(p);
-
+    WX_STAMP(1);
+#if !WX_K2_EARLY_LOADS
+    WX_POINT_LOADS()
+#endif
+#undef WX_POINT_LOADS
+    // ---- pointwise quantities
+    const T rinv = 1.0 / q0;
+    const T u1 = q1 * rinv, u2 = q2 * rinv, u3 = q3 * rinv;
+    const T glog = kGamma * w_log(kRdOverP0 * q4);
+    const T p = kP0 * w_exp(glog);
     if (le < EPB) {
-        fld[6][lb + pt] = logp;
+        fld[6][lb + pt] = kLogP0 + glog;  // log p, without a second logarithm
         fld[7][lb + pt] = sg * q0;
     }
 
-    T acc0 = T(0.0), acc1 = T(0.0), acc2 = T(0.0), acc4 = T(0.0), accw = T(0.0);
+    // ---- forcing, all but the gravity filter (pde_euler_cubesphere.py:12-25, 203-290)
+    T fc0 = T(0.0), fc1 = T(0.0), fc2 = T(0.0);
+    double gcoef = 0.0;
+#if WX_K2_GAMMA_ROLLED
+    if (active) {
+#pragma unroll 1
+        for (int i = 0; i < 3; ++i) {
+            const double* c = P.chr + (size_t)(i * 9) * fs + o;
+            const double c01 = c[0], c02 = c[fs], c03 = c[2 * fs], c11 = c[3 * fs], c12 = c[4 * fs], c13 = c[5 * fs],
+                         c22 = c[6 * fs], c23 = c[7 * fs], c33 = c[8 * fs];
+            T f = 2.0 * q0 * (c01 * u1 + c02 * u2 + c03 * u3) + c11 * (q0 * u1 * u1 + h00 * p) +
+                  2.0 * c12 * (q0 * u1 * u2 + h01 * p) + 2.0 * c13 * (q0 * u1 * u3 + h02 * p) +
+                  c22 * (q0 * u2 * u2 + h11 * p) + 2.0 * c23 * (q0 * u2 * u3 + h12 * p) +
+                  c33 * (q0 * u3 * u3 + h22 * p);
+            if (P.has_damp) f += (P.dcoef[o] * q0) * ((i == 0 ? u1 : (i == 1 ? u2 : u3)) - P.duref[(size_t)i * fs + o]);
+            if (i == 0) fc0 = f;
+            else if (i == 1) fc1 = f;
+            else fc2 = f;
+        }
+        gcoef = P.idz[o] * kGravity;
+    }
+#else
+#if !WX_K2_EARLY_GAMMA
+    WX_GAMMA_LOADS()
+#endif
+#undef WX_GAMMA_LOADS
+    if (active) {
+        T fc[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double* c = cg + i * 9;
+            const double c01 = c[0], c02 = c[1], c03 = c[2], c11 = c[3], c12 = c[4], c13 = c[5],
+                         c22 = c[6], c23 = c[7], c33 = c[8];
+            fc[i] = 2.0 * q0 * (c01 * u1 + c02 * u2 + c03 * u3) + c11 * (q0 * u1 * u1 + h00 * p) +
+                    2.0 * c12 * (q0 * u1 * u2 + h01 * p) + 2.0 * c13 * (q0 * u1 * u3 + h02 * p) +
+                    c22 * (q0 * u2 * u2 + h11 * p) + 2.0 * c23 * (q0 * u2 * u3 + h12 * p) +
+                    c33 * (q0 * u3 * u3 + h22 * p);
+        }
+        if (P.has_damp) {
+            const T dw = P.dcoef[o] * q0;
+            fc[0] += dw * (u1 - P.duref[o]);
+            fc[1] += dw * (u2 - P.duref[fs + o]);
+            fc[2] += dw * (u3 - P.duref[2 * fs + o]);
+        }
+        fc0 = fc[0]; fc1 = fc[1]; fc2 = fc[2];
+        gcoef = idzv * kGravity;
+    }
+#endif
+
+    WX_STAMP(2);
+    // accumulators of sum_d dF^d; the forcing is folded in as sqrtG*f so that the final
+    // -1/sqrtG scaling yields  -1/sqrtG sum_d dF^d - f  (keeps 4 values out of the hot loop)
+    T acc0 = T(0.0), acc1 = sg * fc0, acc2 = sg * fc1, acc4 = T(0.0), accw = sg * fc2;
     T hf = T(0.0);
 
 #pragma unroll 1
     for (int d = 0; d < 3; ++d) {
         const T ud = d == 0 ? u1 : (d == 1 ? u2 : u3);
+#if WX_K2_RELOAD_H
+        double hd0 = 0, hd1 = 0, hd2 = 0;
+        if (active) {
+            const double* hr = P.h + (size_t)(3 * d) * fs + o;
+            hd0 = hr[0]; hd1 = hr[fs]; hd2 = hr[2 * fs];
+        }
+#else
         const double hd0 = d == 0 ? h00 : (d == 1 ? h01 : h02);
         const double hd1 = d == 0 ? h01 : (d == 1 ? h11 : h12);
         const double hd2 = d == 0 ? h02 : (d == 1 ? h12 : h22);
+#endif
         const T sgu = sg * ud;
         const T Bd = T(sg * hd2);
         if (d > 0) __syncthreads();  // previous direction's reads are done
@@ -355,56 +485,66 @@ __global__ __launch_bounds__(Cfg<N>::BS) void euler_rhs_kernel(const EulerParams
         else if (d == 1) { base = lb + kl * N2 + il; stride = N; idx = jl; fp = kl * N + il; }
         else { base = lb + jl * N + il; stride = N2; idx = kl; fp = jl * N + il; }
 
-        T dv[7];
+        double dm[N];
 #pragma unroll
-        for (int c = 0; c < 7; ++c) dv[c] = T(0.0);
-#pragma unroll
-        for (int m = 0; m < N; ++m) {
-            const double dm = sD[idx * N + m];
-            const int a = base + m * stride;
-#pragma unroll
-            for (int c = 0; c < 7; ++c) dv[c] += dm * fld[c][a];
-            if (d == 2) hf += sHF[idx * N + m] * fld[7][a];
-        }
+        for (int m = 0; m < N; ++m) dm[m] = sD[idx * N + m];
         const double cm = sCm[idx], cp = sCp[idx];
         const int lf = le < EPB ? le : 0;
+#if WX_K2_FIELD_BATCH >= 7
+        T dv[7];
 #pragma unroll
-        for (int c = 0; c < 7; ++c) dv[c] += cm * fr[lf][2 * d][c][fp] + cp * fr[lf][2 * d + 1][c][fp];
-
+        for (int c = 0; c < 7; ++c) {
+            T a = cm * fr[lf][2 * d][c][fp] + cp * fr[lf][2 * d + 1][c][fp];
+#pragma unroll
+            for (int m = 0; m < N; ++m) a += dm[m] * fld[c][base + m * stride];
+            dv[c] = a;
+        }
         acc0 += dv[0];
         acc1 += dv[1];
         acc2 += dv[2];
         acc4 += dv[3];
         // W^d = [A@D + A*@C] + p [B@D + B*@C] + p B [log p@D + log p^@C]   (rhs_dfr.py:113-136)
         accw += dv[4] + dv[5] * p + dv[6] * (p * Bd);
+#else
+        // rolled over field batches: bounds the LDS reads in flight (register pressure)
+        const T pB = p * Bd;
+#pragma unroll 1
+        for (int c0 = 0; c0 < 7; c0 += WX_K2_FIELD_BATCH) {
+#pragma unroll
+            for (int cc = 0; cc < WX_K2_FIELD_BATCH; ++cc) {
+                const int c = c0 + cc;
+                if (c < 7) {
+                    T a = cm * fr[lf][2 * d][c][fp] + cp * fr[lf][2 * d + 1][c][fp];
+#pragma unroll
+                    for (int m = 0; m < N; ++m) a += dm[m] * fld[c][base + m * stride];
+                    // W^d = [A@D + A*@C] + p [B@D + B*@C] + p B [log p@D + log p^@C]  (rhs_dfr.py:113-136)
+                    if (c == 0) acc0 += a;
+                    else if (c == 1) acc1 += a;
+                    else if (c == 2) acc2 += a;
+                    else if (c == 3) acc4 += a;
+                    else if (c == 4) accw += a;
+                    else if (c == 5) accw += a * p;
+                    else accw += a * pB;
+                }
+            }
+        }
+#endif
+        if (d == 2) {
+#pragma unroll
+            for (int m = 0; m < N; ++m) hf += sHF[idx * N + m] * fld[7][base + m * stride];
+        }
+        WX_STAMP(3 + d);
     }
 
+#if WX_K2_STAMPS
+    if (active) {
+#else
     if (!active) return;
+#endif
 
     const double inv_sg = 1.0 / sg;
+    accw += gcoef * hf;  // gravity: inv_dzdeta * g * 1/sqrtG * HF_k(sqrtG rho)
     T r0 = -inv_sg * acc0, r1 = -inv_sg * acc1, r2 = -inv_sg * acc2, r3 = -inv_sg * accw, r4 = -inv_sg * acc4;
-
-    // ---- forcing (pde_euler_cubesphere.py:12-25, 203-290)
-    T fc[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const double* c = P.chr + (size_t)(i * 9) * fs + o;
-        const double c01 = c[0], c02 = c[fs], c03 = c[2 * fs], c11 = c[3 * fs], c12 = c[4 * fs], c13 = c[5 * fs],
-                     c22 = c[6 * fs], c23 = c[7 * fs], c33 = c[8 * fs];
-        fc[i] = 2.0 * q0 * (c01 * u1 + c02 * u2 + c03 * u3) + c11 * (q0 * u1 * u1 + h00 * p) +
-                2.0 * c12 * (q0 * u1 * u2 + h01 * p) + 2.0 * c13 * (q0 * u1 * u3 + h02 * p) +
-                c22 * (q0 * u2 * u2 + h11 * p) + 2.0 * c23 * (q0 * u2 * u3 + h12 * p) + c33 * (q0 * u3 * u3 + h22 * p);
-    }
-    fc[2] += (P.idz[o] * kGravity * inv_sg) * hf;
-    if (P.has_damp) {
-        const T dw = P.dcoef[o] * q0;
-        fc[0] += dw * (u1 - P.duref[o]);
-        fc[1] += dw * (u2 - P.duref[fs + o]);
-        fc[2] += dw * (u3 - P.duref[2 * fs + o]);
-    }
-    r1 -= fc[0];
-    r2 -= fc[1];
-    r3 -= fc[2];
     if (P.advection_only) { r0 = r1 = r2 = r3 = r4 = T(0.0); }
 
     P.rhs[o] = r0;
@@ -412,6 +552,11 @@ __global__ __launch_bounds__(Cfg<N>::BS) void euler_rhs_kernel(const EulerParams
     P.rhs[2 * fs + o] = r2;
     P.rhs[3 * fs + o] = r3;
     P.rhs[4 * fs + o] = r4;
+#if WX_K2_STAMPS
+    }
+    WX_STAMP(6);
+#endif
+#undef WX_STAMP
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -447,9 +592,10 @@ struct wx_euler3d_plan {
     int n, H, V, case_number, panel;
     wx_dtype dtype;
     size_t nelem;
-    void* itf;         // device: [elem][6][5][n^2] of dtype
+    void* itf;         // device: [elem][6][NQ][n^2] of dtype
     size_t itf_bytes;
     EulerConsts* consts;  // device
+    unsigned long long* stamps = nullptr;  // device, diagnostic builds only
     EulerParams<double> base;  // pointer-free parts + metric pointers (q/rhs/halo/send filled per call)
 };
 
@@ -480,6 +626,7 @@ EulerParams<T> make_params(const wx_euler3d_plan* pl) {
     P.halo_s = P.halo_n = P.halo_w = P.halo_e = nullptr;
     P.send_s = P.send_n = P.send_w = P.send_e = nullptr;
     P.K = pl->consts;
+    P.stamps = pl->stamps;
     P.sg = b.sg; P.h = b.h; P.chr = b.chr; P.idz = b.idz;
     P.sgi = b.sgi; P.sgj = b.sgj; P.sgk = b.sgk; P.hi = b.hi; P.hj = b.hj; P.hk = b.hk;
     P.dcoef = b.dcoef; P.duref = b.duref; P.bsn = b.bsn; P.bwe = b.bwe;
@@ -548,7 +695,7 @@ wx_status wx_euler3d_plan_create(wx_euler3d_plan** out, int n, int H, int V, int
     pl->n = n; pl->H = H; pl->V = V; pl->case_number = case_number; pl->panel = panel; pl->dtype = dtype;
     pl->nelem = (size_t)V * H * H;
     const size_t esz = dtype == WX_C128 ? 16 : 8;
-    pl->itf_bytes = pl->nelem * 6 * 5 * n * n * esz;
+    pl->itf_bytes = pl->nelem * 6 * NQ * n * n * esz;
     hipError_t e = hipMalloc(&pl->itf, pl->itf_bytes);
     if (e != hipSuccess) {
         delete pl;
@@ -596,8 +743,15 @@ wx_status wx_euler3d_plan_destroy(wx_euler3d_plan* pl) {
     return WX_OK;
 }
 
+// Diagnostic (not in wxhip.h): give the plan a device buffer of 8 uint64 per workgroup for phase stamps.
+wx_status wx_euler3d_debug_set_stamps(wx_euler3d_plan* pl, void* dev_buffer) {
+    if (!pl) return fail(WX_ERR_INVALID, "null plan");
+    pl->stamps = static_cast<unsigned long long*>(dev_buffer);
+    return WX_OK;
+}
+
 size_t wx_euler3d_edge_count(const wx_euler3d_plan* pl) {
-    return pl ? (size_t)5 * pl->V * pl->H * pl->n * pl->n : 0;
+    return pl ? (size_t)NQ * pl->V * pl->H * pl->n * pl->n : 0;
 }
 
 wx_status wx_euler3d_extrap_pack(wx_euler3d_plan* pl, const void* q, void* const send[4], wx_stream stream) {

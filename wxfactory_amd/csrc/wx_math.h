@@ -17,6 +17,7 @@ constexpr double kCpd = 1005.46;
 constexpr double kCvd = kCpd - kRd;
 constexpr double kGamma = kCpd / kCvd;  // heat_capacity_ratio
 constexpr double kRdOverP0 = kRd / kP0;
+constexpr double kLogP0 = 11.512925464970228420;  // log(1e5)
 
 struct cplx {
     double re, im;
@@ -35,6 +36,7 @@ __device__ __forceinline__ cplx operator*(double a, cplx b) { return {a * b.re, 
 __device__ __forceinline__ cplx operator*(cplx a, double b) { return {a.re * b, a.im * b}; }
 __device__ __forceinline__ cplx operator+(cplx a, double b) { return {a.re + b, a.im}; }
 __device__ __forceinline__ cplx operator+(double a, cplx b) { return {a + b.re, b.im}; }
+__device__ __forceinline__ cplx operator-(double a, cplx b) { return {a - b.re, -b.im}; }
 __device__ __forceinline__ cplx operator-(cplx a, double b) { return {a.re - b, a.im}; }
 __device__ __forceinline__ cplx operator/(cplx a, cplx b) {
     // Smith's algorithm (what NumPy uses for complex division)
