@@ -52,6 +52,11 @@ struct Cfg {
     // elements per workgroup: whole elements, <= 256 points unless one element is larger
     static constexpr int EPB = (N3 >= 216) ? 1 : (256 / N3);
     static constexpr int BS = ((EPB * N3 + 63) / 64) * 64;
+    // LDS image of one element's nodal field: rows of N nodes padded to an odd length so that
+    // line reads along i (lane stride = one row) do not pile onto a few banks (N=8: 8-way -> none)
+    static constexpr int NP = (N % 2 == 0) ? N + 1 : N;
+    static constexpr int LE = N2 * NP;  // doubles per element image
+    __host__ __device__ static constexpr int lidx(int kl, int jl, int il) { return (kl * N + jl) * NP + il; }
 };
 
 enum { F_W = 0, F_E = 1, F_S = 2, F_N = 3, F_B = 4, F_T = 5 };
@@ -134,7 +139,7 @@ template <int N, typename T>
 __global__ __launch_bounds__(Cfg<N>::BS) void euler_extrap_kernel(const EulerParams<T> P) {
     using C = Cfg<N>;
     constexpr int N2 = C::N2, N3 = C::N3, EPB = C::EPB, BS = C::BS;
-    __shared__ T fld[5][EPB * N3];
+    __shared__ T fld[5][EPB * C::LE];
 
     const int tid = threadIdx.x;
     const int H = P.H, V = P.V;
@@ -145,11 +150,12 @@ __global__ __launch_bounds__(Cfg<N>::BS) void euler_extrap_kernel(const EulerPar
         const Elem el = decode_elem(blockIdx.x * EPB + le, P.nelem, WX_REGION_ALL, H, V);
         if (le < EPB && el.valid) {
             const size_t o = (size_t)el.e * N3 + pt;
-            fld[0][le * N3 + pt] = w_log(P.q[o]);
-            fld[1][le * N3 + pt] = P.q[fs + o];
-            fld[2][le * N3 + pt] = P.q[2 * fs + o];
-            fld[3][le * N3 + pt] = P.q[3 * fs + o];
-            fld[4][le * N3 + pt] = w_log(P.q[4 * fs + o]);
+            const int lp = le * C::LE + C::lidx(pt / N2, (pt / N) % N, pt % N);
+            fld[0][lp] = w_log(P.q[o]);
+            fld[1][lp] = P.q[fs + o];
+            fld[2][lp] = P.q[2 * fs + o];
+            fld[3][lp] = P.q[3 * fs + o];
+            fld[4][lp] = w_log(P.q[4 * fs + o]);
         }
     }
     __syncthreads();
@@ -164,9 +170,9 @@ __global__ __launch_bounds__(Cfg<N>::BS) void euler_extrap_kernel(const EulerPar
         const int a = fp / N, b = fp % N;
         // point index of m-th node on the line normal to the face, and its stride
         int base, stride;
-        if (d == 0) { base = (a * N + b) * N; stride = 1; }        // (kl=a, jl=b, il=m)
-        else if (d == 1) { base = a * N2 + b; stride = N; }        // (kl=a, jl=m, il=b)
-        else { base = a * N + b; stride = N2; }                    // (kl=m, jl=a, il=b)
+        if (d == 0) { base = C::lidx(a, b, 0); stride = 1; }           // (kl=a, jl=b, il=m)
+        else if (d == 1) { base = C::lidx(a, 0, b); stride = C::NP; }  // (kl=a, jl=m, il=b)
+        else { base = C::lidx(0, a, b); stride = N * C::NP; }          // (kl=m, jl=a, il=b)
         const double* w = plus ? P.K->ep : P.K->em;
         T s[5];
 #pragma unroll
@@ -175,12 +181,16 @@ __global__ __launch_bounds__(Cfg<N>::BS) void euler_extrap_kernel(const EulerPar
         for (int m = 0; m < N; ++m) {
             const double wm = w[m];
 #pragma unroll
-            for (int v = 0; v < 5; ++v) s[v] += wm * fld[v][le * N3 + base + m * stride];
+            for (int v = 0; v < 5; ++v) s[v] += wm * fld[v][le * C::LE + base + m * stride];
         }
+        const T s4log = s[4];
         s[0] = w_exp(s[0]);
         s[4] = w_exp(s[4]);
-        const T pf = kP0 * w_exp(kGamma * w_log(s[4] * kRdOverP0));  // pde_euler_cubesphere.py:158
-        const T lpf = w_log(pf);                                     // rhs_dfr.py:113-115
+        // face pressure p0*exp(gamma*log(rho_theta*Rd/p0)) (pde_euler_cubesphere.py:158) and its log
+        // (rhs_dfr.py:113-115); log(rho_theta) is the extrapolated value itself, so no logarithm is needed
+        const T glog = kGamma * (s4log + kLogRdOverP0);
+        const T pf = kP0 * w_exp(glog);
+        const T lpf = kLogP0 + glog;
         T* dst = P.itf + ((size_t)el.e * 6 + f) * NQ * N2 + fp;
 #pragma unroll
         for (int v = 0; v < 5; ++v) dst[v * N2] = s[v];
@@ -262,7 +272,7 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
     constexpr int N2 = C::N2, N3 = C::N3, EPB = C::EPB, BS = C::BS;
     constexpr int NF = 8;   // staged fields: 4 F rows, A, B (per direction) + log p + sqrtG*rho
     constexpr int NC = 7;   // face quantities, see rusanov_face
-    __shared__ T fld[NF][EPB * N3];
+    __shared__ T fld[NF][EPB * C::LE];
     __shared__ T fr[EPB][6][NC][N2];
     __shared__ double sD[N * N], sHF[N * N], sCm[N], sCp[N];
 
@@ -294,7 +304,8 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
     const Elem el = decode_elem(blockIdx.x * EPB + le, P.count, P.region, H, V);
     const bool active = (le < EPB) && el.valid;
     const int kl = pt / N2, jl = (pt / N) % N, il = pt % N;
-    const int lb = (le < EPB ? le : 0) * N3;  // LDS base of this thread's element
+    const int lb = (le < EPB ? le : 0) * C::LE;  // LDS base of this thread's element
+    const int lpt = lb + C::lidx(kl, jl, il);    // this thread's node in the padded LDS image
     const size_t o = (size_t)el.e * N3 + pt;
 
     T q0 = T(1.0), q1 = T(0.0), q2 = T(0.0), q3 = T(0.0), q4 = T(1.0);
@@ -394,8 +405,8 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
     const T glog = kGamma * w_log(kRdOverP0 * q4);
     const T p = kP0 * w_exp(glog);
     if (le < EPB) {
-        fld[6][lb + pt] = kLogP0 + glog;  // log p, without a second logarithm
-        fld[7][lb + pt] = sg * q0;
+        fld[6][lpt] = kLogP0 + glog;  // log p, without a second logarithm
+        fld[7][lpt] = sg * q0;
     }
 
     // ---- forcing, all but the gravity filter (pde_euler_cubesphere.py:12-25, 203-290)
@@ -471,19 +482,19 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
         const T Bd = T(sg * hd2);
         if (d > 0) __syncthreads();  // previous direction's reads are done
         if (le < EPB) {
-            fld[0][lb + pt] = sgu * q0;
-            fld[1][lb + pt] = sgu * q1 + (sg * hd0) * p;
-            fld[2][lb + pt] = sgu * q2 + (sg * hd1) * p;
-            fld[3][lb + pt] = sgu * q4;
-            fld[4][lb + pt] = sgu * q3;
-            fld[5][lb + pt] = Bd;
+            fld[0][lpt] = sgu * q0;
+            fld[1][lpt] = sgu * q1 + (sg * hd0) * p;
+            fld[2][lpt] = sgu * q2 + (sg * hd1) * p;
+            fld[3][lpt] = sgu * q4;
+            fld[4][lpt] = sgu * q3;
+            fld[5][lpt] = Bd;
         }
         __syncthreads();
 
         int base, stride, idx, fp;
-        if (d == 0) { base = lb + (kl * N + jl) * N; stride = 1; idx = il; fp = kl * N + jl; }
-        else if (d == 1) { base = lb + kl * N2 + il; stride = N; idx = jl; fp = kl * N + il; }
-        else { base = lb + jl * N + il; stride = N2; idx = kl; fp = jl * N + il; }
+        if (d == 0) { base = lb + C::lidx(kl, jl, 0); stride = 1; idx = il; fp = kl * N + jl; }
+        else if (d == 1) { base = lb + C::lidx(kl, 0, il); stride = C::NP; idx = jl; fp = kl * N + il; }
+        else { base = lb + C::lidx(0, jl, il); stride = N * C::NP; idx = kl; fp = jl * N + il; }
 
         double dm[N];
 #pragma unroll

@@ -18,6 +18,7 @@ constexpr double kCvd = kCpd - kRd;
 constexpr double kGamma = kCpd / kCvd;  // heat_capacity_ratio
 constexpr double kRdOverP0 = kRd / kP0;
 constexpr double kLogP0 = 11.512925464970228420;  // log(1e5)
+constexpr double kLogRdOverP0 = -5.853269048356583;     // log(287.05/1e5)
 
 struct cplx {
     double re, im;
