@@ -215,6 +215,190 @@ def euler_case(name, ini, overrides, metric_panels, phase_panels, perturb=0.0, s
           f"max|R| per var panel0 = {numpy.abs(res[0]['R']).max(axis=(1,2,3,4))}", flush=True)
 
 
+
+# ---------------------------------------------------------------------------------------------
+# Shallow water on the cubed sphere (rhs_sw.py)
+# ---------------------------------------------------------------------------------------------
+SW_METRIC_ATTRS = [
+    "sqrtG", "inv_sqrtG", "H_contra_11", "H_contra_12", "H_contra_21", "H_contra_22",
+    "christoffel_1_01", "christoffel_1_02", "christoffel_1_11", "christoffel_1_12",
+    "christoffel_2_01", "christoffel_2_02", "christoffel_2_12", "christoffel_2_22",
+    "sqrtG_itf_i", "sqrtG_itf_j",
+    "H_contra_11_itf_i", "H_contra_21_itf_i", "H_contra_12_itf_j", "H_contra_22_itf_j",
+]
+SW_TOPO_ATTRS = ["hsurf", "dzdx1", "dzdx2", "hsurf_itf_i", "hsurf_itf_j"]
+
+
+class _Recorder:
+    """Wraps a ProcessTopology's exchange starters to keep what wait() delivered (harness-side
+    instrumentation; the reference object itself is untouched)."""
+
+    def __init__(self, pt):
+        self.pt = pt
+        self.vectors = None
+        self.scalars = None
+        self._sv, self._ss = pt.start_exchange_vectors, pt.start_exchange_scalars
+        pt.start_exchange_vectors = self._vec
+        pt.start_exchange_scalars = self._sca
+
+    def _wrap(self, req, slot):
+        rec = self
+        orig_wait = req.wait
+
+        def wait():
+            out = orig_wait()
+            setattr(rec, slot, [numpy.array(o, copy=True) for o in out])
+            return out
+
+        req.wait = wait
+        return req
+
+    def _vec(self, *a, **k):
+        return self._wrap(self._sv(*a, **k), "vectors")
+
+    def _sca(self, *a, **k):
+        return self._wrap(self._ss(*a, **k), "scalars")
+
+
+def sw_case(name, ini, overrides, perturb=0.0, seed=4321):
+    cfg_probe = _config(ini, overrides)
+    print(f"[{name}] {ini} n={cfg_probe.num_solpts} H={cfg_probe.num_elements_horizontal}", flush=True)
+
+    def work(rank):
+        from device import CpuDevice
+        from process_topology import ProcessTopology
+        from geometry import CubedSphere2D, DFROperators
+        from init.init_state_vars import init_state_vars
+        from rhs.rhs_selector import RhsBundle
+
+        cfg = _config(ini, overrides)
+        comm = MPI.COMM_WORLD
+        dev = CpuDevice(comm)
+        pt = ProcessTopology(dev, comm=comm)
+        geom = CubedSphere2D(cfg.num_elements_horizontal, cfg.num_solpts, cfg.lambda0, cfg.phi0, cfg.alpha0,
+                             pt, cfg, dev)
+        ops = DFROperators(geom, cfg, dev)
+        Q, topo, metric = init_state_vars(geom, ops, cfg)
+        rhs = RhsBundle(geom, ops, metric, topo, pt, cfg, Q.shape, False)
+        rec = _Recorder(pt)
+        rng = numpy.random.default_rng(seed + rank)
+        if perturb > 0.0:
+            Q = Q * (1.0 + perturb * rng.uniform(-1.0, 1.0, Q.shape))
+            Q[1:] += perturb * 1e-6 * Q[0] * rng.uniform(-1.0, 1.0, Q[1:].shape)
+        out = {"Q": Q.copy()}
+        with numpy.errstate(all="ignore"):
+            out["R"] = rhs.full(Q).copy()
+        # halo faces as delivered: [edge][var h, hu1, hu2] each (H, n)
+        out["halo"] = numpy.stack([numpy.stack([rec.scalars[e], rec.vectors[e][0], rec.vectors[e][1]])
+                                   for e in range(4)])
+        v = rng.uniform(-1.0, 1.0, Q.shape) * numpy.abs(Q).max(axis=(1, 2, 3), keepdims=True) * 1e-3
+        eps = numpy.sqrt(numpy.finfo(float).eps)
+        with numpy.errstate(all="ignore"):
+            Rc = rhs.full(Q + 1j * eps * v)
+        out["V"] = v
+        out["Rc"] = Rc.copy()
+        out["chalo"] = numpy.stack([numpy.stack([rec.scalars[e], rec.vectors[e][0], rec.vectors[e][1]])
+                                    for e in range(4)])
+        for a in SW_METRIC_ATTRS:
+            out["metric/" + a] = numpy.array(getattr(metric, a), copy=True)
+        if topo is not None:
+            for a in SW_TOPO_ATTRS:
+                out["topo/" + a] = numpy.array(getattr(topo, a), copy=True)
+        out["geom/boundary_sn"] = numpy.array(geom.boundary_sn, copy=True)
+        out["geom/boundary_we"] = numpy.array(geom.boundary_we, copy=True)
+        if rank == 0:
+            out.update(_ops_1d(ops, geom))
+            out["meta/case_number"] = numpy.int64(cfg.case_number)
+            out["meta/n"] = numpy.int64(cfg.num_solpts)
+            out["meta/H"] = numpy.int64(cfg.num_elements_horizontal)
+            out["meta/eps"] = numpy.float64(eps)
+            n = cfg.num_solpts
+            u = numpy.random.default_rng(7).uniform(-1, 1, n * n)
+            out["kron/u"] = u
+            for opn in ("derivative_x", "derivative_y", "extrap_x", "extrap_y"):
+                out["kron/" + opn] = u @ getattr(ops, opn)
+            f = numpy.random.default_rng(8).uniform(-1, 1, 2 * n)
+            out["kron/f"] = f
+            for opn in ("correction_WE", "correction_SN"):
+                out["kron/" + opn] = f @ getattr(ops, opn)
+        return out
+
+    _run6(name, work)
+
+
+# ---------------------------------------------------------------------------------------------
+# 2-D Cartesian Euler (rhs_dfr.py:8-45 + pde_euler_cartesian.py + the reference's native pde_cpp)
+# ---------------------------------------------------------------------------------------------
+def cart2d_case(name, ini, overrides, seed=99):
+    MPI.reset_world(1)
+
+    def work(rank):
+        from device import CpuDevice
+        from geometry import Cartesian2D, DFROperators
+        from init.init_state_vars import init_state_vars
+        from rhs.rhs_selector import RhsBundle
+
+        cfg = _config(ini, overrides)
+        dev = CpuDevice(MPI.COMM_WORLD)
+        geom = Cartesian2D((cfg.x0, cfg.x1), (cfg.z0, cfg.z1), cfg.num_elements_horizontal,
+                           cfg.num_elements_vertical, cfg.num_solpts, dev)
+        ops = DFROperators(geom, cfg, dev)
+        Q, topo, metric = init_state_vars(geom, ops, cfg)
+        rng = numpy.random.default_rng(seed)
+        Q = Q * (1.0 + 1e-3 * rng.uniform(-1, 1, Q.shape))
+        Q[1] += 0.5 * Q[0] * rng.uniform(-1, 1, Q[0].shape)   # some wind so that both AUSM branches are hit
+        Q[2] += 0.5 * Q[0] * rng.uniform(-1, 1, Q[0].shape)
+        rhs = RhsBundle(geom, ops, metric, topo, None, cfg, Q.shape, False)
+        out = {"Q": Q.copy(), "R": rhs.full(Q).copy()}
+        r = rhs.full
+        for a in ("q_itf_x1", "q_itf_x3", "f_x1", "f_x3", "f_itf_x1", "f_itf_x3"):
+            out["phase/" + a] = numpy.array(getattr(r, a), copy=True)
+        v = rng.uniform(-1, 1, Q.shape) * numpy.abs(Q).max(axis=(1, 2, 3), keepdims=True) * 1e-3
+        eps = numpy.sqrt(numpy.finfo(float).eps)
+        out["V"] = v
+        out["Rc"] = rhs.full(Q + 1j * eps * v).copy()
+        out.update(_ops_1d(ops, geom))
+        out["meta/n"] = numpy.int64(cfg.num_solpts)
+        out["meta/nx"] = numpy.int64(cfg.num_elements_horizontal)
+        out["meta/nz"] = numpy.int64(cfg.num_elements_vertical)
+        out["meta/dx1"] = numpy.float64(geom.Δx1)
+        out["meta/dx3"] = numpy.float64(geom.Δx3)
+        out["meta/eps"] = numpy.float64(eps)
+        return out
+
+    t0 = time.time()
+    print(f"[{name}] {ini}", flush=True)
+    res, err = MPI.run_ranks(work, 1)
+    if err[0]:
+        print(err[0])
+        raise SystemExit(1)
+    path = os.path.join(GOLDEN, name + ".npz")
+    numpy.savez_compressed(path, **res[0])
+    print(f"   -> {path}  {os.path.getsize(path)/1e6:.2f} MB  ({time.time()-t0:.1f}s)", flush=True)
+    MPI.reset_world(6)
+
+
+def _run6(name, work):
+    t0 = time.time()
+    MPI.reset_world(6)
+    res, err = MPI.run_ranks(work, 6)
+    for e in err:
+        if e:
+            print(e)
+            raise SystemExit(1)
+    flat = {}
+    for p, d in enumerate(res):
+        for k, v in d.items():
+            if k.startswith(("ops/", "meta/", "kron/")):
+                flat[k] = v
+            else:
+                flat[f"p{p}/{k}"] = v
+    path = os.path.join(GOLDEN, name + ".npz")
+    numpy.savez_compressed(path, **flat)
+    print(f"   -> {path}  {os.path.getsize(path)/1e6:.2f} MB  ({time.time()-t0:.1f}s)  "
+          f"max|R| panel0 = {numpy.abs(res[0]['R']).max(axis=tuple(range(1, res[0]['R'].ndim)))}", flush=True)
+
+
 CASES = {
     # balanced gravity-wave state, small n: all panels carry metrics + phases (exchange coverage)
     "euler3d_c31_n3_h4_v2": lambda nm: euler_case(
@@ -235,6 +419,16 @@ CASES = {
     "euler3d_c21_n4_h3_v4": lambda nm: euler_case(
         nm, "dcmip21.ini", dict(num_solpts=4, num_elements_horizontal=3, num_elements_vertical=4),
         metric_panels=(0, 3, 5), phase_panels=()),
+    # shallow water: Rossby-Haurwitz wave (case 6), p=4 as BASELINE config 2; mountain (case 5,
+    # topography); steady zonal flow (case 2) at the benchmark order p=7
+    "sw_c6_n5_h4": lambda nm: sw_case(nm, "case6.ini", dict(num_solpts=5, num_elements_horizontal=4)),
+    "sw_c5_n4_h3": lambda nm: sw_case(nm, "case5.ini", dict(num_solpts=4, num_elements_horizontal=3)),
+    "sw_c2p_n8_h3": lambda nm: sw_case(nm, "case2.ini", dict(num_solpts=8, num_elements_horizontal=3), perturb=0.01),
+    # 2-D Cartesian Euler: the plumbing reference (config/gaussian_bubble.ini, smaller grid)
+    "cart2d_bubble_n5": lambda nm: cart2d_case(nm, "gaussian_bubble.ini",
+                                               dict(num_solpts=5, num_elements_horizontal=7, num_elements_vertical=9)),
+    "cart2d_bubble_n4": lambda nm: cart2d_case(nm, "gaussian_bubble.ini",
+                                               dict(num_solpts=4, num_elements_horizontal=5, num_elements_vertical=6)),
 }
 
 

@@ -82,3 +82,76 @@ def halo7(h5):
 
     p = p0 * np.exp((cpd / cvd) * np.log(h5[4] * (Rd / p0)))
     return np.concatenate((h5, p[None], np.log(p)[None]), axis=0)
+
+
+SW_FIXTURES = ["sw_c6_n5_h4", "sw_c5_n4_h3", "sw_c2p_n8_h3"]
+CART2D_FIXTURES = ["cart2d_bubble_n5", "cart2d_bubble_n4"]
+
+
+class GoldenSW:
+    def __init__(self, name):
+        self.name = name
+        self.z = np.load(os.path.join(GOLDEN, name + ".npz"))
+        self.n, self.H = int(self.z["meta/n"]), int(self.z["meta/H"])
+        self.case = int(self.z["meta/case_number"])
+        self.eps = float(self.z["meta/eps"])
+        self.ops = {k[4:]: self.z[k] for k in self.z.files if k.startswith("ops/")}
+
+    def __getitem__(self, k):
+        return self.z[k]
+
+    def sub(self, p, group):
+        pre = f"p{p}/{group}/"
+        return {k[len(pre):]: self.z[k] for k in self.z.files if k.startswith(pre)}
+
+    def q(self, p, cplx=False):
+        q = self.z[f"p{p}/Q"]
+        return q + 1j * self.eps * self.z[f"p{p}/V"] if cplx else q
+
+    def halo(self, p, cplx=False):
+        return list(self.z[f"p{p}/chalo" if cplx else f"p{p}/halo"])
+
+    def r(self, p, cplx=False):
+        return self.z[f"p{p}/Rc" if cplx else f"p{p}/R"]
+
+
+def golden_sw(name) -> GoldenSW:
+    if name not in _cache:
+        _cache[name] = GoldenSW(name)
+    return _cache[name]
+
+
+def make_sw_oracle(g: GoldenSW, p: int):
+    from oracle.sw2d import SW2DOracle
+
+    return SW2DOracle(g.n, g.H, g.ops, g.sub(p, "metric"), g.sub(p, "topo"), g[f"p{p}/geom/boundary_sn"],
+                      g[f"p{p}/geom/boundary_we"], panel=p)
+
+
+class GoldenCart:
+    def __init__(self, name):
+        self.z = np.load(os.path.join(GOLDEN, name + ".npz"))
+        z = self.z
+        self.n, self.nx, self.nz = int(z["meta/n"]), int(z["meta/nx"]), int(z["meta/nz"])
+        self.dx1, self.dx3, self.eps = float(z["meta/dx1"]), float(z["meta/dx3"]), float(z["meta/eps"])
+        self.ops = {k[4:]: z[k] for k in z.files if k.startswith("ops/")}
+
+    def __getitem__(self, k):
+        return self.z[k]
+
+    def q(self, cplx=False):
+        return self.z["Q"] + 1j * self.eps * self.z["V"] if cplx else self.z["Q"]
+
+    def r(self, cplx=False):
+        return self.z["Rc"] if cplx else self.z["R"]
+
+    def oracle(self):
+        from oracle.cart2d import Cart2DOracle
+
+        return Cart2DOracle(self.n, self.nx, self.nz, self.dx1, self.dx3, self.ops)
+
+
+def golden_cart(name) -> GoldenCart:
+    if name not in _cache:
+        _cache[name] = GoldenCart(name)
+    return _cache[name]
