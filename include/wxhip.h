@@ -126,6 +126,58 @@ wx_status wx_euler3d_extrap_pack(wx_euler3d_plan* plan, const void* q, void* con
 wx_status wx_euler3d_rhs(wx_euler3d_plan* plan, const void* q, const void* const halo[4], void* rhs,
                          wx_region region, wx_stream stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Shallow water on a cubed-sphere tile.
+ * Replaces  rhs/rhs_sw.py:38-240 (RhsShallowWater.__call__ / __compute_rhs__).
+ * Layout: q[var][ej][ei][p], p = jl*n + il (geometry/cubed_sphere_2d.py:134-170); variables
+ * (h, h u1, h u2); halo-padded interface arrays (H, H+2, 2n) / (H+2, H, 2n).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const double* sqrtG;             /* (H,H,n^2)    geometry/metric2d.py:17-167           */
+    const double* H_contra_11;       /* (H,H,n^2)                                          */
+    const double* H_contra_12;
+    const double* H_contra_21;
+    const double* H_contra_22;
+    const double* christoffel_1_01;  /* (H,H,n^2) the eight symbols rhs_sw.py:223-235 reads */
+    const double* christoffel_1_02;
+    const double* christoffel_1_11;
+    const double* christoffel_1_12;
+    const double* christoffel_2_01;
+    const double* christoffel_2_02;
+    const double* christoffel_2_12;
+    const double* christoffel_2_22;
+    const double* sqrtG_itf_i;       /* (H,H+2,2n)                                         */
+    const double* sqrtG_itf_j;       /* (H+2,H,2n)                                         */
+    const double* H_contra_11_itf_i; /* (H,H+2,2n)                                         */
+    const double* H_contra_21_itf_i;
+    const double* H_contra_12_itf_j; /* (H+2,H,2n)                                         */
+    const double* H_contra_22_itf_j;
+    /* bottom topography (init Topo: rhs_sw.py:80-82, 153-155, 213-220); all five NULL when flat */
+    const double* hsurf;             /* (H,H,n^2)  */
+    const double* dzdx1;
+    const double* dzdx2;
+    const double* hsurf_itf_i;       /* (H,H+2,2n) */
+    const double* hsurf_itf_j;       /* (H+2,H,2n) */
+    const double* boundary_sn;       /* (H*n) tan(x1) along S/N edges: geom.boundary_sn */
+    const double* boundary_we;       /* (H*n) tan(x2) along W/E edges: geom.boundary_we */
+} wx_sw_metric;
+
+typedef struct wx_sw_plan wx_sw_plan;
+
+wx_status wx_sw_plan_create(wx_sw_plan** plan, int n, int H, wx_dtype dtype, int panel, const wx_dfr_ops* ops,
+                            const wx_sw_metric* metric);
+wx_status wx_sw_plan_destroy(wx_sw_plan* plan);
+/* Elements of dtype per edge message: 3*H*n, layout [var][along][n]: exactly what the reference's
+ * exchange delivers (rhs_sw.py:103-117, 138-150): h (+ surface height), then the rotated (hu1, hu2). */
+size_t wx_sw_edge_count(const wx_sw_plan* plan);
+/* rhs_sw.py:76-117 sender side: extrapolate (h+hsurf, hu1, hu2) to the element faces into the plan's
+ * interface buffer; rotate + flip the four tile-edge lines into send[e] (e = S,N,W,E). */
+wx_status wx_sw_extrap_pack(wx_sw_plan* plan, const void* q, void* const send[4], wx_stream stream);
+/* rhs_sw.py:119-240: fluxes, derivatives, AUSM common fluxes with the received halo lines,
+ * corrections, Coriolis/metric/topography forcing; writes rhs for the elements of `region`. */
+wx_status wx_sw_rhs(wx_sw_plan* plan, const void* q, const void* const halo[4], void* rhs, wx_region region,
+                    wx_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,19 @@ class Euler3DMetric(ctypes.Structure):
     _fields_ = [(k, c_void_p) for k in EULER3D_METRIC_FIELDS]
 
 
+SW_METRIC_FIELDS = (
+    "sqrtG", "H_contra_11", "H_contra_12", "H_contra_21", "H_contra_22",
+    "christoffel_1_01", "christoffel_1_02", "christoffel_1_11", "christoffel_1_12",
+    "christoffel_2_01", "christoffel_2_02", "christoffel_2_12", "christoffel_2_22",
+    "sqrtG_itf_i", "sqrtG_itf_j", "H_contra_11_itf_i", "H_contra_21_itf_i", "H_contra_12_itf_j", "H_contra_22_itf_j",
+    "hsurf", "dzdx1", "dzdx2", "hsurf_itf_i", "hsurf_itf_j", "boundary_sn", "boundary_we",
+)
+
+
+class SwMetric(ctypes.Structure):
+    _fields_ = [(k, c_void_p) for k in SW_METRIC_FIELDS]
+
+
 # every symbol include/wxhip.h declares: (restype, argtypes)
 SIGNATURES = {
     "wx_last_error": (c_char_p, []),
@@ -46,6 +59,11 @@ SIGNATURES = {
     "wx_euler3d_edge_count": (c_size_t, [c_void_p]),
     "wx_euler3d_extrap_pack": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p]),
     "wx_euler3d_rhs": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_int, c_void_p]),
+    "wx_sw_plan_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, POINTER(DfrOps), POINTER(SwMetric)]),
+    "wx_sw_plan_destroy": (c_int, [c_void_p]),
+    "wx_sw_edge_count": (c_size_t, [c_void_p]),
+    "wx_sw_extrap_pack": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p]),
+    "wx_sw_rhs": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_int, c_void_p]),
 }
 
 _lib = None

@@ -14,6 +14,7 @@
 // Kronecker operators of the reference become 1-D contractions staged through LDS.
 #include "wx_common.h"
 #include "wx_math.h"
+#include "wx_panels.h"
 
 #include <cstring>
 #include <new>
@@ -65,7 +66,6 @@ enum { F_W = 0, F_E = 1, F_S = 2, F_N = 3, F_B = 4, F_T = 5 };
 // that the two elements sharing a face do not both redo exp(gamma*log(.)) (fluxes.py evaluates it
 // once per face side as well: pde_euler_cubesphere.py:158-160).
 constexpr int NQ = 7;
-enum { E_S = 0, E_N = 1, E_W = 2, E_E = 3 };
 
 // 1-D operator pieces and the tile's edge tables, in device memory (one copy per plan): dynamic
 // indexing into a by-value kernel argument would force the whole struct into scratch.
@@ -211,11 +211,7 @@ __global__ __launch_bounds__(Cfg<N>::BS) void euler_extrap_kernel(const EulerPar
         }
         T* sendp = edge == E_S ? P.send_s : (edge == E_N ? P.send_n : (edge == E_W ? P.send_w : P.send_e));
         if (edge >= 0 && sendp != nullptr) {
-            const double* mt = P.K->rot[edge];
-            const double c = 2.0 * X / (1.0 + X * X);
-            const T a1 = s[1], a2 = s[2];
-            s[1] = mt[0] * a1 + mt[1] * a2 + c * (mt[2] * a1 + mt[3] * a2);
-            s[2] = mt[4] * a1 + mt[5] * a2 + c * (mt[6] * a1 + mt[7] * a2);
+            rotate_contra<T>(P.K->rot[edge], X, s[1], s[2]);
             int al = along, bb = b;
             if (P.K->flip[edge]) { al = H - 1 - along; bb = N - 1 - b; }
             T* out = sendp + ((size_t)el.ek * H + al) * N2 + a * N + bb;
@@ -611,20 +607,6 @@ struct wx_euler3d_plan {
 };
 
 namespace {
-
-// flip / rotation tables, reference process_topology.py:126-175 (one tile per panel).
-// rot[p][edge] = (m0..m7):  b1 = m0 a1 + m1 a2 + c (m2 a1 + m3 a2),  b2 = m4 a1 + m5 a2 + c (m6 a1 + m7 a2)
-const int kFlip[6][4] = {{0, 0, 0, 0}, {1, 0, 0, 0}, {1, 1, 0, 0}, {0, 1, 0, 0}, {0, 1, 1, 0}, {1, 0, 0, 1}};
-#define WX_W0 {1, 0, 0, 0, 0, 1, 1, 0}
-#define WX_E0 {1, 0, 0, 0, 0, 1, -1, 0}
-const double kRot[6][4][8] = {
-    {{1, 0, 0, 1, 0, 1, 0, 0}, {1, 0, 0, -1, 0, 1, 0, 0}, WX_W0, WX_E0},
-    {{0, 1, 0, 0, -1, 0, 0, -1}, {0, -1, 0, 0, 1, 0, 0, -1}, WX_W0, WX_E0},
-    {{-1, 0, 0, -1, 0, -1, 0, 0}, {-1, 0, 0, 1, 0, -1, 0, 0}, WX_W0, WX_E0},
-    {{0, -1, 0, 0, 1, 0, 0, 1}, {0, 1, 0, 0, -1, 0, 0, 1}, WX_W0, WX_E0},
-    {{1, 0, 0, 1, 0, 1, 0, 0}, {-1, 0, 0, 1, 0, -1, 0, 0}, {0, -1, -1, 0, 1, 0, 0, 0}, {0, 1, -1, 0, -1, 0, 0, 0}},
-    {{-1, 0, 0, -1, 0, -1, 0, 0}, {1, 0, 0, -1, 0, 1, 0, 0}, {0, 1, 1, 0, -1, 0, 0, 0}, {0, -1, 1, 0, 1, 0, 0, 0}},
-};
 
 template <typename T>
 EulerParams<T> make_params(const wx_euler3d_plan* pl) {

@@ -1,0 +1,494 @@
+// Shallow-water RHS on one cubed-sphere tile: hand-written HIP for gfx950 (MI355X).
+//
+// Replaces reference wx_factory/rhs/rhs_sw.py:38-240.  Same two-kernel, element-blocked shape
+// as the 3-D Euler path (euler3d.hip):
+//   K1 sw_extrap_kernel  rhs_sw.py:76-117  faces of (h+hsurf, hu1, hu2) -> interface buffer,
+//                        rotated/flipped tile-edge lines -> send buffers
+//   K2 sw_rhs_kernel     rhs_sw.py:119-240 fluxes, derivatives, AUSM, corrections, forcing -> R
+// An element is n^2 points (one wave at n=8), so a 256-thread workgroup owns EPB = 256/n^2
+// whole elements.  The S7 workload (60x60 elements, n=8) is 5.5 MB of state per panel: the path is
+// launch-latency bound, which is why everything after the exchange is ONE kernel.
+#include "wx_common.h"
+#include "wx_math.h"
+#include "wx_panels.h"
+
+#include <cstring>
+#include <new>
+
+namespace wx {
+
+constexpr int kMaxN2 = 8;
+
+template <int N>
+struct Cfg2 {
+    static constexpr int N2 = N * N;
+    static constexpr int EPB = 256 / N2;
+    static constexpr int BS = ((EPB * N2 + 63) / 64) * 64;
+    static constexpr int NP = (N % 2 == 0) ? N + 1 : N;  // padded LDS row (see Cfg<N>::NP in euler3d.hip)
+    static constexpr int LE = N * NP;
+    __host__ __device__ static constexpr int lidx(int jl, int il) { return jl * NP + il; }
+};
+
+struct SwConsts {
+    double em[kMaxN2], ep[kMaxN2], cm[kMaxN2], cp[kMaxN2];
+    double D[kMaxN2 * kMaxN2];
+    double rot[4][8];
+    int flip[4];
+};
+
+template <typename T>
+struct SwParams {
+    int H, nelem, count, region, has_topo;
+    const T* q;
+    T* rhs;
+    T* itf;  // [elem][4 faces W,E,S,N][3 vars][N]
+    const T *halo_s, *halo_n, *halo_w, *halo_e;
+    T *send_s, *send_n, *send_w, *send_e;
+    const double *sg, *h11, *h12, *h21, *h22;
+    const double *c101, *c102, *c111, *c112, *c201, *c202, *c212, *c222;
+    const double *sgi, *sgj, *h11i, *h21i, *h12j, *h22j;
+    const double *hsurf, *dz1, *dz2, *hsi, *hsj;
+    const double *bsn, *bwe;
+    const SwConsts* K;
+};
+
+struct Elem2 {
+    int ej, ei, e;
+    bool valid;
+};
+
+__device__ __forceinline__ Elem2 decode_elem2(int slot, int count, int region, int H) {
+    Elem2 r;
+    r.valid = slot < count;
+    if (!r.valid) slot = 0;
+    if (region == WX_REGION_ALL) {
+        r.ei = slot % H;
+        r.ej = slot / H;
+    } else if (region == WX_REGION_INTERIOR) {
+        const int w = H - 2;
+        r.ei = 1 + slot % w;
+        r.ej = 1 + slot / w;
+    } else {
+        const int w = H > 2 ? H - 2 : 0;
+        int s = slot;
+        if (s < H) {
+            r.ej = 0;
+            r.ei = s;
+        } else if (s < 2 * H) {
+            r.ej = H - 1;
+            r.ei = s - H;
+        } else {
+            s -= 2 * H;
+            r.ej = 1 + s % w;
+            r.ei = (s / w) ? H - 1 : 0;
+        }
+    }
+    r.e = r.ej * H + r.ei;
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int N, typename T>
+__global__ __launch_bounds__(Cfg2<N>::BS) void sw_extrap_kernel(const SwParams<T> P) {
+    using C = Cfg2<N>;
+    constexpr int N2 = C::N2, EPB = C::EPB, BS = C::BS;
+    __shared__ T fld[3][EPB * C::LE];
+    const int tid = threadIdx.x;
+    const int H = P.H;
+    const size_t fs = (size_t)P.nelem * N2;
+    {
+        const int le = tid / N2, pt = tid % N2;
+        const Elem2 el = decode_elem2(blockIdx.x * EPB + le, P.nelem, WX_REGION_ALL, H);
+        if (le < EPB && el.valid) {
+            const size_t o = (size_t)el.e * N2 + pt;
+            const int lp = le * C::LE + C::lidx(pt / N, pt % N);
+            T h = P.q[o];
+            if (P.has_topo) h = h + P.hsurf[o];
+            fld[0][lp] = h;
+            fld[1][lp] = P.q[fs + o];
+            fld[2][lp] = P.q[2 * fs + o];
+        }
+    }
+    __syncthreads();
+    for (int fi = tid; fi < EPB * 4 * N; fi += BS) {
+        const int le = fi / (4 * N);
+        const int r = fi % (4 * N);
+        const int f = r / N, k = r % N;
+        const Elem2 el = decode_elem2(blockIdx.x * EPB + le, P.nelem, WX_REGION_ALL, H);
+        if (!el.valid) continue;
+        const int d = f >> 1, plus = f & 1;
+        const int base = d == 0 ? C::lidx(k, 0) : C::lidx(0, k);
+        const int stride = d == 0 ? 1 : C::NP;
+        const double* w = plus ? P.K->ep : P.K->em;
+        T s[3] = {T(0.0), T(0.0), T(0.0)};
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+            const double wm = w[m];
+#pragma unroll
+            for (int v = 0; v < 3; ++v) s[v] += wm * fld[v][le * C::LE + base + m * stride];
+        }
+        T* dst = P.itf + ((size_t)el.e * 4 + f) * 3 * N + k;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) dst[v * N] = s[v];
+
+        int edge = -1, along = 0;
+        double X = 0.0;
+        if (d == 0 && ((plus && el.ei == H - 1) || (!plus && el.ei == 0))) {
+            edge = plus ? E_E : E_W;
+            along = el.ej;
+            X = P.bwe[el.ej * N + k];
+        } else if (d == 1 && ((plus && el.ej == H - 1) || (!plus && el.ej == 0))) {
+            edge = plus ? E_N : E_S;
+            along = el.ei;
+            X = P.bsn[el.ei * N + k];
+        }
+        T* sendp = edge == E_S ? P.send_s : (edge == E_N ? P.send_n : (edge == E_W ? P.send_w : P.send_e));
+        if (edge >= 0 && sendp != nullptr) {
+            rotate_contra<T>(P.K->rot[edge], X, s[1], s[2]);
+            int pos = along * N + k;
+            if (P.K->flip[edge]) pos = H * N - 1 - pos;
+            const size_t vs = (size_t)H * N;
+#pragma unroll
+            for (int v = 0; v < 3; ++v) sendp[v * vs + pos] = s[v];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int N, typename T>
+__global__ __launch_bounds__(Cfg2<N>::BS) void sw_rhs_kernel(const SwParams<T> P) {
+    using C = Cfg2<N>;
+    constexpr int N2 = C::N2, EPB = C::EPB, BS = C::BS;
+    __shared__ T fld[3][EPB * C::LE];
+    __shared__ T fr[EPB][4][3][N];
+    __shared__ double sD[N * N], sCm[N], sCp[N];
+    const int tid = threadIdx.x;
+    const int H = P.H;
+    const size_t fs = (size_t)P.nelem * N2;
+    for (int i = tid; i < N * N; i += BS) sD[i] = P.K->D[i];
+    if (tid < N) {
+        sCm[tid] = P.K->cm[tid];
+        sCp[tid] = P.K->cp[tid];
+    }
+
+    // ---- face stage: AUSM common flux of the 4 faces (rhs_sw.py:157-207)
+    for (int fi = tid; fi < EPB * 4 * N; fi += BS) {
+        const int le = fi / (4 * N);
+        const int r = fi % (4 * N);
+        const int f = r / N, k = r % N;
+        const Elem2 el = decode_elem2(blockIdx.x * EPB + le, P.count, P.region, H);
+        if (!el.valid) continue;
+        const int d = f >> 1, plus = f & 1;
+        const T* own = P.itf + ((size_t)el.e * 4 + f) * 3 * N + k;
+        const T* nbr;
+        size_t nstride = N;
+        size_t o_own, o_nbr;  // slots in the halo-padded interface arrays (own side, neighbour side)
+        const double *sgp, *hddp, *hodp, *hsp;
+        if (d == 0) {
+            const int ne = el.ei + (plus ? 1 : -1);
+            if (ne >= 0 && ne < H) nbr = P.itf + ((size_t)(el.e + (plus ? 1 : -1)) * 4 + (f ^ 1)) * 3 * N + k;
+            else { nbr = (plus ? P.halo_e : P.halo_w) + (size_t)el.ej * N + k; nstride = (size_t)H * N; }
+            const size_t row = (size_t)el.ej * (H + 2);
+            o_own = (row + el.ei + 1) * 2 * N + plus * N + k;
+            o_nbr = (row + el.ei + 1 + (plus ? 1 : -1)) * 2 * N + (1 - plus) * N + k;
+            sgp = P.sgi; hddp = P.h11i; hodp = P.h21i; hsp = P.hsi;
+        } else {
+            const int ne = el.ej + (plus ? 1 : -1);
+            if (ne >= 0 && ne < H) nbr = P.itf + ((size_t)(el.e + (plus ? H : -H)) * 4 + (f ^ 1)) * 3 * N + k;
+            else { nbr = (plus ? P.halo_n : P.halo_s) + (size_t)el.ei * N + k; nstride = (size_t)H * N; }
+            o_own = ((size_t)(el.ej + 1) * H + el.ei) * 2 * N + plus * N + k;
+            o_nbr = ((size_t)(el.ej + 1 + (plus ? 1 : -1)) * H + el.ei) * 2 * N + (1 - plus) * N + k;
+            sgp = P.sgj; hddp = P.h22j; hodp = P.h12j; hsp = P.hsj;
+        }
+        T qo[3], qn[3];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            qo[v] = own[v * N];
+            qn[v] = nbr[v * nstride];
+        }
+        if (P.has_topo) {  // "substract topo after extrapolation" (rhs_sw.py:153-155), slot by slot
+            qo[0] = qo[0] - hsp[o_own];
+            qn[0] = qn[0] - hsp[o_nbr];
+        }
+        const double sg = sgp[o_own], hdd = hddp[o_own], hod = hodp[o_own];
+        T qL[3], qR[3];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            qL[v] = plus ? qo[v] : qn[v];
+            qR[v] = plus ? qn[v] : qo[v];
+        }
+        const T unL = d == 0 ? qL[1] : qL[2], unR = d == 0 ? qR[1] : qR[2];
+        const T aL = w_sqrt(kGravity * qL[0] * hdd), aR = w_sqrt(kGravity * qR[0] * hdd);
+        const T tL = qL[0] * aL, tR = qR[0] * aR;
+        const T mL = (w_real(tL) != 0.0 || w_abs(tL) != 0.0) ? unL / tL : T(0.0);
+        const T mR = (w_real(tR) != 0.0 || w_abs(tR) != 0.0) ? unR / tR : T(0.0);
+        const T M = 0.25 * ((mL + 1.0) * (mL + 1.0) - (mR - 1.0) * (mR - 1.0));
+        const T Mp = w_max(T(0.0), M), Mm = w_min(T(0.0), M);
+        T out[3];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) out[v] = sg * (Mp * aL * qL[v] + Mm * aR * qR[v]);
+        const double sgg = sg * (0.5 * kGravity);
+        const T hL2 = qL[0] * qL[0], hR2 = qR[0] * qR[0];
+        const T pddL = (sgg * hdd) * hL2, pddR = (sgg * hdd) * hR2;
+        const T podL = (sgg * hod) * hL2, podR = (sgg * hod) * hR2;
+        const T pn = 0.5 * ((1.0 + mL) * pddL + (1.0 - mR) * pddR);  // on the normal component
+        const T po = 0.5 * ((1.0 + mL) * podL + (1.0 - mR) * podR);  // on the other one
+        out[1] += d == 0 ? pn : po;
+        out[2] += d == 0 ? po : pn;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) fr[le][f][v][k] = out[v];
+    }
+
+    // ---- point stage
+    const int le = tid / N2, pt = tid % N2;
+    const Elem2 el = decode_elem2(blockIdx.x * EPB + le, P.count, P.region, H);
+    const bool active = (le < EPB) && el.valid;
+    const int jl = pt / N, il = pt % N;
+    const int lf = le < EPB ? le : 0;
+    const int lb = lf * C::LE;
+    const int lpt = lb + C::lidx(jl, il);
+    const size_t o = (size_t)el.e * N2 + pt;
+
+    T q0 = T(1.0), q1 = T(0.0), q2 = T(0.0);
+    double sg = 1.0, h11 = 0, h12 = 0, h21 = 0, h22 = 0;
+    if (active) {
+        q0 = P.q[o]; q1 = P.q[fs + o]; q2 = P.q[2 * fs + o];
+        sg = P.sg[o];
+        h11 = P.h11[o]; h12 = P.h12[o]; h21 = P.h21[o]; h22 = P.h22[o];
+    }
+    const T u1 = q1 / q0, u2 = q2 / q0;
+    const T hsq = q0 * q0;
+    T forc1 = T(0.0), forc2 = T(0.0);
+    if (active) {
+        double dz1 = 0.0, dz2 = 0.0;
+        if (P.has_topo) { dz1 = P.dz1[o]; dz2 = P.dz2[o]; }
+        forc1 = 2.0 * (P.c101[o] * q1 + P.c102[o] * q2) + P.c111[o] * q1 * u1 + 2.0 * P.c112[o] * q1 * u2 +
+                kGravity * q0 * (h11 * dz1 + h12 * dz2);
+        forc2 = 2.0 * (P.c201[o] * q1 + P.c202[o] * q2) + 2.0 * P.c212[o] * q1 * u2 + P.c222[o] * q2 * u2 +
+                kGravity * q0 * (h21 * dz1 + h22 * dz2);
+    }
+    T acc0 = T(0.0), acc1 = T(0.0), acc2 = T(0.0);
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const T ud = d == 0 ? u1 : u2;
+        const double ha = d == 0 ? h11 : h12, hb = d == 0 ? h21 : h22;
+        if (d > 0) __syncthreads();
+        if (le < EPB) {
+            fld[0][lpt] = sg * (d == 0 ? q1 : q2);
+            fld[1][lpt] = sg * (q1 * ud + (0.5 * kGravity * ha) * hsq);
+            fld[2][lpt] = sg * (q2 * ud + (0.5 * kGravity * hb) * hsq);
+        }
+        __syncthreads();
+        const int base = d == 0 ? lb + C::lidx(jl, 0) : lb + C::lidx(0, il);
+        const int stride = d == 0 ? 1 : C::NP;
+        const int idx = d == 0 ? il : jl;
+        const int fp = d == 0 ? jl : il;
+        const double cm = sCm[idx], cp = sCp[idx];
+        T dv[3];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) dv[v] = cm * fr[lf][2 * d][v][fp] + cp * fr[lf][2 * d + 1][v][fp];
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+            const double dm = sD[idx * N + m];
+#pragma unroll
+            for (int v = 0; v < 3; ++v) dv[v] += dm * fld[v][base + m * stride];
+        }
+        acc0 += dv[0];
+        acc1 += dv[1];
+        acc2 += dv[2];
+    }
+    if (!active) return;
+    const double inv_sg = 1.0 / sg;
+    P.rhs[o] = inv_sg * (-acc0);
+    P.rhs[fs + o] = inv_sg * (-acc1) - forc1;
+    P.rhs[2 * fs + o] = inv_sg * (-acc2) - forc2;
+}
+
+}  // namespace wx
+
+// ------------------------------------------------------------------------------------------------
+using namespace wx;
+
+struct wx_sw_plan {
+    int n, H, panel;
+    wx_dtype dtype;
+    void* itf = nullptr;
+    SwConsts* consts = nullptr;
+    SwParams<double> base;
+};
+
+namespace {
+
+template <typename T>
+SwParams<T> make_sw_params(const wx_sw_plan* pl) {
+    SwParams<T> P;
+    const SwParams<double>& b = pl->base;
+    P.H = b.H; P.nelem = b.nelem; P.count = 0; P.region = 0; P.has_topo = b.has_topo;
+    P.q = nullptr; P.rhs = nullptr; P.itf = static_cast<T*>(pl->itf);
+    P.halo_s = P.halo_n = P.halo_w = P.halo_e = nullptr;
+    P.send_s = P.send_n = P.send_w = P.send_e = nullptr;
+    P.sg = b.sg; P.h11 = b.h11; P.h12 = b.h12; P.h21 = b.h21; P.h22 = b.h22;
+    P.c101 = b.c101; P.c102 = b.c102; P.c111 = b.c111; P.c112 = b.c112;
+    P.c201 = b.c201; P.c202 = b.c202; P.c212 = b.c212; P.c222 = b.c222;
+    P.sgi = b.sgi; P.sgj = b.sgj; P.h11i = b.h11i; P.h21i = b.h21i; P.h12j = b.h12j; P.h22j = b.h22j;
+    P.hsurf = b.hsurf; P.dz1 = b.dz1; P.dz2 = b.dz2; P.hsi = b.hsi; P.hsj = b.hsj;
+    P.bsn = b.bsn; P.bwe = b.bwe; P.K = pl->consts;
+    return P;
+}
+
+template <int N, typename T>
+wx_status sw_launch(bool extrap, const SwParams<T>& P, hipStream_t st) {
+    using C = Cfg2<N>;
+    const int cnt = extrap ? P.nelem : P.count;
+    if (cnt == 0) return WX_OK;
+    const int grid = (cnt + C::EPB - 1) / C::EPB;
+    if (extrap) hipLaunchKernelGGL((sw_extrap_kernel<N, T>), dim3(grid), dim3(C::BS), 0, st, P);
+    else hipLaunchKernelGGL((sw_rhs_kernel<N, T>), dim3(grid), dim3(C::BS), 0, st, P);
+    WX_HIP_TRY(hipGetLastError());
+    return WX_OK;
+}
+
+template <typename T>
+wx_status sw_dispatch(int n, bool extrap, const SwParams<T>& P, hipStream_t st) {
+    switch (n) {
+        case 2: return sw_launch<2, T>(extrap, P, st);
+        case 3: return sw_launch<3, T>(extrap, P, st);
+        case 4: return sw_launch<4, T>(extrap, P, st);
+        case 5: return sw_launch<5, T>(extrap, P, st);
+        case 6: return sw_launch<6, T>(extrap, P, st);
+        case 7: return sw_launch<7, T>(extrap, P, st);
+        case 8: return sw_launch<8, T>(extrap, P, st);
+    }
+    return fail(WX_ERR_UNSUPPORTED, "num_solpts %d not in 2..8", n);
+}
+
+}  // namespace
+
+extern "C" {
+
+wx_status wx_sw_plan_create(wx_sw_plan** out, int n, int H, wx_dtype dtype, int panel, const wx_dfr_ops* ops,
+                            const wx_sw_metric* m) {
+    if (!out || !ops || !m) return fail(WX_ERR_INVALID, "wx_sw_plan_create: null argument");
+    *out = nullptr;
+    if (n < 2 || n > kMaxN2) return fail(WX_ERR_UNSUPPORTED, "num_solpts %d not in 2..%d", n, kMaxN2);
+    if (H < 1) return fail(WX_ERR_INVALID, "bad tile size H=%d", H);
+    if (panel < 0 || panel > 5) return fail(WX_ERR_INVALID, "panel %d not in 0..5", panel);
+    if (dtype != WX_F64 && dtype != WX_C128) return fail(WX_ERR_INVALID, "unknown dtype %d", (int)dtype);
+    if (!ops->extrap_neg || !ops->extrap_pos || !ops->diff_solpt || !ops->correction)
+        return fail(WX_ERR_INVALID, "wx_dfr_ops has a null member");
+    const double* req[] = {m->sqrtG, m->H_contra_11, m->H_contra_12, m->H_contra_21, m->H_contra_22,
+                           m->christoffel_1_01, m->christoffel_1_02, m->christoffel_1_11, m->christoffel_1_12,
+                           m->christoffel_2_01, m->christoffel_2_02, m->christoffel_2_12, m->christoffel_2_22,
+                           m->sqrtG_itf_i, m->sqrtG_itf_j, m->H_contra_11_itf_i, m->H_contra_21_itf_i,
+                           m->H_contra_12_itf_j, m->H_contra_22_itf_j, m->boundary_sn, m->boundary_we};
+    for (const double* p : req)
+        if (!p) return fail(WX_ERR_INVALID, "wx_sw_metric has a null member");
+    const int ntopo = (m->hsurf != nullptr) + (m->dzdx1 != nullptr) + (m->dzdx2 != nullptr) +
+                      (m->hsurf_itf_i != nullptr) + (m->hsurf_itf_j != nullptr);
+    if (ntopo != 0 && ntopo != 5) return fail(WX_ERR_INVALID, "topography needs all five arrays or none");
+
+    wx_sw_plan* pl = new (std::nothrow) wx_sw_plan();
+    if (!pl) return fail(WX_ERR_NOMEM, "out of host memory");
+    pl->n = n; pl->H = H; pl->panel = panel; pl->dtype = dtype;
+    const size_t esz = dtype == WX_C128 ? 16 : 8;
+    hipError_t e = hipMalloc(&pl->itf, (size_t)H * H * 4 * 3 * n * esz);
+    if (e == hipSuccess) e = hipMalloc((void**)&pl->consts, sizeof(SwConsts));
+    SwConsts hc;
+    memset(&hc, 0, sizeof(hc));
+    for (int i = 0; i < n; ++i) {
+        hc.em[i] = ops->extrap_neg[i]; hc.ep[i] = ops->extrap_pos[i];
+        hc.cm[i] = ops->correction[2 * i]; hc.cp[i] = ops->correction[2 * i + 1];
+        for (int j = 0; j < n; ++j) hc.D[i * n + j] = ops->diff_solpt[i * n + j];
+    }
+    for (int ed = 0; ed < 4; ++ed) {
+        hc.flip[ed] = kFlip[panel][ed];
+        for (int i = 0; i < 8; ++i) hc.rot[ed][i] = kRot[panel][ed][i];
+    }
+    if (e == hipSuccess) e = hipMemcpy(pl->consts, &hc, sizeof(hc), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (pl->itf) (void)hipFree(pl->itf);
+        if (pl->consts) (void)hipFree(pl->consts);
+        delete pl;
+        return fail(WX_ERR_HIP, "wx_sw_plan_create: device allocation failed: %s", hipGetErrorString(e));
+    }
+    SwParams<double>& b = pl->base;
+    b.H = H; b.nelem = H * H; b.has_topo = ntopo == 5;
+    b.sg = m->sqrtG; b.h11 = m->H_contra_11; b.h12 = m->H_contra_12; b.h21 = m->H_contra_21; b.h22 = m->H_contra_22;
+    b.c101 = m->christoffel_1_01; b.c102 = m->christoffel_1_02; b.c111 = m->christoffel_1_11;
+    b.c112 = m->christoffel_1_12; b.c201 = m->christoffel_2_01; b.c202 = m->christoffel_2_02;
+    b.c212 = m->christoffel_2_12; b.c222 = m->christoffel_2_22;
+    b.sgi = m->sqrtG_itf_i; b.sgj = m->sqrtG_itf_j; b.h11i = m->H_contra_11_itf_i; b.h21i = m->H_contra_21_itf_i;
+    b.h12j = m->H_contra_12_itf_j; b.h22j = m->H_contra_22_itf_j;
+    b.hsurf = m->hsurf; b.dz1 = m->dzdx1; b.dz2 = m->dzdx2; b.hsi = m->hsurf_itf_i; b.hsj = m->hsurf_itf_j;
+    b.bsn = m->boundary_sn; b.bwe = m->boundary_we;
+    *out = pl;
+    return WX_OK;
+}
+
+wx_status wx_sw_plan_destroy(wx_sw_plan* pl) {
+    if (!pl) return WX_OK;
+    hipError_t e = hipFree(pl->itf);
+    hipError_t e2 = hipFree(pl->consts);
+    if (e == hipSuccess) e = e2;
+    delete pl;
+    if (e != hipSuccess) return fail(WX_ERR_HIP, "hipFree failed: %s", hipGetErrorString(e));
+    return WX_OK;
+}
+
+size_t wx_sw_edge_count(const wx_sw_plan* pl) { return pl ? (size_t)3 * pl->H * pl->n : 0; }
+
+wx_status wx_sw_extrap_pack(wx_sw_plan* pl, const void* q, void* const send[4], wx_stream stream) {
+    if (!pl || !q) return fail(WX_ERR_INVALID, "wx_sw_extrap_pack: null argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (pl->dtype == WX_F64) {
+        SwParams<double> P = make_sw_params<double>(pl);
+        P.q = static_cast<const double*>(q);
+        if (send) {
+            P.send_s = static_cast<double*>(send[0]); P.send_n = static_cast<double*>(send[1]);
+            P.send_w = static_cast<double*>(send[2]); P.send_e = static_cast<double*>(send[3]);
+        }
+        return sw_dispatch<double>(pl->n, true, P, st);
+    }
+    SwParams<cplx> P = make_sw_params<cplx>(pl);
+    P.q = static_cast<const cplx*>(q);
+    if (send) {
+        P.send_s = static_cast<cplx*>(send[0]); P.send_n = static_cast<cplx*>(send[1]);
+        P.send_w = static_cast<cplx*>(send[2]); P.send_e = static_cast<cplx*>(send[3]);
+    }
+    return sw_dispatch<cplx>(pl->n, true, P, st);
+}
+
+wx_status wx_sw_rhs(wx_sw_plan* pl, const void* q, const void* const halo[4], void* rhs, wx_region region,
+                    wx_stream stream) {
+    if (!pl || !q || !rhs) return fail(WX_ERR_INVALID, "wx_sw_rhs: null argument");
+    if (region != WX_REGION_ALL && region != WX_REGION_INTERIOR && region != WX_REGION_BOUNDARY)
+        return fail(WX_ERR_INVALID, "unknown region %d", (int)region);
+    if (region != WX_REGION_INTERIOR) {
+        if (!halo) return fail(WX_ERR_INVALID, "wx_sw_rhs: halo is required for this region");
+        for (int e = 0; e < 4; ++e)
+            if (!halo[e]) return fail(WX_ERR_INVALID, "wx_sw_rhs: halo[%d] is null", e);
+    }
+    const int H = pl->H, w = H > 2 ? H - 2 : 0;
+    const int count = region == WX_REGION_ALL ? H * H : (region == WX_REGION_INTERIOR ? w * w : H * H - w * w);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (pl->dtype == WX_F64) {
+        SwParams<double> P = make_sw_params<double>(pl);
+        P.q = static_cast<const double*>(q); P.rhs = static_cast<double*>(rhs);
+        P.region = region; P.count = count;
+        if (halo) {
+            P.halo_s = static_cast<const double*>(halo[0]); P.halo_n = static_cast<const double*>(halo[1]);
+            P.halo_w = static_cast<const double*>(halo[2]); P.halo_e = static_cast<const double*>(halo[3]);
+        }
+        return sw_dispatch<double>(pl->n, false, P, st);
+    }
+    SwParams<cplx> P = make_sw_params<cplx>(pl);
+    P.q = static_cast<const cplx*>(q); P.rhs = static_cast<cplx*>(rhs);
+    P.region = region; P.count = count;
+    if (halo) {
+        P.halo_s = static_cast<const cplx*>(halo[0]); P.halo_n = static_cast<const cplx*>(halo[1]);
+        P.halo_w = static_cast<const cplx*>(halo[2]); P.halo_e = static_cast<const cplx*>(halo[3]);
+    }
+    return sw_dispatch<cplx>(pl->n, false, P, st);
+}
+
+}  // extern "C"

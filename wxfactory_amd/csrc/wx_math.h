@@ -58,6 +58,7 @@ __device__ __forceinline__ double w_exp(double x) { return exp(x); }
 __device__ __forceinline__ double w_sqrt(double x) { return sqrt(x); }
 __device__ __forceinline__ double w_abs(double x) { return fabs(x); }
 __device__ __forceinline__ double w_max(double a, double b) { return (a > b || a != a) ? a : b; }
+__device__ __forceinline__ double w_min(double a, double b) { return (a < b || a != a) ? a : b; }
 __device__ __forceinline__ double w_real(double x) { return x; }
 
 __device__ __forceinline__ cplx w_log(cplx z) { return {log(hypot(z.re, z.im)), atan2(z.im, z.re)}; }
@@ -83,6 +84,10 @@ __device__ __forceinline__ cplx w_max(cplx a, cplx b) {
     // numpy.maximum on complex: a if a >= b lexicographically (or a is nan) else b
     const bool ge = (a.re > b.re) || (a.re == b.re && a.im >= b.im) || (a.re != a.re) || (a.im != a.im);
     return ge ? a : b;
+}
+__device__ __forceinline__ cplx w_min(cplx a, cplx b) {
+    const bool le = (a.re < b.re) || (a.re == b.re && a.im <= b.im) || (a.re != a.re) || (a.im != a.im);
+    return le ? a : b;
 }
 __device__ __forceinline__ double w_real(cplx z) { return z.re; }
 

@@ -1,0 +1,128 @@
+"""Shallow-water RHS on cubed-sphere panels: host-side mirror of the reference's callable.
+
+Same contract as reference wx_factory/rhs/rhs_sw.py:38-56 (`RhsShallowWater.__call__`): takes a
+state of any shape whose size matches `(3, H, H, n^2)`, returns the right-hand side in that shape
+and dtype (float64 / complex128).  One plan per cube panel; the exchange of rhs_sw.py:103-150
+(vector message + scalar message through Ineighbor_alltoall) is one 3-variable edge line per
+neighbour, rotated and flipped by the pack kernel.
+"""
+import ctypes
+from typing import Dict, Optional, Sequence
+
+import numpy
+import torch
+
+from . import _lib
+from ._lib import DfrOps, SwMetric, check
+from .exchange import PanelExchange
+
+_DTYPES = {torch.float64: _lib.WX_F64, torch.complex128: _lib.WX_C128}
+_TOPO = ("hsurf", "dzdx1", "dzdx2", "hsurf_itf_i", "hsurf_itf_j")
+
+
+class SwPlan:
+    def __init__(self, n: int, H: int, panel: int, ops: Dict[str, numpy.ndarray], metric: Dict[str, torch.Tensor],
+                 dtype: torch.dtype = torch.float64):
+        self.lib = _lib.load()
+        if dtype not in _DTYPES:
+            raise TypeError(f"dtype must be float64 or complex128, not {dtype}")
+        self.n, self.H, self.panel, self.dtype = n, H, panel, dtype
+        self.shape = (3, H, H, n * n)
+        self._keep = []
+        o = DfrOps()
+        for k in ("extrap_neg", "extrap_pos", "diff_solpt", "correction", "highfilter"):
+            a = numpy.ascontiguousarray(ops[k], dtype=numpy.float64)
+            self._keep.append(a)
+            setattr(o, k, a.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+        pts, ii, jj = (H, H, n * n), (H, H + 2, 2 * n), (H + 2, H, 2 * n)
+        expect = {k: pts for k in _lib.SW_METRIC_FIELDS}
+        for k in ("sqrtG_itf_i", "H_contra_11_itf_i", "H_contra_21_itf_i", "hsurf_itf_i"):
+            expect[k] = ii
+        for k in ("sqrtG_itf_j", "H_contra_12_itf_j", "H_contra_22_itf_j", "hsurf_itf_j"):
+            expect[k] = jj
+        expect["boundary_sn"] = expect["boundary_we"] = (H * n,)
+        self.device = metric["sqrtG"].device
+        m = SwMetric()
+        for k in _lib.SW_METRIC_FIELDS:
+            t = metric.get(k)
+            if t is None:
+                if k not in _TOPO:
+                    raise ValueError(f"metric[{k!r}] is required")
+                setattr(m, k, None)
+                continue
+            if tuple(t.shape) != expect[k] or t.dtype != torch.float64 or not t.is_contiguous() or t.device != self.device:
+                raise ValueError(f"metric[{k!r}]: need contiguous float64 {expect[k]} on {self.device}, "
+                                 f"got {t.dtype} {tuple(t.shape)} on {t.device}")
+            self._keep.append(t)
+            setattr(m, k, t.data_ptr())
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            check(self.lib.wx_sw_plan_create(ctypes.byref(self._h), n, H, _DTYPES[dtype], panel, ctypes.byref(o),
+                                             ctypes.byref(m)), "wx_sw_plan_create")
+        self.edge_count = int(self.lib.wx_sw_edge_count(self._h))
+
+    def _check_q(self, q):
+        if q.dtype != self.dtype or q.numel() != 3 * self.H * self.H * self.n**2 or not q.is_contiguous() \
+                or q.device != self.device:
+            raise ValueError(f"state must be a contiguous {self.dtype} tensor of {self.shape} on {self.device}")
+
+    def extrap_pack(self, q, send_ptrs: Optional[Sequence[int]]):
+        self._check_q(q)
+        arr = (ctypes.c_void_p * 4)(*send_ptrs) if send_ptrs is not None else None
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.wx_sw_extrap_pack(self._h, q.data_ptr(), arr, st), "wx_sw_extrap_pack")
+
+    def rhs(self, q, halo_ptrs: Optional[Sequence[int]], out, region: int = _lib.WX_REGION_ALL):
+        self._check_q(q)
+        self._check_q(out)
+        arr = (ctypes.c_void_p * 4)(*halo_ptrs) if halo_ptrs is not None else None
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.wx_sw_rhs(self._h, q.data_ptr(), arr, out.data_ptr(), region, st), "wx_sw_rhs")
+
+    def close(self):
+        if self._h:
+            self.lib.wx_sw_plan_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RhsShallowWater:
+    """R(Q) for the panels this rank owns; see RhsEuler3D for the calling convention."""
+
+    def __init__(self, plans: Dict[int, SwPlan], exchange: PanelExchange, overlap: bool = True):
+        self.plans, self.ex, self.overlap = plans, exchange, overlap
+        self.panels = sorted(plans)
+
+    def __call__(self, qs):
+        single = isinstance(qs, torch.Tensor)
+        if single:
+            if len(self.panels) != 1:
+                raise ValueError("a single tensor was given but this rank owns several panels")
+            qs = {self.panels[0]: qs}
+        shapes = {p: q.shape for p, q in qs.items()}
+        flat = {p: q.reshape(self.plans[p].shape) for p, q in qs.items()}
+        outs = {p: torch.empty_like(flat[p]) for p in self.panels}
+        ex = self.ex
+        for p in self.panels:
+            self.plans[p].extrap_pack(flat[p], ex.send_ptrs(p))
+        if ex.needs_comm and self.overlap:
+            ex.start()
+            for p in self.panels:
+                self.plans[p].rhs(flat[p], None, outs[p], _lib.WX_REGION_INTERIOR)
+            ex.wait()
+            for p in self.panels:
+                self.plans[p].rhs(flat[p], ex.halo_ptrs(p), outs[p], _lib.WX_REGION_BOUNDARY)
+        else:
+            ex.start()
+            ex.wait()
+            for p in self.panels:
+                self.plans[p].rhs(flat[p], ex.halo_ptrs(p), outs[p], _lib.WX_REGION_ALL)
+        res = {p: outs[p].reshape(shapes[p]) for p in self.panels}
+        return res[self.panels[0]] if single else res
+
+    full = __call__
