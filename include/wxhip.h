@@ -178,6 +178,36 @@ wx_status wx_sw_extrap_pack(wx_sw_plan* plan, const void* q, void* const send[4]
 wx_status wx_sw_rhs(wx_sw_plan* plan, const void* q, const void* const halo[4], void* rhs, wx_region region,
                     wx_stream stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The reference's compiled `pde` module, function for function (pde/interface.cpp:282-302,
+ * pde/interface.cu:433-442): same argument order and array layouts (C-contiguous, variable-major
+ * q[var][elem_x3][elem_x1][pt]); the dtype that pybind11 / the CUDA dispatcher derives from the
+ * array objects is an explicit argument here.  Unlike interface.cu:190-210, 328-350 an unknown
+ * dtype is an error, not a silent no-op.
+ * ------------------------------------------------------------------------------------------ */
+/* pde/kernels/pointwise_flux.hpp:3-31 via interface.cpp:11-47 */
+wx_status wx_pointwise_eulercartesian_2d(const void* q, void* flux_x1, void* flux_x3, int num_elem_x1, int num_elem_x3,
+                                         int num_solpts_tot, wx_dtype dtype, wx_stream stream);
+/* pde/kernels/riemann_flux.hpp:5-80 + boundary_flux.hpp:3-24 via interface.cpp:127-238
+ * (interface arrays (4, nz, nx, 2n); entries the reference never writes are left untouched) */
+wx_status wx_riemann_eulercartesian_ausm_2d(const void* q_itf_x1, const void* q_itf_x3, void* flux_itf_x1,
+                                            void* flux_itf_x3, int num_elem_x1, int num_elem_x3, int num_solpts,
+                                            wx_dtype dtype, wx_stream stream);
+/* pde/kernels/forcing.hpp:6-100 via interface.cpp:241-279: q (5,.), pressure, sqrt_g (unused, as in the
+ * reference), h (9,.), christoffel (27,.) -> forcing rows rho_u, rho_v, rho_w (rows rho, rho_theta untouched) */
+wx_status wx_forcing_euler_cubesphere_3d(const void* q, const void* pressure, const double* sqrt_g, const double* h,
+                                         const double* christoffel, void* forcing, int num_elem_x1, int num_elem_x2,
+                                         int num_elem_x3, int num_solpts, wx_dtype dtype, wx_stream stream);
+
+/* The whole 2-D Cartesian Euler RHS in one launch: rhs/rhs_dfr.py:8-45 (RHSDirecFluxReconstruction)
+ * with pde/pde_euler_cartesian.py:24-48: extrapolate, pointwise fluxes, derivative, AUSM + solid walls,
+ * correction, scale by -2/dx, gravity.  q, rhs: (4, nz, nx, n^2). */
+typedef struct wx_cart2d_plan wx_cart2d_plan;
+wx_status wx_cart2d_plan_create(wx_cart2d_plan** plan, int n, int num_elem_x1, int num_elem_x3, double dx1, double dx3,
+                                wx_dtype dtype, const wx_dfr_ops* ops);
+wx_status wx_cart2d_plan_destroy(wx_cart2d_plan* plan);
+wx_status wx_cart2d_rhs(wx_cart2d_plan* plan, const void* q, void* rhs, wx_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,14 @@ SIGNATURES = {
     "wx_sw_edge_count": (c_size_t, [c_void_p]),
     "wx_sw_extrap_pack": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p]),
     "wx_sw_rhs": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_int, c_void_p]),
+    "wx_pointwise_eulercartesian_2d": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "wx_riemann_eulercartesian_ausm_2d": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                                  c_void_p]),
+    "wx_forcing_euler_cubesphere_3d": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                               c_int, c_int, c_int, c_void_p]),
+    "wx_cart2d_plan_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_double, c_double, c_int, POINTER(DfrOps)]),
+    "wx_cart2d_plan_destroy": (c_int, [c_void_p]),
+    "wx_cart2d_rhs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None
