@@ -399,6 +399,66 @@ def _run6(name, work):
           f"max|R| panel0 = {numpy.abs(res[0]['R']).max(axis=tuple(range(1, res[0]['R'].ndim)))}", flush=True)
 
 
+
+# ---------------------------------------------------------------------------------------------
+# Callers of the path: SSP-RK3 step, matvec_fun / matvec_rat JVPs, Ros2 + FGMRES step
+# ---------------------------------------------------------------------------------------------
+def callers_case(name, ini, overrides, dt_rk=2.0, dt_jvp=30.0, perturb=0.01, seed=777):
+    print(f"[{name}] {ini}", flush=True)
+
+    def work(rank):
+        from device import CpuDevice
+        from process_topology import ProcessTopology
+        from geometry import CubedSphere3D, DFROperators
+        from init.init_state_vars import init_state_vars
+        from rhs.rhs_selector import RhsBundle
+        from integrators import Tvdrk3, Ros2
+        from solvers.matvec import matvec_fun, matvec_rat
+
+        cfg = _config(ini, overrides)
+        cfg.verbose_solver = 0
+        comm = MPI.COMM_WORLD
+        dev = CpuDevice(comm)
+        pt = ProcessTopology(dev, comm=comm)
+        geom = CubedSphere3D(cfg.num_elements_horizontal, cfg.num_elements_vertical, cfg.num_solpts,
+                             cfg.lambda0, cfg.phi0, cfg.alpha0, cfg.ztop, pt, cfg, dev)
+        ops = DFROperators(geom, cfg, dev)
+        Q, topo, metric = init_state_vars(geom, ops, cfg)
+        rhs = RhsBundle(geom, ops, metric, topo, pt, cfg, Q.shape, False)
+        rng = numpy.random.default_rng(seed + rank)
+        Q = Q * (1.0 + perturb * rng.uniform(-1.0, 1.0, Q.shape))
+        v = rng.uniform(-1.0, 1.0, Q.shape) * numpy.abs(Q).max(axis=(1, 2, 3, 4), keepdims=True) * 1e-3
+        out = {"Q": Q.copy(), "V": v.copy()}
+        R = rhs.full(Q)
+        out["R"] = R.copy()
+        out["jvp_complex"] = matvec_fun(v.flatten(), dt_jvp, Q, R, rhs.full, "complex").reshape(Q.shape)
+        out["jvp_fd"] = matvec_fun(v.flatten(), dt_jvp, Q, R, rhs.full, "fd").reshape(Q.shape)
+        out["rat"] = matvec_rat(v.flatten(), dt_jvp, Q, R, rhs.full).reshape(Q.shape)
+        rk = Tvdrk3(cfg, rhs.full, device=dev)
+        out["rk3"] = rk.step(Q.copy(), dt_rk).copy()
+        cfg.tolerance = 1e-9
+        cfg.gmres_restart = 30
+        cfg.linear_solver = "fgmres"
+        ros = Ros2(cfg, rhs.full, device=dev)
+        out["ros2"] = ros.step(Q.copy(), dt_jvp).copy()
+        for a in EULER_METRIC_ATTRS:
+            out["metric/" + a] = numpy.array(getattr(metric, a), copy=True)
+        out["geom/boundary_sn_new"] = numpy.array(geom.boundary_sn_new, copy=True)
+        out["geom/boundary_we_new"] = numpy.array(geom.boundary_we_new, copy=True)
+        if rank == 0:
+            out.update(_ops_1d(ops, geom))
+            out["meta/case_number"] = numpy.int64(cfg.case_number)
+            out["meta/n"] = numpy.int64(cfg.num_solpts)
+            out["meta/H"] = numpy.int64(cfg.num_elements_horizontal)
+            out["meta/V"] = numpy.int64(cfg.num_elements_vertical)
+            out["meta/dt_rk"] = numpy.float64(dt_rk)
+            out["meta/dt_jvp"] = numpy.float64(dt_jvp)
+            out["meta/eps"] = numpy.float64(numpy.sqrt(numpy.finfo(float).eps))
+        return out
+
+    _run6(name, work)
+
+
 CASES = {
     # balanced gravity-wave state, small n: all panels carry metrics + phases (exchange coverage)
     "euler3d_c31_n3_h4_v2": lambda nm: euler_case(
@@ -424,6 +484,9 @@ CASES = {
     "sw_c6_n5_h4": lambda nm: sw_case(nm, "case6.ini", dict(num_solpts=5, num_elements_horizontal=4)),
     "sw_c5_n4_h3": lambda nm: sw_case(nm, "case5.ini", dict(num_solpts=4, num_elements_horizontal=3)),
     "sw_c2p_n8_h3": lambda nm: sw_case(nm, "case2.ini", dict(num_solpts=8, num_elements_horizontal=3), perturb=0.01),
+    # callers: one SSP-RK3 step, JVPs (complex step / finite difference), Rosenbrock operator, Ros2 step
+    "callers_euler3d_n3_h3_v2": lambda nm: callers_case(
+        nm, "dcmip31.ini", dict(num_solpts=3, num_elements_horizontal=3, num_elements_vertical=2)),
     # 2-D Cartesian Euler: the plumbing reference (config/gaussian_bubble.ini, smaller grid)
     "cart2d_bubble_n5": lambda nm: cart2d_case(nm, "gaussian_bubble.ini",
                                                dict(num_solpts=5, num_elements_horizontal=7, num_elements_vertical=9)),

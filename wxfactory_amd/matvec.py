@@ -1,0 +1,56 @@
+"""Matrix-free Jacobian-vector products through the RHS kernels.
+
+Mirrors reference wx_factory/solvers/matvec.py:36-88: same names, argument order, epsilons and
+formulas; states are torch tensors on the GPU (any of the structures PanelRhs accepts, flattened
+results like the reference's `.flatten()`).
+  matvec_fun(..., method="complex")  dt * Im R(Q + i eps v) / eps,  eps = sqrt(eps_f64)   (:56-61)
+  matvec_fun(..., method="fd")       dt * (R(Q + eps v) - R(Q)) / eps, eps = sqrt(eps_f32) (:62-66)
+  matvec_rat                         v - 1/2 dt (R(Q + eps v) - R(Q)) / eps               (:76-88)
+"""
+import math
+from typing import Callable
+
+import torch
+
+EPS_COMPLEX = math.sqrt(torch.finfo(torch.float64).eps)
+EPS_FD = math.sqrt(torch.finfo(torch.float32).eps)
+
+
+def matvec_fun(vec: torch.Tensor, dt: float, Q: torch.Tensor, rhs: torch.Tensor, rhs_handle: Callable,
+               method: str = "complex") -> torch.Tensor:
+    if method == "complex":
+        Qvec = torch.complex(Q, EPS_COMPLEX * vec.reshape(Q.shape))
+        jac = dt * (rhs_handle(Qvec).imag / EPS_COMPLEX)
+    else:
+        Qvec = Q + EPS_FD * vec.reshape(Q.shape)
+        jac = dt * (rhs_handle(Qvec) - rhs) / EPS_FD
+    return jac.flatten()
+
+
+def matvec_rat(vec: torch.Tensor, dt: float, Q: torch.Tensor, rhs: torch.Tensor, rhs_handle: Callable) -> torch.Tensor:
+    Qvec = Q + EPS_FD * vec.reshape(Q.shape)
+    jac = dt * (rhs_handle(Qvec) - rhs) / EPS_FD
+    return vec.flatten() - 0.5 * jac.flatten()
+
+
+class MatvecOp:
+    """solvers/matvec.py:7-28"""
+
+    def __init__(self, matvec: Callable, dtype, shape):
+        self.matvec, self.dtype, self.shape = matvec, dtype, tuple(shape)
+        self.size = math.prod(self.shape)
+
+    def __call__(self, vec):
+        return self.matvec(vec)
+
+
+class MatvecOpRat(MatvecOp):
+    """solvers/matvec.py:71-73"""
+
+    def __init__(self, dt, Q, rhs_vec, rhs_handle):
+        super().__init__(lambda vec: matvec_rat(vec, dt, Q, rhs_vec, rhs_handle), Q.dtype, Q.shape)
+
+
+class MatvecOpBasic(MatvecOp):
+    def __init__(self, dt, Q, rhs_vec, rhs_handle, method="complex"):
+        super().__init__(lambda vec: matvec_fun(vec, dt, Q, rhs_vec, rhs_handle, method), Q.dtype, Q.shape)

@@ -1,0 +1,102 @@
+"""Shared driver of a cubed-sphere RHS evaluation over the panels one rank owns.
+
+Phase ordering of the reference's RHS template (rhs/rhs.py:88-118) in terms of the two HIP
+kernels per panel: extrapolate+pack -> start exchange -> interior elements -> wait -> tile-edge
+elements.  Accepts float64 and complex128 states (the complex twin of every plan and of the exchange
+buffers is created on first use: matvec_fun's complex step, solvers/matvec.py:56-61).
+"""
+from typing import Dict
+
+import torch
+
+from . import _lib
+from .exchange import PanelExchange
+
+
+class PanelRhs:
+    def __init__(self, plans: Dict[int, object], exchange: PanelExchange = None, overlap: bool = True,
+                 rank: int = 0, world_size: int = 1, group=None):
+        self.panels = sorted(plans)
+        self.overlap = overlap
+        self.rank, self.world, self.group = rank, world_size, group
+        first = plans[self.panels[0]] if self.panels else None
+        self.device = first.device if first is not None else None
+        self._plans = {first.dtype if first is not None else torch.float64: plans}
+        self._ex = {}
+        if exchange is not None:
+            self._ex[first.dtype if first is not None else torch.float64] = exchange
+            self.rank, self.world, self.group = exchange.rank, exchange.world, exchange.group
+        self.edge_count = first.edge_count if first is not None else 0
+        self.panel_shape = first.shape if first is not None else None
+
+    # -- per-dtype resources
+    def plans_for(self, dtype):
+        if dtype not in self._plans:
+            base = next(iter(self._plans.values()))
+            self._plans[dtype] = {p: pl.twin(dtype) for p, pl in base.items()}
+        return self._plans[dtype]
+
+    def exchange_for(self, dtype):
+        if dtype not in self._ex:
+            words = self.edge_count * (2 if dtype.is_complex else 1)
+            dev = self.device if self.device is not None else "cpu"
+            self._ex[dtype] = PanelExchange(words, dev, rank=self.rank, world_size=self.world, group=self.group)
+        return self._ex[dtype]
+
+    @property
+    def plans(self):
+        return next(iter(self._plans.values()))
+
+    @property
+    def ex(self):
+        return self.exchange_for(next(iter(self._plans)))
+
+    # -- the evaluation
+    def __call__(self, qs):
+        np_ = len(self.panels)
+        kind = "dict"
+        if isinstance(qs, torch.Tensor):
+            per = 1
+            for s in self.panel_shape:
+                per *= s
+            if qs.numel() == per and np_ == 1:
+                kind, shape = "single", qs.shape
+                qs = {self.panels[0]: qs}
+            elif qs.numel() == per * np_:
+                kind, shape = "stacked", qs.shape
+                flat = qs.reshape((np_,) + tuple(self.panel_shape))
+                qs = {p: flat[i] for i, p in enumerate(self.panels)}
+            else:
+                raise ValueError(f"state of {qs.numel()} values does not match {np_} panel(s) of {self.panel_shape}")
+        if not self.panels:
+            return qs
+        dtype = next(iter(qs.values())).dtype
+        plans, ex = self.plans_for(dtype), self.exchange_for(dtype)
+        shapes = {p: q.shape for p, q in qs.items()}
+        flat = {p: q.reshape(self.panel_shape) for p, q in qs.items()}
+        if kind == "stacked":
+            out_all = torch.empty((np_,) + tuple(self.panel_shape), dtype=dtype, device=self.device)
+            outs = {p: out_all[i] for i, p in enumerate(self.panels)}
+        else:
+            outs = {p: torch.empty_like(flat[p]) for p in self.panels}
+        for p in self.panels:
+            plans[p].extrap_pack(flat[p], ex.send_ptrs(p))
+        if ex.needs_comm and self.overlap:
+            ex.start()
+            for p in self.panels:
+                plans[p].rhs(flat[p], None, outs[p], _lib.WX_REGION_INTERIOR)
+            ex.wait()
+            for p in self.panels:
+                plans[p].rhs(flat[p], ex.halo_ptrs(p), outs[p], _lib.WX_REGION_BOUNDARY)
+        else:
+            ex.start()
+            ex.wait()
+            for p in self.panels:
+                plans[p].rhs(flat[p], ex.halo_ptrs(p), outs[p], _lib.WX_REGION_ALL)
+        if kind == "stacked":
+            return out_all.reshape(shape)
+        if kind == "single":
+            return outs[self.panels[0]].reshape(shape)
+        return {p: outs[p].reshape(shapes[p]) for p in self.panels}
+
+    full = __call__

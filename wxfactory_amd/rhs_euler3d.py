@@ -14,7 +14,8 @@ import torch
 
 from . import _lib
 from ._lib import DfrOps, Euler3DMetric, check
-from .exchange import PanelExchange
+from .exchange import PanelExchange  # noqa: F401
+from .panel_rhs import PanelRhs
 
 _DTYPES = {torch.float64: _lib.WX_F64, torch.complex128: _lib.WX_C128}
 
@@ -34,6 +35,7 @@ class Euler3DPlan:
             raise TypeError(f"dtype must be float64 or complex128, not {dtype}")
         self.n, self.H, self.V, self.case_number, self.panel, self.dtype = n, H, V, case_number, panel, dtype
         self.shape = (5, V, H, H, n**3)
+        self._ops, self._metric = ops, metric
         self._keep = []
         o = DfrOps()
         for k in ("extrap_neg", "extrap_pos", "diff_solpt", "correction", "highfilter"):
@@ -68,6 +70,10 @@ class Euler3DPlan:
                                                   ctypes.byref(o), ctypes.byref(m)), "wx_euler3d_plan_create")
         self.edge_count = int(self.lib.wx_euler3d_edge_count(self._h))
 
+    def twin(self, dtype):
+        """Plan of another dtype over the same (borrowed) metric tensors."""
+        return Euler3DPlan(self.n, self.H, self.V, self.case_number, self.panel, self._ops, self._metric, dtype=dtype)
+
     def _check_q(self, q):
         if q.dtype != self.dtype or q.numel() != 5 * self.V * self.H * self.H * self.n**3 or not q.is_contiguous() \
                 or q.device != self.device:
@@ -98,47 +104,9 @@ class Euler3DPlan:
             pass
 
 
-class RhsEuler3D:
+class RhsEuler3D(PanelRhs):
     """R(Q) for the panels this rank owns (all six on one GPU, or one per GPU on six).
 
-    `plans` : {panel: Euler3DPlan}; `exchange` : PanelExchange built for the same ownership.
-    Call with {panel: Q} (or a single tensor when the rank owns one panel); returns the same
-    structure of freshly allocated R tensors, shaped like the inputs."""
-
-    def __init__(self, plans: Dict[int, Euler3DPlan], exchange: PanelExchange, overlap: bool = True):
-        self.plans = plans
-        self.ex = exchange
-        self.overlap = overlap
-        self.panels = sorted(plans)
-        any_plan = next(iter(plans.values())) if plans else None
-        self.device = any_plan.device if any_plan else None
-        self.timestamps = None
-
-    def __call__(self, qs):
-        single = isinstance(qs, torch.Tensor)
-        if single:
-            if len(self.panels) != 1:
-                raise ValueError("a single tensor was given but this rank owns several panels")
-            qs = {self.panels[0]: qs}
-        shapes = {p: q.shape for p, q in qs.items()}
-        flat = {p: q.reshape(self.plans[p].shape) for p, q in qs.items()}
-        outs = {p: torch.empty_like(flat[p]) for p in self.panels}
-        ex = self.ex
-        for p in self.panels:
-            self.plans[p].extrap_pack(flat[p], ex.send_ptrs(p))
-        if ex.needs_comm and self.overlap:
-            ex.start()
-            for p in self.panels:
-                self.plans[p].rhs(flat[p], None, outs[p], _lib.WX_REGION_INTERIOR)
-            ex.wait()
-            for p in self.panels:
-                self.plans[p].rhs(flat[p], ex.halo_ptrs(p), outs[p], _lib.WX_REGION_BOUNDARY)
-        else:
-            ex.start()
-            ex.wait()
-            for p in self.panels:
-                self.plans[p].rhs(flat[p], ex.halo_ptrs(p), outs[p], _lib.WX_REGION_ALL)
-        res = {p: outs[p].reshape(shapes[p]) for p in self.panels}
-        return res[self.panels[0]] if single else res
-
-    full = __call__
+    `plans` : {panel: Euler3DPlan}.  Call with {panel: Q}, with a single tensor when the rank owns
+    one panel, or with the panels stacked along a leading axis; returns the same structure of
+    freshly allocated R, shaped like the input (the contract of rhs/rhs.py:75-122)."""

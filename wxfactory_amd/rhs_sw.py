@@ -14,7 +14,8 @@ import torch
 
 from . import _lib
 from ._lib import DfrOps, SwMetric, check
-from .exchange import PanelExchange
+from .exchange import PanelExchange  # noqa: F401
+from .panel_rhs import PanelRhs
 
 _DTYPES = {torch.float64: _lib.WX_F64, torch.complex128: _lib.WX_C128}
 _TOPO = ("hsurf", "dzdx1", "dzdx2", "hsurf_itf_i", "hsurf_itf_j")
@@ -28,6 +29,7 @@ class SwPlan:
             raise TypeError(f"dtype must be float64 or complex128, not {dtype}")
         self.n, self.H, self.panel, self.dtype = n, H, panel, dtype
         self.shape = (3, H, H, n * n)
+        self._ops, self._metric = ops, metric
         self._keep = []
         o = DfrOps()
         for k in ("extrap_neg", "extrap_pos", "diff_solpt", "correction", "highfilter"):
@@ -61,6 +63,9 @@ class SwPlan:
                                              ctypes.byref(m)), "wx_sw_plan_create")
         self.edge_count = int(self.lib.wx_sw_edge_count(self._h))
 
+    def twin(self, dtype):
+        return SwPlan(self.n, self.H, self.panel, self._ops, self._metric, dtype=dtype)
+
     def _check_q(self, q):
         if q.dtype != self.dtype or q.numel() != 3 * self.H * self.H * self.n**2 or not q.is_contiguous() \
                 or q.device != self.device:
@@ -91,38 +96,6 @@ class SwPlan:
             pass
 
 
-class RhsShallowWater:
-    """R(Q) for the panels this rank owns; see RhsEuler3D for the calling convention."""
-
-    def __init__(self, plans: Dict[int, SwPlan], exchange: PanelExchange, overlap: bool = True):
-        self.plans, self.ex, self.overlap = plans, exchange, overlap
-        self.panels = sorted(plans)
-
-    def __call__(self, qs):
-        single = isinstance(qs, torch.Tensor)
-        if single:
-            if len(self.panels) != 1:
-                raise ValueError("a single tensor was given but this rank owns several panels")
-            qs = {self.panels[0]: qs}
-        shapes = {p: q.shape for p, q in qs.items()}
-        flat = {p: q.reshape(self.plans[p].shape) for p, q in qs.items()}
-        outs = {p: torch.empty_like(flat[p]) for p in self.panels}
-        ex = self.ex
-        for p in self.panels:
-            self.plans[p].extrap_pack(flat[p], ex.send_ptrs(p))
-        if ex.needs_comm and self.overlap:
-            ex.start()
-            for p in self.panels:
-                self.plans[p].rhs(flat[p], None, outs[p], _lib.WX_REGION_INTERIOR)
-            ex.wait()
-            for p in self.panels:
-                self.plans[p].rhs(flat[p], ex.halo_ptrs(p), outs[p], _lib.WX_REGION_BOUNDARY)
-        else:
-            ex.start()
-            ex.wait()
-            for p in self.panels:
-                self.plans[p].rhs(flat[p], ex.halo_ptrs(p), outs[p], _lib.WX_REGION_ALL)
-        res = {p: outs[p].reshape(shapes[p]) for p in self.panels}
-        return res[self.panels[0]] if single else res
-
-    full = __call__
+class RhsShallowWater(PanelRhs):
+    """R(Q) for the panels this rank owns; same calling convention as RhsEuler3D
+    (contract of rhs/rhs_sw.py:38-56)."""
