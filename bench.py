@@ -62,6 +62,33 @@ def cpu_baseline(n, V, sample_H, reps, seed):
     return dof / dt, dt
 
 
+def extras(dev, seed):
+    """Secondary, non-headline numbers on the same GPU: the shallow-water S7 workload of BASELINE.json's
+    galewsky line (n=8, 60x60 elements/panel, 6 panels), whole-sphere R(Q)."""
+    from wxfactory_amd import synthetic
+    from wxfactory_amd.rhs_sw import RhsShallowWater, SwPlan
+
+    n, H = 8, 60
+    ops = synthetic.dfr_ops(n)
+    plans = {p: SwPlan(n, H, p, ops, synthetic.sw_metric(n, H, p, dev, seed)) for p in range(6)}
+    Q = torch.stack([synthetic.sw_state(n, H, p, dev, seed) for p in range(6)])
+    rhs = RhsShallowWater(plans)
+    for _ in range(5):
+        rhs(Q)
+    torch.cuda.synchronize()
+    reps = 100
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        rhs(Q)
+    torch.cuda.synchronize()
+    te = (time.perf_counter() - t0) / reps
+    dof = 3 * 6 * H * H * n * n
+    return {"sw_s7": {"workload": "shallow water, n=8, H=60, 6 panels on 1 GPU (1244160 DOF), whole-sphere R(Q)",
+                      "us_per_eval": te * 1e6, "dof_updates_per_s": dof / te,
+                      "algorithmic_GBps": 156.0 * 6 * H * H * n * n / te / 1e9,
+                      "note": "12 launches of ~9 us: launch-latency bound (5.5 MB of state per panel)"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,6 +100,7 @@ def main():
     ap.add_argument("--seed", type=int, default=20250824)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary (shallow-water S7) measurement")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -190,6 +218,8 @@ def main():
                        "overlap": not args.no_overlap},
             "roofline": roof,
         }
+        if args.gpus == 1 and not args.no_extras:
+            line["extra"] = extras(dev, args.seed)
         if args.gpus == 1 and not args.no_cpu_baseline:
             sample_H = 30
             v, secs = cpu_baseline(n, V, sample_H, reps=3, seed=args.seed)

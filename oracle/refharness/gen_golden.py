@@ -441,6 +441,20 @@ def callers_case(name, ini, overrides, dt_rk=2.0, dt_jvp=30.0, perturb=0.01, see
         cfg.linear_solver = "fgmres"
         ros = Ros2(cfg, rhs.full, device=dev)
         out["ros2"] = ros.step(Q.copy(), dt_jvp).copy()
+        # EPI2 + KIOPS with the complex-step JVP (config/dcmip31.ini's own integrator)
+        from integrators import Epi
+        from solvers.kiops import kiops
+        cfg.tolerance = 1e-7
+        cfg.exponential_solver = "kiops"
+        cfg.jacobian_method = "complex"
+        epi = Epi(cfg, 2, rhs.full, device=dev)
+        out["epi2"] = epi.step(Q.copy(), dt_jvp).copy()
+        vec = numpy.zeros((2, R.size))
+        vec[1, :] = R.flatten()
+        phiv, stats = kiops([1], lambda x: matvec_fun(x, dt_jvp, Q, R, rhs.full, "complex"), vec, tol=1e-7,
+                            m_init=1, mmin=16, mmax=64, task1=False, device=dev)
+        out["kiops_phiv"] = numpy.asarray(phiv).reshape(Q.shape)
+        out["kiops_stats"] = numpy.array([float(x) for x in stats])
         for a in EULER_METRIC_ATTRS:
             out["metric/" + a] = numpy.array(getattr(metric, a), copy=True)
         out["geom/boundary_sn_new"] = numpy.array(geom.boundary_sn_new, copy=True)

@@ -76,3 +76,28 @@ def test_ros2_fgmres_step(setup):
     upd = np.abs(ref - q0).max(axis=ax)
     err = np.abs(Qn.cpu().numpy() - ref).max(axis=ax)
     assert (err <= 2e-4 * upd + 1e-12 * np.abs(ref).max(axis=ax)).all(), (err / upd)
+
+
+def test_kiops_and_epi2_step(setup):
+    """phi_1(dt J) R through KIOPS with the complex-step JVP, and the EPI2 step built on it
+    (the integrator config/dcmip31.ini actually ships with), against the reference's kiops.py/epi.py."""
+    from wxfactory_amd.integrators import Epi
+    from wxfactory_amd.matvec import matvec_fun
+    from wxfactory_amd.solvers import kiops
+
+    g, rhs, stack = setup
+    Q, R = stack("Q"), stack("R")
+    dt = float(g["meta/dt_jvp"])
+    vec = torch.zeros((2, R.numel()), dtype=torch.float64, device=DEV)
+    vec[1] = R.flatten()
+    phiv, stats = kiops([1], lambda v: matvec_fun(v, dt, Q, R, rhs, "complex"), vec, tol=1e-7, m_init=1, mmin=16, mmax=64)
+    ref_stats = g["p0/kiops_stats"]
+    assert stats[0] == int(ref_stats[0]) and abs(stats[2] - int(ref_stats[2])) <= 6, (stats, ref_stats)
+    ref = stack("kiops_phiv").cpu().numpy()
+    ax = (0, 2, 3, 4, 5)
+    err = np.abs(phiv.cpu().numpy().reshape(ref.shape) - ref).max(axis=ax) / np.abs(ref).max(axis=ax)
+    assert (err < 1e-5).all(), err  # both sides converge to tol=1e-7 of the same phi_1(dt J) R
+    Qn = Epi(2, rhs, tol=1e-7).step(Q, dt)
+    refq, q0 = stack("epi2").cpu().numpy(), Q.cpu().numpy()
+    upd = np.abs(refq - q0).max(axis=ax)
+    assert (np.abs(Qn.cpu().numpy() - refq).max(axis=ax) <= 1e-5 * upd).all()

@@ -46,3 +46,74 @@ class Ros2:
                                 rel_residual=norm_r / norm_b)
         self.failure_flag = flag
         return Qnew.reshape(Q.shape)
+
+
+class Epi:
+    """Exponential propagation iterative methods, orders 2-6 (integrators/epi.py:28-360), with the
+    phi-function evaluation by KIOPS (solvers/kiops.py) and the JVP by the RHS kernels
+    (matvec_fun: complex step by default, `jacobian_method` of config-format.json)."""
+
+    _A = {
+        2: [[]],
+        3: [[2 / 3]],
+        4: [[-3 / 10, 3 / 40], [32 / 5, -11 / 10]],
+        5: [[-4 / 5, 2 / 5, -4 / 45], [12, -9 / 2, 8 / 9], [3, 0, -1 / 3]],
+        6: [[-49 / 60, 351 / 560, -359 / 1260, 367 / 6720], [92 / 7, -99 / 14, 176 / 63, -1 / 2],
+            [485 / 21, -151 / 14, 23 / 9, -31 / 168]],
+    }
+
+    def __init__(self, order: int, rhs: Callable, tol: float = 1e-7, jacobian_method: str = "complex",
+                 init_substeps: int = 1, init_method=None):
+        from collections import deque
+
+        if order not in self._A:
+            raise ValueError(f"Unsupported order {order} for EPI method")
+        self.rhs, self.tol, self.jacobian_method = rhs, tol, jacobian_method
+        self.A = self._A[order]
+        k = len(self.A)
+        self.n_prev = len(self.A[0])
+        if order == 2:
+            k -= 1
+        self.max_phi = k + 1
+        self.krylov_size = 1
+        self.previous_Q, self.previous_rhs = deque(), deque()
+        self.dt = 0.0
+        self.init_method = init_method if (init_method or self.n_prev == 0) else Epi(2, rhs, tol, jacobian_method)
+        self.init_substeps = init_substeps
+        self.solver_info = None
+
+    def step(self, Q: torch.Tensor, dt: float) -> torch.Tensor:
+        import math
+
+        from .matvec import matvec_fun
+        from .solvers import kiops
+
+        if self.dt and abs(self.dt - dt) > 1e-10:
+            self.previous_Q.clear()
+            self.previous_rhs.clear()
+        self.dt = dt
+        if len(self.previous_Q) < self.n_prev:
+            self.previous_Q.appendleft(Q)
+            self.previous_rhs.appendleft(self.rhs(Q))
+            for _ in range(self.init_substeps):
+                Q = self.init_method.step(Q, dt / self.init_substeps)
+            return Q
+        rhs = self.rhs(Q)
+        vec = torch.zeros((self.max_phi + 1, rhs.numel()), dtype=Q.dtype, device=Q.device)
+        vec[1] = rhs.flatten()
+        for i in range(self.n_prev):
+            JdQ = matvec_fun((self.previous_Q[i] - Q).flatten(), 1.0, Q, rhs, self.rhs, self.jacobian_method)
+            r = (self.previous_rhs[i] - rhs).flatten() - JdQ
+            for k, row in enumerate(self.A, start=2):
+                vec[k] += row[i] * r
+        phiv, stats = kiops([1], lambda v: matvec_fun(v, dt, Q, rhs, self.rhs, self.jacobian_method), vec,
+                            tol=self.tol, m_init=self.krylov_size, mmin=16, mmax=64, task1=False)
+        self.krylov_size = math.floor(0.7 * stats[5] + 0.3 * self.krylov_size)
+        self.solver_info = dict(substeps=stats[0], rejected=stats[1], iterations=stats[2], exps=stats[3],
+                                error=stats[4], krylov_size=stats[5])
+        if self.n_prev > 0:
+            self.previous_Q.pop()
+            self.previous_Q.appendleft(Q)
+            self.previous_rhs.pop()
+            self.previous_rhs.appendleft(rhs)
+        return Q + phiv.reshape(Q.shape) * dt

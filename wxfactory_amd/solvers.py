@@ -134,3 +134,161 @@ def fgmres(A: Callable, b: torch.Tensor, x0: Optional[torch.Tensor] = None, tol:
         if norm_r < tol_abs:
             return x, norm_r, norm_b, niter, 0, residuals
     return x, norm_r, norm_b, niter, (0 if norm_r < tol_abs else -1), residuals
+
+
+def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int = 10, mmin: int = 10, mmax: int = 128,
+          iop: int = 2, task1: bool = False, group=None):
+    """w(i) = sum_k phi_k(tau_i A) u[k]  by the adaptive Krylov method with incomplete orthogonalisation.
+
+    Same signature, adaptivity rules and `stats` tuple as reference wx_factory/solvers/kiops.py:10-347
+    (KIOPS: Gaudreault, Rainwater, Tokman, J. Comput. Phys. 2018; after phipm, Niesen & Wright 2012).
+    Layout here: the n-long parts of the Krylov basis live on the GPU (`Vd`), the p augmented
+    components and the Hessenberg matrix on the host; each Krylov vector costs one matvec (= one
+    RHS evaluation through `A`), two fused reductions (iop dot products, norm) and no other sync;
+    the (m+1)x(m+1) matrix exponential runs on the host (scipy), as in the reference.
+    Returns (w, (steps, rejected, krylov_steps, exps, error_estimate, last_m)).
+    """
+    import numpy as np
+    from scipy.linalg import expm
+
+    dev, dtype = u.device, u.dtype
+    tau_out = [float(t) for t in tau_out]
+    ppo, n = u.shape
+    p = ppo - 1
+    if p == 0:
+        p = 1
+        u = torch.cat((u, torch.zeros((1, n), dtype=dtype, device=dev)))
+    m = max(mmin, min(m_init, mmax))
+    Vd = torch.zeros((mmax + 1, n), dtype=dtype, device=dev)
+    Va = np.zeros((mmax + 1, p))
+    H = np.zeros((mmax + 1, mmax + 1))
+    step = krystep = ireject = reject = exps = 0
+    sgn = math.copysign(1.0, tau_out[-1])
+    tau_now, tau_end = 0.0, abs(tau_out[-1])
+    happy = False
+    j = 0
+    conv = 0.0
+    num_steps = len(tau_out)
+    w = torch.zeros((num_steps, n), dtype=dtype, device=dev)
+    w[0] = u[0]
+    normU = float(_allreduce(u[1:].abs().sum(dim=1), group).max()) if ppo > 1 else 0.0
+    if ppo > 1 and normU > 0:
+        ex = math.ceil(math.log2(normU))
+        nu, mu = 2.0 ** (-ex), 2.0 ** ex
+    else:
+        nu = mu = 1.0
+    u_flip = nu * torch.flipud(u[1:])
+    tau = tau_end
+    gamma, gamma_mmax = (0.2, 0.1) if tau_end > 1 else (0.9, 0.6)
+    delta = 1.4
+    oldm, oldtau, omega = -1, math.nan, math.nan
+    orderold = kestold = True
+    order, kest = 1.0, 2.0
+    l = 0
+    beta = 1.0
+    while tau_now < tau_end:
+        if j == 0:
+            Vd[0] = w[l]
+            Va[0, :] = 0.0
+            for k in range(p - 1):
+                i = p - k + 1
+                Va[0, k] = (tau_now ** i) / math.factorial(i) * mu
+            Va[0, p - 1] = mu
+            beta = math.sqrt(float(global_dotprod(Vd[0], Vd[0], group)) + float(Va[0] @ Va[0]))
+            Vd[0] /= beta
+            Va[0] /= beta
+        while j < m:
+            j += 1
+            Vd[j] = A(Vd[j - 1]) + torch.as_tensor(Va[j - 1], dtype=dtype, device=dev) @ u_flip
+            Va[j, : p - 1] = Va[j - 1, 1:p]
+            Va[j, p - 1] = 0.0
+            ilow = max(0, j - iop)
+            hcol = _allreduce(Vd[ilow:j] @ Vd[j], group).cpu().numpy() + Va[ilow:j] @ Va[j]
+            H[ilow:j, j - 1] = hcol
+            Vd[j] -= torch.as_tensor(hcol, dtype=dtype, device=dev) @ Vd[ilow:j]
+            Va[j] -= hcol @ Va[ilow:j]
+            nrm = math.sqrt(float(global_dotprod(Vd[j], Vd[j], group)) + float(Va[j] @ Va[j]))
+            if nrm < tol:
+                happy = True
+                break
+            H[j, j - 1] = nrm
+            Vd[j] /= nrm
+            Va[j] /= nrm
+            krystep += 1
+        H[0, j] = 1.0
+        nrm = H[j, j - 1]
+        H[j, j - 1] = 0.0
+        F = expm(sgn * tau * H[: j + 1, : j + 1])
+        exps += 1
+        H[j, j - 1] = nrm
+        if happy:
+            omega = 0.0
+            err = 0.0
+            tau_new = min(tau_end - (tau_now + tau), tau)
+            m_new = m
+            happy = False
+        else:
+            err = abs(beta * nrm * F[j - 1, j])
+            oldomega = omega
+            omega = tau_end * err / (tau * tol)
+            if m == oldm and tau != oldtau and ireject >= 1:
+                order = max(1.0, math.log(omega / oldomega) / math.log(tau / oldtau))
+                orderold = False
+            elif orderold or ireject == 0:
+                orderold = True
+                order = j / 4
+            else:
+                orderold = True
+            if m != oldm and tau == oldtau and ireject >= 1:
+                kest = max(1.1, (omega / oldomega) ** (1 / (oldm - m)))
+                kestold = False
+            elif kestold or ireject == 0:
+                kestold = True
+                kest = 2
+            else:
+                kestold = True
+            remaining = tau_end - tau_now if omega > delta else tau_end - (tau_now + tau)
+            same_tau = min(remaining, tau)
+            tau_opt = tau * (gamma / omega) ** (1 / order)
+            tau_opt = min(remaining, max(tau / 5, min(5 * tau, tau_opt)))
+            m_opt = math.ceil(j + math.log(omega / gamma) / math.log(kest))
+            m_opt = max(mmin, min(mmax, max(math.floor(3 / 4 * m), min(m_opt, math.ceil(4 / 3 * m)))))
+            if j == mmax:
+                if omega > delta:
+                    m_new = j
+                    tau_new = tau * (gamma_mmax / omega) ** (1 / order)
+                    tau_new = min(tau_end - tau_now, max(tau / 5, tau_new))
+                else:
+                    tau_new = tau_opt
+                    m_new = m
+            else:
+                m_new = m_opt
+                tau_new = same_tau
+        if omega <= delta:
+            reject += ireject
+            step += 1
+            blown = 0
+            next_t = tau_now + tau
+            for k in range(l, num_steps):
+                if abs(tau_out[k]) < abs(next_t):
+                    blown += 1
+            if blown != 0:
+                w[l + blown] = w[l]
+                for k in range(blown):
+                    F2 = expm(sgn * (tau_out[l + k] - tau_now) * H[:j, :j])
+                    w[l + k] = torch.as_tensor(beta * F2[:j, 0], dtype=dtype, device=dev) @ Vd[:j]
+                l += blown
+            w[l] = torch.as_tensor(beta * F[:j, 0], dtype=dtype, device=dev) @ Vd[:j]
+            tau_now += tau
+            j = 0
+            ireject = 0
+            conv += err
+        else:
+            ireject += 1
+            H[0, j] = 0.0
+        oldtau, tau = tau, tau_new
+        oldm, m = m, int(m_new)
+    if task1:
+        for k in range(num_steps):
+            w[k] /= tau_out[k]
+    return w, (step, reject, krystep, exps, conv, m)

@@ -105,6 +105,67 @@ def euler3d_state(n: int, H: int, V: int, panel: int, device, seed: int = 202508
     return q
 
 
+def _pad_itf2(face: torch.Tensor, axis: int, n: int) -> torch.Tensor:
+    """2-D twin of _pad_itf; the shallow-water interface metric keeps its values in the outermost
+    slots too (geometry/metric2d.py), harmless either way."""
+    E = face.shape[axis] - 1
+    shape = list(face.shape)
+    shape[axis] = E + 2
+    shape[-1] = 2 * n
+    out = torch.zeros(shape, dtype=face.dtype, device=face.device)
+    im = [slice(None)] * face.ndim
+    ip = [slice(None)] * face.ndim
+    im[axis], im[-1] = slice(1, None), slice(0, n)
+    ip[axis], ip[-1] = slice(0, E + 1), slice(n, None)
+    out[tuple(im)] = face
+    out[tuple(ip)] = face
+    return out
+
+
+def sw_metric(n: int, H: int, panel: int, device, seed: int = 20250824, topo: bool = False) -> Dict[str, torch.Tensor]:
+    """S7-style synthetic shallow-water metric: sqrtG ~ 1e9, H_contra ~ 4e-10 SPD,
+    Christoffel ~ 1e-2 xi."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed + 1000 * panel + 11)
+    pts = (H, H, n * n)
+    m = {"sqrtG": 1e9 * (1.0 + 0.1 * _u(pts, gen, device))}
+    m["H_contra_11"] = 4e-10 * (1.0 + 0.1 * _u(pts, gen, device))
+    m["H_contra_22"] = 4e-10 * (1.0 + 0.1 * _u(pts, gen, device))
+    m["H_contra_12"] = 1e-11 * _u(pts, gen, device)
+    m["H_contra_21"] = m["H_contra_12"].clone()
+    for k in ("1_01", "1_02", "1_11", "1_12", "2_01", "2_02", "2_12", "2_22"):
+        m["christoffel_" + k] = 1e-2 * _u(pts, gen, device)
+    fi, fj = (H, H + 1, n), (H + 1, H, n)
+    m["sqrtG_itf_i"] = _pad_itf2(1e9 * (1.0 + 0.1 * _u(fi, gen, device)), 1, n).contiguous()
+    m["sqrtG_itf_j"] = _pad_itf2(1e9 * (1.0 + 0.1 * _u(fj, gen, device)), 0, n).contiguous()
+    m["H_contra_11_itf_i"] = _pad_itf2(4e-10 * (1.0 + 0.1 * _u(fi, gen, device)), 1, n).contiguous()
+    m["H_contra_21_itf_i"] = _pad_itf2(1e-11 * _u(fi, gen, device), 1, n).contiguous()
+    m["H_contra_22_itf_j"] = _pad_itf2(4e-10 * (1.0 + 0.1 * _u(fj, gen, device)), 0, n).contiguous()
+    m["H_contra_12_itf_j"] = _pad_itf2(1e-11 * _u(fj, gen, device), 0, n).contiguous()
+    x = (torch.arange(H * n, dtype=torch.float64, device=device) + 0.5) / (H * n) * (math.pi / 2) - math.pi / 4
+    m["boundary_sn"] = torch.tan(x).contiguous()
+    m["boundary_we"] = torch.tan(x).contiguous()
+    if topo:
+        m["hsurf"] = 500.0 * (1.0 + _u(pts, gen, device))
+        m["dzdx1"] = 1e2 * _u(pts, gen, device)
+        m["dzdx2"] = 1e2 * _u(pts, gen, device)
+        m["hsurf_itf_i"] = _pad_itf2(500.0 * (1.0 + _u(fi, gen, device)), 1, n).contiguous()
+        m["hsurf_itf_j"] = _pad_itf2(500.0 * (1.0 + _u(fj, gen, device)), 0, n).contiguous()
+    return m
+
+
+def sw_state(n: int, H: int, panel: int, device, seed: int = 20250824) -> torch.Tensor:
+    """h = 8000 (1 + 0.05 xi), hu^i = h 1e-6 (30 + 10 xi)   """
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed + 1000 * panel + 12)
+    pts = (H, H, n * n)
+    q = torch.empty((3,) + pts, dtype=torch.float64, device=device)
+    q[0] = 8000.0 * (1.0 + 0.05 * _u(pts, gen, device))
+    q[1] = q[0] * 1e-6 * (30.0 + 10.0 * _u(pts, gen, device))
+    q[2] = q[0] * 1e-6 * (30.0 + 10.0 * _u(pts, gen, device))
+    return q
+
+
 def dfr_ops(n: int):
     """1-D DFR operator pieces on Gauss-Legendre points, computed from their definitions
     (reference geometry/operators.py:55-80, 86-99, 144-148 builds the same objects with sympy):
