@@ -62,6 +62,20 @@ def cpu_baseline(n, V, sample_H, reps, seed):
     return dof / dt, dt
 
 
+def pmc_traffic(region, n, H, V):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_summary.json: separate FETCH_SIZE / WRITE_SIZE runs of tools/kbench.py on one E7 panel,
+    gfx950 corrections applied by tools/pmc_summary.py).  Counters cannot be read from inside this
+    process, so the number is only reported for the configuration it was measured on."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    if not (os.path.exists(path) and region == 0 and (n, H, V) == (8, 60, 8)):
+        return None
+    try:
+        return json.load(open(path))["kernels"]["wx::euler_rhs_kernel<8, double>"]["hbm_bytes"]
+    except (KeyError, ValueError):
+        return None
+
+
 def extras(dev, seed):
     """Secondary, non-headline numbers on the same GPU: the shallow-water S7 workload of BASELINE.json's
     galewsky line (n=8, 60x60 elements/panel, 6 panels), whole-sphere R(Q)."""
@@ -201,7 +215,7 @@ def main():
         achieved = bytes_launch / tk / 1e9
         roof = {"bound": "hbm", "kernel": "euler_rhs_kernel<8,double>", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None, "launch_ms": round(tk * 1e3, 4),
+                "traffic": pmc_traffic(region, n, H, V), "launch_ms": round(tk * 1e3, 4),
                 "algorithmic_bytes_per_launch": bytes_launch,
                 "region": {0: "all", 1: "interior", 2: "boundary"}[region]}
 

@@ -130,3 +130,41 @@ def test_whole_sphere_on_one_gpu():
         err = var_err(Rs[p].cpu().numpy(), ref)
         assert (err <= TOL * np.maximum(var_max(ref), _scale(g, p, False))).all(), (p, err)
         assert Rs[p].shape == qs[p].shape and Rs[p].dtype == qs[p].dtype
+
+
+def test_rccl_exchange_path_on_one_gpu():
+    """The N>1 code path end to end on one GPU: a 1-rank RCCL process group with the exchange in
+    loopback mode, so every edge message goes through all_to_all_single on device buffers,
+    asynchronously, while the INTERIOR launch runs, then BOUNDARY - and must equal the aliasing path."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    from tests.gpu_util import make_plan, to_dev
+    from wxfactory_amd.exchange import PanelExchange
+    from wxfactory_amd.rhs_euler3d import RhsEuler3D
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        g = golden("euler3d_c31p_n3_h4_v2")
+        plans = {p: make_plan(g, p) for p in range(6)}
+        ex = PanelExchange(plans[0].edge_count, DEV, rank=0, world_size=1, loopback=True)
+        assert ex.needs_comm and ex.n_remote_out == 24 and ex.n_remote_in == 24
+        rhs = RhsEuler3D(plans, ex, overlap=True)
+        qs = {p: to_dev(g.q(p)) for p in range(6)}
+        a = rhs(qs)
+        b = RhsEuler3D(plans)(qs)
+        torch.cuda.synchronize()
+        for p in range(6):
+            assert torch.equal(a[p], b[p]), p
+            ref = g.r(p)
+            err = var_err(a[p].cpu().numpy(), ref)
+            assert (err <= TOL * np.maximum(var_max(ref), _scale(g, p, False))).all()
+    finally:
+        dist.destroy_process_group()

@@ -101,3 +101,76 @@ def test_panel_graph_matches_reference_delivery():
     assert owner_of_panels(4) == [0, 1, 2, 3, 0, 1]
     assert owner_of_panels(8) == [0, 1, 2, 3, 4, 5]
     assert panels_of_rank(7, 8) == [] and panels_of_rank(1, 2) == [1, 3, 5]
+
+
+class _CpuPlan:
+    """Test double with the plan interface PanelRhs drives (extrap_pack / rhs / twin), computing with
+    the CPU oracle: lets the orchestration (phase order, regions, idle ranks, stacked states) run under
+    gloo without a GPU.  Not a fallback: it lives in tests/ only."""
+
+    def __init__(self, g, p):
+        self.g, self.p = g, p
+        self.o = make_oracle(g, p)
+        self.dtype, self.device = torch.float64, torch.device("cpu")
+        self.shape = (5, g.V, g.H, g.H, g.n**3)
+        self.edge_count = 7 * g.V * g.H * g.n**2
+        self.calls = []
+
+    def extrap_pack(self, q, send):
+        self.itf = self.o.extrapolate(q.numpy())
+        for e, s in enumerate(self.o.pack_edges(self.itf)):
+            send[e].copy_(torch.from_numpy(halo7(s).reshape(-1)))
+        self.calls.append("pack")
+
+    def rhs(self, q, halo, out, region=0):
+        self.calls.append(("rhs", region))
+        if region == 1:  # INTERIOR: nothing to check without halos; BOUNDARY/ALL computes everything
+            return
+        h5 = [h.numpy().reshape(7, self.g.V, self.g.H, self.g.n**2)[:5] for h in halo]
+        out.copy_(torch.from_numpy(self.o.rhs(q.numpy(), h5, itf=self.itf)))
+
+
+def _rhs_worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from wxfactory_amd.panel_rhs import PanelRhs
+        from wxfactory_amd.panels import panels_of_rank
+
+        g = golden(FIXTURE)
+        mine = panels_of_rank(rank, world)
+        plans = {p: _CpuPlan(g, p) for p in mine}
+        rhs = PanelRhs(plans, rank=rank, world_size=world, device="cpu", edge_count=7 * g.V * g.H * g.n**2)
+        qs = {p: torch.from_numpy(g.q(p).copy()) for p in mine}
+        out = rhs(qs)
+        for p in mine:
+            ref = g.r(p)
+            err = np.abs(out[p].numpy() - ref).max(axis=(1, 2, 3, 4)) / np.abs(ref).max(axis=(1, 2, 3, 4))
+            assert (err < 1e-10).all(), (rank, p, err)
+            assert plans[p].calls == ["pack", ("rhs", 1), ("rhs", 2)]  # overlap ordering of rhs.py:88-118
+        if mine:  # stacked-state form
+            st = torch.stack([qs[p] for p in mine])
+            o2 = rhs(st)
+            assert o2.shape == st.shape and all(torch.equal(o2[i], out[p]) for i, p in enumerate(mine))
+        else:
+            rhs({})  # idle rank takes part in the second collective too
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, traceback.format_exc()))
+        raise
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_panel_rhs_orchestration_over_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rhs_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=240) for _ in range(world)]
+    [p.join(timeout=60) for p in procs]
+    assert all(r[1] == "ok" for r in res), [r for r in res if r[1] != "ok"]

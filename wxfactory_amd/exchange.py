@@ -20,11 +20,15 @@ from .panels import NEIGHBOR, landing_edge, owner_of_panels
 
 
 class PanelExchange:
-    def __init__(self, edge_doubles: int, device, rank: int = 0, world_size: int = 1, group=None):
+    def __init__(self, edge_doubles: int, device, rank: int = 0, world_size: int = 1, group=None,
+                 loopback: bool = False):
         """edge_doubles: float64 words per edge message (5*V*H*n^2, doubled for complex128);
         buffers are float64 (complex payloads travel as interleaved re/im, which RCCL accepts)."""
         dtype = torch.float64
         self.edge_count = int(edge_doubles)
+        # loopback (tests): route same-rank messages through the collective too, so that a single
+        # process exercises the RCCL path (split sizes, slot order, async wait) end to end
+        self.loopback = loopback
         self.rank, self.world = rank, world_size
         self.group = group
         owner = owner_of_panels(world_size)
@@ -36,14 +40,14 @@ class PanelExchange:
         for p in self.local:
             for e in range(4):
                 q, e2 = NEIGHBOR[p][e], landing_edge(p, e)
-                if owner[q] == rank:
+                if owner[q] == rank and not loopback:
                     local_msgs.append((p, e, q, e2))
                 else:
                     remote_out.setdefault(owner[q], []).append((q, e2, p, e))
         for q in self.local:
             for e2 in range(4):
                 p = NEIGHBOR[q][e2]
-                if owner[p] != rank:
+                if owner[p] != rank or loopback:
                     remote_in.setdefault(owner[p], []).append((q, e2))
         # canonical order inside each rank pair: by (destination panel, destination edge)
         n_remote_out = sum(len(v) for v in remote_out.values())
@@ -86,6 +90,12 @@ class PanelExchange:
         buf = self.send_buf if kind == "send" else self.recv_buf
         return buf[s * self.edge_count:(s + 1) * self.edge_count]
 
+    def send_views(self, panel: int) -> List[torch.Tensor]:
+        return [self.send_view(panel, e) for e in range(4)]
+
+    def halo_views(self, panel: int) -> List[torch.Tensor]:
+        return [self.halo_view(panel, e) for e in range(4)]
+
     def send_ptrs(self, panel: int) -> List[int]:
         return [self.send_view(panel, e).data_ptr() for e in range(4)]
 
@@ -94,7 +104,7 @@ class PanelExchange:
 
     @property
     def needs_comm(self) -> bool:
-        return self.world > 1
+        return self.world > 1 or self.loopback
 
     def start(self):
         """Post the exchange of everything the pack kernels wrote (stream-ordered after them)."""

@@ -13,20 +13,30 @@ from . import _lib
 from .exchange import PanelExchange
 
 
+def _ptr_array(items):
+    """Four edge buffers (tensors, or raw device addresses) -> void*[4] for the C ABI; None passes NULL."""
+    import ctypes
+
+    if items is None:
+        return None
+    return (ctypes.c_void_p * 4)(*[(t.data_ptr() if isinstance(t, torch.Tensor) else int(t)) for t in items])
+
+
 class PanelRhs:
     def __init__(self, plans: Dict[int, object], exchange: PanelExchange = None, overlap: bool = True,
-                 rank: int = 0, world_size: int = 1, group=None):
+                 rank: int = 0, world_size: int = 1, group=None, device=None, edge_count: int = 0):
+        """`device` / `edge_count` are only needed by a rank that owns no panel (plans == {})."""
         self.panels = sorted(plans)
         self.overlap = overlap
         self.rank, self.world, self.group = rank, world_size, group
         first = plans[self.panels[0]] if self.panels else None
-        self.device = first.device if first is not None else None
+        self.device = first.device if first is not None else device
         self._plans = {first.dtype if first is not None else torch.float64: plans}
         self._ex = {}
         if exchange is not None:
             self._ex[first.dtype if first is not None else torch.float64] = exchange
             self.rank, self.world, self.group = exchange.rank, exchange.world, exchange.group
-        self.edge_count = first.edge_count if first is not None else 0
+        self.edge_count = first.edge_count if first is not None else edge_count
         self.panel_shape = first.shape if first is not None else None
 
     # -- per-dtype resources
@@ -52,7 +62,7 @@ class PanelRhs:
         return self.exchange_for(next(iter(self._plans)))
 
     # -- the evaluation
-    def __call__(self, qs):
+    def __call__(self, qs, dtype=None):
         np_ = len(self.panels)
         kind = "dict"
         if isinstance(qs, torch.Tensor):
@@ -69,6 +79,11 @@ class PanelRhs:
             else:
                 raise ValueError(f"state of {qs.numel()} values does not match {np_} panel(s) of {self.panel_shape}")
         if not self.panels:
+            # a rank that owns no panel (ranks 6, 7 of an 8-GPU node) still takes part in the collective
+            ex = self.exchange_for(dtype or torch.float64)
+            if ex.needs_comm:
+                ex.start()
+                ex.wait()
             return qs
         dtype = next(iter(qs.values())).dtype
         plans, ex = self.plans_for(dtype), self.exchange_for(dtype)
@@ -80,19 +95,19 @@ class PanelRhs:
         else:
             outs = {p: torch.empty_like(flat[p]) for p in self.panels}
         for p in self.panels:
-            plans[p].extrap_pack(flat[p], ex.send_ptrs(p))
+            plans[p].extrap_pack(flat[p], ex.send_views(p))
         if ex.needs_comm and self.overlap:
             ex.start()
             for p in self.panels:
                 plans[p].rhs(flat[p], None, outs[p], _lib.WX_REGION_INTERIOR)
             ex.wait()
             for p in self.panels:
-                plans[p].rhs(flat[p], ex.halo_ptrs(p), outs[p], _lib.WX_REGION_BOUNDARY)
+                plans[p].rhs(flat[p], ex.halo_views(p), outs[p], _lib.WX_REGION_BOUNDARY)
         else:
             ex.start()
             ex.wait()
             for p in self.panels:
-                plans[p].rhs(flat[p], ex.halo_ptrs(p), outs[p], _lib.WX_REGION_ALL)
+                plans[p].rhs(flat[p], ex.halo_views(p), outs[p], _lib.WX_REGION_ALL)
         if kind == "stacked":
             return out_all.reshape(shape)
         if kind == "single":

@@ -15,7 +15,7 @@ import torch
 from . import _lib
 from ._lib import DfrOps, Euler3DMetric, check
 from .exchange import PanelExchange  # noqa: F401
-from .panel_rhs import PanelRhs
+from .panel_rhs import PanelRhs, _ptr_array
 
 _DTYPES = {torch.float64: _lib.WX_F64, torch.complex128: _lib.WX_C128}
 
@@ -81,14 +81,14 @@ class Euler3DPlan:
 
     def extrap_pack(self, q: torch.Tensor, send_ptrs: Optional[Sequence[int]]):
         self._check_q(q)
-        arr = (ctypes.c_void_p * 4)(*send_ptrs) if send_ptrs is not None else None
+        arr = _ptr_array(send_ptrs)
         st = torch.cuda.current_stream(self.device).cuda_stream
         check(self.lib.wx_euler3d_extrap_pack(self._h, q.data_ptr(), arr, st), "wx_euler3d_extrap_pack")
 
     def rhs(self, q: torch.Tensor, halo_ptrs: Optional[Sequence[int]], out: torch.Tensor, region: int = _lib.WX_REGION_ALL):
         self._check_q(q)
         self._check_q(out)
-        arr = (ctypes.c_void_p * 4)(*halo_ptrs) if halo_ptrs is not None else None
+        arr = _ptr_array(halo_ptrs)
         st = torch.cuda.current_stream(self.device).cuda_stream
         check(self.lib.wx_euler3d_rhs(self._h, q.data_ptr(), arr, out.data_ptr(), region, st), "wx_euler3d_rhs")
 
