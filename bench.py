@@ -147,7 +147,7 @@ def main():
         metric = synthetic.euler3d_metric(n, H, V, p, dev, args.seed)
         plans[p] = Euler3DPlan(n, H, V, 31, p, ops, metric)
         qs[p] = synthetic.euler3d_state(n, H, V, p, dev, args.seed)
-    edge_doubles = 7 * V * H * n * n  # WX_EULER3D_EDGE_FIELDS
+    edge_doubles = 5 * V * H * n * n  # WX_EULER3D_EDGE_FIELDS
     ex = PanelExchange(edge_doubles, dev, rank=rank, world_size=world)
     rhs = RhsEuler3D(plans, ex, overlap=not args.no_overlap)
 

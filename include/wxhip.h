@@ -97,26 +97,25 @@ typedef struct wx_euler3d_plan wx_euler3d_plan;
 
 /* Build a plan for one tile.  `panel` (0..5) selects the flip/rotation tables of
  * process_topology.py:105-175 for the four lateral edges (one tile per panel).
- * Allocates the plan's private interface buffer (6*7*n^2 values per element). */
+ * Allocates the plan's private interface buffer (6*5*n^2 values per element). */
 wx_status wx_euler3d_plan_create(wx_euler3d_plan** plan, int n, int H, int V, int case_number, wx_dtype dtype,
                                  int panel, const wx_dfr_ops* ops, const wx_euler3d_metric* metric);
 wx_status wx_euler3d_plan_destroy(wx_euler3d_plan* plan);
 
 /* Values per face point in an edge message: the 5 prognostic variables the reference exchanges
- * (rho, rho u1, rho u2, rho w, rho theta) followed by 2 the sender derives from them once instead
- * of both sides redoing it: the face pressure p0*exp(cpd/cvd*log(rho theta*Rd/p0))
- * (pde_euler_cubesphere.py:158-160) and its logarithm (rhs_dfr.py:113-115). */
-#define WX_EULER3D_EDGE_FIELDS 7
-/* Number of ELEMENTS of dtype in one edge message: 7*V*H*n^2, layout [field][ek][along][n^2];
- * the first 5*V*H*n^2 are exactly the reference's q_itf_{s,n,w,e} after wait(). */
+ * (rho, rho u1, rho u2, rho w, rho theta).  (Builds with -DWX_EULER_NQ=6/7 append the face pressure and
+ * its logarithm; wx_euler3d_edge_count() always reports the size in use.) */
+#define WX_EULER3D_EDGE_FIELDS 5
+/* Number of ELEMENTS of dtype in one edge message: 5*V*H*n^2, layout [var][ek][along][n^2] =
+ * exactly the reference's q_itf_{s,n,w,e} after ExchangeRequest.wait(). */
 size_t wx_euler3d_edge_count(const wx_euler3d_plan* plan);
 
 /* Phases 1-2, sender side (rhs_dfr.py:50-71, 141-172; process_topology.py:269-386):
  * extrapolate q to all element faces (log-space for rho, rho*theta) into the plan's
  * interface buffer, and write the four outward tile-edge faces - rotated into the
  * neighbour's basis and flipped as the reference does before MPI - to send[e]
- * (e = S,N,W,E; each wx_euler3d_edge_count() values).  The first five fields of send[e] are
- * exactly what the neighbour's q_itf_{s,n,w,e} holds after ExchangeRequest.wait(). */
+ * (e = S,N,W,E; each wx_euler3d_edge_count() values).  send[e] is exactly what the neighbour's
+ * q_itf_{s,n,w,e} holds after ExchangeRequest.wait(). */
 wx_status wx_euler3d_extrap_pack(wx_euler3d_plan* plan, const void* q, void* const send[4], wx_stream stream);
 
 /* Phases 3-8 (rhs_dfr.py:73-139, 203-313): pointwise fluxes, derivatives, Rusanov fluxes
@@ -125,6 +124,15 @@ wx_status wx_euler3d_extrap_pack(wx_euler3d_plan* plan, const void* q, void* con
  * Requires wx_euler3d_extrap_pack(plan, q, ...) to have run on the same stream. */
 wx_status wx_euler3d_rhs(wx_euler3d_plan* plan, const void* q, const void* const halo[4], void* rhs,
                          wx_region region, wx_stream stream);
+
+/* Same evaluation with the stage update of an explicit Runge-Kutta scheme fused into the store:
+ *     out = a*y + b*q + c*R(q)          (y may be NULL: then out = b*q + c*R(q))
+ * e.g. the three stages of integrators/tvdrk3.py:12-19 are (y,a,b,c) = (-,0,1,dt), (Q,3/4,1/4,dt/4),
+ * (Q,1/3,2/3,2dt/3).  q is already in registers when R is formed, so a stage costs one extra
+ * stream (y) instead of three passes over the state.  out must not alias q (neighbours read q's
+ * faces through the interface buffer, but the INTERIOR/BOUNDARY launches both read q itself). */
+wx_status wx_euler3d_rhs_axpy(wx_euler3d_plan* plan, const void* q, const void* const halo[4], const void* y, void* out,
+                              double a, double b, double c, wx_region region, wx_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Shallow water on a cubed-sphere tile.

@@ -51,11 +51,14 @@ def test_matvec_fun_and_rat(setup):
     assert (_rel(jf, jc.cpu().numpy().reshape(6, *Q.shape[1:])) < 1e-3).all()
 
 
-def test_tvdrk3_step(setup):
+@pytest.mark.parametrize("fused", [False, True])
+def test_tvdrk3_step(setup, fused):
     from wxfactory_amd.integrators import Tvdrk3
 
     g, rhs, stack = setup
-    Qn = Tvdrk3(rhs).step(stack("Q"), float(g["meta/dt_rk"]))
+    stepper = Tvdrk3(rhs, fused=fused)
+    assert stepper.fused == fused
+    Qn = stepper.step(stack("Q"), float(g["meta/dt_rk"]))
     ref = stack("rk3").cpu().numpy()
     dq = np.abs(ref - stack("Q").cpu().numpy()).max(axis=(0, 2, 3, 4, 5))
     err = np.abs(Qn.cpu().numpy() - ref).max(axis=(0, 2, 3, 4, 5))

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import EULER_FIXTURES, golden, halo7, make_oracle, var_err, var_max
+from tests.util import EDGE_FIELDS, EULER_FIXTURES, golden, halo7, make_oracle, var_err, var_max
 
 pytestmark = pytest.mark.gpu
 
@@ -50,11 +50,11 @@ def test_pack_matches_reference_halos(name):
             send = torch.zeros((4, plan.edge_count), dtype=dtype, device=DEV)
             plan.extrap_pack(q, [send[e].data_ptr() for e in range(4)])
             torch.cuda.synchronize()
-            got = send.cpu().numpy().reshape(4, 7, g.V, g.H, g.n**2)
+            got = send.cpu().numpy().reshape(4, EDGE_FIELDS, g.V, g.H, g.n**2)
             for e in range(4):
                 nb, e2 = NEIGHBOR[p][e], landing_edge(p, e)
                 ref = halo7(g.halo(nb, cplx)[e2])
-                for v in range(7):  # 0-4: the reference's message; 5-6: derived pressure, log p
+                for v in range(EDGE_FIELDS):  # 0-4: the reference's message (5, 6: pressure, log p in NQ=7 builds)
                     assert np.abs(got[e][v] - ref[v]).max() <= 1e-13 * np.abs(ref[v]).max(), (name, p, e, v, cplx)
             plan.close()
 

@@ -14,7 +14,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from tests.util import golden, halo7, make_oracle
+from tests.util import EDGE_FIELDS, golden, halo7, make_oracle
 
 FIXTURE = "euler3d_c31p_n3_h4_v2"
 
@@ -35,7 +35,7 @@ def _worker(rank, world, port, q):
         from wxfactory_amd.panels import panels_of_rank
 
         g = golden(FIXTURE)
-        edge = 7 * g.V * g.H * g.n**2
+        edge = EDGE_FIELDS * g.V * g.H * g.n**2
         ex = PanelExchange(edge, "cpu", rank=rank, world_size=world)
         assert ex.local == panels_of_rank(rank, world)
         for rep in range(2):  # twice: buffers are reused across RHS evaluations
@@ -48,7 +48,7 @@ def _worker(rank, world, port, q):
             ex.wait()
             for p in ex.local:
                 for e in range(4):
-                    got = ex.halo_view(p, e).numpy().reshape(7, g.V, g.H, g.n**2)
+                    got = ex.halo_view(p, e).numpy().reshape(EDGE_FIELDS, g.V, g.H, g.n**2)
                     ref = halo7(g.halo(p)[e])
                     err = np.abs(got - ref).max() / np.abs(ref).max()
                     assert err < 1e-13, (rank, p, e, err)
@@ -113,7 +113,7 @@ class _CpuPlan:
         self.o = make_oracle(g, p)
         self.dtype, self.device = torch.float64, torch.device("cpu")
         self.shape = (5, g.V, g.H, g.H, g.n**3)
-        self.edge_count = 7 * g.V * g.H * g.n**2
+        self.edge_count = EDGE_FIELDS * g.V * g.H * g.n**2
         self.calls = []
 
     def extrap_pack(self, q, send):
@@ -126,7 +126,7 @@ class _CpuPlan:
         self.calls.append(("rhs", region))
         if region == 1:  # INTERIOR: nothing to check without halos; BOUNDARY/ALL computes everything
             return
-        h5 = [h.numpy().reshape(7, self.g.V, self.g.H, self.g.n**2)[:5] for h in halo]
+        h5 = [h.numpy().reshape(EDGE_FIELDS, self.g.V, self.g.H, self.g.n**2)[:5] for h in halo]
         out.copy_(torch.from_numpy(self.o.rhs(q.numpy(), h5, itf=self.itf)))
 
 
@@ -140,7 +140,7 @@ def _rhs_worker(rank, world, port, q):
         g = golden(FIXTURE)
         mine = panels_of_rank(rank, world)
         plans = {p: _CpuPlan(g, p) for p in mine}
-        rhs = PanelRhs(plans, rank=rank, world_size=world, device="cpu", edge_count=7 * g.V * g.H * g.n**2)
+        rhs = PanelRhs(plans, rank=rank, world_size=world, device="cpu", edge_count=EDGE_FIELDS * g.V * g.H * g.n**2)
         qs = {p: torch.from_numpy(g.q(p).copy()) for p in mine}
         out = rhs(qs)
         for p in mine:

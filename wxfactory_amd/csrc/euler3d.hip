@@ -35,11 +35,26 @@
 #ifndef WX_K2_FIELD_BATCH
 #define WX_K2_FIELD_BATCH 3   // derivative fields contracted per (rolled) batch: 7 = fully unrolled
 #endif
+#ifndef WX_ELEM_ORDER
+#define WX_ELEM_ORDER 0   // processing order of elements: 0 = memory order (ek,ej,ei); 1 = vertical columns first
+#endif
+#ifndef WX_XCD_CHUNK
+#define WX_XCD_CHUNK 0    // 1: give each XCD (blockIdx % 8) a contiguous run of the processing order
+#endif
+#ifndef WX_K2_NT_METRIC
+#define WX_K2_NT_METRIC 1 // 1: non-temporal loads for the streamed-once metric fields
+#endif
 #ifndef WX_K2_STAMPS
 #define WX_K2_STAMPS 0   // diagnostic build: per-workgroup phase timestamps (never in the product build)
 #endif
 #ifndef WX_K2_EARLY_LOADS
 #define WX_K2_EARLY_LOADS 0   // issue the point loads before the face stage
+#endif
+
+#if WX_K2_NT_METRIC
+#define WX_LDM(p) __builtin_nontemporal_load(p)
+#else
+#define WX_LDM(p) (*(p))
 #endif
 
 namespace wx {
@@ -61,11 +76,14 @@ struct Cfg {
 };
 
 enum { F_W = 0, F_E = 1, F_S = 2, F_N = 3, F_B = 4, F_T = 5 };
-// values per face point in the interface buffer and in the edge messages: the five prognostic
-// variables (exactly the reference's q_itf) followed by the face pressure and its logarithm, so
-// that the two elements sharing a face do not both redo exp(gamma*log(.)) (fluxes.py evaluates it
-// once per face side as well: pde_euler_cubesphere.py:158-160).
-constexpr int NQ = 7;
+// values per face point in the interface buffer and in the edge messages.  5 = the prognostic
+// variables, exactly the reference's q_itf (default: measured fastest - the kernel is HBM-bound and
+// the two extra streams cost more than redoing exp(gamma*log(.)) on both sides of a face);
+// 6 / 7 additionally carry the face pressure / its logarithm (pde_euler_cubesphere.py:158-160).
+#ifndef WX_EULER_NQ
+#define WX_EULER_NQ 5   // 7: state + p + log p;  6: state + p;  5: state only (pressures redone per side)
+#endif
+constexpr int NQ = WX_EULER_NQ;
 
 // 1-D operator pieces and the tile's edge tables, in device memory (one copy per plan): dynamic
 // indexing into a by-value kernel argument would force the whole struct into scratch.
@@ -80,6 +98,9 @@ template <typename T>
 struct EulerParams {
     int H, V, nelem, count, region;
     int advection_only, has_damp;
+    int axpy;              // 1: out = ca*y + cb*q + cc*R(q) (explicit RK stage), 0: out = R(q)
+    double ca, cb, cc;
+    const T* y;            // nullable (then ca is ignored)
     const T* q;
     T* rhs;
     T* itf;  // [elem][6 faces][NQ = 5 vars + pressure + log pressure][N2]
@@ -97,15 +118,33 @@ struct Elem {
     bool valid;
 };
 
+// workgroup -> position in the processing order.  Workgroups are dealt round-robin to the 8 XCDs
+// (speed only, never correctness): with WX_XCD_CHUNK each XCD walks a contiguous run, so the two
+// elements that read a face (owner and neighbour) tend to share an L2.
+__device__ __forceinline__ int block_slot(int nblocks) {
+#if WX_XCD_CHUNK
+    const int b = blockIdx.x, per = nblocks / 8;
+    return b < per * 8 ? (b % 8) * per + b / 8 : b;  // bijection; the ragged tail (< 8 blocks) maps to itself
+#else
+    return blockIdx.x;
+#endif
+}
+
 // slot (position in this launch's processing order) -> element of the tile
 __device__ __forceinline__ Elem decode_elem(int slot, int count, int region, int H, int V) {
     Elem r;
     r.valid = slot < count;
     if (!r.valid) slot = 0;
     if (region == WX_REGION_ALL) {
+#if WX_ELEM_ORDER == 1
+        r.ek = slot % V;
+        r.ei = (slot / V) % H;
+        r.ej = slot / (V * H);
+#else
         r.ei = slot % H;
         r.ej = (slot / H) % H;
         r.ek = slot / (H * H);
+#endif
     } else if (region == WX_REGION_INTERIOR) {
         const int w = H - 2;
         r.ei = 1 + slot % w;
@@ -194,8 +233,8 @@ __global__ __launch_bounds__(Cfg<N>::BS) void euler_extrap_kernel(const EulerPar
         T* dst = P.itf + ((size_t)el.e * 6 + f) * NQ * N2 + fp;
 #pragma unroll
         for (int v = 0; v < 5; ++v) dst[v * N2] = s[v];
-        dst[5 * N2] = pf;
-        dst[6 * N2] = lpf;
+        if (NQ > 5) dst[5 * N2] = pf;
+        if (NQ > 6) dst[6 * N2] = lpf;
 
         // outward faces of the tile edge: rotate into the neighbour's basis, flip, pack
         int edge = -1, along = 0;
@@ -218,8 +257,8 @@ __global__ __launch_bounds__(Cfg<N>::BS) void euler_extrap_kernel(const EulerPar
             const size_t vs = (size_t)V * H * N2;
 #pragma unroll
             for (int v = 0; v < 5; ++v) out[v * vs] = s[v];
-            out[5 * vs] = pf;
-            out[6 * vs] = lpf;
+            if (NQ > 5) out[5 * vs] = pf;
+            if (NQ > 6) out[6 * vs] = lpf;
         }
     }
 }
@@ -297,7 +336,7 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
 
     // ---- point loads first: in flight while the face stage computes
     const int le = tid / N3, pt = tid % N3;
-    const Elem el = decode_elem(blockIdx.x * EPB + le, P.count, P.region, H, V);
+    const Elem el = decode_elem(block_slot(gridDim.x) * EPB + le, P.count, P.region, H, V);
     const bool active = (le < EPB) && el.valid;
     const int kl = pt / N2, jl = (pt / N) % N, il = pt % N;
     const int lb = (le < EPB ? le : 0) * C::LE;  // LDS base of this thread's element
@@ -309,9 +348,9 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
 #define WX_POINT_LOADS()                                                                                   \
     if (active) {                                                                                          \
         q0 = P.q[o]; q1 = P.q[fs + o]; q2 = P.q[2 * fs + o]; q3 = P.q[3 * fs + o]; q4 = P.q[4 * fs + o];   \
-        sg = P.sg[o];                                                                                      \
-        h00 = P.h[0 * fs + o]; h01 = P.h[1 * fs + o]; h02 = P.h[2 * fs + o];                               \
-        h11 = P.h[4 * fs + o]; h12 = P.h[5 * fs + o]; h22 = P.h[8 * fs + o];                               \
+        sg = WX_LDM(P.sg + o);                                                                             \
+        h00 = WX_LDM(P.h + 0 * fs + o); h01 = WX_LDM(P.h + 1 * fs + o); h02 = WX_LDM(P.h + 2 * fs + o);    \
+        h11 = WX_LDM(P.h + 4 * fs + o); h12 = WX_LDM(P.h + 5 * fs + o); h22 = WX_LDM(P.h + 8 * fs + o);    \
     }
 #if WX_K2_EARLY_LOADS
     WX_POINT_LOADS()
@@ -320,8 +359,8 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
     double cg[27], idzv = 0.0;
 #define WX_GAMMA_LOADS()                                                        \
     if (active) {                                                               \
-        _Pragma("unroll") for (int i = 0; i < 27; ++i) cg[i] = P.chr[(size_t)i * fs + o]; \
-        idzv = P.idz[o];                                                        \
+        _Pragma("unroll") for (int i = 0; i < 27; ++i) cg[i] = WX_LDM(P.chr + (size_t)i * fs + o); \
+        idzv = WX_LDM(P.idz + o);                                               \
     } else {                                                                    \
         _Pragma("unroll") for (int i = 0; i < 27; ++i) cg[i] = 0.0;             \
     }
@@ -335,7 +374,7 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
         const int le = fi / (6 * N2);
         const int r = fi % (6 * N2);
         const int f = r / N2, fp = r % N2;
-        const Elem el = decode_elem(blockIdx.x * EPB + le, P.count, P.region, H, V);
+        const Elem el = decode_elem(block_slot(gridDim.x) * EPB + le, P.count, P.region, H, V);
         if (!el.valid) continue;
         const int d = f >> 1, plus = f & 1;
         const size_t vsh = (size_t)V * H * N2;  // var stride in a halo edge message
@@ -371,11 +410,18 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
             sgp = P.sgk + o;
             hp = P.hk + 2 * 3 * hfs + o;
         }
-        T qo[NQ], qn[NQ];
+        T qo[7], qn[7];
 #pragma unroll
         for (int v = 0; v < NQ; ++v) {
             qo[v] = own[v * N2];
             qn[v] = nbr[v * nstride];
+        }
+        if (NQ == 5) {  // pressures from rho*theta on both sides (pde_euler_cubesphere.py:158-160)
+            const T go = kGamma * w_log(qo[4] * kRdOverP0), gn = kGamma * w_log(qn[4] * kRdOverP0);
+            qo[5] = kP0 * w_exp(go); qn[5] = kP0 * w_exp(gn);
+            qo[6] = kLogP0 + go; qn[6] = kLogP0 + gn;
+        } else if (NQ == 6) {
+            qo[6] = w_log(qo[5]); qn[6] = qo[6];  // only the own side's log p is used
         }
         const double sg = *sgp, h0 = hp[0], h1 = hp[hfs], h2 = hp[2 * hfs];
         const double hdd = d == 0 ? h0 : (d == 1 ? h1 : h2);
@@ -554,6 +600,14 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
     T r0 = -inv_sg * acc0, r1 = -inv_sg * acc1, r2 = -inv_sg * acc2, r3 = -inv_sg * accw, r4 = -inv_sg * acc4;
     if (P.advection_only) { r0 = r1 = r2 = r3 = r4 = T(0.0); }
 
+    if (P.axpy) {  // fused stage update of an explicit Runge-Kutta scheme (integrators/tvdrk3.py:12-19)
+        r0 = P.cb * q0 + P.cc * r0; r1 = P.cb * q1 + P.cc * r1; r2 = P.cb * q2 + P.cc * r2;
+        r3 = P.cb * q3 + P.cc * r3; r4 = P.cb * q4 + P.cc * r4;
+        if (P.y != nullptr) {
+            r0 += P.ca * P.y[o]; r1 += P.ca * P.y[fs + o]; r2 += P.ca * P.y[2 * fs + o];
+            r3 += P.ca * P.y[3 * fs + o]; r4 += P.ca * P.y[4 * fs + o];
+        }
+    }
     P.rhs[o] = r0;
     P.rhs[fs + o] = r1;
     P.rhs[2 * fs + o] = r2;
@@ -616,6 +670,7 @@ EulerParams<T> make_params(const wx_euler3d_plan* pl) {
     P.H = b.H; P.V = b.V; P.nelem = b.nelem; P.count = b.count; P.region = b.region;
     P.advection_only = b.advection_only; P.has_damp = b.has_damp;
     P.q = nullptr; P.rhs = nullptr; P.itf = static_cast<T*>(pl->itf);
+    P.axpy = 0; P.ca = P.cb = 0.0; P.cc = 1.0; P.y = nullptr;
     P.halo_s = P.halo_n = P.halo_w = P.halo_e = nullptr;
     P.send_s = P.send_n = P.send_w = P.send_e = nullptr;
     P.K = pl->consts;
@@ -768,9 +823,12 @@ wx_status wx_euler3d_extrap_pack(wx_euler3d_plan* pl, const void* q, void* const
     return dispatch_extrap<cplx>(pl->n, P, st);
 }
 
-wx_status wx_euler3d_rhs(wx_euler3d_plan* pl, const void* q, const void* const halo[4], void* rhs, wx_region region,
-                         wx_stream stream) {
-    if (!pl || !q || !rhs) return fail(WX_ERR_INVALID, "wx_euler3d_rhs: null argument");
+static wx_status euler3d_rhs_impl(wx_euler3d_plan* pl, const void* q, const void* const halo[4], void* out,
+                                  wx_region region, wx_stream stream, int axpy, const void* y, double ca, double cb,
+                                  double cc) {
+    if (!pl || !q || !out) return fail(WX_ERR_INVALID, "wx_euler3d_rhs: null argument");
+    if (out == q)
+        return fail(WX_ERR_INVALID, "wx_euler3d_rhs: output must not alias the state (neighbours still read it)");
     if (region != WX_REGION_ALL && region != WX_REGION_INTERIOR && region != WX_REGION_BOUNDARY)
         return fail(WX_ERR_INVALID, "unknown region %d", (int)region);
     if (region != WX_REGION_INTERIOR) {
@@ -782,8 +840,9 @@ wx_status wx_euler3d_rhs(wx_euler3d_plan* pl, const void* q, const void* const h
     const int count = region_count(region, pl->H, pl->V);
     if (pl->dtype == WX_F64) {
         EulerParams<double> P = make_params<double>(pl);
-        P.q = static_cast<const double*>(q); P.rhs = static_cast<double*>(rhs);
+        P.q = static_cast<const double*>(q); P.rhs = static_cast<double*>(out);
         P.region = region; P.count = count;
+        P.axpy = axpy; P.ca = ca; P.cb = cb; P.cc = cc; P.y = static_cast<const double*>(y);
         if (halo) {
             P.halo_s = static_cast<const double*>(halo[0]); P.halo_n = static_cast<const double*>(halo[1]);
             P.halo_w = static_cast<const double*>(halo[2]); P.halo_e = static_cast<const double*>(halo[3]);
@@ -791,13 +850,24 @@ wx_status wx_euler3d_rhs(wx_euler3d_plan* pl, const void* q, const void* const h
         return dispatch_rhs<double>(pl->n, P, st);
     }
     EulerParams<cplx> P = make_params<cplx>(pl);
-    P.q = static_cast<const cplx*>(q); P.rhs = static_cast<cplx*>(rhs);
+    P.q = static_cast<const cplx*>(q); P.rhs = static_cast<cplx*>(out);
     P.region = region; P.count = count;
+    P.axpy = axpy; P.ca = ca; P.cb = cb; P.cc = cc; P.y = static_cast<const cplx*>(y);
     if (halo) {
         P.halo_s = static_cast<const cplx*>(halo[0]); P.halo_n = static_cast<const cplx*>(halo[1]);
         P.halo_w = static_cast<const cplx*>(halo[2]); P.halo_e = static_cast<const cplx*>(halo[3]);
     }
     return dispatch_rhs<cplx>(pl->n, P, st);
+}
+
+wx_status wx_euler3d_rhs(wx_euler3d_plan* pl, const void* q, const void* const halo[4], void* rhs, wx_region region,
+                         wx_stream stream) {
+    return euler3d_rhs_impl(pl, q, halo, rhs, region, stream, 0, nullptr, 0.0, 0.0, 1.0);
+}
+
+wx_status wx_euler3d_rhs_axpy(wx_euler3d_plan* pl, const void* q, const void* const halo[4], const void* y, void* out,
+                              double a, double b, double c, wx_region region, wx_stream stream) {
+    return euler3d_rhs_impl(pl, q, halo, out, region, stream, 1, y, a, b, c);
 }
 
 }  // extern "C"

@@ -63,6 +63,14 @@ class PanelRhs:
 
     # -- the evaluation
     def __call__(self, qs, dtype=None):
+        return self._run(qs, None, None, dtype)
+
+    def axpy(self, qs, ys, a: float, b: float, c: float):
+        """a*ys + b*qs + c*R(qs) with the update fused into the RHS kernel's store (one explicit
+        Runge-Kutta stage; `ys` may be None).  Same structures as __call__."""
+        return self._run(qs, ys, (float(a), float(b), float(c)), None)
+
+    def _structure(self, qs):
         np_ = len(self.panels)
         kind = "dict"
         if isinstance(qs, torch.Tensor):
@@ -78,6 +86,13 @@ class PanelRhs:
                 qs = {p: flat[i] for i, p in enumerate(self.panels)}
             else:
                 raise ValueError(f"state of {qs.numel()} values does not match {np_} panel(s) of {self.panel_shape}")
+        return kind, (shape if kind != "dict" else None), qs
+
+    def _run(self, qs, ys, coef, dtype):
+        np_ = len(self.panels)
+        kind, shape, qs = self._structure(qs)
+        if ys is not None:
+            ys = self._structure(ys)[2]
         if not self.panels:
             # a rank that owns no panel (ranks 6, 7 of an 8-GPU node) still takes part in the collective
             ex = self.exchange_for(dtype or torch.float64)
@@ -89,6 +104,14 @@ class PanelRhs:
         plans, ex = self.plans_for(dtype), self.exchange_for(dtype)
         shapes = {p: q.shape for p, q in qs.items()}
         flat = {p: q.reshape(self.panel_shape) for p, q in qs.items()}
+        yflat = {p: y.reshape(self.panel_shape) for p, y in ys.items()} if ys is not None else {}
+
+        def launch(p, halo, region):
+            if coef is None:
+                plans[p].rhs(flat[p], halo, outs[p], region)
+            else:
+                plans[p].rhs_axpy(flat[p], halo, yflat.get(p), outs[p], coef[0], coef[1], coef[2], region)
+
         if kind == "stacked":
             out_all = torch.empty((np_,) + tuple(self.panel_shape), dtype=dtype, device=self.device)
             outs = {p: out_all[i] for i, p in enumerate(self.panels)}
@@ -99,15 +122,15 @@ class PanelRhs:
         if ex.needs_comm and self.overlap:
             ex.start()
             for p in self.panels:
-                plans[p].rhs(flat[p], None, outs[p], _lib.WX_REGION_INTERIOR)
+                launch(p, None, _lib.WX_REGION_INTERIOR)
             ex.wait()
             for p in self.panels:
-                plans[p].rhs(flat[p], ex.halo_views(p), outs[p], _lib.WX_REGION_BOUNDARY)
+                launch(p, ex.halo_views(p), _lib.WX_REGION_BOUNDARY)
         else:
             ex.start()
             ex.wait()
             for p in self.panels:
-                plans[p].rhs(flat[p], ex.halo_views(p), outs[p], _lib.WX_REGION_ALL)
+                launch(p, ex.halo_views(p), _lib.WX_REGION_ALL)
         if kind == "stacked":
             return out_all.reshape(shape)
         if kind == "single":
