@@ -38,7 +38,15 @@ typedef enum {
     WX_ERR_NOMEM = 4
 } wx_status;
 
-typedef enum { WX_F64 = 0, WX_C128 = 1 } wx_dtype;
+typedef enum {
+    WX_F64 = 0,
+    WX_C128 = 1,   /* complex128, true complex arithmetic with NumPy's abs / maximum rules */
+    /* complex128 STORAGE with first-order (dual-number) arithmetic: re = value, im = tangent.  For the
+     * complex-step Jacobian-vector product of solvers/matvec.py:56-61 it returns the same real and
+     * imaginary parts as WX_C128 up to O(eps^2) ~ 2e-16 at a fraction of the cost; it is NOT complex
+     * arithmetic for inputs whose imaginary part is not a small perturbation. */
+    WX_DUAL128 = 2
+} wx_dtype;
 
 /* Which elements of the tile an RHS launch covers (lets the caller overlap the halo
  * exchange with the interior, the ordering of rhs/rhs.py:88-118). */

@@ -168,3 +168,28 @@ def test_rccl_exchange_path_on_one_gpu():
             assert (err <= TOL * np.maximum(var_max(ref), _scale(g, p, False))).all()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["euler3d_c31p_n3_h4_v2", "euler3d_c31p_n8_h2_v2", "euler3d_c21_n4_h3_v4"])
+def test_dual_number_arithmetic_equals_complex_step(name):
+    """WX_DUAL128 (first-order arithmetic in complex128 storage) returns the reference's complex-step
+    result: same real part, same tangent Im R / eps, to the 1e-10 bound."""
+    from tests.gpu_util import device_metric, to_dev
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan
+
+    g = golden(name)
+    for p in g.metric_panels():
+        plan = Euler3DPlan(g.n, g.H, g.V, g.case, p, g.ops, device_metric(g, p, DEV), dtype=torch.complex128, dual=True)
+        q = to_dev(g.q(p, True))
+        halo = [to_dev(halo7(h)) for h in g.halo(p, True)]
+        out = torch.full_like(q, float("nan"))
+        plan.extrap_pack(q, None)
+        plan.rhs(q, halo, out)
+        torch.cuda.synchronize()
+        R, ref = out.cpu().numpy(), g.r(p, True)
+        s = _scale(g, p, True)
+        assert (var_err(R.real, ref.real) <= TOL * np.maximum(var_max(ref.real), s)).all()
+        tight = "31p" in name
+        ierr = var_err(R.imag, ref.imag) / np.maximum(var_max(ref.imag), g.eps * s * 1e-3)
+        assert (ierr <= (1e-10 if tight else 1e-3)).all(), (name, p, ierr)
+        plan.close()

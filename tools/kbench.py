@@ -24,7 +24,7 @@ def child(args):
     n, H, V = args.n, args.H, args.V
     dtype = torch.complex128 if args.cplx else torch.float64
     m = synthetic.euler3d_metric(n, H, V, 0, dev)
-    plan = Euler3DPlan(n, H, V, 31, 0, synthetic.dfr_ops(n), m, dtype=dtype)
+    plan = Euler3DPlan(n, H, V, 31, 0, synthetic.dfr_ops(n), m, dtype=dtype, dual=args.dual)
     q = synthetic.euler3d_state(n, H, V, 0, dev)
     if args.cplx:
         q = q + 1e-8j * q
@@ -57,6 +57,7 @@ if __name__ == "__main__":
     ap.add_argument("--V", type=int, default=8)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--cplx", action="store_true")
+    ap.add_argument("--dual", action="store_true", help="with --cplx: dual-number arithmetic (WX_DUAL128)")
     ap.add_argument("--child", action="store_true")
     ap.add_argument("libs", nargs="*")
     a = ap.parse_args()
@@ -67,7 +68,7 @@ if __name__ == "__main__":
         for lib in a.libs or ["libwxhip.so"]:
             env = dict(os.environ, WXHIP_LIB=lib if os.path.isabs(lib) else os.path.join(libdir, lib))
             cmd = [sys.executable, os.path.abspath(__file__), "--child", "--n", str(a.n), "--H", str(a.H), "--V", str(a.V),
-                   "--reps", str(a.reps)] + (["--cplx"] if a.cplx else [])
+                   "--reps", str(a.reps)] + (["--cplx"] if a.cplx else []) + (["--dual"] if a.dual else [])
             r = subprocess.run(cmd, env=env)
             if r.returncode != 0:
                 print(f"{lib}: FAILED rc={r.returncode}", flush=True)

@@ -11,7 +11,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WXHIP_LIB") or os.path.join(PKG, "lib", "libwxhip.so")  # WXHIP_LIB: A/B variants
 
 WX_OK = 0
-WX_F64, WX_C128 = 0, 1
+WX_F64, WX_C128, WX_DUAL128 = 0, 1, 2
 WX_REGION_ALL, WX_REGION_INTERIOR, WX_REGION_BOUNDARY = 0, 1, 2
 
 

@@ -54,14 +54,14 @@ __device__ __forceinline__ void ausm_2d(const T* qL, const T* qR, int dir, T* f)
     const T uL = qL[1] * invL, wL = qL[2] * invL, uR = qR[1] * invR, wR = qR[2] * invR;
     const T pL = pressure_pow<T>(qL[3]), pR = pressure_pow<T>(qR[3]);
     const T aL = w_sqrt(kGamma * pL * invL), aR = w_sqrt(kGamma * pR * invR);
-    const T vL = dir == 0 ? uL : wL, vR = dir == 0 ? uR : wR;
+    const T vL = w_sel(dir == 0, uL, wL), vR = w_sel(dir == 0, uR, wR);
     const T ML = vL / aL + 1.0, MR = vR / aR - 1.0;
     const T M = 0.25 * (ML * ML - MR * MR);
     const T Mmax = w_max(T(0.0), M) * aL, Mmin = w_min(T(0.0), M) * aR;
     const T pf = 0.5 * (ML * pL - MR * pR);
     f[0] = qL[0] * Mmax + qR[0] * Mmin;
-    f[1] = dir == 0 ? pf : qL[1] * Mmax + qR[1] * Mmin;
-    f[2] = dir == 0 ? qL[2] * Mmax + qR[2] * Mmin : pf;
+    f[1] = w_sel(dir == 0, pf, qL[1] * Mmax + qR[1] * Mmin);
+    f[2] = w_sel(dir == 0, qL[2] * Mmax + qR[2] * Mmin, pf);
     f[3] = qL[3] * Mmax + qR[3] * Mmin;
 }
 
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64) void cart2d_rhs_kernel(const CartParams<T> P) {
         T out[4];
         if (wall) {
             const T p = pressure_pow<T>(qo[3]);
-            out[0] = T(0.0); out[1] = d == 0 ? p : T(0.0); out[2] = d == 0 ? T(0.0) : p; out[3] = T(0.0);
+            out[0] = T(0.0); out[1] = w_sel(d == 0, p, T(0.0)); out[2] = w_sel(d == 0, T(0.0), p); out[3] = T(0.0);
         } else if (plus) {
             ausm_2d<T>(qo, qn, d, out);
         } else {
@@ -292,6 +292,9 @@ wx_status wx_pointwise_eulercartesian_2d(const void* q, void* flux_x1, void* flu
     else if (dtype == WX_C128)
         hipLaunchKernelGGL((cart2d_pointwise_kernel<cplx>), dim3(grid), dim3(256), 0, st, (const cplx*)q, (cplx*)flux_x1,
                            (cplx*)flux_x3, npts);
+    else if (dtype == WX_DUAL128)
+        hipLaunchKernelGGL((cart2d_pointwise_kernel<dual>), dim3(grid), dim3(256), 0, st, (const dual*)q, (dual*)flux_x1,
+                           (dual*)flux_x3, npts);
     else
         return fail(WX_ERR_INVALID, "unknown dtype %d (the reference's CUDA dispatcher is silent here)", (int)dtype);
     WX_HIP_TRY(hipGetLastError());
@@ -315,6 +318,10 @@ wx_status wx_riemann_eulercartesian_ausm_2d(const void* q_itf_x1, const void* q_
         hipLaunchKernelGGL((cart2d_riemann_kernel<cplx>), dim3(grid), dim3(256), 0, st, (const cplx*)q_itf_x1,
                            (const cplx*)q_itf_x3, (cplx*)flux_itf_x1, (cplx*)flux_itf_x3, num_elem_x1, num_elem_x3,
                            num_solpts);
+    else if (dtype == WX_DUAL128)
+        hipLaunchKernelGGL((cart2d_riemann_kernel<dual>), dim3(grid), dim3(256), 0, st, (const dual*)q_itf_x1,
+                           (const dual*)q_itf_x3, (dual*)flux_itf_x1, (dual*)flux_itf_x3, num_elem_x1, num_elem_x3,
+                           num_solpts);
     else
         return fail(WX_ERR_INVALID, "unknown dtype %d", (int)dtype);
     WX_HIP_TRY(hipGetLastError());
@@ -336,6 +343,9 @@ wx_status wx_forcing_euler_cubesphere_3d(const void* q, const void* pressure, co
     else if (dtype == WX_C128)
         hipLaunchKernelGGL((euler3d_forcing_kernel<cplx>), dim3(grid), dim3(128), 0, st, (const cplx*)q,
                            (const cplx*)pressure, h, christoffel, (cplx*)forcing, npts);
+    else if (dtype == WX_DUAL128)
+        hipLaunchKernelGGL((euler3d_forcing_kernel<dual>), dim3(grid), dim3(128), 0, st, (const dual*)q,
+                           (const dual*)pressure, h, christoffel, (dual*)forcing, npts);
     else
         return fail(WX_ERR_INVALID, "unknown dtype %d", (int)dtype);
     WX_HIP_TRY(hipGetLastError());
@@ -348,7 +358,7 @@ wx_status wx_cart2d_plan_create(wx_cart2d_plan** out, int n, int num_elem_x1, in
     *out = nullptr;
     if (n < 2 || n > kMaxNc) return fail(WX_ERR_UNSUPPORTED, "num_solpts %d not in 2..%d", n, kMaxNc);
     if (num_elem_x1 < 1 || num_elem_x3 < 1 || !(dx1 > 0.0) || !(dx3 > 0.0)) return fail(WX_ERR_INVALID, "bad grid");
-    if (dtype != WX_F64 && dtype != WX_C128) return fail(WX_ERR_INVALID, "unknown dtype %d", (int)dtype);
+    if (dtype != WX_F64 && dtype != WX_C128 && dtype != WX_DUAL128) return fail(WX_ERR_INVALID, "unknown dtype %d", (int)dtype);
     if (!ops->extrap_neg || !ops->extrap_pos || !ops->diff_solpt || !ops->correction)
         return fail(WX_ERR_INVALID, "wx_dfr_ops has a null member");
     wx_cart2d_plan* pl = new (std::nothrow) wx_cart2d_plan();
@@ -386,6 +396,10 @@ wx_status wx_cart2d_rhs(wx_cart2d_plan* pl, const void* q, void* rhs, wx_stream 
     if (pl->dtype == WX_F64) {
         CartParams<double> P{pl->nx, pl->nz, -2.0 / pl->dx1, -2.0 / pl->dx3, (const double*)q, (double*)rhs, pl->consts};
         return cart_dispatch<double>(pl->n, P, st);
+    }
+    if (pl->dtype == WX_DUAL128) {
+        CartParams<dual> P{pl->nx, pl->nz, -2.0 / pl->dx1, -2.0 / pl->dx3, (const dual*)q, (dual*)rhs, pl->consts};
+        return cart_dispatch<dual>(pl->n, P, st);
     }
     CartParams<cplx> P{pl->nx, pl->nz, -2.0 / pl->dx1, -2.0 / pl->dx3, (const cplx*)q, (cplx*)rhs, pl->consts};
     return cart_dispatch<cplx>(pl->n, P, st);

@@ -294,8 +294,8 @@ __device__ __forceinline__ void rusanov_face(const T* qL, const T* qR, T unL, T 
     out[2] = 0.5 * ((sguL * qL[2] + sgh1 * pL) + (sguR * qR[2] + sgh1 * pR) - es * (qR[2] - qL[2]));
     out[3] = 0.5 * (sguL * qL[4] + sguR * qR[4] - es * (qR[4] - qL[4]));
     out[4] = 0.5 * (sguL * qL[3] + sguR * qR[3] - es * (qR[3] - qL[3]));
-    out[5] = 0.5 * (sgh2 * pL + sgh2 * pR) / (own_is_L ? pL : pR);
-    out[6] = own_is_L ? qL[6] : qR[6];
+    out[5] = 0.5 * (sgh2 * pL + sgh2 * pR) / w_sel(own_is_L, pL, pR);
+    out[6] = w_sel(own_is_L, qL[6], qR[6]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -426,12 +426,22 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
         const double sg = *sgp, h0 = hp[0], h1 = hp[hfs], h2 = hp[2 * hfs];
         const double hdd = d == 0 ? h0 : (d == 1 ? h1 : h2);
         const T ro = 1.0 / qo[0], rn = 1.0 / qn[0];
-        T uo = qo[1 + d] * ro;
-        T un = qn[1 + d] * rn;
+        // (explicit selects: a run-time index into a register array of 16-byte values goes to scratch)
+        T uo = w_sel(d == 0, qo[1], w_sel(d == 1, qo[2], qo[3])) * ro;
+        T un = w_sel(d == 0, qn[1], w_sel(d == 1, qn[2], qn[3])) * rn;
         if (mirror) un = -uo;  // no-flow wall: odd symmetry of w (pde_euler_cubesphere.py:150-156)
+        // left = plus-side state of the lower element, right = minus-side state of the upper one
+        // (by value with selects: passing swapped array pointers would push both arrays to scratch)
+        T qL[7], qR[7];
+#pragma unroll
+        for (int v = 0; v < 7; ++v) {
+            qL[v] = w_sel(plus != 0, qo[v], qn[v]);
+            qR[v] = w_sel(plus != 0, qn[v], qo[v]);
+        }
         T out[NC];
-        if (plus) rusanov_face<T>(qo, qn, uo, un, ro, rn, sg, h0, h1, h2, hdd, true, P.advection_only, out);
-        else rusanov_face<T>(qn, qo, un, uo, rn, ro, sg, h0, h1, h2, hdd, false, P.advection_only, out);
+        const bool pl = plus != 0;
+        rusanov_face<T>(qL, qR, w_sel(pl, uo, un), w_sel(pl, un, uo), w_sel(pl, ro, rn), w_sel(pl, rn, ro), sg, h0, h1,
+                        h2, hdd, pl, P.advection_only, out);
 #pragma unroll
         for (int c = 0; c < NC; ++c) fr[le][f][c][fp] = out[c];
     }
@@ -508,7 +518,7 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
 
 #pragma unroll 1
     for (int d = 0; d < 3; ++d) {
-        const T ud = d == 0 ? u1 : (d == 1 ? u2 : u3);
+        const T ud = w_sel(d == 0, u1, w_sel(d == 1, u2, u3));
 #if WX_K2_RELOAD_H
         double hd0 = 0, hd1 = 0, hd2 = 0;
         if (active) {
@@ -709,6 +719,33 @@ wx_status dispatch_rhs(int n, const EulerParams<T>& P, hipStream_t st) {
     return fail(WX_ERR_UNSUPPORTED, "num_solpts %d not in 2..8", n);
 }
 
+int region_count(int region, int H, int V);
+
+template <typename T>
+wx_status run_extrap(wx_euler3d_plan* pl, const void* q, void* const send[4], hipStream_t st) {
+    EulerParams<T> P = make_params<T>(pl);
+    P.q = static_cast<const T*>(q);
+    if (send) {
+        P.send_s = static_cast<T*>(send[0]); P.send_n = static_cast<T*>(send[1]);
+        P.send_w = static_cast<T*>(send[2]); P.send_e = static_cast<T*>(send[3]);
+    }
+    return dispatch_extrap<T>(pl->n, P, st);
+}
+
+template <typename T>
+wx_status run_rhs(wx_euler3d_plan* pl, const void* q, const void* const halo[4], void* out, wx_region region,
+                  hipStream_t st, int axpy, const void* y, double ca, double cb, double cc) {
+    EulerParams<T> P = make_params<T>(pl);
+    P.q = static_cast<const T*>(q); P.rhs = static_cast<T*>(out);
+    P.region = region; P.count = region_count(region, pl->H, pl->V);
+    P.axpy = axpy; P.ca = ca; P.cb = cb; P.cc = cc; P.y = static_cast<const T*>(y);
+    if (halo) {
+        P.halo_s = static_cast<const T*>(halo[0]); P.halo_n = static_cast<const T*>(halo[1]);
+        P.halo_w = static_cast<const T*>(halo[2]); P.halo_e = static_cast<const T*>(halo[3]);
+    }
+    return dispatch_rhs<T>(pl->n, P, st);
+}
+
 int region_count(int region, int H, int V) {
     const int w = H > 2 ? H - 2 : 0;
     if (region == WX_REGION_ALL) return V * H * H;
@@ -727,7 +764,7 @@ wx_status wx_euler3d_plan_create(wx_euler3d_plan** out, int n, int H, int V, int
     if (n < 2 || n > kMaxN) return fail(WX_ERR_UNSUPPORTED, "num_solpts %d not in 2..%d", n, kMaxN);
     if (H < 1 || V < 1) return fail(WX_ERR_INVALID, "bad tile size H=%d V=%d", H, V);
     if (panel < 0 || panel > 5) return fail(WX_ERR_INVALID, "panel %d not in 0..5", panel);
-    if (dtype != WX_F64 && dtype != WX_C128) return fail(WX_ERR_INVALID, "unknown dtype %d", (int)dtype);
+    if (dtype != WX_F64 && dtype != WX_C128 && dtype != WX_DUAL128) return fail(WX_ERR_INVALID, "unknown dtype %d", (int)dtype);
     if (!ops->extrap_neg || !ops->extrap_pos || !ops->diff_solpt || !ops->correction || !ops->highfilter)
         return fail(WX_ERR_INVALID, "wx_dfr_ops has a null member");
     if (!m->sqrtG || !m->h_contra || !m->christoffel || !m->inv_dzdeta || !m->sqrtG_itf_i || !m->sqrtG_itf_j ||
@@ -742,7 +779,7 @@ wx_status wx_euler3d_plan_create(wx_euler3d_plan** out, int n, int H, int V, int
     if (!pl) return fail(WX_ERR_NOMEM, "out of host memory");
     pl->n = n; pl->H = H; pl->V = V; pl->case_number = case_number; pl->panel = panel; pl->dtype = dtype;
     pl->nelem = (size_t)V * H * H;
-    const size_t esz = dtype == WX_C128 ? 16 : 8;
+    const size_t esz = dtype == WX_F64 ? 8 : 16;
     pl->itf_bytes = pl->nelem * 6 * NQ * n * n * esz;
     hipError_t e = hipMalloc(&pl->itf, pl->itf_bytes);
     if (e != hipSuccess) {
@@ -805,30 +842,19 @@ size_t wx_euler3d_edge_count(const wx_euler3d_plan* pl) {
 wx_status wx_euler3d_extrap_pack(wx_euler3d_plan* pl, const void* q, void* const send[4], wx_stream stream) {
     if (!pl || !q) return fail(WX_ERR_INVALID, "wx_euler3d_extrap_pack: null argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (pl->dtype == WX_F64) {
-        EulerParams<double> P = make_params<double>(pl);
-        P.q = static_cast<const double*>(q);
-        if (send) {
-            P.send_s = static_cast<double*>(send[0]); P.send_n = static_cast<double*>(send[1]);
-            P.send_w = static_cast<double*>(send[2]); P.send_e = static_cast<double*>(send[3]);
-        }
-        return dispatch_extrap<double>(pl->n, P, st);
+    switch (pl->dtype) {
+        case WX_F64: return run_extrap<double>(pl, q, send, st);
+        case WX_C128: return run_extrap<cplx>(pl, q, send, st);
+        case WX_DUAL128: return run_extrap<dual>(pl, q, send, st);
     }
-    EulerParams<cplx> P = make_params<cplx>(pl);
-    P.q = static_cast<const cplx*>(q);
-    if (send) {
-        P.send_s = static_cast<cplx*>(send[0]); P.send_n = static_cast<cplx*>(send[1]);
-        P.send_w = static_cast<cplx*>(send[2]); P.send_e = static_cast<cplx*>(send[3]);
-    }
-    return dispatch_extrap<cplx>(pl->n, P, st);
+    return fail(WX_ERR_INVALID, "bad plan dtype");
 }
 
 static wx_status euler3d_rhs_impl(wx_euler3d_plan* pl, const void* q, const void* const halo[4], void* out,
                                   wx_region region, wx_stream stream, int axpy, const void* y, double ca, double cb,
                                   double cc) {
     if (!pl || !q || !out) return fail(WX_ERR_INVALID, "wx_euler3d_rhs: null argument");
-    if (out == q)
-        return fail(WX_ERR_INVALID, "wx_euler3d_rhs: output must not alias the state (neighbours still read it)");
+    if (out == q) return fail(WX_ERR_INVALID, "wx_euler3d_rhs: output must not alias the state");
     if (region != WX_REGION_ALL && region != WX_REGION_INTERIOR && region != WX_REGION_BOUNDARY)
         return fail(WX_ERR_INVALID, "unknown region %d", (int)region);
     if (region != WX_REGION_INTERIOR) {
@@ -837,27 +863,12 @@ static wx_status euler3d_rhs_impl(wx_euler3d_plan* pl, const void* q, const void
             if (!halo[e]) return fail(WX_ERR_INVALID, "wx_euler3d_rhs: halo[%d] is null", e);
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int count = region_count(region, pl->H, pl->V);
-    if (pl->dtype == WX_F64) {
-        EulerParams<double> P = make_params<double>(pl);
-        P.q = static_cast<const double*>(q); P.rhs = static_cast<double*>(out);
-        P.region = region; P.count = count;
-        P.axpy = axpy; P.ca = ca; P.cb = cb; P.cc = cc; P.y = static_cast<const double*>(y);
-        if (halo) {
-            P.halo_s = static_cast<const double*>(halo[0]); P.halo_n = static_cast<const double*>(halo[1]);
-            P.halo_w = static_cast<const double*>(halo[2]); P.halo_e = static_cast<const double*>(halo[3]);
-        }
-        return dispatch_rhs<double>(pl->n, P, st);
+    switch (pl->dtype) {
+        case WX_F64: return run_rhs<double>(pl, q, halo, out, region, st, axpy, y, ca, cb, cc);
+        case WX_C128: return run_rhs<cplx>(pl, q, halo, out, region, st, axpy, y, ca, cb, cc);
+        case WX_DUAL128: return run_rhs<dual>(pl, q, halo, out, region, st, axpy, y, ca, cb, cc);
     }
-    EulerParams<cplx> P = make_params<cplx>(pl);
-    P.q = static_cast<const cplx*>(q); P.rhs = static_cast<cplx*>(out);
-    P.region = region; P.count = count;
-    P.axpy = axpy; P.ca = ca; P.cb = cb; P.cc = cc; P.y = static_cast<const cplx*>(y);
-    if (halo) {
-        P.halo_s = static_cast<const cplx*>(halo[0]); P.halo_n = static_cast<const cplx*>(halo[1]);
-        P.halo_w = static_cast<const cplx*>(halo[2]); P.halo_e = static_cast<const cplx*>(halo[3]);
-    }
-    return dispatch_rhs<cplx>(pl->n, P, st);
+    return fail(WX_ERR_INVALID, "bad plan dtype");
 }
 
 wx_status wx_euler3d_rhs(wx_euler3d_plan* pl, const void* q, const void* const halo[4], void* rhs, wx_region region,

@@ -214,14 +214,14 @@ __global__ __launch_bounds__(Cfg2<N>::BS) void sw_rhs_kernel(const SwParams<T> P
         T qL[3], qR[3];
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
-            qL[v] = plus ? qo[v] : qn[v];
-            qR[v] = plus ? qn[v] : qo[v];
+            qL[v] = w_sel(plus != 0, qo[v], qn[v]);
+            qR[v] = w_sel(plus != 0, qn[v], qo[v]);
         }
-        const T unL = d == 0 ? qL[1] : qL[2], unR = d == 0 ? qR[1] : qR[2];
+        const T unL = w_sel(d == 0, qL[1], qL[2]), unR = w_sel(d == 0, qR[1], qR[2]);
         const T aL = w_sqrt(kGravity * qL[0] * hdd), aR = w_sqrt(kGravity * qR[0] * hdd);
         const T tL = qL[0] * aL, tR = qR[0] * aR;
-        const T mL = (w_real(tL) != 0.0 || w_abs(tL) != 0.0) ? unL / tL : T(0.0);
-        const T mR = (w_real(tR) != 0.0 || w_abs(tR) != 0.0) ? unR / tR : T(0.0);
+        const T mL = w_sel(w_real(tL) != 0.0 || w_abs(tL) != 0.0, unL / tL, T(0.0));
+        const T mR = w_sel(w_real(tR) != 0.0 || w_abs(tR) != 0.0, unR / tR, T(0.0));
         const T M = 0.25 * ((mL + 1.0) * (mL + 1.0) - (mR - 1.0) * (mR - 1.0));
         const T Mp = w_max(T(0.0), M), Mm = w_min(T(0.0), M);
         T out[3];
@@ -233,8 +233,8 @@ __global__ __launch_bounds__(Cfg2<N>::BS) void sw_rhs_kernel(const SwParams<T> P
         const T podL = (sgg * hod) * hL2, podR = (sgg * hod) * hR2;
         const T pn = 0.5 * ((1.0 + mL) * pddL + (1.0 - mR) * pddR);  // on the normal component
         const T po = 0.5 * ((1.0 + mL) * podL + (1.0 - mR) * podR);  // on the other one
-        out[1] += d == 0 ? pn : po;
-        out[2] += d == 0 ? po : pn;
+        out[1] += w_sel(d == 0, pn, po);
+        out[2] += w_sel(d == 0, po, pn);
 #pragma unroll
         for (int v = 0; v < 3; ++v) fr[le][f][v][k] = out[v];
     }
@@ -270,11 +270,11 @@ __global__ __launch_bounds__(Cfg2<N>::BS) void sw_rhs_kernel(const SwParams<T> P
     T acc0 = T(0.0), acc1 = T(0.0), acc2 = T(0.0);
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
-        const T ud = d == 0 ? u1 : u2;
+        const T ud = w_sel(d == 0, u1, u2);
         const double ha = d == 0 ? h11 : h12, hb = d == 0 ? h21 : h22;
         if (d > 0) __syncthreads();
         if (le < EPB) {
-            fld[0][lpt] = sg * (d == 0 ? q1 : q2);
+            fld[0][lpt] = sg * w_sel(d == 0, q1, q2);
             fld[1][lpt] = sg * (q1 * ud + (0.5 * kGravity * ha) * hsq);
             fld[2][lpt] = sg * (q2 * ud + (0.5 * kGravity * hb) * hsq);
         }
@@ -362,6 +362,23 @@ wx_status sw_dispatch(int n, bool extrap, const SwParams<T>& P, hipStream_t st) 
     return fail(WX_ERR_UNSUPPORTED, "num_solpts %d not in 2..8", n);
 }
 
+template <typename T>
+wx_status sw_run(wx_sw_plan* pl, bool extrap, const void* q, void* const send[4], const void* const halo[4], void* rhs,
+                 int region, int count, hipStream_t st) {
+    SwParams<T> P = make_sw_params<T>(pl);
+    P.q = static_cast<const T*>(q); P.rhs = static_cast<T*>(rhs);
+    P.region = region; P.count = count;
+    if (send) {
+        P.send_s = static_cast<T*>(send[0]); P.send_n = static_cast<T*>(send[1]);
+        P.send_w = static_cast<T*>(send[2]); P.send_e = static_cast<T*>(send[3]);
+    }
+    if (halo) {
+        P.halo_s = static_cast<const T*>(halo[0]); P.halo_n = static_cast<const T*>(halo[1]);
+        P.halo_w = static_cast<const T*>(halo[2]); P.halo_e = static_cast<const T*>(halo[3]);
+    }
+    return sw_dispatch<T>(pl->n, extrap, P, st);
+}
+
 }  // namespace
 
 extern "C" {
@@ -373,7 +390,7 @@ wx_status wx_sw_plan_create(wx_sw_plan** out, int n, int H, wx_dtype dtype, int 
     if (n < 2 || n > kMaxN2) return fail(WX_ERR_UNSUPPORTED, "num_solpts %d not in 2..%d", n, kMaxN2);
     if (H < 1) return fail(WX_ERR_INVALID, "bad tile size H=%d", H);
     if (panel < 0 || panel > 5) return fail(WX_ERR_INVALID, "panel %d not in 0..5", panel);
-    if (dtype != WX_F64 && dtype != WX_C128) return fail(WX_ERR_INVALID, "unknown dtype %d", (int)dtype);
+    if (dtype != WX_F64 && dtype != WX_C128 && dtype != WX_DUAL128) return fail(WX_ERR_INVALID, "unknown dtype %d", (int)dtype);
     if (!ops->extrap_neg || !ops->extrap_pos || !ops->diff_solpt || !ops->correction)
         return fail(WX_ERR_INVALID, "wx_dfr_ops has a null member");
     const double* req[] = {m->sqrtG, m->H_contra_11, m->H_contra_12, m->H_contra_21, m->H_contra_22,
@@ -390,7 +407,7 @@ wx_status wx_sw_plan_create(wx_sw_plan** out, int n, int H, wx_dtype dtype, int 
     wx_sw_plan* pl = new (std::nothrow) wx_sw_plan();
     if (!pl) return fail(WX_ERR_NOMEM, "out of host memory");
     pl->n = n; pl->H = H; pl->panel = panel; pl->dtype = dtype;
-    const size_t esz = dtype == WX_C128 ? 16 : 8;
+    const size_t esz = dtype == WX_F64 ? 8 : 16;
     hipError_t e = hipMalloc(&pl->itf, (size_t)H * H * 4 * 3 * n * esz);
     if (e == hipSuccess) e = hipMalloc((void**)&pl->consts, sizeof(SwConsts));
     SwConsts hc;
@@ -440,22 +457,12 @@ size_t wx_sw_edge_count(const wx_sw_plan* pl) { return pl ? (size_t)3 * pl->H * 
 wx_status wx_sw_extrap_pack(wx_sw_plan* pl, const void* q, void* const send[4], wx_stream stream) {
     if (!pl || !q) return fail(WX_ERR_INVALID, "wx_sw_extrap_pack: null argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (pl->dtype == WX_F64) {
-        SwParams<double> P = make_sw_params<double>(pl);
-        P.q = static_cast<const double*>(q);
-        if (send) {
-            P.send_s = static_cast<double*>(send[0]); P.send_n = static_cast<double*>(send[1]);
-            P.send_w = static_cast<double*>(send[2]); P.send_e = static_cast<double*>(send[3]);
-        }
-        return sw_dispatch<double>(pl->n, true, P, st);
+    switch (pl->dtype) {
+        case WX_F64: return sw_run<double>(pl, true, q, send, nullptr, nullptr, 0, 0, st);
+        case WX_C128: return sw_run<cplx>(pl, true, q, send, nullptr, nullptr, 0, 0, st);
+        case WX_DUAL128: return sw_run<dual>(pl, true, q, send, nullptr, nullptr, 0, 0, st);
     }
-    SwParams<cplx> P = make_sw_params<cplx>(pl);
-    P.q = static_cast<const cplx*>(q);
-    if (send) {
-        P.send_s = static_cast<cplx*>(send[0]); P.send_n = static_cast<cplx*>(send[1]);
-        P.send_w = static_cast<cplx*>(send[2]); P.send_e = static_cast<cplx*>(send[3]);
-    }
-    return sw_dispatch<cplx>(pl->n, true, P, st);
+    return fail(WX_ERR_INVALID, "bad plan dtype");
 }
 
 wx_status wx_sw_rhs(wx_sw_plan* pl, const void* q, const void* const halo[4], void* rhs, wx_region region,
@@ -471,24 +478,12 @@ wx_status wx_sw_rhs(wx_sw_plan* pl, const void* q, const void* const halo[4], vo
     const int H = pl->H, w = H > 2 ? H - 2 : 0;
     const int count = region == WX_REGION_ALL ? H * H : (region == WX_REGION_INTERIOR ? w * w : H * H - w * w);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (pl->dtype == WX_F64) {
-        SwParams<double> P = make_sw_params<double>(pl);
-        P.q = static_cast<const double*>(q); P.rhs = static_cast<double*>(rhs);
-        P.region = region; P.count = count;
-        if (halo) {
-            P.halo_s = static_cast<const double*>(halo[0]); P.halo_n = static_cast<const double*>(halo[1]);
-            P.halo_w = static_cast<const double*>(halo[2]); P.halo_e = static_cast<const double*>(halo[3]);
-        }
-        return sw_dispatch<double>(pl->n, false, P, st);
+    switch (pl->dtype) {
+        case WX_F64: return sw_run<double>(pl, false, q, nullptr, halo, rhs, region, count, st);
+        case WX_C128: return sw_run<cplx>(pl, false, q, nullptr, halo, rhs, region, count, st);
+        case WX_DUAL128: return sw_run<dual>(pl, false, q, nullptr, halo, rhs, region, count, st);
     }
-    SwParams<cplx> P = make_sw_params<cplx>(pl);
-    P.q = static_cast<const cplx*>(q); P.rhs = static_cast<cplx*>(rhs);
-    P.region = region; P.count = count;
-    if (halo) {
-        P.halo_s = static_cast<const cplx*>(halo[0]); P.halo_n = static_cast<const cplx*>(halo[1]);
-        P.halo_w = static_cast<const cplx*>(halo[2]); P.halo_e = static_cast<const cplx*>(halo[3]);
-    }
-    return sw_dispatch<cplx>(pl->n, false, P, st);
+    return fail(WX_ERR_INVALID, "bad plan dtype");
 }
 
 }  // extern "C"

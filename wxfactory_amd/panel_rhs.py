@@ -24,8 +24,12 @@ def _ptr_array(items):
 
 class PanelRhs:
     def __init__(self, plans: Dict[int, object], exchange: PanelExchange = None, overlap: bool = True,
-                 rank: int = 0, world_size: int = 1, group=None, device=None, edge_count: int = 0):
+                 rank: int = 0, world_size: int = 1, group=None, device=None, edge_count: int = 0,
+                 complex_arith: str = "complex"):
         """`device` / `edge_count` are only needed by a rank that owns no panel (plans == {})."""
+        if complex_arith not in ("complex", "dual"):
+            raise ValueError("complex_arith must be 'complex' (true complex arithmetic) or 'dual' (first order)")
+        self.complex_arith = complex_arith
         self.panels = sorted(plans)
         self.overlap = overlap
         self.rank, self.world, self.group = rank, world_size, group
@@ -43,7 +47,7 @@ class PanelRhs:
     def plans_for(self, dtype):
         if dtype not in self._plans:
             base = next(iter(self._plans.values()))
-            self._plans[dtype] = {p: pl.twin(dtype) for p, pl in base.items()}
+            self._plans[dtype] = {p: pl.twin(dtype, dual=self.complex_arith == "dual") for p, pl in base.items()}
         return self._plans[dtype]
 
     def exchange_for(self, dtype):

@@ -29,10 +29,14 @@ class Euler3DPlan:
     (kept alive here) exactly as the reference's pde module borrows NumPy/CuPy buffers."""
 
     def __init__(self, n: int, H: int, V: int, case_number: int, panel: int, ops: Dict[str, numpy.ndarray],
-                 metric: Dict[str, torch.Tensor], dtype: torch.dtype = torch.float64):
+                 metric: Dict[str, torch.Tensor], dtype: torch.dtype = torch.float64, dual: bool = False):
         self.lib = _lib.load()
         if dtype not in _DTYPES:
             raise TypeError(f"dtype must be float64 or complex128, not {dtype}")
+        # complex128 storage can run true complex arithmetic (WX_C128) or first-order dual-number
+        # arithmetic (WX_DUAL128: same complex-step JVP to O(eps^2), much cheaper); see include/wxhip.h
+        self.dual = bool(dual) and dtype == torch.complex128
+        wx_dtype = _lib.WX_DUAL128 if self.dual else _DTYPES[dtype]
         self.n, self.H, self.V, self.case_number, self.panel, self.dtype = n, H, V, case_number, panel, dtype
         self.shape = (5, V, H, H, n**3)
         self._ops, self._metric = ops, metric
@@ -66,13 +70,14 @@ class Euler3DPlan:
             setattr(m, k, t.data_ptr())
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            check(self.lib.wx_euler3d_plan_create(ctypes.byref(self._h), n, H, V, case_number, _DTYPES[dtype], panel,
+            check(self.lib.wx_euler3d_plan_create(ctypes.byref(self._h), n, H, V, case_number, wx_dtype, panel,
                                                   ctypes.byref(o), ctypes.byref(m)), "wx_euler3d_plan_create")
         self.edge_count = int(self.lib.wx_euler3d_edge_count(self._h))
 
-    def twin(self, dtype):
+    def twin(self, dtype, dual: bool = False):
         """Plan of another dtype over the same (borrowed) metric tensors."""
-        return Euler3DPlan(self.n, self.H, self.V, self.case_number, self.panel, self._ops, self._metric, dtype=dtype)
+        return Euler3DPlan(self.n, self.H, self.V, self.case_number, self.panel, self._ops, self._metric, dtype=dtype,
+                           dual=dual)
 
     def _check_q(self, q):
         if q.dtype != self.dtype or q.numel() != 5 * self.V * self.H * self.H * self.n**3 or not q.is_contiguous() \

@@ -23,10 +23,14 @@ _TOPO = ("hsurf", "dzdx1", "dzdx2", "hsurf_itf_i", "hsurf_itf_j")
 
 class SwPlan:
     def __init__(self, n: int, H: int, panel: int, ops: Dict[str, numpy.ndarray], metric: Dict[str, torch.Tensor],
-                 dtype: torch.dtype = torch.float64):
+                 dtype: torch.dtype = torch.float64, dual: bool = False):
         self.lib = _lib.load()
         if dtype not in _DTYPES:
             raise TypeError(f"dtype must be float64 or complex128, not {dtype}")
+        # complex128 storage can run true complex arithmetic (WX_C128) or first-order dual-number
+        # arithmetic (WX_DUAL128: same complex-step JVP to O(eps^2), much cheaper); see include/wxhip.h
+        self.dual = bool(dual) and dtype == torch.complex128
+        wx_dtype = _lib.WX_DUAL128 if self.dual else _DTYPES[dtype]
         self.n, self.H, self.panel, self.dtype = n, H, panel, dtype
         self.shape = (3, H, H, n * n)
         self._ops, self._metric = ops, metric
@@ -59,12 +63,12 @@ class SwPlan:
             setattr(m, k, t.data_ptr())
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            check(self.lib.wx_sw_plan_create(ctypes.byref(self._h), n, H, _DTYPES[dtype], panel, ctypes.byref(o),
+            check(self.lib.wx_sw_plan_create(ctypes.byref(self._h), n, H, wx_dtype, panel, ctypes.byref(o),
                                              ctypes.byref(m)), "wx_sw_plan_create")
         self.edge_count = int(self.lib.wx_sw_edge_count(self._h))
 
-    def twin(self, dtype):
-        return SwPlan(self.n, self.H, self.panel, self._ops, self._metric, dtype=dtype)
+    def twin(self, dtype, dual: bool = False):
+        return SwPlan(self.n, self.H, self.panel, self._ops, self._metric, dtype=dtype, dual=dual)
 
     def _check_q(self, q):
         if q.dtype != self.dtype or q.numel() != 3 * self.H * self.H * self.n**2 or not q.is_contiguous() \
