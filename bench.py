@@ -100,7 +100,8 @@ def extras(dev, seed):
     return {"sw_s7": {"workload": "shallow water, n=8, H=60, 6 panels on 1 GPU (1244160 DOF), whole-sphere R(Q)",
                       "us_per_eval": te * 1e6, "dof_updates_per_s": dof / te,
                       "algorithmic_GBps": 156.0 * 6 * H * H * n * n / te / 1e9,
-                      "note": "12 launches of ~9 us: launch-latency bound (5.5 MB of state per panel)"}}
+                      "note": "all six panels in one launch per phase (wx_sw_batch_*): 2 launches per R(Q); launch-latency "
+                              "bound (5.5 MB of state per panel)"}}
 
 
 def main():

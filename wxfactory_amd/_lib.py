@@ -66,6 +66,10 @@ SIGNATURES = {
     "wx_sw_edge_count": (c_size_t, [c_void_p]),
     "wx_sw_extrap_pack": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p]),
     "wx_sw_rhs": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_int, c_void_p]),
+    "wx_sw_batch_create": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_int, c_void_p, c_void_p]),
+    "wx_sw_batch_destroy": (c_int, [c_void_p]),
+    "wx_sw_batch_extrap_pack": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wx_sw_batch_rhs": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "wx_pointwise_eulercartesian_2d": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "wx_riemann_eulercartesian_ausm_2d": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                                   c_void_p]),

@@ -36,11 +36,17 @@ struct SwConsts {
     int flip[4];
 };
 
+// per-launch part (state, result, which elements); everything else is static per plan
 template <typename T>
-struct SwParams {
-    int H, nelem, count, region, has_topo;
+struct SwDyn {
     const T* q;
     T* rhs;
+    int count, region;
+};
+
+template <typename T>
+struct SwParams {
+    int H, nelem, has_topo;
     T* itf;  // [elem][4 faces W,E,S,N][3 vars][N]
     const T *halo_s, *halo_n, *halo_w, *halo_e;
     T *send_s, *send_n, *send_w, *send_e;
@@ -89,7 +95,7 @@ __device__ __forceinline__ Elem2 decode_elem2(int slot, int count, int region, i
 
 // ------------------------------------------------------------------------------------------------
 template <int N, typename T>
-__global__ __launch_bounds__(Cfg2<N>::BS) void sw_extrap_kernel(const SwParams<T> P) {
+__device__ __forceinline__ void sw_extrap_body(const SwParams<T> P, const SwDyn<T> D) {
     using C = Cfg2<N>;
     constexpr int N2 = C::N2, EPB = C::EPB, BS = C::BS;
     __shared__ T fld[3][EPB * C::LE];
@@ -102,11 +108,11 @@ __global__ __launch_bounds__(Cfg2<N>::BS) void sw_extrap_kernel(const SwParams<T
         if (le < EPB && el.valid) {
             const size_t o = (size_t)el.e * N2 + pt;
             const int lp = le * C::LE + C::lidx(pt / N, pt % N);
-            T h = P.q[o];
+            T h = D.q[o];
             if (P.has_topo) h = h + P.hsurf[o];
             fld[0][lp] = h;
-            fld[1][lp] = P.q[fs + o];
-            fld[2][lp] = P.q[2 * fs + o];
+            fld[1][lp] = D.q[fs + o];
+            fld[2][lp] = D.q[2 * fs + o];
         }
     }
     __syncthreads();
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(Cfg2<N>::BS) void sw_extrap_kernel(const SwParams<T
 
 // ------------------------------------------------------------------------------------------------
 template <int N, typename T>
-__global__ __launch_bounds__(Cfg2<N>::BS) void sw_rhs_kernel(const SwParams<T> P) {
+__device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> D) {
     using C = Cfg2<N>;
     constexpr int N2 = C::N2, EPB = C::EPB, BS = C::BS;
     __shared__ T fld[3][EPB * C::LE];
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(Cfg2<N>::BS) void sw_rhs_kernel(const SwParams<T> P
         const int le = fi / (4 * N);
         const int r = fi % (4 * N);
         const int f = r / N, k = r % N;
-        const Elem2 el = decode_elem2(blockIdx.x * EPB + le, P.count, P.region, H);
+        const Elem2 el = decode_elem2(blockIdx.x * EPB + le, D.count, D.region, H);
         if (!el.valid) continue;
         const int d = f >> 1, plus = f & 1;
         const T* own = P.itf + ((size_t)el.e * 4 + f) * 3 * N + k;
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(Cfg2<N>::BS) void sw_rhs_kernel(const SwParams<T> P
 
     // ---- point stage
     const int le = tid / N2, pt = tid % N2;
-    const Elem2 el = decode_elem2(blockIdx.x * EPB + le, P.count, P.region, H);
+    const Elem2 el = decode_elem2(blockIdx.x * EPB + le, D.count, D.region, H);
     const bool active = (le < EPB) && el.valid;
     const int jl = pt / N, il = pt % N;
     const int lf = le < EPB ? le : 0;
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(Cfg2<N>::BS) void sw_rhs_kernel(const SwParams<T> P
     T q0 = T(1.0), q1 = T(0.0), q2 = T(0.0);
     double sg = 1.0, h11 = 0, h12 = 0, h21 = 0, h22 = 0;
     if (active) {
-        q0 = P.q[o]; q1 = P.q[fs + o]; q2 = P.q[2 * fs + o];
+        q0 = D.q[o]; q1 = D.q[fs + o]; q2 = D.q[2 * fs + o];
         sg = P.sg[o];
         h11 = P.h11[o]; h12 = P.h12[o]; h21 = P.h21[o]; h22 = P.h22[o];
     }
@@ -299,9 +305,33 @@ __global__ __launch_bounds__(Cfg2<N>::BS) void sw_rhs_kernel(const SwParams<T> P
     }
     if (!active) return;
     const double inv_sg = 1.0 / sg;
-    P.rhs[o] = inv_sg * (-acc0);
-    P.rhs[fs + o] = inv_sg * (-acc1) - forc1;
-    P.rhs[2 * fs + o] = inv_sg * (-acc2) - forc2;
+    D.rhs[o] = inv_sg * (-acc0);
+    D.rhs[fs + o] = inv_sg * (-acc1) - forc1;
+    D.rhs[2 * fs + o] = inv_sg * (-acc2) - forc2;
+}
+
+// one tile per launch: parameters by value
+template <int N, typename T>
+__global__ __launch_bounds__(Cfg2<N>::BS) void sw_extrap_kernel(const SwParams<T> P, const SwDyn<T> D) {
+    sw_extrap_body<N, T>(P, D);
+}
+template <int N, typename T>
+__global__ __launch_bounds__(Cfg2<N>::BS) void sw_rhs_kernel(const SwParams<T> P, const SwDyn<T> D) {
+    sw_rhs_body<N, T>(P, D);
+}
+// several tiles (the panels one rank owns) per launch: blockIdx.y selects the tile's static parameters
+// from a device-resident table; states/results are slices of one stacked array
+template <int N, typename T>
+__global__ __launch_bounds__(Cfg2<N>::BS) void sw_extrap_batch_kernel(const SwParams<T>* __restrict__ PB, const T* q,
+                                                                     size_t stride) {
+    SwDyn<T> D{q + (size_t)blockIdx.y * stride, nullptr, 0, 0};
+    sw_extrap_body<N, T>(PB[blockIdx.y], D);
+}
+template <int N, typename T>
+__global__ __launch_bounds__(Cfg2<N>::BS) void sw_rhs_batch_kernel(const SwParams<T>* __restrict__ PB, const T* q, T* rhs,
+                                                                  size_t stride, int count, int region) {
+    SwDyn<T> D{q + (size_t)blockIdx.y * stride, rhs + (size_t)blockIdx.y * stride, count, region};
+    sw_rhs_body<N, T>(PB[blockIdx.y], D);
 }
 
 }  // namespace wx
@@ -317,14 +347,21 @@ struct wx_sw_plan {
     SwParams<double> base;
 };
 
+// Several plans driven by one launch per phase (the panels one rank owns; S7 is launch-bound).
+struct wx_sw_batch {
+    int n, H, count;
+    wx_dtype dtype;
+    void* table = nullptr;  // device: SwParams<T>[count]
+};
+
 namespace {
 
 template <typename T>
 SwParams<T> make_sw_params(const wx_sw_plan* pl) {
     SwParams<T> P;
     const SwParams<double>& b = pl->base;
-    P.H = b.H; P.nelem = b.nelem; P.count = 0; P.region = 0; P.has_topo = b.has_topo;
-    P.q = nullptr; P.rhs = nullptr; P.itf = static_cast<T*>(pl->itf);
+    P.H = b.H; P.nelem = b.nelem; P.has_topo = b.has_topo;
+    P.itf = static_cast<T*>(pl->itf);
     P.halo_s = P.halo_n = P.halo_w = P.halo_e = nullptr;
     P.send_s = P.send_n = P.send_w = P.send_e = nullptr;
     P.sg = b.sg; P.h11 = b.h11; P.h12 = b.h12; P.h21 = b.h21; P.h22 = b.h22;
@@ -336,38 +373,8 @@ SwParams<T> make_sw_params(const wx_sw_plan* pl) {
     return P;
 }
 
-template <int N, typename T>
-wx_status sw_launch(bool extrap, const SwParams<T>& P, hipStream_t st) {
-    using C = Cfg2<N>;
-    const int cnt = extrap ? P.nelem : P.count;
-    if (cnt == 0) return WX_OK;
-    const int grid = (cnt + C::EPB - 1) / C::EPB;
-    if (extrap) hipLaunchKernelGGL((sw_extrap_kernel<N, T>), dim3(grid), dim3(C::BS), 0, st, P);
-    else hipLaunchKernelGGL((sw_rhs_kernel<N, T>), dim3(grid), dim3(C::BS), 0, st, P);
-    WX_HIP_TRY(hipGetLastError());
-    return WX_OK;
-}
-
 template <typename T>
-wx_status sw_dispatch(int n, bool extrap, const SwParams<T>& P, hipStream_t st) {
-    switch (n) {
-        case 2: return sw_launch<2, T>(extrap, P, st);
-        case 3: return sw_launch<3, T>(extrap, P, st);
-        case 4: return sw_launch<4, T>(extrap, P, st);
-        case 5: return sw_launch<5, T>(extrap, P, st);
-        case 6: return sw_launch<6, T>(extrap, P, st);
-        case 7: return sw_launch<7, T>(extrap, P, st);
-        case 8: return sw_launch<8, T>(extrap, P, st);
-    }
-    return fail(WX_ERR_UNSUPPORTED, "num_solpts %d not in 2..8", n);
-}
-
-template <typename T>
-wx_status sw_run(wx_sw_plan* pl, bool extrap, const void* q, void* const send[4], const void* const halo[4], void* rhs,
-                 int region, int count, hipStream_t st) {
-    SwParams<T> P = make_sw_params<T>(pl);
-    P.q = static_cast<const T*>(q); P.rhs = static_cast<T*>(rhs);
-    P.region = region; P.count = count;
+void set_edges(SwParams<T>& P, void* const send[4], const void* const halo[4]) {
     if (send) {
         P.send_s = static_cast<T*>(send[0]); P.send_n = static_cast<T*>(send[1]);
         P.send_w = static_cast<T*>(send[2]); P.send_e = static_cast<T*>(send[3]);
@@ -376,7 +383,76 @@ wx_status sw_run(wx_sw_plan* pl, bool extrap, const void* q, void* const send[4]
         P.halo_s = static_cast<const T*>(halo[0]); P.halo_n = static_cast<const T*>(halo[1]);
         P.halo_w = static_cast<const T*>(halo[2]); P.halo_e = static_cast<const T*>(halo[3]);
     }
-    return sw_dispatch<T>(pl->n, extrap, P, st);
+}
+
+int sw_region_count(int region, int H) {
+    const int w = H > 2 ? H - 2 : 0;
+    return region == WX_REGION_ALL ? H * H : (region == WX_REGION_INTERIOR ? w * w : H * H - w * w);
+}
+
+// what: 0 single extrap, 1 single rhs, 2 batch extrap, 3 batch rhs
+template <int N, typename T>
+wx_status sw_launch(int what, const SwParams<T>* P, const SwDyn<T>& D, const SwParams<T>* table, int nb, size_t stride,
+                    hipStream_t st) {
+    using C = Cfg2<N>;
+    const int cnt = (what == 0 || what == 2) ? (P ? P->nelem : D.count) : D.count;
+    if (cnt == 0) return WX_OK;
+    const int grid = (cnt + C::EPB - 1) / C::EPB;
+    switch (what) {
+        case 0: hipLaunchKernelGGL((sw_extrap_kernel<N, T>), dim3(grid), dim3(C::BS), 0, st, *P, D); break;
+        case 1: hipLaunchKernelGGL((sw_rhs_kernel<N, T>), dim3(grid), dim3(C::BS), 0, st, *P, D); break;
+        case 2: hipLaunchKernelGGL((sw_extrap_batch_kernel<N, T>), dim3(grid, nb), dim3(C::BS), 0, st, table, D.q, stride); break;
+        default: hipLaunchKernelGGL((sw_rhs_batch_kernel<N, T>), dim3(grid, nb), dim3(C::BS), 0, st, table, D.q, D.rhs,
+                                    stride, D.count, D.region);
+    }
+    WX_HIP_TRY(hipGetLastError());
+    return WX_OK;
+}
+
+template <typename T>
+wx_status sw_dispatch(int n, int what, const SwParams<T>* P, const SwDyn<T>& D, const SwParams<T>* table, int nb,
+                      size_t stride, hipStream_t st) {
+    switch (n) {
+        case 2: return sw_launch<2, T>(what, P, D, table, nb, stride, st);
+        case 3: return sw_launch<3, T>(what, P, D, table, nb, stride, st);
+        case 4: return sw_launch<4, T>(what, P, D, table, nb, stride, st);
+        case 5: return sw_launch<5, T>(what, P, D, table, nb, stride, st);
+        case 6: return sw_launch<6, T>(what, P, D, table, nb, stride, st);
+        case 7: return sw_launch<7, T>(what, P, D, table, nb, stride, st);
+        case 8: return sw_launch<8, T>(what, P, D, table, nb, stride, st);
+    }
+    return fail(WX_ERR_UNSUPPORTED, "num_solpts %d not in 2..8", n);
+}
+
+template <typename T>
+wx_status sw_run(wx_sw_plan* pl, bool extrap, const void* q, void* const send[4], const void* const halo[4], void* rhs,
+                 int region, int count, hipStream_t st) {
+    SwParams<T> P = make_sw_params<T>(pl);
+    set_edges<T>(P, send, halo);
+    SwDyn<T> D{static_cast<const T*>(q), static_cast<T*>(rhs), count, region};
+    return sw_dispatch<T>(pl->n, extrap ? 0 : 1, &P, D, nullptr, 0, 0, st);
+}
+
+template <typename T>
+wx_status sw_batch_build(wx_sw_batch* b, wx_sw_plan* const plans[], int count, void* const send[][4],
+                         const void* const halo[][4]) {
+    SwParams<T>* host = new (std::nothrow) SwParams<T>[count];
+    if (!host) return fail(WX_ERR_NOMEM, "out of host memory");
+    for (int i = 0; i < count; ++i) {
+        host[i] = make_sw_params<T>(plans[i]);
+        set_edges<T>(host[i], send[i], halo[i]);
+    }
+    hipError_t e = hipMalloc(&b->table, sizeof(SwParams<T>) * count);
+    if (e == hipSuccess) e = hipMemcpy(b->table, host, sizeof(SwParams<T>) * count, hipMemcpyHostToDevice);
+    delete[] host;
+    if (e != hipSuccess) return fail(WX_ERR_HIP, "wx_sw_batch_create: %s", hipGetErrorString(e));
+    return WX_OK;
+}
+
+template <typename T>
+wx_status sw_batch_run(wx_sw_batch* b, bool extrap, const void* q, void* rhs, size_t stride, int region, hipStream_t st) {
+    SwDyn<T> D{static_cast<const T*>(q), static_cast<T*>(rhs), extrap ? b->H * b->H : sw_region_count(region, b->H), region};
+    return sw_dispatch<T>(b->n, extrap ? 2 : 3, nullptr, D, static_cast<const SwParams<T>*>(b->table), b->count, stride, st);
 }
 
 }  // namespace
@@ -475,8 +551,7 @@ wx_status wx_sw_rhs(wx_sw_plan* pl, const void* q, const void* const halo[4], vo
         for (int e = 0; e < 4; ++e)
             if (!halo[e]) return fail(WX_ERR_INVALID, "wx_sw_rhs: halo[%d] is null", e);
     }
-    const int H = pl->H, w = H > 2 ? H - 2 : 0;
-    const int count = region == WX_REGION_ALL ? H * H : (region == WX_REGION_INTERIOR ? w * w : H * H - w * w);
+    const int count = sw_region_count(region, pl->H);
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (pl->dtype) {
         case WX_F64: return sw_run<double>(pl, false, q, nullptr, halo, rhs, region, count, st);
@@ -484,6 +559,66 @@ wx_status wx_sw_rhs(wx_sw_plan* pl, const void* q, const void* const halo[4], vo
         case WX_DUAL128: return sw_run<dual>(pl, false, q, nullptr, halo, rhs, region, count, st);
     }
     return fail(WX_ERR_INVALID, "bad plan dtype");
+}
+
+wx_status wx_sw_batch_create(wx_sw_batch** out, wx_sw_plan* const plans[], int count, void* const send[][4],
+                             const void* const halo[][4]) {
+    if (!out || !plans || !send || !halo || count < 1) return fail(WX_ERR_INVALID, "wx_sw_batch_create: bad argument");
+    *out = nullptr;
+    for (int i = 0; i < count; ++i) {
+        if (!plans[i]) return fail(WX_ERR_INVALID, "wx_sw_batch_create: plans[%d] is null", i);
+        if (plans[i]->n != plans[0]->n || plans[i]->H != plans[0]->H || plans[i]->dtype != plans[0]->dtype)
+            return fail(WX_ERR_INVALID, "wx_sw_batch_create: plans differ in n, H or dtype");
+        for (int e = 0; e < 4; ++e)
+            if (!send[i][e] || !halo[i][e]) return fail(WX_ERR_INVALID, "wx_sw_batch_create: null edge buffer");
+    }
+    wx_sw_batch* b = new (std::nothrow) wx_sw_batch();
+    if (!b) return fail(WX_ERR_NOMEM, "out of host memory");
+    b->n = plans[0]->n; b->H = plans[0]->H; b->count = count; b->dtype = plans[0]->dtype;
+    wx_status st;
+    switch (b->dtype) {
+        case WX_F64: st = sw_batch_build<double>(b, plans, count, send, halo); break;
+        case WX_C128: st = sw_batch_build<cplx>(b, plans, count, send, halo); break;
+        default: st = sw_batch_build<dual>(b, plans, count, send, halo);
+    }
+    if (st != WX_OK) {
+        if (b->table) (void)hipFree(b->table);
+        delete b;
+        return st;
+    }
+    *out = b;
+    return WX_OK;
+}
+
+wx_status wx_sw_batch_destroy(wx_sw_batch* b) {
+    if (!b) return WX_OK;
+    hipError_t e = hipFree(b->table);
+    delete b;
+    if (e != hipSuccess) return fail(WX_ERR_HIP, "hipFree failed: %s", hipGetErrorString(e));
+    return WX_OK;
+}
+
+wx_status wx_sw_batch_extrap_pack(wx_sw_batch* b, const void* q, size_t panel_stride, wx_stream stream) {
+    if (!b || !q) return fail(WX_ERR_INVALID, "wx_sw_batch_extrap_pack: null argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (b->dtype) {
+        case WX_F64: return sw_batch_run<double>(b, true, q, nullptr, panel_stride, 0, st);
+        case WX_C128: return sw_batch_run<cplx>(b, true, q, nullptr, panel_stride, 0, st);
+        default: return sw_batch_run<dual>(b, true, q, nullptr, panel_stride, 0, st);
+    }
+}
+
+wx_status wx_sw_batch_rhs(wx_sw_batch* b, const void* q, void* rhs, size_t panel_stride, wx_region region,
+                          wx_stream stream) {
+    if (!b || !q || !rhs) return fail(WX_ERR_INVALID, "wx_sw_batch_rhs: null argument");
+    if (region != WX_REGION_ALL && region != WX_REGION_INTERIOR && region != WX_REGION_BOUNDARY)
+        return fail(WX_ERR_INVALID, "unknown region %d", (int)region);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (b->dtype) {
+        case WX_F64: return sw_batch_run<double>(b, false, q, rhs, panel_stride, region, st);
+        case WX_C128: return sw_batch_run<cplx>(b, false, q, rhs, panel_stride, region, st);
+        default: return sw_batch_run<dual>(b, false, q, rhs, panel_stride, region, st);
+    }
 }
 
 }  // extern "C"

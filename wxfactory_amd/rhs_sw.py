@@ -100,6 +100,79 @@ class SwPlan:
             pass
 
 
+class SwBatch:
+    """All panels of a rank in one launch per phase (wx_sw_batch_*): the edge buffers are the
+    exchange's persistent send/halo slots, the states are slices of one stacked tensor."""
+
+    def __init__(self, plans: Dict[int, SwPlan], exchange: PanelExchange):
+        self.lib = _lib.load()
+        self.panels = sorted(plans)
+        n = len(self.panels)
+        first = plans[self.panels[0]]
+        self.device, self.dtype = first.device, first.dtype
+        self.stride = 3 * first.H * first.H * first.n**2
+        handles = (ctypes.c_void_p * n)(*[plans[p]._h for p in self.panels])
+        send = ((ctypes.c_void_p * 4) * n)()
+        halo = ((ctypes.c_void_p * 4) * n)()
+        for i, p in enumerate(self.panels):
+            for e in range(4):
+                send[i][e] = exchange.send_view(p, e).data_ptr()
+                halo[i][e] = exchange.halo_view(p, e).data_ptr()
+        self._keep = (plans, exchange)
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            check(self.lib.wx_sw_batch_create(ctypes.byref(self._h), handles, n, send, halo), "wx_sw_batch_create")
+
+    def extrap_pack(self, q):
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.wx_sw_batch_extrap_pack(self._h, q.data_ptr(), self.stride, st), "wx_sw_batch_extrap_pack")
+
+    def rhs(self, q, out, region):
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.wx_sw_batch_rhs(self._h, q.data_ptr(), out.data_ptr(), self.stride, region, st), "wx_sw_batch_rhs")
+
+    def close(self):
+        if self._h:
+            self.lib.wx_sw_batch_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class RhsShallowWater(PanelRhs):
     """R(Q) for the panels this rank owns; same calling convention as RhsEuler3D
-    (contract of rhs/rhs_sw.py:38-56)."""
+    (contract of rhs/rhs_sw.py:38-56).  A stacked, contiguous state of several panels is evaluated
+    with ONE launch per phase for all of them (SwBatch)."""
+
+    batched = True
+
+    def _run(self, qs, ys, coef, dtype):
+        if (self.batched and coef is None and isinstance(qs, torch.Tensor) and len(self.panels) > 1
+                and qs.is_contiguous() and qs.numel() == len(self.panels) * 3 * self.panel_shape[1] ** 2 * self.panel_shape[3]):
+            return self._run_batched(qs)
+        return super()._run(qs, ys, coef, dtype)
+
+    def _run_batched(self, q):
+        dt = q.dtype
+        plans, ex = self.plans_for(dt), self.exchange_for(dt)
+        if not hasattr(self, "_batches"):
+            self._batches = {}
+        if dt not in self._batches:
+            self._batches[dt] = SwBatch(plans, ex)
+        b = self._batches[dt]
+        out = torch.empty_like(q)
+        b.extrap_pack(q)
+        if ex.needs_comm and self.overlap:
+            ex.start()
+            b.rhs(q, out, _lib.WX_REGION_INTERIOR)
+            ex.wait()
+            b.rhs(q, out, _lib.WX_REGION_BOUNDARY)
+        else:
+            ex.start()
+            ex.wait()
+            b.rhs(q, out, _lib.WX_REGION_ALL)
+        return out
