@@ -141,6 +141,12 @@ wx_status wx_euler3d_rhs(wx_euler3d_plan* plan, const void* q, const void* const
  * faces through the interface buffer, but the INTERIOR/BOUNDARY launches both read q itself). */
 wx_status wx_euler3d_rhs_axpy(wx_euler3d_plan* plan, const void* q, const void* const halo[4], const void* y, void* out,
                               double a, double b, double c, wx_region region, wx_stream stream);
+/* ... and with a second array:  out = a*y + b*q + c*R(q) + d*z.  With q = Q + eps*v, y = v, z = R(Q),
+ * (a,b,c,d) = (1, 0, -dt/(2 eps), +dt/(2 eps)) this is the Rosenbrock operator of solvers/matvec.py:76-88
+ * (matvec_rat) in one launch; (0, 0, dt/eps, -dt/eps) is the finite-difference matvec_fun (:62-66). */
+wx_status wx_euler3d_rhs_axpy2(wx_euler3d_plan* plan, const void* q, const void* const halo[4], const void* y,
+                               const void* z, void* out, double a, double b, double c, double d, wx_region region,
+                               wx_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Shallow water on a cubed-sphere tile.

@@ -61,6 +61,8 @@ SIGNATURES = {
     "wx_euler3d_rhs": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_int, c_void_p]),
     "wx_euler3d_rhs_axpy": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_double, c_double,
                                     c_double, c_int, c_void_p]),
+    "wx_euler3d_rhs_axpy2": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_double,
+                                     c_double, c_double, c_double, c_int, c_void_p]),
     "wx_sw_plan_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, POINTER(DfrOps), POINTER(SwMetric)]),
     "wx_sw_plan_destroy": (c_int, [c_void_p]),
     "wx_sw_edge_count": (c_size_t, [c_void_p]),

@@ -98,9 +98,10 @@ template <typename T>
 struct EulerParams {
     int H, V, nelem, count, region;
     int advection_only, has_damp;
-    int axpy;              // 1: out = ca*y + cb*q + cc*R(q) (explicit RK stage), 0: out = R(q)
-    double ca, cb, cc;
+    int axpy;              // 1: out = ca*y + cb*q + cc*R(q) + cd*z (RK stage / FD Jacobian operator), 0: out = R(q)
+    double ca, cb, cc, cd;
     const T* y;            // nullable (then ca is ignored)
+    const T* z;            // nullable (then cd is ignored)
     const T* q;
     T* rhs;
     T* itf;  // [elem][6 faces][NQ = 5 vars + pressure + log pressure][N2]
@@ -617,6 +618,10 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
             r0 += P.ca * P.y[o]; r1 += P.ca * P.y[fs + o]; r2 += P.ca * P.y[2 * fs + o];
             r3 += P.ca * P.y[3 * fs + o]; r4 += P.ca * P.y[4 * fs + o];
         }
+        if (P.z != nullptr) {
+            r0 += P.cd * P.z[o]; r1 += P.cd * P.z[fs + o]; r2 += P.cd * P.z[2 * fs + o];
+            r3 += P.cd * P.z[3 * fs + o]; r4 += P.cd * P.z[4 * fs + o];
+        }
     }
     P.rhs[o] = r0;
     P.rhs[fs + o] = r1;
@@ -680,7 +685,7 @@ EulerParams<T> make_params(const wx_euler3d_plan* pl) {
     P.H = b.H; P.V = b.V; P.nelem = b.nelem; P.count = b.count; P.region = b.region;
     P.advection_only = b.advection_only; P.has_damp = b.has_damp;
     P.q = nullptr; P.rhs = nullptr; P.itf = static_cast<T*>(pl->itf);
-    P.axpy = 0; P.ca = P.cb = 0.0; P.cc = 1.0; P.y = nullptr;
+    P.axpy = 0; P.ca = P.cb = P.cd = 0.0; P.cc = 1.0; P.y = nullptr; P.z = nullptr;
     P.halo_s = P.halo_n = P.halo_w = P.halo_e = nullptr;
     P.send_s = P.send_n = P.send_w = P.send_e = nullptr;
     P.K = pl->consts;
@@ -734,11 +739,12 @@ wx_status run_extrap(wx_euler3d_plan* pl, const void* q, void* const send[4], hi
 
 template <typename T>
 wx_status run_rhs(wx_euler3d_plan* pl, const void* q, const void* const halo[4], void* out, wx_region region,
-                  hipStream_t st, int axpy, const void* y, double ca, double cb, double cc) {
+                  hipStream_t st, int axpy, const void* y, double ca, double cb, double cc, const void* z, double cd) {
     EulerParams<T> P = make_params<T>(pl);
     P.q = static_cast<const T*>(q); P.rhs = static_cast<T*>(out);
     P.region = region; P.count = region_count(region, pl->H, pl->V);
-    P.axpy = axpy; P.ca = ca; P.cb = cb; P.cc = cc; P.y = static_cast<const T*>(y);
+    P.axpy = axpy; P.ca = ca; P.cb = cb; P.cc = cc; P.cd = cd;
+    P.y = static_cast<const T*>(y); P.z = static_cast<const T*>(z);
     if (halo) {
         P.halo_s = static_cast<const T*>(halo[0]); P.halo_n = static_cast<const T*>(halo[1]);
         P.halo_w = static_cast<const T*>(halo[2]); P.halo_e = static_cast<const T*>(halo[3]);
@@ -852,7 +858,7 @@ wx_status wx_euler3d_extrap_pack(wx_euler3d_plan* pl, const void* q, void* const
 
 static wx_status euler3d_rhs_impl(wx_euler3d_plan* pl, const void* q, const void* const halo[4], void* out,
                                   wx_region region, wx_stream stream, int axpy, const void* y, double ca, double cb,
-                                  double cc) {
+                                  double cc, const void* z, double cd) {
     if (!pl || !q || !out) return fail(WX_ERR_INVALID, "wx_euler3d_rhs: null argument");
     if (out == q) return fail(WX_ERR_INVALID, "wx_euler3d_rhs: output must not alias the state");
     if (region != WX_REGION_ALL && region != WX_REGION_INTERIOR && region != WX_REGION_BOUNDARY)
@@ -864,21 +870,27 @@ static wx_status euler3d_rhs_impl(wx_euler3d_plan* pl, const void* q, const void
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (pl->dtype) {
-        case WX_F64: return run_rhs<double>(pl, q, halo, out, region, st, axpy, y, ca, cb, cc);
-        case WX_C128: return run_rhs<cplx>(pl, q, halo, out, region, st, axpy, y, ca, cb, cc);
-        case WX_DUAL128: return run_rhs<dual>(pl, q, halo, out, region, st, axpy, y, ca, cb, cc);
+        case WX_F64: return run_rhs<double>(pl, q, halo, out, region, st, axpy, y, ca, cb, cc, z, cd);
+        case WX_C128: return run_rhs<cplx>(pl, q, halo, out, region, st, axpy, y, ca, cb, cc, z, cd);
+        case WX_DUAL128: return run_rhs<dual>(pl, q, halo, out, region, st, axpy, y, ca, cb, cc, z, cd);
     }
     return fail(WX_ERR_INVALID, "bad plan dtype");
 }
 
 wx_status wx_euler3d_rhs(wx_euler3d_plan* pl, const void* q, const void* const halo[4], void* rhs, wx_region region,
                          wx_stream stream) {
-    return euler3d_rhs_impl(pl, q, halo, rhs, region, stream, 0, nullptr, 0.0, 0.0, 1.0);
+    return euler3d_rhs_impl(pl, q, halo, rhs, region, stream, 0, nullptr, 0.0, 0.0, 1.0, nullptr, 0.0);
 }
 
 wx_status wx_euler3d_rhs_axpy(wx_euler3d_plan* pl, const void* q, const void* const halo[4], const void* y, void* out,
                               double a, double b, double c, wx_region region, wx_stream stream) {
-    return euler3d_rhs_impl(pl, q, halo, out, region, stream, 1, y, a, b, c);
+    return euler3d_rhs_impl(pl, q, halo, out, region, stream, 1, y, a, b, c, nullptr, 0.0);
+}
+
+wx_status wx_euler3d_rhs_axpy2(wx_euler3d_plan* pl, const void* q, const void* const halo[4], const void* y,
+                               const void* z, void* out, double a, double b, double c, double d, wx_region region,
+                               wx_stream stream) {
+    return euler3d_rhs_impl(pl, q, halo, out, region, stream, 1, y, a, b, c, z, d);
 }
 
 }  // extern "C"

@@ -20,7 +20,7 @@ class Tvdrk3:
 
     def __init__(self, rhs: Callable, fused: bool = True):
         self.rhs = rhs
-        self.fused = fused and hasattr(rhs, "axpy")
+        self.fused = fused and bool(getattr(rhs, "supports_axpy", False))
 
     def step(self, Q: torch.Tensor, dt: float) -> torch.Tensor:
         rhs = self.rhs

@@ -21,6 +21,10 @@ def matvec_fun(vec: torch.Tensor, dt: float, Q: torch.Tensor, rhs: torch.Tensor,
     if method == "complex":
         Qvec = torch.complex(Q, EPS_COMPLEX * vec.reshape(Q.shape))
         jac = dt * (rhs_handle(Qvec).imag / EPS_COMPLEX)
+    elif getattr(rhs_handle, "supports_axpy", False) and isinstance(Q, torch.Tensor) and Q.dtype == torch.float64:
+        # fused store: dt/eps * R(Q + eps v) - dt/eps * R(Q) in the RHS launch itself
+        Qvec = torch.add(Q, vec.reshape(Q.shape), alpha=EPS_FD)
+        jac = rhs_handle.axpy(Qvec, None, 0.0, 0.0, dt / EPS_FD, zs=rhs.reshape(Q.shape), d=-dt / EPS_FD)
     else:
         Qvec = Q + EPS_FD * vec.reshape(Q.shape)
         jac = dt * (rhs_handle(Qvec) - rhs) / EPS_FD
@@ -28,6 +32,12 @@ def matvec_fun(vec: torch.Tensor, dt: float, Q: torch.Tensor, rhs: torch.Tensor,
 
 
 def matvec_rat(vec: torch.Tensor, dt: float, Q: torch.Tensor, rhs: torch.Tensor, rhs_handle: Callable) -> torch.Tensor:
+    if getattr(rhs_handle, "supports_axpy", False) and isinstance(Q, torch.Tensor) and Q.dtype == torch.float64:
+        # v - dt/(2 eps) (R(Q + eps v) - R(Q)) formed in the RHS kernel's store
+        v = vec.reshape(Q.shape)
+        Qvec = torch.add(Q, v, alpha=EPS_FD)
+        c = 0.5 * dt / EPS_FD
+        return rhs_handle.axpy(Qvec, v, 1.0, 0.0, -c, zs=rhs.reshape(Q.shape), d=c).flatten()
     Qvec = Q + EPS_FD * vec.reshape(Q.shape)
     jac = dt * (rhs_handle(Qvec) - rhs) / EPS_FD
     return vec.flatten() - 0.5 * jac.flatten()

@@ -58,6 +58,11 @@ class PanelRhs:
         return self._ex[dtype]
 
     @property
+    def supports_axpy(self) -> bool:
+        """True when the plans can fuse linear combinations into the RHS store (rhs_axpy)."""
+        return bool(self.panels) and all(hasattr(pl, "rhs_axpy") for pl in self.plans.values())
+
+    @property
     def plans(self):
         return next(iter(self._plans.values()))
 
@@ -67,12 +72,13 @@ class PanelRhs:
 
     # -- the evaluation
     def __call__(self, qs, dtype=None):
-        return self._run(qs, None, None, dtype)
+        return self._run(qs, None, None, dtype, None)
 
-    def axpy(self, qs, ys, a: float, b: float, c: float):
-        """a*ys + b*qs + c*R(qs) with the update fused into the RHS kernel's store (one explicit
-        Runge-Kutta stage; `ys` may be None).  Same structures as __call__."""
-        return self._run(qs, ys, (float(a), float(b), float(c)), None)
+    def axpy(self, qs, ys, a: float, b: float, c: float, zs=None, d: float = 0.0):
+        """a*ys + b*qs + c*R(qs) [+ d*zs] with the update fused into the RHS kernel's store (an explicit
+        Runge-Kutta stage, or the finite-difference Jacobian operators of solvers/matvec.py); `ys`, `zs`
+        may be None.  Same structures as __call__."""
+        return self._run(qs, ys, (float(a), float(b), float(c), float(d)), None, zs)
 
     def _structure(self, qs):
         np_ = len(self.panels)
@@ -92,11 +98,13 @@ class PanelRhs:
                 raise ValueError(f"state of {qs.numel()} values does not match {np_} panel(s) of {self.panel_shape}")
         return kind, (shape if kind != "dict" else None), qs
 
-    def _run(self, qs, ys, coef, dtype):
+    def _run(self, qs, ys, coef, dtype, zs=None):
         np_ = len(self.panels)
         kind, shape, qs = self._structure(qs)
         if ys is not None:
             ys = self._structure(ys)[2]
+        if zs is not None:
+            zs = self._structure(zs)[2]
         if not self.panels:
             # a rank that owns no panel (ranks 6, 7 of an 8-GPU node) still takes part in the collective
             ex = self.exchange_for(dtype or torch.float64)
@@ -109,12 +117,14 @@ class PanelRhs:
         shapes = {p: q.shape for p, q in qs.items()}
         flat = {p: q.reshape(self.panel_shape) for p, q in qs.items()}
         yflat = {p: y.reshape(self.panel_shape) for p, y in ys.items()} if ys is not None else {}
+        zflat = {p: z.reshape(self.panel_shape) for p, z in zs.items()} if zs is not None else {}
 
         def launch(p, halo, region):
             if coef is None:
                 plans[p].rhs(flat[p], halo, outs[p], region)
             else:
-                plans[p].rhs_axpy(flat[p], halo, yflat.get(p), outs[p], coef[0], coef[1], coef[2], region)
+                plans[p].rhs_axpy(flat[p], halo, yflat.get(p), outs[p], coef[0], coef[1], coef[2], region,
+                                  zflat.get(p), coef[3])
 
         if kind == "stacked":
             out_all = torch.empty((np_,) + tuple(self.panel_shape), dtype=dtype, device=self.device)

@@ -97,16 +97,19 @@ class Euler3DPlan:
         st = torch.cuda.current_stream(self.device).cuda_stream
         check(self.lib.wx_euler3d_rhs(self._h, q.data_ptr(), arr, out.data_ptr(), region, st), "wx_euler3d_rhs")
 
-    def rhs_axpy(self, q, halo_ptrs, y, out, a: float, b: float, c: float, region: int = _lib.WX_REGION_ALL):
-        """out = a*y + b*q + c*R(q) in the same launch (y may be None)."""
+    def rhs_axpy(self, q, halo_ptrs, y, out, a: float, b: float, c: float, region: int = _lib.WX_REGION_ALL,
+                 z=None, d: float = 0.0):
+        """out = a*y + b*q + c*R(q) [+ d*z] in the same launch (y, z may be None)."""
         self._check_q(q)
         self._check_q(out)
-        if y is not None:
-            self._check_q(y)
+        for t in (y, z):
+            if t is not None:
+                self._check_q(t)
         arr = _ptr_array(halo_ptrs)
         st = torch.cuda.current_stream(self.device).cuda_stream
-        check(self.lib.wx_euler3d_rhs_axpy(self._h, q.data_ptr(), arr, y.data_ptr() if y is not None else None,
-                                           out.data_ptr(), a, b, c, region, st), "wx_euler3d_rhs_axpy")
+        check(self.lib.wx_euler3d_rhs_axpy2(self._h, q.data_ptr(), arr, y.data_ptr() if y is not None else None,
+                                            z.data_ptr() if z is not None else None, out.data_ptr(), a, b, c, d, region,
+                                            st), "wx_euler3d_rhs_axpy2")
 
     def close(self):
         if self._h:

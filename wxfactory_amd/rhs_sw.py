@@ -150,11 +150,11 @@ class RhsShallowWater(PanelRhs):
 
     batched = True
 
-    def _run(self, qs, ys, coef, dtype):
+    def _run(self, qs, ys, coef, dtype, zs=None):
         if (self.batched and coef is None and isinstance(qs, torch.Tensor) and len(self.panels) > 1
                 and qs.is_contiguous() and qs.numel() == len(self.panels) * 3 * self.panel_shape[1] ** 2 * self.panel_shape[3]):
             return self._run_batched(qs)
-        return super()._run(qs, ys, coef, dtype)
+        return super()._run(qs, ys, coef, dtype, zs)
 
     def _run_batched(self, q):
         dt = q.dtype
