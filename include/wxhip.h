@@ -148,6 +148,16 @@ wx_status wx_euler3d_rhs_axpy2(wx_euler3d_plan* plan, const void* q, const void*
                                const void* z, void* out, double a, double b, double c, double d, wx_region region,
                                wx_stream stream);
 
+/* Complex-step Jacobian-vector product (solvers/matvec.py:56-61) with no complex array in HBM.
+ * The plan must be WX_DUAL128.  q and v are REAL (n-double) arrays in the state layout; the kernels form
+ * the dual state (q, eps*v) on load, exchange dual faces as usual (send/halo buffers are those of a
+ * WX_DUAL128 plan: wx_euler3d_edge_count() 16-byte values) and store only  out = scale * Im R(q + i eps v)
+ * as a REAL array - e.g. scale = dt/eps gives matvec_fun's result directly. */
+wx_status wx_euler3d_jvp_extrap_pack(wx_euler3d_plan* plan, const double* q, const double* v, double eps,
+                                     void* const send[4], wx_stream stream);
+wx_status wx_euler3d_jvp(wx_euler3d_plan* plan, const double* q, const double* v, double eps, const void* const halo[4],
+                         double* out, double scale, wx_region region, wx_stream stream);
+
 /* ------------------------------------------------------------------------------------------
  * Shallow water on a cubed-sphere tile.
  * Replaces  rhs/rhs_sw.py:38-240 (RhsShallowWater.__call__ / __compute_rhs__).

@@ -118,3 +118,21 @@ def test_complex_step_jvp_with_dual_arithmetic(setup):
     jd = matvec_fun(V.flatten(), float(g["meta/dt_jvp"]), Q, R, rhs_dual, "complex")
     assert next(iter(rhs_dual.plans_for(torch.complex128).values())).dual
     assert (_rel(jd, stack("jvp_complex").cpu().numpy()) < 1e-9).all()
+
+
+def test_fused_jvp_equals_unfused_complex_step(setup):
+    """wx_euler3d_jvp (dual state formed on load, real tangent stored) == the literal complex-step recipe."""
+    from wxfactory_amd.matvec import matvec_fun
+
+    g, rhs, stack = setup
+    Q, V, R = stack("Q"), stack("V"), stack("R")
+    dt = float(g["meta/dt_jvp"])
+    a = matvec_fun(V.flatten(), dt, Q, R, rhs, "complex")           # fused path (supports_jvp)
+    rhs.fused_jvp = False
+    try:
+        b = matvec_fun(V.flatten(), dt, Q, R, rhs, "complex")       # torch.complex + complex128 kernels + .imag
+    finally:
+        rhs.fused_jvp = True
+    ref = stack("jvp_complex").cpu().numpy()
+    assert (_rel(a, ref) < 1e-9).all() and (_rel(b, ref) < 1e-9).all()
+    assert (_rel(a, b.cpu().numpy().reshape(ref.shape)) < 1e-12).all()

@@ -63,6 +63,9 @@ SIGNATURES = {
                                     c_double, c_int, c_void_p]),
     "wx_euler3d_rhs_axpy2": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_double,
                                      c_double, c_double, c_double, c_int, c_void_p]),
+    "wx_euler3d_jvp_extrap_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_double, POINTER(c_void_p), c_void_p]),
+    "wx_euler3d_jvp": (c_int, [c_void_p, c_void_p, c_void_p, c_double, POINTER(c_void_p), c_void_p, c_double, c_int,
+                               c_void_p]),
     "wx_sw_plan_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, POINTER(DfrOps), POINTER(SwMetric)]),
     "wx_sw_plan_destroy": (c_int, [c_void_p]),
     "wx_sw_edge_count": (c_size_t, [c_void_p]),

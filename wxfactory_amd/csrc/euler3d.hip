@@ -102,6 +102,12 @@ struct EulerParams {
     double ca, cb, cc, cd;
     const T* y;            // nullable (then ca is ignored)
     const T* z;            // nullable (then cd is ignored)
+    // JVP mode (T = dual only): the state is formed on load as (q_re, jvp_eps * q_tan) from two REAL arrays
+    // and only jvp_scale * tangent(R) is stored, as a real array - no complex temporaries in HBM
+    int jvp;
+    const double *q_re, *q_tan;
+    double* out_tan;
+    double jvp_eps, jvp_scale;
     const T* q;
     T* rhs;
     T* itf;  // [elem][6 faces][NQ = 5 vars + pressure + log pressure][N2]
@@ -172,6 +178,25 @@ __device__ __forceinline__ Elem decode_elem(int slot, int count, int region, int
     return r;
 }
 
+template <typename T>
+__device__ __forceinline__ T load_q(const EulerParams<T>& P, size_t i) {
+    return P.q[i];
+}
+template <>
+__device__ __forceinline__ dual load_q<dual>(const EulerParams<dual>& P, size_t i) {
+    if (P.jvp) return dual(P.q_re[i], P.jvp_eps * P.q_tan[i]);
+    return P.q[i];
+}
+template <typename T>
+__device__ __forceinline__ void store_r(const EulerParams<T>& P, size_t i, T r) {
+    P.rhs[i] = r;
+}
+template <>
+__device__ __forceinline__ void store_r<dual>(const EulerParams<dual>& P, size_t i, dual r) {
+    if (P.jvp) P.out_tan[i] = P.jvp_scale * r.im;
+    else P.rhs[i] = r;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1: extrapolation to element faces + tile-edge pack
 // ------------------------------------------------------------------------------------------------
@@ -191,11 +216,11 @@ __global__ __launch_bounds__(Cfg<N>::BS) void euler_extrap_kernel(const EulerPar
         if (le < EPB && el.valid) {
             const size_t o = (size_t)el.e * N3 + pt;
             const int lp = le * C::LE + C::lidx(pt / N2, (pt / N) % N, pt % N);
-            fld[0][lp] = w_log(P.q[o]);
-            fld[1][lp] = P.q[fs + o];
-            fld[2][lp] = P.q[2 * fs + o];
-            fld[3][lp] = P.q[3 * fs + o];
-            fld[4][lp] = w_log(P.q[4 * fs + o]);
+            fld[0][lp] = w_log(load_q<T>(P, o));
+            fld[1][lp] = load_q<T>(P, fs + o);
+            fld[2][lp] = load_q<T>(P, 2 * fs + o);
+            fld[3][lp] = load_q<T>(P, 3 * fs + o);
+            fld[4][lp] = w_log(load_q<T>(P, 4 * fs + o));
         }
     }
     __syncthreads();
@@ -348,7 +373,8 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
     double sg = 1.0, h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0;
 #define WX_POINT_LOADS()                                                                                   \
     if (active) {                                                                                          \
-        q0 = P.q[o]; q1 = P.q[fs + o]; q2 = P.q[2 * fs + o]; q3 = P.q[3 * fs + o]; q4 = P.q[4 * fs + o];   \
+        q0 = load_q<T>(P, o); q1 = load_q<T>(P, fs + o); q2 = load_q<T>(P, 2 * fs + o);                     \
+        q3 = load_q<T>(P, 3 * fs + o); q4 = load_q<T>(P, 4 * fs + o);                                      \
         sg = WX_LDM(P.sg + o);                                                                             \
         h00 = WX_LDM(P.h + 0 * fs + o); h01 = WX_LDM(P.h + 1 * fs + o); h02 = WX_LDM(P.h + 2 * fs + o);    \
         h11 = WX_LDM(P.h + 4 * fs + o); h12 = WX_LDM(P.h + 5 * fs + o); h22 = WX_LDM(P.h + 8 * fs + o);    \
@@ -623,11 +649,11 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
             r3 += P.cd * P.z[3 * fs + o]; r4 += P.cd * P.z[4 * fs + o];
         }
     }
-    P.rhs[o] = r0;
-    P.rhs[fs + o] = r1;
-    P.rhs[2 * fs + o] = r2;
-    P.rhs[3 * fs + o] = r3;
-    P.rhs[4 * fs + o] = r4;
+    store_r<T>(P, o, r0);
+    store_r<T>(P, fs + o, r1);
+    store_r<T>(P, 2 * fs + o, r2);
+    store_r<T>(P, 3 * fs + o, r3);
+    store_r<T>(P, 4 * fs + o, r4);
 #if WX_K2_STAMPS
     }
     WX_STAMP(6);
@@ -686,6 +712,7 @@ EulerParams<T> make_params(const wx_euler3d_plan* pl) {
     P.advection_only = b.advection_only; P.has_damp = b.has_damp;
     P.q = nullptr; P.rhs = nullptr; P.itf = static_cast<T*>(pl->itf);
     P.axpy = 0; P.ca = P.cb = P.cd = 0.0; P.cc = 1.0; P.y = nullptr; P.z = nullptr;
+    P.jvp = 0; P.q_re = P.q_tan = nullptr; P.out_tan = nullptr; P.jvp_eps = 0.0; P.jvp_scale = 1.0;
     P.halo_s = P.halo_n = P.halo_w = P.halo_e = nullptr;
     P.send_s = P.send_n = P.send_w = P.send_e = nullptr;
     P.K = pl->consts;
@@ -885,6 +912,41 @@ wx_status wx_euler3d_rhs(wx_euler3d_plan* pl, const void* q, const void* const h
 wx_status wx_euler3d_rhs_axpy(wx_euler3d_plan* pl, const void* q, const void* const halo[4], const void* y, void* out,
                               double a, double b, double c, wx_region region, wx_stream stream) {
     return euler3d_rhs_impl(pl, q, halo, out, region, stream, 1, y, a, b, c, nullptr, 0.0);
+}
+
+// Complex-step Jacobian-vector product without complex arrays in HBM (WX_DUAL128 plans only).
+wx_status wx_euler3d_jvp_extrap_pack(wx_euler3d_plan* pl, const double* q, const double* v, double eps, void* const send[4],
+                                     wx_stream stream) {
+    if (!pl || !q || !v) return fail(WX_ERR_INVALID, "wx_euler3d_jvp_extrap_pack: null argument");
+    if (pl->dtype != WX_DUAL128) return fail(WX_ERR_INVALID, "wx_euler3d_jvp_*: the plan must be WX_DUAL128");
+    EulerParams<dual> P = make_params<dual>(pl);
+    P.jvp = 1; P.q_re = q; P.q_tan = v; P.jvp_eps = eps;
+    if (send) {
+        P.send_s = static_cast<dual*>(send[0]); P.send_n = static_cast<dual*>(send[1]);
+        P.send_w = static_cast<dual*>(send[2]); P.send_e = static_cast<dual*>(send[3]);
+    }
+    return dispatch_extrap<dual>(pl->n, P, static_cast<hipStream_t>(stream));
+}
+
+wx_status wx_euler3d_jvp(wx_euler3d_plan* pl, const double* q, const double* v, double eps, const void* const halo[4],
+                         double* out, double scale, wx_region region, wx_stream stream) {
+    if (!pl || !q || !v || !out) return fail(WX_ERR_INVALID, "wx_euler3d_jvp: null argument");
+    if (pl->dtype != WX_DUAL128) return fail(WX_ERR_INVALID, "wx_euler3d_jvp_*: the plan must be WX_DUAL128");
+    if (region != WX_REGION_ALL && region != WX_REGION_INTERIOR && region != WX_REGION_BOUNDARY)
+        return fail(WX_ERR_INVALID, "unknown region %d", (int)region);
+    if (region != WX_REGION_INTERIOR) {
+        if (!halo) return fail(WX_ERR_INVALID, "wx_euler3d_jvp: halo is required for this region");
+        for (int e = 0; e < 4; ++e)
+            if (!halo[e]) return fail(WX_ERR_INVALID, "wx_euler3d_jvp: halo[%d] is null", e);
+    }
+    EulerParams<dual> P = make_params<dual>(pl);
+    P.jvp = 1; P.q_re = q; P.q_tan = v; P.jvp_eps = eps; P.out_tan = out; P.jvp_scale = scale;
+    P.region = region; P.count = region_count(region, pl->H, pl->V);
+    if (halo) {
+        P.halo_s = static_cast<const dual*>(halo[0]); P.halo_n = static_cast<const dual*>(halo[1]);
+        P.halo_w = static_cast<const dual*>(halo[2]); P.halo_e = static_cast<const dual*>(halo[3]);
+    }
+    return dispatch_rhs<dual>(pl->n, P, static_cast<hipStream_t>(stream));
 }
 
 wx_status wx_euler3d_rhs_axpy2(wx_euler3d_plan* pl, const void* q, const void* const halo[4], const void* y,

@@ -111,6 +111,27 @@ class Euler3DPlan:
                                             z.data_ptr() if z is not None else None, out.data_ptr(), a, b, c, d, region,
                                             st), "wx_euler3d_rhs_axpy2")
 
+    def _check_real(self, t):
+        if t.dtype != torch.float64 or t.numel() != 5 * self.V * self.H * self.H * self.n**3 or not t.is_contiguous() \
+                or t.device != self.device:
+            raise ValueError(f"need a contiguous float64 tensor of {self.shape} on {self.device}")
+
+    def jvp_extrap_pack(self, q, v, eps: float, send):
+        """dual plans only: phase 1-2 on the dual state (q, eps*v) formed on load from two real arrays."""
+        self._check_real(q)
+        self._check_real(v)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.wx_euler3d_jvp_extrap_pack(self._h, q.data_ptr(), v.data_ptr(), eps, _ptr_array(send), st),
+              "wx_euler3d_jvp_extrap_pack")
+
+    def jvp(self, q, v, eps: float, halo, out, scale: float, region: int = _lib.WX_REGION_ALL):
+        """dual plans only: out (real) = scale * Im R(q + i eps v)."""
+        for t in (q, v, out):
+            self._check_real(t)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.wx_euler3d_jvp(self._h, q.data_ptr(), v.data_ptr(), eps, _ptr_array(halo), out.data_ptr(), scale,
+                                      region, st), "wx_euler3d_jvp")
+
     def close(self):
         if self._h:
             self.lib.wx_euler3d_plan_destroy(self._h)
@@ -129,3 +150,34 @@ class RhsEuler3D(PanelRhs):
     `plans` : {panel: Euler3DPlan}.  Call with {panel: Q}, with a single tensor when the rank owns
     one panel, or with the panels stacked along a leading axis; returns the same structure of
     freshly allocated R, shaped like the input (the contract of rhs/rhs.py:75-122)."""
+
+    supports_jvp = True
+
+    def jvp(self, Q: torch.Tensor, v: torch.Tensor, eps: float, scale: float) -> torch.Tensor:
+        """scale * Im R(Q + i eps v) for stacked real Q, v -> real tensor shaped like Q.  The dual state is
+        formed inside the kernels and only the tangent is stored: the complex-step JVP of
+        solvers/matvec.py:56-61 without a complex array in HBM."""
+        np_ = len(self.panels)
+        Qs = Q.reshape((np_,) + tuple(self.panel_shape))
+        vs = v.reshape((np_,) + tuple(self.panel_shape))
+        if "jvp" not in self._plans:
+            base = self.plans
+            self._plans["jvp"] = {p: pl.twin(torch.complex128, dual=True) for p, pl in base.items()}
+        plans = self._plans["jvp"]
+        ex = self.exchange_for(torch.complex128)
+        out = torch.empty_like(Qs)
+        for i, p in enumerate(self.panels):
+            plans[p].jvp_extrap_pack(Qs[i], vs[i], eps, ex.send_views(p))
+        if ex.needs_comm and self.overlap:
+            ex.start()
+            for i, p in enumerate(self.panels):
+                plans[p].jvp(Qs[i], vs[i], eps, None, out[i], scale, _lib.WX_REGION_INTERIOR)
+            ex.wait()
+            for i, p in enumerate(self.panels):
+                plans[p].jvp(Qs[i], vs[i], eps, ex.halo_views(p), out[i], scale, _lib.WX_REGION_BOUNDARY)
+        else:
+            ex.start()
+            ex.wait()
+            for i, p in enumerate(self.panels):
+                plans[p].jvp(Qs[i], vs[i], eps, ex.halo_views(p), out[i], scale, _lib.WX_REGION_ALL)
+        return out.reshape(Q.shape)
