@@ -210,6 +210,10 @@ wx_status wx_sw_extrap_pack(wx_sw_plan* plan, const void* q, void* const send[4]
 wx_status wx_sw_rhs(wx_sw_plan* plan, const void* q, const void* const halo[4], void* rhs, wx_region region,
                     wx_stream stream);
 
+/* out = a*y + b*q + c*R(q): explicit Runge-Kutta stage fused into the store (see wx_euler3d_rhs_axpy) */
+wx_status wx_sw_rhs_axpy(wx_sw_plan* plan, const void* q, const void* const halo[4], const void* y, void* out, double a,
+                         double b, double c, wx_region region, wx_stream stream);
+
 /* Several tiles of one rank (e.g. all six panels on one GPU) in ONE launch per phase: the shallow-water
  * workload is launch-latency bound (5.5 MB of state per panel at n=8, H=60).  The states / results are
  * slices q + i*panel_stride of one stacked array (panel_stride in elements of dtype); the edge buffers
@@ -221,6 +225,9 @@ wx_status wx_sw_batch_destroy(wx_sw_batch* batch);
 wx_status wx_sw_batch_extrap_pack(wx_sw_batch* batch, const void* q, size_t panel_stride, wx_stream stream);
 wx_status wx_sw_batch_rhs(wx_sw_batch* batch, const void* q, void* rhs, size_t panel_stride, wx_region region,
                           wx_stream stream);
+/* y (nullable) and out are stacked like q */
+wx_status wx_sw_batch_rhs_axpy(wx_sw_batch* batch, const void* q, const void* y, void* out, size_t panel_stride, double a,
+                               double b, double c, wx_region region, wx_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * The reference's compiled `pde` module, function for function (pde/interface.cpp:282-302,

@@ -103,3 +103,30 @@ def test_batched_launch_equals_per_panel(cplx, built_lib):
         ref = g.r(p, cplx)
         scale = np.maximum(var_max(ref.real), _scale(g, p, cplx))
         assert (var_err(Rb[p].cpu().numpy().real, ref.real) <= TOL * scale).all()
+
+
+def test_tvdrk3_fused_stage_equals_literal_sequence(built_lib):
+    """SSP-RK3 on the shallow-water sphere (BASELINE configs 2-3): stage updates fused into the RHS
+    store (batched, one launch per phase) == the reference's literal sequence of axpys."""
+    from wxfactory_amd.integrators import Tvdrk3
+    from wxfactory_amd.matvec import matvec_rat
+    from wxfactory_amd.rhs_sw import RhsShallowWater
+
+    g = golden_sw("sw_c6_n5_h4")
+    rhs = RhsShallowWater({p: _plan(g, p) for p in range(6)})
+    assert rhs.supports_axpy and not rhs.supports_axpy2
+    Q = torch.stack([_dev(g.q(p)) for p in range(6)])
+    dt = 200.0
+    a = Tvdrk3(rhs, fused=True).step(Q, dt)
+    b = Tvdrk3(rhs, fused=False).step(Q, dt)
+    rhs.batched = False
+    c = Tvdrk3(rhs, fused=True).step(Q, dt)
+    torch.cuda.synchronize()
+    upd = (b - Q).abs().amax(dim=(0, 2, 3, 4))
+    qmax = Q.abs().amax(dim=(0, 2, 3, 4))
+    assert ((a - b).abs().amax(dim=(0, 2, 3, 4)) <= 1e-12 * upd + 1e-15 * qmax).all()  # a few ulp of the state
+    assert torch.equal(a, c)
+    # the FD Rosenbrock operator falls back to torch ops for shallow water (no second fused array)
+    v = torch.randn_like(Q) * 1e-3 * Q.abs().amax(dim=(0, 2, 3, 4), keepdim=True)
+    out = matvec_rat(v.flatten(), dt, Q, rhs(Q), rhs)
+    assert torch.isfinite(out).all()

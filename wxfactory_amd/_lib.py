@@ -71,6 +71,10 @@ SIGNATURES = {
     "wx_sw_edge_count": (c_size_t, [c_void_p]),
     "wx_sw_extrap_pack": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p]),
     "wx_sw_rhs": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_int, c_void_p]),
+    "wx_sw_rhs_axpy": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_double, c_double, c_double,
+                               c_int, c_void_p]),
+    "wx_sw_batch_rhs_axpy": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_double, c_double, c_double,
+                                     c_int, c_void_p]),
     "wx_sw_batch_create": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_int, c_void_p, c_void_p]),
     "wx_sw_batch_destroy": (c_int, [c_void_p]),
     "wx_sw_batch_extrap_pack": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -33,7 +33,10 @@
 #define WX_K2_GAMMA_ROLLED 0  // forcing rows one at a time (9 Christoffel loads in flight, not 27)
 #endif
 #ifndef WX_K2_FIELD_BATCH
-#define WX_K2_FIELD_BATCH 3   // derivative fields contracted per (rolled) batch: 7 = fully unrolled
+#define WX_K2_FIELD_BATCH 3   // derivative fields contracted per (rolled) batch (7 = fully unrolled: spills)
+#endif
+#ifndef WX_K2_FIELD_BATCH_WIDE
+#define WX_K2_FIELD_BATCH_WIDE 4   // same for the 16-byte dtypes (1 workgroup/CU: a little more ILP pays)
 #endif
 #ifndef WX_ELEM_ORDER
 #define WX_ELEM_ORDER 0   // processing order of elements: 0 = memory order (ek,ej,ei); 1 = vertical columns first
@@ -580,28 +583,14 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
         for (int m = 0; m < N; ++m) dm[m] = sD[idx * N + m];
         const double cm = sCm[idx], cp = sCp[idx];
         const int lf = le < EPB ? le : 0;
-#if WX_K2_FIELD_BATCH >= 7
-        T dv[7];
-#pragma unroll
-        for (int c = 0; c < 7; ++c) {
-            T a = cm * fr[lf][2 * d][c][fp] + cp * fr[lf][2 * d + 1][c][fp];
-#pragma unroll
-            for (int m = 0; m < N; ++m) a += dm[m] * fld[c][base + m * stride];
-            dv[c] = a;
-        }
-        acc0 += dv[0];
-        acc1 += dv[1];
-        acc2 += dv[2];
-        acc4 += dv[3];
-        // W^d = [A@D + A*@C] + p [B@D + B*@C] + p B [log p@D + log p^@C]   (rhs_dfr.py:113-136)
-        accw += dv[4] + dv[5] * p + dv[6] * (p * Bd);
-#else
-        // rolled over field batches: bounds the LDS reads in flight (register pressure)
+        // rolled over field batches: bounds the LDS reads in flight (register pressure); fully
+        // unrolled, the compiler clusters 70 LDS reads and needs 241 VGPRs (1 workgroup/CU)
+        constexpr int FB = is_complex<T>::value ? WX_K2_FIELD_BATCH_WIDE : WX_K2_FIELD_BATCH;
         const T pB = p * Bd;
 #pragma unroll 1
-        for (int c0 = 0; c0 < 7; c0 += WX_K2_FIELD_BATCH) {
+        for (int c0 = 0; c0 < 7; c0 += FB) {
 #pragma unroll
-            for (int cc = 0; cc < WX_K2_FIELD_BATCH; ++cc) {
+            for (int cc = 0; cc < FB; ++cc) {
                 const int c = c0 + cc;
                 if (c < 7) {
                     T a = cm * fr[lf][2 * d][c][fp] + cp * fr[lf][2 * d + 1][c][fp];
@@ -618,7 +607,6 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
                 }
             }
         }
-#endif
         if (d == 2) {
 #pragma unroll
             for (int m = 0; m < N; ++m) hf += sHF[idx * N + m] * fld[7][base + m * stride];

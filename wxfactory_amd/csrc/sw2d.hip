@@ -42,6 +42,10 @@ struct SwDyn {
     const T* q;
     T* rhs;
     int count, region;
+    // fused explicit Runge-Kutta stage: out = ca*y + cb*q + cc*R(q)  (y nullable); axpy = 0: out = R(q)
+    int axpy;
+    const T* y;
+    double ca, cb, cc;
 };
 
 template <typename T>
@@ -305,9 +309,14 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
     }
     if (!active) return;
     const double inv_sg = 1.0 / sg;
-    D.rhs[o] = inv_sg * (-acc0);
-    D.rhs[fs + o] = inv_sg * (-acc1) - forc1;
-    D.rhs[2 * fs + o] = inv_sg * (-acc2) - forc2;
+    T r0 = inv_sg * (-acc0), r1 = inv_sg * (-acc1) - forc1, r2 = inv_sg * (-acc2) - forc2;
+    if (D.axpy) {  // integrators/tvdrk3.py:12-19 stage formed in the store
+        r0 = D.cb * q0 + D.cc * r0; r1 = D.cb * q1 + D.cc * r1; r2 = D.cb * q2 + D.cc * r2;
+        if (D.y != nullptr) { r0 += D.ca * D.y[o]; r1 += D.ca * D.y[fs + o]; r2 += D.ca * D.y[2 * fs + o]; }
+    }
+    D.rhs[o] = r0;
+    D.rhs[fs + o] = r1;
+    D.rhs[2 * fs + o] = r2;
 }
 
 // one tile per launch: parameters by value
@@ -324,13 +333,15 @@ __global__ __launch_bounds__(Cfg2<N>::BS) void sw_rhs_kernel(const SwParams<T> P
 template <int N, typename T>
 __global__ __launch_bounds__(Cfg2<N>::BS) void sw_extrap_batch_kernel(const SwParams<T>* __restrict__ PB, const T* q,
                                                                      size_t stride) {
-    SwDyn<T> D{q + (size_t)blockIdx.y * stride, nullptr, 0, 0};
+    SwDyn<T> D{q + (size_t)blockIdx.y * stride, nullptr, 0, 0, 0, nullptr, 0.0, 0.0, 1.0};
     sw_extrap_body<N, T>(PB[blockIdx.y], D);
 }
 template <int N, typename T>
 __global__ __launch_bounds__(Cfg2<N>::BS) void sw_rhs_batch_kernel(const SwParams<T>* __restrict__ PB, const T* q, T* rhs,
-                                                                  size_t stride, int count, int region) {
-    SwDyn<T> D{q + (size_t)blockIdx.y * stride, rhs + (size_t)blockIdx.y * stride, count, region};
+                                                                  size_t stride, int count, int region, int axpy,
+                                                                  const T* y, double ca, double cb, double cc) {
+    SwDyn<T> D{q + (size_t)blockIdx.y * stride, rhs + (size_t)blockIdx.y * stride, count, region, axpy,
+               y ? y + (size_t)blockIdx.y * stride : nullptr, ca, cb, cc};
     sw_rhs_body<N, T>(PB[blockIdx.y], D);
 }
 
@@ -403,7 +414,7 @@ wx_status sw_launch(int what, const SwParams<T>* P, const SwDyn<T>& D, const SwP
         case 1: hipLaunchKernelGGL((sw_rhs_kernel<N, T>), dim3(grid), dim3(C::BS), 0, st, *P, D); break;
         case 2: hipLaunchKernelGGL((sw_extrap_batch_kernel<N, T>), dim3(grid, nb), dim3(C::BS), 0, st, table, D.q, stride); break;
         default: hipLaunchKernelGGL((sw_rhs_batch_kernel<N, T>), dim3(grid, nb), dim3(C::BS), 0, st, table, D.q, D.rhs,
-                                    stride, D.count, D.region);
+                                    stride, D.count, D.region, D.axpy, D.y, D.ca, D.cb, D.cc);
     }
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
@@ -426,10 +437,11 @@ wx_status sw_dispatch(int n, int what, const SwParams<T>* P, const SwDyn<T>& D, 
 
 template <typename T>
 wx_status sw_run(wx_sw_plan* pl, bool extrap, const void* q, void* const send[4], const void* const halo[4], void* rhs,
-                 int region, int count, hipStream_t st) {
+                 int region, int count, hipStream_t st, int axpy = 0, const void* y = nullptr, double ca = 0.0,
+                 double cb = 0.0, double cc = 1.0) {
     SwParams<T> P = make_sw_params<T>(pl);
     set_edges<T>(P, send, halo);
-    SwDyn<T> D{static_cast<const T*>(q), static_cast<T*>(rhs), count, region};
+    SwDyn<T> D{static_cast<const T*>(q), static_cast<T*>(rhs), count, region, axpy, static_cast<const T*>(y), ca, cb, cc};
     return sw_dispatch<T>(pl->n, extrap ? 0 : 1, &P, D, nullptr, 0, 0, st);
 }
 
@@ -450,8 +462,10 @@ wx_status sw_batch_build(wx_sw_batch* b, wx_sw_plan* const plans[], int count, v
 }
 
 template <typename T>
-wx_status sw_batch_run(wx_sw_batch* b, bool extrap, const void* q, void* rhs, size_t stride, int region, hipStream_t st) {
-    SwDyn<T> D{static_cast<const T*>(q), static_cast<T*>(rhs), extrap ? b->H * b->H : sw_region_count(region, b->H), region};
+wx_status sw_batch_run(wx_sw_batch* b, bool extrap, const void* q, void* rhs, size_t stride, int region, hipStream_t st,
+                       int axpy = 0, const void* y = nullptr, double ca = 0.0, double cb = 0.0, double cc = 1.0) {
+    SwDyn<T> D{static_cast<const T*>(q), static_cast<T*>(rhs), extrap ? b->H * b->H : sw_region_count(region, b->H), region,
+               axpy, static_cast<const T*>(y), ca, cb, cc};
     return sw_dispatch<T>(b->n, extrap ? 2 : 3, nullptr, D, static_cast<const SwParams<T>*>(b->table), b->count, stride, st);
 }
 
@@ -559,6 +573,46 @@ wx_status wx_sw_rhs(wx_sw_plan* pl, const void* q, const void* const halo[4], vo
         case WX_DUAL128: return sw_run<dual>(pl, false, q, nullptr, halo, rhs, region, count, st);
     }
     return fail(WX_ERR_INVALID, "bad plan dtype");
+}
+
+static wx_status sw_check_rhs_args(const void* pl, const void* q, const void* out, const void* const halo[4], int region) {
+    if (!pl || !q || !out) return fail(WX_ERR_INVALID, "wx_sw_rhs: null argument");
+    if (out == q) return fail(WX_ERR_INVALID, "wx_sw_rhs: output must not alias the state");
+    if (region != WX_REGION_ALL && region != WX_REGION_INTERIOR && region != WX_REGION_BOUNDARY)
+        return fail(WX_ERR_INVALID, "unknown region %d", region);
+    if (region != WX_REGION_INTERIOR) {
+        if (!halo) return fail(WX_ERR_INVALID, "wx_sw_rhs: halo is required for this region");
+        for (int e = 0; e < 4; ++e)
+            if (!halo[e]) return fail(WX_ERR_INVALID, "wx_sw_rhs: halo[%d] is null", e);
+    }
+    return WX_OK;
+}
+
+wx_status wx_sw_rhs_axpy(wx_sw_plan* pl, const void* q, const void* const halo[4], const void* y, void* out, double a,
+                         double b, double c, wx_region region, wx_stream stream) {
+    wx_status ok = sw_check_rhs_args(pl, q, out, halo, region);
+    if (ok != WX_OK) return ok;
+    const int count = sw_region_count(region, pl->H);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (pl->dtype) {
+        case WX_F64: return sw_run<double>(pl, false, q, nullptr, halo, out, region, count, st, 1, y, a, b, c);
+        case WX_C128: return sw_run<cplx>(pl, false, q, nullptr, halo, out, region, count, st, 1, y, a, b, c);
+        default: return sw_run<dual>(pl, false, q, nullptr, halo, out, region, count, st, 1, y, a, b, c);
+    }
+}
+
+wx_status wx_sw_batch_rhs_axpy(wx_sw_batch* bt, const void* q, const void* y, void* out, size_t panel_stride, double a,
+                               double b, double c, wx_region region, wx_stream stream) {
+    if (!bt || !q || !out) return fail(WX_ERR_INVALID, "wx_sw_batch_rhs_axpy: null argument");
+    if (out == q) return fail(WX_ERR_INVALID, "wx_sw_batch_rhs_axpy: output must not alias the state");
+    if (region != WX_REGION_ALL && region != WX_REGION_INTERIOR && region != WX_REGION_BOUNDARY)
+        return fail(WX_ERR_INVALID, "unknown region %d", (int)region);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (bt->dtype) {
+        case WX_F64: return sw_batch_run<double>(bt, false, q, out, panel_stride, region, st, 1, y, a, b, c);
+        case WX_C128: return sw_batch_run<cplx>(bt, false, q, out, panel_stride, region, st, 1, y, a, b, c);
+        default: return sw_batch_run<dual>(bt, false, q, out, panel_stride, region, st, 1, y, a, b, c);
+    }
 }
 
 wx_status wx_sw_batch_create(wx_sw_batch** out, wx_sw_plan* const plans[], int count, void* const send[][4],

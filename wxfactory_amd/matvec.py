@@ -25,7 +25,7 @@ def matvec_fun(vec: torch.Tensor, dt: float, Q: torch.Tensor, rhs: torch.Tensor,
     if method == "complex":
         Qvec = torch.complex(Q, EPS_COMPLEX * vec.reshape(Q.shape))
         jac = dt * (rhs_handle(Qvec).imag / EPS_COMPLEX)
-    elif getattr(rhs_handle, "supports_axpy", False) and isinstance(Q, torch.Tensor) and Q.dtype == torch.float64:
+    elif getattr(rhs_handle, "supports_axpy2", False) and isinstance(Q, torch.Tensor) and Q.dtype == torch.float64:
         # fused store: dt/eps * R(Q + eps v) - dt/eps * R(Q) in the RHS launch itself
         Qvec = torch.add(Q, vec.reshape(Q.shape), alpha=EPS_FD)
         jac = rhs_handle.axpy(Qvec, None, 0.0, 0.0, dt / EPS_FD, zs=rhs.reshape(Q.shape), d=-dt / EPS_FD)
@@ -36,7 +36,7 @@ def matvec_fun(vec: torch.Tensor, dt: float, Q: torch.Tensor, rhs: torch.Tensor,
 
 
 def matvec_rat(vec: torch.Tensor, dt: float, Q: torch.Tensor, rhs: torch.Tensor, rhs_handle: Callable) -> torch.Tensor:
-    if getattr(rhs_handle, "supports_axpy", False) and isinstance(Q, torch.Tensor) and Q.dtype == torch.float64:
+    if getattr(rhs_handle, "supports_axpy2", False) and isinstance(Q, torch.Tensor) and Q.dtype == torch.float64:
         # v - dt/(2 eps) (R(Q + eps v) - R(Q)) formed in the RHS kernel's store
         v = vec.reshape(Q.shape)
         Qvec = torch.add(Q, v, alpha=EPS_FD)

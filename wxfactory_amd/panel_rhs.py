@@ -63,6 +63,11 @@ class PanelRhs:
         return bool(self.panels) and all(hasattr(pl, "rhs_axpy") for pl in self.plans.values())
 
     @property
+    def supports_axpy2(self) -> bool:
+        """... and a second extra array (the finite-difference Jacobian operators need y and z)."""
+        return self.supports_axpy and all(getattr(pl, "axpy_two", False) for pl in self.plans.values())
+
+    @property
     def plans(self):
         return next(iter(self._plans.values()))
 

@@ -74,6 +74,8 @@ class Euler3DPlan:
                                                   ctypes.byref(o), ctypes.byref(m)), "wx_euler3d_plan_create")
         self.edge_count = int(self.lib.wx_euler3d_edge_count(self._h))
 
+    axpy_two = True  # rhs_axpy takes a second array (z, d)
+
     def twin(self, dtype, dual: bool = False):
         """Plan of another dtype over the same (borrowed) metric tensors."""
         return Euler3DPlan(self.n, self.H, self.V, self.case_number, self.panel, self._ops, self._metric, dtype=dtype,

@@ -88,6 +88,18 @@ class SwPlan:
         st = torch.cuda.current_stream(self.device).cuda_stream
         check(self.lib.wx_sw_rhs(self._h, q.data_ptr(), arr, out.data_ptr(), region, st), "wx_sw_rhs")
 
+    def rhs_axpy(self, q, halo_ptrs, y, out, a, b, c, region: int = _lib.WX_REGION_ALL, z=None, d: float = 0.0):
+        """out = a*y + b*q + c*R(q) in the RHS launch (y may be None)."""
+        if z is not None:
+            raise NotImplementedError("the shallow-water kernel fuses one extra array (y) only")
+        self._check_q(q)
+        self._check_q(out)
+        if y is not None:
+            self._check_q(y)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.wx_sw_rhs_axpy(self._h, q.data_ptr(), _ptr_array(halo_ptrs), y.data_ptr() if y is not None else None,
+                                      out.data_ptr(), a, b, c, region, st), "wx_sw_rhs_axpy")
+
     def close(self):
         if self._h:
             self.lib.wx_sw_plan_destroy(self._h)
@@ -127,9 +139,14 @@ class SwBatch:
         st = torch.cuda.current_stream(self.device).cuda_stream
         check(self.lib.wx_sw_batch_extrap_pack(self._h, q.data_ptr(), self.stride, st), "wx_sw_batch_extrap_pack")
 
-    def rhs(self, q, out, region):
+    def rhs(self, q, out, region, y=None, coef=None):
         st = torch.cuda.current_stream(self.device).cuda_stream
-        check(self.lib.wx_sw_batch_rhs(self._h, q.data_ptr(), out.data_ptr(), self.stride, region, st), "wx_sw_batch_rhs")
+        if coef is None:
+            check(self.lib.wx_sw_batch_rhs(self._h, q.data_ptr(), out.data_ptr(), self.stride, region, st), "wx_sw_batch_rhs")
+        else:
+            check(self.lib.wx_sw_batch_rhs_axpy(self._h, q.data_ptr(), y.data_ptr() if y is not None else None,
+                                                out.data_ptr(), self.stride, coef[0], coef[1], coef[2], region, st),
+                  "wx_sw_batch_rhs_axpy")
 
     def close(self):
         if self._h:
@@ -151,12 +168,13 @@ class RhsShallowWater(PanelRhs):
     batched = True
 
     def _run(self, qs, ys, coef, dtype, zs=None):
-        if (self.batched and coef is None and isinstance(qs, torch.Tensor) and len(self.panels) > 1
-                and qs.is_contiguous() and qs.numel() == len(self.panels) * 3 * self.panel_shape[1] ** 2 * self.panel_shape[3]):
-            return self._run_batched(qs)
+        if (self.batched and zs is None and isinstance(qs, torch.Tensor) and len(self.panels) > 1
+                and qs.is_contiguous() and qs.numel() == len(self.panels) * 3 * self.panel_shape[1] ** 2 * self.panel_shape[3]
+                and (ys is None or (isinstance(ys, torch.Tensor) and ys.is_contiguous() and ys.numel() == qs.numel()))):
+            return self._run_batched(qs, ys, coef)
         return super()._run(qs, ys, coef, dtype, zs)
 
-    def _run_batched(self, q):
+    def _run_batched(self, q, y=None, coef=None):
         dt = q.dtype
         plans, ex = self.plans_for(dt), self.exchange_for(dt)
         if not hasattr(self, "_batches"):
@@ -168,11 +186,11 @@ class RhsShallowWater(PanelRhs):
         b.extrap_pack(q)
         if ex.needs_comm and self.overlap:
             ex.start()
-            b.rhs(q, out, _lib.WX_REGION_INTERIOR)
+            b.rhs(q, out, _lib.WX_REGION_INTERIOR, y, coef)
             ex.wait()
-            b.rhs(q, out, _lib.WX_REGION_BOUNDARY)
+            b.rhs(q, out, _lib.WX_REGION_BOUNDARY, y, coef)
         else:
             ex.start()
             ex.wait()
-            b.rhs(q, out, _lib.WX_REGION_ALL)
+            b.rhs(q, out, _lib.WX_REGION_ALL, y, coef)
         return out
