@@ -473,6 +473,37 @@ def callers_case(name, ini, overrides, dt_rk=2.0, dt_jvp=30.0, perturb=0.01, see
     _run6(name, work)
 
 
+def state_file_case(name):
+    """Bytes written by the reference's save_state (output/state.py:9-16) for a seeded global state."""
+    import types
+    from common import ConfigurationSchema
+    from output.state import save_state
+    from device import CpuDevice
+
+    MPI.reset_world(1)
+    schema = ConfigurationSchema(SCHEMA_TEXT)
+    rng = numpy.random.default_rng(2024)
+    state = rng.uniform(-1, 1, (6, 3, 2, 2, 9))
+    cfg_text = "[General]\nequations = shallow_water\n\n[Grid]\ngrid_type = cubed_sphere\n"
+    param = types.SimpleNamespace(state_version=schema.version, config_content=cfg_text)
+    path = "/tmp/wx_golden_state.npy"
+
+    def work(rank):
+        save_state(state, param, path, device=CpuDevice(MPI.COMM_WORLD))
+        return True
+
+    res, err = MPI.run_ranks(work, 1)
+    if err[0]:
+        print(err[0])
+        raise SystemExit(1)
+    raw = numpy.frombuffer(open(path, "rb").read(), dtype=numpy.uint8)
+    out = os.path.join(GOLDEN, name + ".npz")
+    numpy.savez_compressed(out, file_bytes=raw, state=state, state_version=numpy.array(str(schema.version)),
+                           config_text=numpy.array(cfg_text))
+    print(f"[{name}] -> {out} ({raw.size} bytes in the reference-written file, version {schema.version!r})", flush=True)
+    MPI.reset_world(6)
+
+
 CASES = {
     # balanced gravity-wave state, small n: all panels carry metrics + phases (exchange coverage)
     "euler3d_c31_n3_h4_v2": lambda nm: euler_case(
@@ -501,6 +532,7 @@ CASES = {
     # callers: one SSP-RK3 step, JVPs (complex step / finite difference), Rosenbrock operator, Ros2 step
     "callers_euler3d_n3_h3_v2": lambda nm: callers_case(
         nm, "dcmip31.ini", dict(num_solpts=3, num_elements_horizontal=3, num_elements_vertical=2)),
+    "state_file_v": state_file_case,
     # 2-D Cartesian Euler: the plumbing reference (config/gaussian_bubble.ini, smaller grid)
     "cart2d_bubble_n5": lambda nm: cart2d_case(nm, "gaussian_bubble.ini",
                                                dict(num_solpts=5, num_elements_horizontal=7, num_elements_vertical=9)),

@@ -174,3 +174,39 @@ def test_panel_rhs_orchestration_over_gloo(world):
     res = [q.get(timeout=240) for _ in range(world)]
     [p.join(timeout=60) for p in procs]
     assert all(r[1] == "ok" for r in res), [r for r in res if r[1] != "ok"]
+
+
+def _state_worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from wxfactory_amd.panels import panels_of_rank
+        from wxfactory_amd.state import distribute_cube, gather_cube
+
+        glob = torch.arange(6 * 3 * 2 * 2 * 4, dtype=torch.float64).reshape(6, 3, 2, 2, 4)
+        local = distribute_cube(glob if rank == 0 else None, rank, world)
+        assert torch.equal(local, glob[panels_of_rank(rank, world)])
+        back = gather_cube(local, rank, world)
+        assert (back is None) == (rank != 0)
+        if rank == 0:
+            assert torch.equal(back, glob)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, traceback.format_exc()))
+        raise
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_checkpoint_layout_is_rank_count_independent(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_state_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=180) for _ in range(world)]
+    [p.join(timeout=60) for p in procs]
+    assert all(r[1] == "ok" for r in res), [r for r in res if r[1] != "ok"]
