@@ -6,9 +6,10 @@
 
 One "step" = one complete collective R(Q) on the WHOLE cubed sphere (6 panels, n=8 (p=7),
 60x60 elements per panel, V vertical elements), inputs resident in HBM, result left in HBM,
-halo exchange included.  STRONG scaling: the same sphere is split over min(N,6) GPUs
-(panel p on rank p % min(N,6); at N=1 all six panels live on one GPU and exchange by
-aliasing; ranks >= 6 idle).  value = DOF-updates/s = 5 vars * points * 6 panels * evals/s.
+halo exchange included.  STRONG scaling: the same sphere is cut into 6 k^2 tiles (the reference's own
+decomposition), k the smallest that spreads evenly over the N GPUs (k=1, whole panels, for N = 1, 2, 3, 6;
+k=2 for N = 4, 8); at N=1 all six panels live on one GPU and exchange by aliasing.
+value = DOF-updates/s = 5 vars * points * 6 panels * evals/s.
 
 Prints ONE JSON line (rank 0) with `roofline` for the dominant kernel (euler_rhs_kernel,
 timed live with HIP events on its launch stream) and `cpu_baseline` (the NumPy oracle on a
@@ -115,6 +116,8 @@ def main():
     ap.add_argument("--seed", type=int, default=20250824)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--whole-panels", action="store_true", help="one tile per panel even when 6 does not divide N")
+    ap.add_argument("--tiles-per-side", type=int, default=0, help="force k (6 k^2 tiles); default: chosen from N")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary (shallow-water S7) measurement")
     args = ap.parse_args()
 
@@ -136,20 +139,27 @@ def main():
 
     from wxfactory_amd import _lib, synthetic
     from wxfactory_amd.exchange import PanelExchange
-    from wxfactory_amd.panels import panels_of_rank
+    from wxfactory_amd.panels import CubeTopology, tiles_of_rank, tiles_per_side_for
     from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D
 
     _lib.load()
     n, H, V = args.n, args.H, args.V
     ops = synthetic.dfr_ops(n)
-    mine = panels_of_rank(rank, world)
+    # the sphere is cut into 6 k^2 tiles (the reference's own decomposition, process_topology.py:69-94) with the
+    # smallest k that spreads evenly over the ranks: k = 1 (whole panels) for 1, 2, 3, 6 GPUs, k = 2 for 4 and 8
+    k = args.tiles_per_side or (1 if args.whole_panels else tiles_per_side_for(world))
+    if H % k:
+        raise SystemExit(f"H={H} is not divisible by {k} tiles per panel side")
+    topo = CubeTopology(k)
+    Ht = H // k
+    mine = tiles_of_rank(rank, world, topo.ntiles)
     plans, qs = {}, {}
-    for p in mine:
-        metric = synthetic.euler3d_metric(n, H, V, p, dev, args.seed)
-        plans[p] = Euler3DPlan(n, H, V, 31, p, ops, metric)
-        qs[p] = synthetic.euler3d_state(n, H, V, p, dev, args.seed)
-    edge_doubles = 5 * V * H * n * n  # WX_EULER3D_EDGE_FIELDS
-    ex = PanelExchange(edge_doubles, dev, rank=rank, world_size=world)
+    for t in mine:
+        metric = synthetic.euler3d_metric(n, Ht, V, t, dev, args.seed)
+        plans[t] = Euler3DPlan(n, Ht, V, 31, topo.locate(t)[0], ops, metric, on_panel_edge=topo.on_panel_edge(t))
+        qs[t] = synthetic.euler3d_state(n, Ht, V, t, dev, args.seed)
+    edge_doubles = 5 * V * Ht * n * n  # WX_EULER3D_EDGE_FIELDS
+    ex = PanelExchange(edge_doubles, dev, rank=rank, world_size=world, tiles_per_side=k)
     rhs = RhsEuler3D(plans, ex, overlap=not args.no_overlap)
 
     # live timing of the dominant kernel: HIP events on the launch stream around every K2 launch
@@ -206,17 +216,17 @@ def main():
         by_region = {}
         for a, b, region in ev:
             by_region.setdefault(region, []).append(a.elapsed_time(b) * 1e-3)
-        w = H - 2 if H > 2 else 0
-        frac_of_panel = {_lib.WX_REGION_ALL: 1.0, _lib.WX_REGION_INTERIOR: (w * w) / (H * H),
-                         _lib.WX_REGION_BOUNDARY: 1.0 - (w * w) / (H * H)}
+        w = Ht - 2 if Ht > 2 else 0
+        frac_of_panel = {_lib.WX_REGION_ALL: 1.0, _lib.WX_REGION_INTERIOR: (w * w) / (Ht * Ht),
+                         _lib.WX_REGION_BOUNDARY: 1.0 - (w * w) / (Ht * Ht)}
         # the dominant launch shape: ALL at N=1, INTERIOR when the exchange is overlapped
         region = max(by_region, key=lambda r: sum(by_region[r]))
         tk = sum(by_region[region]) / len(by_region[region])
-        bytes_launch = ALGO_BYTES_PER_POINT * pts_panel * frac_of_panel[region]
+        bytes_launch = ALGO_BYTES_PER_POINT * (pts_panel / (k * k)) * frac_of_panel[region]
         achieved = bytes_launch / tk / 1e9
         roof = {"bound": "hbm", "kernel": "euler_rhs_kernel<8,double>", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic(region, n, H, V), "launch_ms": round(tk * 1e3, 4),
+                "traffic": pmc_traffic(region, n, Ht, V), "launch_ms": round(tk * 1e3, 4),
                 "algorithmic_bytes_per_launch": bytes_launch,
                 "region": {0: "all", 1: "interior", 2: "boundary"}[region]}
 
@@ -229,7 +239,8 @@ def main():
             "rhs_evals_per_s": evals_per_s,
             "config": {"workload": f"E7: 3-D Euler RHS, n={n} (p={n-1}), H={H}x{H} elem/panel, V={V}, 6 panels "
                                    f"({5*pts_panel*6} DOF), halo exchange included",
-                       "n": n, "H": H, "V": V, "panels_per_gpu": len(mine), "parallelism": f"panel-dd{min(world,6)}",
+                       "n": n, "H": H, "V": V, "tiles": topo.ntiles, "tile_H": Ht, "tiles_per_gpu": len(mine),
+                       "parallelism": f"tile-dd{min(world, topo.ntiles)}",
                        "overlap": not args.no_overlap},
             "roofline": roof,
         }

@@ -108,6 +108,13 @@ typedef struct wx_euler3d_plan wx_euler3d_plan;
  * Allocates the plan's private interface buffer (6*5*n^2 values per element). */
 wx_status wx_euler3d_plan_create(wx_euler3d_plan** plan, int n, int H, int V, int case_number, wx_dtype dtype,
                                  int panel, const wx_dfr_ops* ops, const wx_euler3d_metric* metric);
+/* The same for one of k x k tiles of a panel (the reference's 6 k^2-rank decomposition,
+ * process_topology.py:69-94): on_panel_edge[e] != 0 where edge e (S,N,W,E) of the tile lies on the
+ * panel's edge and takes the panel's rotation / flip; interior tile edges exchange unrotated, unflipped
+ * (process_topology.py:219-228).  H, the metric arrays and boundary_sn/we are the TILE's. */
+wx_status wx_euler3d_plan_create_tile(wx_euler3d_plan** plan, int n, int H, int V, int case_number, wx_dtype dtype,
+                                      int panel, const int on_panel_edge[4], const wx_dfr_ops* ops,
+                                      const wx_euler3d_metric* metric);
 wx_status wx_euler3d_plan_destroy(wx_euler3d_plan* plan);
 
 /* Values per face point in an edge message: the 5 prognostic variables the reference exchanges
@@ -198,6 +205,8 @@ typedef struct wx_sw_plan wx_sw_plan;
 
 wx_status wx_sw_plan_create(wx_sw_plan** plan, int n, int H, wx_dtype dtype, int panel, const wx_dfr_ops* ops,
                             const wx_sw_metric* metric);
+wx_status wx_sw_plan_create_tile(wx_sw_plan** plan, int n, int H, wx_dtype dtype, int panel, const int on_panel_edge[4],
+                                 const wx_dfr_ops* ops, const wx_sw_metric* metric);
 wx_status wx_sw_plan_destroy(wx_sw_plan* plan);
 /* Elements of dtype per edge message: 3*H*n, layout [var][along][n]: exactly what the reference's
  * exchange delivers (rhs_sw.py:103-117, 138-150): h (+ surface height), then the rotated (hu1, hu2). */

@@ -42,7 +42,8 @@ RHO, RHO_U1, RHO_U2, RHO_W, RHO_THETA = 0, 1, 2, 3, 4
 
 
 class Euler3DOracle:
-    def __init__(self, n, H, V, case_number, ops, metric, boundary_sn=None, boundary_we=None, panel=0):
+    def __init__(self, n, H, V, case_number, ops, metric, boundary_sn=None, boundary_we=None, panel=0,
+                 on_panel_edge=(True, True, True, True)):
         """ops: dict with extrap_neg, extrap_pos, diff_solpt, correction, highfilter (1-D pieces).
         metric: dict with the reference's *_new arrays (see EULER_METRIC_ATTRS in gen_golden.py),
         optionally damp_coef/damp_uref for cases 21/22."""
@@ -56,6 +57,8 @@ class Euler3DOracle:
         self.HF = numpy.asarray(ops["highfilter"], dtype=float)
         self.m = metric
         self.panel = panel
+        # k x k tiles per panel: interior tile edges are neither rotated nor flipped (process_topology.py:219-228)
+        self.on_panel_edge = tuple(on_panel_edge)
         self.boundary_sn = boundary_sn
         self.boundary_we = boundary_we
 
@@ -129,8 +132,9 @@ class Euler3DOracle:
         for e in range(4):
             a = raw[e].reshape(5, V, H, n, n).copy()
             bd = self.boundary_sn if e < 2 else self.boundary_we  # (H, n, n)
-            a[RHO_U1], a[RHO_U2] = cs.rotate(self.panel, e, a[RHO_U1], a[RHO_U2], bd)
-            if cs.FLIP[self.panel][e]:
+            if self.on_panel_edge[e]:
+                a[RHO_U1], a[RHO_U2] = cs.rotate(self.panel, e, a[RHO_U1], a[RHO_U2], bd)
+            if cs.FLIP[self.panel][e] and self.on_panel_edge[e]:
                 a = numpy.flip(a, axis=(-3, -1))
             out.append(numpy.ascontiguousarray(a).reshape(5, V, H, n2))
         return out

@@ -473,6 +473,75 @@ def callers_case(name, ini, overrides, dt_rk=2.0, dt_jvp=30.0, perturb=0.01, see
     _run6(name, work)
 
 
+def euler_tiles_case(name, ini, overrides, n_ranks, metric_tiles, perturb=0.01, seed=4242):
+    """3-D Euler on 6 k^2 tiles (k^2 ranks per panel): pins the tile topology, the identity rotation on
+    interior tile edges and the panel-edge tables for tiles (process_topology.py:69-256)."""
+    print(f"[{name}] {ini} on {n_ranks} ranks", flush=True)
+
+    def work(rank):
+        from device import CpuDevice
+        from process_topology import ProcessTopology
+        from geometry import CubedSphere3D, DFROperators
+        from init.init_state_vars import init_state_vars
+        from rhs.rhs_selector import RhsBundle
+
+        cfg = _config(ini, overrides)
+        import math
+        per_line = int(math.isqrt(n_ranks // 6))
+        cfg.num_elements_horizontal = cfg.num_elements_horizontal_total // per_line
+        comm = MPI.COMM_WORLD
+        dev = CpuDevice(comm)
+        pt = ProcessTopology(dev, comm=comm)
+        geom = CubedSphere3D(cfg.num_elements_horizontal, cfg.num_elements_vertical, cfg.num_solpts,
+                             cfg.lambda0, cfg.phi0, cfg.alpha0, cfg.ztop, pt, cfg, dev)
+        ops = DFROperators(geom, cfg, dev)
+        Q, topo, metric = init_state_vars(geom, ops, cfg)
+        rhs = RhsBundle(geom, ops, metric, topo, pt, cfg, Q.shape, False)
+        rng = numpy.random.default_rng(seed + rank)
+        Q = Q * (1.0 + perturb * rng.uniform(-1.0, 1.0, Q.shape))
+        Q[3] = Q[3] + Q[0] * perturb * 1e-5 * rng.uniform(-1.0, 1.0, Q[0].shape)
+        out = {"Q": Q.copy(), "R": rhs.full(Q).copy()}
+        r = rhs.full
+        for a in EULER_LIGHT_ATTRS:
+            out["phase/" + a] = numpy.array(getattr(r, a), copy=True)
+        out["topo/neighbors"] = numpy.array(pt.sources, dtype=numpy.int64)      # S, N, W, E ranks
+        out["topo/flip"] = numpy.array(pt.flip, dtype=numpy.int64)
+        out["topo/panel_row_col"] = numpy.array([pt.my_panel, pt.my_row, pt.my_col], dtype=numpy.int64)
+        if rank in metric_tiles:
+            for a in EULER_METRIC_ATTRS:
+                out["metric/" + a] = numpy.array(getattr(metric, a), copy=True)
+        out["geom/boundary_sn_new"] = numpy.array(geom.boundary_sn_new, copy=True)
+        out["geom/boundary_we_new"] = numpy.array(geom.boundary_we_new, copy=True)
+        if rank == 0:
+            out.update(_ops_1d(ops, geom))
+            out["meta/case_number"] = numpy.int64(cfg.case_number)
+            out["meta/n"] = numpy.int64(cfg.num_solpts)
+            out["meta/H"] = numpy.int64(cfg.num_elements_horizontal)
+            out["meta/V"] = numpy.int64(cfg.num_elements_vertical)
+            out["meta/k"] = numpy.int64(per_line)
+            out["meta/eps"] = numpy.float64(numpy.sqrt(numpy.finfo(float).eps))
+        return out
+
+    t0 = time.time()
+    MPI.reset_world(n_ranks)
+    res, err = MPI.run_ranks(work, n_ranks)
+    for e in err:
+        if e:
+            print(e)
+            raise SystemExit(1)
+    flat = {}
+    for p, d in enumerate(res):
+        for k, v in d.items():
+            if k.startswith(("ops/", "meta/")):
+                flat[k] = v
+            else:
+                flat[f"p{p}/{k}"] = v
+    path = os.path.join(GOLDEN, name + ".npz")
+    numpy.savez_compressed(path, **flat)
+    print(f"   -> {path}  {os.path.getsize(path)/1e6:.2f} MB  ({time.time()-t0:.1f}s)", flush=True)
+    MPI.reset_world(6)
+
+
 def state_file_case(name):
     """Bytes written by the reference's save_state (output/state.py:9-16) for a seeded global state."""
     import types
@@ -533,6 +602,10 @@ CASES = {
     "callers_euler3d_n3_h3_v2": lambda nm: callers_case(
         nm, "dcmip31.ini", dict(num_solpts=3, num_elements_horizontal=3, num_elements_vertical=2)),
     "state_file_v": state_file_case,
+    # 24 ranks = 2x2 tiles per panel (the reference's own 6 k^2 decomposition)
+    "euler3d_tiles24_n3_h2_v2": lambda nm: euler_tiles_case(
+        nm, "dcmip31.ini", dict(num_solpts=3, num_elements_horizontal=4, num_elements_vertical=2), 24,
+        metric_tiles=(0, 3, 6, 9, 13, 18, 23)),
     # 2-D Cartesian Euler: the plumbing reference (config/gaussian_bubble.ini, smaller grid)
     "cart2d_bubble_n5": lambda nm: cart2d_case(nm, "gaussian_bubble.ini",
                                                dict(num_solpts=5, num_elements_horizontal=7, num_elements_vertical=9)),

@@ -193,3 +193,40 @@ def test_dual_number_arithmetic_equals_complex_step(name):
         ierr = var_err(R.imag, ref.imag) / np.maximum(var_max(ref.imag), g.eps * s * 1e-3)
         assert (ierr <= (1e-10 if tight else 1e-3)).all(), (name, p, ierr)
         plan.close()
+
+
+def test_tiles_of_a_24_rank_decomposition():
+    """k x k tiles per panel (the reference's 6 k^2 ranks): plans with on_panel_edge flags reproduce what the
+    reference packed and computed on 24 MPI ranks (interior tile edges unrotated/unflipped)."""
+    from tests.gpu_util import device_metric, to_dev
+    from wxfactory_amd.panels import CubeTopology
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan
+
+    g = golden("euler3d_tiles24_n3_h2_v2")
+    topo = CubeTopology(int(g["meta/k"]))
+    for t in g.metric_panels():
+        plan = Euler3DPlan(g.n, g.H, g.V, g.case, topo.locate(t)[0], g.ops, device_metric(g, t, DEV),
+                           on_panel_edge=topo.on_panel_edge(t))
+        q = to_dev(g.q(t))
+        send = torch.zeros((4, plan.edge_count), dtype=torch.float64, device=DEV)
+        plan.extrap_pack(q, list(send))
+        out = torch.full_like(q, float("nan"))
+        plan.rhs(q, [to_dev(halo7(h)) for h in g.halo(t)], out)
+        torch.cuda.synchronize()
+        got = send.cpu().numpy().reshape(4, EDGE_FIELDS, g.V, g.H, g.n**2)
+        for e in range(4):
+            ref = halo7(g.halo(topo.neighbor(t, e))[topo.landing(t, e)])
+            assert np.abs(got[e] - ref).max() <= 1e-13 * np.abs(ref).max(), (t, e)
+        ref = g.r(t)
+        assert (var_err(out.cpu().numpy(), ref) <= TOL * np.maximum(var_max(ref), _scale_tile(g, t, topo))).all(), t
+        plan.close()
+
+
+def _scale_tile(g, t, topo):
+    from oracle.euler3d import Euler3DOracle
+
+    o = Euler3DOracle(g.n, g.H, g.V, g.case, g.ops, g.metric(t), g[f"p{t}/geom/boundary_sn_new"],
+                      g[f"p{t}/geom/boundary_we_new"], panel=topo.locate(t)[0], on_panel_edge=topo.on_panel_edge(t))
+    want = {}
+    o.rhs(g.q(t), g.halo(t), want=want)
+    return o.cancel_scale(want)

@@ -98,9 +98,9 @@ def test_panel_graph_matches_reference_delivery():
     N, S, W, E = 1, 0, 2, 3
     assert lands == [[N, S, E, W], [E, E, E, W], [S, N, E, W], [W, W, E, W], [N, N, N, N], [S, S, S, S]]
     assert owner_of_panels(1) == [0] * 6
-    assert owner_of_panels(4) == [0, 1, 2, 3, 0, 1]
+    assert owner_of_panels(4) == [0, 1, 2, 3, 0, 1]  # 6 tiles do not split evenly over 4: round-robin
     assert owner_of_panels(8) == [0, 1, 2, 3, 4, 5]
-    assert panels_of_rank(7, 8) == [] and panels_of_rank(1, 2) == [1, 3, 5]
+    assert panels_of_rank(7, 8) == [] and panels_of_rank(1, 2) == [3, 4, 5]  # contiguous runs when even
 
 
 class _CpuPlan:
@@ -208,5 +208,76 @@ def test_checkpoint_layout_is_rank_count_independent(world):
     procs = [ctx.Process(target=_state_worker, args=(r, world, port, q)) for r in range(world)]
     [p.start() for p in procs]
     res = [q.get(timeout=180) for _ in range(world)]
+    [p.join(timeout=60) for p in procs]
+    assert all(r[1] == "ok" for r in res), [r for r in res if r[1] != "ok"]
+
+
+# ------------------------------------------------------------------------------------------------
+# 6 k^2 tiles (k = 2): the reference's own finer decomposition, pinned by a 24-rank run of the reference
+# ------------------------------------------------------------------------------------------------
+TILES = "euler3d_tiles24_n3_h2_v2"
+
+
+def test_tile_topology_matches_reference_process_topology():
+    from wxfactory_amd.panels import CubeTopology, tiles_per_side_for
+
+    g = golden(TILES)
+    T = CubeTopology(int(g["meta/k"]))
+    for t in range(T.ntiles):
+        assert [T.neighbor(t, e) for e in range(4)] == list(g[f"p{t}/topo/neighbors"])
+        assert T.flips(t) == [bool(x) for x in g[f"p{t}/topo/flip"]]
+        assert T.locate(t) == tuple(int(x) for x in g[f"p{t}/topo/panel_row_col"])
+    assert [tiles_per_side_for(n) for n in (1, 2, 3, 4, 6, 8, 24)] == [1, 1, 1, 2, 1, 2, 2]
+
+
+def _tile_oracle(g, t, topo):
+    from oracle.euler3d import Euler3DOracle
+
+    return Euler3DOracle(g.n, g.H, g.V, g.case, g.ops, g.metric(t), g[f"p{t}/geom/boundary_sn_new"],
+                         g[f"p{t}/geom/boundary_we_new"], panel=topo.locate(t)[0], on_panel_edge=topo.on_panel_edge(t))
+
+
+def _tile_worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from wxfactory_amd.exchange import PanelExchange
+        from wxfactory_amd.panels import tiles_of_rank
+
+        g = golden(TILES)
+        k = int(g["meta/k"])
+        ex = PanelExchange(EDGE_FIELDS * g.V * g.H * g.n**2, "cpu", rank=rank, world_size=world, tiles_per_side=k)
+        assert ex.local == tiles_of_rank(rank, world, 6 * k * k)
+        for t in ex.local:
+            o = _tile_oracle(g, t, ex.topo)
+            for e, s in enumerate(o.pack_edges(o.extrapolate(g.q(t)))):
+                ex.send_view(t, e).copy_(torch.from_numpy(halo7(s).reshape(-1)))
+        ex.start()
+        ex.wait()
+        for t in ex.local:
+            for e in range(4):
+                got = ex.halo_view(t, e).numpy().reshape(EDGE_FIELDS, g.V, g.H, g.n**2)
+                ref = halo7(g.halo(t)[e])
+                assert np.abs(got - ref).max() < 1e-13 * np.abs(ref).max(), (rank, t, e)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, traceback.format_exc()))
+        raise
+
+
+@pytest.mark.parametrize("world", [1, 4, 8])
+def test_tile_exchange_over_gloo(world):
+    """24 tiles over 1, 4 and 8 ranks (6, 3 tiles each): pack (rotation/flip only on panel edges) + routing
+    == the halos the reference delivered on 24 MPI ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tile_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=240) for _ in range(world)]
     [p.join(timeout=60) for p in procs]
     assert all(r[1] == "ok" for r in res), [r for r in res if r[1] != "ok"]

@@ -55,6 +55,8 @@ SIGNATURES = {
     "wx_device_count": (c_int, []),
     "wx_euler3d_plan_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int,
                                        POINTER(DfrOps), POINTER(Euler3DMetric)]),
+    "wx_euler3d_plan_create_tile": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_int),
+                                            POINTER(DfrOps), POINTER(Euler3DMetric)]),
     "wx_euler3d_plan_destroy": (c_int, [c_void_p]),
     "wx_euler3d_edge_count": (c_size_t, [c_void_p]),
     "wx_euler3d_extrap_pack": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p]),
@@ -67,6 +69,8 @@ SIGNATURES = {
     "wx_euler3d_jvp": (c_int, [c_void_p, c_void_p, c_void_p, c_double, POINTER(c_void_p), c_void_p, c_double, c_int,
                                c_void_p]),
     "wx_sw_plan_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, POINTER(DfrOps), POINTER(SwMetric)]),
+    "wx_sw_plan_create_tile": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(DfrOps),
+                                       POINTER(SwMetric)]),
     "wx_sw_plan_destroy": (c_int, [c_void_p]),
     "wx_sw_edge_count": (c_size_t, [c_void_p]),
     "wx_sw_extrap_pack": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p]),

@@ -780,6 +780,14 @@ extern "C" {
 
 wx_status wx_euler3d_plan_create(wx_euler3d_plan** out, int n, int H, int V, int case_number, wx_dtype dtype,
                                  int panel, const wx_dfr_ops* ops, const wx_euler3d_metric* m) {
+    static const int all_edges[4] = {1, 1, 1, 1};
+    return wx_euler3d_plan_create_tile(out, n, H, V, case_number, dtype, panel, all_edges, ops, m);
+}
+
+wx_status wx_euler3d_plan_create_tile(wx_euler3d_plan** out, int n, int H, int V, int case_number, wx_dtype dtype,
+                                      int panel, const int on_panel_edge[4], const wx_dfr_ops* ops,
+                                      const wx_euler3d_metric* m) {
+    if (!on_panel_edge) return fail(WX_ERR_INVALID, "wx_euler3d_plan_create_tile: null on_panel_edge");
     if (!out || !ops || !m) return fail(WX_ERR_INVALID, "wx_euler3d_plan_create: null argument");
     *out = nullptr;
     if (n < 2 || n > kMaxN) return fail(WX_ERR_UNSUPPORTED, "num_solpts %d not in 2..%d", n, kMaxN);
@@ -823,9 +831,10 @@ wx_status wx_euler3d_plan_create(wx_euler3d_plan** out, int n, int H, int V, int
         hc.cm[i] = ops->correction[2 * i]; hc.cp[i] = ops->correction[2 * i + 1];
         for (int j = 0; j < n; ++j) { hc.D[i * n + j] = ops->diff_solpt[i * n + j]; hc.HF[i * n + j] = ops->highfilter[i * n + j]; }
     }
-    for (int ed = 0; ed < 4; ++ed) {
-        hc.flip[ed] = kFlip[panel][ed];
-        for (int i = 0; i < 8; ++i) hc.rot[ed][i] = kRot[panel][ed][i];
+    static const double identity[8] = {1, 0, 0, 0, 0, 1, 0, 0};
+    for (int ed = 0; ed < 4; ++ed) {  // interior tile edges: no flip, no rotation (process_topology.py:219-228)
+        hc.flip[ed] = on_panel_edge[ed] ? kFlip[panel][ed] : 0;
+        for (int i = 0; i < 8; ++i) hc.rot[ed][i] = on_panel_edge[ed] ? kRot[panel][ed][i] : identity[i];
     }
     e = hipMalloc((void**)&pl->consts, sizeof(EulerConsts));
     if (e == hipSuccess) e = hipMemcpy(pl->consts, &hc, sizeof(hc), hipMemcpyHostToDevice);

@@ -16,12 +16,12 @@ from typing import Dict, List, Optional, Tuple
 import torch
 import torch.distributed as dist
 
-from .panels import NEIGHBOR, landing_edge, owner_of_panels
+from .panels import CubeTopology, owner_of_tiles
 
 
 class PanelExchange:
     def __init__(self, edge_doubles: int, device, rank: int = 0, world_size: int = 1, group=None,
-                 loopback: bool = False):
+                 loopback: bool = False, tiles_per_side: int = 1):
         """edge_doubles: float64 words per edge message (5*V*H*n^2, doubled for complex128);
         buffers are float64 (complex payloads travel as interleaved re/im, which RCCL accepts)."""
         dtype = torch.float64
@@ -31,22 +31,24 @@ class PanelExchange:
         self.loopback = loopback
         self.rank, self.world = rank, world_size
         self.group = group
-        owner = owner_of_panels(world_size)
+        # tiles: 6 k^2 of them (k = 1: one tile per panel); "panel" below means tile id
+        self.topo = topo = CubeTopology(tiles_per_side)
+        owner = owner_of_tiles(world_size, topo.ntiles)
         self.owner = owner
-        self.local = [p for p in range(6) if owner[p] == rank]
+        self.local = [p for p in range(topo.ntiles) if owner[p] == rank]
 
         # messages this rank sends: (src panel, src edge) -> (dst rank, dst panel, dst edge)
         local_msgs, remote_out, remote_in = [], {}, {}
         for p in self.local:
             for e in range(4):
-                q, e2 = NEIGHBOR[p][e], landing_edge(p, e)
+                q, e2 = topo.neighbor(p, e), topo.landing(p, e)
                 if owner[q] == rank and not loopback:
                     local_msgs.append((p, e, q, e2))
                 else:
                     remote_out.setdefault(owner[q], []).append((q, e2, p, e))
         for q in self.local:
             for e2 in range(4):
-                p = NEIGHBOR[q][e2]
+                p = topo.neighbor(q, e2)
                 if owner[p] != rank or loopback:
                     remote_in.setdefault(owner[p], []).append((q, e2))
         # canonical order inside each rank pair: by (destination panel, destination edge)

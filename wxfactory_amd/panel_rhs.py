@@ -25,12 +25,13 @@ def _ptr_array(items):
 class PanelRhs:
     def __init__(self, plans: Dict[int, object], exchange: PanelExchange = None, overlap: bool = True,
                  rank: int = 0, world_size: int = 1, group=None, device=None, edge_count: int = 0,
-                 complex_arith: str = "complex"):
+                 complex_arith: str = "complex", tiles_per_side: int = 1):
         """`device` / `edge_count` are only needed by a rank that owns no panel (plans == {})."""
         if complex_arith not in ("complex", "dual"):
             raise ValueError("complex_arith must be 'complex' (true complex arithmetic) or 'dual' (first order)")
         self.complex_arith = complex_arith
-        self.panels = sorted(plans)
+        self.tiles_per_side = exchange.topo.k if exchange is not None else tiles_per_side
+        self.panels = sorted(plans)  # tile ids (k = 1: panel ids)
         self.overlap = overlap
         self.rank, self.world, self.group = rank, world_size, group
         first = plans[self.panels[0]] if self.panels else None
@@ -54,7 +55,8 @@ class PanelRhs:
         if dtype not in self._ex:
             words = self.edge_count * (2 if dtype.is_complex else 1)
             dev = self.device if self.device is not None else "cpu"
-            self._ex[dtype] = PanelExchange(words, dev, rank=self.rank, world_size=self.world, group=self.group)
+            self._ex[dtype] = PanelExchange(words, dev, rank=self.rank, world_size=self.world, group=self.group,
+                                            tiles_per_side=self.tiles_per_side)
         return self._ex[dtype]
 
     @property

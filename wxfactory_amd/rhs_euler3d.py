@@ -29,7 +29,8 @@ class Euler3DPlan:
     (kept alive here) exactly as the reference's pde module borrows NumPy/CuPy buffers."""
 
     def __init__(self, n: int, H: int, V: int, case_number: int, panel: int, ops: Dict[str, numpy.ndarray],
-                 metric: Dict[str, torch.Tensor], dtype: torch.dtype = torch.float64, dual: bool = False):
+                 metric: Dict[str, torch.Tensor], dtype: torch.dtype = torch.float64, dual: bool = False,
+                 on_panel_edge=(True, True, True, True)):
         self.lib = _lib.load()
         if dtype not in _DTYPES:
             raise TypeError(f"dtype must be float64 or complex128, not {dtype}")
@@ -40,6 +41,7 @@ class Euler3DPlan:
         self.n, self.H, self.V, self.case_number, self.panel, self.dtype = n, H, V, case_number, panel, dtype
         self.shape = (5, V, H, H, n**3)
         self._ops, self._metric = ops, metric
+        self.on_panel_edge = tuple(bool(x) for x in on_panel_edge)  # k x k tiles per panel: interior edges False
         self._keep = []
         o = DfrOps()
         for k in ("extrap_neg", "extrap_pos", "diff_solpt", "correction", "highfilter"):
@@ -70,8 +72,9 @@ class Euler3DPlan:
             setattr(m, k, t.data_ptr())
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            check(self.lib.wx_euler3d_plan_create(ctypes.byref(self._h), n, H, V, case_number, wx_dtype, panel,
-                                                  ctypes.byref(o), ctypes.byref(m)), "wx_euler3d_plan_create")
+            flags = (ctypes.c_int * 4)(*[int(x) for x in self.on_panel_edge])
+            check(self.lib.wx_euler3d_plan_create_tile(ctypes.byref(self._h), n, H, V, case_number, wx_dtype, panel, flags,
+                                                       ctypes.byref(o), ctypes.byref(m)), "wx_euler3d_plan_create_tile")
         self.edge_count = int(self.lib.wx_euler3d_edge_count(self._h))
 
     axpy_two = True  # rhs_axpy takes a second array (z, d)
@@ -79,7 +82,7 @@ class Euler3DPlan:
     def twin(self, dtype, dual: bool = False):
         """Plan of another dtype over the same (borrowed) metric tensors."""
         return Euler3DPlan(self.n, self.H, self.V, self.case_number, self.panel, self._ops, self._metric, dtype=dtype,
-                           dual=dual)
+                           dual=dual, on_panel_edge=self.on_panel_edge)
 
     def _check_q(self, q):
         if q.dtype != self.dtype or q.numel() != 5 * self.V * self.H * self.H * self.n**3 or not q.is_contiguous() \

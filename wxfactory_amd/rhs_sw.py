@@ -23,7 +23,7 @@ _TOPO = ("hsurf", "dzdx1", "dzdx2", "hsurf_itf_i", "hsurf_itf_j")
 
 class SwPlan:
     def __init__(self, n: int, H: int, panel: int, ops: Dict[str, numpy.ndarray], metric: Dict[str, torch.Tensor],
-                 dtype: torch.dtype = torch.float64, dual: bool = False):
+                 dtype: torch.dtype = torch.float64, dual: bool = False, on_panel_edge=(True, True, True, True)):
         self.lib = _lib.load()
         if dtype not in _DTYPES:
             raise TypeError(f"dtype must be float64 or complex128, not {dtype}")
@@ -34,6 +34,7 @@ class SwPlan:
         self.n, self.H, self.panel, self.dtype = n, H, panel, dtype
         self.shape = (3, H, H, n * n)
         self._ops, self._metric = ops, metric
+        self.on_panel_edge = tuple(bool(x) for x in on_panel_edge)
         self._keep = []
         o = DfrOps()
         for k in ("extrap_neg", "extrap_pos", "diff_solpt", "correction", "highfilter"):
@@ -63,12 +64,14 @@ class SwPlan:
             setattr(m, k, t.data_ptr())
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            check(self.lib.wx_sw_plan_create(ctypes.byref(self._h), n, H, wx_dtype, panel, ctypes.byref(o),
-                                             ctypes.byref(m)), "wx_sw_plan_create")
+            flags = (ctypes.c_int * 4)(*[int(x) for x in self.on_panel_edge])
+            check(self.lib.wx_sw_plan_create_tile(ctypes.byref(self._h), n, H, wx_dtype, panel, flags, ctypes.byref(o),
+                                                  ctypes.byref(m)), "wx_sw_plan_create_tile")
         self.edge_count = int(self.lib.wx_sw_edge_count(self._h))
 
     def twin(self, dtype, dual: bool = False):
-        return SwPlan(self.n, self.H, self.panel, self._ops, self._metric, dtype=dtype, dual=dual)
+        return SwPlan(self.n, self.H, self.panel, self._ops, self._metric, dtype=dtype, dual=dual,
+                      on_panel_edge=self.on_panel_edge)
 
     def _check_q(self, q):
         if q.dtype != self.dtype or q.numel() != 3 * self.H * self.H * self.n**2 or not q.is_contiguous() \
