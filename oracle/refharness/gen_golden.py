@@ -312,6 +312,7 @@ def sw_case(name, ini, overrides, perturb=0.0, seed=4321):
             out["meta/n"] = numpy.int64(cfg.num_solpts)
             out["meta/H"] = numpy.int64(cfg.num_elements_horizontal)
             out["meta/eps"] = numpy.float64(eps)
+            out["meta/grid_rotation"] = numpy.array([cfg.lambda0, cfg.phi0, cfg.alpha0], dtype=float)
             n = cfg.num_solpts
             u = numpy.random.default_rng(7).uniform(-1, 1, n * n)
             out["kron/u"] = u
