@@ -81,11 +81,14 @@ def extras(dev, seed):
     """Secondary, non-headline numbers on the same GPU: the shallow-water S7 workload of BASELINE.json's
     galewsky line (n=8, 60x60 elements/panel, 6 panels), whole-sphere R(Q)."""
     from wxfactory_amd import synthetic
+    from wxfactory_amd.geometry import CubedSphereTile2D, metric2d_torch
     from wxfactory_amd.rhs_sw import RhsShallowWater, SwPlan
 
     n, H = 8, 60
     ops = synthetic.dfr_ops(n)
-    plans = {p: SwPlan(n, H, p, ops, synthetic.sw_metric(n, H, p, dev, seed)) for p in range(6)}
+    # the true equiangular-gnomonic metric (wxfactory_amd/geometry.py, pinned against the reference's), synthetic state
+    plans = {p: SwPlan(n, H, p, ops, metric2d_torch(CubedSphereTile2D(n, H, p, phi0=0.7853981633974483), dev))
+             for p in range(6)}
     Q = torch.stack([synthetic.sw_state(n, H, p, dev, seed) for p in range(6)])
     rhs = RhsShallowWater(plans)
     for _ in range(5):

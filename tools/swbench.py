@@ -10,6 +10,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 from wxfactory_amd import synthetic  # noqa: E402
+from wxfactory_amd.geometry import CubedSphereTile2D, metric2d_torch  # noqa: E402
 from wxfactory_amd.rhs_sw import RhsShallowWater, SwPlan  # noqa: E402
 
 dev = torch.device("cuda", 0)
@@ -17,7 +18,7 @@ n, H = 8, 60
 ops = synthetic.dfr_ops(n)
 plans, qs = {}, []
 for p in range(6):
-    plans[p] = SwPlan(n, H, p, ops, synthetic.sw_metric(n, H, p, dev))
+    plans[p] = SwPlan(n, H, p, ops, metric2d_torch(CubedSphereTile2D(n, H, p, phi0=0.7853981633974483), dev))
     qs.append(synthetic.sw_state(n, H, p, dev))
 Q = torch.stack(qs)
 rhs = RhsShallowWater(plans)
