@@ -155,6 +155,19 @@ wx_status wx_euler3d_rhs_axpy2(wx_euler3d_plan* plan, const void* q, const void*
                                const void* z, void* out, double a, double b, double c, double d, wx_region region,
                                wx_stream stream);
 
+/* Stage pipeline for explicit Runge-Kutta loops.  The plan owns two interface buffers (slots 0, 1).
+ * wx_euler3d_stage evaluates  out = a*y + b*q + c*R(q) + d*z  reading q's faces from slot `itf_in`
+ * and - when prepare_next != 0 - extrapolates `out` (the next stage's state, still in registers) to
+ * the element faces into the OTHER slot and packs its tile-edge faces into next_send[e]: the next
+ * stage then needs no wx_euler3d_extrap_pack (one read of Q and a launch saved per stage).
+ * next_send must not be the buffers the current stage's halos alias.
+ * wx_euler3d_extrap_pack_slot is wx_euler3d_extrap_pack into a chosen slot (pipeline start-up). */
+wx_status wx_euler3d_extrap_pack_slot(wx_euler3d_plan* plan, const void* q, void* const send[4], int slot,
+                                      wx_stream stream);
+wx_status wx_euler3d_stage(wx_euler3d_plan* plan, const void* q, const void* const halo[4], const void* y, const void* z,
+                           void* out, double a, double b, double c, double d, wx_region region, int itf_in,
+                           void* const next_send[4], int prepare_next, wx_stream stream);
+
 /* Complex-step Jacobian-vector product (solvers/matvec.py:56-61) with no complex array in HBM.
  * The plan must be WX_DUAL128.  q and v are REAL (n-double) arrays in the state layout; the kernels form
  * the dual state (q, eps*v) on load, exchange dual faces as usual (send/halo buffers are those of a

@@ -166,6 +166,20 @@ def test_rccl_exchange_path_on_one_gpu():
             ref = g.r(p)
             err = var_err(a[p].cpu().numpy(), ref)
             assert (err <= TOL * np.maximum(var_max(ref), _scale(g, p, False))).all()
+        # stage pipeline over the collective: INTERIOR / BOUNDARY launches each write the faces and the
+        # edge messages of their part of the next state into the second buffer set
+        Q = torch.stack([qs[p] for p in range(6)])
+        dt = 1e-3
+        piped, plain = RhsEuler3D(plans, ex, overlap=True), RhsEuler3D(plans)
+        Q1 = piped.stage(Q, None, 0.0, 1.0, dt)
+        Q2 = piped.stage(Q1, Q, 0.75, 0.25, 0.25 * dt)
+        Q3 = piped.stage(Q2, Q, 1.0 / 3.0, 2.0 / 3.0, (2.0 / 3.0) * dt)
+        P1 = plain.axpy(Q, None, 0.0, 1.0, dt)
+        P2 = plain.axpy(P1, Q, 0.75, 0.25, 0.25 * dt)
+        P3 = plain.axpy(P2, Q, 1.0 / 3.0, 2.0 / 3.0, (2.0 / 3.0) * dt)
+        torch.cuda.synchronize()
+        scale = P3.abs().amax(dim=(0, 2, 3, 4, 5), keepdim=True)
+        assert ((Q3 - P3).abs() <= 1e-14 * scale).all()
     finally:
         dist.destroy_process_group()
 

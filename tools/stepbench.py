@@ -20,8 +20,8 @@ plans = {p: Euler3DPlan(n, H, V, 31, p, ops, synthetic.euler3d_metric(n, H, V, p
 Q = torch.stack([synthetic.euler3d_state(n, H, V, p, dev) for p in range(6)])
 rhs = RhsEuler3D(plans)
 dof = Q.numel()
-for fused in (False, True):
-    st = Tvdrk3(rhs, fused=fused)
+for fused, pipeline in ((False, False), (True, False), (True, True)):
+    st = Tvdrk3(rhs, fused=fused, pipeline=pipeline)
     q = Q
     for _ in range(2):
         q = st.step(q, 1e-3)
@@ -32,5 +32,5 @@ for fused in (False, True):
         q = st.step(q, 1e-3)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    print(f"Tvdrk3 fused={fused!s:5}: {dt*1e3:7.2f} ms/step = {dt*1e3/3:6.2f} ms per stage; {dof/dt/1e9:6.2f} G DOF-steps/s; "
+    print(f"Tvdrk3 fused={fused!s:5} pipeline={pipeline!s:5}: {dt*1e3:7.2f} ms/step = {dt*1e3/3:6.2f} ms per stage; {dof/dt/1e9:6.2f} G DOF-steps/s; "
           f"finite={bool(torch.isfinite(q).all())}")

@@ -105,6 +105,10 @@ struct EulerParams {
     double ca, cb, cc, cd;
     const T* y;            // nullable (then ca is ignored)
     const T* z;            // nullable (then cd is ignored)
+    // stage pipeline: when itf_out != null the kernel also extrapolates ITS OUTPUT (the next stage's state)
+    // to the element faces (phase 1-2 of the NEXT evaluation) into itf_out / nsend_*: no separate K1 pass
+    T* itf_out;
+    T *nsend_s, *nsend_n, *nsend_w, *nsend_e;
     // JVP mode (T = dual only): the state is formed on load as (q_re, jvp_eps * q_tan) from two REAL arrays
     // and only jvp_scale * tangent(R) is stored, as a real array - no complex temporaries in HBM
     int jvp;
@@ -200,6 +204,80 @@ __device__ __forceinline__ void store_r<dual>(const EulerParams<dual>& P, size_t
     else P.rhs[i] = r;
 }
 
+// Phase 1-2 on nodal values already staged in LDS (log rho, rho u1, rho u2, rho w, log rho*theta):
+// one thread per face point extrapolates, exponentiates, writes the interface buffer and, on outward
+// tile-edge faces, the rotated / flipped edge message.  Shared by K1 and by K2's stage-pipeline epilogue.
+template <int N, typename T>
+__device__ __forceinline__ void extrap_faces(const EulerParams<T>& P, T (*fld)[Cfg<N>::EPB * Cfg<N>::LE], int slot0,
+                                             int count, int region, T* itf_dst, T* ss, T* sn, T* sw, T* se) {
+    using C = Cfg<N>;
+    constexpr int N2 = C::N2, EPB = C::EPB, BS = C::BS;
+    const int tid = threadIdx.x;
+    const int H = P.H, V = P.V;
+    for (int fi = tid; fi < EPB * 6 * N2; fi += BS) {
+        const int le = fi / (6 * N2);
+        const int r = fi % (6 * N2);
+        const int f = r / N2, fp = r % N2;
+        const Elem el = decode_elem(slot0 + le, count, region, H, V);
+        if (!el.valid) continue;
+        const int d = f >> 1, plus = f & 1;
+        const int a = fp / N, b = fp % N;
+        // point index of m-th node on the line normal to the face, and its stride
+        int base, stride;
+        if (d == 0) { base = C::lidx(a, b, 0); stride = 1; }           // (kl=a, jl=b, il=m)
+        else if (d == 1) { base = C::lidx(a, 0, b); stride = C::NP; }  // (kl=a, jl=m, il=b)
+        else { base = C::lidx(0, a, b); stride = N * C::NP; }          // (kl=m, jl=a, il=b)
+        const double* w = plus ? P.K->ep : P.K->em;
+        T s[5];
+#pragma unroll
+        for (int v = 0; v < 5; ++v) s[v] = T(0.0);
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+            const double wm = w[m];
+#pragma unroll
+            for (int v = 0; v < 5; ++v) s[v] += wm * fld[v][le * C::LE + base + m * stride];
+        }
+        const T s4log = s[4];
+        s[0] = w_exp(s[0]);
+        s[4] = w_exp(s[4]);
+        // face pressure p0*exp(gamma*log(rho_theta*Rd/p0)) (pde_euler_cubesphere.py:158) and its log
+        // (rhs_dfr.py:113-115); log(rho_theta) is the extrapolated value itself, so no logarithm is needed
+        const T glog = kGamma * (s4log + kLogRdOverP0);
+        const T pf = kP0 * w_exp(glog);
+        const T lpf = kLogP0 + glog;
+        T* dst = itf_dst + ((size_t)el.e * 6 + f) * NQ * N2 + fp;
+#pragma unroll
+        for (int v = 0; v < 5; ++v) dst[v * N2] = s[v];
+        if (NQ > 5) dst[5 * N2] = pf;
+        if (NQ > 6) dst[6 * N2] = lpf;
+
+        // outward faces of the tile edge: rotate into the neighbour's basis, flip, pack
+        int edge = -1, along = 0;
+        double X = 0.0;
+        if (d == 0 && ((plus && el.ei == H - 1) || (!plus && el.ei == 0))) {
+            edge = plus ? E_E : E_W;
+            along = el.ej;
+            X = P.bwe[el.ej * N + b];
+        } else if (d == 1 && ((plus && el.ej == H - 1) || (!plus && el.ej == 0))) {
+            edge = plus ? E_N : E_S;
+            along = el.ei;
+            X = P.bsn[el.ei * N + b];
+        }
+        T* sendp = edge == E_S ? ss : (edge == E_N ? sn : (edge == E_W ? sw : se));
+        if (edge >= 0 && sendp != nullptr) {
+            rotate_contra<T>(P.K->rot[edge], X, s[1], s[2]);
+            int al = along, bb = b;
+            if (P.K->flip[edge]) { al = H - 1 - along; bb = N - 1 - b; }
+            T* out = sendp + ((size_t)el.ek * H + al) * N2 + a * N + bb;
+            const size_t vs = (size_t)V * H * N2;
+#pragma unroll
+            for (int v = 0; v < 5; ++v) out[v * vs] = s[v];
+            if (NQ > 5) out[5 * vs] = pf;
+            if (NQ > 6) out[6 * vs] = lpf;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1: extrapolation to element faces + tile-edge pack
 // ------------------------------------------------------------------------------------------------
@@ -228,68 +306,7 @@ __global__ __launch_bounds__(Cfg<N>::BS) void euler_extrap_kernel(const EulerPar
     }
     __syncthreads();
 
-    for (int fi = tid; fi < EPB * 6 * N2; fi += BS) {
-        const int le = fi / (6 * N2);
-        const int r = fi % (6 * N2);
-        const int f = r / N2, fp = r % N2;
-        const Elem el = decode_elem(blockIdx.x * EPB + le, P.nelem, WX_REGION_ALL, H, V);
-        if (!el.valid) continue;
-        const int d = f >> 1, plus = f & 1;
-        const int a = fp / N, b = fp % N;
-        // point index of m-th node on the line normal to the face, and its stride
-        int base, stride;
-        if (d == 0) { base = C::lidx(a, b, 0); stride = 1; }           // (kl=a, jl=b, il=m)
-        else if (d == 1) { base = C::lidx(a, 0, b); stride = C::NP; }  // (kl=a, jl=m, il=b)
-        else { base = C::lidx(0, a, b); stride = N * C::NP; }          // (kl=m, jl=a, il=b)
-        const double* w = plus ? P.K->ep : P.K->em;
-        T s[5];
-#pragma unroll
-        for (int v = 0; v < 5; ++v) s[v] = T(0.0);
-#pragma unroll
-        for (int m = 0; m < N; ++m) {
-            const double wm = w[m];
-#pragma unroll
-            for (int v = 0; v < 5; ++v) s[v] += wm * fld[v][le * C::LE + base + m * stride];
-        }
-        const T s4log = s[4];
-        s[0] = w_exp(s[0]);
-        s[4] = w_exp(s[4]);
-        // face pressure p0*exp(gamma*log(rho_theta*Rd/p0)) (pde_euler_cubesphere.py:158) and its log
-        // (rhs_dfr.py:113-115); log(rho_theta) is the extrapolated value itself, so no logarithm is needed
-        const T glog = kGamma * (s4log + kLogRdOverP0);
-        const T pf = kP0 * w_exp(glog);
-        const T lpf = kLogP0 + glog;
-        T* dst = P.itf + ((size_t)el.e * 6 + f) * NQ * N2 + fp;
-#pragma unroll
-        for (int v = 0; v < 5; ++v) dst[v * N2] = s[v];
-        if (NQ > 5) dst[5 * N2] = pf;
-        if (NQ > 6) dst[6 * N2] = lpf;
-
-        // outward faces of the tile edge: rotate into the neighbour's basis, flip, pack
-        int edge = -1, along = 0;
-        double X = 0.0;
-        if (d == 0 && ((plus && el.ei == H - 1) || (!plus && el.ei == 0))) {
-            edge = plus ? E_E : E_W;
-            along = el.ej;
-            X = P.bwe[el.ej * N + b];
-        } else if (d == 1 && ((plus && el.ej == H - 1) || (!plus && el.ej == 0))) {
-            edge = plus ? E_N : E_S;
-            along = el.ei;
-            X = P.bsn[el.ei * N + b];
-        }
-        T* sendp = edge == E_S ? P.send_s : (edge == E_N ? P.send_n : (edge == E_W ? P.send_w : P.send_e));
-        if (edge >= 0 && sendp != nullptr) {
-            rotate_contra<T>(P.K->rot[edge], X, s[1], s[2]);
-            int al = along, bb = b;
-            if (P.K->flip[edge]) { al = H - 1 - along; bb = N - 1 - b; }
-            T* out = sendp + ((size_t)el.ek * H + al) * N2 + a * N + bb;
-            const size_t vs = (size_t)V * H * N2;
-#pragma unroll
-            for (int v = 0; v < 5; ++v) out[v * vs] = s[v];
-            if (NQ > 5) out[5 * vs] = pf;
-            if (NQ > 6) out[6 * vs] = lpf;
-        }
-    }
+    extrap_faces<N, T>(P, fld, blockIdx.x * EPB, P.nelem, WX_REGION_ALL, P.itf, P.send_s, P.send_n, P.send_w, P.send_e);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -614,38 +631,45 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
         WX_STAMP(3 + d);
     }
 
-#if WX_K2_STAMPS
-    if (active) {
-#else
-    if (!active) return;
-#endif
-
     const double inv_sg = 1.0 / sg;
     accw += gcoef * hf;  // gravity: inv_dzdeta * g * 1/sqrtG * HF_k(sqrtG rho)
     T r0 = -inv_sg * acc0, r1 = -inv_sg * acc1, r2 = -inv_sg * acc2, r3 = -inv_sg * accw, r4 = -inv_sg * acc4;
     if (P.advection_only) { r0 = r1 = r2 = r3 = r4 = T(0.0); }
-
-    if (P.axpy) {  // fused stage update of an explicit Runge-Kutta scheme (integrators/tvdrk3.py:12-19)
-        r0 = P.cb * q0 + P.cc * r0; r1 = P.cb * q1 + P.cc * r1; r2 = P.cb * q2 + P.cc * r2;
-        r3 = P.cb * q3 + P.cc * r3; r4 = P.cb * q4 + P.cc * r4;
-        if (P.y != nullptr) {
-            r0 += P.ca * P.y[o]; r1 += P.ca * P.y[fs + o]; r2 += P.ca * P.y[2 * fs + o];
-            r3 += P.ca * P.y[3 * fs + o]; r4 += P.ca * P.y[4 * fs + o];
+    if (active) {
+        if (P.axpy) {  // fused stage update of an explicit Runge-Kutta scheme (integrators/tvdrk3.py:12-19)
+            r0 = P.cb * q0 + P.cc * r0; r1 = P.cb * q1 + P.cc * r1; r2 = P.cb * q2 + P.cc * r2;
+            r3 = P.cb * q3 + P.cc * r3; r4 = P.cb * q4 + P.cc * r4;
+            if (P.y != nullptr) {
+                r0 += P.ca * P.y[o]; r1 += P.ca * P.y[fs + o]; r2 += P.ca * P.y[2 * fs + o];
+                r3 += P.ca * P.y[3 * fs + o]; r4 += P.ca * P.y[4 * fs + o];
+            }
+            if (P.z != nullptr) {
+                r0 += P.cd * P.z[o]; r1 += P.cd * P.z[fs + o]; r2 += P.cd * P.z[2 * fs + o];
+                r3 += P.cd * P.z[3 * fs + o]; r4 += P.cd * P.z[4 * fs + o];
+            }
         }
-        if (P.z != nullptr) {
-            r0 += P.cd * P.z[o]; r1 += P.cd * P.z[fs + o]; r2 += P.cd * P.z[2 * fs + o];
-            r3 += P.cd * P.z[3 * fs + o]; r4 += P.cd * P.z[4 * fs + o];
-        }
-    }
-    store_r<T>(P, o, r0);
-    store_r<T>(P, fs + o, r1);
-    store_r<T>(P, 2 * fs + o, r2);
-    store_r<T>(P, 3 * fs + o, r3);
-    store_r<T>(P, 4 * fs + o, r4);
-#if WX_K2_STAMPS
+        store_r<T>(P, o, r0);
+        store_r<T>(P, fs + o, r1);
+        store_r<T>(P, 2 * fs + o, r2);
+        store_r<T>(P, 3 * fs + o, r3);
+        store_r<T>(P, 4 * fs + o, r4);
     }
     WX_STAMP(6);
-#endif
+    // ---- stage pipeline: the output is the next stage's state; extrapolate it to the faces now, while it
+    // is in registers (saves the next evaluation's K1: one read of Q and a launch)
+    if (P.itf_out != nullptr) {
+        __syncthreads();  // the last directional pass has finished reading fld
+        if (le < EPB) {
+            fld[0][lpt] = active ? w_log(r0) : T(0.0);
+            fld[1][lpt] = r1;
+            fld[2][lpt] = r2;
+            fld[3][lpt] = r3;
+            fld[4][lpt] = active ? w_log(r4) : T(0.0);
+        }
+        __syncthreads();
+        extrap_faces<N, T>(P, fld, block_slot(gridDim.x) * EPB, P.count, P.region, P.itf_out, P.nsend_s, P.nsend_n,
+                           P.nsend_w, P.nsend_e);
+    }
 #undef WX_STAMP
 }
 
@@ -682,7 +706,8 @@ struct wx_euler3d_plan {
     int n, H, V, case_number, panel;
     wx_dtype dtype;
     size_t nelem;
-    void* itf;         // device: [elem][6][NQ][n^2] of dtype
+    void* itf;         // device: [elem][6][NQ][n^2] of dtype (interface slot 0)
+    void* itf2 = nullptr;  // interface slot 1, allocated on first use of the stage pipeline
     size_t itf_bytes;
     EulerConsts* consts;  // device
     unsigned long long* stamps = nullptr;  // device, diagnostic builds only
@@ -700,6 +725,7 @@ EulerParams<T> make_params(const wx_euler3d_plan* pl) {
     P.advection_only = b.advection_only; P.has_damp = b.has_damp;
     P.q = nullptr; P.rhs = nullptr; P.itf = static_cast<T*>(pl->itf);
     P.axpy = 0; P.ca = P.cb = P.cd = 0.0; P.cc = 1.0; P.y = nullptr; P.z = nullptr;
+    P.itf_out = nullptr; P.nsend_s = P.nsend_n = P.nsend_w = P.nsend_e = nullptr;
     P.jvp = 0; P.q_re = P.q_tan = nullptr; P.out_tan = nullptr; P.jvp_eps = 0.0; P.jvp_scale = 1.0;
     P.halo_s = P.halo_n = P.halo_w = P.halo_e = nullptr;
     P.send_s = P.send_n = P.send_w = P.send_e = nullptr;
@@ -742,8 +768,9 @@ wx_status dispatch_rhs(int n, const EulerParams<T>& P, hipStream_t st) {
 int region_count(int region, int H, int V);
 
 template <typename T>
-wx_status run_extrap(wx_euler3d_plan* pl, const void* q, void* const send[4], hipStream_t st) {
+wx_status run_extrap(wx_euler3d_plan* pl, const void* q, void* const send[4], hipStream_t st, int slot = 0) {
     EulerParams<T> P = make_params<T>(pl);
+    if (slot == 1) P.itf = static_cast<T*>(pl->itf2);
     P.q = static_cast<const T*>(q);
     if (send) {
         P.send_s = static_cast<T*>(send[0]); P.send_n = static_cast<T*>(send[1]);
@@ -754,8 +781,17 @@ wx_status run_extrap(wx_euler3d_plan* pl, const void* q, void* const send[4], hi
 
 template <typename T>
 wx_status run_rhs(wx_euler3d_plan* pl, const void* q, const void* const halo[4], void* out, wx_region region,
-                  hipStream_t st, int axpy, const void* y, double ca, double cb, double cc, const void* z, double cd) {
+                  hipStream_t st, int axpy, const void* y, double ca, double cb, double cc, const void* z, double cd,
+                  int itf_in = 0, void* const next_send[4] = nullptr, bool epilogue = false) {
     EulerParams<T> P = make_params<T>(pl);
+    if (itf_in == 1) P.itf = static_cast<T*>(pl->itf2);
+    if (epilogue) {
+        P.itf_out = static_cast<T*>(itf_in == 1 ? pl->itf : pl->itf2);
+        if (next_send) {
+            P.nsend_s = static_cast<T*>(next_send[0]); P.nsend_n = static_cast<T*>(next_send[1]);
+            P.nsend_w = static_cast<T*>(next_send[2]); P.nsend_e = static_cast<T*>(next_send[3]);
+        }
+    }
     P.q = static_cast<const T*>(q); P.rhs = static_cast<T*>(out);
     P.region = region; P.count = region_count(region, pl->H, pl->V);
     P.axpy = axpy; P.ca = ca; P.cb = cb; P.cc = cc; P.cd = cd;
@@ -851,6 +887,7 @@ wx_status wx_euler3d_plan_create_tile(wx_euler3d_plan** out, int n, int H, int V
 wx_status wx_euler3d_plan_destroy(wx_euler3d_plan* pl) {
     if (!pl) return WX_OK;
     hipError_t e = hipFree(pl->itf);
+    if (pl->itf2) (void)hipFree(pl->itf2);
     hipError_t e2 = hipFree(pl->consts);
     if (e == hipSuccess) e = e2;
     delete pl;
@@ -950,6 +987,52 @@ wx_status wx_euler3d_rhs_axpy2(wx_euler3d_plan* pl, const void* q, const void* c
                                const void* z, void* out, double a, double b, double c, double d, wx_region region,
                                wx_stream stream) {
     return euler3d_rhs_impl(pl, q, halo, out, region, stream, 1, y, a, b, c, z, d);
+}
+
+static wx_status ensure_slot1(wx_euler3d_plan* pl) {
+    if (pl->itf2) return WX_OK;
+    hipError_t e = hipMalloc(&pl->itf2, pl->itf_bytes);
+    if (e != hipSuccess) return fail(WX_ERR_NOMEM, "hipMalloc(%zu bytes) for the second interface buffer failed: %s",
+                                     pl->itf_bytes, hipGetErrorString(e));
+    return WX_OK;
+}
+
+wx_status wx_euler3d_extrap_pack_slot(wx_euler3d_plan* pl, const void* q, void* const send[4], int slot,
+                                      wx_stream stream) {
+    if (!pl || !q) return fail(WX_ERR_INVALID, "wx_euler3d_extrap_pack_slot: null argument");
+    if (slot != 0 && slot != 1) return fail(WX_ERR_INVALID, "interface slot %d not in {0,1}", slot);
+    if (slot == 1) { wx_status s1 = ensure_slot1(pl); if (s1 != WX_OK) return s1; }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (pl->dtype) {
+        case WX_F64: return run_extrap<double>(pl, q, send, st, slot);
+        case WX_C128: return run_extrap<cplx>(pl, q, send, st, slot);
+        case WX_DUAL128: return run_extrap<dual>(pl, q, send, st, slot);
+    }
+    return fail(WX_ERR_INVALID, "bad plan dtype");
+}
+
+wx_status wx_euler3d_stage(wx_euler3d_plan* pl, const void* q, const void* const halo[4], const void* y, const void* z,
+                           void* out, double a, double b, double c, double d, wx_region region, int itf_in,
+                           void* const next_send[4], int prepare_next, wx_stream stream) {
+    if (!pl || !q || !out) return fail(WX_ERR_INVALID, "wx_euler3d_stage: null argument");
+    if (out == q) return fail(WX_ERR_INVALID, "wx_euler3d_stage: output must not alias the state");
+    if (itf_in != 0 && itf_in != 1) return fail(WX_ERR_INVALID, "interface slot %d not in {0,1}", itf_in);
+    if (region != WX_REGION_ALL && region != WX_REGION_INTERIOR && region != WX_REGION_BOUNDARY)
+        return fail(WX_ERR_INVALID, "unknown region %d", (int)region);
+    if (region != WX_REGION_INTERIOR) {
+        if (!halo) return fail(WX_ERR_INVALID, "wx_euler3d_stage: halo is required for this region");
+        for (int e = 0; e < 4; ++e)
+            if (!halo[e]) return fail(WX_ERR_INVALID, "wx_euler3d_stage: halo[%d] is null", e);
+    }
+    if (prepare_next || itf_in == 1) { wx_status s1 = ensure_slot1(pl); if (s1 != WX_OK) return s1; }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool ep = prepare_next != 0;
+    switch (pl->dtype) {
+        case WX_F64: return run_rhs<double>(pl, q, halo, out, region, st, 1, y, a, b, c, z, d, itf_in, next_send, ep);
+        case WX_C128: return run_rhs<cplx>(pl, q, halo, out, region, st, 1, y, a, b, c, z, d, itf_in, next_send, ep);
+        case WX_DUAL128: return run_rhs<dual>(pl, q, halo, out, region, st, 1, y, a, b, c, z, d, itf_in, next_send, ep);
+    }
+    return fail(WX_ERR_INVALID, "bad plan dtype");
 }
 
 }  // extern "C"

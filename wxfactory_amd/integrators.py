@@ -18,12 +18,18 @@ class Tvdrk3:
     linear combination is formed in the RHS kernel's store), a step is three RHS evaluations plus two
     extra reads of Q and nothing else; `fused=False` is the reference's literal sequence."""
 
-    def __init__(self, rhs: Callable, fused: bool = True):
+    def __init__(self, rhs: Callable, fused: bool = True, pipeline: bool = True):
         self.rhs = rhs
         self.fused = fused and bool(getattr(rhs, "supports_axpy", False))
+        # stage pipeline: each stage's kernel also extrapolates its output to the faces (no separate pass)
+        self.pipeline = self.fused and pipeline and bool(getattr(rhs, "supports_pipeline", False))
 
     def step(self, Q: torch.Tensor, dt: float) -> torch.Tensor:
         rhs = self.rhs
+        if self.pipeline and isinstance(Q, torch.Tensor) and Q.is_contiguous() and rhs.panels:
+            Q1 = rhs.stage(Q, None, 0.0, 1.0, dt)
+            Q2 = rhs.stage(Q1, Q, 0.75, 0.25, 0.25 * dt)
+            return rhs.stage(Q2, Q, 1.0 / 3.0, 2.0 / 3.0, (2.0 / 3.0) * dt)
         if self.fused:
             Q1 = rhs.axpy(Q, None, 0.0, 1.0, dt)
             Q2 = rhs.axpy(Q1, Q, 0.75, 0.25, 0.25 * dt)

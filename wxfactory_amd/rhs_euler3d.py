@@ -7,6 +7,7 @@ phases of the reference collapse into two HIP kernels per panel (see csrc/euler3
 phase timers of rhs.py:88-118 are kept as four buckets (extrap+pack, exchange, interior, boundary).
 """
 import ctypes
+import weakref
 from typing import Dict, List, Optional, Sequence
 
 import numpy
@@ -32,6 +33,7 @@ class Euler3DPlan:
                  metric: Dict[str, torch.Tensor], dtype: torch.dtype = torch.float64, dual: bool = False,
                  on_panel_edge=(True, True, True, True)):
         self.lib = _lib.load()
+        self.faces_epoch = 0  # bumped by every call that rewrites an interface buffer (pipeline validity)
         if dtype not in _DTYPES:
             raise TypeError(f"dtype must be float64 or complex128, not {dtype}")
         # complex128 storage can run true complex arithmetic (WX_C128) or first-order dual-number
@@ -91,6 +93,7 @@ class Euler3DPlan:
 
     def extrap_pack(self, q: torch.Tensor, send_ptrs: Optional[Sequence[int]]):
         self._check_q(q)
+        self.faces_epoch += 1
         arr = _ptr_array(send_ptrs)
         st = torch.cuda.current_stream(self.device).cuda_stream
         check(self.lib.wx_euler3d_extrap_pack(self._h, q.data_ptr(), arr, st), "wx_euler3d_extrap_pack")
@@ -116,6 +119,27 @@ class Euler3DPlan:
                                             z.data_ptr() if z is not None else None, out.data_ptr(), a, b, c, d, region,
                                             st), "wx_euler3d_rhs_axpy2")
 
+    def extrap_pack_slot(self, q, send, slot: int):
+        self._check_q(q)
+        self.faces_epoch += 1
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.wx_euler3d_extrap_pack_slot(self._h, q.data_ptr(), _ptr_array(send), slot, st),
+              "wx_euler3d_extrap_pack_slot")
+
+    def stage(self, q, halo, y, z, out, a, b, c, d, region, itf_in: int, next_send, prepare_next: bool):
+        """out = a*y + b*q + c*R(q) + d*z reading faces from slot itf_in; with prepare_next also the faces of
+        `out` into the other slot / next_send (stage pipeline)."""
+        self._check_q(q)
+        self._check_q(out)
+        for t in (y, z):
+            if t is not None:
+                self._check_q(t)
+        self.faces_epoch += int(bool(prepare_next))
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.wx_euler3d_stage(self._h, q.data_ptr(), _ptr_array(halo), y.data_ptr() if y is not None else None,
+                                        z.data_ptr() if z is not None else None, out.data_ptr(), a, b, c, d, region,
+                                        itf_in, _ptr_array(next_send), int(bool(prepare_next)), st), "wx_euler3d_stage")
+
     def _check_real(self, t):
         if t.dtype != torch.float64 or t.numel() != 5 * self.V * self.H * self.H * self.n**3 or not t.is_contiguous() \
                 or t.device != self.device:
@@ -125,6 +149,7 @@ class Euler3DPlan:
         """dual plans only: phase 1-2 on the dual state (q, eps*v) formed on load from two real arrays."""
         self._check_real(q)
         self._check_real(v)
+        self.faces_epoch += 1
         st = torch.cuda.current_stream(self.device).cuda_stream
         check(self.lib.wx_euler3d_jvp_extrap_pack(self._h, q.data_ptr(), v.data_ptr(), eps, _ptr_array(send), st),
               "wx_euler3d_jvp_extrap_pack")
@@ -157,6 +182,54 @@ class RhsEuler3D(PanelRhs):
     freshly allocated R, shaped like the input (the contract of rhs/rhs.py:75-122)."""
 
     supports_jvp = True
+    supports_pipeline = True
+
+    def stage(self, Q: torch.Tensor, Y, a: float, b: float, c: float) -> torch.Tensor:
+        """One explicit Runge-Kutta stage  a*Y + b*Q + c*R(Q)  on stacked states with the stage pipeline:
+        the kernel that produces the result also extrapolates it to the element faces, so the NEXT call
+        whose Q is that result (same storage, not modified in between) starts without the
+        extrapolation pass.  Two sets of interface / edge buffers alternate."""
+        np_ = len(self.panels)
+        dtype = Q.dtype
+        plans = self.plans_for(dtype)
+        if not hasattr(self, "_pipe"):
+            self._pipe = {}
+        st = self._pipe.setdefault(dtype, {"slot": 0, "ready": None, "ex": [self.exchange_for(dtype), None]})
+        if st["ex"][1] is None:
+            words = self.edge_count * (2 if dtype.is_complex else 1)
+            st["ex"][1] = PanelExchange(words, self.device, rank=self.rank, world_size=self.world, group=self.group,
+                                        loopback=st["ex"][0].loopback, tiles_per_side=self.tiles_per_side)
+        Qs = Q.reshape((np_,) + tuple(self.panel_shape))
+        Ys = Y.reshape((np_,) + tuple(self.panel_shape)) if Y is not None else None
+        out = torch.empty_like(Qs)
+        cur = st["slot"]
+        ex, exn = st["ex"][cur], st["ex"][1 - cur]
+        last = st["ready"][0]() if st["ready"] is not None else None  # alive => its storage was not recycled
+        epochs = lambda: tuple(plans[p].faces_epoch for p in self.panels)  # noqa: E731
+        if last is None or st["ready"][1:] != (Q.data_ptr(), Q._version, Q.numel(), epochs()):
+            for i, p in enumerate(self.panels):
+                plans[p].extrap_pack_slot(Qs[i], ex.send_views(p), cur)
+
+        def launch(i, p, halo, region):
+            plans[p].stage(Qs[i], halo, Ys[i] if Ys is not None else None, None, out[i], a, b, c, 0.0, region, cur,
+                           exn.send_views(p), True)
+
+        if ex.needs_comm and self.overlap:
+            ex.start()
+            for i, p in enumerate(self.panels):
+                launch(i, p, None, _lib.WX_REGION_INTERIOR)
+            ex.wait()
+            for i, p in enumerate(self.panels):
+                launch(i, p, ex.halo_views(p), _lib.WX_REGION_BOUNDARY)
+        else:
+            ex.start()
+            ex.wait()
+            for i, p in enumerate(self.panels):
+                launch(i, p, ex.halo_views(p), _lib.WX_REGION_ALL)
+        res = out.reshape(Q.shape)
+        st["slot"] = 1 - cur
+        st["ready"] = (weakref.ref(res), res.data_ptr(), res._version, res.numel(), epochs())
+        return res
 
     def jvp(self, Q: torch.Tensor, v: torch.Tensor, eps: float, scale: float) -> torch.Tensor:
         """scale * Im R(Q + i eps v) for stacked real Q, v -> real tensor shaped like Q.  The dual state is
