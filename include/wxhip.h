@@ -281,6 +281,26 @@ wx_status wx_cart2d_plan_create(wx_cart2d_plan** plan, int n, int num_elem_x1, i
 wx_status wx_cart2d_plan_destroy(wx_cart2d_plan* plan);
 wx_status wx_cart2d_rhs(wx_cart2d_plan* plan, const void* q, void* rhs, wx_stream stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Per-step filters of the explicit time loop (simulation/simulation.py:147-155).
+ *
+ * wx_expfilter_*: DFROperators.apply_filter_3d (geometry/operators.py:114-119, 257-261),
+ *   out = ((sqrtG * q) @ (Fx Fy Fz)) * (1 / sqrtG)  with the nodal 1-D exponential modal filter F (n x n,
+ *   row-major, host pointer at creation: operators.make_filter, :208-233) applied along the three local
+ *   axes of every element.  q, out: (nvar <= 5, nelem, n^3) of dtype; out may be q (in place).
+ *   sqrtG: (nelem, n^3) float64 on the device.  nan_flag (device int, nullable) is set to 1 when the result
+ *   holds a NaN - simulation._check_for_nan (:399-408) without a second pass over the state.
+ * wx_check_nan: the same flag for a state that is not filtered; count = number of dtype scalars.
+ * wx_cart2d_sponge: rho_w *= 1 / (1 + beta dt)  (operators.py:242-253; beta float64 on the device).
+ * The flag is only ever raised, never cleared: the caller zeroes it. */
+typedef struct wx_expfilter wx_expfilter;
+wx_status wx_expfilter_create(wx_expfilter** out, int n, const double* filter);
+wx_status wx_expfilter_destroy(wx_expfilter* h);
+wx_status wx_expfilter_apply(const wx_expfilter* h, const void* q, void* out, const double* sqrtG, int nvar, size_t nelem,
+                             wx_dtype dtype, int* nan_flag, wx_stream stream);
+wx_status wx_check_nan(const void* q, size_t count, wx_dtype dtype, int* flag, wx_stream stream);
+wx_status wx_cart2d_sponge(void* rho_w, const double* beta, double dt, size_t count, wx_dtype dtype, wx_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

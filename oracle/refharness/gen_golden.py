@@ -574,6 +574,46 @@ def state_file_case(name):
     MPI.reset_world(6)
 
 
+# ---------------------------------------------------------------------------------------------
+# Per-step filter of the explicit loop: operators.apply_filters = 3-D exponential modal filter
+# ---------------------------------------------------------------------------------------------
+def filters_case(name, ini, overrides, perturb=0.02, seed=31337):
+    print(f"[{name}] {ini}", flush=True)
+
+    def work(rank):
+        from device import CpuDevice
+        from process_topology import ProcessTopology
+        from geometry import CubedSphere3D, DFROperators
+        from init.init_state_vars import init_state_vars
+
+        cfg = _config(ini, overrides)
+        comm = MPI.COMM_WORLD
+        dev = CpuDevice(comm)
+        pt = ProcessTopology(dev, comm=comm)
+        geom = CubedSphere3D(cfg.num_elements_horizontal, cfg.num_elements_vertical, cfg.num_solpts,
+                             cfg.lambda0, cfg.phi0, cfg.alpha0, cfg.ztop, pt, cfg, dev)
+        ops = DFROperators(geom, cfg, dev)
+        Q, topo, metric = init_state_vars(geom, ops, cfg)
+        rng = numpy.random.default_rng(seed + rank)
+        Q = Q * (1.0 + perturb * rng.uniform(-1.0, 1.0, Q.shape))
+        assert ops.expfilter_apply
+        out = {"Q": Q.copy(), "R": ops.apply_filters(Q.copy(), geom, metric, cfg.dt).copy(),
+               "metric/sqrtG_new": numpy.array(metric.sqrtG_new, copy=True),
+               "metric/inv_sqrtG_new": numpy.array(metric.inv_sqrtG_new, copy=True)}
+        if rank == 0:
+            out["ops/expfilter"] = numpy.array(ops.expfilter, copy=True)
+            out["ops/solution_points"] = numpy.array(geom.solutionPoints, copy=True)
+            out["meta/n"] = numpy.int64(cfg.num_solpts)
+            out["meta/H"] = numpy.int64(cfg.num_elements_horizontal)
+            out["meta/V"] = numpy.int64(cfg.num_elements_vertical)
+            out["meta/expfilter_strength"] = numpy.float64(cfg.expfilter_strength)
+            out["meta/expfilter_order"] = numpy.int64(cfg.expfilter_order)
+            out["meta/expfilter_cutoff"] = numpy.float64(cfg.expfilter_cutoff)
+        return out
+
+    _run6(name, work)
+
+
 CASES = {
     # balanced gravity-wave state, small n: all panels carry metrics + phases (exchange coverage)
     "euler3d_c31_n3_h4_v2": lambda nm: euler_case(
@@ -603,6 +643,12 @@ CASES = {
     "callers_euler3d_n3_h3_v2": lambda nm: callers_case(
         nm, "dcmip31.ini", dict(num_solpts=3, num_elements_horizontal=3, num_elements_vertical=2)),
     "state_file_v": state_file_case,
+    # exponential modal filter applied after every step (dcmip21.ini: strength 0.1, order 4, cutoff 0.5;
+    # dcmip21_rk3.ini: strength 1e-3), even and odd n
+    "filters_c21_n4_h3_v4": lambda nm: filters_case(
+        nm, "dcmip21.ini", dict(num_solpts=4, num_elements_horizontal=3, num_elements_vertical=4)),
+    "filters_c21_n5_h2_v2": lambda nm: filters_case(
+        nm, "dcmip21_rk3.ini", dict(num_solpts=5, num_elements_horizontal=2, num_elements_vertical=2)),
     # 24 ranks = 2x2 tiles per panel (the reference's own 6 k^2 decomposition)
     "euler3d_tiles24_n3_h2_v2": lambda nm: euler_tiles_case(
         nm, "dcmip31.ini", dict(num_solpts=3, num_elements_horizontal=4, num_elements_vertical=2), 24,

@@ -83,6 +83,9 @@ enum { F_W = 0, F_E = 1, F_S = 2, F_N = 3, F_B = 4, F_T = 5 };
 // variables, exactly the reference's q_itf (default: measured fastest - the kernel is HBM-bound and
 // the two extra streams cost more than redoing exp(gamma*log(.)) on both sides of a face);
 // 6 / 7 additionally carry the face pressure / its logarithm (pde_euler_cubesphere.py:158-160).
+#ifndef WX_K2_OWN_FACES
+#define WX_K2_OWN_FACES 0  // 1: K2 re-extrapolates its own-side face values instead of reading them back
+#endif
 #ifndef WX_EULER_NQ
 #define WX_EULER_NQ 5   // 7: state + p + log p;  6: state + p;  5: state only (pressures redone per side)
 #endif
@@ -347,7 +350,7 @@ __device__ __forceinline__ void rusanov_face(const T* qL, const T* qR, T unL, T 
 // ------------------------------------------------------------------------------------------------
 // K2: fused phases 3-8
 // ------------------------------------------------------------------------------------------------
-template <int N, typename T>
+template <int N, typename T, bool PIPE>
 __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES)) void euler_rhs_kernel(const EulerParams<T> P) {
     using C = Cfg<N>;
     constexpr int N2 = C::N2, N3 = C::N3, EPB = C::EPB, BS = C::BS;
@@ -391,16 +394,22 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
 
     T q0 = T(1.0), q1 = T(0.0), q2 = T(0.0), q3 = T(0.0), q4 = T(1.0);
     double sg = 1.0, h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0;
-#define WX_POINT_LOADS()                                                                                   \
+#define WX_Q_LOADS()                                                                                       \
     if (active) {                                                                                          \
         q0 = load_q<T>(P, o); q1 = load_q<T>(P, fs + o); q2 = load_q<T>(P, 2 * fs + o);                     \
         q3 = load_q<T>(P, 3 * fs + o); q4 = load_q<T>(P, 4 * fs + o);                                      \
+    }
+#define WX_PMETRIC_LOADS()                                                                                 \
+    if (active) {                                                                                          \
         sg = WX_LDM(P.sg + o);                                                                             \
         h00 = WX_LDM(P.h + 0 * fs + o); h01 = WX_LDM(P.h + 1 * fs + o); h02 = WX_LDM(P.h + 2 * fs + o);    \
         h11 = WX_LDM(P.h + 4 * fs + o); h12 = WX_LDM(P.h + 5 * fs + o); h22 = WX_LDM(P.h + 8 * fs + o);    \
     }
+#define WX_POINT_LOADS() WX_Q_LOADS() WX_PMETRIC_LOADS()
 #if WX_K2_EARLY_LOADS
     WX_POINT_LOADS()
+#elif WX_K2_OWN_FACES
+    WX_Q_LOADS()
 #endif
 #if !WX_K2_GAMMA_ROLLED
     double cg[27], idzv = 0.0;
@@ -416,6 +425,14 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
 #endif
 #endif
 
+#if WX_K2_OWN_FACES
+    // own-side face values are re-extrapolated here from the nodal state (same arithmetic as K1, which
+    // still writes them for the NEIGHBOUR to read): 5 of the 10 interface-buffer reads per face point saved
+    if (le < EPB) {
+        fld[0][lpt] = w_log(q0); fld[1][lpt] = q1; fld[2][lpt] = q2; fld[3][lpt] = q3; fld[4][lpt] = w_log(q4);
+    }
+    __syncthreads();
+#endif
     // ---- face stage: Riemann problems of all 6 faces of the block's elements -> LDS
     for (int fi = tid; fi < EPB * 6 * N2; fi += BS) {
         const int le = fi / (6 * N2);
@@ -458,11 +475,39 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
             hp = P.hk + 2 * 3 * hfs + o;
         }
         T qo[7], qn[7];
+#if WX_K2_OWN_FACES
+        static_assert(NQ == 5, "WX_K2_OWN_FACES recomputes the 5 prognostic face values only");
+#pragma unroll
+        for (int v = 0; v < NQ; ++v) qn[v] = nbr[v * nstride];
+        {
+            const int a = fp / N, b = fp % N;
+            int base, stride;
+            if (d == 0) { base = C::lidx(a, b, 0); stride = 1; }
+            else if (d == 1) { base = C::lidx(a, 0, b); stride = C::NP; }
+            else { base = C::lidx(0, a, b); stride = N * C::NP; }
+            const double* w = plus ? P.K->ep : P.K->em;
+#pragma unroll
+            for (int v = 0; v < 5; ++v) qo[v] = T(0.0);
+#pragma unroll
+            for (int m = 0; m < N; ++m) {
+                const double wm = w[m];
+#pragma unroll
+                for (int v = 0; v < 5; ++v) qo[v] += wm * fld[v][le * C::LE + base + m * stride];
+            }
+            qo[0] = w_exp(qo[0]);
+            qo[4] = w_exp(qo[4]);
+            if (mirror) {
+#pragma unroll
+                for (int v = 0; v < NQ; ++v) qn[v] = qo[v];
+            }
+        }
+#else
 #pragma unroll
         for (int v = 0; v < NQ; ++v) {
             qo[v] = own[v * N2];
             qn[v] = nbr[v * nstride];
         }
+#endif
         if (NQ == 5) {  // pressures from rho*theta on both sides (pde_euler_cubesphere.py:158-160)
             const T go = kGamma * w_log(qo[4] * kRdOverP0), gn = kGamma * w_log(qn[4] * kRdOverP0);
             qo[5] = kP0 * w_exp(go); qn[5] = kP0 * w_exp(gn);
@@ -494,7 +539,9 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
     }
 
     WX_STAMP(1);
-#if !WX_K2_EARLY_LOADS
+#if WX_K2_OWN_FACES && !WX_K2_EARLY_LOADS
+    WX_PMETRIC_LOADS()
+#elif !WX_K2_EARLY_LOADS
     WX_POINT_LOADS()
 #endif
 #undef WX_POINT_LOADS
@@ -579,7 +626,7 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
 #endif
         const T sgu = sg * ud;
         const T Bd = T(sg * hd2);
-        if (d > 0) __syncthreads();  // previous direction's reads are done
+        if (d > 0 || WX_K2_OWN_FACES) __syncthreads();  // previous direction's (or the face stage's) reads are done
         if (le < EPB) {
             fld[0][lpt] = sgu * q0;
             fld[1][lpt] = sgu * q1 + (sg * hd0) * p;
@@ -657,7 +704,7 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
     WX_STAMP(6);
     // ---- stage pipeline: the output is the next stage's state; extrapolate it to the faces now, while it
     // is in registers (saves the next evaluation's K1: one read of Q and a launch)
-    if (P.itf_out != nullptr) {
+    if (PIPE) {  // (a separate instantiation: the plain kernel keeps its instruction schedule)
         __syncthreads();  // the last directional pass has finished reading fld
         if (le < EPB) {
             fld[0][lpt] = active ? w_log(r0) : T(0.0);
@@ -690,7 +737,8 @@ static wx_status launch_rhs(const EulerParams<T>& P, hipStream_t st) {
     using C = Cfg<N>;
     if (P.count == 0) return WX_OK;
     const int grid = (P.count + C::EPB - 1) / C::EPB;
-    hipLaunchKernelGGL((euler_rhs_kernel<N, T>), dim3(grid), dim3(C::BS), 0, st, P);
+    if (P.itf_out != nullptr) hipLaunchKernelGGL((euler_rhs_kernel<N, T, true>), dim3(grid), dim3(C::BS), 0, st, P);
+    else hipLaunchKernelGGL((euler_rhs_kernel<N, T, false>), dim3(grid), dim3(C::BS), 0, st, P);
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
 }
@@ -875,8 +923,8 @@ wx_status wx_euler3d_plan_create_tile(wx_euler3d_plan** out, int n, int H, int V
     e = hipMalloc((void**)&pl->consts, sizeof(EulerConsts));
     if (e == hipSuccess) e = hipMemcpy(pl->consts, &hc, sizeof(hc), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
-        hipFree(pl->itf);
-        if (pl->consts) hipFree(pl->consts);
+        (void)hipFree(pl->itf);
+        if (pl->consts) (void)hipFree(pl->consts);
         delete pl;
         return fail(WX_ERR_HIP, "constant upload failed: %s", hipGetErrorString(e));
     }

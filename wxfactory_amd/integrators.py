@@ -132,3 +132,36 @@ class Epi:
             self.previous_rhs.pop()
             self.previous_rhs.appendleft(rhs)
         return Q + phiv.reshape(Q.shape) * dt
+
+
+class StepLoop:
+    """The device-side body of `Simulation.step` (simulation/simulation.py:147-155):
+    Q = integrator.step(Q, dt); Q = operators.apply_filters(Q, ...); NaN check (ValueError("NaN") on all ranks).
+
+    `filt` is a filters.ExpFilter3D (or None), `nan_flag` a filters.NanFlag (or None).  When the filter owns
+    the flag it raises it while filtering, so the state is not read a second time.  The flag is fetched
+    (one host sync + one tiny all-reduce) every `check_every` steps; the reference does so every step."""
+
+    def __init__(self, stepper, filt=None, nan_flag=None, check_every: int = 1):
+        self.stepper, self.filt, self.nan_flag = stepper, filt, nan_flag
+        self.check_every = max(1, int(check_every))
+        self.step_id = 0
+        if filt is not None and nan_flag is not None and filt.nan_flag is None:
+            filt.nan_flag = nan_flag
+
+    def step(self, Q: torch.Tensor, dt: float) -> torch.Tensor:
+        Q = self.stepper.step(Q, dt)
+        if self.filt is not None:
+            Q = self.filt(Q, out=Q)  # the stepper returned fresh storage: filter it in place
+        self.step_id += 1
+        if self.nan_flag is not None:
+            if self.filt is None or self.filt.nan_flag is not self.nan_flag:
+                self.nan_flag.check(Q)
+            if self.step_id % self.check_every == 0:
+                self.nan_flag.raise_if_set()
+        return Q
+
+    def run(self, Q: torch.Tensor, dt: float, nsteps: int) -> torch.Tensor:
+        for _ in range(nsteps):
+            Q = self.step(Q, dt)
+        return Q

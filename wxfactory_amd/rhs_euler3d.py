@@ -188,7 +188,9 @@ class RhsEuler3D(PanelRhs):
         """One explicit Runge-Kutta stage  a*Y + b*Q + c*R(Q)  on stacked states with the stage pipeline:
         the kernel that produces the result also extrapolates it to the element faces, so the NEXT call
         whose Q is that result (same storage, not modified in between) starts without the
-        extrapolation pass.  Two sets of interface / edge buffers alternate."""
+        extrapolation pass.  Two sets of interface / edge buffers alternate.  "Not modified" is judged by
+        torch's version counter: code that writes a state through a raw pointer must call
+        torch.autograd.graph.increment_version on it (filters.ExpFilter3D does)."""
         np_ = len(self.panels)
         dtype = Q.dtype
         plans = self.plans_for(dtype)
