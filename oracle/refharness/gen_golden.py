@@ -543,6 +543,71 @@ def euler_tiles_case(name, ini, overrides, n_ranks, metric_tiles, perturb=0.01, 
     MPI.reset_world(6)
 
 
+def metric_case(name, ini, overrides, n_ranks, direct=False):
+    """Only the static metric of a 3-D run: every tile, any grid rotation, with topography
+    (cases 21/22 through init_state_vars) or, with direct=True, Metric3DTopo.build_metric on the smooth sphere
+    for a case number whose planet rotates (exercises the rotation Christoffel symbols)."""
+    print(f"[{name}] {ini} on {n_ranks} ranks", flush=True)
+
+    def work(rank):
+        import math
+        from device import CpuDevice
+        from process_topology import ProcessTopology
+        from geometry import CubedSphere3D, DFROperators, Metric3DTopo
+        from init.init_state_vars import init_state_vars
+
+        cfg = _config(ini, overrides)
+        per_line = int(math.isqrt(n_ranks // 6))
+        cfg.num_elements_horizontal = cfg.num_elements_horizontal_total // per_line
+        comm = MPI.COMM_WORLD
+        dev = CpuDevice(comm)
+        pt = ProcessTopology(dev, comm=comm)
+        geom = CubedSphere3D(cfg.num_elements_horizontal, cfg.num_elements_vertical, cfg.num_solpts,
+                             cfg.lambda0, cfg.phi0, cfg.alpha0, cfg.ztop, pt, cfg, dev)
+        ops = DFROperators(geom, cfg, dev)
+        if direct:
+            metric = Metric3DTopo(geom, ops)
+            metric.build_metric()
+        else:
+            Q, topo, metric = init_state_vars(geom, ops, cfg)
+        out = {}
+        for a in EULER_METRIC_ATTRS:
+            out["metric/" + a] = numpy.array(getattr(metric, a), copy=True)
+        if cfg.case_number in (21, 22) and not direct:
+            coef, uref = _damping_fields(geom, metric, cfg.case_number, Q.shape[1:])
+            out["metric/damp_coef"] = coef
+            out["metric/damp_uref"] = uref
+        out["geom/boundary_sn_new"] = numpy.array(geom.boundary_sn_new, copy=True)
+        out["geom/boundary_we_new"] = numpy.array(geom.boundary_we_new, copy=True)
+        out["topo/panel_row_col"] = numpy.array([pt.my_panel, pt.my_row, pt.my_col], dtype=numpy.int64)
+        if rank == 0:
+            out["meta/case_number"] = numpy.int64(cfg.case_number)
+            out["meta/n"] = numpy.int64(cfg.num_solpts)
+            out["meta/H"] = numpy.int64(cfg.num_elements_horizontal)
+            out["meta/V"] = numpy.int64(cfg.num_elements_vertical)
+            out["meta/k"] = numpy.int64(per_line)
+            out["meta/ztop"] = numpy.float64(cfg.ztop)
+            out["meta/rotation"] = numpy.array([cfg.lambda0, cfg.phi0, cfg.alpha0], dtype=numpy.float64)
+            out["meta/deep"] = numpy.int64(cfg.depth_approx.lower() == "deep")
+        return out
+
+    t0 = time.time()
+    MPI.reset_world(n_ranks)
+    res, err = MPI.run_ranks(work, n_ranks)
+    for e in err:
+        if e:
+            print(e)
+            raise SystemExit(1)
+    flat = {}
+    for p, d in enumerate(res):
+        for k, v in d.items():
+            flat[k if k.startswith("meta/") else f"p{p}/{k}"] = v
+    path = os.path.join(GOLDEN, name + ".npz")
+    numpy.savez_compressed(path, **flat)
+    print(f"   -> {path}  {os.path.getsize(path)/1e6:.2f} MB  ({time.time()-t0:.1f}s)", flush=True)
+    MPI.reset_world(6)
+
+
 def state_file_case(name):
     """Bytes written by the reference's save_state (output/state.py:9-16) for a seeded global state."""
     import types
@@ -643,6 +708,14 @@ CASES = {
     "callers_euler3d_n3_h3_v2": lambda nm: callers_case(
         nm, "dcmip31.ini", dict(num_solpts=3, num_elements_horizontal=3, num_elements_vertical=2)),
     "state_file_v": state_file_case,
+    # static metric only: Schaer mountain on a rotated grid over 24 tiles (every kind of tile edge carries
+    # a slope); deep atmosphere on a rotating Earth-size planet (rotation Christoffel symbols)
+    "metric3d_c21_rot_tiles24_n3_h2_v3": lambda nm: metric_case(
+        nm, "dcmip21.ini", dict(num_solpts=3, num_elements_horizontal=4, num_elements_vertical=3,
+                                lambda0=-0.3, phi0=0.6, alpha0=-0.4), 24),
+    "metric3d_c77_deep_rot_n4_h2_v2": lambda nm: metric_case(
+        nm, "dcmip31.ini", dict(num_solpts=4, num_elements_horizontal=2, num_elements_vertical=2, case_number=77,
+                                depth_approx="deep", lambda0=-0.2, phi0=0.3, alpha0=-0.1), 6, direct=True),
     # exponential modal filter applied after every step (dcmip21.ini: strength 0.1, order 4, cutoff 0.5;
     # dcmip21_rk3.ini: strength 1e-3), even and odd n
     "filters_c21_n4_h3_v4": lambda nm: filters_case(

@@ -244,3 +244,28 @@ def _scale_tile(g, t, topo):
     want = {}
     o.rhs(g.q(t), g.halo(t), want=want)
     return o.cancel_scale(want)
+
+
+@pytest.mark.parametrize("name,ztop", [("euler3d_c21_n4_h3_v4", 30000.0), ("euler3d_c31p_n8_h2_v2", 10000.0)])
+def test_rhs_with_own_geometry_and_metric(name, ztop):
+    """End to end without any reference-supplied array but the state: geometry3d builds the metric of all six
+    panels (Schaer mountain + sponge for case 21), the kernels evaluate R(Q), the reference's R is the check."""
+    from tests.gpu_util import to_dev
+    from wxfactory_amd.geometry3d import CubedSphere3DTile, metric3d_torch, planet_for_case, topography_for_case
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D
+    from wxfactory_amd.synthetic import dfr_ops
+
+    g = golden(name)
+    topo = topography_for_case(g.case, planet_for_case(g.case)[0])
+    plans = {}
+    for p in range(6):
+        t = CubedSphere3DTile(g.n, g.H, g.V, p, ztop, g.case, topo=topo)
+        plans[p] = Euler3DPlan(g.n, g.H, g.V, g.case, p, dfr_ops(g.n), metric3d_torch(t, DEV))
+    Rs = RhsEuler3D(plans)({p: to_dev(g.q(p)) for p in range(6)})
+    torch.cuda.synchronize()
+    scales = {p: _scale(g, p, False) for p in g.metric_panels()}
+    floor = np.max(np.stack(list(scales.values())), axis=0)
+    for p in range(6):
+        ref = g.r(p)
+        err = var_err(Rs[p].cpu().numpy(), ref)
+        assert (err <= TOL * np.maximum(var_max(ref), scales.get(p, floor))).all(), (p, err)

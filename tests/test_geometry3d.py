@@ -1,0 +1,127 @@
+"""Setup-time 3-D geometry + metric against the reference's own Metric3DTopo arrays.
+
+Fixtures: smooth sphere (case 31, odd and even n), Schaer mountain (case 21) on 6 panels, the same
+mountain on a ROTATED grid over 24 tiles (slopes cross every kind of tile edge: interior, rotated,
+flipped), and a deep-atmosphere rotating planet (rotation Christoffel symbols).
+
+Norm: components that vanish analytically hold rounding residue in both implementations (h^13 ~ 1e-23 next to
+h^11 ~ 1e-8 without topography), so each component is compared relative to the natural scale of its
+tensor: sqrt(max|h^aa| max|h^bb|) for h^ab; for the Christoffel symbols of one upper index, the size of
+their contribution to the forcing  G^i_jk (rho u^j u^k + h^jk p),  i.e. weighted by sqrt(h^jj h^kk)
+(space part) or sqrt(h^jj) (rotation part, G^i_0j u^j), rows made commensurable by 1/sqrt(h^ii)."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.util import GOLDEN
+from wxfactory_amd.geometry3d import (CubedSphere3DTile, metric3d, planet_for_case, schar_damping_fields,
+                                       topography_for_case)
+
+TOL = 2e-10
+NAMES = {"sqrtG_new": "sqrtG", "inv_dzdeta_new": "inv_dzdeta", "sqrtG_itf_i_new": "sqrtG_itf_i",
+         "sqrtG_itf_j_new": "sqrtG_itf_j", "sqrtG_itf_k_new": "sqrtG_itf_k"}
+TENSORS = {"h_contra_new": "h_contra", "h_contra_itf_i_new": "h_contra_itf_i", "h_contra_itf_j_new": "h_contra_itf_j",
+           "h_contra_itf_k_new": "h_contra_itf_k"}
+
+
+def _check(m, g, pre, label):
+    for k, mine in NAMES.items():
+        ref = g[pre + k]
+        assert np.abs(m[mine].reshape(ref.shape) - ref).max() <= TOL * np.abs(ref).max(), (label, k)
+    for k, mine in TENSORS.items():
+        ref = g[pre + k]
+        a = m[mine].reshape(ref.shape)
+        diag = [np.abs(ref[i, i]).max() for i in range(3)]
+        for i in range(3):
+            for j in range(3):
+                err = np.abs(a[i, j] - ref[i, j]).max()
+                assert err <= TOL * np.sqrt(diag[i] * diag[j]), (label, k, i, j, err)
+    ref = g[pre + "christoffel"]
+    a = m["christoffel"].reshape(ref.shape)
+    hd = [np.sqrt(np.abs(g[pre + "h_contra_new"][i, i]).max()) for i in range(3)]
+    w_rot = np.array(hd)
+    w_space = np.array([hd[j] * hd[k] for j, k in ((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))])
+    red = tuple(range(1, ref.ndim - 1))
+    # (row i of the forcing has units 1/length_i: divide by sqrt(h^ii) to compare rows with each other)
+    for cols, w in ((slice(0, 3), w_rot), (slice(3, 9), w_space)):
+        size = max((np.abs(ref[i, cols]).max(axis=red) * w).max() / hd[i] for i in range(3))
+        for i in range(3):
+            err = (np.abs(a[i, cols] - ref[i, cols]).max(axis=red) * w).max() / hd[i]
+            assert err <= TOL * size, (label, "christoffel", i, cols, err, size)
+    sn = g[pre.replace("metric/", "geom/") + "boundary_sn_new"][:, 0, :].reshape(-1)
+    we = g[pre.replace("metric/", "geom/") + "boundary_we_new"][:, 0, :].reshape(-1)
+    assert np.abs(m["boundary_sn"] - sn).max() < 1e-14 and np.abs(m["boundary_we"] - we).max() < 1e-14
+
+
+@pytest.mark.parametrize("name,ztop", [("euler3d_c31_n3_h4_v2", 10000.0), ("euler3d_c31p_n8_h2_v2", 10000.0),
+                                       ("euler3d_c21_n4_h3_v4", 30000.0)])
+def test_metric3d_whole_panels(name, ztop):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    n, H, V, case = (int(g[f"meta/{k}"]) for k in ("n", "H", "V", "case_number"))
+    done = 0
+    for p in range(6):
+        if f"p{p}/metric/sqrtG_new" not in g.files:
+            continue
+        t = CubedSphere3DTile(n, H, V, p, ztop, case, topo=topography_for_case(case, planet_for_case(case)[0]))
+        _check(metric3d(t), g, f"p{p}/metric/", (name, p))
+        done += 1
+    assert done >= 2
+
+
+def test_metric3d_rotated_grid_mountain_on_24_tiles():
+    g = np.load(os.path.join(GOLDEN, "metric3d_c21_rot_tiles24_n3_h2_v3.npz"))
+    n, H, V, case, k = (int(g[f"meta/{x}"]) for x in ("n", "H", "V", "case_number", "k"))
+    lam, phi, alp = g["meta/rotation"]
+    topo = topography_for_case(case, planet_for_case(case)[0])
+    assert k == 2 and case == 21
+    for r in range(24):
+        p, row, col = (int(x) for x in g[f"p{r}/topo/panel_row_col"])
+        t = CubedSphere3DTile(n, H, V, p, float(g["meta/ztop"]), case, row=row, col=col, k=k, lambda0=lam, phi0=phi,
+                              alpha0=alp, topo=topo)
+        _check(metric3d(t), g, f"p{r}/metric/", ("tile", r))
+    # the mountain really straddles panels 0, 1 and 5 (edges 1-5 are rotated AND flipped): steep slopes there
+    for r in (1, 4, 5, 21, 23):
+        h = g[f"p{r}/metric/h_contra_new"]
+        assert np.abs(h[0, 2]).max() > 1e-3 * np.sqrt(np.abs(h[0, 0]).max() * np.abs(h[2, 2]).max())
+
+
+def test_schar_sponge_fields():
+    for name in ("euler3d_c21_n4_h3_v4", "metric3d_c21_rot_tiles24_n3_h2_v3"):
+        g = np.load(os.path.join(GOLDEN, name + ".npz"))
+        n, H, V, case = (int(g[f"meta/{x}"]) for x in ("n", "H", "V", "case_number"))
+        k = int(g["meta/k"]) if "meta/k" in g.files else 1
+        lam, phi, alp = g["meta/rotation"] if "meta/rotation" in g.files else (0.0, 0.0, 0.0)
+        topo = topography_for_case(case, planet_for_case(case)[0])
+        seen = 0
+        for r in range(6 * k * k):
+            if f"p{r}/metric/damp_coef" not in g.files:
+                continue
+            p, row, col = (int(x) for x in g[f"p{r}/topo/panel_row_col"]) if k > 1 else (r, 0, 0)
+            t = CubedSphere3DTile(n, H, V, p, 30000.0, case, row=row, col=col, k=k, lambda0=lam, phi0=phi, alpha0=alp, topo=topo)
+            d = schar_damping_fields(t)
+            coef, uref = g[f"p{r}/metric/damp_coef"], g[f"p{r}/metric/damp_uref"]
+            assert np.abs(d["damp_coef"] - coef).max() <= 1e-13 * np.abs(coef).max()
+            assert (coef > 0).any() and (coef == 0).any()
+            for i in range(3):  # the fixture's reference wind was recovered by a division (1e-12 noise)
+                assert np.abs(d["damp_uref"][i] - uref[i]).max() <= 1e-9 * max(np.abs(uref[:2]).max(), 1e-300), (name, r, i)
+            seen += 1
+        assert seen >= 3
+
+
+def test_metric3d_deep_atmosphere_rotating_planet():
+    g = np.load(os.path.join(GOLDEN, "metric3d_c77_deep_rot_n4_h2_v2.npz"))
+    n, H, V, case = (int(g[f"meta/{x}"]) for x in ("n", "H", "V", "case_number"))
+    lam, phi, alp = g["meta/rotation"]
+    assert int(g["meta/deep"]) == 1
+    for p in range(6):
+        t = CubedSphere3DTile(n, H, V, p, float(g["meta/ztop"]), case, depth_approx="deep", lambda0=lam, phi0=phi, alpha0=alp)
+        assert t.rotation_speed > 0
+        _check(metric3d(t), g, f"p{p}/metric/", ("deep", p))
+        assert np.abs(g[f"p{p}/metric/christoffel"][:, :3]).max() > 0  # rotation symbols are exercised
+
+
+def test_slab_size_does_not_change_the_result():
+    t = CubedSphere3DTile(3, 2, 2, 4, 10000.0, 31)
+    a, b = metric3d(t, slab_points=10), metric3d(t, slab_points=10**7)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
