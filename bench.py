@@ -122,6 +122,9 @@ def main():
     ap.add_argument("--whole-panels", action="store_true", help="one tile per panel even when 6 does not divide N")
     ap.add_argument("--tiles-per-side", type=int, default=0, help="force k (6 k^2 tiles); default: chosen from N")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary (shallow-water S7) measurement")
+    ap.add_argument("--metric", choices=("true", "synthetic"), default="true",
+                    help="static metric fields: the cubed-sphere metric of the DCMIP 3-1 planet from wxfactory_amd.geometry3d "
+                         "(default, SURVEY 8d) or SURVEY's seeded synthetic fields; values do not affect speed")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -157,10 +160,18 @@ def main():
     Ht = H // k
     mine = tiles_of_rank(rank, world, topo.ntiles)
     plans, qs = {}, {}
+    t_setup = time.perf_counter()
     for t in mine:
-        metric = synthetic.euler3d_metric(n, Ht, V, t, dev, args.seed)
+        if args.metric == "true":
+            from wxfactory_amd.geometry3d import CubedSphere3DTile, metric3d_torch
+
+            panel, row, col = topo.locate(t)
+            metric = metric3d_torch(CubedSphere3DTile(n, Ht, V, panel, 10000.0, 31, row=row, col=col, k=k), dev)
+        else:
+            metric = synthetic.euler3d_metric(n, Ht, V, t, dev, args.seed)
         plans[t] = Euler3DPlan(n, Ht, V, 31, topo.locate(t)[0], ops, metric, on_panel_edge=topo.on_panel_edge(t))
         qs[t] = synthetic.euler3d_state(n, Ht, V, t, dev, args.seed)
+    t_setup = time.perf_counter() - t_setup
     edge_doubles = 5 * V * Ht * n * n  # WX_EULER3D_EDGE_FIELDS
     ex = PanelExchange(edge_doubles, dev, rank=rank, world_size=world, tiles_per_side=k)
     rhs = RhsEuler3D(plans, ex, overlap=not args.no_overlap)
@@ -244,7 +255,10 @@ def main():
                                    f"({5*pts_panel*6} DOF), halo exchange included",
                        "n": n, "H": H, "V": V, "tiles": topo.ntiles, "tile_H": Ht, "tiles_per_gpu": len(mine),
                        "parallelism": f"tile-dd{min(world, topo.ntiles)}",
-                       "overlap": not args.no_overlap},
+                       "overlap": not args.no_overlap,
+                       "metric": "geometry3d: equiangular cubed sphere, DCMIP 3-1 planet (R/125), ztop 10 km"
+                                 if args.metric == "true" else "seeded synthetic fields (SURVEY 8d)",
+                       "metric_setup_s": round(t_setup, 1)},
             "roofline": roof,
         }
         if args.gpus == 1 and not args.no_extras:

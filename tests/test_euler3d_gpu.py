@@ -269,3 +269,14 @@ def test_rhs_with_own_geometry_and_metric(name, ztop):
         ref = g.r(p)
         err = var_err(Rs[p].cpu().numpy(), ref)
         assert (err <= TOL * np.maximum(var_max(ref), scales.get(p, floor))).all(), (p, err)
+
+
+def test_metric3d_on_the_gpu_equals_numpy():
+    from wxfactory_amd.geometry3d import CubedSphere3DTile, metric3d, planet_for_case, topography_for_case
+
+    t = CubedSphere3DTile(4, 3, 2, 1, 30000.0, 21, topo=topography_for_case(21, planet_for_case(21)[0]))
+    a, b = metric3d(t, threads=1), metric3d(t, device=DEV)
+    for k in a:
+        assert b[k].is_cuda and tuple(b[k].shape) == a[k].shape
+        tol = 1e-11 if k == "christoffel" else 1e-13
+        assert np.abs(b[k].cpu().numpy() - a[k]).max() <= tol * np.abs(a[k]).max(), k

@@ -121,7 +121,38 @@ def test_metric3d_deep_atmosphere_rotating_planet():
         assert np.abs(g[f"p{p}/metric/christoffel"][:, :3]).max() > 0  # rotation symbols are exercised
 
 
-def test_slab_size_does_not_change_the_result():
-    t = CubedSphere3DTile(3, 2, 2, 4, 10000.0, 31)
-    a, b = metric3d(t, slab_points=10), metric3d(t, slab_points=10**7)
-    assert all(np.array_equal(a[k], b[k]) for k in a)
+def test_closed_form_christoffel_equals_the_reference_procedure():
+    """The spatial symbols by hand-inverting the reference's 27 x 27 pointwise system (default) against
+    solving it with LAPACK as the reference does, on any number of threads."""
+    for kw in (dict(n=3, H=2, V=2, panel=4, ztop=10000.0, case_number=31),
+               dict(n=4, H=2, V=3, panel=0, ztop=30000.0, case_number=21),
+               dict(n=4, H=2, V=2, panel=2, ztop=10000.0, case_number=77, depth_approx="deep", lambda0=-0.2, phi0=0.3)):
+        case = kw["case_number"]
+        t = CubedSphere3DTile(topo=topography_for_case(case, planet_for_case(case)[0]), **kw)
+        a = metric3d(t, christoffel="solve", threads=1)
+        b = metric3d(t, christoffel="solve", threads=4)
+        c = metric3d(t)
+        assert all(np.array_equal(a[k], b[k]) for k in a)
+        assert all(np.array_equal(a[k], c[k]) for k in a if k != "christoffel")
+        assert np.abs(a["christoffel"] - c["christoffel"]).max() <= 1e-13 * np.abs(a["christoffel"]).max()
+    with pytest.raises(ValueError):
+        metric3d(t, christoffel="other")
+
+
+def test_torch_block_stage_equals_numpy():
+    """The device flavour of the block stage (same code on torch tensors, whole layers per block) against the
+    NumPy flavour - here on the CPU device; the GPU suite repeats it on cuda:0."""
+    import torch
+
+    for kw in (dict(n=4, H=3, V=2, panel=1, ztop=30000.0, case_number=21),
+               dict(n=3, H=2, V=2, panel=5, ztop=10000.0, case_number=77, depth_approx="deep", alpha0=-0.3)):
+        case = kw["case_number"]
+        t = CubedSphere3DTile(topo=topography_for_case(case, planet_for_case(case)[0]), **kw)
+        a = metric3d(t, threads=1)
+        for rows in (None, 2):
+            b = metric3d(t, device="cpu", rows_per_block=rows)
+            for k in a:
+                assert isinstance(b[k], torch.Tensor) and tuple(b[k].shape) == a[k].shape
+                scale = np.abs(a[k]).max()
+                tol = 1e-11 if k == "christoffel" else 1e-13  # (second derivatives: BLAS vs torch matmul rounding)
+                assert np.abs(b[k].numpy() - a[k]).max() <= tol * scale, (k, rows)

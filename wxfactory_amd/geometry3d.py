@@ -20,10 +20,12 @@ the metric arrays of the reference-generated fixtures, with and without topograp
     one-element-deep strip of that neighbour (heights are analytic in (lon, lat, eta)), so the setup of a
     tile needs nothing but its own parameters - any decomposition, any rank count;
   * work arrays are (nk, nj, ni) grids, converted to the kernels' layouts once at the end;
-  * the 27 x 27 solves are batched in slabs of bounded size (the reference materialises all of them at once:
-    86 GB per panel at E7).
+  * the pointwise 27 x 27 system for the spatial Christoffel symbols is inverted in closed form (default;
+    ~100x faster than LAPACK on 27 x 27 blocks, which the reference materialises all at once: 86 GB per panel at
+    E7); `christoffel="solve"` runs the reference's literal procedure in bounded slabs as a cross-check.
 """
 import math
+import os
 from typing import Callable, Dict, Optional
 
 import numpy
@@ -311,69 +313,99 @@ def _neighbour_message(t: CubedSphere3DTile, e: int, dfr: _Dfr):
     return msg
 
 
-def _compute_metric(X, Y, R, d1, d2, d3, dx, dy, de, A, deep):
-    """Covariant and contravariant metric and sqrt(g) in reference-element units (metric3d.py:519-646);
+_PAIRS = ((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))  # unique components of a symmetric 3 x 3 tensor
+
+
+def _hcontra_sqrtg(X, Y, R, d1, d2, d3, dx, dy, de, A, deep):
+    """Contravariant metric (its six unique components, keyed (a, b), a <= b) and sqrt(g) in reference-element
+    units (metric3d.py:519-646; the covariant metric the reference also builds is not read by the RHS).
     `A` = planet radius (shallow atmosphere) - the deep form uses the local radius R instead."""
     rad = R if deep else A
     delsq = 1 + X**2 + Y**2
-    del4 = delsq**2
-    hcov = numpy.empty((3, 3) + numpy.broadcast(X, d1).shape)
-    hcon = numpy.empty_like(hcov)
-    hcov[0, 0] = (dx**2 / 4) * (rad**2 / del4 * (1 + X**2) ** 2 * (1 + Y**2) + d1**2)
-    hcov[0, 1] = hcov[1, 0] = (dx * dy / 4) * (-(rad**2) / del4 * X * Y * (1 + X**2) * (1 + Y**2) + d1 * d2)
-    hcov[0, 2] = hcov[2, 0] = de * dx / 4 * d1 * d3
-    hcov[1, 1] = dy**2 / 4 * (rad**2 / del4 * (1 + X**2) * (1 + Y**2) ** 2 + d2**2)
-    hcov[1, 2] = hcov[2, 1] = de * dy / 4 * d2 * d3
-    hcov[2, 2] = (de**2 / 4) * d3**2
-    hcon[0, 0] = (4 / dx**2) * (delsq / (rad**2 * (1 + X**2)))
-    hcon[0, 1] = hcon[1, 0] = (4 / dx / dy) * (X * Y * delsq / (rad**2 * (1 + X**2) * (1 + Y**2)))
-    hcon[0, 2] = hcon[2, 0] = (4 / dx / de) * (
+    h = {}
+    h[0, 0] = (4 / dx**2) * (delsq / (rad**2 * (1 + X**2))) + 0.0 * d1
+    h[0, 1] = (4 / dx / dy) * (X * Y * delsq / (rad**2 * (1 + X**2) * (1 + Y**2))) + 0.0 * d1
+    h[0, 2] = (4 / dx / de) * (
         -(d1 * delsq / (rad**2 * (1 + X**2)) + d2 * delsq * X * Y / (rad**2 * (1 + X**2) * (1 + Y**2))) / d3)
-    hcon[1, 1] = (4 / dy**2) * (delsq / (rad**2 * (1 + Y**2)))
-    hcon[1, 2] = hcon[2, 1] = (4 / dy / de) * (
+    h[1, 1] = (4 / dy**2) * (delsq / (rad**2 * (1 + Y**2))) + 0.0 * d1
+    h[1, 2] = (4 / dy / de) * (
         -(d1 * X * Y * delsq / (rad**2 * (1 + X**2) * (1 + Y**2)) + d2 * delsq / (rad**2 * (1 + Y**2))) / d3)
-    hcon[2, 2] = (4 / de**2) * (1 + d1**2 * delsq / (rad**2 * (1 + X**2))
-                                + 2 * d1 * d2 * X * Y * delsq / (rad**2 * (1 + X**2) * (1 + Y**2))
-                                + d2**2 * delsq / (rad**2 * (1 + Y**2))) / d3**2
-    rootg = (dx / 2) * (dy / 2) * (de / 2) * rad**2 * (1 + X**2) * (1 + Y**2) * numpy.abs(d3) / delsq**1.5
-    return hcov, hcon, rootg
+    h[2, 2] = (4 / de**2) * (1 + d1**2 * delsq / (rad**2 * (1 + X**2))
+                             + 2 * d1 * d2 * X * Y * delsq / (rad**2 * (1 + X**2) * (1 + Y**2))
+                             + d2**2 * delsq / (rad**2 * (1 + Y**2))) / d3**2
+    rootg = (dx / 2) * (dy / 2) * (de / 2) * rad**2 * (1 + X**2) * (1 + Y**2) * abs(d3) / delsq**1.5
+    return h, rootg
 
 
-def _space_christoffel(dfr, hcon, sg, hcon_i, sg_i, hcon_j, sg_j, hcon_k, sg_k, slab_points=200_000):
-    """The 18 spatial Christoffel symbols from the derivatives of sqrtG h^ab (metric3d.py:905-957), solved
-    pointwise (27 unknowns, the symmetric pairs come out equal) in slabs of k-levels."""
-    f = hcon * sg[None, None]
-    fi, fj, fk = hcon_i * sg_i[None, None], hcon_j * sg_j[None, None], hcon_k * sg_k[None, None]
-    grad = numpy.stack((dfr.comma(f, fi[..., :-1], fi[..., 1:], -1),
-                        dfr.comma(f, fj[..., :-1, :], fj[..., 1:, :], -2),
-                        dfr.comma(f, fk[..., :-1, :, :], fk[..., 1:, :, :], -3)))   # [c, a, b, k, j, i]
-    nk, nj, ni = sg.shape
-    gam = numpy.empty((3, 3, 3, nk, nj, ni))
-    step = max(1, slab_points // (nj * ni))
-    for k0 in range(0, nk, step):
-        sl = slice(k0, min(nk, k0 + step))
-        s, h = sg[sl], hcon[:, :, sl]
-        m = s.shape[0]
-        lhs = numpy.zeros((m, nj, ni, 3, 3, 3, 3, 3, 3))
-        for a in range(3):
-            for b in range(3):
-                for c in range(3):
-                    for d in range(3):
-                        lhs[..., a, b, c, d, c, d] += s * h[a, b]
-                        lhs[..., a, b, c, a, d, c] -= s * h[d, b]
-                        lhs[..., a, b, c, b, c, d] -= s * h[a, d]
-        rhs = numpy.moveaxis(grad[:, :, :, sl], (0, 1, 2), (5, 3, 4))  # [k, j, i, a, b, c]
-        sol = numpy.linalg.solve(lhs.reshape(m, nj, ni, 27, 27), rhs.reshape(m, nj, ni, 27, 1))[..., 0]
-        gam[:, :, :, sl] = numpy.moveaxis(sol.reshape(m, nj, ni, 3, 3, 3), (3, 4, 5), (0, 1, 2))
-    return gam
+def _sym(h, a, b):
+    return h[(a, b) if a <= b else (b, a)]
 
 
-def metric3d(t: CubedSphere3DTile, slab_points: int = 200_000) -> Dict[str, numpy.ndarray]:
+def _space_christoffel_solve(T, h, sg):
+    """The 18 spatial Christoffel symbols exactly as the reference obtains them (metric3d.py:905-957): the
+    pointwise 27 x 27 system  (sqrtG h^ab)_,c = sqrtG (G^d_cd h^ab - G^a_dc h^db - G^b_cd h^ad)  solved with
+    LAPACK.  ~40 us per point: kept as the cross-check of the closed form below.  T[(a,b)][c] = the left side."""
+    shp = sg.shape
+    lhs = numpy.zeros(shp + (3, 3, 3, 3, 3, 3))
+    rhs = numpy.empty(shp + (3, 3, 3))
+    for a in range(3):
+        for b in range(3):
+            for c in range(3):
+                rhs[..., a, b, c] = _sym(T, a, b)[c]
+                for d in range(3):
+                    lhs[..., a, b, c, d, c, d] += sg * _sym(h, a, b)
+                    lhs[..., a, b, c, a, d, c] -= sg * _sym(h, d, b)
+                    lhs[..., a, b, c, b, c, d] -= sg * _sym(h, a, d)
+    sol = numpy.linalg.solve(lhs.reshape(shp + (27, 27)), rhs.reshape(shp + (27, 1)))[..., 0].reshape(shp + (3, 3, 3))
+    return {(d, b, c): sol[..., d, b, c] for d in range(3) for (b, c) in _PAIRS}
+
+
+def _space_christoffel_closed(T, h, sg):
+    """The same symbols by inverting that linear relation by hand.  With T^ab_c = (sqrtG h^ab)_,c / sqrtG and
+    g = (h^..)^-1:   G^d_cd = g_ab T^ab_c =: t_c;   S^ab_c = t_c h^ab - T^ab_c = G^a_dc h^db + G^b_dc h^da;
+    lowering both indices, S_abc = G_a,bc + G_b,ac, hence G_a,bc = (S_abc + S_acb - S_bca) / 2 and
+    G^d_bc = h^da G_a,bc.  The 27 x 27 system is non-singular, so this symmetric solution is its solution."""
+    H = lambda a, b: _sym(h, a, b)  # noqa: E731
+    det = (H(0, 0) * (H(1, 1) * H(2, 2) - H(1, 2) * H(1, 2)) - H(0, 1) * (H(0, 1) * H(2, 2) - H(1, 2) * H(0, 2))
+           + H(0, 2) * (H(0, 1) * H(1, 2) - H(1, 1) * H(0, 2)))
+    inv = 1.0 / det
+    g = {}
+    for a, b in _PAIRS:  # adjugate / det
+        a1, a2, b1, b2 = (a + 1) % 3, (a + 2) % 3, (b + 1) % 3, (b + 2) % 3
+        g[a, b] = (H(a1, b1) * H(a2, b2) - H(a1, b2) * H(a2, b1)) * inv
+    G = lambda a, b: _sym(g, a, b)  # noqa: E731
+    Sl = {}  # S_abc, symmetric in (a, b): keyed (a, b, c) with a <= b
+    for c in range(3):
+        tc = sum((1.0 if a == b else 2.0) * g[a, b] * (T[a, b][c] / sg) for a, b in _PAIRS)
+        S = {ab: tc * h[ab] - T[ab][c] / sg for ab in _PAIRS}
+        M = [[sum(G(a, p) * _sym(S, p, q) for p in range(3)) for q in range(3)] for a in range(3)]  # (g S)_a^q
+        for a, b in _PAIRS:
+            Sl[a, b, c] = sum(M[a][q] * G(q, b) for q in range(3))
+    SL = lambda a, b, c: Sl[(a, b, c) if a <= b else (b, a, c)]  # noqa: E731
+    low = {(a, b, c): 0.5 * (SL(a, b, c) + SL(a, c, b) - SL(b, c, a)) for a in range(3) for (b, c) in _PAIRS}
+    return {(d, b, c): sum(H(d, a) * low[a, b, c] for a in range(3)) for d in range(3) for (b, c) in _PAIRS}
+
+
+def metric3d(t: CubedSphere3DTile, christoffel: str = "closed", threads: Optional[int] = None, device=None,
+             rows_per_block: Optional[int] = None):
     """Every static array `wx_euler3d_metric` needs (minus the case-21/22 sponge fields), named as in
-    include/wxhip.h, in the kernels' layouts.  Metric3DTopo.build_metric for one tile."""
+    include/wxhip.h, in the kernels' layouts.  Metric3DTopo.build_metric for one tile.
+
+    The slopes (three fields) are computed for the whole tile with NumPy; everything after them is local to an
+    element, so the metric, its derivatives and the Christoffel symbols are produced one block of
+    (vertical layer, element rows) at a time and written straight into the final layouts:
+      * device=None: NumPy, cache-sized blocks (one element row) spread over `threads`; returns ndarrays;
+      * device=<torch device>: the same block code on torch tensors (whole layers per block); returns tensors
+        on that device - the 4.6 GB of an E7 panel are produced where the kernels read them."""
+    if christoffel not in ("closed", "solve"):
+        raise ValueError("christoffel must be 'closed' or 'solve'")
+    use_torch = device is not None
+    if use_torch and christoffel != "closed":
+        raise ValueError("the LAPACK cross-check runs on the NumPy path only")
     dfr = _Dfr(t.n)
     sl = _Slopes(t, dfr)
-    nk, nj, ni, Hi, Hj, V = t.nk, t.nj, t.ni, t.nie, t.nje, t.V
+    n, nj, ni, Hi, Hj, V = t.n, t.nj, t.ni, t.nie, t.nje, t.V
+    n2, n3 = n * n, n * n * n
     dx, dy, de = t.delta_x1, t.delta_x2, t.delta_eta
     A = t.earth_radius
 
@@ -394,68 +426,149 @@ def metric3d(t: CubedSphere3DTile, slab_points: int = 200_000) -> Dict[str, nump
 
     a_i = faces(sl.side_i, 2, halo[WEST], halo[EAST])     # (nk, nj, Hi+1) x 3
     a_j = faces(sl.side_j, 1, halo[SOUTH], halo[NORTH])   # (nk, Hj+1, ni) x 3
-    d1_i = sl.cov_i[0, 0][None] * a_i[0] + sl.cov_i[0, 1][None] * a_i[1]
-    d2_i = sl.cov_i[1, 0][None] * a_i[0] + sl.cov_i[1, 1][None] * a_i[1]
-    d3_i = a_i[2]
-    d1_j = sl.cov_j[0, 0][None] * a_j[0] + sl.cov_j[0, 1][None] * a_j[1]
-    d2_j = sl.cov_j[1, 0][None] * a_j[0] + sl.cov_j[1, 1][None] * a_j[1]
-    d3_j = a_j[2]
+    di = [sl.cov_i[0, 0][None] * a_i[0] + sl.cov_i[0, 1][None] * a_i[1],
+          sl.cov_i[1, 0][None] * a_i[0] + sl.cov_i[1, 1][None] * a_i[1], a_i[2]]
+    dj = [sl.cov_j[0, 0][None] * a_j[0] + sl.cov_j[0, 1][None] * a_j[1],
+          sl.cov_j[1, 0][None] * a_j[0] + sl.cov_j[1, 1][None] * a_j[1], a_j[2]]
     dk = []
-    for lo_hi in sl.ext_k:  # vertical: one-sided at the bottom and the top, average inside
-        lo, hi = lo_hi
+    for lo, hi in sl.ext_k:  # vertical: one-sided at the bottom and the top, average inside
         f = numpy.empty((V + 1, nj, ni))
         f[0], f[-1] = lo[0], hi[-1]
         f[1:-1] = 0.5 * (lo[1:] + hi[:-1])
         dk.append(f)
+    del a_i, a_j, halo
 
-    # -- metric at nodes and on the interfaces
-    X, Y = numpy.meshgrid(numpy.tan(t.x1), numpy.tan(t.x2))
-    X, Y = X[None], Y[None]
-    h = sl.h
-    hcov, hcon, sg = _compute_metric(X, Y, h["int"] + A, sl.d1, sl.d2, sl.d3, dx, dy, de, A, t.deep)
-    _, hcon_i, sg_i = _compute_metric(sl.Xi[None], sl.Yi[None], h["itf_i"] + A, d1_i, d2_i, d3_i, dx, dy, de, A, t.deep)
-    _, hcon_j, sg_j = _compute_metric(sl.Xj[None], sl.Yj[None], h["itf_j"] + A, d1_j, d2_j, d3_j, dx, dy, de, A, t.deep)
-    _, hcon_k, sg_k = _compute_metric(X, Y, h["itf_k"] + A, dk[0], dk[1], dk[2], dx, dy, de, A, t.deep)
+    # -- array namespace of the block stage
+    if use_torch:
+        import torch
 
-    # -- Christoffel symbols: rotation part in closed form (metric3d.py:661-836), space part numerically
-    R = (h["int"] + A) if t.deep else A
-    d1, d2, d3 = sl.d1, sl.d2, sl.d3
+        dev = torch.device(device)
+        on = lambda a: torch.from_numpy(numpy.ascontiguousarray(a)).to(dev)  # noqa: E731
+        empty = lambda shape: torch.empty(shape, dtype=torch.float64, device=dev)  # noqa: E731
+        zeros = lambda shape: torch.zeros(shape, dtype=torch.float64, device=dev)  # noqa: E731
+        perm = lambda a, *ax: a.permute(*ax)  # noqa: E731
+    else:
+        on = lambda a: a  # noqa: E731
+        empty, zeros = numpy.empty, numpy.zeros
+        perm = lambda a, *ax: a.transpose(*ax)  # noqa: E731
+    h = {k_: on(v) for k_, v in sl.h.items()}
+    d_int = [on(sl.d1), on(sl.d2), on(sl.d3)]
+    di, dj, dk = [on(a) for a in di], [on(a) for a in dj], [on(a) for a in dk]
+    tx1, tx2 = on(numpy.tan(t.x1)), on(numpy.tan(t.x2))
+    tx1f, tx2f = on(numpy.tan(t.x1_itf)), on(numpy.tan(t.x2_itf))
+    D, C0, C1 = on(dfr.D), on(dfr.C[:, 0].copy()), on(dfr.C[:, 1].copy())
+    DT = on(dfr.D.T.copy())
     sphi, cphi = math.sin(t.lat_p), math.cos(t.lat_p)
     salp, calp = math.sin(t.angle_p), math.cos(t.angle_p)
-    rot1 = sphi - X * cphi * salp + Y * cphi * calp
-    rot2 = (1 + X**2) * cphi * calp - Y * sphi + X * Y * cphi * salp
-    rot3 = (1 + Y**2) * cphi * salp + X * sphi + X * Y * cphi * calp
-    dsq = 1 + X**2 + Y**2
     Om = t.rotation_speed
-    c101 = Om * X * Y / dsq * rot1 + d1 * Om / (R * (1 + X**2)) * rot2
-    c102 = -Om * (-(1 + Y**2) / dsq) * rot1 + d2 * Om / (R * (1 + X**2)) * rot2
-    c103 = d3 * Om / (R * (1 + X**2)) * rot2
-    c201 = Om * (1 + X**2) / dsq * rot1 + d1 * Om / (R * (1 + Y**2)) * rot3
-    c202 = -Om * X * Y / dsq * rot2 + d2 * Om / (R * (1 + Y**2)) * rot3
-    c203 = d3 * Om / (R * (1 + Y**2)) * rot3
-    c301 = -(d3**-1) * (d1 * c101 + d2 * c201 + R / dsq * Om * (1 + X**2) * (cphi * calp - Y * sphi))
-    c302 = -(d3**-1) * (d1 * c102 + d2 * c202 + R / dsq * Om * (1 + Y**2) * (cphi * salp + X * sphi))
-    c303 = -d1 * Om / (R * (1 + X**2)) * rot2 - d2 * Om / (R * (1 + Y**2)) * rot3
-    gam = _space_christoffel(dfr, hcon, sg, hcon_i, sg_i, hcon_j, sg_j, hcon_k, sg_k, slab_points)
-    shape = (nk, nj, ni)
-    chr_ = numpy.empty((3, 9) + shape)
-    scale = ((2 / dx), (2 / dy), (2 / de))
-    half = (dx / 2, dy / 2, de / 2)
-    for i, (c1, c2, c3) in enumerate(((c101, c102, c103), (c201, c202, c203), (c301, c302, c303))):
-        chr_[i, 0] = numpy.broadcast_to(c1 * (scale[i] * half[0]), shape)
-        chr_[i, 1] = numpy.broadcast_to(c2 * (scale[i] * half[1]), shape)
-        chr_[i, 2] = numpy.broadcast_to(c3 * (scale[i] * half[2]), shape)
-        for s, (b, c) in enumerate(((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))):
-            chr_[i, 3 + s] = gam[i, b, c]
 
-    out = {
-        "sqrtG": t.to_blocked(sg), "h_contra": t.to_blocked(hcon), "christoffel": t.to_blocked(chr_),
-        "inv_dzdeta": t.to_blocked(1 / d3 * 2 / de),
-        "sqrtG_itf_i": t.to_itf_i(sg_i), "sqrtG_itf_j": t.to_itf_j(sg_j), "sqrtG_itf_k": t.to_itf_k(sg_k),
-        "h_contra_itf_i": t.to_itf_i(hcon_i), "h_contra_itf_j": t.to_itf_j(hcon_j), "h_contra_itf_k": t.to_itf_k(hcon_k),
-        "boundary_sn": t.boundary_sn.copy(), "boundary_we": t.boundary_we.copy(),
+    O = {
+        "sqrtG": empty((V, Hj, Hi, n3)), "h_contra": empty((3, 3, V, Hj, Hi, n3)),
+        "christoffel": zeros((3, 9, V, Hj, Hi, n3)), "inv_dzdeta": empty((V, Hj, Hi, n3)),
+        "sqrtG_itf_i": zeros((V, Hj, Hi + 2, 2 * n2)), "h_contra_itf_i": zeros((3, 3, V, Hj, Hi + 2, 2 * n2)),
+        "sqrtG_itf_j": zeros((V, Hj + 2, Hi, 2 * n2)), "h_contra_itf_j": zeros((3, 3, V, Hj + 2, Hi, 2 * n2)),
+        "sqrtG_itf_k": zeros((V + 2, Hj, Hi, 2 * n2)), "h_contra_itf_k": zeros((3, 3, V + 2, Hj, Hi, 2 * n2)),
     }
-    return {k_: numpy.ascontiguousarray(v, dtype=numpy.float64) for k_, v in out.items()}
+
+    def put(name, idx, value):          # scalar field, or the symmetric tensor {(a, b): field}
+        if isinstance(value, dict):
+            for (a, b), v in value.items():
+                O["h_contra" + name][(a, b) + idx] = v
+                if a != b:
+                    O["h_contra" + name][(b, a) + idx] = v
+        else:
+            O["sqrtG" + name][idx] = value
+
+    def both(fn, hc, sg):
+        return {ab: fn(v) for ab, v in hc.items()}, fn(sg)
+
+    def block(spec):
+        kv, r0, r1 = spec                      # vertical layer, element rows [r0, r1)
+        nr = r1 - r0
+        ks, js = slice(kv * n, (kv + 1) * n), slice(r0 * n, r1 * n)
+        X = tx1[None, None, None, :]
+        Y = tx2[js].reshape(nr, n)[None, :, :, None]
+        nodes = lambda a: a[ks, js].reshape(n, nr, n, -1)  # noqa: E731  [k, row, j, i]
+        d1, d2, d3 = (nodes(a) for a in d_int)
+        R_int = nodes(h["int"]) + A
+        hc, sg = _hcontra_sqrtg(X, Y, R_int, d1, d2, d3, dx, dy, de, A, t.deep)
+        hci, sgi = _hcontra_sqrtg(tx1f[None, None, None, :], Y, nodes(h["itf_i"]) + A, nodes(di[0]), nodes(di[1]),
+                                  nodes(di[2]), dx, dy, de, A, t.deep)                      # [k, row, j, face]
+        fj = slice(r0, r1 + 1)
+        hcj, sgj = _hcontra_sqrtg(tx1[None, None, :], tx2f[fj][None, :, None], h["itf_j"][ks, fj] + A, dj[0][ks, fj],
+                                  dj[1][ks, fj], dj[2][ks, fj], dx, dy, de, A, t.deep)      # [k, face, i]
+        fk = slice(kv, kv + 2)
+        kf = lambda a: a[fk, js].reshape(2, nr, n, ni)  # noqa: E731
+        hck, sgk = _hcontra_sqrtg(X, Y, kf(h["itf_k"]) + A, kf(dk[0]), kf(dk[1]), kf(dk[2]), dx, dy, de, A, t.deep)
+        # (sqrtG h^ab)_,c in reference-element units (operators.grad, operators.py:635-700), unique (a, b) only
+        T = {}
+        for ab in _PAIRS:
+            f, fi, fjj, fkk = hc[ab] * sg, hci[ab] * sgi, hcj[ab] * sgj, hck[ab] * sgk
+            gi = (f.reshape(n, nr, n, Hi, n) @ DT + fi[..., :-1, None] * C0 + fi[..., 1:, None] * C1).reshape(n, nr, n, ni)
+            gj = D @ f + C0[None, None, :, None] * fjj[:, :-1, None, :] + C1[None, None, :, None] * fjj[:, 1:, None, :]
+            gk = (D @ f.reshape(n, -1)).reshape(f.shape) + C0[:, None, None, None] * fkk[0][None] + C1[:, None, None, None] * fkk[1][None]
+            T[ab] = (gi, gj, gk)
+        gam = (_space_christoffel_closed if christoffel == "closed" else _space_christoffel_solve)(T, hc, sg)
+
+        rows = slice(r0, r1)
+        blocked = lambda a: perm(a.reshape(n, nr, n, Hi, n), 1, 3, 0, 2, 4).reshape(nr, Hi, n3)  # noqa: E731
+        O["sqrtG"][kv, rows] = blocked(sg)
+        O["inv_dzdeta"][kv, rows] = blocked(1 / d3 * 2 / de)
+        for (a, b), v in hc.items():
+            O["h_contra"][a, b, kv, rows] = blocked(v)
+            if a != b:
+                O["h_contra"][b, a, kv, rows] = O["h_contra"][a, b, kv, rows]
+        for (d, b, c), v in gam.items():
+            O["christoffel"][d, 3 + _PAIRS.index((b, c)), kv, rows] = blocked(v)
+        if Om != 0.0:  # rotation part in closed form (metric3d.py:661-836)
+            R = R_int if t.deep else A
+            rot1 = sphi - X * cphi * salp + Y * cphi * calp
+            rot2 = (1 + X**2) * cphi * calp - Y * sphi + X * Y * cphi * salp
+            rot3 = (1 + Y**2) * cphi * salp + X * sphi + X * Y * cphi * calp
+            dsq = 1 + X**2 + Y**2
+            c101 = Om * X * Y / dsq * rot1 + d1 * Om / (R * (1 + X**2)) * rot2
+            c102 = -Om * (-(1 + Y**2) / dsq) * rot1 + d2 * Om / (R * (1 + X**2)) * rot2
+            c103 = d3 * Om / (R * (1 + X**2)) * rot2
+            c201 = Om * (1 + X**2) / dsq * rot1 + d1 * Om / (R * (1 + Y**2)) * rot3
+            c202 = -Om * X * Y / dsq * rot2 + d2 * Om / (R * (1 + Y**2)) * rot3
+            c203 = d3 * Om / (R * (1 + Y**2)) * rot3
+            c301 = -(d3**-1) * (d1 * c101 + d2 * c201 + R / dsq * Om * (1 + X**2) * (cphi * calp - Y * sphi))
+            c302 = -(d3**-1) * (d1 * c102 + d2 * c202 + R / dsq * Om * (1 + Y**2) * (cphi * salp + X * sphi))
+            c303 = -d1 * Om / (R * (1 + X**2)) * rot2 - d2 * Om / (R * (1 + Y**2)) * rot3
+            scale, half = (2 / dx, 2 / dy, 2 / de), (dx / 2, dy / 2, de / 2)
+            for i, row in enumerate(((c101, c102, c103), (c201, c202, c203), (c301, c302, c303))):
+                for j in range(3):
+                    O["christoffel"][i, j, kv, rows] = blocked(row[j] * (scale[i] * half[j]))
+        # interfaces: face f fills the minus slot of padded element f+1 and the plus slot of padded element f
+        lo, hi = slice(0, n2), slice(n2, None)
+        ti, si = both(lambda a: perm(a, 1, 3, 0, 2).reshape(nr, Hi + 1, n2), hci, sgi)          # point (kl, jl)
+        tj, sj = both(lambda a: perm(a.reshape(n, nr + 1, Hi, n), 1, 2, 0, 3).reshape(nr + 1, Hi, n2), hcj, sgj)  # (kl, il)
+        tk, sk = both(lambda a: perm(a.reshape(2, nr, n, Hi, n), 0, 1, 3, 2, 4).reshape(2, nr, Hi, n2), hck, sgk)  # (jl, il)
+        for val in (ti, si):
+            put("_itf_i", (kv, rows, slice(1, None), lo), val)
+            put("_itf_i", (kv, rows, slice(0, -1), hi), val)
+        for val in (tj, sj):
+            put("_itf_j", (kv, slice(r0 + 1, r1 + 2), slice(None), lo), val)
+            put("_itf_j", (kv, slice(r0, r1 + 1), slice(None), hi), val)
+        for f in (0, 1):
+            for val in ({ab: v[f] for ab, v in tk.items()}, sk[f]):
+                put("_itf_k", (kv + f + 1, rows, slice(None), lo), val)
+                put("_itf_k", (kv + f, rows, slice(None), hi), val)
+
+    if rows_per_block is None:
+        rows_per_block = Hj if use_torch else 1
+    blocks = [(kv, r0, min(Hj, r0 + rows_per_block)) for kv in range(V) for r0 in range(0, Hj, rows_per_block)]
+    nthreads = 1 if use_torch else (threads if threads is not None else min(4, os.cpu_count() or 1))
+    if nthreads > 1 and len(blocks) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(max_workers=nthreads) as pool:
+            list(pool.map(block, blocks))
+    else:
+        for bl in blocks:
+            block(bl)
+    O["boundary_sn"], O["boundary_we"] = on(t.boundary_sn.copy()), on(t.boundary_we.copy())
+    return O
 
 
 def schar_damping_fields(t: CubedSphere3DTile, shear: Optional[bool] = None) -> Dict[str, numpy.ndarray]:
@@ -488,9 +601,10 @@ def schar_damping_fields(t: CubedSphere3DTile, shear: Optional[bool] = None) -> 
 
 
 def metric3d_torch(t: CubedSphere3DTile, device, **kw):
+    """metric3d on `device` (plus the sponge fields of cases 21/22): what Euler3DPlan takes as `metric`."""
     import torch
 
-    m = metric3d(t, **kw)
+    m = metric3d(t, device=device, **kw)
     if t.case_number in (21, 22):
-        m.update(schar_damping_fields(t))
-    return {k_: torch.from_numpy(v).to(device) for k_, v in m.items()}
+        m.update({k_: torch.from_numpy(v).to(device) for k_, v in schar_damping_fields(t).items()})
+    return m
