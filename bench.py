@@ -65,14 +65,14 @@ def cpu_baseline(n, V, sample_H, reps, seed):
 
 def pmc_traffic(region, n, H, V):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_summary.json: separate FETCH_SIZE / WRITE_SIZE runs of tools/kbench.py on one E7 panel,
+    (profiles/r01_v5_pmc_summary.json: separate FETCH_SIZE / WRITE_SIZE runs of tools/kbench.py on one E7 panel,
     gfx950 corrections applied by tools/pmc_summary.py).  Counters cannot be read from inside this
     process, so the number is only reported for the configuration it was measured on."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    path = os.path.join(ROOT, "profiles", "r01_v5_pmc_summary.json")
     if not (os.path.exists(path) and region == 0 and (n, H, V) == (8, 60, 8)):
         return None
     try:
-        return json.load(open(path))["kernels"]["wx::euler_rhs_kernel<8, double>"]["hbm_bytes"]
+        return json.load(open(path))["kernels"]["wx::euler_rhs_kernel<8, double, false>"]["hbm_bytes"]
     except (KeyError, ValueError):
         return None
 
