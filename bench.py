@@ -63,18 +63,47 @@ def cpu_baseline(n, V, sample_H, reps, seed):
     return dof / dt, dt
 
 
-def pmc_traffic(region, n, H, V):
+def pmc_traffic(region, n, H, V, bpp=ALGO_BYTES_PER_POINT):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/r01_v5_pmc_summary.json: separate FETCH_SIZE / WRITE_SIZE runs of tools/kbench.py on one E7 panel,
     gfx950 corrections applied by tools/pmc_summary.py).  Counters cannot be read from inside this
     process, so the number is only reported for the configuration it was measured on."""
     path = os.path.join(ROOT, "profiles", "r01_v5_pmc_summary.json")
-    if not (os.path.exists(path) and region == 0 and (n, H, V) == (8, 60, 8)):
-        return None
+    if not (os.path.exists(path) and region == 0 and (n, H, V) == (8, 60, 8) and bpp == ALGO_BYTES_PER_POINT):
+        return None  # (the PMC passes were taken on the full 27-Christoffel-field configuration)
     try:
         return json.load(open(path))["kernels"]["wx::euler_rhs_kernel<8, double, false>"]["hbm_bytes"]
     except (KeyError, ValueError):
         return None
+
+
+def k2_full_metric(dev, seed, n=8, H=60, V=8, reps=20):
+    """The fused RHS kernel on one E7 panel whose 27 Christoffel fields are all non-zero (SURVEY 8d's synthetic
+    metric = a rotating planet): the full 384 B/point configuration, where nothing is skipped at plan time."""
+    from wxfactory_amd import _lib, synthetic
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan
+
+    plan = Euler3DPlan(n, H, V, 31, 0, synthetic.dfr_ops(n), synthetic.euler3d_metric(n, H, V, 0, dev, seed))
+    q = synthetic.euler3d_state(n, H, V, 0, dev, seed)
+    send = torch.zeros((4, plan.edge_count), dtype=torch.float64, device=dev)
+    sp = [send[e] for e in range(4)]
+    out = torch.empty_like(q)
+    ts = []
+    for it in range(reps + 3):
+        plan.extrap_pack(q, sp)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        plan.rhs(q, sp, out, _lib.WX_REGION_ALL)
+        b.record()
+        torch.cuda.synchronize()
+        if it >= 3:
+            ts.append(a.elapsed_time(b) * 1e-3)
+    tk = sum(ts) / len(ts)
+    bpp = plan.bytes_per_point
+    gbs = bpp * V * H * H * n**3 / tk / 1e9
+    return {"workload": "one E7 panel, seeded synthetic metric (SURVEY 8d)", "launch_ms": round(tk * 1e3, 4),
+            "algorithmic_bytes_per_point": bpp, "achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "traffic": pmc_traffic(0, n, H, V, bpp)}
 
 
 def extras(dev, seed):
@@ -101,7 +130,7 @@ def extras(dev, seed):
     torch.cuda.synchronize()
     te = (time.perf_counter() - t0) / reps
     dof = 3 * 6 * H * H * n * n
-    return {"sw_s7": {"workload": "shallow water, n=8, H=60, 6 panels on 1 GPU (1244160 DOF), whole-sphere R(Q)",
+    return {"euler_k2_all_27_christoffel": k2_full_metric(dev, seed), "sw_s7": {"workload": "shallow water, n=8, H=60, 6 panels on 1 GPU (1244160 DOF), whole-sphere R(Q)",
                       "us_per_eval": te * 1e6, "dof_updates_per_s": dof / te,
                       "algorithmic_GBps": 156.0 * 6 * H * H * n * n / te / 1e9,
                       "note": "all six panels in one launch per phase (wx_sw_batch_*): 2 launches per R(Q); launch-latency "
@@ -236,12 +265,16 @@ def main():
         # the dominant launch shape: ALL at N=1, INTERIOR when the exchange is overlapped
         region = max(by_region, key=lambda r: sum(by_region[r]))
         tk = sum(by_region[region]) / len(by_region[region])
-        bytes_launch = ALGO_BYTES_PER_POINT * (pts_panel / (k * k)) * frac_of_panel[region]
+        # compulsory bytes of THIS launch: SURVEY 8d's 384 B/point, minus the 72 B/point of the nine rotation
+        # Christoffel fields when the plan found them identically zero (non-rotating planet) and skips them
+        bpp = next(iter(plans.values())).bytes_per_point if plans else ALGO_BYTES_PER_POINT
+        bytes_launch = bpp * (pts_panel / (k * k)) * frac_of_panel[region]
         achieved = bytes_launch / tk / 1e9
         roof = {"bound": "hbm", "kernel": "euler_rhs_kernel<8,double>", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic(region, n, Ht, V), "launch_ms": round(tk * 1e3, 4),
-                "algorithmic_bytes_per_launch": bytes_launch,
+                "traffic": pmc_traffic(region, n, Ht, V, bpp), "launch_ms": round(tk * 1e3, 4),
+                "algorithmic_bytes_per_launch": bytes_launch, "algorithmic_bytes_per_point": bpp,
+                "survey_bytes_per_point": ALGO_BYTES_PER_POINT,
                 "region": {0: "all", 1: "interior", 2: "boundary"}[region]}
 
     if rank == 0:

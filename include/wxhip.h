@@ -121,6 +121,12 @@ wx_status wx_euler3d_plan_destroy(wx_euler3d_plan* plan);
  * (rho, rho u1, rho u2, rho w, rho theta).  (Builds with -DWX_EULER_NQ=6/7 append the face pressure and
  * its logarithm; wx_euler3d_edge_count() always reports the size in use.) */
 #define WX_EULER3D_EDGE_FIELDS 5
+/* Compulsory HBM bytes per solution point of one wx_euler3d_rhs launch on this plan (SURVEY.md 8d figure:
+ * 8 (5 Q + 5 R + sqrtG + 6 h + 27 Gamma + inv_dzdeta) + interface metric = 384 B at n = 8), after the plan-time
+ * specialisations: plan creation scans the nine rotation Christoffel symbols christoffel[:, 0:3] once and, when
+ * they are identically zero (non-rotating planets: DCMIP 2-x / 3-1), the kernels never read them (312 B). */
+double wx_euler3d_bytes_per_point(const wx_euler3d_plan* plan);
+
 /* Number of ELEMENTS of dtype in one edge message: 5*V*H*n^2, layout [var][ek][along][n^2] =
  * exactly the reference's q_itf_{s,n,w,e} after ExchangeRequest.wait(). */
 size_t wx_euler3d_edge_count(const wx_euler3d_plan* plan);

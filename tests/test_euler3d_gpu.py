@@ -280,3 +280,30 @@ def test_metric3d_on_the_gpu_equals_numpy():
         assert b[k].is_cuda and tuple(b[k].shape) == a[k].shape
         tol = 1e-11 if k == "christoffel" else 1e-13
         assert np.abs(b[k].cpu().numpy() - a[k]).max() <= tol * np.abs(a[k]).max(), k
+
+
+def test_plan_skips_identically_zero_rotation_symbols():
+    """Plan-time specialisation: on a non-rotating planet (every DCMIP fixture here) christoffel[:, 0:3] is
+    identically zero and the kernels do not read it; the result is the same as with the loads."""
+    from tests.gpu_util import device_metric, to_dev
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan
+
+    g = golden("euler3d_c31p_n8_h2_v2")
+    m = device_metric(g, 0, DEV)
+    assert float(m["christoffel"].reshape(3, 9, -1)[:, :3].abs().max()) == 0.0
+    plan = Euler3DPlan(g.n, g.H, g.V, g.case, 0, g.ops, m)
+    assert plan.bytes_per_point == 8 * (5 + 5 + 1 + 6 + 18 + 1) + 24
+    m2 = dict(m)
+    m2["christoffel"] = m["christoffel"].clone()
+    m2["christoffel"].view(3, 9, -1)[0, 0, 0] = 1e-300  # one tiny non-zero value: the full-load path
+    full = Euler3DPlan(g.n, g.H, g.V, g.case, 0, g.ops, m2)
+    assert full.bytes_per_point == 384.0
+    q = to_dev(g.q(0))
+    halo = [to_dev(h) for h in g.halo(0)]
+    send = [torch.empty_like(h) for h in halo]
+    a, b = torch.empty_like(q), torch.empty_like(q)
+    for pl, out in ((plan, a), (full, b)):
+        pl.extrap_pack(q, send)
+        pl.rhs(q, halo, out)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)

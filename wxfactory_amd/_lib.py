@@ -59,6 +59,7 @@ SIGNATURES = {
                                             POINTER(DfrOps), POINTER(Euler3DMetric)]),
     "wx_euler3d_plan_destroy": (c_int, [c_void_p]),
     "wx_euler3d_edge_count": (c_size_t, [c_void_p]),
+    "wx_euler3d_bytes_per_point": (c_double, [c_void_p]),
     "wx_euler3d_extrap_pack": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p]),
     "wx_euler3d_rhs": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_int, c_void_p]),
     "wx_euler3d_rhs_axpy": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_double, c_double,

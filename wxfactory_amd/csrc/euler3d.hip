@@ -51,7 +51,7 @@
 #define WX_K2_STAMPS 0   // diagnostic build: per-workgroup phase timestamps (never in the product build)
 #endif
 #ifndef WX_K2_EARLY_LOADS
-#define WX_K2_EARLY_LOADS 0   // issue the point loads before the face stage
+#define WX_K2_EARLY_LOADS 1   // issue the point loads before the face stage
 #endif
 
 #if WX_K2_NT_METRIC
@@ -83,6 +83,13 @@ enum { F_W = 0, F_E = 1, F_S = 2, F_N = 3, F_B = 4, F_T = 5 };
 // variables, exactly the reference's q_itf (default: measured fastest - the kernel is HBM-bound and
 // the two extra streams cost more than redoing exp(gamma*log(.)) on both sides of a face);
 // 6 / 7 additionally carry the face pressure / its logarithm (pde_euler_cubesphere.py:158-160).
+#ifndef WX_K2_UNROLL_DIRS
+#define WX_K2_UNROLL_DIRS 1  // 1: one copy of the directional pass per direction: constant LDS strides, so the
+                             // reads pair up as ds_read2_b64 with immediate offsets (half the LDS instructions)
+#endif
+#ifndef WX_K2_SKELETON
+#define WX_K2_SKELETON 0   // diagnostic build: K2 keeps its loads, LDS writes and stores but skips the arithmetic
+#endif
 #ifndef WX_K2_OWN_FACES
 #define WX_K2_OWN_FACES 0  // 1: K2 re-extrapolates its own-side face values instead of reading them back
 #endif
@@ -104,6 +111,7 @@ template <typename T>
 struct EulerParams {
     int H, V, nelem, count, region;
     int advection_only, has_damp;
+    int rot_zero;          // plan-time finding: christoffel[:, 0:3] (the rotation symbols) is identically zero
     int axpy;              // 1: out = ca*y + cb*q + cc*R(q) + cd*z (RK stage / FD Jacobian operator), 0: out = R(q)
     double ca, cb, cc, cd;
     const T* y;            // nullable (then ca is ignored)
@@ -414,7 +422,11 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
 #if !WX_K2_GAMMA_ROLLED
     double cg[27], idzv = 0.0;
 #define WX_GAMMA_LOADS()                                                        \
-    if (active) {                                                               \
+    if (active && P.rot_zero) { /* non-rotating planet: the 9 rotation symbols are identically zero */ \
+        _Pragma("unroll") for (int i = 0; i < 27; ++i)                          \
+            cg[i] = (i % 9) < 3 ? 0.0 : WX_LDM(P.chr + (size_t)i * fs + o);     \
+        idzv = WX_LDM(P.idz + o);                                               \
+    } else if (active) {                                                        \
         _Pragma("unroll") for (int i = 0; i < 27; ++i) cg[i] = WX_LDM(P.chr + (size_t)i * fs + o); \
         idzv = WX_LDM(P.idz + o);                                               \
     } else {                                                                    \
@@ -516,6 +528,16 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
             qo[6] = w_log(qo[5]); qn[6] = qo[6];  // only the own side's log p is used
         }
         const double sg = *sgp, h0 = hp[0], h1 = hp[hfs], h2 = hp[2 * hfs];
+#if WX_K2_SKELETON
+        {   // diagnostic: same loads and LDS writes, no Riemann arithmetic
+            T sum = T(sg + h0 + h1 + h2);
+#pragma unroll
+            for (int v = 0; v < NQ; ++v) sum += qo[v] + qn[v];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) fr[le][f][c][fp] = sum;
+            continue;
+        }
+#endif
         const double hdd = d == 0 ? h0 : (d == 1 ? h1 : h2);
         const T ro = 1.0 / qo[0], rn = 1.0 / qn[0];
         // (explicit selects: a run-time index into a register array of 16-byte values goes to scratch)
@@ -610,8 +632,16 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
     T acc0 = T(0.0), acc1 = sg * fc0, acc2 = sg * fc1, acc4 = T(0.0), accw = sg * fc2;
     T hf = T(0.0);
 
+#if WX_K2_SKELETON
+    __syncthreads();
+    acc0 += fr[le < EPB ? le : 0][0][0][pt % N2] + fld[6][lpt];
+#endif
+#if WX_K2_UNROLL_DIRS
+#pragma unroll
+#else
 #pragma unroll 1
-    for (int d = 0; d < 3; ++d) {
+#endif
+    for (int d = 0; d < (WX_K2_SKELETON ? 0 : 3); ++d) {
         const T ud = w_sel(d == 0, u1, w_sel(d == 1, u2, u3));
 #if WX_K2_RELOAD_H
         double hd0 = 0, hd1 = 0, hd2 = 0;
@@ -720,6 +750,14 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
 #undef WX_STAMP
 }
 
+// plan-time scan of a static field: raises *flag when any value differs from (+/-) zero
+__global__ __launch_bounds__(256) void any_nonzero_kernel(const double* __restrict__ x, size_t count, int* flag) {
+    bool any = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+        any = any || (x[i] != 0.0);
+    if (any) *flag = 1;
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -770,7 +808,7 @@ EulerParams<T> make_params(const wx_euler3d_plan* pl) {
     EulerParams<T> P;
     const EulerParams<double>& b = pl->base;
     P.H = b.H; P.V = b.V; P.nelem = b.nelem; P.count = b.count; P.region = b.region;
-    P.advection_only = b.advection_only; P.has_damp = b.has_damp;
+    P.advection_only = b.advection_only; P.has_damp = b.has_damp; P.rot_zero = b.rot_zero;
     P.q = nullptr; P.rhs = nullptr; P.itf = static_cast<T*>(pl->itf);
     P.axpy = 0; P.ca = P.cb = P.cd = 0.0; P.cc = 1.0; P.y = nullptr; P.z = nullptr;
     P.itf_out = nullptr; P.nsend_s = P.nsend_n = P.nsend_w = P.nsend_e = nullptr;
@@ -908,6 +946,27 @@ wx_status wx_euler3d_plan_create_tile(wx_euler3d_plan** out, int n, int H, int V
     b.hi = m->h_contra_itf_i; b.hj = m->h_contra_itf_j; b.hk = m->h_contra_itf_k;
     b.dcoef = damp ? m->damp_coef : nullptr; b.duref = damp ? m->damp_uref : nullptr;
     b.bsn = m->boundary_sn; b.bwe = m->boundary_we;
+    {   // static-field specialisation: are the nine rotation Christoffel symbols identically zero (cases on a
+        // non-rotating planet: DCMIP 2-x, 3-1)?  One pass over them now saves 72 B/point in every evaluation.
+        int* flag = nullptr;
+        int any = 1;
+        e = hipMalloc((void**)&flag, sizeof(int));
+        if (e == hipSuccess) e = hipMemset(flag, 0, sizeof(int));
+        if (e == hipSuccess) {
+            const size_t fs = pl->nelem * (size_t)n * n * n;
+            for (int r = 0; r < 3; ++r)
+                hipLaunchKernelGGL(any_nonzero_kernel, dim3(4096), dim3(256), 0, 0, m->christoffel + (size_t)(r * 9) * fs,
+                                   3 * fs, flag);
+            e = hipMemcpy(&any, flag, sizeof(int), hipMemcpyDeviceToHost);
+        }
+        if (flag) (void)hipFree(flag);
+        if (e != hipSuccess) {
+            (void)hipFree(pl->itf);
+            delete pl;
+            return fail(WX_ERR_HIP, "scan of the rotation Christoffel symbols failed: %s", hipGetErrorString(e));
+        }
+        b.rot_zero = any ? 0 : 1;
+    }
     EulerConsts hc;
     memset(&hc, 0, sizeof(hc));
     for (int i = 0; i < n; ++i) {
@@ -948,6 +1007,15 @@ wx_status wx_euler3d_debug_set_stamps(wx_euler3d_plan* pl, void* dev_buffer) {
     if (!pl) return fail(WX_ERR_INVALID, "null plan");
     pl->stamps = static_cast<unsigned long long*>(dev_buffer);
     return WX_OK;
+}
+
+double wx_euler3d_bytes_per_point(const wx_euler3d_plan* pl) {
+    if (!pl) return 0.0;
+    // compulsory HBM traffic of one RHS-kernel launch per solution point: Q, R, sqrtG, 6 h^ij,
+    // the Christoffel fields this plan reads, inv_dzdeta, the interface metric, the sponge fields
+    const int n = pl->n;
+    const double gammas = pl->base.rot_zero ? 18.0 : 27.0;
+    return 8.0 * (5 + 5 + 1 + 6 + gammas + 1) + 3.0 * 2 * 4 * 8 / n + (pl->base.has_damp ? 32.0 : 0.0);
 }
 
 size_t wx_euler3d_edge_count(const wx_euler3d_plan* pl) {

@@ -91,6 +91,11 @@ class Euler3DPlan:
                 or q.device != self.device:
             raise ValueError(f"state must be a contiguous {self.dtype} tensor of {self.shape} on {self.device}")
 
+    @property
+    def bytes_per_point(self) -> float:
+        """Compulsory HBM bytes per point of one RHS launch on this plan (after plan-time specialisation)."""
+        return float(self.lib.wx_euler3d_bytes_per_point(self._h))
+
     def extrap_pack(self, q: torch.Tensor, send_ptrs: Optional[Sequence[int]]):
         self._check_q(q)
         self.faces_epoch += 1
