@@ -161,6 +161,16 @@ wx_status wx_euler3d_rhs_axpy2(wx_euler3d_plan* plan, const void* q, const void*
                                const void* z, void* out, double a, double b, double c, double d, wx_region region,
                                wx_stream stream);
 
+/* Finite-difference Jacobian products (solvers/matvec.py:62-66, 76-88) without materialising Q + eps v: the
+ * two kernels of a WX_F64 plan evaluate on the shifted state  q + eps * v  formed on load;
+ *   out = a*y + b*(q + eps v) + c*R(q + eps v) + d*z.
+ * matvec_fun("fd"):  a = -dt/eps, y = R(q), b = 0, c = dt/eps;   matvec_rat: additionally d = 1, z = v, c = -dt/(2 eps). */
+wx_status wx_euler3d_shifted_extrap_pack(wx_euler3d_plan* plan, const double* q, const double* v, double eps,
+                                         void* const send[4], wx_stream stream);
+wx_status wx_euler3d_shifted_rhs_axpy2(wx_euler3d_plan* plan, const double* q, const double* v, double eps,
+                                       const void* const halo[4], const double* y, const double* z, double* out, double a,
+                                       double b, double c, double d, wx_region region, wx_stream stream);
+
 /* Stage pipeline for explicit Runge-Kutta loops.  The plan owns two interface buffers (slots 0, 1).
  * wx_euler3d_stage evaluates  out = a*y + b*q + c*R(q) + d*z  reading q's faces from slot `itf_in`
  * and - when prepare_next != 0 - extrapolates `out` (the next stage's state, still in registers) to

@@ -43,7 +43,11 @@ rhs_d = RhsEuler3D(plans, complex_arith="dual")
 rhs_d.fused_jvp = False
 b = timeit("matvec_fun complex: torch.complex + dual kernels + .imag", lambda: matvec_fun(v.flatten(), dt, Q, R, rhs_d, "complex"))
 c = timeit("matvec_fun complex: torch.complex + complex128 kernels", lambda: matvec_fun(v.flatten(), dt, Q, R, rhs, "complex"))
-d = timeit("matvec_fun fd: fused store (axpy2)", lambda: matvec_fun(v.flatten(), dt, Q, R, rhs, "fd"))
-e = timeit("matvec_rat: fused store (axpy2)", lambda: matvec_rat(v.flatten(), dt, Q, R, rhs))
+d = timeit("matvec_fun fd: shift on load + fused store", lambda: matvec_fun(v.flatten(), dt, Q, R, rhs, "fd"))
+e = timeit("matvec_rat: shift on load + fused store", lambda: matvec_rat(v.flatten(), dt, Q, R, rhs))
+rhs.fused_shift = False
+d2 = timeit("matvec_fun fd: torch add + fused store (axpy2)", lambda: matvec_fun(v.flatten(), dt, Q, R, rhs, "fd"))
+timeit("matvec_rat: torch add + fused store (axpy2)", lambda: matvec_rat(v.flatten(), dt, Q, R, rhs))
+print("fd shift-on-load vs materialised rel diff", float((d - d2).abs().max() / d2.abs().max()))
 print("fused vs complex128 rel diff", float((ref - c).abs().max() / c.abs().max()), " dual vs complex128", float((b - c).abs().max() / c.abs().max()),
       " fd vs complex", float((d - c).abs().max() / c.abs().max()))

@@ -66,6 +66,9 @@ SIGNATURES = {
                                     c_double, c_int, c_void_p]),
     "wx_euler3d_rhs_axpy2": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_double,
                                      c_double, c_double, c_double, c_int, c_void_p]),
+    "wx_euler3d_shifted_extrap_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_double, POINTER(c_void_p), c_void_p]),
+    "wx_euler3d_shifted_rhs_axpy2": (c_int, [c_void_p, c_void_p, c_void_p, c_double, POINTER(c_void_p), c_void_p, c_void_p,
+                                             c_void_p, c_double, c_double, c_double, c_double, c_int, c_void_p]),
     "wx_euler3d_extrap_pack_slot": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_int, c_void_p]),
     "wx_euler3d_stage": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_double, c_double,
                                  c_double, c_double, c_int, c_int, POINTER(c_void_p), c_int, c_void_p]),

@@ -83,6 +83,9 @@ enum { F_W = 0, F_E = 1, F_S = 2, F_N = 3, F_B = 4, F_T = 5 };
 // variables, exactly the reference's q_itf (default: measured fastest - the kernel is HBM-bound and
 // the two extra streams cost more than redoing exp(gamma*log(.)) on both sides of a face);
 // 6 / 7 additionally carry the face pressure / its logarithm (pde_euler_cubesphere.py:158-160).
+#ifndef WX_K2_GAMMA_PER_DIR
+#define WX_K2_GAMMA_PER_DIR 0  // 1: forcing row d fetched across directional pass d (needs WX_K2_UNROLL_DIRS)
+#endif
 #ifndef WX_K2_UNROLL_DIRS
 #define WX_K2_UNROLL_DIRS 1  // 1: one copy of the directional pass per direction: constant LDS strides, so the
                              // reads pair up as ds_read2_b64 with immediate offsets (half the LDS instructions)
@@ -198,6 +201,13 @@ __device__ __forceinline__ Elem decode_elem(int slot, int count, int region, int
 
 template <typename T>
 __device__ __forceinline__ T load_q(const EulerParams<T>& P, size_t i) {
+    return P.q[i];
+}
+// float64 plans: the state may be a shifted one, q + eps * v formed on load (finite-difference Jacobian
+// products: no pass that materialises Q + eps v)
+template <>
+__device__ __forceinline__ double load_q<double>(const EulerParams<double>& P, size_t i) {
+    if (P.q_tan != nullptr) return P.q[i] + P.jvp_eps * P.q_tan[i];
     return P.q[i];
 }
 template <>
@@ -580,7 +590,9 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
     // ---- forcing, all but the gravity filter (pde_euler_cubesphere.py:12-25, 203-290)
     T fc0 = T(0.0), fc1 = T(0.0), fc2 = T(0.0);
     double gcoef = 0.0;
-#if WX_K2_GAMMA_ROLLED
+#if WX_K2_GAMMA_PER_DIR
+    // (row d of the Christoffel fields is fetched at the top of directional pass d and consumed after it)
+#elif WX_K2_GAMMA_ROLLED
     if (active) {
 #pragma unroll 1
         for (int i = 0; i < 3; ++i) {
@@ -654,6 +666,21 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
         const double hd1 = d == 0 ? h01 : (d == 1 ? h11 : h12);
         const double hd2 = d == 0 ? h02 : (d == 1 ? h12 : h22);
 #endif
+#if WX_K2_GAMMA_PER_DIR
+        // forcing row d: its 9 Christoffel loads fly while this pass works through LDS
+        double cr[9], idzv = 0.0;
+        if (active && P.rot_zero) {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) cr[j] = j < 3 ? 0.0 : WX_LDM(P.chr + (size_t)(d * 9 + j) * fs + o);
+        } else if (active) {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) cr[j] = WX_LDM(P.chr + (size_t)(d * 9 + j) * fs + o);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) cr[j] = 0.0;
+        }
+        if (d == 2 && active) idzv = WX_LDM(P.idz + o);
+#endif
         const T sgu = sg * ud;
         const T Bd = T(sg * hd2);
         if (d > 0 || WX_K2_OWN_FACES) __syncthreads();  // previous direction's (or the face stage's) reads are done
@@ -705,6 +732,18 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
 #pragma unroll
             for (int m = 0; m < N; ++m) hf += sHF[idx * N + m] * fld[7][base + m * stride];
         }
+#if WX_K2_GAMMA_PER_DIR
+        {
+            T f = 2.0 * q0 * (cr[0] * u1 + cr[1] * u2 + cr[2] * u3) + cr[3] * (q0 * u1 * u1 + h00 * p) +
+                  2.0 * cr[4] * (q0 * u1 * u2 + h01 * p) + 2.0 * cr[5] * (q0 * u1 * u3 + h02 * p) +
+                  cr[6] * (q0 * u2 * u2 + h11 * p) + 2.0 * cr[7] * (q0 * u2 * u3 + h12 * p) +
+                  cr[8] * (q0 * u3 * u3 + h22 * p);
+            if (P.has_damp && active) f += (P.dcoef[o] * q0) * (ud - P.duref[(size_t)d * fs + o]);
+            if (d == 0) acc1 += sg * f;
+            else if (d == 1) acc2 += sg * f;
+            else { accw += sg * f; gcoef = idzv * kGravity; }
+        }
+#endif
         WX_STAMP(3 + d);
     }
 
@@ -1103,6 +1142,44 @@ wx_status wx_euler3d_rhs_axpy2(wx_euler3d_plan* pl, const void* q, const void* c
                                const void* z, void* out, double a, double b, double c, double d, wx_region region,
                                wx_stream stream) {
     return euler3d_rhs_impl(pl, q, halo, out, region, stream, 1, y, a, b, c, z, d);
+}
+
+// Finite-difference Jacobian products: the same two kernels on the shifted state q + eps v, formed on load.
+wx_status wx_euler3d_shifted_extrap_pack(wx_euler3d_plan* pl, const double* q, const double* v, double eps,
+                                         void* const send[4], wx_stream stream) {
+    if (!pl || !q || !v) return fail(WX_ERR_INVALID, "wx_euler3d_shifted_extrap_pack: null argument");
+    if (pl->dtype != WX_F64) return fail(WX_ERR_INVALID, "wx_euler3d_shifted_*: the plan must be WX_F64");
+    EulerParams<double> P = make_params<double>(pl);
+    P.q = q; P.q_tan = v; P.jvp_eps = eps;
+    if (send) {
+        P.send_s = static_cast<double*>(send[0]); P.send_n = static_cast<double*>(send[1]);
+        P.send_w = static_cast<double*>(send[2]); P.send_e = static_cast<double*>(send[3]);
+    }
+    return dispatch_extrap<double>(pl->n, P, static_cast<hipStream_t>(stream));
+}
+
+wx_status wx_euler3d_shifted_rhs_axpy2(wx_euler3d_plan* pl, const double* q, const double* v, double eps,
+                                       const void* const halo[4], const double* y, const double* z, double* out, double a,
+                                       double b, double c, double d, wx_region region, wx_stream stream) {
+    if (!pl || !q || !v || !out) return fail(WX_ERR_INVALID, "wx_euler3d_shifted_rhs_axpy2: null argument");
+    if (pl->dtype != WX_F64) return fail(WX_ERR_INVALID, "wx_euler3d_shifted_*: the plan must be WX_F64");
+    if (out == q || out == v) return fail(WX_ERR_INVALID, "wx_euler3d_shifted_rhs_axpy2: output must not alias q or v");
+    if (region != WX_REGION_ALL && region != WX_REGION_INTERIOR && region != WX_REGION_BOUNDARY)
+        return fail(WX_ERR_INVALID, "unknown region %d", (int)region);
+    if (region != WX_REGION_INTERIOR) {
+        if (!halo) return fail(WX_ERR_INVALID, "wx_euler3d_shifted_rhs_axpy2: halo is required for this region");
+        for (int e = 0; e < 4; ++e)
+            if (!halo[e]) return fail(WX_ERR_INVALID, "wx_euler3d_shifted_rhs_axpy2: halo[%d] is null", e);
+    }
+    EulerParams<double> P = make_params<double>(pl);
+    P.q = q; P.q_tan = v; P.jvp_eps = eps; P.rhs = out;
+    P.region = region; P.count = region_count(region, pl->H, pl->V);
+    P.axpy = 1; P.ca = a; P.cb = b; P.cc = c; P.cd = d; P.y = y; P.z = z;
+    if (halo) {
+        P.halo_s = static_cast<const double*>(halo[0]); P.halo_n = static_cast<const double*>(halo[1]);
+        P.halo_w = static_cast<const double*>(halo[2]); P.halo_e = static_cast<const double*>(halo[3]);
+    }
+    return dispatch_rhs<double>(pl->n, P, static_cast<hipStream_t>(stream));
 }
 
 static wx_status ensure_slot1(wx_euler3d_plan* pl) {

@@ -16,6 +16,11 @@ EPS_COMPLEX = math.sqrt(torch.finfo(torch.float64).eps)
 EPS_FD = math.sqrt(torch.finfo(torch.float32).eps)
 
 
+def _can_shift(rhs_handle, Q) -> bool:
+    return bool(getattr(rhs_handle, "supports_shift", False) and getattr(rhs_handle, "fused_shift", True)
+                and isinstance(Q, torch.Tensor) and Q.dtype == torch.float64 and Q.is_contiguous() and rhs_handle.panels)
+
+
 def matvec_fun(vec: torch.Tensor, dt: float, Q: torch.Tensor, rhs: torch.Tensor, rhs_handle: Callable,
                method: str = "complex") -> torch.Tensor:
     if method == "complex" and getattr(rhs_handle, "supports_jvp", False) and getattr(rhs_handle, "fused_jvp", True) \
@@ -25,6 +30,10 @@ def matvec_fun(vec: torch.Tensor, dt: float, Q: torch.Tensor, rhs: torch.Tensor,
     if method == "complex":
         Qvec = torch.complex(Q, EPS_COMPLEX * vec.reshape(Q.shape))
         jac = dt * (rhs_handle(Qvec).imag / EPS_COMPLEX)
+    elif _can_shift(rhs_handle, Q):
+        # Q + eps v formed on load, dt/eps * (R(Q + eps v) - R(Q)) formed in the store: two launches per panel
+        jac = rhs_handle.shifted_axpy(Q, vec.reshape(Q.shape).contiguous(), EPS_FD, rhs.reshape(Q.shape).contiguous(),
+                                      -dt / EPS_FD, 0.0, dt / EPS_FD)
     elif getattr(rhs_handle, "supports_axpy2", False) and isinstance(Q, torch.Tensor) and Q.dtype == torch.float64:
         # fused store: dt/eps * R(Q + eps v) - dt/eps * R(Q) in the RHS launch itself
         Qvec = torch.add(Q, vec.reshape(Q.shape), alpha=EPS_FD)
@@ -36,6 +45,10 @@ def matvec_fun(vec: torch.Tensor, dt: float, Q: torch.Tensor, rhs: torch.Tensor,
 
 
 def matvec_rat(vec: torch.Tensor, dt: float, Q: torch.Tensor, rhs: torch.Tensor, rhs_handle: Callable) -> torch.Tensor:
+    if _can_shift(rhs_handle, Q):
+        v = vec.reshape(Q.shape).contiguous()
+        c = 0.5 * dt / EPS_FD
+        return rhs_handle.shifted_axpy(Q, v, EPS_FD, rhs.reshape(Q.shape).contiguous(), c, 0.0, -c, v, 1.0).flatten()
     if getattr(rhs_handle, "supports_axpy2", False) and isinstance(Q, torch.Tensor) and Q.dtype == torch.float64:
         # v - dt/(2 eps) (R(Q + eps v) - R(Q)) formed in the RHS kernel's store
         v = vec.reshape(Q.shape)

@@ -124,6 +124,26 @@ class Euler3DPlan:
                                             z.data_ptr() if z is not None else None, out.data_ptr(), a, b, c, d, region,
                                             st), "wx_euler3d_rhs_axpy2")
 
+    def shifted_extrap_pack(self, q, v, eps: float, send):
+        """Phase 1-2 on the state q + eps*v formed on load (float64 plans)."""
+        self._check_real(q)
+        self._check_real(v)
+        self.faces_epoch += 1
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.wx_euler3d_shifted_extrap_pack(self._h, q.data_ptr(), v.data_ptr(), eps, _ptr_array(send), st),
+              "wx_euler3d_shifted_extrap_pack")
+
+    def shifted_rhs_axpy(self, q, v, eps: float, halo, y, out, a, b, c, region=_lib.WX_REGION_ALL, z=None, d: float = 0.0):
+        """out = a*y + b*(q + eps v) + c*R(q + eps v) + d*z, the shifted state never materialised."""
+        for t in (q, v, out, y, z):
+            if t is not None:
+                self._check_real(t)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.wx_euler3d_shifted_rhs_axpy2(self._h, q.data_ptr(), v.data_ptr(), eps, _ptr_array(halo),
+                                                    y.data_ptr() if y is not None else None,
+                                                    z.data_ptr() if z is not None else None, out.data_ptr(), a, b, c, d,
+                                                    region, st), "wx_euler3d_shifted_rhs_axpy2")
+
     def extrap_pack_slot(self, q, send, slot: int):
         self._check_q(q)
         self.faces_epoch += 1
@@ -237,6 +257,41 @@ class RhsEuler3D(PanelRhs):
         st["slot"] = 1 - cur
         st["ready"] = (weakref.ref(res), res.data_ptr(), res._version, res.numel(), epochs())
         return res
+
+    supports_shift = True
+
+    def shifted_axpy(self, Q: torch.Tensor, v: torch.Tensor, eps: float, Y, a: float, b: float, c: float, Z=None,
+                     d: float = 0.0) -> torch.Tensor:
+        """a*Y + b*(Q + eps v) + c*R(Q + eps v) + d*Z for stacked real states; Q + eps v is formed inside the
+        kernels (the finite-difference Jacobian products of solvers/matvec.py:62-66, 76-88 in two launches per
+        panel and no pass over the state besides them)."""
+        np_ = len(self.panels)
+        shp = (np_,) + tuple(self.panel_shape)
+        Qs, vs = Q.reshape(shp), v.reshape(shp)
+        Ys = Y.reshape(shp) if Y is not None else None
+        Zs = Z.reshape(shp) if Z is not None else None
+        plans, ex = self.plans_for(torch.float64), self.exchange_for(torch.float64)
+        out = torch.empty_like(Qs)
+        for i, p in enumerate(self.panels):
+            plans[p].shifted_extrap_pack(Qs[i], vs[i], eps, ex.send_views(p))
+
+        def launch(i, p, halo, region):
+            plans[p].shifted_rhs_axpy(Qs[i], vs[i], eps, halo, Ys[i] if Ys is not None else None, out[i], a, b, c, region,
+                                      Zs[i] if Zs is not None else None, d)
+
+        if ex.needs_comm and self.overlap:
+            ex.start()
+            for i, p in enumerate(self.panels):
+                launch(i, p, None, _lib.WX_REGION_INTERIOR)
+            ex.wait()
+            for i, p in enumerate(self.panels):
+                launch(i, p, ex.halo_views(p), _lib.WX_REGION_BOUNDARY)
+        else:
+            ex.start()
+            ex.wait()
+            for i, p in enumerate(self.panels):
+                launch(i, p, ex.halo_views(p), _lib.WX_REGION_ALL)
+        return out.reshape(Q.shape)
 
     def jvp(self, Q: torch.Tensor, v: torch.Tensor, eps: float, scale: float) -> torch.Tensor:
         """scale * Im R(Q + i eps v) for stacked real Q, v -> real tensor shaped like Q.  The dual state is
