@@ -64,16 +64,17 @@ def cpu_baseline(n, V, sample_H, reps, seed):
 
 
 def pmc_traffic(region, n, H, V, bpp=ALGO_BYTES_PER_POINT):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_v5_pmc_summary.json: separate FETCH_SIZE / WRITE_SIZE runs of tools/kbench.py on one E7 panel,
-    gfx950 corrections applied by tools/pmc_summary.py).  Counters cannot be read from inside this
-    process, so the number is only reported for the configuration it was measured on."""
-    path = os.path.join(ROOT, "profiles", "r01_v5_pmc_summary.json")
-    if not (os.path.exists(path) and region == 0 and (n, H, V) == (8, 60, 8) and bpp == ALGO_BYTES_PER_POINT):
-        return None  # (the PMC passes were taken on the full 27-Christoffel-field configuration)
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
+    WRITE_SIZE runs of tools/kbench.py on one E7 panel, gfx950 corrections applied by tools/pmc_summary.py):
+    profiles/r01_v5_pmc_summary.json for the 27-Christoffel-field configuration (384 B/point),
+    profiles/r01_v6_pmc_rotzero_summary.json for a non-rotating planet (312 B/point).  Counters cannot be read
+    from inside this process, so the number is only reported for the configurations it was measured on."""
+    name = {384.0: "r01_v5_pmc_summary.json", 312.0: "r01_v6_pmc_rotzero_summary.json"}.get(float(bpp))
+    if name is None or region != 0 or (n, H, V) != (8, 60, 8):
+        return None
     try:
-        return json.load(open(path))["kernels"]["wx::euler_rhs_kernel<8, double, false>"]["hbm_bytes"]
-    except (KeyError, ValueError):
+        return json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]["wx::euler_rhs_kernel<8, double, false>"]["hbm_bytes"]
+    except (OSError, KeyError, ValueError):
         return None
 
 

@@ -159,3 +159,21 @@ def test_fused_jvp_equals_unfused_complex_step(setup):
     ref = stack("jvp_complex").cpu().numpy()
     assert (_rel(a, ref) < 1e-9).all() and (_rel(b, ref) < 1e-9).all()
     assert (_rel(a, b.cpu().numpy().reshape(ref.shape)) < 1e-12).all()
+
+
+def test_shift_on_load_equals_materialised_shift(setup):
+    """matvec_fun("fd") / matvec_rat with Q + eps v formed inside the kernels (wx_euler3d_shifted_*) against the
+    same operators with Q + eps v formed by a torch pass first: the same arithmetic, bit for bit."""
+    from wxfactory_amd.matvec import matvec_fun, matvec_rat
+
+    g, rhs, stack = setup
+    Q, V, R = stack("Q"), stack("V"), stack("R")
+    dt = float(g["meta/dt_jvp"])
+    assert rhs.supports_shift
+    a, b = matvec_fun(V.flatten(), dt, Q, R, rhs, "fd"), matvec_rat(V.flatten(), dt, Q, R, rhs)
+    rhs.fused_shift = False
+    try:
+        a2, b2 = matvec_fun(V.flatten(), dt, Q, R, rhs, "fd"), matvec_rat(V.flatten(), dt, Q, R, rhs)
+    finally:
+        rhs.fused_shift = True
+    assert torch.equal(a, a2) and torch.equal(b, b2)
