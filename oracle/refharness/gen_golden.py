@@ -679,6 +679,69 @@ def filters_case(name, ini, overrides, perturb=0.02, seed=31337):
     _run6(name, work)
 
 
+# ---------------------------------------------------------------------------------------------
+# The body of Simulation.step repeated (simulation.py:147-155): integrator step, apply_filters, NaN check
+# ---------------------------------------------------------------------------------------------
+def steploop_case(name, ini, overrides, nsteps=5, dt=None, perturb=0.01, seed=2718):
+    print(f"[{name}] {ini}", flush=True)
+
+    def work(rank):
+        from device import CpuDevice
+        from process_topology import ProcessTopology
+        from geometry import CubedSphere3D, DFROperators
+        from init.init_state_vars import init_state_vars
+        from rhs.rhs_selector import RhsBundle
+        from integrators import Tvdrk3
+
+        cfg = _config(ini, overrides)
+        step = float(dt if dt is not None else cfg.dt)
+        comm = MPI.COMM_WORLD
+        dev = CpuDevice(comm)
+        pt = ProcessTopology(dev, comm=comm)
+        geom = CubedSphere3D(cfg.num_elements_horizontal, cfg.num_elements_vertical, cfg.num_solpts,
+                             cfg.lambda0, cfg.phi0, cfg.alpha0, cfg.ztop, pt, cfg, dev)
+        ops = DFROperators(geom, cfg, dev)
+        Q, topo, metric = init_state_vars(geom, ops, cfg)
+        rhs = RhsBundle(geom, ops, metric, topo, pt, cfg, Q.shape, False)
+        rng = numpy.random.default_rng(seed + rank)
+        Q = Q * (1.0 + perturb * rng.uniform(-1.0, 1.0, Q.shape))
+        out = {"Q": Q.copy()}
+        stepper = Tvdrk3(cfg, rhs.full, device=dev)
+        assert ops.expfilter_apply
+        for i in range(nsteps):
+            Q = stepper.step(Q, step)
+            Q = ops.apply_filters(Q, geom, metric, step)
+            assert not numpy.any(numpy.isnan(Q))
+            if i == 0:
+                out["Q1"] = Q.copy()
+        out["Qn"] = Q.copy()
+        if rank == 0:
+            out["ops/expfilter"] = numpy.array(ops.expfilter, copy=True)
+            out["meta/case_number"] = numpy.int64(cfg.case_number)
+            out["meta/n"] = numpy.int64(cfg.num_solpts)
+            out["meta/H"] = numpy.int64(cfg.num_elements_horizontal)
+            out["meta/V"] = numpy.int64(cfg.num_elements_vertical)
+            out["meta/ztop"] = numpy.float64(cfg.ztop)
+            out["meta/dt"] = numpy.float64(step)
+            out["meta/nsteps"] = numpy.int64(nsteps)
+        return out
+
+    t0 = time.time()
+    MPI.reset_world(6)
+    res, err = MPI.run_ranks(work, 6)
+    for e in err:
+        if e:
+            print(e)
+            raise SystemExit(1)
+    flat = {}
+    for p, d in enumerate(res):
+        for k, v in d.items():
+            flat[k if k.startswith(("meta/", "ops/")) else f"p{p}/{k}"] = v
+    path = os.path.join(GOLDEN, name + ".npz")
+    numpy.savez_compressed(path, **flat)
+    print(f"   -> {path}  {os.path.getsize(path)/1e6:.2f} MB  ({time.time()-t0:.1f}s)", flush=True)
+
+
 CASES = {
     # balanced gravity-wave state, small n: all panels carry metrics + phases (exchange coverage)
     "euler3d_c31_n3_h4_v2": lambda nm: euler_case(
@@ -708,6 +771,9 @@ CASES = {
     "callers_euler3d_n3_h3_v2": lambda nm: callers_case(
         nm, "dcmip31.ini", dict(num_solpts=3, num_elements_horizontal=3, num_elements_vertical=2)),
     "state_file_v": state_file_case,
+    # five SSP-RK3 steps + exponential filter of the Schaer-mountain case (topography, sponge): the time loop
+    "steploop_c21_n4_h2_v3": lambda nm: steploop_case(
+        nm, "dcmip21_rk3.ini", dict(num_solpts=4, num_elements_horizontal=2, num_elements_vertical=3), nsteps=5, dt=0.05),
     # static metric only: Schaer mountain on a rotated grid over 24 tiles (every kind of tile edge carries
     # a slope); deep atmosphere on a rotating Earth-size planet (rotation Christoffel symbols)
     "metric3d_c21_rot_tiles24_n3_h2_v3": lambda nm: metric_case(

@@ -168,3 +168,44 @@ def test_gpu_step_loop_filters_and_flags(built_lib):
     loop.step(bad, dt)  # step 3: flag raised on the device, not fetched yet
     with pytest.raises(ValueError, match="NaN"):
         loop.step(Q0, dt)  # step 4: fetched
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_gpu_time_loop_matches_reference_run(built_lib, pipeline):
+    """Five steps of the reference's own loop (Tvdrk3.step + apply_filters, simulation.py:147-155) on the Schaer
+    mountain case, reproduced with nothing reference-supplied but the initial state: geometry3d metric + sponge,
+    pipelined SSP-RK3 stages, the filter kernel with its NaN flag."""
+    import torch
+
+    from wxfactory_amd.filters import ExpFilter3D, NanFlag, make_filter
+    from wxfactory_amd.geometry3d import CubedSphere3DTile, metric3d_torch, planet_for_case, topography_for_case
+    from wxfactory_amd.integrators import StepLoop, Tvdrk3
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D
+    from wxfactory_amd.synthetic import dfr_ops
+
+    dev = "cuda:0"
+    g = _load("steploop_c21_n4_h2_v3")
+    n, H, V, case = (int(g[f"meta/{k}"]) for k in ("n", "H", "V", "case_number"))
+    topo = topography_for_case(case, planet_for_case(case)[0])
+    metrics, plans = {}, {}
+    for p in range(6):
+        t = CubedSphere3DTile(n, H, V, p, float(g["meta/ztop"]), case, topo=topo)
+        metrics[p] = metric3d_torch(t, dev)
+        plans[p] = Euler3DPlan(n, H, V, case, p, dfr_ops(n), metrics[p])
+    F = make_filter(1e-3, 4, 0.5, np.polynomial.legendre.leggauss(n)[0])
+    assert np.abs(F - g["ops/expfilter"]).max() < 1e-14
+    flag = NanFlag(dev)
+    loop = StepLoop(Tvdrk3(RhsEuler3D(plans), pipeline=pipeline), ExpFilter3D(F, [metrics[p]["sqrtG"] for p in range(6)]),
+                    flag, check_every=5)
+    stack = lambda key: np.stack([g[f"p{p}/{key}"] for p in range(6)])  # noqa: E731
+    Q0 = torch.from_numpy(stack("Q")).to(dev)
+    dt, nsteps = float(g["meta/dt"]), int(g["meta/nsteps"])
+    Q1 = loop.step(Q0, dt)
+    Qn = loop.run(Q1, dt, nsteps - 1)
+    ax = (0, 2, 3, 4, 5)
+    for got, key in ((Q1, "Q1"), (Qn, "Qn")):
+        ref = stack(key)
+        moved = np.abs(ref - stack("Q")).max(axis=ax)
+        err = np.abs(got.cpu().numpy() - ref).max(axis=ax)
+        assert (err <= 1e-9 * moved + 1e-13 * np.abs(ref).max(axis=ax)).all(), (key, err, moved)

@@ -48,7 +48,7 @@ def matvec_rat(vec: torch.Tensor, dt: float, Q: torch.Tensor, rhs: torch.Tensor,
     if _can_shift(rhs_handle, Q):
         v = vec.reshape(Q.shape).contiguous()
         c = 0.5 * dt / EPS_FD
-        return rhs_handle.shifted_axpy(Q, v, EPS_FD, rhs.reshape(Q.shape).contiguous(), c, 0.0, -c, v, 1.0).flatten()
+        return rhs_handle.shifted_axpy(Q, v, EPS_FD, v, 1.0, 0.0, -c, rhs.reshape(Q.shape).contiguous(), c).flatten()
     if getattr(rhs_handle, "supports_axpy2", False) and isinstance(Q, torch.Tensor) and Q.dtype == torch.float64:
         # v - dt/(2 eps) (R(Q + eps v) - R(Q)) formed in the RHS kernel's store
         v = vec.reshape(Q.shape)
