@@ -105,6 +105,24 @@ class PanelRhs:
                 raise ValueError(f"state of {qs.numel()} values does not match {np_} panel(s) of {self.panel_shape}")
         return kind, (shape if kind != "dict" else None), qs
 
+    def _exchange_and_launch(self, ex: PanelExchange, launch):
+        """The phase order of rhs/rhs.py:88-118 once the edge messages are packed: start the exchange, evaluate
+        the elements that need no halo (INTERIOR) while it is in flight, then the ring (BOUNDARY); when nothing
+        travels (all neighbours on this rank: the halos alias the packed buffers) one launch covers ALL.
+        `launch(i, tile, halo_or_None, region)` enqueues one tile's kernel."""
+        if ex.needs_comm and self.overlap:
+            ex.start()
+            for i, p in enumerate(self.panels):
+                launch(i, p, None, _lib.WX_REGION_INTERIOR)
+            ex.wait()
+            for i, p in enumerate(self.panels):
+                launch(i, p, ex.halo_views(p), _lib.WX_REGION_BOUNDARY)
+        else:
+            ex.start()
+            ex.wait()
+            for i, p in enumerate(self.panels):
+                launch(i, p, ex.halo_views(p), _lib.WX_REGION_ALL)
+
     def _run(self, qs, ys, coef, dtype, zs=None):
         np_ = len(self.panels)
         kind, shape, qs = self._structure(qs)
@@ -140,18 +158,7 @@ class PanelRhs:
             outs = {p: torch.empty_like(flat[p]) for p in self.panels}
         for p in self.panels:
             plans[p].extrap_pack(flat[p], ex.send_views(p))
-        if ex.needs_comm and self.overlap:
-            ex.start()
-            for p in self.panels:
-                launch(p, None, _lib.WX_REGION_INTERIOR)
-            ex.wait()
-            for p in self.panels:
-                launch(p, ex.halo_views(p), _lib.WX_REGION_BOUNDARY)
-        else:
-            ex.start()
-            ex.wait()
-            for p in self.panels:
-                launch(p, ex.halo_views(p), _lib.WX_REGION_ALL)
+        self._exchange_and_launch(ex, lambda i, p, halo, region: launch(p, halo, region))
         if kind == "stacked":
             return out_all.reshape(shape)
         if kind == "single":

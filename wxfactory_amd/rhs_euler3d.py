@@ -241,18 +241,7 @@ class RhsEuler3D(PanelRhs):
             plans[p].stage(Qs[i], halo, Ys[i] if Ys is not None else None, None, out[i], a, b, c, 0.0, region, cur,
                            exn.send_views(p), True)
 
-        if ex.needs_comm and self.overlap:
-            ex.start()
-            for i, p in enumerate(self.panels):
-                launch(i, p, None, _lib.WX_REGION_INTERIOR)
-            ex.wait()
-            for i, p in enumerate(self.panels):
-                launch(i, p, ex.halo_views(p), _lib.WX_REGION_BOUNDARY)
-        else:
-            ex.start()
-            ex.wait()
-            for i, p in enumerate(self.panels):
-                launch(i, p, ex.halo_views(p), _lib.WX_REGION_ALL)
+        self._exchange_and_launch(ex, launch)
         res = out.reshape(Q.shape)
         st["slot"] = 1 - cur
         st["ready"] = (weakref.ref(res), res.data_ptr(), res._version, res.numel(), epochs())
@@ -279,18 +268,7 @@ class RhsEuler3D(PanelRhs):
             plans[p].shifted_rhs_axpy(Qs[i], vs[i], eps, halo, Ys[i] if Ys is not None else None, out[i], a, b, c, region,
                                       Zs[i] if Zs is not None else None, d)
 
-        if ex.needs_comm and self.overlap:
-            ex.start()
-            for i, p in enumerate(self.panels):
-                launch(i, p, None, _lib.WX_REGION_INTERIOR)
-            ex.wait()
-            for i, p in enumerate(self.panels):
-                launch(i, p, ex.halo_views(p), _lib.WX_REGION_BOUNDARY)
-        else:
-            ex.start()
-            ex.wait()
-            for i, p in enumerate(self.panels):
-                launch(i, p, ex.halo_views(p), _lib.WX_REGION_ALL)
+        self._exchange_and_launch(ex, launch)
         return out.reshape(Q.shape)
 
     def jvp(self, Q: torch.Tensor, v: torch.Tensor, eps: float, scale: float) -> torch.Tensor:
@@ -308,16 +286,5 @@ class RhsEuler3D(PanelRhs):
         out = torch.empty_like(Qs)
         for i, p in enumerate(self.panels):
             plans[p].jvp_extrap_pack(Qs[i], vs[i], eps, ex.send_views(p))
-        if ex.needs_comm and self.overlap:
-            ex.start()
-            for i, p in enumerate(self.panels):
-                plans[p].jvp(Qs[i], vs[i], eps, None, out[i], scale, _lib.WX_REGION_INTERIOR)
-            ex.wait()
-            for i, p in enumerate(self.panels):
-                plans[p].jvp(Qs[i], vs[i], eps, ex.halo_views(p), out[i], scale, _lib.WX_REGION_BOUNDARY)
-        else:
-            ex.start()
-            ex.wait()
-            for i, p in enumerate(self.panels):
-                plans[p].jvp(Qs[i], vs[i], eps, ex.halo_views(p), out[i], scale, _lib.WX_REGION_ALL)
+        self._exchange_and_launch(ex, lambda i, p, halo, region: plans[p].jvp(Qs[i], vs[i], eps, halo, out[i], scale, region))
         return out.reshape(Q.shape)
