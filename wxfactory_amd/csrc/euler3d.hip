@@ -83,6 +83,12 @@ enum { F_W = 0, F_E = 1, F_S = 2, F_N = 3, F_B = 4, F_T = 5 };
 // variables, exactly the reference's q_itf (default: measured fastest - the kernel is HBM-bound and
 // the two extra streams cost more than redoing exp(gamma*log(.)) on both sides of a face);
 // 6 / 7 additionally carry the face pressure / its logarithm (pde_euler_cubesphere.py:158-160).
+#ifndef WX_NO_SHIFT
+#define WX_NO_SHIFT 0   // diagnostic: compile the shift-on-load branch out of the float64 kernels
+#endif
+#ifndef WX_K1_WAVES
+#define WX_K1_WAVES 1   // minimum waves per SIMD requested for the extrapolation kernel (register cap = 512 / waves)
+#endif
 #ifndef WX_K2_GAMMA_PER_DIR
 #define WX_K2_GAMMA_PER_DIR 0  // 1: forcing row d fetched across directional pass d (needs WX_K2_UNROLL_DIRS)
 #endif
@@ -207,7 +213,9 @@ __device__ __forceinline__ T load_q(const EulerParams<T>& P, size_t i) {
 // products: no pass that materialises Q + eps v)
 template <>
 __device__ __forceinline__ double load_q<double>(const EulerParams<double>& P, size_t i) {
-    if (P.q_tan != nullptr) return P.q[i] + P.jvp_eps * P.q_tan[i];
+#if !WX_NO_SHIFT
+    if (P.q_tan != nullptr) return P.q[i] + P.jvp_eps * P.q_tan[i];  // (same expression as load_state<double>)
+#endif
     return P.q[i];
 }
 template <>
@@ -215,6 +223,40 @@ __device__ __forceinline__ dual load_q<dual>(const EulerParams<dual>& P, size_t 
     if (P.jvp) return dual(P.q_re[i], P.jvp_eps * P.q_tan[i]);
     return P.q[i];
 }
+// the five prognostic values of one point, the mode decided ONCE (a branch per load costs the extrapolation
+// kernel 12 %: the compiler no longer issues the five loads back to back)
+template <typename T>
+__device__ __forceinline__ void load_state(const EulerParams<T>& P, size_t o, size_t fs, T& a0, T& a1, T& a2, T& a3, T& a4) {
+    a0 = load_q<T>(P, o); a1 = load_q<T>(P, fs + o); a2 = load_q<T>(P, 2 * fs + o);
+    a3 = load_q<T>(P, 3 * fs + o); a4 = load_q<T>(P, 4 * fs + o);
+}
+template <>
+__device__ __forceinline__ void load_state<double>(const EulerParams<double>& P, size_t o, size_t fs, double& a0, double& a1,
+                                                   double& a2, double& a3, double& a4) {
+    const double* q = P.q;
+    a0 = q[o]; a1 = q[fs + o]; a2 = q[2 * fs + o]; a3 = q[3 * fs + o]; a4 = q[4 * fs + o];
+#if !WX_NO_SHIFT
+    if (P.q_tan != nullptr) {
+        const double* v = P.q_tan;
+        const double e = P.jvp_eps;
+        a0 += e * v[o]; a1 += e * v[fs + o]; a2 += e * v[2 * fs + o]; a3 += e * v[3 * fs + o]; a4 += e * v[4 * fs + o];
+    }
+#endif
+}
+template <>
+__device__ __forceinline__ void load_state<dual>(const EulerParams<dual>& P, size_t o, size_t fs, dual& a0, dual& a1, dual& a2,
+                                                 dual& a3, dual& a4) {
+    if (P.jvp) {
+        const double *r = P.q_re, *t = P.q_tan;
+        const double e = P.jvp_eps;
+        a0 = dual(r[o], e * t[o]); a1 = dual(r[fs + o], e * t[fs + o]); a2 = dual(r[2 * fs + o], e * t[2 * fs + o]);
+        a3 = dual(r[3 * fs + o], e * t[3 * fs + o]); a4 = dual(r[4 * fs + o], e * t[4 * fs + o]);
+    } else {
+        const dual* q = P.q;
+        a0 = q[o]; a1 = q[fs + o]; a2 = q[2 * fs + o]; a3 = q[3 * fs + o]; a4 = q[4 * fs + o];
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ void store_r(const EulerParams<T>& P, size_t i, T r) {
     P.rhs[i] = r;
@@ -303,7 +345,7 @@ __device__ __forceinline__ void extrap_faces(const EulerParams<T>& P, T (*fld)[C
 // K1: extrapolation to element faces + tile-edge pack
 // ------------------------------------------------------------------------------------------------
 template <int N, typename T>
-__global__ __launch_bounds__(Cfg<N>::BS) void euler_extrap_kernel(const EulerParams<T> P) {
+__global__ __launch_bounds__(Cfg<N>::BS, WX_K1_WAVES) void euler_extrap_kernel(const EulerParams<T> P) {
     using C = Cfg<N>;
     constexpr int N2 = C::N2, N3 = C::N3, EPB = C::EPB, BS = C::BS;
     __shared__ T fld[5][EPB * C::LE];
@@ -318,11 +360,13 @@ __global__ __launch_bounds__(Cfg<N>::BS) void euler_extrap_kernel(const EulerPar
         if (le < EPB && el.valid) {
             const size_t o = (size_t)el.e * N3 + pt;
             const int lp = le * C::LE + C::lidx(pt / N2, (pt / N) % N, pt % N);
-            fld[0][lp] = w_log(load_q<T>(P, o));
-            fld[1][lp] = load_q<T>(P, fs + o);
-            fld[2][lp] = load_q<T>(P, 2 * fs + o);
-            fld[3][lp] = load_q<T>(P, 3 * fs + o);
-            fld[4][lp] = w_log(load_q<T>(P, 4 * fs + o));
+            T a0, a1, a2, a3, a4;
+            load_state<T>(P, o, fs, a0, a1, a2, a3, a4);
+            fld[0][lp] = w_log(a0);
+            fld[1][lp] = a1;
+            fld[2][lp] = a2;
+            fld[3][lp] = a3;
+            fld[4][lp] = w_log(a4);
         }
     }
     __syncthreads();
@@ -414,8 +458,7 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
     double sg = 1.0, h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0;
 #define WX_Q_LOADS()                                                                                       \
     if (active) {                                                                                          \
-        q0 = load_q<T>(P, o); q1 = load_q<T>(P, fs + o); q2 = load_q<T>(P, 2 * fs + o);                     \
-        q3 = load_q<T>(P, 3 * fs + o); q4 = load_q<T>(P, 4 * fs + o);                                      \
+        load_state<T>(P, o, fs, q0, q1, q2, q3, q4);                                                       \
     }
 #define WX_PMETRIC_LOADS()                                                                                 \
     if (active) {                                                                                          \
