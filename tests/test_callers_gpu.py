@@ -177,3 +177,21 @@ def test_shift_on_load_equals_materialised_shift(setup):
     finally:
         rhs.fused_shift = True
     assert torch.equal(a, a2) and torch.equal(b, b2)
+
+
+def test_lean_jvp_kernel_in_a_subprocess():
+    """The JVP-specialised kernel (tangent-only LDS staging; opt-in, WXHIP_JVP_LEAN=1, read once per process)
+    must pass the same JVP parity tests as the default dual-number kernel."""
+    import os
+    import subprocess
+    import sys
+
+    if os.environ.get("WXHIP_JVP_LEAN") == "1":
+        pytest.skip("already inside the lean-kernel run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WXHIP_JVP_LEAN="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_callers_gpu.py", "-k",
+                        "matvec_fun_and_rat or fused_jvp or kiops"], cwd=root, env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "passed" in r.stdout

@@ -15,9 +15,13 @@ from wxfactory_amd.rhs_euler3d import Euler3DPlan  # noqa: E402
 
 dev = torch.device("cuda", 0)
 n, H, V = 8, 60, 8
-plan = Euler3DPlan(n, H, V, 31, 0, synthetic.dfr_ops(n), synthetic.euler3d_metric(n, H, V, 0, dev))
+DUAL = "--dual" in sys.argv  # phase timeline of the dual-number instantiation (JVP kernels)
+dt = torch.complex128 if DUAL else torch.float64
+plan = Euler3DPlan(n, H, V, 31, 0, synthetic.dfr_ops(n), synthetic.euler3d_metric(n, H, V, 0, dev), dtype=dt, dual=DUAL)
 q = synthetic.euler3d_state(n, H, V, 0, dev)
-send = torch.zeros((4, plan.edge_count), dtype=torch.float64, device=dev)
+if DUAL:
+    q = q + 1e-8j * q
+send = torch.zeros((4, plan.edge_count), dtype=dt, device=dev)
 sp = [send[e].data_ptr() for e in range(4)]
 out = torch.empty_like(q)
 nb = V * H * H

@@ -16,6 +16,7 @@
 #include "wx_math.h"
 #include "wx_panels.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -409,6 +410,113 @@ __device__ __forceinline__ void rusanov_face(const T* qL, const T* qR, T unL, T 
     out[6] = w_sel(own_is_L, qL[6], qR[6]);
 }
 
+// The same common flux written from the point of view of the element that owns the face point (own / neighbour
+// instead of left / right): no left-right copies of the two 7-value states, which is what keeps the dual-number
+// JVP kernel inside 128 registers.  plus = the face is the element's upper one (own state is the left one).
+template <typename T>
+__device__ __forceinline__ void rusanov_own(const T* qo, const T* qn, T uo, T un, T ro, T rn, double sg, double h0, double h1,
+                                            double h2, double hdd, bool plus, bool advection_only, T* out) {
+    const T po = qo[5], pn = qn[5];
+    T eo, en;
+    if (advection_only) {
+        eo = T(w_abs(uo));
+        en = T(w_abs(un));
+    } else {
+        eo = w_abs(uo) + w_sqrt((hdd * kGamma) * po * ro);
+        en = w_abs(un) + w_sqrt((hdd * kGamma) * pn * rn);
+    }
+    const T eig = w_max(w_sel(plus, eo, en), w_sel(plus, en, eo));  // (left, right) order: the tie-break of numpy.maximum
+    const T sguo = sg * uo, sgun = sg * un;
+    const T es = (plus ? sg : -sg) * eig;   // eig sqrtG (q_R - q_L) = +-(q_n - q_o)
+    const double sgh0 = sg * h0, sgh1 = sg * h1, sgh2 = sg * h2;
+    out[0] = 0.5 * (sguo * qo[0] + sgun * qn[0] - es * (qn[0] - qo[0]));
+    out[1] = 0.5 * ((sguo * qo[1] + sgh0 * po) + (sgun * qn[1] + sgh0 * pn) - es * (qn[1] - qo[1]));
+    out[2] = 0.5 * ((sguo * qo[2] + sgh1 * po) + (sgun * qn[2] + sgh1 * pn) - es * (qn[2] - qo[2]));
+    out[3] = 0.5 * (sguo * qo[4] + sgun * qn[4] - es * (qn[4] - qo[4]));
+    out[4] = 0.5 * (sguo * qo[3] + sgun * qn[3] - es * (qn[3] - qo[3]));
+    out[5] = 0.5 * (sgh2 * po + sgh2 * pn) / po;
+    out[6] = qo[6];
+}
+
+// One face point of one element: the two face states (own slot of the interface buffer; the neighbour
+// element's slot, the received halo on a lateral tile edge, or the mirrored state at ground / top), the
+// interface metric, and the Rusanov problem.  out[0..6] as in rusanov_face.  Shared by the fused RHS kernel
+// and the JVP kernel.
+template <int N, typename T, bool OWN_FORM = false>
+__device__ __forceinline__ void face_problem(const EulerParams<T>& P, const Elem& el, int f, int fp, T* out) {
+    constexpr int N2 = N * N;
+    const int H = P.H, V = P.V;
+        const int d = f >> 1, plus = f & 1;
+        const size_t vsh = (size_t)V * H * N2;  // var stride in a halo edge message
+
+        const T* own = P.itf + ((size_t)el.e * 6 + f) * NQ * N2 + fp;
+        const T* nbr;
+        size_t nstride = N2;
+        bool mirror = false;
+        const double *sgp, *hp;
+        size_t hfs;  // field stride of the h_contra_itf array
+        if (d == 0) {
+            const int ne = el.ei + (plus ? 1 : -1);
+            if (ne >= 0 && ne < H) nbr = P.itf + ((size_t)(el.e + (plus ? 1 : -1)) * 6 + (f ^ 1)) * NQ * N2 + fp;
+            else { nbr = (plus ? P.halo_e : P.halo_w) + ((size_t)el.ek * H + el.ej) * N2 + fp; nstride = vsh; }
+            const size_t o = (((size_t)el.ek * H + el.ej) * (H + 2) + el.ei + 1) * 2 * N2 + plus * N2 + fp;
+            hfs = (size_t)V * H * (H + 2) * 2 * N2;
+            sgp = P.sgi + o;
+            hp = P.hi + 0 * 3 * hfs + o;
+        } else if (d == 1) {
+            const int ne = el.ej + (plus ? 1 : -1);
+            if (ne >= 0 && ne < H) nbr = P.itf + ((size_t)(el.e + (plus ? H : -H)) * 6 + (f ^ 1)) * NQ * N2 + fp;
+            else { nbr = (plus ? P.halo_n : P.halo_s) + ((size_t)el.ek * H + el.ei) * N2 + fp; nstride = vsh; }
+            const size_t o = (((size_t)el.ek * (H + 2) + el.ej + 1) * H + el.ei) * 2 * N2 + plus * N2 + fp;
+            hfs = (size_t)V * (H + 2) * H * 2 * N2;
+            sgp = P.sgj + o;
+            hp = P.hj + 1 * 3 * hfs + o;
+        } else {
+            const int ne = el.ek + (plus ? 1 : -1);
+            if (ne >= 0 && ne < V) nbr = P.itf + ((size_t)(el.e + (plus ? H * H : -H * H)) * 6 + (f ^ 1)) * NQ * N2 + fp;
+            else { nbr = own; mirror = true; }
+            const size_t o = ((((size_t)el.ek + 1) * H + el.ej) * H + el.ei) * 2 * N2 + plus * N2 + fp;
+            hfs = (size_t)(V + 2) * H * H * 2 * N2;
+            sgp = P.sgk + o;
+            hp = P.hk + 2 * 3 * hfs + o;
+        }
+        T qo[7], qn[7];
+#pragma unroll
+        for (int v = 0; v < NQ; ++v) {
+            qo[v] = own[v * N2];
+            qn[v] = nbr[v * nstride];
+        }
+        if (NQ == 5) {  // pressures from rho*theta on both sides (pde_euler_cubesphere.py:158-160)
+            const T go = kGamma * w_log(qo[4] * kRdOverP0), gn = kGamma * w_log(qn[4] * kRdOverP0);
+            qo[5] = kP0 * w_exp(go); qn[5] = kP0 * w_exp(gn);
+            qo[6] = kLogP0 + go; qn[6] = kLogP0 + gn;
+        } else if (NQ == 6) {
+            qo[6] = w_log(qo[5]); qn[6] = qo[6];  // only the own side's log p is used
+        }
+        const double sg = *sgp, h0 = hp[0], h1 = hp[hfs], h2 = hp[2 * hfs];
+        const double hdd = d == 0 ? h0 : (d == 1 ? h1 : h2);
+        const T ro = 1.0 / qo[0], rn = 1.0 / qn[0];
+        // (explicit selects: a run-time index into a register array of 16-byte values goes to scratch)
+        T uo = w_sel(d == 0, qo[1], w_sel(d == 1, qo[2], qo[3])) * ro;
+        T un = w_sel(d == 0, qn[1], w_sel(d == 1, qn[2], qn[3])) * rn;
+        if (mirror) un = -uo;  // no-flow wall: odd symmetry of w (pde_euler_cubesphere.py:150-156)
+        if (OWN_FORM) {
+            rusanov_own<T>(qo, qn, uo, un, ro, rn, sg, h0, h1, h2, hdd, plus != 0, P.advection_only, out);
+            return;
+        }
+        // left = plus-side state of the lower element, right = minus-side state of the upper one
+        // (by value with selects: passing swapped array pointers would push both arrays to scratch)
+        T qL[7], qR[7];
+#pragma unroll
+        for (int v = 0; v < 7; ++v) {
+            qL[v] = w_sel(plus != 0, qo[v], qn[v]);
+            qR[v] = w_sel(plus != 0, qn[v], qo[v]);
+        }
+        const bool pl = plus != 0;
+        rusanov_face<T>(qL, qR, w_sel(pl, uo, un), w_sel(pl, un, uo), w_sel(pl, ro, rn), w_sel(pl, rn, ro), sg, h0, h1,
+                        h2, hdd, pl, P.advection_only, out);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2: fused phases 3-8
 // ------------------------------------------------------------------------------------------------
@@ -505,6 +613,10 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
         const int f = r / N2, fp = r % N2;
         const Elem el = decode_elem(block_slot(gridDim.x) * EPB + le, P.count, P.region, H, V);
         if (!el.valid) continue;
+#if !WX_K2_OWN_FACES && !WX_K2_SKELETON
+        T out[NC];
+        face_problem<N, T>(P, el, f, fp, out);
+#else
         const int d = f >> 1, plus = f & 1;
         const size_t vsh = (size_t)V * H * N2;  // var stride in a halo edge message
 
@@ -609,6 +721,7 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
         const bool pl = plus != 0;
         rusanov_face<T>(qL, qR, w_sel(pl, uo, un), w_sel(pl, un, uo), w_sel(pl, ro, rn), w_sel(pl, rn, ro), sg, h0, h1,
                         h2, hdd, pl, P.advection_only, out);
+#endif
 #pragma unroll
         for (int c = 0; c < NC; ++c) fr[le][f][c][fp] = out[c];
     }
@@ -832,6 +945,207 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
 #undef WX_STAMP
 }
 
+// ------------------------------------------------------------------------------------------------
+// K2-JVP: the fused phases 3-8 specialised for the complex-step Jacobian-vector product (wx_euler3d_jvp).
+// Only the TANGENT of R is wanted, and the derivative contractions are linear, so of the eight fields the generic
+// dual-number kernel stages through LDS as (value, tangent) pairs, six need their tangent only (the four flux
+// rows, the advective rho*w flux, sqrtG*rho), one is a pure metric quantity with no tangent (B = sqrtG h^{d3})
+// and one needs both (log p, multiplied by p B afterwards).  The same holds for the face quantities.  LDS per
+// element 118 KB -> 70 KB and half the registers in the accumulators: TWO workgroups per CU instead of one,
+// and 40 % fewer LDS bytes and contraction flops.  Arithmetic is the generic kernel's, term by term.
+// ------------------------------------------------------------------------------------------------
+// STATUS (round 1): correct (the JVP parity tests pass on it) but not the default.  Unconstrained, hipcc wants 184
+// VGPRs for it; capped at 128 (2 workgroups/CU) it spills 172 B/lane and runs 19.3 ms per E7-sphere JVP against
+// 12.9 ms for the generic kernel at 1 workgroup/CU; uncapped (1 workgroup/CU) it ties the generic kernel (13.3 ms):
+// the saving in LDS traffic alone buys nothing, the occupancy would.  Selected at run time by WXHIP_JVP_LEAN=1.
+#ifndef WX_JVP_WAVES
+#define WX_JVP_WAVES 2
+#endif
+#ifndef WX_JVP_FIELD_BATCH
+#define WX_JVP_FIELD_BATCH 3
+#endif
+#ifndef WX_JVP_EARLY_LOADS
+#define WX_JVP_EARLY_LOADS 0
+#endif
+#ifndef WX_JVP_GAMMA_ROLLED
+#define WX_JVP_GAMMA_ROLLED 1
+#endif
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::BS, WX_JVP_WAVES) void euler_jvp_kernel(const EulerParams<dual> P) {
+    using C = Cfg<N>;
+    using T = dual;
+    constexpr int N2 = C::N2, N3 = C::N3, EPB = C::EPB, BS = C::BS;
+    __shared__ double ft[6][EPB * C::LE];     // tangents: F rows rho, rho u1, rho u2, rho theta; A; sqrtG*rho
+    __shared__ double fB[EPB * C::LE];        // B = sqrtG h^{d3} (metric only)
+    __shared__ T fL[EPB * C::LE];             // log p
+    __shared__ double frt[EPB][6][5][N2];     // tangents of the face quantities 0..4 of rusanov_face
+    __shared__ T frf[EPB][6][2][N2];          // B*_own, log p_own
+    __shared__ double sD[N * N], sHF[N * N], sCm[N], sCp[N];
+
+    const int tid = threadIdx.x;
+    const int H = P.H, V = P.V;
+    const size_t fs = (size_t)P.nelem * N3;
+    for (int i = tid; i < N * N; i += BS) {
+        sD[i] = P.K->D[i];
+        sHF[i] = P.K->HF[i];
+    }
+    if (tid < N) {
+        sCm[tid] = P.K->cm[tid];
+        sCp[tid] = P.K->cp[tid];
+    }
+
+    const int le = tid / N3, pt = tid % N3;
+    const Elem el = decode_elem(block_slot(gridDim.x) * EPB + le, P.count, P.region, H, V);
+    const bool active = (le < EPB) && el.valid;
+    const int kl = pt / N2, jl = (pt / N) % N, il = pt % N;
+    const int lb = (le < EPB ? le : 0) * C::LE;
+    const int lpt = lb + C::lidx(kl, jl, il);
+    const size_t o = (size_t)el.e * N3 + pt;
+
+    // point loads first: in flight while the face stage computes
+    T q0 = T(1.0), q1 = T(0.0), q2 = T(0.0), q3 = T(0.0), q4 = T(1.0);
+    double sg = 1.0, h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0;
+#define WX_JVP_POINT_LOADS()                                                                               \
+    if (active) {                                                                                          \
+        load_state<T>(P, o, fs, q0, q1, q2, q3, q4);                                                       \
+        sg = WX_LDM(P.sg + o);                                                                             \
+        h00 = WX_LDM(P.h + 0 * fs + o); h01 = WX_LDM(P.h + 1 * fs + o); h02 = WX_LDM(P.h + 2 * fs + o);    \
+        h11 = WX_LDM(P.h + 4 * fs + o); h12 = WX_LDM(P.h + 5 * fs + o); h22 = WX_LDM(P.h + 8 * fs + o);    \
+    }
+#if WX_JVP_EARLY_LOADS
+    WX_JVP_POINT_LOADS()
+#endif
+
+    // ---- face stage
+    for (int fi = tid; fi < EPB * 6 * N2; fi += BS) {
+        const int fle = fi / (6 * N2);
+        const int r = fi % (6 * N2);
+        const int f = r / N2, fp = r % N2;
+        const Elem fel = decode_elem(block_slot(gridDim.x) * EPB + fle, P.count, P.region, H, V);
+        if (!fel.valid) continue;
+        T out[7];
+        face_problem<N, T, true>(P, fel, f, fp, out);
+#pragma unroll
+        for (int c = 0; c < 5; ++c) frt[fle][f][c][fp] = out[c].im;
+        frf[fle][f][0][fp] = out[5];
+        frf[fle][f][1][fp] = out[6];
+    }
+
+#if !WX_JVP_EARLY_LOADS
+    WX_JVP_POINT_LOADS()
+#endif
+#undef WX_JVP_POINT_LOADS
+    // ---- pointwise quantities
+    const T rinv = 1.0 / q0;
+    const T u1 = q1 * rinv, u2 = q2 * rinv, u3 = q3 * rinv;
+    const T glog = kGamma * w_log(kRdOverP0 * q4);
+    const T p = kP0 * w_exp(glog);
+    if (le < EPB) {
+        fL[lpt] = kLogP0 + glog;
+        ft[5][lpt] = sg * q0.im;
+    }
+
+    // ---- forcing (tangent), one row of Christoffel symbols at a time: 9 (6) loads in flight, few registers
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc4 = 0.0, accw = 0.0, hf = 0.0, gcoef = 0.0;
+    if (active) {
+#if WX_JVP_GAMMA_ROLLED
+#pragma unroll 1
+#else
+#pragma unroll
+#endif
+        for (int i = 0; i < 3; ++i) {
+            const double* c = P.chr + (size_t)(i * 9) * fs + o;
+            double c01 = 0.0, c02 = 0.0, c03 = 0.0;
+            if (!P.rot_zero) { c01 = WX_LDM(c); c02 = WX_LDM(c + fs); c03 = WX_LDM(c + 2 * fs); }
+            const double c11 = WX_LDM(c + 3 * fs), c12 = WX_LDM(c + 4 * fs), c13 = WX_LDM(c + 5 * fs),
+                         c22 = WX_LDM(c + 6 * fs), c23 = WX_LDM(c + 7 * fs), c33 = WX_LDM(c + 8 * fs);
+            T f = 2.0 * q0 * (c01 * u1 + c02 * u2 + c03 * u3) + c11 * (q0 * u1 * u1 + h00 * p) +
+                  2.0 * c12 * (q0 * u1 * u2 + h01 * p) + 2.0 * c13 * (q0 * u1 * u3 + h02 * p) +
+                  c22 * (q0 * u2 * u2 + h11 * p) + 2.0 * c23 * (q0 * u2 * u3 + h12 * p) +
+                  c33 * (q0 * u3 * u3 + h22 * p);
+            if (P.has_damp) f += (P.dcoef[o] * q0) * ((i == 0 ? u1 : (i == 1 ? u2 : u3)) - P.duref[(size_t)i * fs + o]);
+            if (i == 0) acc1 = sg * f.im;
+            else if (i == 1) acc2 = sg * f.im;
+            else accw = sg * f.im;
+        }
+        gcoef = WX_LDM(P.idz + o) * kGravity;
+    }
+
+#pragma unroll 1
+    for (int d = 0; d < 3; ++d) {
+        const T ud = w_sel(d == 0, u1, w_sel(d == 1, u2, u3));
+        const double hd0 = d == 0 ? h00 : (d == 1 ? h01 : h02);
+        const double hd1 = d == 0 ? h01 : (d == 1 ? h11 : h12);
+        const double hd2 = d == 0 ? h02 : (d == 1 ? h12 : h22);
+        const T sgu = sg * ud;
+        const double Bd = sg * hd2;
+        __syncthreads();  // face stage / previous direction's reads are done
+        if (le < EPB) {
+            ft[0][lpt] = (sgu * q0).im;
+            ft[1][lpt] = (sgu * q1 + (sg * hd0) * p).im;
+            ft[2][lpt] = (sgu * q2 + (sg * hd1) * p).im;
+            ft[3][lpt] = (sgu * q4).im;
+            ft[4][lpt] = (sgu * q3).im;
+            fB[lpt] = Bd;
+        }
+        __syncthreads();
+
+        int base, stride, idx, fp;
+        if (d == 0) { base = lb + C::lidx(kl, jl, 0); stride = 1; idx = il; fp = kl * N + jl; }
+        else if (d == 1) { base = lb + C::lidx(kl, 0, il); stride = C::NP; idx = jl; fp = kl * N + il; }
+        else { base = lb + C::lidx(0, jl, il); stride = N * C::NP; idx = kl; fp = jl * N + il; }
+        double dm[N];
+#pragma unroll
+        for (int m = 0; m < N; ++m) dm[m] = sD[idx * N + m];
+        const double cm = sCm[idx], cp = sCp[idx];
+        const int lf = le < EPB ? le : 0;
+        constexpr int FB = WX_JVP_FIELD_BATCH;
+#pragma unroll 1
+        for (int c0 = 0; c0 < 5; c0 += FB) {
+#pragma unroll
+            for (int cc = 0; cc < FB; ++cc) {
+                const int c = c0 + cc;
+                if (c < 5) {
+                    double a = cm * frt[lf][2 * d][c][fp] + cp * frt[lf][2 * d + 1][c][fp];
+#pragma unroll
+                    for (int m = 0; m < N; ++m) a += dm[m] * ft[c][base + m * stride];
+                    if (c == 0) acc0 += a;
+                    else if (c == 1) acc1 += a;
+                    else if (c == 2) acc2 += a;
+                    else if (c == 3) acc4 += a;
+                    else accw += a;
+                }
+            }
+        }
+        // W^d = [A@D + A*@C] + p [B@D + B*@C] + p B [log p@D + log p^@C]  (rhs_dfr.py:113-136): tangent of the
+        // two products; B@D is a metric-only number
+        {
+            double bsum = 0.0;
+#pragma unroll
+            for (int m = 0; m < N; ++m) bsum += dm[m] * fB[base + m * stride];
+            const T a5 = cm * frf[lf][2 * d][0][fp] + cp * frf[lf][2 * d + 1][0][fp] + bsum;
+            T a6 = cm * frf[lf][2 * d][1][fp] + cp * frf[lf][2 * d + 1][1][fp];
+#pragma unroll
+            for (int m = 0; m < N; ++m) a6 += dm[m] * fL[base + m * stride];
+            accw += (a5 * p).im + (a6 * (p * Bd)).im;
+        }
+        if (d == 2) {
+#pragma unroll
+            for (int m = 0; m < N; ++m) hf += sHF[idx * N + m] * ft[5][base + m * stride];
+        }
+    }
+
+    if (active) {
+        const double s = P.advection_only ? 0.0 : -P.jvp_scale / sg;
+        accw += gcoef * hf;  // gravity: inv_dzdeta * g * 1/sqrtG * HF_k(sqrtG rho)
+        P.out_tan[o] = s * acc0;
+        P.out_tan[fs + o] = s * acc1;
+        P.out_tan[2 * fs + o] = s * acc2;
+        P.out_tan[3 * fs + o] = s * accw;
+        P.out_tan[4 * fs + o] = s * acc4;
+    }
+}
+
 // plan-time scan of a static field: raises *flag when any value differs from (+/-) zero
 __global__ __launch_bounds__(256) void any_nonzero_kernel(const double* __restrict__ x, size_t count, int* flag) {
     bool any = false;
@@ -859,6 +1173,16 @@ static wx_status launch_rhs(const EulerParams<T>& P, hipStream_t st) {
     const int grid = (P.count + C::EPB - 1) / C::EPB;
     if (P.itf_out != nullptr) hipLaunchKernelGGL((euler_rhs_kernel<N, T, true>), dim3(grid), dim3(C::BS), 0, st, P);
     else hipLaunchKernelGGL((euler_rhs_kernel<N, T, false>), dim3(grid), dim3(C::BS), 0, st, P);
+    WX_HIP_TRY(hipGetLastError());
+    return WX_OK;
+}
+
+template <int N>
+static wx_status launch_jvp(const EulerParams<dual>& P, hipStream_t st) {
+    using C = Cfg<N>;
+    if (P.count == 0) return WX_OK;
+    const int grid = (P.count + C::EPB - 1) / C::EPB;
+    hipLaunchKernelGGL((euler_jvp_kernel<N>), dim3(grid), dim3(C::BS), 0, st, P);
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
 }
@@ -1178,7 +1502,19 @@ wx_status wx_euler3d_jvp(wx_euler3d_plan* pl, const double* q, const double* v, 
         P.halo_s = static_cast<const dual*>(halo[0]); P.halo_n = static_cast<const dual*>(halo[1]);
         P.halo_w = static_cast<const dual*>(halo[2]); P.halo_e = static_cast<const dual*>(halo[3]);
     }
-    return dispatch_rhs<dual>(pl->n, P, static_cast<hipStream_t>(stream));
+    static const bool lean = [] { const char* e = getenv("WXHIP_JVP_LEAN"); return e && e[0] == '1'; }();
+    if (!lean) return dispatch_rhs<dual>(pl->n, P, static_cast<hipStream_t>(stream));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (pl->n) {
+        case 2: return launch_jvp<2>(P, st);
+        case 3: return launch_jvp<3>(P, st);
+        case 4: return launch_jvp<4>(P, st);
+        case 5: return launch_jvp<5>(P, st);
+        case 6: return launch_jvp<6>(P, st);
+        case 7: return launch_jvp<7>(P, st);
+        case 8: return launch_jvp<8>(P, st);
+    }
+    return fail(WX_ERR_UNSUPPORTED, "num_solpts %d not in 2..8", pl->n);
 }
 
 wx_status wx_euler3d_rhs_axpy2(wx_euler3d_plan* pl, const void* q, const void* const halo[4], const void* y,
