@@ -307,3 +307,25 @@ def test_plan_skips_identically_zero_rotation_symbols():
         pl.rhs(q, halo, out)
     torch.cuda.synchronize()
     assert torch.equal(a, b)
+
+
+def test_rhs_timing_interface():
+    """RHS.timestamps / timings / retrieve_last_times / clear_timings of the reference (rhs/rhs.py:39-40, 69-121)."""
+    from tests.gpu_util import make_plan, to_dev
+    from wxfactory_amd.rhs_euler3d import RhsEuler3D
+
+    g = golden("euler3d_c31p_n3_h4_v2")
+    rhs = RhsEuler3D({p: make_plan(g, p) for p in range(6)})
+    qs = {p: to_dev(g.q(p)) for p in range(6)}
+    rhs(qs)
+    assert not getattr(rhs, "timestamps", [])  # off by default
+    rhs.timed = True
+    rhs.clear_timings()
+    for _ in range(3):
+        rhs(qs)
+    rhs.retrieve_last_times()
+    assert len(rhs.timings) == 3
+    for t in rhs.timings:
+        assert len(t) == 9 and all(x >= 0.0 for x in t) and abs(sum(t[:8]) - t[8]) < 1e-4 and t[8] > 0.0
+    rhs.clear_timings()
+    assert rhs.timings == [] and rhs.timestamps == []

@@ -84,6 +84,9 @@ enum { F_W = 0, F_E = 1, F_S = 2, F_N = 3, F_B = 4, F_T = 5 };
 // variables, exactly the reference's q_itf (default: measured fastest - the kernel is HBM-bound and
 // the two extra streams cost more than redoing exp(gamma*log(.)) on both sides of a face);
 // 6 / 7 additionally carry the face pressure / its logarithm (pde_euler_cubesphere.py:158-160).
+#ifndef WX_K2_OWN_FORM
+#define WX_K2_OWN_FORM 0   // 1: Rusanov flux in own/neighbour form (rusanov_own) instead of left/right copies
+#endif
 #ifndef WX_NO_SHIFT
 #define WX_NO_SHIFT 0   // diagnostic: compile the shift-on-load branch out of the float64 kernels
 #endif
@@ -615,7 +618,7 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
         if (!el.valid) continue;
 #if !WX_K2_OWN_FACES && !WX_K2_SKELETON
         T out[NC];
-        face_problem<N, T>(P, el, f, fp, out);
+        face_problem<N, T, WX_K2_OWN_FORM != 0>(P, el, f, fp, out);
 #else
         const int d = f >> 1, plus = f & 1;
         const size_t vsh = (size_t)V * H * N2;  // var stride in a halo edge message

@@ -105,23 +105,62 @@ class PanelRhs:
                 raise ValueError(f"state of {qs.numel()} values does not match {np_} panel(s) of {self.panel_shape}")
         return kind, (shape if kind != "dict" else None), qs
 
+    # -- the reference's timing interface (rhs/rhs.py:39-40, 69-121): nine device timestamps per evaluation,
+    #    `timings` = lists of the eight intervals + total, consumed by Integrator.step (integrators/integrator.py:99-106)
+    timed = False  # opt-in: nine event records per evaluation
+
+    def clear_timings(self):
+        self.timestamps, self.timings = [], []
+
+    def retrieve_last_times(self):
+        """Append the intervals (seconds) between the last evaluation's timestamps, and their total.  With the
+        phases fused into two kernels the nine stamps of the reference map to: 0 start, 1 extrapolation + pack
+        done, 2 exchange started, 3 = 4 interior launch done (pointwise fluxes and their divergence are one kernel),
+        5 exchange complete, 6 = 7 = 8 boundary (or whole-tile) launch done (Riemann, correction, forcing)."""
+        ts = getattr(self, "timestamps", [])
+        if not ts:
+            return
+        if not hasattr(self, "timings"):
+            self.timings = []
+        ts[-1].synchronize()
+        out = [ts[i].elapsed_time(ts[i + 1]) * 1e-3 for i in range(len(ts) - 1)]
+        out.append(ts[0].elapsed_time(ts[-1]) * 1e-3)
+        self.timings.append(out)
+        self.timestamps = []
+
+    def _stamp(self, *slots):
+        if self.timed and self.device is not None and torch.device(self.device).type == "cuda":
+            if len(getattr(self, "timestamps", [])) != 9:
+                self.timestamps = [None] * 9
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(self.device))
+            for i in slots:
+                self.timestamps[i] = ev
+
     def _exchange_and_launch(self, ex: PanelExchange, launch):
         """The phase order of rhs/rhs.py:88-118 once the edge messages are packed: start the exchange, evaluate
         the elements that need no halo (INTERIOR) while it is in flight, then the ring (BOUNDARY); when nothing
         travels (all neighbours on this rank: the halos alias the packed buffers) one launch covers ALL.
         `launch(i, tile, halo_or_None, region)` enqueues one tile's kernel."""
+        self._stamp(1)
         if ex.needs_comm and self.overlap:
             ex.start()
+            self._stamp(2)
             for i, p in enumerate(self.panels):
                 launch(i, p, None, _lib.WX_REGION_INTERIOR)
+            self._stamp(3, 4)
             ex.wait()
+            self._stamp(5)
             for i, p in enumerate(self.panels):
                 launch(i, p, ex.halo_views(p), _lib.WX_REGION_BOUNDARY)
         else:
             ex.start()
+            self._stamp(2, 3, 4)
             ex.wait()
+            self._stamp(5)
             for i, p in enumerate(self.panels):
                 launch(i, p, ex.halo_views(p), _lib.WX_REGION_ALL)
+        self._stamp(6, 7, 8)
 
     def _run(self, qs, ys, coef, dtype, zs=None):
         np_ = len(self.panels)
@@ -139,6 +178,10 @@ class PanelRhs:
             return qs
         dtype = next(iter(qs.values())).dtype
         plans, ex = self.plans_for(dtype), self.exchange_for(dtype)
+        if self.timed:
+            if getattr(self, "timestamps", None):
+                self.retrieve_last_times()  # rhs.py:78-79: timing of the previous call
+            self._stamp(0)
         shapes = {p: q.shape for p, q in qs.items()}
         flat = {p: q.reshape(self.panel_shape) for p, q in qs.items()}
         yflat = {p: y.reshape(self.panel_shape) for p, y in ys.items()} if ys is not None else {}
