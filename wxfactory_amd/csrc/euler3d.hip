@@ -84,6 +84,9 @@ enum { F_W = 0, F_E = 1, F_S = 2, F_N = 3, F_B = 4, F_T = 5 };
 // variables, exactly the reference's q_itf (default: measured fastest - the kernel is HBM-bound and
 // the two extra streams cost more than redoing exp(gamma*log(.)) on both sides of a face);
 // 6 / 7 additionally carry the face pressure / its logarithm (pde_euler_cubesphere.py:158-160).
+#ifndef WX_UNIFORM_FACE
+#define WX_UNIFORM_FACE 1  // 1: face index made wave-uniform (readfirstlane) where a face is whole waves (n = 8)
+#endif
 #ifndef WX_K2_OWN_FORM
 #define WX_K2_OWN_FORM 0   // 1: Rusanov flux in own/neighbour form (rusanov_own) instead of left/right copies
 #endif
@@ -284,7 +287,13 @@ __device__ __forceinline__ void extrap_faces(const EulerParams<T>& P, T (*fld)[C
     for (int fi = tid; fi < EPB * 6 * N2; fi += BS) {
         const int le = fi / (6 * N2);
         const int r = fi % (6 * N2);
-        const int f = r / N2, fp = r % N2;
+        int f = r / N2;
+        const int fp = r % N2;
+#if WX_UNIFORM_FACE
+        // a face is a whole number of waves when n^2 is a multiple of 64 (n = 8): tell the compiler, so that the
+        // face's direction, strides and weights live in scalar registers
+        if (N2 % 64 == 0 && BS % 64 == 0) f = __builtin_amdgcn_readfirstlane(f);
+#endif
         const Elem el = decode_elem(slot0 + le, count, region, H, V);
         if (!el.valid) continue;
         const int d = f >> 1, plus = f & 1;
@@ -613,7 +622,11 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
     for (int fi = tid; fi < EPB * 6 * N2; fi += BS) {
         const int le = fi / (6 * N2);
         const int r = fi % (6 * N2);
-        const int f = r / N2, fp = r % N2;
+        int f = r / N2;
+        const int fp = r % N2;
+#if WX_UNIFORM_FACE
+        if (N2 % 64 == 0 && BS % 64 == 0) f = __builtin_amdgcn_readfirstlane(f);
+#endif
         const Elem el = decode_elem(block_slot(gridDim.x) * EPB + le, P.count, P.region, H, V);
         if (!el.valid) continue;
 #if !WX_K2_OWN_FACES && !WX_K2_SKELETON
