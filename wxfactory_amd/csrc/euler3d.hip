@@ -450,12 +450,20 @@ __device__ __forceinline__ void rusanov_own(const T* qo, const T* qn, T uo, T un
     out[6] = qo[6];
 }
 
-// One face point of one element: the two face states (own slot of the interface buffer; the neighbour
-// element's slot, the received halo on a lateral tile edge, or the mirrored state at ground / top), the
-// interface metric, and the Rusanov problem.  out[0..6] as in rusanov_face.  Shared by the fused RHS kernel
-// and the JVP kernel.
-template <int N, typename T, bool OWN_FORM = false>
-__device__ __forceinline__ void face_problem(const EulerParams<T>& P, const Elem& el, int f, int fp, T* out) {
+// Inputs of one face point: the two face states and the interface metric, as loaded.
+template <typename T>
+struct FaceIn {
+    T qo[5], qn[5];
+    double sg, h0, h1, h2;
+    bool mirror;
+};
+
+// The loads of one face point of one element: own slot of the interface buffer; the neighbour element's slot,
+// the received halo on a lateral tile edge, or the own state again (mirrored later) at ground / top; the
+// interface metric.  Separate from the arithmetic so that a kernel can issue them early.
+template <int N, typename T>
+__device__ __forceinline__ void face_load(const EulerParams<T>& P, const Elem& el, int f, int fp, FaceIn<T>& in) {
+    static_assert(NQ == 5, "face_load reads the five prognostic face values");
     constexpr int N2 = N * N;
     const int H = P.H, V = P.V;
         const int d = f >> 1, plus = f & 1;
@@ -492,41 +500,59 @@ __device__ __forceinline__ void face_problem(const EulerParams<T>& P, const Elem
             sgp = P.sgk + o;
             hp = P.hk + 2 * 3 * hfs + o;
         }
-        T qo[7], qn[7];
 #pragma unroll
-        for (int v = 0; v < NQ; ++v) {
-            qo[v] = own[v * N2];
-            qn[v] = nbr[v * nstride];
-        }
-        if (NQ == 5) {  // pressures from rho*theta on both sides (pde_euler_cubesphere.py:158-160)
-            const T go = kGamma * w_log(qo[4] * kRdOverP0), gn = kGamma * w_log(qn[4] * kRdOverP0);
-            qo[5] = kP0 * w_exp(go); qn[5] = kP0 * w_exp(gn);
-            qo[6] = kLogP0 + go; qn[6] = kLogP0 + gn;
-        } else if (NQ == 6) {
-            qo[6] = w_log(qo[5]); qn[6] = qo[6];  // only the own side's log p is used
-        }
-        const double sg = *sgp, h0 = hp[0], h1 = hp[hfs], h2 = hp[2 * hfs];
-        const double hdd = d == 0 ? h0 : (d == 1 ? h1 : h2);
-        const T ro = 1.0 / qo[0], rn = 1.0 / qn[0];
-        // (explicit selects: a run-time index into a register array of 16-byte values goes to scratch)
-        T uo = w_sel(d == 0, qo[1], w_sel(d == 1, qo[2], qo[3])) * ro;
-        T un = w_sel(d == 0, qn[1], w_sel(d == 1, qn[2], qn[3])) * rn;
-        if (mirror) un = -uo;  // no-flow wall: odd symmetry of w (pde_euler_cubesphere.py:150-156)
-        if (OWN_FORM) {
-            rusanov_own<T>(qo, qn, uo, un, ro, rn, sg, h0, h1, h2, hdd, plus != 0, P.advection_only, out);
-            return;
-        }
-        // left = plus-side state of the lower element, right = minus-side state of the upper one
-        // (by value with selects: passing swapped array pointers would push both arrays to scratch)
-        T qL[7], qR[7];
+    for (int v = 0; v < 5; ++v) {
+        in.qo[v] = own[v * N2];
+        in.qn[v] = nbr[v * nstride];
+    }
+    in.sg = *sgp; in.h0 = hp[0]; in.h1 = hp[hfs]; in.h2 = hp[2 * hfs];
+    in.mirror = mirror;
+}
+
+// The Rusanov problem of one face point from its loaded inputs.  out[0..6] as in rusanov_face.
+template <typename T, bool OWN_FORM = false>
+__device__ __forceinline__ void face_flux(const FaceIn<T>& in, int f, bool advection_only, T* out) {
+    const int d = f >> 1, plus = f & 1;
+    T qo[7], qn[7];
 #pragma unroll
-        for (int v = 0; v < 7; ++v) {
-            qL[v] = w_sel(plus != 0, qo[v], qn[v]);
-            qR[v] = w_sel(plus != 0, qn[v], qo[v]);
-        }
-        const bool pl = plus != 0;
-        rusanov_face<T>(qL, qR, w_sel(pl, uo, un), w_sel(pl, un, uo), w_sel(pl, ro, rn), w_sel(pl, rn, ro), sg, h0, h1,
-                        h2, hdd, pl, P.advection_only, out);
+    for (int v = 0; v < 5; ++v) {
+        qo[v] = in.qo[v];
+        qn[v] = in.qn[v];
+    }
+    // pressures from rho*theta on both sides (pde_euler_cubesphere.py:158-160)
+    const T go = kGamma * w_log(qo[4] * kRdOverP0), gn = kGamma * w_log(qn[4] * kRdOverP0);
+    qo[5] = kP0 * w_exp(go); qn[5] = kP0 * w_exp(gn);
+    qo[6] = kLogP0 + go; qn[6] = kLogP0 + gn;
+    const double sg = in.sg, h0 = in.h0, h1 = in.h1, h2 = in.h2;
+    const double hdd = d == 0 ? h0 : (d == 1 ? h1 : h2);
+    const T ro = 1.0 / qo[0], rn = 1.0 / qn[0];
+    // (explicit selects: a run-time index into a register array of 16-byte values goes to scratch)
+    T uo = w_sel(d == 0, qo[1], w_sel(d == 1, qo[2], qo[3])) * ro;
+    T un = w_sel(d == 0, qn[1], w_sel(d == 1, qn[2], qn[3])) * rn;
+    if (in.mirror) un = -uo;  // no-flow wall: odd symmetry of w (pde_euler_cubesphere.py:150-156)
+    if (OWN_FORM) {
+        rusanov_own<T>(qo, qn, uo, un, ro, rn, sg, h0, h1, h2, hdd, plus != 0, advection_only, out);
+        return;
+    }
+    // left = plus-side state of the lower element, right = minus-side state of the upper one
+    // (by value with selects: passing swapped array pointers would push both arrays to scratch)
+    T qL[7], qR[7];
+#pragma unroll
+    for (int v = 0; v < 7; ++v) {
+        qL[v] = w_sel(plus != 0, qo[v], qn[v]);
+        qR[v] = w_sel(plus != 0, qn[v], qo[v]);
+    }
+    const bool pl = plus != 0;
+    rusanov_face<T>(qL, qR, w_sel(pl, uo, un), w_sel(pl, un, uo), w_sel(pl, ro, rn), w_sel(pl, rn, ro), sg, h0, h1, h2, hdd,
+                    pl, advection_only, out);
+}
+
+// One face point of one element, loads + arithmetic.  Shared by the fused RHS kernel and the JVP kernel.
+template <int N, typename T, bool OWN_FORM = false>
+__device__ __forceinline__ void face_problem(const EulerParams<T>& P, const Elem& el, int f, int fp, T* out) {
+    FaceIn<T> in;
+    face_load<N, T>(P, el, f, fp, in);
+    face_flux<T, OWN_FORM>(in, f, P.advection_only, out);
 }
 
 // ------------------------------------------------------------------------------------------------
