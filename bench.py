@@ -138,6 +138,42 @@ def extras(dev, seed):
                               "bound (5.5 MB of state per panel)"}}
 
 
+def caller_extras(rhs, qs, reps=5):
+    """the JVP variants and one explicit step on the SAME plans / metric as the headline (N = 1)."""
+    from wxfactory_amd.integrators import Tvdrk3
+    from wxfactory_amd.matvec import matvec_fun, matvec_rat
+
+    Q = torch.stack([qs[p] for p in sorted(qs)])
+    g = torch.Generator(device=Q.device).manual_seed(1)
+    v = (torch.rand(Q.shape, generator=g, device=Q.device, dtype=Q.dtype) - 0.5) * 1e-3 * Q.abs().amax(dim=(0, 2, 3, 4, 5), keepdim=True)
+    R = rhs(Q)
+    dt = 1.0
+
+    def timeit(fn):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    out = {"matvec_fun_complex_ms": timeit(lambda: matvec_fun(v.flatten(), dt, Q, R, rhs, "complex")),
+           "matvec_fun_fd_ms": timeit(lambda: matvec_fun(v.flatten(), dt, Q, R, rhs, "fd")),
+           "matvec_rat_ms": timeit(lambda: matvec_rat(v.flatten(), dt, Q, R, rhs))}
+    stepper = Tvdrk3(rhs)
+    state = {"q": Q}
+
+    def step():
+        state["q"] = stepper.step(state["q"], 1e-3)
+
+    out["tvdrk3_step_ms"] = timeit(step)
+    out["note"] = ("whole sphere, same plans as the headline: complex-step JVP = fused dual-number kernels (wx_euler3d_jvp); "
+                   "fd / Rosenbrock operator = shifted state formed on load + difference formed in the store; SSP-RK3 step "
+                   "= 3 pipelined stages (wx_euler3d_stage)")
+    return {k: (round(x, 3) if isinstance(x, float) else x) for k, x in out.items()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -296,7 +332,9 @@ def main():
             "roofline": roof,
         }
         if args.gpus == 1 and not args.no_extras:
+            Euler3DPlan.rhs = orig_rhs
             line["extra"] = extras(dev, args.seed)
+            line["extra"]["euler_callers"] = caller_extras(rhs, qs)
         if args.gpus == 1 and not args.no_cpu_baseline:
             sample_H = 30
             v, secs = cpu_baseline(n, V, sample_H, reps=3, seed=args.seed)
