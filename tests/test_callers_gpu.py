@@ -179,17 +179,17 @@ def test_shift_on_load_equals_materialised_shift(setup):
     assert torch.equal(a, a2) and torch.equal(b, b2)
 
 
-def test_lean_jvp_kernel_in_a_subprocess():
-    """The JVP-specialised kernel (tangent-only LDS staging; opt-in, WXHIP_JVP_LEAN=1, read once per process)
-    must pass the same JVP parity tests as the default dual-number kernel."""
+def test_generic_dual_jvp_kernel_in_a_subprocess():
+    """wx_euler3d_jvp runs the JVP-specialised kernel (tangent-only LDS staging) by default; WXHIP_JVP_LEAN=0 (read
+    once per process) selects the generic dual-number instantiation, which must pass the same JVP parity tests."""
     import os
     import subprocess
     import sys
 
-    if os.environ.get("WXHIP_JVP_LEAN") == "1":
-        pytest.skip("already inside the lean-kernel run")
+    if os.environ.get("WXHIP_JVP_LEAN") == "0":
+        pytest.skip("already inside the generic-kernel run")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, WXHIP_JVP_LEAN="1")
+    env = dict(os.environ, WXHIP_JVP_LEAN="0")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_callers_gpu.py", "-k",
                         "matvec_fun_and_rat or fused_jvp or kiops"], cwd=root, env=env, capture_output=True, text=True,
                        timeout=600)

@@ -996,12 +996,12 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
 // element 118 KB -> 70 KB and half the registers in the accumulators: TWO workgroups per CU instead of one,
 // and 40 % fewer LDS bytes and contraction flops.  Arithmetic is the generic kernel's, term by term.
 // ------------------------------------------------------------------------------------------------
-// STATUS (round 1): correct (the JVP parity tests pass on it) but not the default.  Unconstrained, hipcc wants 184
-// VGPRs for it; capped at 128 (2 workgroups/CU) it spills 172 B/lane and runs 19.3 ms per E7-sphere JVP against
-// 12.9 ms for the generic kernel at 1 workgroup/CU; uncapped (1 workgroup/CU) it ties the generic kernel (13.3 ms):
-// the saving in LDS traffic alone buys nothing, the occupancy would.  Selected at run time by WXHIP_JVP_LEAN=1.
+// 127 VGPRs, 70 KB LDS: two workgroups per CU, where the generic dual-number instantiation (152 VGPRs, 118 KB) gets
+// one; an E7-sphere JVP takes 11.2 ms instead of 12.9 ms.  The reads of the B / log p planes go one plane at a
+// time (rolled loop): with all of them in flight the compiler wanted 184 VGPRs.  WXHIP_JVP_LEAN=0 (environment,
+// read once) sends wx_euler3d_jvp through the generic kernel instead.
 #ifndef WX_JVP_WAVES
-#define WX_JVP_WAVES 2
+#define WX_JVP_WAVES 4
 #endif
 #ifndef WX_JVP_FIELD_BATCH
 #define WX_JVP_FIELD_BATCH 3
@@ -1018,8 +1018,7 @@ __global__ __launch_bounds__(Cfg<N>::BS, WX_JVP_WAVES) void euler_jvp_kernel(con
     using T = dual;
     constexpr int N2 = C::N2, N3 = C::N3, EPB = C::EPB, BS = C::BS;
     __shared__ double ft[6][EPB * C::LE];     // tangents: F rows rho, rho u1, rho u2, rho theta; A; sqrtG*rho
-    __shared__ double fB[EPB * C::LE];        // B = sqrtG h^{d3} (metric only)
-    __shared__ T fL[EPB * C::LE];             // log p
+    __shared__ double fx[3][EPB * C::LE];     // B = sqrtG h^{d3} (metric only); log p, value and tangent planes
     __shared__ double frt[EPB][6][5][N2];     // tangents of the face quantities 0..4 of rusanov_face
     __shared__ T frf[EPB][6][2][N2];          // B*_own, log p_own
     __shared__ double sD[N * N], sHF[N * N], sCm[N], sCp[N];
@@ -1083,7 +1082,9 @@ __global__ __launch_bounds__(Cfg<N>::BS, WX_JVP_WAVES) void euler_jvp_kernel(con
     const T glog = kGamma * w_log(kRdOverP0 * q4);
     const T p = kP0 * w_exp(glog);
     if (le < EPB) {
-        fL[lpt] = kLogP0 + glog;
+        const T lp = kLogP0 + glog;
+        fx[1][lpt] = lp.re;
+        fx[2][lpt] = lp.im;
         ft[5][lpt] = sg * q0.im;
     }
 
@@ -1128,7 +1129,7 @@ __global__ __launch_bounds__(Cfg<N>::BS, WX_JVP_WAVES) void euler_jvp_kernel(con
             ft[2][lpt] = (sgu * q2 + (sg * hd1) * p).im;
             ft[3][lpt] = (sgu * q4).im;
             ft[4][lpt] = (sgu * q3).im;
-            fB[lpt] = Bd;
+            fx[0][lpt] = Bd;
         }
         __syncthreads();
 
@@ -1160,15 +1161,20 @@ __global__ __launch_bounds__(Cfg<N>::BS, WX_JVP_WAVES) void euler_jvp_kernel(con
             }
         }
         // W^d = [A@D + A*@C] + p [B@D + B*@C] + p B [log p@D + log p^@C]  (rhs_dfr.py:113-136): tangent of the
-        // two products; B@D is a metric-only number
+        // two products; B@D is a metric-only number.  One plane at a time: bounds the LDS reads in flight
         {
-            double bsum = 0.0;
+            double xs0 = 0.0, xs1 = 0.0, xs2 = 0.0;
+#pragma unroll 1
+            for (int w = 0; w < 3; ++w) {
+                double acc = 0.0;
 #pragma unroll
-            for (int m = 0; m < N; ++m) bsum += dm[m] * fB[base + m * stride];
-            const T a5 = cm * frf[lf][2 * d][0][fp] + cp * frf[lf][2 * d + 1][0][fp] + bsum;
-            T a6 = cm * frf[lf][2 * d][1][fp] + cp * frf[lf][2 * d + 1][1][fp];
-#pragma unroll
-            for (int m = 0; m < N; ++m) a6 += dm[m] * fL[base + m * stride];
+                for (int m = 0; m < N; ++m) acc += dm[m] * fx[w][base + m * stride];
+                if (w == 0) xs0 = acc;
+                else if (w == 1) xs1 = acc;
+                else xs2 = acc;
+            }
+            const T a5 = cm * frf[lf][2 * d][0][fp] + cp * frf[lf][2 * d + 1][0][fp] + xs0;
+            const T a6 = cm * frf[lf][2 * d][1][fp] + cp * frf[lf][2 * d + 1][1][fp] + T(xs1, xs2);
             accw += (a5 * p).im + (a6 * (p * Bd)).im;
         }
         if (d == 2) {
@@ -1544,7 +1550,7 @@ wx_status wx_euler3d_jvp(wx_euler3d_plan* pl, const double* q, const double* v, 
         P.halo_s = static_cast<const dual*>(halo[0]); P.halo_n = static_cast<const dual*>(halo[1]);
         P.halo_w = static_cast<const dual*>(halo[2]); P.halo_e = static_cast<const dual*>(halo[3]);
     }
-    static const bool lean = [] { const char* e = getenv("WXHIP_JVP_LEAN"); return e && e[0] == '1'; }();
+    static const bool lean = [] { const char* e = getenv("WXHIP_JVP_LEAN"); return !(e && e[0] == '0'); }();
     if (!lean) return dispatch_rhs<dual>(pl->n, P, static_cast<hipStream_t>(stream));
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (pl->n) {
