@@ -1003,6 +1003,9 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
 #ifndef WX_JVP_WAVES
 #define WX_JVP_WAVES 4
 #endif
+#ifndef WX_JVP_UNROLL_DIRS
+#define WX_JVP_UNROLL_DIRS 1
+#endif
 #ifndef WX_JVP_FIELD_BATCH
 #define WX_JVP_FIELD_BATCH 3
 #endif
@@ -1114,7 +1117,11 @@ __global__ __launch_bounds__(Cfg<N>::BS, WX_JVP_WAVES) void euler_jvp_kernel(con
         gcoef = WX_LDM(P.idz + o) * kGravity;
     }
 
+#if WX_JVP_UNROLL_DIRS
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
     for (int d = 0; d < 3; ++d) {
         const T ud = w_sel(d == 0, u1, w_sel(d == 1, u2, u3));
         const double hd0 = d == 0 ? h00 : (d == 1 ? h01 : h02);
