@@ -90,14 +90,8 @@ enum { F_W = 0, F_E = 1, F_S = 2, F_N = 3, F_B = 4, F_T = 5 };
 #ifndef WX_K2_OWN_FORM
 #define WX_K2_OWN_FORM 0   // 1: Rusanov flux in own/neighbour form (rusanov_own) instead of left/right copies
 #endif
-#ifndef WX_NO_SHIFT
-#define WX_NO_SHIFT 0   // diagnostic: compile the shift-on-load branch out of the float64 kernels
-#endif
 #ifndef WX_K1_WAVES
 #define WX_K1_WAVES 1   // minimum waves per SIMD requested for the extrapolation kernel (register cap = 512 / waves)
-#endif
-#ifndef WX_K2_GAMMA_PER_DIR
-#define WX_K2_GAMMA_PER_DIR 0  // 1: forcing row d fetched across directional pass d (needs WX_K2_UNROLL_DIRS)
 #endif
 #ifndef WX_K2_UNROLL_DIRS
 #define WX_K2_UNROLL_DIRS 1  // 1: one copy of the directional pass per direction: constant LDS strides, so the
@@ -105,9 +99,6 @@ enum { F_W = 0, F_E = 1, F_S = 2, F_N = 3, F_B = 4, F_T = 5 };
 #endif
 #ifndef WX_K2_SKELETON
 #define WX_K2_SKELETON 0   // diagnostic build: K2 keeps its loads, LDS writes and stores but skips the arithmetic
-#endif
-#ifndef WX_K2_OWN_FACES
-#define WX_K2_OWN_FACES 0  // 1: K2 re-extrapolates its own-side face values instead of reading them back
 #endif
 #ifndef WX_EULER_NQ
 #define WX_EULER_NQ 5   // 7: state + p + log p;  6: state + p;  5: state only (pressures redone per side)
@@ -220,9 +211,7 @@ __device__ __forceinline__ T load_q(const EulerParams<T>& P, size_t i) {
 // products: no pass that materialises Q + eps v)
 template <>
 __device__ __forceinline__ double load_q<double>(const EulerParams<double>& P, size_t i) {
-#if !WX_NO_SHIFT
     if (P.q_tan != nullptr) return P.q[i] + P.jvp_eps * P.q_tan[i];  // (same expression as load_state<double>)
-#endif
     return P.q[i];
 }
 template <>
@@ -242,13 +231,11 @@ __device__ __forceinline__ void load_state<double>(const EulerParams<double>& P,
                                                    double& a2, double& a3, double& a4) {
     const double* q = P.q;
     a0 = q[o]; a1 = q[fs + o]; a2 = q[2 * fs + o]; a3 = q[3 * fs + o]; a4 = q[4 * fs + o];
-#if !WX_NO_SHIFT
     if (P.q_tan != nullptr) {
         const double* v = P.q_tan;
         const double e = P.jvp_eps;
         a0 += e * v[o]; a1 += e * v[fs + o]; a2 += e * v[2 * fs + o]; a3 += e * v[3 * fs + o]; a4 += e * v[4 * fs + o];
     }
-#endif
 }
 template <>
 __device__ __forceinline__ void load_state<dual>(const EulerParams<dual>& P, size_t o, size_t fs, dual& a0, dual& a1, dual& a2,
@@ -524,6 +511,16 @@ __device__ __forceinline__ void face_flux(const FaceIn<T>& in, int f, bool advec
     qo[5] = kP0 * w_exp(go); qn[5] = kP0 * w_exp(gn);
     qo[6] = kLogP0 + go; qn[6] = kLogP0 + gn;
     const double sg = in.sg, h0 = in.h0, h1 = in.h1, h2 = in.h2;
+#if WX_K2_SKELETON
+    {   // diagnostic: every load consumed, no Riemann arithmetic
+        T sum = T(sg + h0 + h1 + h2);
+#pragma unroll
+        for (int v = 0; v < 5; ++v) sum += in.qo[v] + in.qn[v];
+#pragma unroll
+        for (int c = 0; c < 7; ++c) out[c] = sum;
+        return;
+    }
+#endif
     const double hdd = d == 0 ? h0 : (d == 1 ? h1 : h2);
     const T ro = 1.0 / qo[0], rn = 1.0 / qn[0];
     // (explicit selects: a run-time index into a register array of 16-byte values goes to scratch)
@@ -615,8 +612,6 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
 #define WX_POINT_LOADS() WX_Q_LOADS() WX_PMETRIC_LOADS()
 #if WX_K2_EARLY_LOADS
     WX_POINT_LOADS()
-#elif WX_K2_OWN_FACES
-    WX_Q_LOADS()
 #endif
 #if !WX_K2_GAMMA_ROLLED
     double cg[27], idzv = 0.0;
@@ -636,14 +631,6 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
 #endif
 #endif
 
-#if WX_K2_OWN_FACES
-    // own-side face values are re-extrapolated here from the nodal state (same arithmetic as K1, which
-    // still writes them for the NEIGHBOUR to read): 5 of the 10 interface-buffer reads per face point saved
-    if (le < EPB) {
-        fld[0][lpt] = w_log(q0); fld[1][lpt] = q1; fld[2][lpt] = q2; fld[3][lpt] = q3; fld[4][lpt] = w_log(q4);
-    }
-    __syncthreads();
-#endif
     // ---- face stage: Riemann problems of all 6 faces of the block's elements -> LDS
     for (int fi = tid; fi < EPB * 6 * N2; fi += BS) {
         const int le = fi / (6 * N2);
@@ -655,123 +642,14 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
 #endif
         const Elem el = decode_elem(block_slot(gridDim.x) * EPB + le, P.count, P.region, H, V);
         if (!el.valid) continue;
-#if !WX_K2_OWN_FACES && !WX_K2_SKELETON
         T out[NC];
         face_problem<N, T, WX_K2_OWN_FORM != 0>(P, el, f, fp, out);
-#else
-        const int d = f >> 1, plus = f & 1;
-        const size_t vsh = (size_t)V * H * N2;  // var stride in a halo edge message
-
-        const T* own = P.itf + ((size_t)el.e * 6 + f) * NQ * N2 + fp;
-        const T* nbr;
-        size_t nstride = N2;
-        bool mirror = false;
-        const double *sgp, *hp;
-        size_t hfs;  // field stride of the h_contra_itf array
-        if (d == 0) {
-            const int ne = el.ei + (plus ? 1 : -1);
-            if (ne >= 0 && ne < H) nbr = P.itf + ((size_t)(el.e + (plus ? 1 : -1)) * 6 + (f ^ 1)) * NQ * N2 + fp;
-            else { nbr = (plus ? P.halo_e : P.halo_w) + ((size_t)el.ek * H + el.ej) * N2 + fp; nstride = vsh; }
-            const size_t o = (((size_t)el.ek * H + el.ej) * (H + 2) + el.ei + 1) * 2 * N2 + plus * N2 + fp;
-            hfs = (size_t)V * H * (H + 2) * 2 * N2;
-            sgp = P.sgi + o;
-            hp = P.hi + 0 * 3 * hfs + o;
-        } else if (d == 1) {
-            const int ne = el.ej + (plus ? 1 : -1);
-            if (ne >= 0 && ne < H) nbr = P.itf + ((size_t)(el.e + (plus ? H : -H)) * 6 + (f ^ 1)) * NQ * N2 + fp;
-            else { nbr = (plus ? P.halo_n : P.halo_s) + ((size_t)el.ek * H + el.ei) * N2 + fp; nstride = vsh; }
-            const size_t o = (((size_t)el.ek * (H + 2) + el.ej + 1) * H + el.ei) * 2 * N2 + plus * N2 + fp;
-            hfs = (size_t)V * (H + 2) * H * 2 * N2;
-            sgp = P.sgj + o;
-            hp = P.hj + 1 * 3 * hfs + o;
-        } else {
-            const int ne = el.ek + (plus ? 1 : -1);
-            if (ne >= 0 && ne < V) nbr = P.itf + ((size_t)(el.e + (plus ? H * H : -H * H)) * 6 + (f ^ 1)) * NQ * N2 + fp;
-            else { nbr = own; mirror = true; }
-            const size_t o = ((((size_t)el.ek + 1) * H + el.ej) * H + el.ei) * 2 * N2 + plus * N2 + fp;
-            hfs = (size_t)(V + 2) * H * H * 2 * N2;
-            sgp = P.sgk + o;
-            hp = P.hk + 2 * 3 * hfs + o;
-        }
-        T qo[7], qn[7];
-#if WX_K2_OWN_FACES
-        static_assert(NQ == 5, "WX_K2_OWN_FACES recomputes the 5 prognostic face values only");
-#pragma unroll
-        for (int v = 0; v < NQ; ++v) qn[v] = nbr[v * nstride];
-        {
-            const int a = fp / N, b = fp % N;
-            int base, stride;
-            if (d == 0) { base = C::lidx(a, b, 0); stride = 1; }
-            else if (d == 1) { base = C::lidx(a, 0, b); stride = C::NP; }
-            else { base = C::lidx(0, a, b); stride = N * C::NP; }
-            const double* w = plus ? P.K->ep : P.K->em;
-#pragma unroll
-            for (int v = 0; v < 5; ++v) qo[v] = T(0.0);
-#pragma unroll
-            for (int m = 0; m < N; ++m) {
-                const double wm = w[m];
-#pragma unroll
-                for (int v = 0; v < 5; ++v) qo[v] += wm * fld[v][le * C::LE + base + m * stride];
-            }
-            qo[0] = w_exp(qo[0]);
-            qo[4] = w_exp(qo[4]);
-            if (mirror) {
-#pragma unroll
-                for (int v = 0; v < NQ; ++v) qn[v] = qo[v];
-            }
-        }
-#else
-#pragma unroll
-        for (int v = 0; v < NQ; ++v) {
-            qo[v] = own[v * N2];
-            qn[v] = nbr[v * nstride];
-        }
-#endif
-        if (NQ == 5) {  // pressures from rho*theta on both sides (pde_euler_cubesphere.py:158-160)
-            const T go = kGamma * w_log(qo[4] * kRdOverP0), gn = kGamma * w_log(qn[4] * kRdOverP0);
-            qo[5] = kP0 * w_exp(go); qn[5] = kP0 * w_exp(gn);
-            qo[6] = kLogP0 + go; qn[6] = kLogP0 + gn;
-        } else if (NQ == 6) {
-            qo[6] = w_log(qo[5]); qn[6] = qo[6];  // only the own side's log p is used
-        }
-        const double sg = *sgp, h0 = hp[0], h1 = hp[hfs], h2 = hp[2 * hfs];
-#if WX_K2_SKELETON
-        {   // diagnostic: same loads and LDS writes, no Riemann arithmetic
-            T sum = T(sg + h0 + h1 + h2);
-#pragma unroll
-            for (int v = 0; v < NQ; ++v) sum += qo[v] + qn[v];
-#pragma unroll
-            for (int c = 0; c < NC; ++c) fr[le][f][c][fp] = sum;
-            continue;
-        }
-#endif
-        const double hdd = d == 0 ? h0 : (d == 1 ? h1 : h2);
-        const T ro = 1.0 / qo[0], rn = 1.0 / qn[0];
-        // (explicit selects: a run-time index into a register array of 16-byte values goes to scratch)
-        T uo = w_sel(d == 0, qo[1], w_sel(d == 1, qo[2], qo[3])) * ro;
-        T un = w_sel(d == 0, qn[1], w_sel(d == 1, qn[2], qn[3])) * rn;
-        if (mirror) un = -uo;  // no-flow wall: odd symmetry of w (pde_euler_cubesphere.py:150-156)
-        // left = plus-side state of the lower element, right = minus-side state of the upper one
-        // (by value with selects: passing swapped array pointers would push both arrays to scratch)
-        T qL[7], qR[7];
-#pragma unroll
-        for (int v = 0; v < 7; ++v) {
-            qL[v] = w_sel(plus != 0, qo[v], qn[v]);
-            qR[v] = w_sel(plus != 0, qn[v], qo[v]);
-        }
-        T out[NC];
-        const bool pl = plus != 0;
-        rusanov_face<T>(qL, qR, w_sel(pl, uo, un), w_sel(pl, un, uo), w_sel(pl, ro, rn), w_sel(pl, rn, ro), sg, h0, h1,
-                        h2, hdd, pl, P.advection_only, out);
-#endif
 #pragma unroll
         for (int c = 0; c < NC; ++c) fr[le][f][c][fp] = out[c];
     }
 
     WX_STAMP(1);
-#if WX_K2_OWN_FACES && !WX_K2_EARLY_LOADS
-    WX_PMETRIC_LOADS()
-#elif !WX_K2_EARLY_LOADS
+#if !WX_K2_EARLY_LOADS
     WX_POINT_LOADS()
 #endif
 #undef WX_POINT_LOADS
@@ -788,9 +666,7 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
     // ---- forcing, all but the gravity filter (pde_euler_cubesphere.py:12-25, 203-290)
     T fc0 = T(0.0), fc1 = T(0.0), fc2 = T(0.0);
     double gcoef = 0.0;
-#if WX_K2_GAMMA_PER_DIR
-    // (row d of the Christoffel fields is fetched at the top of directional pass d and consumed after it)
-#elif WX_K2_GAMMA_ROLLED
+#if WX_K2_GAMMA_ROLLED
     if (active) {
 #pragma unroll 1
         for (int i = 0; i < 3; ++i) {
@@ -864,24 +740,9 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
         const double hd1 = d == 0 ? h01 : (d == 1 ? h11 : h12);
         const double hd2 = d == 0 ? h02 : (d == 1 ? h12 : h22);
 #endif
-#if WX_K2_GAMMA_PER_DIR
-        // forcing row d: its 9 Christoffel loads fly while this pass works through LDS
-        double cr[9], idzv = 0.0;
-        if (active && P.rot_zero) {
-#pragma unroll
-            for (int j = 0; j < 9; ++j) cr[j] = j < 3 ? 0.0 : WX_LDM(P.chr + (size_t)(d * 9 + j) * fs + o);
-        } else if (active) {
-#pragma unroll
-            for (int j = 0; j < 9; ++j) cr[j] = WX_LDM(P.chr + (size_t)(d * 9 + j) * fs + o);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 9; ++j) cr[j] = 0.0;
-        }
-        if (d == 2 && active) idzv = WX_LDM(P.idz + o);
-#endif
         const T sgu = sg * ud;
         const T Bd = T(sg * hd2);
-        if (d > 0 || WX_K2_OWN_FACES) __syncthreads();  // previous direction's (or the face stage's) reads are done
+        if (d > 0) __syncthreads();  // previous direction's reads are done
         if (le < EPB) {
             fld[0][lpt] = sgu * q0;
             fld[1][lpt] = sgu * q1 + (sg * hd0) * p;
@@ -930,18 +791,6 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
 #pragma unroll
             for (int m = 0; m < N; ++m) hf += sHF[idx * N + m] * fld[7][base + m * stride];
         }
-#if WX_K2_GAMMA_PER_DIR
-        {
-            T f = 2.0 * q0 * (cr[0] * u1 + cr[1] * u2 + cr[2] * u3) + cr[3] * (q0 * u1 * u1 + h00 * p) +
-                  2.0 * cr[4] * (q0 * u1 * u2 + h01 * p) + 2.0 * cr[5] * (q0 * u1 * u3 + h02 * p) +
-                  cr[6] * (q0 * u2 * u2 + h11 * p) + 2.0 * cr[7] * (q0 * u2 * u3 + h12 * p) +
-                  cr[8] * (q0 * u3 * u3 + h22 * p);
-            if (P.has_damp && active) f += (P.dcoef[o] * q0) * (ud - P.duref[(size_t)d * fs + o]);
-            if (d == 0) acc1 += sg * f;
-            else if (d == 1) acc2 += sg * f;
-            else { accw += sg * f; gcoef = idzv * kGravity; }
-        }
-#endif
         WX_STAMP(3 + d);
     }
 
