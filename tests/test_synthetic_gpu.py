@@ -97,3 +97,51 @@ def test_sw_all_orders(n, H, panel, topo, built_lib):
     ax = (1, 2, 3)
     scale = np.maximum(np.abs(ref).max(axis=ax), o.cancel_scale(want))
     assert (np.abs(got - ref).max(axis=ax) <= 1e-10 * scale).all(), np.abs(got - ref).max(axis=ax) / scale
+
+
+@pytest.mark.parametrize("n,H,V", [(8, 60, 8), (5, 12, 3)])
+def test_mass_conservation_at_full_size(n, H, V):
+    """Size-independent property at the BENCHMARK's size (E7: n = 8, 60 x 60 x 8 elements per panel, 442 M DOF):
+    the scheme is conservative, so the quadrature of sqrtG * R[rho] over the closed sphere telescopes to zero -
+    every interface flux, including the rotated / flipped ones across panel edges, must be the same number seen
+    from both sides.  Own geometry, own initial state (DCMIP 3-1) plus a seeded perturbation."""
+    import numpy as np
+
+    from wxfactory_amd.geometry3d import CubedSphere3DTile, metric3d_torch
+    from wxfactory_amd.initial import initial_state
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D
+    from wxfactory_amd.synthetic import dfr_ops
+
+    dev = "cuda:0"
+    w1 = np.polynomial.legendre.leggauss(n)[1]
+    w3 = torch.from_numpy(np.einsum("k,j,i->kji", w1, w1, w1).reshape(-1)).to(dev)
+    plans, qs, sg = {}, {}, {}
+    gen = torch.Generator(device=dev).manual_seed(11)
+    for p in range(6):
+        t = CubedSphere3DTile(n, H, V, p, 10000.0, 31)
+        m = metric3d_torch(t, dev)
+        sg[p] = m["sqrtG"]
+        plans[p] = Euler3DPlan(n, H, V, 31, p, dfr_ops(n), m)
+        q = torch.from_numpy(initial_state(t)).to(dev)
+        qs[p] = q * (1.0 + 0.01 * (torch.rand(q.shape, generator=gen, device=dev, dtype=q.dtype) - 0.5))
+    R = RhsEuler3D(plans)(qs)
+    total, gross = 0.0, 0.0
+    for p in range(6):
+        dens = sg[p] * R[p][0] * w3
+        total += float(dens.sum())
+        gross += float(dens.abs().sum())
+    assert gross > 0 and abs(total) <= 1e-11 * gross, (total, gross)
+
+    # ... and so one pipelined SSP-RK3 step (fused stage updates, faces written by the stage kernels) keeps the
+    # total mass:  sum w sqrtG rho  before == after, to rounding
+    from wxfactory_amd.integrators import Tvdrk3
+
+    Q = torch.stack([qs[p] for p in range(6)])
+    SG = torch.stack([sg[p] for p in range(6)])
+    mass = lambda X: float((SG * X[:, 0] * w3).sum())  # noqa: E731
+    stepper = Tvdrk3(RhsEuler3D(plans))
+    assert stepper.pipeline
+    Q1 = stepper.step(Q, 0.02)
+    Q2 = stepper.step(Q1, 0.02)  # second step starts from faces prepared by the first
+    m0, m2 = mass(Q), mass(Q2)
+    assert float((Q2 - Q).abs().max()) > 0 and abs(m2 - m0) <= 1e-12 * abs(m0), (m0, m2)
