@@ -317,6 +317,18 @@ wx_status wx_expfilter_apply(const wx_expfilter* h, const void* q, void* out, co
 wx_status wx_check_nan(const void* q, size_t count, wx_dtype dtype, int* flag, wx_stream stream);
 wx_status wx_cart2d_sponge(void* rho_w, const double* beta, double dt, size_t count, wx_dtype dtype, wx_stream stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Vector kernels of the matrix-free Krylov solvers (solvers/fgmres.py:150-200, solvers/kiops.py:170-200): the
+ * Gram-Schmidt passes over a basis of m device vectors of n doubles (rows of V, row stride ldv >= n), each in one
+ * pass over the data and without temporaries:
+ *   wx_multi_dot   out[k] = <V[k], w>, k < m   (out: m doubles on the device; workspace: wx_multi_dot_workspace(m)
+ *                  doubles on the device; deterministic two-stage reduction, no floating-point atomics)
+ *   wx_multi_axpy  w -= sum_k h[k] V[k]        (h: m doubles on the device) */
+size_t wx_multi_dot_workspace(int m);
+wx_status wx_multi_dot(const double* V, size_t ldv, int m, const double* w, size_t n, double* out, double* workspace,
+                       wx_stream stream);
+wx_status wx_multi_axpy(double* w, const double* V, size_t ldv, int m, const double* h, size_t n, wx_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

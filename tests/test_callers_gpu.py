@@ -195,3 +195,27 @@ def test_generic_dual_jvp_kernel_in_a_subprocess():
                        timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "passed" in r.stdout
+
+
+@pytest.mark.parametrize("m,n", [(1, 1000), (7, 4097), (8, 65536), (21, 100003)])
+def test_krylov_vector_kernels(built_lib, m, n):
+    """wx_multi_dot / wx_multi_axpy (the Gram-Schmidt sweeps of fgmres) against torch, on a padded basis."""
+    from wxfactory_amd.solvers import _Basis
+
+    gen = torch.Generator(device=DEV).manual_seed(m * 1000 + n)
+    Vfull = torch.randn((m + 2, n + 5), generator=gen, device=DEV, dtype=torch.float64)
+    V = Vfull[:, :n]  # row stride n + 5: not contiguous -> torch path
+    Vc = V.contiguous()
+    w = torch.randn(n, generator=gen, device=DEV, dtype=torch.float64)
+    basis = _Basis(Vc)
+    assert basis.gpu
+    h = basis.dots(1, 1 + m, w)
+    ref = Vc[1:1 + m] @ w
+    assert torch.allclose(h, ref, rtol=1e-12, atol=1e-12 * float(ref.abs().max()))
+    assert torch.equal(h, basis.dots(1, 1 + m, w))  # deterministic reduction
+    w2 = w.clone()
+    out = basis.subtract(w2, 1, 1 + m, h)
+    assert out is w2
+    ref2 = w - h @ Vc[1:1 + m]
+    assert torch.allclose(w2, ref2, rtol=1e-12, atol=1e-12 * float(ref2.abs().max()))
+    assert not _Basis(V).gpu

@@ -19,7 +19,7 @@ import torch  # noqa: E402
 from wxfactory_amd.filters import ExpFilter3D, NanFlag, make_filter  # noqa: E402
 from wxfactory_amd.geometry3d import CubedSphere3DTile, metric3d_torch, planet_for_case, topography_for_case  # noqa: E402
 from wxfactory_amd.initial import initial_state  # noqa: E402
-from wxfactory_amd.integrators import StepLoop, Tvdrk3  # noqa: E402
+from wxfactory_amd.integrators import Epi, Ros2, StepLoop, Tvdrk3  # noqa: E402
 from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D  # noqa: E402
 from wxfactory_amd.synthetic import dfr_ops  # noqa: E402
 
@@ -31,6 +31,8 @@ ap.add_argument("--V", type=int, default=6)
 ap.add_argument("--dt", type=float, default=0.25)
 ap.add_argument("--steps", type=int, default=40)
 ap.add_argument("--report", type=int, default=10)
+ap.add_argument("--integrator", default="tvdrk3", choices=("tvdrk3", "ros2", "epi2"))
+ap.add_argument("--tol", type=float, default=1e-7)
 ap.add_argument("--filter", type=float, default=None, help="exponential filter strength (default: 1e-3 for cases 21/22, off for 31)")
 a = ap.parse_args()
 
@@ -52,7 +54,9 @@ w1 = np.polynomial.legendre.leggauss(a.n)[1]
 w3 = torch.from_numpy(np.einsum("k,j,i->kji", w1, w1, w1).reshape(-1)).to(dev)
 strength = a.filter if a.filter is not None else (1e-3 if a.case != 31 else 0.0)
 filt = ExpFilter3D(make_filter(strength, 4, 0.5, np.polynomial.legendre.leggauss(a.n)[0]), sg) if strength > 0 else None
-loop = StepLoop(Tvdrk3(RhsEuler3D(plans)), filt, NanFlag(dev), check_every=a.report)
+rhs = RhsEuler3D(plans)
+stepper = {"tvdrk3": lambda: Tvdrk3(rhs), "ros2": lambda: Ros2(rhs, tol=a.tol, verbose=int(os.environ.get("WX_VERBOSE", "0"))), "epi2": lambda: Epi(2, rhs, tol=a.tol)}[a.integrator]()
+loop = StepLoop(stepper, filt, NanFlag(dev), check_every=a.report)
 
 
 def diag(X):
@@ -71,4 +75,8 @@ for s in range(1, a.steps + 1):
         el, n_int = time.perf_counter() - t0, s - last  # this reporting interval only (the first holds the warm-up)
         print(f"step {s:5d}  t={s*a.dt:8.2f} s  mass drift {abs(m-m0)/abs(m0):.2e}  max|w| {wmax:.3e}  theta [{tmin:.3f}, {tmax:.3f}]"
               f"  {el/n_int*1e3:7.2f} ms/step  {Q.numel()*n_int/el/1e9:.2f} G DOF-steps/s", flush=True)
+        info = getattr(stepper, "solver_info", None)
+        if info:
+            print("           last solve:", {k: v for k, v in info.items() if k in ("iterations", "rel_residual", "flag", "time")}
+                  if isinstance(info, dict) else info, flush=True)
         t0, last = time.perf_counter(), s

@@ -13,7 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libwxhip.so")
-SOURCES = ["wx_api.hip", "euler3d.hip", "sw2d.hip", "cart2d.hip", "filters.hip"]
+SOURCES = ["wx_api.hip", "euler3d.hip", "sw2d.hip", "cart2d.hip", "filters.hip", "krylov.hip"]
 ARCH = "gfx950"
 
 

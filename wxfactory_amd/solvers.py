@@ -38,6 +38,43 @@ def global_inf_norm(a: torch.Tensor, group=None) -> torch.Tensor:
     return m[0]
 
 
+class _Basis:
+    """Gram-Schmidt passes over the rows of a basis matrix V (m, n) against a vector w: on the GPU the two
+    single-pass kernels of csrc/krylov.hip (no temporaries of Krylov-vector size), elsewhere torch expressions."""
+
+    def __init__(self, V: torch.Tensor):
+        self.V = V
+        self.gpu = V.is_cuda and V.dtype == torch.float64 and V.is_contiguous()
+        if self.gpu:
+            from . import _lib
+
+            self.lib = _lib.load()
+            self.check = _lib.check
+            self.work = torch.empty(int(self.lib.wx_multi_dot_workspace(V.shape[0])), dtype=torch.float64, device=V.device)
+
+    def dots(self, lo: int, hi: int, w: torch.Tensor) -> torch.Tensor:
+        """<V[k], w> for lo <= k < hi (device tensor)."""
+        V = self.V
+        if not (self.gpu and w.is_contiguous()):
+            return V[lo:hi] @ w
+        out = torch.empty(hi - lo, dtype=torch.float64, device=V.device)
+        st = torch.cuda.current_stream(V.device).cuda_stream
+        self.check(self.lib.wx_multi_dot(V[lo].data_ptr(), V.stride(0), hi - lo, w.data_ptr(), w.numel(), out.data_ptr(),
+                                         self.work.data_ptr(), st), "wx_multi_dot")
+        return out
+
+    def subtract(self, w: torch.Tensor, lo: int, hi: int, h: torch.Tensor) -> torch.Tensor:
+        """w -= sum_k h[k - lo] V[k], in place."""
+        V = self.V
+        if not (self.gpu and w.is_contiguous() and h.is_cuda):
+            w -= h.to(w.device, w.dtype) @ V[lo:hi]
+            return w
+        st = torch.cuda.current_stream(V.device).cuda_stream
+        self.check(self.lib.wx_multi_axpy(w.data_ptr(), V[lo].data_ptr(), V.stride(0), hi - lo, h.contiguous().data_ptr(),
+                                          w.numel(), st), "wx_multi_axpy")
+        return w
+
+
 def _rotg(a: float, b: float):
     """solvers/fgmres.py:75-94"""
     if b == 0.0:
@@ -71,7 +108,8 @@ def fgmres(A: Callable, b: torch.Tensor, x0: Optional[torch.Tensor] = None, tol:
     residuals = [(norm_r / norm_b, time() - t0, 0.0)]
     niter = 0
     V = torch.empty((restart + 1, n), dtype=b.dtype, device=b.device)
-    Z = torch.empty((restart, n), dtype=b.dtype, device=b.device)
+    Z = torch.empty((restart, n), dtype=b.dtype, device=b.device) if preconditioner is not None else V  # Z[j] = V[j]
+    basis = _Basis(V)
     for _outer in range(maxiter):
         H = [[0.0] * (restart + 1) for _ in range(restart)]  # H[j][i] = h_{i,j}
         cs, sn = [], []
@@ -81,18 +119,19 @@ def fgmres(A: Callable, b: torch.Tensor, x0: Optional[torch.Tensor] = None, tol:
         k = 0
         for j in range(restart):
             niter += 1
-            Z[j] = M(V[j])
+            if preconditioner is not None:
+                Z[j] = M(V[j])
             w = A(Z[j])
-            # classical Gram-Schmidt, twice
-            h = _allreduce(V[: j + 1] @ w, group)
-            w = w - h @ V[: j + 1]
-            h2 = _allreduce(V[: j + 1] @ w, group)
-            w = w - h2 @ V[: j + 1]
+            # classical Gram-Schmidt, twice; each pass = one sweep for the dots, one for the update
+            h = _allreduce(basis.dots(0, j + 1, w), group)
+            w = basis.subtract(w, 0, j + 1, h)
+            h2 = _allreduce(basis.dots(0, j + 1, w), group)
+            w = basis.subtract(w, 0, j + 1, h2)
             h = h + h2
             hn = float(global_norm(w, group))
             hj = h.tolist() + [hn]
             if hn != 0.0:
-                V[j + 1] = w / hn
+                torch.div(w, hn, out=V[j + 1])
             for i in range(j):  # previous rotations
                 t = cs[i] * hj[i] + sn[i] * hj[i + 1]
                 hj[i + 1] = -sn[i] * hj[i] + cs[i] * hj[i + 1]
@@ -120,20 +159,41 @@ def fgmres(A: Callable, b: torch.Tensor, x0: Optional[torch.Tensor] = None, tol:
                 acc -= H[l][i] * y[l]
             y[i] = acc / H[i][i]
         update = torch.as_tensor(y, dtype=b.dtype, device=b.device) @ Z[:k]
-        x = x + update
+        x += update
         r = b - A(x)
         norm_r = float(global_norm(r, group))
         residuals.append((norm_r / norm_b, time() - t0, 0.0))
         if verbose > 0:
             print(f"res: {norm_r/norm_b:.2e} (iter {niter})", flush=True)
-        nz = x != 0
-        if bool(nz.any()):
-            change = float(global_inf_norm((update[nz] / x[nz]), group))
+        # largest relative change of a non-zero component (fgmres.py:263-268), without index arrays
+        update.div_(torch.where(x != 0, x, torch.full_like(x, math.inf)))
+        if bool((x != 0).any()):
+            change = float(global_inf_norm(update, group))
             if change < 1e-12:
                 return x, norm_r, norm_b, niter, -1, residuals
         if norm_r < tol_abs:
             return x, norm_r, norm_b, niter, 0, residuals
     return x, norm_r, norm_b, niter, (0 if norm_r < tol_abs else -1), residuals
+
+
+def _log(x: float) -> float:
+    """numpy.log on a float: -inf at 0, nan below, inf at inf (math.log raises instead; the reference's adaptivity
+    formulas rely on the IEEE behaviour when an error estimate under- or overflows)."""
+    if x != x or x < 0.0:
+        return math.nan
+    if x == 0.0:
+        return -math.inf
+    return math.inf if x == math.inf else math.log(x)
+
+
+def _ceil_clamped(x: float, lo: float, hi: float) -> int:
+    """int(ceil(x)) limited to [lo, hi]; +inf goes to hi, -inf and nan to lo: what numpy.ceil followed by the
+    reference's max(lo, min(x, hi)) with Python's builtins yields (solvers/kiops.py:275-276)."""
+    if x == math.inf:
+        return int(hi)
+    if x != x or x == -math.inf:
+        return int(lo)
+    return int(min(hi, max(lo, math.ceil(x))))
 
 
 def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int = 10, mmin: int = 10, mmax: int = 128,
@@ -232,7 +292,8 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
             oldomega = omega
             omega = tau_end * err / (tau * tol)
             if m == oldm and tau != oldtau and ireject >= 1:
-                order = max(1.0, math.log(omega / oldomega) / math.log(tau / oldtau))
+                o = _log(omega / oldomega) / _log(tau / oldtau) if oldomega > 0 and tau != oldtau else math.nan
+                order = max(1.0, o) if o == o and o != math.inf else 1.0
                 orderold = False
             elif orderold or ireject == 0:
                 orderold = True
@@ -251,8 +312,8 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
             same_tau = min(remaining, tau)
             tau_opt = tau * (gamma / omega) ** (1 / order)
             tau_opt = min(remaining, max(tau / 5, min(5 * tau, tau_opt)))
-            m_opt = math.ceil(j + math.log(omega / gamma) / math.log(kest))
-            m_opt = max(mmin, min(mmax, max(math.floor(3 / 4 * m), min(m_opt, math.ceil(4 / 3 * m)))))
+            m_opt = _ceil_clamped(j + _log(omega / gamma) / _log(kest), math.floor(3 / 4 * m), math.ceil(4 / 3 * m))
+            m_opt = max(mmin, min(mmax, m_opt))
             if j == mmax:
                 if omega > delta:
                     m_new = j
