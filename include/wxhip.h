@@ -177,12 +177,17 @@ wx_status wx_euler3d_shifted_rhs_axpy2(wx_euler3d_plan* plan, const double* q, c
  * the element faces into the OTHER slot and packs its tile-edge faces into next_send[e]: the next
  * stage then needs no wx_euler3d_extrap_pack (one read of Q and a launch saved per stage).
  * next_send must not be the buffers the current stage's halos alias.
+ * prepare_next == 2 additionally applies the per-step exponential filter (operators.apply_filter_3d; the nodal
+ * 1-D matrix is given once by wx_euler3d_set_exp_filter: host pointer, n x n row-major) to `out` before it is
+ * stored and extrapolated - the last stage of a step then produces the filtered new state - and raises *nan_flag
+ * (device int, nullable) when the stored values hold a NaN: simulation.py:147-155 in one kernel.
  * wx_euler3d_extrap_pack_slot is wx_euler3d_extrap_pack into a chosen slot (pipeline start-up). */
 wx_status wx_euler3d_extrap_pack_slot(wx_euler3d_plan* plan, const void* q, void* const send[4], int slot,
                                       wx_stream stream);
+wx_status wx_euler3d_set_exp_filter(wx_euler3d_plan* plan, const double* filter);
 wx_status wx_euler3d_stage(wx_euler3d_plan* plan, const void* q, const void* const halo[4], const void* y, const void* z,
                            void* out, double a, double b, double c, double d, wx_region region, int itf_in,
-                           void* const next_send[4], int prepare_next, wx_stream stream);
+                           void* const next_send[4], int prepare_next, int* nan_flag, wx_stream stream);
 
 /* Complex-step Jacobian-vector product (solvers/matvec.py:56-61) with no complex array in HBM.
  * The plan must be WX_DUAL128.  q and v are REAL (n-double) arrays in the state layout; the kernels form

@@ -70,8 +70,9 @@ SIGNATURES = {
     "wx_euler3d_shifted_rhs_axpy2": (c_int, [c_void_p, c_void_p, c_void_p, c_double, POINTER(c_void_p), c_void_p, c_void_p,
                                              c_void_p, c_double, c_double, c_double, c_double, c_int, c_void_p]),
     "wx_euler3d_extrap_pack_slot": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_int, c_void_p]),
+    "wx_euler3d_set_exp_filter": (c_int, [c_void_p, POINTER(c_double)]),
     "wx_euler3d_stage": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_double, c_double,
-                                 c_double, c_double, c_int, c_int, POINTER(c_void_p), c_int, c_void_p]),
+                                 c_double, c_double, c_int, c_int, POINTER(c_void_p), c_int, c_void_p, c_void_p]),
     "wx_multi_dot_workspace": (c_size_t, [c_int]),
     "wx_multi_dot": (c_int, [c_void_p, c_size_t, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "wx_multi_axpy": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_size_t, c_void_p]),

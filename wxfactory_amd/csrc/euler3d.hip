@@ -110,6 +110,7 @@ constexpr int NQ = WX_EULER_NQ;
 struct EulerConsts {
     double em[kMaxN], ep[kMaxN], cm[kMaxN], cp[kMaxN];
     double D[kMaxN * kMaxN], HF[kMaxN * kMaxN];
+    double EF[kMaxN * kMaxN];  // nodal exponential filter (wx_euler3d_set_exp_filter), identity until set
     double rot[4][8];
     int flip[4];
 };
@@ -127,6 +128,8 @@ struct EulerParams {
     // to the element faces (phase 1-2 of the NEXT evaluation) into itf_out / nsend_*: no separate K1 pass
     T* itf_out;
     T *nsend_s, *nsend_n, *nsend_w, *nsend_e;
+    int efilter;           // stage pipeline only: apply the exponential filter to the stage's output before storing it
+    int* nan_flag;         // ... and raise this device flag when the stored values hold a NaN (nullable)
     // JVP mode (T = dual only): the state is formed on load as (q_re, jvp_eps * q_tan) from two REAL arrays
     // and only jvp_scale * tangent(R) is stored, as a real array - no complex temporaries in HBM
     int jvp;
@@ -564,10 +567,13 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
     __shared__ T fld[NF][EPB * C::LE];
     __shared__ T fr[EPB][6][NC][N2];
     __shared__ double sD[N * N], sHF[N * N], sCm[N], sCp[N];
+    __shared__ double sEF[PIPE ? N * N : 1];
 
     const int tid = threadIdx.x;
     const int H = P.H, V = P.V;
     const size_t fs = (size_t)P.nelem * N3;
+    if (PIPE && P.efilter)
+        for (int i = tid; i < N * N; i += BS) sEF[i] = P.K->EF[i];
 #if WX_K2_STAMPS
 #define WX_STAMP(i)                                                                           \
     do {                                                                                      \
@@ -798,19 +804,50 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
     accw += gcoef * hf;  // gravity: inv_dzdeta * g * 1/sqrtG * HF_k(sqrtG rho)
     T r0 = -inv_sg * acc0, r1 = -inv_sg * acc1, r2 = -inv_sg * acc2, r3 = -inv_sg * accw, r4 = -inv_sg * acc4;
     if (P.advection_only) { r0 = r1 = r2 = r3 = r4 = T(0.0); }
-    if (active) {
-        if (P.axpy) {  // fused stage update of an explicit Runge-Kutta scheme (integrators/tvdrk3.py:12-19)
-            r0 = P.cb * q0 + P.cc * r0; r1 = P.cb * q1 + P.cc * r1; r2 = P.cb * q2 + P.cc * r2;
-            r3 = P.cb * q3 + P.cc * r3; r4 = P.cb * q4 + P.cc * r4;
-            if (P.y != nullptr) {
-                r0 += P.ca * P.y[o]; r1 += P.ca * P.y[fs + o]; r2 += P.ca * P.y[2 * fs + o];
-                r3 += P.ca * P.y[3 * fs + o]; r4 += P.ca * P.y[4 * fs + o];
+    if (active && P.axpy) {  // fused stage update of an explicit Runge-Kutta scheme (integrators/tvdrk3.py:12-19)
+        r0 = P.cb * q0 + P.cc * r0; r1 = P.cb * q1 + P.cc * r1; r2 = P.cb * q2 + P.cc * r2;
+        r3 = P.cb * q3 + P.cc * r3; r4 = P.cb * q4 + P.cc * r4;
+        if (P.y != nullptr) {
+            r0 += P.ca * P.y[o]; r1 += P.ca * P.y[fs + o]; r2 += P.ca * P.y[2 * fs + o];
+            r3 += P.ca * P.y[3 * fs + o]; r4 += P.ca * P.y[4 * fs + o];
+        }
+        if (P.z != nullptr) {
+            r0 += P.cd * P.z[o]; r1 += P.cd * P.z[fs + o]; r2 += P.cd * P.z[2 * fs + o];
+            r3 += P.cd * P.z[3 * fs + o]; r4 += P.cd * P.z[4 * fs + o];
+        }
+    }
+    if (PIPE && P.efilter) {
+        // the per-step exponential filter (operators.py:114-119, 257-261) on the stage's output while it is in
+        // registers: ((sqrtG q) F_i F_j F_k) / sqrtG through the LDS images the directional passes are done with
+        T t0 = active ? sg * r0 : T(0.0), t1 = active ? sg * r1 : T(0.0), t2 = active ? sg * r2 : T(0.0),
+          t3 = active ? sg * r3 : T(0.0), t4 = active ? sg * r4 : T(0.0);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            __syncthreads();  // previous reads of fld are done
+            if (le < EPB) {
+                fld[0][lpt] = t0; fld[1][lpt] = t1; fld[2][lpt] = t2; fld[3][lpt] = t3; fld[4][lpt] = t4;
             }
-            if (P.z != nullptr) {
-                r0 += P.cd * P.z[o]; r1 += P.cd * P.z[fs + o]; r2 += P.cd * P.z[2 * fs + o];
-                r3 += P.cd * P.z[3 * fs + o]; r4 += P.cd * P.z[4 * fs + o];
+            __syncthreads();
+            int base, stride, idx;
+            if (d == 0) { base = lb + C::lidx(kl, jl, 0); stride = 1; idx = il; }
+            else if (d == 1) { base = lb + C::lidx(kl, 0, il); stride = C::NP; idx = jl; }
+            else { base = lb + C::lidx(0, jl, il); stride = N * C::NP; idx = kl; }
+            t0 = t1 = t2 = t3 = t4 = T(0.0);
+#pragma unroll
+            for (int m = 0; m < N; ++m) {
+                const double w = sEF[idx * N + m];
+                t0 += w * fld[0][base + m * stride]; t1 += w * fld[1][base + m * stride];
+                t2 += w * fld[2][base + m * stride]; t3 += w * fld[3][base + m * stride];
+                t4 += w * fld[4][base + m * stride];
             }
         }
+        r0 = t0 * inv_sg; r1 = t1 * inv_sg; r2 = t2 * inv_sg; r3 = t3 * inv_sg; r4 = t4 * inv_sg;
+        if (active && P.nan_flag != nullptr &&
+            (w_real(r0) != w_real(r0) || w_real(r1) != w_real(r1) || w_real(r2) != w_real(r2) ||
+             w_real(r3) != w_real(r3) || w_real(r4) != w_real(r4)))
+            *P.nan_flag = 1;
+    }
+    if (active) {
         store_r<T>(P, o, r0);
         store_r<T>(P, fs + o, r1);
         store_r<T>(P, 2 * fs + o, r2);
@@ -1122,6 +1159,7 @@ EulerParams<T> make_params(const wx_euler3d_plan* pl) {
     P.q = nullptr; P.rhs = nullptr; P.itf = static_cast<T*>(pl->itf);
     P.axpy = 0; P.ca = P.cb = P.cd = 0.0; P.cc = 1.0; P.y = nullptr; P.z = nullptr;
     P.itf_out = nullptr; P.nsend_s = P.nsend_n = P.nsend_w = P.nsend_e = nullptr;
+    P.efilter = 0; P.nan_flag = nullptr;
     P.jvp = 0; P.q_re = P.q_tan = nullptr; P.out_tan = nullptr; P.jvp_eps = 0.0; P.jvp_scale = 1.0;
     P.halo_s = P.halo_n = P.halo_w = P.halo_e = nullptr;
     P.send_s = P.send_n = P.send_w = P.send_e = nullptr;
@@ -1178,8 +1216,11 @@ wx_status run_extrap(wx_euler3d_plan* pl, const void* q, void* const send[4], hi
 template <typename T>
 wx_status run_rhs(wx_euler3d_plan* pl, const void* q, const void* const halo[4], void* out, wx_region region,
                   hipStream_t st, int axpy, const void* y, double ca, double cb, double cc, const void* z, double cd,
-                  int itf_in = 0, void* const next_send[4] = nullptr, bool epilogue = false) {
+                  int itf_in = 0, void* const next_send[4] = nullptr, bool epilogue = false, bool efilter = false,
+                  int* nan_flag = nullptr) {
     EulerParams<T> P = make_params<T>(pl);
+    P.efilter = (epilogue && efilter) ? 1 : 0;
+    P.nan_flag = nan_flag;
     if (itf_in == 1) P.itf = static_cast<T*>(pl->itf2);
     if (epilogue) {
         P.itf_out = static_cast<T*>(itf_in == 1 ? pl->itf : pl->itf2);
@@ -1283,6 +1324,7 @@ wx_status wx_euler3d_plan_create_tile(wx_euler3d_plan** out, int n, int H, int V
         hc.em[i] = ops->extrap_neg[i]; hc.ep[i] = ops->extrap_pos[i];
         hc.cm[i] = ops->correction[2 * i]; hc.cp[i] = ops->correction[2 * i + 1];
         for (int j = 0; j < n; ++j) { hc.D[i * n + j] = ops->diff_solpt[i * n + j]; hc.HF[i * n + j] = ops->highfilter[i * n + j]; }
+        hc.EF[i * n + i] = 1.0;
     }
     static const double identity[8] = {1, 0, 0, 0, 0, 1, 0, 0};
     for (int ed = 0; ed < 4; ++ed) {  // interior tile edges: no flip, no rotation (process_topology.py:219-228)
@@ -1487,9 +1529,17 @@ wx_status wx_euler3d_extrap_pack_slot(wx_euler3d_plan* pl, const void* q, void* 
     return fail(WX_ERR_INVALID, "bad plan dtype");
 }
 
+wx_status wx_euler3d_set_exp_filter(wx_euler3d_plan* pl, const double* filter) {
+    if (!pl || !filter) return fail(WX_ERR_INVALID, "wx_euler3d_set_exp_filter: null argument");
+    double ef[kMaxN * kMaxN] = {0.0};
+    for (int i = 0; i < pl->n * pl->n; ++i) ef[i] = filter[i];
+    WX_HIP_TRY(hipMemcpy(pl->consts->EF, ef, sizeof(ef), hipMemcpyHostToDevice));
+    return WX_OK;
+}
+
 wx_status wx_euler3d_stage(wx_euler3d_plan* pl, const void* q, const void* const halo[4], const void* y, const void* z,
                            void* out, double a, double b, double c, double d, wx_region region, int itf_in,
-                           void* const next_send[4], int prepare_next, wx_stream stream) {
+                           void* const next_send[4], int prepare_next, int* nan_flag, wx_stream stream) {
     if (!pl || !q || !out) return fail(WX_ERR_INVALID, "wx_euler3d_stage: null argument");
     if (out == q) return fail(WX_ERR_INVALID, "wx_euler3d_stage: output must not alias the state");
     if (itf_in != 0 && itf_in != 1) return fail(WX_ERR_INVALID, "interface slot %d not in {0,1}", itf_in);
@@ -1502,11 +1552,11 @@ wx_status wx_euler3d_stage(wx_euler3d_plan* pl, const void* q, const void* const
     }
     if (prepare_next || itf_in == 1) { wx_status s1 = ensure_slot1(pl); if (s1 != WX_OK) return s1; }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const bool ep = prepare_next != 0;
+    const bool ep = prepare_next != 0, ef = prepare_next == 2;
     switch (pl->dtype) {
-        case WX_F64: return run_rhs<double>(pl, q, halo, out, region, st, 1, y, a, b, c, z, d, itf_in, next_send, ep);
-        case WX_C128: return run_rhs<cplx>(pl, q, halo, out, region, st, 1, y, a, b, c, z, d, itf_in, next_send, ep);
-        case WX_DUAL128: return run_rhs<dual>(pl, q, halo, out, region, st, 1, y, a, b, c, z, d, itf_in, next_send, ep);
+        case WX_F64: return run_rhs<double>(pl, q, halo, out, region, st, 1, y, a, b, c, z, d, itf_in, next_send, ep, ef, nan_flag);
+        case WX_C128: return run_rhs<cplx>(pl, q, halo, out, region, st, 1, y, a, b, c, z, d, itf_in, next_send, ep, ef, nan_flag);
+        case WX_DUAL128: return run_rhs<dual>(pl, q, halo, out, region, st, 1, y, a, b, c, z, d, itf_in, next_send, ep, ef, nan_flag);
     }
     return fail(WX_ERR_INVALID, "bad plan dtype");
 }

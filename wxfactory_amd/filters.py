@@ -76,6 +76,7 @@ class ExpFilter3D:
         if F.ndim != 2 or F.shape[0] != F.shape[1]:
             raise ValueError("filter matrix must be square (n x n)")
         self.n = F.shape[0]
+        self.matrix = F
         self.sqrtG = [s.contiguous() for s in sqrtG]
         for s in self.sqrtG:
             if s.dtype != torch.float64 or not s.is_cuda or s.numel() % self.n**3:

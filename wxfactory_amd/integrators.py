@@ -18,17 +18,27 @@ class Tvdrk3:
     linear combination is formed in the RHS kernel's store), a step is three RHS evaluations plus two
     extra reads of Q and nothing else; `fused=False` is the reference's literal sequence."""
 
-    def __init__(self, rhs: Callable, fused: bool = True, pipeline: bool = True):
+    def __init__(self, rhs: Callable, fused: bool = True, pipeline: bool = True, final_filter=None, nan_flag=None):
+        """final_filter: a filters.ExpFilter3D (or its n x n matrix) to apply to the new state inside the LAST
+        stage's kernel (pipelined path only), with nan_flag (filters.NanFlag) raised by the same kernel: the body
+        of Simulation.step (simulation.py:147-155) in three launches per panel."""
         self.rhs = rhs
+        self.final_filter, self.nan_flag = final_filter, nan_flag
         self.fused = fused and bool(getattr(rhs, "supports_axpy", False))
         # stage pipeline: each stage's kernel also extrapolates its output to the faces (no separate pass)
         self.pipeline = self.fused and pipeline and bool(getattr(rhs, "supports_pipeline", False))
+        self.fused_filter = False
+        if final_filter is not None and self.pipeline and hasattr(rhs, "set_exp_filter"):
+            rhs.set_exp_filter(getattr(final_filter, "matrix", final_filter))
+            self.fused_filter = True
 
     def step(self, Q: torch.Tensor, dt: float) -> torch.Tensor:
         rhs = self.rhs
         if self.pipeline and isinstance(Q, torch.Tensor) and Q.is_contiguous() and rhs.panels:
             Q1 = rhs.stage(Q, None, 0.0, 1.0, dt)
             Q2 = rhs.stage(Q1, Q, 0.75, 0.25, 0.25 * dt)
+            if self.fused_filter:
+                return rhs.stage(Q2, Q, 1.0 / 3.0, 2.0 / 3.0, (2.0 / 3.0) * dt, filtered=True, nan_flag=self.nan_flag)
             return rhs.stage(Q2, Q, 1.0 / 3.0, 2.0 / 3.0, (2.0 / 3.0) * dt)
         if self.fused:
             Q1 = rhs.axpy(Q, None, 0.0, 1.0, dt)
@@ -148,14 +158,23 @@ class StepLoop:
         self.step_id = 0
         if filt is not None and nan_flag is not None and filt.nan_flag is None:
             filt.nan_flag = nan_flag
+        # a pipelined SSP-RK3 can filter (and NaN-check) inside its last stage's kernel
+        self.fused = False
+        if filt is not None and isinstance(stepper, Tvdrk3) and stepper.pipeline and not stepper.fused_filter \
+                and hasattr(stepper.rhs, "set_exp_filter") and getattr(filt, "matrix", None) is not None:
+            stepper.rhs.set_exp_filter(filt.matrix)
+            stepper.final_filter, stepper.nan_flag, stepper.fused_filter = filt, nan_flag, True
+        if isinstance(stepper, Tvdrk3) and stepper.fused_filter:
+            self.fused = True
 
     def step(self, Q: torch.Tensor, dt: float) -> torch.Tensor:
         Q = self.stepper.step(Q, dt)
-        if self.filt is not None:
+        if self.filt is not None and not self.fused:
             Q = self.filt(Q, out=Q)  # the stepper returned fresh storage: filter it in place
         self.step_id += 1
         if self.nan_flag is not None:
-            if self.filt is None or self.filt.nan_flag is not self.nan_flag:
+            scanned = self.fused or (self.filt is not None and self.filt.nan_flag is self.nan_flag)
+            if not scanned:
                 self.nan_flag.check(Q)
             if self.step_id % self.check_every == 0:
                 self.nan_flag.raise_if_set()

@@ -151,9 +151,18 @@ class Euler3DPlan:
         check(self.lib.wx_euler3d_extrap_pack_slot(self._h, q.data_ptr(), _ptr_array(send), slot, st),
               "wx_euler3d_extrap_pack_slot")
 
-    def stage(self, q, halo, y, z, out, a, b, c, d, region, itf_in: int, next_send, prepare_next: bool):
+    def set_exp_filter(self, filter_matrix):
+        """The nodal 1-D exponential filter a stage with prepare_next = 2 applies to its output."""
+        F = numpy.ascontiguousarray(filter_matrix, dtype=numpy.float64)
+        if F.shape != (self.n, self.n):
+            raise ValueError(f"filter matrix must be {self.n} x {self.n}")
+        check(self.lib.wx_euler3d_set_exp_filter(self._h, F.ctypes.data_as(ctypes.POINTER(ctypes.c_double))),
+              "wx_euler3d_set_exp_filter")
+
+    def stage(self, q, halo, y, z, out, a, b, c, d, region, itf_in: int, next_send, prepare_next, nan_flag: int = 0):
         """out = a*y + b*q + c*R(q) + d*z reading faces from slot itf_in; with prepare_next also the faces of
-        `out` into the other slot / next_send (stage pipeline)."""
+        `out` into the other slot / next_send (stage pipeline); prepare_next = 2 filters `out` first and raises the
+        device flag at address nan_flag (0: none) on a NaN."""
         self._check_q(q)
         self._check_q(out)
         for t in (y, z):
@@ -163,7 +172,8 @@ class Euler3DPlan:
         st = torch.cuda.current_stream(self.device).cuda_stream
         check(self.lib.wx_euler3d_stage(self._h, q.data_ptr(), _ptr_array(halo), y.data_ptr() if y is not None else None,
                                         z.data_ptr() if z is not None else None, out.data_ptr(), a, b, c, d, region,
-                                        itf_in, _ptr_array(next_send), int(bool(prepare_next)), st), "wx_euler3d_stage")
+                                        itf_in, _ptr_array(next_send), int(prepare_next), nan_flag or None, st),
+              "wx_euler3d_stage")
 
     def _check_real(self, t):
         if t.dtype != torch.float64 or t.numel() != 5 * self.V * self.H * self.H * self.n**3 or not t.is_contiguous() \
@@ -209,7 +219,14 @@ class RhsEuler3D(PanelRhs):
     supports_jvp = True
     supports_pipeline = True
 
-    def stage(self, Q: torch.Tensor, Y, a: float, b: float, c: float) -> torch.Tensor:
+    def set_exp_filter(self, filter_matrix):
+        """Give every plan (of every dtype in use) the nodal 1-D exponential filter for filtered stages."""
+        self._exp_filter = numpy.ascontiguousarray(filter_matrix, dtype=numpy.float64)
+        for plans in self._plans.values():
+            for pl in plans.values():
+                pl.set_exp_filter(self._exp_filter)
+
+    def stage(self, Q: torch.Tensor, Y, a: float, b: float, c: float, filtered: bool = False, nan_flag=None) -> torch.Tensor:
         """One explicit Runge-Kutta stage  a*Y + b*Q + c*R(Q)  on stacked states with the stage pipeline:
         the kernel that produces the result also extrapolates it to the element faces, so the NEXT call
         whose Q is that result (same storage, not modified in between) starts without the
@@ -218,7 +235,14 @@ class RhsEuler3D(PanelRhs):
         torch.autograd.graph.increment_version on it (filters.ExpFilter3D does)."""
         np_ = len(self.panels)
         dtype = Q.dtype
+        fresh = dtype not in self._plans
         plans = self.plans_for(dtype)
+        if filtered:
+            if getattr(self, "_exp_filter", None) is None:
+                raise RuntimeError("stage(filtered=True) needs set_exp_filter first")
+            if fresh:
+                for pl in plans.values():
+                    pl.set_exp_filter(self._exp_filter)
         if not hasattr(self, "_pipe"):
             self._pipe = {}
         st = self._pipe.setdefault(dtype, {"slot": 0, "ready": None, "ex": [self.exchange_for(dtype), None]})
@@ -239,7 +263,7 @@ class RhsEuler3D(PanelRhs):
 
         def launch(i, p, halo, region):
             plans[p].stage(Qs[i], halo, Ys[i] if Ys is not None else None, None, out[i], a, b, c, 0.0, region, cur,
-                           exn.send_views(p), True)
+                           exn.send_views(p), 2 if filtered else 1, nan_flag.ptr() if nan_flag is not None else 0)
 
         self._exchange_and_launch(ex, launch)
         res = out.reshape(Q.shape)
