@@ -220,6 +220,7 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
         u = torch.cat((u, torch.zeros((1, n), dtype=dtype, device=dev)))
     m = max(mmin, min(m_init, mmax))
     Vd = torch.zeros((mmax + 1, n), dtype=dtype, device=dev)
+    basis = _Basis(Vd)
     Va = np.zeros((mmax + 1, p))
     H = np.zeros((mmax + 1, mmax + 1))
     step = krystep = ireject = reject = exps = 0
@@ -263,9 +264,9 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
             Va[j, : p - 1] = Va[j - 1, 1:p]
             Va[j, p - 1] = 0.0
             ilow = max(0, j - iop)
-            hcol = _allreduce(Vd[ilow:j] @ Vd[j], group).cpu().numpy() + Va[ilow:j] @ Va[j]
+            hcol = _allreduce(basis.dots(ilow, j, Vd[j]), group).cpu().numpy() + Va[ilow:j] @ Va[j]
             H[ilow:j, j - 1] = hcol
-            Vd[j] -= torch.as_tensor(hcol, dtype=dtype, device=dev) @ Vd[ilow:j]
+            basis.subtract(Vd[j], ilow, j, torch.as_tensor(hcol, dtype=dtype, device=dev))
             Va[j] -= hcol @ Va[ilow:j]
             nrm = math.sqrt(float(global_dotprod(Vd[j], Vd[j], group)) + float(Va[j] @ Va[j]))
             if nrm < tol:
