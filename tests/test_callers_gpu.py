@@ -219,3 +219,36 @@ def test_krylov_vector_kernels(built_lib, m, n):
     ref2 = w - h @ Vc[1:1 + m]
     assert torch.allclose(w2, ref2, rtol=1e-12, atol=1e-12 * float(ref2.abs().max()))
     assert not _Basis(V).gpu
+
+
+def test_hipgraph_captured_matvec(setup):
+    """BASELINE config 5, "hipGraph-captured matvec": the complex-step and the finite-difference Jacobian-vector
+    products (12 kernel launches each on six small panels) captured once and replayed with one host call."""
+    import time
+
+    from wxfactory_amd.graph import GraphedFunction
+    from wxfactory_amd.matvec import matvec_fun
+
+    g, rhs, stack = setup
+    Q, V, R = stack("Q"), stack("V"), stack("R")
+    dt = float(g["meta/dt_jvp"])
+    for method in ("complex", "fd"):
+        eager = lambda v: matvec_fun(v, dt, Q, R, rhs, method)  # noqa: E731
+        graphed = GraphedFunction(eager, V.flatten())
+        for scale in (1.0, -0.37):
+            v = (scale * V).flatten()
+            assert torch.equal(graphed(v), eager(v)), method
+
+        def clock(fn, reps=200):
+            v = V.flatten()
+            fn(v)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn(v)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / reps * 1e6
+
+        te, tg = clock(eager), clock(graphed)
+        print(f"matvec_fun {method}: eager {te:.0f} us, graph replay {tg:.0f} us")
+        assert tg < te  # launch-bound at this size: the replay must win
