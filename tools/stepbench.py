@@ -16,7 +16,12 @@ from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D  # noqa: E402
 dev = torch.device("cuda", 0)
 n, H, V = 8, 60, int(os.environ.get("V", "8"))
 ops = synthetic.dfr_ops(n)
-plans = {p: Euler3DPlan(n, H, V, 31, p, ops, synthetic.euler3d_metric(n, H, V, p, dev)) for p in range(6)}
+if os.environ.get("TRUE_METRIC") == "1":  # the benchmark's metric (non-rotating planet: 312 B/point kernels)
+    from wxfactory_amd.geometry3d import CubedSphere3DTile, metric3d_torch
+
+    plans = {p: Euler3DPlan(n, H, V, 31, p, ops, metric3d_torch(CubedSphere3DTile(n, H, V, p, 10000.0, 31), dev)) for p in range(6)}
+else:
+    plans = {p: Euler3DPlan(n, H, V, 31, p, ops, synthetic.euler3d_metric(n, H, V, p, dev)) for p in range(6)}
 Q = torch.stack([synthetic.euler3d_state(n, H, V, p, dev) for p in range(6)])
 rhs = RhsEuler3D(plans)
 dof = Q.numel()
