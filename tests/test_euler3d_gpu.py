@@ -329,3 +329,59 @@ def test_rhs_timing_interface():
         assert len(t) == 9 and all(x >= 0.0 for x in t) and abs(sum(t[:8]) - t[8]) < 1e-4 and t[8] > 0.0
     rhs.clear_timings()
     assert rhs.timings == [] and rhs.timestamps == []
+
+
+@pytest.mark.parametrize("name", ["euler3d_c31p_n3_h4_v2", "euler3d_c21_n4_h3_v4", "euler3d_c31p_n8_h2_v2"])
+def test_batched_launch_equals_per_tile_launches(name):
+    """Stacked states go through ONE launch per phase for all tiles (wx_euler3d_batch_*): identical bits to the
+    per-tile launches, plain and with the fused stage update, float64 and complex128; and faster where it is meant
+    to be (small tiles are launch-bound)."""
+    import time
+
+    from tests.gpu_util import device_metric, to_dev
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D
+    from wxfactory_amd.synthetic import dfr_ops
+
+    g = golden(name)
+    if len(g.metric_panels()) == 6:
+        metrics = {p: device_metric(g, p, DEV) for p in range(6)}
+    else:  # fixtures that hold the metric of a few panels only: build all six
+        from wxfactory_amd.geometry3d import CubedSphere3DTile, metric3d_torch, planet_for_case, topography_for_case
+
+        ztop = 30000.0 if g.case in (21, 22) else 10000.0
+        topo = topography_for_case(g.case, planet_for_case(g.case)[0])
+        metrics = {p: metric3d_torch(CubedSphere3DTile(g.n, g.H, g.V, p, ztop, g.case, topo=topo), DEV) for p in range(6)}
+    rhs = RhsEuler3D({p: Euler3DPlan(g.n, g.H, g.V, g.case, p, dfr_ops(g.n), metrics[p]) for p in range(6)})
+    Q = torch.stack([to_dev(g.q(p)) for p in range(6)])
+    Y = Q * 0.5 + 1.0
+    Qc = torch.complex(Q, 1e-8 * Y)
+
+    def both(fn):
+        rhs.batched = True
+        a = fn()
+        rhs.batched = False
+        b = fn()
+        rhs.batched = True
+        return a, b
+
+    for fn in (lambda: rhs(Q), lambda: rhs.axpy(Q, Y, 0.75, 0.25, 0.1), lambda: rhs.axpy(Q, None, 0.0, 1.0, 0.3, Y, -2.0),
+               lambda: rhs(Qc)):
+        a, b = both(fn)
+        assert torch.equal(a, b)
+    ref = np.stack([g.r(p) for p in range(6)])
+    assert np.isfinite(rhs(Q).cpu().numpy()).all() and rhs(Q).shape == ref.shape
+
+    def clock(reps=200):
+        rhs(Q)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            rhs(Q)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e6
+
+    tb = clock()
+    rhs.batched = False
+    tp = clock()
+    print(f"{name}: R(Q) of six panels: batched {tb:.0f} us, per-panel launches {tp:.0f} us")
+    assert tb < tp

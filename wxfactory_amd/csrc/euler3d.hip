@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 // tuning knobs (A/B-tested on MI355X; defaults are the measured best)
 #ifndef WX_K2_WAVES
@@ -348,7 +349,7 @@ __device__ __forceinline__ void extrap_faces(const EulerParams<T>& P, T (*fld)[C
 // K1: extrapolation to element faces + tile-edge pack
 // ------------------------------------------------------------------------------------------------
 template <int N, typename T>
-__global__ __launch_bounds__(Cfg<N>::BS, WX_K1_WAVES) void euler_extrap_kernel(const EulerParams<T> P) {
+__device__ __forceinline__ void euler_extrap_body(const EulerParams<T>& P) {
     using C = Cfg<N>;
     constexpr int N2 = C::N2, N3 = C::N3, EPB = C::EPB, BS = C::BS;
     __shared__ T fld[5][EPB * C::LE];
@@ -375,6 +376,30 @@ __global__ __launch_bounds__(Cfg<N>::BS, WX_K1_WAVES) void euler_extrap_kernel(c
     __syncthreads();
 
     extrap_faces<N, T>(P, fld, blockIdx.x * EPB, P.nelem, WX_REGION_ALL, P.itf, P.send_s, P.send_n, P.send_w, P.send_e);
+}
+
+template <int N, typename T>
+__global__ __launch_bounds__(Cfg<N>::BS, WX_K1_WAVES) void euler_extrap_kernel(const EulerParams<T> P) {
+    euler_extrap_body<N, T>(P);
+}
+
+// All tiles of a rank in one launch (blockIdx.y = tile): the static per-tile parameters come from a device table,
+// the state is a slice of one stacked tensor.  For small tiles the evaluation is launch-bound.
+template <typename T>
+struct EulerBatchDyn {
+    const T *q, *y, *z;
+    T* rhs;
+    size_t stride;  // elements of T between consecutive tiles' states
+    int region, count, axpy;
+    double ca, cb, cc, cd;
+};
+
+template <int N, typename T>
+__global__ __launch_bounds__(Cfg<N>::BS, WX_K1_WAVES) void euler_extrap_batch_kernel(const EulerParams<T>* table,
+                                                                                     const EulerBatchDyn<T> dyn) {
+    EulerParams<T> P = table[blockIdx.y];
+    P.q = dyn.q + (size_t)blockIdx.y * dyn.stride;
+    euler_extrap_body<N, T>(P);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -559,7 +584,7 @@ __device__ __forceinline__ void face_problem(const EulerParams<T>& P, const Elem
 // K2: fused phases 3-8
 // ------------------------------------------------------------------------------------------------
 template <int N, typename T, bool PIPE>
-__global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES)) void euler_rhs_kernel(const EulerParams<T> P) {
+__device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
     using C = Cfg<N>;
     constexpr int N2 = C::N2, N3 = C::N3, EPB = C::EPB, BS = C::BS;
     constexpr int NF = 8;   // staged fields: 4 F rows, A, B (per direction) + log p + sqrtG*rho
@@ -873,6 +898,25 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
 #undef WX_STAMP
 }
 
+template <int N, typename T, bool PIPE>
+__global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES)) void euler_rhs_kernel(const EulerParams<T> P) {
+    euler_rhs_body<N, T, PIPE>(P);
+}
+
+template <int N, typename T>
+__global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES)) void euler_rhs_batch_kernel(
+    const EulerParams<T>* table, const EulerBatchDyn<T> dyn) {
+    EulerParams<T> P = table[blockIdx.y];
+    const size_t off = (size_t)blockIdx.y * dyn.stride;
+    P.q = dyn.q + off;
+    P.rhs = dyn.rhs + off;
+    P.y = dyn.y ? dyn.y + off : nullptr;
+    P.z = dyn.z ? dyn.z + off : nullptr;
+    P.region = dyn.region; P.count = dyn.count;
+    P.axpy = dyn.axpy; P.ca = dyn.ca; P.cb = dyn.cb; P.cc = dyn.cc; P.cd = dyn.cd;
+    euler_rhs_body<N, T, false>(P);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2-JVP: the fused phases 3-8 specialised for the complex-step Jacobian-vector product (wx_euler3d_jvp).
 // Only the TANGENT of R is wanted, and the derivative contractions are linear, so of the eight fields the generic
@@ -1114,6 +1158,26 @@ static wx_status launch_rhs(const EulerParams<T>& P, hipStream_t st) {
     const int grid = (P.count + C::EPB - 1) / C::EPB;
     if (P.itf_out != nullptr) hipLaunchKernelGGL((euler_rhs_kernel<N, T, true>), dim3(grid), dim3(C::BS), 0, st, P);
     else hipLaunchKernelGGL((euler_rhs_kernel<N, T, false>), dim3(grid), dim3(C::BS), 0, st, P);
+    WX_HIP_TRY(hipGetLastError());
+    return WX_OK;
+}
+
+template <int N, typename T>
+static wx_status launch_extrap_batch(const EulerParams<T>* table, const EulerBatchDyn<T>& dyn, int nelem, int ntiles,
+                                     hipStream_t st) {
+    using C = Cfg<N>;
+    const int grid = (nelem + C::EPB - 1) / C::EPB;
+    hipLaunchKernelGGL((euler_extrap_batch_kernel<N, T>), dim3(grid, ntiles), dim3(C::BS), 0, st, table, dyn);
+    WX_HIP_TRY(hipGetLastError());
+    return WX_OK;
+}
+
+template <int N, typename T>
+static wx_status launch_rhs_batch(const EulerParams<T>* table, const EulerBatchDyn<T>& dyn, int ntiles, hipStream_t st) {
+    using C = Cfg<N>;
+    if (dyn.count == 0) return WX_OK;
+    const int grid = (dyn.count + C::EPB - 1) / C::EPB;
+    hipLaunchKernelGGL((euler_rhs_batch_kernel<N, T>), dim3(grid, ntiles), dim3(C::BS), 0, st, table, dyn);
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
 }
@@ -1559,6 +1623,147 @@ wx_status wx_euler3d_stage(wx_euler3d_plan* pl, const void* q, const void* const
         case WX_DUAL128: return run_rhs<dual>(pl, q, halo, out, region, st, 1, y, a, b, c, z, d, itf_in, next_send, ep, ef, nan_flag);
     }
     return fail(WX_ERR_INVALID, "bad plan dtype");
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// batch: all tiles of a rank in one launch per phase
+// ------------------------------------------------------------------------------------------------
+struct wx_euler3d_batch {
+    int n, H, V, count, nelem;
+    wx_dtype dtype;
+    void* table = nullptr;  // device: EulerParams<T>[count]
+};
+
+namespace {
+
+template <typename T>
+wx_status batch_upload(wx_euler3d_batch* b, wx_euler3d_plan* const* plans, void* const (*send)[4],
+                       const void* const (*halo)[4]) {
+    std::vector<EulerParams<T>> host(b->count);
+    for (int i = 0; i < b->count; ++i) {
+        EulerParams<T> P = make_params<T>(plans[i]);
+        P.send_s = static_cast<T*>(send[i][0]); P.send_n = static_cast<T*>(send[i][1]);
+        P.send_w = static_cast<T*>(send[i][2]); P.send_e = static_cast<T*>(send[i][3]);
+        P.halo_s = static_cast<const T*>(halo[i][0]); P.halo_n = static_cast<const T*>(halo[i][1]);
+        P.halo_w = static_cast<const T*>(halo[i][2]); P.halo_e = static_cast<const T*>(halo[i][3]);
+        host[i] = P;
+    }
+    const size_t bytes = sizeof(EulerParams<T>) * b->count;
+    hipError_t e = hipMalloc(&b->table, bytes);
+    if (e == hipSuccess) e = hipMemcpy(b->table, host.data(), bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return fail(WX_ERR_HIP, "batch table upload failed: %s", hipGetErrorString(e));
+    return WX_OK;
+}
+
+template <typename T>
+wx_status batch_extrap(const wx_euler3d_batch* b, const void* q, size_t stride, hipStream_t st) {
+    EulerBatchDyn<T> dyn{};
+    dyn.q = static_cast<const T*>(q);
+    dyn.stride = stride;
+    const EulerParams<T>* t = static_cast<const EulerParams<T>*>(b->table);
+    switch (b->n) {
+        case 2: return launch_extrap_batch<2, T>(t, dyn, b->nelem, b->count, st);
+        case 3: return launch_extrap_batch<3, T>(t, dyn, b->nelem, b->count, st);
+        case 4: return launch_extrap_batch<4, T>(t, dyn, b->nelem, b->count, st);
+        case 5: return launch_extrap_batch<5, T>(t, dyn, b->nelem, b->count, st);
+        case 6: return launch_extrap_batch<6, T>(t, dyn, b->nelem, b->count, st);
+        case 7: return launch_extrap_batch<7, T>(t, dyn, b->nelem, b->count, st);
+        case 8: return launch_extrap_batch<8, T>(t, dyn, b->nelem, b->count, st);
+    }
+    return fail(WX_ERR_UNSUPPORTED, "num_solpts %d not in 2..8", b->n);
+}
+
+template <typename T>
+wx_status batch_rhs(const wx_euler3d_batch* b, const void* q, const void* y, const void* z, void* out, size_t stride,
+                    int axpy, double ca, double cb, double cc, double cd, wx_region region, hipStream_t st) {
+    EulerBatchDyn<T> dyn{};
+    dyn.q = static_cast<const T*>(q); dyn.y = static_cast<const T*>(y); dyn.z = static_cast<const T*>(z);
+    dyn.rhs = static_cast<T*>(out);
+    dyn.stride = stride;
+    dyn.region = region; dyn.count = region_count(region, b->H, b->V);
+    dyn.axpy = axpy; dyn.ca = ca; dyn.cb = cb; dyn.cc = cc; dyn.cd = cd;
+    const EulerParams<T>* t = static_cast<const EulerParams<T>*>(b->table);
+    switch (b->n) {
+        case 2: return launch_rhs_batch<2, T>(t, dyn, b->count, st);
+        case 3: return launch_rhs_batch<3, T>(t, dyn, b->count, st);
+        case 4: return launch_rhs_batch<4, T>(t, dyn, b->count, st);
+        case 5: return launch_rhs_batch<5, T>(t, dyn, b->count, st);
+        case 6: return launch_rhs_batch<6, T>(t, dyn, b->count, st);
+        case 7: return launch_rhs_batch<7, T>(t, dyn, b->count, st);
+        case 8: return launch_rhs_batch<8, T>(t, dyn, b->count, st);
+    }
+    return fail(WX_ERR_UNSUPPORTED, "num_solpts %d not in 2..8", b->n);
+}
+
+}  // namespace
+
+extern "C" {
+
+wx_status wx_euler3d_batch_create(wx_euler3d_batch** out, wx_euler3d_plan* const* plans, int count, void* const (*send)[4],
+                                  const void* const (*halo)[4]) {
+    if (!out || !plans || count < 1 || !send || !halo) return fail(WX_ERR_INVALID, "wx_euler3d_batch_create: bad argument");
+    for (int i = 0; i < count; ++i) {
+        if (!plans[i]) return fail(WX_ERR_INVALID, "wx_euler3d_batch_create: plan %d is null", i);
+        if (plans[i]->n != plans[0]->n || plans[i]->H != plans[0]->H || plans[i]->V != plans[0]->V ||
+            plans[i]->dtype != plans[0]->dtype || plans[i]->case_number != plans[0]->case_number)
+            return fail(WX_ERR_INVALID, "wx_euler3d_batch_create: plan %d differs in shape, dtype or case", i);
+        for (int e = 0; e < 4; ++e)
+            if (!send[i][e] || !halo[i][e]) return fail(WX_ERR_INVALID, "wx_euler3d_batch_create: null edge buffer");
+    }
+    wx_euler3d_batch* b = new (std::nothrow) wx_euler3d_batch;
+    if (!b) return fail(WX_ERR_NOMEM, "out of host memory");
+    b->n = plans[0]->n; b->H = plans[0]->H; b->V = plans[0]->V; b->count = count; b->nelem = (int)plans[0]->nelem;
+    b->dtype = plans[0]->dtype;
+    wx_status s = WX_ERR_INVALID;
+    switch (b->dtype) {
+        case WX_F64: s = batch_upload<double>(b, plans, send, halo); break;
+        case WX_C128: s = batch_upload<cplx>(b, plans, send, halo); break;
+        case WX_DUAL128: s = batch_upload<dual>(b, plans, send, halo); break;
+    }
+    if (s != WX_OK) {
+        if (b->table) (void)hipFree(b->table);
+        delete b;
+        return s;
+    }
+    *out = b;
+    return WX_OK;
+}
+
+wx_status wx_euler3d_batch_destroy(wx_euler3d_batch* b) {
+    if (!b) return WX_OK;
+    hipError_t e = hipFree(b->table);
+    delete b;
+    if (e != hipSuccess) return fail(WX_ERR_HIP, "hipFree failed: %s", hipGetErrorString(e));
+    return WX_OK;
+}
+
+wx_status wx_euler3d_batch_extrap_pack(const wx_euler3d_batch* b, const void* q, size_t panel_stride, wx_stream stream) {
+    if (!b || !q) return fail(WX_ERR_INVALID, "wx_euler3d_batch_extrap_pack: null argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (b->dtype) {
+        case WX_F64: return batch_extrap<double>(b, q, panel_stride, st);
+        case WX_C128: return batch_extrap<cplx>(b, q, panel_stride, st);
+        case WX_DUAL128: return batch_extrap<dual>(b, q, panel_stride, st);
+    }
+    return fail(WX_ERR_INVALID, "bad batch dtype");
+}
+
+wx_status wx_euler3d_batch_rhs_axpy2(const wx_euler3d_batch* b, const void* q, const void* y, const void* z, void* out,
+                                     size_t panel_stride, int axpy, double a, double bq, double c, double d, wx_region region,
+                                     wx_stream stream) {
+    if (!b || !q || !out) return fail(WX_ERR_INVALID, "wx_euler3d_batch_rhs_axpy2: null argument");
+    if (out == q) return fail(WX_ERR_INVALID, "wx_euler3d_batch_rhs_axpy2: output must not alias the state");
+    if (region != WX_REGION_ALL && region != WX_REGION_INTERIOR && region != WX_REGION_BOUNDARY)
+        return fail(WX_ERR_INVALID, "unknown region %d", (int)region);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (b->dtype) {
+        case WX_F64: return batch_rhs<double>(b, q, y, z, out, panel_stride, axpy, a, bq, c, d, region, st);
+        case WX_C128: return batch_rhs<cplx>(b, q, y, z, out, panel_stride, axpy, a, bq, c, d, region, st);
+        case WX_DUAL128: return batch_rhs<dual>(b, q, y, z, out, panel_stride, axpy, a, bq, c, d, region, st);
+    }
+    return fail(WX_ERR_INVALID, "bad batch dtype");
 }
 
 }  // extern "C"
