@@ -192,16 +192,21 @@ wx_status wx_euler3d_stage(wx_euler3d_plan* plan, const void* q, const void* con
 /* All tiles of a rank in ONE launch per phase (for small tiles an evaluation is launch-bound: 2 launches instead of
  * 2 per tile).  The plans must agree in n, H, V, dtype and case; send[i] / halo[i] are the persistent edge buffers of
  * tile i (they are static: the exchange owns them); the states of the tiles are consecutive slices, panel_stride
- * elements of dtype apart, of one stacked array (q, y, z, out alike; y, z nullable).  axpy = 0: out = R(q);
- * axpy = 1: out = a*y + b*q + c*R(q) + d*z.  The plans must outlive the batch. */
+ * elements apart, of one stacked array (q, v, y, z, out alike; v, y, z nullable).  axpy = 0: out = R(.);
+ * axpy = 1: out = a*y + b*(.) + c*R(.) + d*z.  With v: a WX_F64 batch evaluates on the shifted state q + eps v
+ * (wx_euler3d_shifted_*); a WX_DUAL128 batch forms the dual state (q, eps v) from the two REAL arrays
+ * (wx_euler3d_jvp_extrap_pack / wx_euler3d_jvp; panel_stride then counts doubles).  The plans must outlive the batch. */
 typedef struct wx_euler3d_batch wx_euler3d_batch;
 wx_status wx_euler3d_batch_create(wx_euler3d_batch** out, wx_euler3d_plan* const* plans, int count, void* const (*send)[4],
                                   const void* const (*halo)[4]);
 wx_status wx_euler3d_batch_destroy(wx_euler3d_batch* batch);
-wx_status wx_euler3d_batch_extrap_pack(const wx_euler3d_batch* batch, const void* q, size_t panel_stride, wx_stream stream);
-wx_status wx_euler3d_batch_rhs_axpy2(const wx_euler3d_batch* batch, const void* q, const void* y, const void* z, void* out,
-                                     size_t panel_stride, int axpy, double a, double b, double c, double d, wx_region region,
-                                     wx_stream stream);
+wx_status wx_euler3d_batch_extrap_pack(const wx_euler3d_batch* batch, const void* q, const double* v, double eps,
+                                       size_t panel_stride, wx_stream stream);
+wx_status wx_euler3d_batch_rhs_axpy2(const wx_euler3d_batch* batch, const void* q, const double* v, double eps, const void* y,
+                                     const void* z, void* out, size_t panel_stride, int axpy, double a, double b, double c,
+                                     double d, wx_region region, wx_stream stream);
+wx_status wx_euler3d_batch_jvp(const wx_euler3d_batch* batch, const double* q, const double* v, double eps, double* out,
+                               double scale, size_t panel_stride, wx_region region, wx_stream stream);
 
 /* Complex-step Jacobian-vector product (solvers/matvec.py:56-61) with no complex array in HBM.
  * The plan must be WX_DUAL128.  q and v are REAL (n-double) arrays in the state layout; the kernels form

@@ -83,9 +83,10 @@ SIGNATURES = {
     "wx_cart2d_sponge": (c_int, [c_void_p, c_void_p, c_double, c_size_t, c_int, c_void_p]),
     "wx_euler3d_batch_create": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_int, c_void_p, c_void_p]),
     "wx_euler3d_batch_destroy": (c_int, [c_void_p]),
-    "wx_euler3d_batch_extrap_pack": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
-    "wx_euler3d_batch_rhs_axpy2": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_double,
-                                           c_double, c_double, c_double, c_int, c_void_p]),
+    "wx_euler3d_batch_extrap_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_size_t, c_void_p]),
+    "wx_euler3d_batch_rhs_axpy2": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_size_t,
+                                           c_int, c_double, c_double, c_double, c_double, c_int, c_void_p]),
+    "wx_euler3d_batch_jvp": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_double, c_size_t, c_int, c_void_p]),
     "wx_euler3d_jvp_extrap_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_double, POINTER(c_void_p), c_void_p]),
     "wx_euler3d_jvp": (c_int, [c_void_p, c_void_p, c_void_p, c_double, POINTER(c_void_p), c_void_p, c_double, c_int,
                                c_void_p]),

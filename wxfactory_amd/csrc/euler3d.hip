@@ -392,13 +392,29 @@ struct EulerBatchDyn {
     size_t stride;  // elements of T between consecutive tiles' states
     int region, count, axpy;
     double ca, cb, cc, cd;
+    // shifted state q + eps v (float64) or the dual state (q, eps v) formed on load from REAL arrays (dual):
+    const double *q_re, *q_tan;  // stride_re doubles apart per tile
+    double* out_tan;             // dual JVP output (real)
+    size_t stride_re;
+    double eps, scale;
+    int jvp;
 };
+
+template <typename T>
+__device__ __forceinline__ void batch_state(EulerParams<T>& P, const EulerBatchDyn<T>& dyn) {
+    const size_t off = (size_t)blockIdx.y * dyn.stride, offr = (size_t)blockIdx.y * dyn.stride_re;
+    P.q = dyn.q ? dyn.q + off : nullptr;
+    P.q_re = dyn.q_re ? dyn.q_re + offr : nullptr;
+    P.q_tan = dyn.q_tan ? dyn.q_tan + offr : nullptr;
+    P.out_tan = dyn.out_tan ? dyn.out_tan + offr : nullptr;
+    P.jvp = dyn.jvp; P.jvp_eps = dyn.eps; P.jvp_scale = dyn.scale;
+}
 
 template <int N, typename T>
 __global__ __launch_bounds__(Cfg<N>::BS, WX_K1_WAVES) void euler_extrap_batch_kernel(const EulerParams<T>* table,
                                                                                      const EulerBatchDyn<T> dyn) {
     EulerParams<T> P = table[blockIdx.y];
-    P.q = dyn.q + (size_t)blockIdx.y * dyn.stride;
+    batch_state<T>(P, dyn);
     euler_extrap_body<N, T>(P);
 }
 
@@ -908,8 +924,8 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
     const EulerParams<T>* table, const EulerBatchDyn<T> dyn) {
     EulerParams<T> P = table[blockIdx.y];
     const size_t off = (size_t)blockIdx.y * dyn.stride;
-    P.q = dyn.q + off;
-    P.rhs = dyn.rhs + off;
+    batch_state<T>(P, dyn);
+    P.rhs = dyn.rhs ? dyn.rhs + off : nullptr;
     P.y = dyn.y ? dyn.y + off : nullptr;
     P.z = dyn.z ? dyn.z + off : nullptr;
     P.region = dyn.region; P.count = dyn.count;
@@ -946,7 +962,7 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
 #define WX_JVP_GAMMA_ROLLED 1
 #endif
 template <int N>
-__global__ __launch_bounds__(Cfg<N>::BS, WX_JVP_WAVES) void euler_jvp_kernel(const EulerParams<dual> P) {
+__device__ __forceinline__ void euler_jvp_body(const EulerParams<dual>& P) {
     using C = Cfg<N>;
     using T = dual;
     constexpr int N2 = C::N2, N3 = C::N3, EPB = C::EPB, BS = C::BS;
@@ -1131,6 +1147,20 @@ __global__ __launch_bounds__(Cfg<N>::BS, WX_JVP_WAVES) void euler_jvp_kernel(con
     }
 }
 
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::BS, WX_JVP_WAVES) void euler_jvp_kernel(const EulerParams<dual> P) {
+    euler_jvp_body<N>(P);
+}
+
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::BS, WX_JVP_WAVES) void euler_jvp_batch_kernel(const EulerParams<dual>* table,
+                                                                                   const EulerBatchDyn<dual> dyn) {
+    EulerParams<dual> P = table[blockIdx.y];
+    batch_state<dual>(P, dyn);
+    P.region = dyn.region; P.count = dyn.count;
+    euler_jvp_body<N>(P);
+}
+
 // plan-time scan of a static field: raises *flag when any value differs from (+/-) zero
 __global__ __launch_bounds__(256) void any_nonzero_kernel(const double* __restrict__ x, size_t count, int* flag) {
     bool any = false;
@@ -1178,6 +1208,16 @@ static wx_status launch_rhs_batch(const EulerParams<T>* table, const EulerBatchD
     if (dyn.count == 0) return WX_OK;
     const int grid = (dyn.count + C::EPB - 1) / C::EPB;
     hipLaunchKernelGGL((euler_rhs_batch_kernel<N, T>), dim3(grid, ntiles), dim3(C::BS), 0, st, table, dyn);
+    WX_HIP_TRY(hipGetLastError());
+    return WX_OK;
+}
+
+template <int N>
+static wx_status launch_jvp_batch(const EulerParams<dual>* table, const EulerBatchDyn<dual>& dyn, int ntiles, hipStream_t st) {
+    using C = Cfg<N>;
+    if (dyn.count == 0) return WX_OK;
+    const int grid = (dyn.count + C::EPB - 1) / C::EPB;
+    hipLaunchKernelGGL((euler_jvp_batch_kernel<N>), dim3(grid, ntiles), dim3(C::BS), 0, st, table, dyn);
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
 }
@@ -1658,10 +1698,16 @@ wx_status batch_upload(wx_euler3d_batch* b, wx_euler3d_plan* const* plans, void*
 }
 
 template <typename T>
-wx_status batch_extrap(const wx_euler3d_batch* b, const void* q, size_t stride, hipStream_t st) {
+wx_status batch_extrap(const wx_euler3d_batch* b, const void* q, const double* v, double eps, size_t stride, hipStream_t st) {
     EulerBatchDyn<T> dyn{};
-    dyn.q = static_cast<const T*>(q);
     dyn.stride = stride;
+    dyn.stride_re = stride;
+    if (v != nullptr && std::is_same<T, dual>::value) {  // dual state (q, eps v) from two real arrays
+        dyn.q_re = static_cast<const double*>(q); dyn.q_tan = v; dyn.eps = eps; dyn.jvp = 1;
+    } else {
+        dyn.q = static_cast<const T*>(q);
+        dyn.q_tan = v; dyn.eps = eps;  // float64: shifted state q + eps v (null: plain)
+    }
     const EulerParams<T>* t = static_cast<const EulerParams<T>*>(b->table);
     switch (b->n) {
         case 2: return launch_extrap_batch<2, T>(t, dyn, b->nelem, b->count, st);
@@ -1676,12 +1722,15 @@ wx_status batch_extrap(const wx_euler3d_batch* b, const void* q, size_t stride, 
 }
 
 template <typename T>
-wx_status batch_rhs(const wx_euler3d_batch* b, const void* q, const void* y, const void* z, void* out, size_t stride,
-                    int axpy, double ca, double cb, double cc, double cd, wx_region region, hipStream_t st) {
+wx_status batch_rhs(const wx_euler3d_batch* b, const void* q, const double* v, double eps, const void* y, const void* z,
+                    void* out, size_t stride, int axpy, double ca, double cb, double cc, double cd, wx_region region,
+                    hipStream_t st) {
     EulerBatchDyn<T> dyn{};
     dyn.q = static_cast<const T*>(q); dyn.y = static_cast<const T*>(y); dyn.z = static_cast<const T*>(z);
     dyn.rhs = static_cast<T*>(out);
     dyn.stride = stride;
+    dyn.stride_re = stride;
+    dyn.q_tan = v; dyn.eps = eps;
     dyn.region = region; dyn.count = region_count(region, b->H, b->V);
     dyn.axpy = axpy; dyn.ca = ca; dyn.cb = cb; dyn.cc = cc; dyn.cd = cd;
     const EulerParams<T>* t = static_cast<const EulerParams<T>*>(b->table);
@@ -1739,29 +1788,56 @@ wx_status wx_euler3d_batch_destroy(wx_euler3d_batch* b) {
     return WX_OK;
 }
 
-wx_status wx_euler3d_batch_extrap_pack(const wx_euler3d_batch* b, const void* q, size_t panel_stride, wx_stream stream) {
+wx_status wx_euler3d_batch_extrap_pack(const wx_euler3d_batch* b, const void* q, const double* v, double eps,
+                                       size_t panel_stride, wx_stream stream) {
     if (!b || !q) return fail(WX_ERR_INVALID, "wx_euler3d_batch_extrap_pack: null argument");
+    if (v && b->dtype == WX_C128) return fail(WX_ERR_INVALID, "a shift / tangent vector needs a WX_F64 or WX_DUAL128 batch");
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (b->dtype) {
-        case WX_F64: return batch_extrap<double>(b, q, panel_stride, st);
-        case WX_C128: return batch_extrap<cplx>(b, q, panel_stride, st);
-        case WX_DUAL128: return batch_extrap<dual>(b, q, panel_stride, st);
+        case WX_F64: return batch_extrap<double>(b, q, v, eps, panel_stride, st);
+        case WX_C128: return batch_extrap<cplx>(b, q, nullptr, 0.0, panel_stride, st);
+        case WX_DUAL128: return batch_extrap<dual>(b, q, v, eps, panel_stride, st);
     }
     return fail(WX_ERR_INVALID, "bad batch dtype");
 }
 
-wx_status wx_euler3d_batch_rhs_axpy2(const wx_euler3d_batch* b, const void* q, const void* y, const void* z, void* out,
-                                     size_t panel_stride, int axpy, double a, double bq, double c, double d, wx_region region,
-                                     wx_stream stream) {
+wx_status wx_euler3d_batch_jvp(const wx_euler3d_batch* b, const double* q, const double* v, double eps, double* out,
+                               double scale, size_t panel_stride, wx_region region, wx_stream stream) {
+    if (!b || !q || !v || !out) return fail(WX_ERR_INVALID, "wx_euler3d_batch_jvp: null argument");
+    if (b->dtype != WX_DUAL128) return fail(WX_ERR_INVALID, "wx_euler3d_batch_jvp: the batch must be WX_DUAL128");
+    if (region != WX_REGION_ALL && region != WX_REGION_INTERIOR && region != WX_REGION_BOUNDARY)
+        return fail(WX_ERR_INVALID, "unknown region %d", (int)region);
+    EulerBatchDyn<dual> dyn{};
+    dyn.q_re = q; dyn.q_tan = v; dyn.out_tan = out; dyn.eps = eps; dyn.scale = scale; dyn.jvp = 1;
+    dyn.stride_re = panel_stride;
+    dyn.region = region; dyn.count = region_count(region, b->H, b->V);
+    const EulerParams<dual>* t = static_cast<const EulerParams<dual>*>(b->table);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (b->n) {
+        case 2: return launch_jvp_batch<2>(t, dyn, b->count, st);
+        case 3: return launch_jvp_batch<3>(t, dyn, b->count, st);
+        case 4: return launch_jvp_batch<4>(t, dyn, b->count, st);
+        case 5: return launch_jvp_batch<5>(t, dyn, b->count, st);
+        case 6: return launch_jvp_batch<6>(t, dyn, b->count, st);
+        case 7: return launch_jvp_batch<7>(t, dyn, b->count, st);
+        case 8: return launch_jvp_batch<8>(t, dyn, b->count, st);
+    }
+    return fail(WX_ERR_UNSUPPORTED, "num_solpts %d not in 2..8", b->n);
+}
+
+wx_status wx_euler3d_batch_rhs_axpy2(const wx_euler3d_batch* b, const void* q, const double* v, double eps, const void* y,
+                                     const void* z, void* out, size_t panel_stride, int axpy, double a, double bq, double c,
+                                     double d, wx_region region, wx_stream stream) {
     if (!b || !q || !out) return fail(WX_ERR_INVALID, "wx_euler3d_batch_rhs_axpy2: null argument");
+    if (v && b->dtype != WX_F64) return fail(WX_ERR_INVALID, "a shifted state needs a WX_F64 batch");
     if (out == q) return fail(WX_ERR_INVALID, "wx_euler3d_batch_rhs_axpy2: output must not alias the state");
     if (region != WX_REGION_ALL && region != WX_REGION_INTERIOR && region != WX_REGION_BOUNDARY)
         return fail(WX_ERR_INVALID, "unknown region %d", (int)region);
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (b->dtype) {
-        case WX_F64: return batch_rhs<double>(b, q, y, z, out, panel_stride, axpy, a, bq, c, d, region, st);
-        case WX_C128: return batch_rhs<cplx>(b, q, y, z, out, panel_stride, axpy, a, bq, c, d, region, st);
-        case WX_DUAL128: return batch_rhs<dual>(b, q, y, z, out, panel_stride, axpy, a, bq, c, d, region, st);
+        case WX_F64: return batch_rhs<double>(b, q, v, eps, y, z, out, panel_stride, axpy, a, bq, c, d, region, st);
+        case WX_C128: return batch_rhs<cplx>(b, q, nullptr, 0.0, y, z, out, panel_stride, axpy, a, bq, c, d, region, st);
+        case WX_DUAL128: return batch_rhs<dual>(b, q, nullptr, 0.0, y, z, out, panel_stride, axpy, a, bq, c, d, region, st);
     }
     return fail(WX_ERR_INVALID, "bad batch dtype");
 }

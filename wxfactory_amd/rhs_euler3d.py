@@ -8,6 +8,7 @@ phase timers of rhs.py:88-118 are kept as four buckets (extrap+pack, exchange, i
 """
 import ctypes
 import math
+import os
 import weakref
 from typing import Dict, List, Optional, Sequence
 
@@ -233,19 +234,29 @@ class Euler3DBatch:
         with torch.cuda.device(self.device):
             check(self.lib.wx_euler3d_batch_create(ctypes.byref(self._h), handles, n, send, halo), "wx_euler3d_batch_create")
 
-    def extrap_pack(self, q):
+    def extrap_pack(self, q, v=None, eps: float = 0.0):
+        """Phase 1-2 of all tiles; with v: on q + eps v (float64 batch) or on the dual state (q, eps v) formed from
+        the two real arrays (dual batch)."""
         for pl in self._keep[0].values():
             pl.faces_epoch += 1
         st = torch.cuda.current_stream(self.device).cuda_stream
-        check(self.lib.wx_euler3d_batch_extrap_pack(self._h, q.data_ptr(), self.stride, st), "wx_euler3d_batch_extrap_pack")
+        check(self.lib.wx_euler3d_batch_extrap_pack(self._h, q.data_ptr(), v.data_ptr() if v is not None else None, eps,
+                                                    self.stride, st), "wx_euler3d_batch_extrap_pack")
 
-    def rhs(self, q, out, region, y=None, z=None, coef=None):
+    def rhs(self, q, out, region, y=None, z=None, coef=None, v=None, eps: float = 0.0):
         st = torch.cuda.current_stream(self.device).cuda_stream
         a, b, c, d = coef if coef is not None else (0.0, 0.0, 1.0, 0.0)
-        check(self.lib.wx_euler3d_batch_rhs_axpy2(self._h, q.data_ptr(), y.data_ptr() if y is not None else None,
+        check(self.lib.wx_euler3d_batch_rhs_axpy2(self._h, q.data_ptr(), v.data_ptr() if v is not None else None, eps,
+                                                  y.data_ptr() if y is not None else None,
                                                   z.data_ptr() if z is not None else None, out.data_ptr(), self.stride,
                                                   0 if coef is None else 1, a, b, c, d, region, st),
               "wx_euler3d_batch_rhs_axpy2")
+
+    def jvp(self, q, v, eps: float, out, scale: float, region):
+        """dual batches: out (real) = scale * Im R(q + i eps v) for all tiles."""
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.wx_euler3d_batch_jvp(self._h, q.data_ptr(), v.data_ptr(), eps, out.data_ptr(), scale, self.stride,
+                                            region, st), "wx_euler3d_batch_jvp")
 
     def close(self):
         if self._h:
@@ -281,25 +292,36 @@ class RhsEuler3D(PanelRhs):
             return self._run_batched(qs, ys, zs, coef)
         return super()._run(qs, ys, coef, dtype, zs)
 
-    def _run_batched(self, q, y, z, coef):
-        dt = q.dtype
-        plans, ex = self.plans_for(dt), self.exchange_for(dt)
+    def _small_tiles(self) -> bool:
+        return (self.batched and len(self.panels) > 1 and self.panel_shape is not None and not self.timed
+                and math.prod(self.panel_shape) // 5 <= self.batch_max_points)
+
+    def _batch_for(self, key, plans, ex) -> Euler3DBatch:
         if not hasattr(self, "_batches"):
             self._batches = {}
-        if dt not in self._batches:
-            self._batches[dt] = Euler3DBatch(plans, ex)
-        b = self._batches[dt]
-        out = torch.empty_like(q)
-        b.extrap_pack(q)
+        if key not in self._batches:
+            self._batches[key] = Euler3DBatch(plans, ex)
+        return self._batches[key]
+
+    def _batched_phases(self, ex, launch):
+        """launch(region) enqueues one kernel for all tiles."""
         if ex.needs_comm and self.overlap:
             ex.start()
-            b.rhs(q, out, _lib.WX_REGION_INTERIOR, y, z, coef)
+            launch(_lib.WX_REGION_INTERIOR)
             ex.wait()
-            b.rhs(q, out, _lib.WX_REGION_BOUNDARY, y, z, coef)
+            launch(_lib.WX_REGION_BOUNDARY)
         else:
             ex.start()
             ex.wait()
-            b.rhs(q, out, _lib.WX_REGION_ALL, y, z, coef)
+            launch(_lib.WX_REGION_ALL)
+
+    def _run_batched(self, q, y, z, coef):
+        dt = q.dtype
+        plans, ex = self.plans_for(dt), self.exchange_for(dt)
+        b = self._batch_for(dt, plans, ex)
+        out = torch.empty_like(q)
+        b.extrap_pack(q)
+        self._batched_phases(ex, lambda region: b.rhs(q, out, region, y, z, coef))
         return out
 
     def set_exp_filter(self, filter_matrix):
@@ -368,6 +390,11 @@ class RhsEuler3D(PanelRhs):
         Zs = Z.reshape(shp) if Z is not None else None
         plans, ex = self.plans_for(torch.float64), self.exchange_for(torch.float64)
         out = torch.empty_like(Qs)
+        if self._small_tiles() and all(t is None or t.is_contiguous() for t in (Q, v, Y, Z)):
+            bt = self._batch_for(torch.float64, plans, ex)
+            bt.extrap_pack(Qs, vs, eps)
+            self._batched_phases(ex, lambda region: bt.rhs(Qs, out, region, Ys, Zs, (a, b, c, d), vs, eps))
+            return out.reshape(Q.shape)
         for i, p in enumerate(self.panels):
             plans[p].shifted_extrap_pack(Qs[i], vs[i], eps, ex.send_views(p))
 
@@ -391,6 +418,12 @@ class RhsEuler3D(PanelRhs):
         plans = self._plans["jvp"]
         ex = self.exchange_for(torch.complex128)
         out = torch.empty_like(Qs)
+        if self._small_tiles() and Q.is_contiguous() and v.is_contiguous() and Q.dtype == torch.float64 \
+                and os.environ.get("WXHIP_JVP_LEAN") != "0":  # (the batch always runs the JVP kernel)
+            bt = self._batch_for("jvp", plans, ex)
+            bt.extrap_pack(Qs, vs, eps)
+            self._batched_phases(ex, lambda region: bt.jvp(Qs, vs, eps, out, scale, region))
+            return out.reshape(Q.shape)
         for i, p in enumerate(self.panels):
             plans[p].jvp_extrap_pack(Qs[i], vs[i], eps, ex.send_views(p))
         self._exchange_and_launch(ex, lambda i, p, halo, region: plans[p].jvp(Qs[i], vs[i], eps, halo, out[i], scale, region))
