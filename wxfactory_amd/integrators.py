@@ -34,7 +34,10 @@ class Tvdrk3:
 
     def step(self, Q: torch.Tensor, dt: float) -> torch.Tensor:
         rhs = self.rhs
-        if self.pipeline and isinstance(Q, torch.Tensor) and Q.is_contiguous() and rhs.panels:
+        small = bool(getattr(rhs, "_small_tiles", lambda: False)()) and not self.fused_filter
+        # (small tiles are launch-bound: the batched stage update, two launches per stage for all tiles, beats the
+        #  per-tile pipelined stages)
+        if self.pipeline and not small and isinstance(Q, torch.Tensor) and Q.is_contiguous() and rhs.panels:
             Q1 = rhs.stage(Q, None, 0.0, 1.0, dt)
             Q2 = rhs.stage(Q1, Q, 0.75, 0.25, 0.25 * dt)
             if self.fused_filter:
