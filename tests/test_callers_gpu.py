@@ -58,7 +58,11 @@ def test_tvdrk3_step(setup, fused, pipeline):
     g, rhs, stack = setup
     stepper = Tvdrk3(rhs, fused=fused, pipeline=pipeline)
     assert stepper.fused == fused and stepper.pipeline == pipeline
-    Qn = stepper.step(stack("Q"), float(g["meta/dt_rk"]))
+    rhs.batched = not pipeline  # (small tiles: the batched stage update would pre-empt the pipeline)
+    try:
+        Qn = stepper.step(stack("Q"), float(g["meta/dt_rk"]))
+    finally:
+        rhs.batched = True
     ref = stack("rk3").cpu().numpy()
     dq = np.abs(ref - stack("Q").cpu().numpy()).max(axis=(0, 2, 3, 4, 5))
     err = np.abs(Qn.cpu().numpy() - ref).max(axis=(0, 2, 3, 4, 5))
@@ -74,6 +78,14 @@ def test_stage_pipeline_equals_separate_extrapolation(setup):
     g, rhs, stack = setup
     dt = float(g["meta/dt_rk"])
     plain, piped = Tvdrk3(rhs, pipeline=False), Tvdrk3(rhs, pipeline=True)
+    rhs.batched = False  # (tiles this small would otherwise take the batched stage update, not the pipeline)
+    try:
+        _pipeline_against_plain(plain, piped, stack, dt)
+    finally:
+        rhs.batched = True
+
+
+def _pipeline_against_plain(plain, piped, stack, dt):
     Qa = Qb = stack("Q")
     for step in range(3):
         Qa, Qb = plain.step(Qa, dt), piped.step(Qb, dt)
