@@ -107,6 +107,45 @@ def k2_full_metric(dev, seed, n=8, H=60, V=8, reps=20):
             "traffic": pmc_traffic(0, n, H, V, bpp)}
 
 
+def ini_size_extras(dev, seed):
+    """The 3-D Euler configs of BASELINE.json at the sizes their .ini files ship with (config/dcmip31.ini: n = 2,
+    12 x 12 x 3 elements per panel; config/dcmip21.ini: n = 3, 3 x 3 x 4): launch-bound, evaluated with one launch
+    per phase for all six panels (wx_euler3d_batch_*)."""
+    from wxfactory_amd.geometry3d import CubedSphere3DTile, metric3d_torch, planet_for_case, topography_for_case
+    from wxfactory_amd.initial import initial_state
+    from wxfactory_amd.matvec import matvec_fun, matvec_rat
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D
+    from wxfactory_amd import synthetic
+
+    out = {}
+    for label, case, n, H, V, ztop in (("dcmip31.ini", 31, 2, 12, 3, 10000.0), ("dcmip21.ini", 21, 3, 3, 4, 30000.0)):
+        topo = topography_for_case(case, planet_for_case(case)[0])
+        plans, q = {}, []
+        for p in range(6):
+            t = CubedSphere3DTile(n, H, V, p, ztop, case, topo=topo)
+            plans[p] = Euler3DPlan(n, H, V, case, p, synthetic.dfr_ops(n), metric3d_torch(t, dev))
+            q.append(torch.from_numpy(initial_state(t)).to(dev))
+        Q = torch.stack(q)
+        rhs = RhsEuler3D(plans)
+        R = rhs(Q)
+        v = (torch.rand(Q.shape, device=dev, dtype=Q.dtype) - 0.5).flatten()
+
+        def clock(fn, reps=300):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return round((time.perf_counter() - t0) / reps * 1e6, 1)
+
+        out[label] = {"n": n, "elements_per_panel": [H, H, V], "dof": Q.numel(), "rhs_us": clock(lambda: rhs(Q)),
+                      "matvec_complex_us": clock(lambda: matvec_fun(v, 1.0, Q, R, rhs, "complex")),
+                      "matvec_rat_us": clock(lambda: matvec_rat(v, 1.0, Q, R, rhs))}
+    return out
+
+
 def extras(dev, seed):
     """Secondary, non-headline numbers on the same GPU: the shallow-water S7 workload of BASELINE.json's
     galewsky line (n=8, 60x60 elements/panel, 6 panels), whole-sphere R(Q)."""
@@ -339,6 +378,7 @@ def main():
             Euler3DPlan.rhs = orig_rhs
             line["extra"] = extras(dev, args.seed)
             line["extra"]["euler_callers"] = caller_extras(rhs, qs)
+            line["extra"]["euler_ini_sizes"] = ini_size_extras(dev, args.seed)
         if args.gpus == 1 and not args.no_cpu_baseline:
             sample_H = 30
             v, secs = cpu_baseline(n, V, sample_H, reps=3, seed=args.seed)
