@@ -260,9 +260,9 @@ class _Recorder:
         return self._wrap(self._ss(*a, **k), "scalars")
 
 
-def sw_case(name, ini, overrides, perturb=0.0, seed=4321):
+def sw_case(name, ini, overrides, perturb=0.0, seed=4321, n_ranks=6):
     cfg_probe = _config(ini, overrides)
-    print(f"[{name}] {ini} n={cfg_probe.num_solpts} H={cfg_probe.num_elements_horizontal}", flush=True)
+    print(f"[{name}] {ini} n={cfg_probe.num_solpts} H={cfg_probe.num_elements_horizontal} on {n_ranks} ranks", flush=True)
 
     def work(rank):
         from device import CpuDevice
@@ -272,6 +272,9 @@ def sw_case(name, ini, overrides, perturb=0.0, seed=4321):
         from rhs.rhs_selector import RhsBundle
 
         cfg = _config(ini, overrides)
+        import math
+        per_line = int(math.isqrt(n_ranks // 6))
+        cfg.num_elements_horizontal = cfg.num_elements_horizontal_total // per_line
         comm = MPI.COMM_WORLD
         dev = CpuDevice(comm)
         pt = ProcessTopology(dev, comm=comm)
@@ -306,11 +309,13 @@ def sw_case(name, ini, overrides, perturb=0.0, seed=4321):
                 out["topo/" + a] = numpy.array(getattr(topo, a), copy=True)
         out["geom/boundary_sn"] = numpy.array(geom.boundary_sn, copy=True)
         out["geom/boundary_we"] = numpy.array(geom.boundary_we, copy=True)
+        out["tile/panel_row_col"] = numpy.array([pt.my_panel, pt.my_row, pt.my_col], dtype=numpy.int64)
         if rank == 0:
             out.update(_ops_1d(ops, geom))
             out["meta/case_number"] = numpy.int64(cfg.case_number)
             out["meta/n"] = numpy.int64(cfg.num_solpts)
             out["meta/H"] = numpy.int64(cfg.num_elements_horizontal)
+            out["meta/k"] = numpy.int64(per_line)
             out["meta/eps"] = numpy.float64(eps)
             out["meta/grid_rotation"] = numpy.array([cfg.lambda0, cfg.phi0, cfg.alpha0], dtype=float)
             n = cfg.num_solpts
@@ -324,7 +329,24 @@ def sw_case(name, ini, overrides, perturb=0.0, seed=4321):
                 out["kron/" + opn] = f @ getattr(ops, opn)
         return out
 
-    _run6(name, work)
+    if n_ranks == 6:
+        _run6(name, work)
+        return
+    t0 = time.time()
+    MPI.reset_world(n_ranks)
+    res, err = MPI.run_ranks(work, n_ranks)
+    for e in err:
+        if e:
+            print(e)
+            raise SystemExit(1)
+    flat = {}
+    for p, d in enumerate(res):
+        for k, v in d.items():
+            flat[k if k.startswith(("ops/", "meta/", "kron/")) else f"p{p}/{k}"] = v
+    path = os.path.join(GOLDEN, name + ".npz")
+    numpy.savez_compressed(path, **flat)
+    print(f"   -> {path}  {os.path.getsize(path)/1e6:.2f} MB  ({time.time()-t0:.1f}s)", flush=True)
+    MPI.reset_world(6)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -767,6 +789,9 @@ CASES = {
     "sw_c6_n5_h4": lambda nm: sw_case(nm, "case6.ini", dict(num_solpts=5, num_elements_horizontal=4)),
     "sw_c5_n4_h3": lambda nm: sw_case(nm, "case5.ini", dict(num_solpts=4, num_elements_horizontal=3)),
     "sw_c2p_n8_h3": lambda nm: sw_case(nm, "case2.ini", dict(num_solpts=8, num_elements_horizontal=3), perturb=0.01),
+    # 24 ranks = 2x2 tiles per panel, mountain case (topography), grid as shipped
+    "sw_tiles24_c5_n4_h2": lambda nm: sw_case(nm, "case5.ini", dict(num_solpts=4, num_elements_horizontal=4), perturb=0.01,
+                                              n_ranks=24),
     # callers: one SSP-RK3 step, JVPs (complex step / finite difference), Rosenbrock operator, Ros2 step
     "callers_euler3d_n3_h3_v2": lambda nm: callers_case(
         nm, "dcmip31.ini", dict(num_solpts=3, num_elements_horizontal=3, num_elements_vertical=2)),

@@ -225,7 +225,8 @@ def test_tiles_of_a_24_rank_decomposition():
         send = torch.zeros((4, plan.edge_count), dtype=torch.float64, device=DEV)
         plan.extrap_pack(q, list(send))
         out = torch.full_like(q, float("nan"))
-        plan.rhs(q, [to_dev(halo7(h)) for h in g.halo(t)], out)
+        halo = [to_dev(halo7(h)) for h in g.halo(t)]  # (kept alive until the launch has run)
+        plan.rhs(q, halo, out)
         torch.cuda.synchronize()
         got = send.cpu().numpy().reshape(4, EDGE_FIELDS, g.V, g.H, g.n**2)
         for e in range(4):

@@ -88,7 +88,7 @@ def halo7(h5, fields=EDGE_FIELDS):
     return np.concatenate((h5, p[None], np.log(p)[None]), axis=0)[:fields]
 
 
-SW_FIXTURES = ["sw_c6_n5_h4", "sw_c5_n4_h3", "sw_c2p_n8_h3"]
+SW_FIXTURES = ["sw_c6_n5_h4", "sw_c5_n4_h3", "sw_c2p_n8_h3"]  # (+ sw_tiles24_c5_n4_h2: 24 ranks, tests/test_sw_gpu.py)
 CART2D_FIXTURES = ["cart2d_bubble_n5", "cart2d_bubble_n4"]
 
 
