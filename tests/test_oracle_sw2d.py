@@ -49,3 +49,19 @@ def test_rhs_matches_reference(name, cplx):
         assert (var_err(R.real, ref.real) <= TOL * scale).all()
         if cplx:
             assert (var_err(R.imag, ref.imag) <= 1e-10 * var_max(ref.imag)).all()
+
+
+def test_oracle_on_tiles_of_a_24_rank_run():
+    """The restatement against the reference run on 24 MPI ranks (2 x 2 tiles per panel, mountain case): every
+    tile's R from its own metric / topography arrays and the halos the reference delivered."""
+    from oracle.sw2d import SW2DOracle
+    from tests.util import golden_sw, var_err, var_max
+
+    g = golden_sw("sw_tiles24_c5_n4_h2")
+    assert int(g["meta/k"]) == 2 and g.H == 2
+    for t in range(24):
+        p = int(g[f"p{t}/tile/panel_row_col"][0])
+        o = SW2DOracle(g.n, g.H, g.ops, g.sub(t, "metric"), g.sub(t, "topo"), g[f"p{t}/geom/boundary_sn"],
+                       g[f"p{t}/geom/boundary_we"], panel=p)
+        ref = g.r(t)
+        assert (var_err(o.rhs(g.q(t), g.halo(t)), ref) <= 1e-13 * var_max(ref)).all(), t
