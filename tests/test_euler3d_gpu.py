@@ -386,3 +386,36 @@ def test_batched_launch_equals_per_tile_launches(name):
     tp = clock()
     print(f"{name}: R(Q) of six panels: batched {tb:.0f} us, per-panel launches {tp:.0f} us")
     assert tb < tp
+
+
+def test_whole_sphere_of_24_tiles_batched():
+    """All 24 tiles of the reference's 24-rank run on one GPU, metric of every tile from geometry3d, the stacked
+    state evaluated with one launch per phase for all tiles (zero-copy exchange between them): R of every tile."""
+    from tests.gpu_util import to_dev
+    from wxfactory_amd.exchange import PanelExchange
+    from wxfactory_amd.geometry3d import CubedSphere3DTile, metric3d_torch
+    from wxfactory_amd.panels import CubeTopology
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D
+    from wxfactory_amd.synthetic import dfr_ops
+
+    g = golden("euler3d_tiles24_n3_h2_v2")
+    k = int(g["meta/k"])
+    topo = CubeTopology(k)
+    plans = {}
+    for t in range(topo.ntiles):
+        p, row, col = topo.locate(t)
+        tile = CubedSphere3DTile(g.n, g.H, g.V, p, 10000.0, g.case, row=row, col=col, k=k)
+        plans[t] = Euler3DPlan(g.n, g.H, g.V, g.case, p, dfr_ops(g.n), metric3d_torch(tile, DEV),
+                               on_panel_edge=topo.on_panel_edge(t))
+    ex = PanelExchange(plans[0].edge_count, DEV, rank=0, world_size=1, tiles_per_side=k)
+    rhs = RhsEuler3D(plans, ex)
+    assert rhs._small_tiles()
+    Q = torch.stack([to_dev(g.q(t)) for t in range(topo.ntiles)])
+    R = rhs(Q).cpu().numpy()
+    rhs.batched = False
+    assert np.array_equal(rhs(Q).cpu().numpy(), R)
+    scales = {t: _scale_tile(g, t, topo) for t in g.metric_panels()}
+    floor = np.max(np.stack(list(scales.values())), axis=0)
+    for t in range(topo.ntiles):
+        ref = g.r(t)
+        assert (var_err(R[t], ref) <= TOL * np.maximum(var_max(ref), scales.get(t, floor))).all(), t
