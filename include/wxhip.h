@@ -338,6 +338,9 @@ wx_status wx_expfilter_create(wx_expfilter** out, int n, const double* filter);
 wx_status wx_expfilter_destroy(wx_expfilter* h);
 wx_status wx_expfilter_apply(const wx_expfilter* h, const void* q, void* out, const double* sqrtG, int nvar, size_t nelem,
                              wx_dtype dtype, int* nan_flag, wx_stream stream);
+/* The same filter on npanels stacked panels in one launch: q, out (npanels, nvar, nelem, n^3), sqrtG (npanels, nelem, n^3). */
+wx_status wx_expfilter_apply_stacked(const wx_expfilter* h, const void* q, void* out, const double* sqrtG, int nvar,
+                                     size_t nelem, int npanels, wx_dtype dtype, int* nan_flag, wx_stream stream);
 wx_status wx_check_nan(const void* q, size_t count, wx_dtype dtype, int* flag, wx_stream stream);
 wx_status wx_cart2d_sponge(void* rho_w, const double* beta, double dt, size_t count, wx_dtype dtype, wx_stream stream);
 

@@ -196,8 +196,11 @@ def test_gpu_time_loop_matches_reference_run(built_lib, pipeline):
     F = make_filter(1e-3, 4, 0.5, np.polynomial.legendre.leggauss(n)[0])
     assert np.abs(F - g["ops/expfilter"]).max() < 1e-14
     flag = NanFlag(dev)
-    loop = StepLoop(Tvdrk3(RhsEuler3D(plans), pipeline=pipeline), ExpFilter3D(F, [metrics[p]["sqrtG"] for p in range(6)]),
+    rhs = RhsEuler3D(plans)
+    rhs.batched = not pipeline  # small tiles: batched stages + stacked filter, or (forced) the fused stage kernels
+    loop = StepLoop(Tvdrk3(rhs, pipeline=pipeline), ExpFilter3D(F, [metrics[p]["sqrtG"] for p in range(6)]),
                     flag, check_every=5)
+    assert loop.fused == pipeline
     stack = lambda key: np.stack([g[f"p{p}/{key}"] for p in range(6)])  # noqa: E731
     Q0 = torch.from_numpy(stack("Q")).to(dev)
     dt, nsteps = float(g["meta/dt"]), int(g["meta/nsteps"])

@@ -79,6 +79,8 @@ SIGNATURES = {
     "wx_expfilter_create": (c_int, [POINTER(c_void_p), c_int, POINTER(c_double)]),
     "wx_expfilter_destroy": (c_int, [c_void_p]),
     "wx_expfilter_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_int, c_void_p, c_void_p]),
+    "wx_expfilter_apply_stacked": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_int, c_int, c_void_p,
+                                           c_void_p]),
     "wx_check_nan": (c_int, [c_void_p, c_size_t, c_int, c_void_p, c_void_p]),
     "wx_cart2d_sponge": (c_int, [c_void_p, c_void_p, c_double, c_size_t, c_int, c_void_p]),
     "wx_euler3d_batch_create": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_int, c_void_p, c_void_p]),

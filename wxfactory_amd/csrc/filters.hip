@@ -34,7 +34,11 @@ template <int N, typename T>
 __global__ __launch_bounds__(FCfg<N>::BS) void expfilter_kernel(const T* __restrict__ q, T* __restrict__ out,
                                                                 const double* __restrict__ sqrtG,
                                                                 const double* __restrict__ filter, int nvar, size_t nelem,
-                                                                int* nan_flag) {
+                                                                int* nan_flag, size_t q_panel_stride, size_t sg_panel_stride) {
+    // blockIdx.y = panel of a stacked state (strides 0 and gridDim.y = 1 for a single panel)
+    q += (size_t)blockIdx.y * q_panel_stride;
+    out += (size_t)blockIdx.y * q_panel_stride;
+    sqrtG += (size_t)blockIdx.y * sg_panel_stride;
     using C = FCfg<N>;
     constexpr int N2 = C::N2, N3 = C::N3, EPB = C::EPB;
     __shared__ T fld[kFilterMaxVar][EPB * C::LE];
@@ -107,26 +111,27 @@ __global__ __launch_bounds__(256) void sponge_kernel(T* __restrict__ rho_w, cons
 
 template <int N, typename T>
 static wx_status launch_filter(const void* q, void* out, const double* sg, const double* f, int nvar, size_t nelem,
-                               int* flag, hipStream_t st) {
+                               int* flag, int npanels, hipStream_t st) {
     using C = FCfg<N>;
     const size_t grid = (nelem + C::EPB - 1) / C::EPB;
-    hipLaunchKernelGGL((expfilter_kernel<N, T>), dim3((unsigned)grid), dim3(C::BS), 0, st, static_cast<const T*>(q),
-                       static_cast<T*>(out), sg, f, nvar, nelem, flag);
+    const size_t sgs = npanels > 1 ? nelem * C::N3 : 0, qs = sgs * nvar;
+    hipLaunchKernelGGL((expfilter_kernel<N, T>), dim3((unsigned)grid, (unsigned)npanels), dim3(C::BS), 0, st,
+                       static_cast<const T*>(q), static_cast<T*>(out), sg, f, nvar, nelem, flag, qs, sgs);
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
 }
 
 template <typename T>
 static wx_status dispatch_filter(int n, const void* q, void* out, const double* sg, const double* f, int nvar,
-                                 size_t nelem, int* flag, hipStream_t st) {
+                                 size_t nelem, int* flag, int npanels, hipStream_t st) {
     switch (n) {
-        case 2: return launch_filter<2, T>(q, out, sg, f, nvar, nelem, flag, st);
-        case 3: return launch_filter<3, T>(q, out, sg, f, nvar, nelem, flag, st);
-        case 4: return launch_filter<4, T>(q, out, sg, f, nvar, nelem, flag, st);
-        case 5: return launch_filter<5, T>(q, out, sg, f, nvar, nelem, flag, st);
-        case 6: return launch_filter<6, T>(q, out, sg, f, nvar, nelem, flag, st);
-        case 7: return launch_filter<7, T>(q, out, sg, f, nvar, nelem, flag, st);
-        case 8: return launch_filter<8, T>(q, out, sg, f, nvar, nelem, flag, st);
+        case 2: return launch_filter<2, T>(q, out, sg, f, nvar, nelem, flag, npanels, st);
+        case 3: return launch_filter<3, T>(q, out, sg, f, nvar, nelem, flag, npanels, st);
+        case 4: return launch_filter<4, T>(q, out, sg, f, nvar, nelem, flag, npanels, st);
+        case 5: return launch_filter<5, T>(q, out, sg, f, nvar, nelem, flag, npanels, st);
+        case 6: return launch_filter<6, T>(q, out, sg, f, nvar, nelem, flag, npanels, st);
+        case 7: return launch_filter<7, T>(q, out, sg, f, nvar, nelem, flag, npanels, st);
+        case 8: return launch_filter<8, T>(q, out, sg, f, nvar, nelem, flag, npanels, st);
     }
     return fail(WX_ERR_UNSUPPORTED, "num_solpts %d not in 2..8", n);
 }
@@ -165,17 +170,31 @@ wx_status wx_expfilter_destroy(wx_expfilter* h) {
     return WX_OK;
 }
 
+static wx_status expfilter_apply_impl(const wx_expfilter* h, const void* q, void* out, const double* sqrtG, int nvar,
+                                      size_t nelem, int npanels, wx_dtype dtype, int* nan_flag, wx_stream stream);
+
 wx_status wx_expfilter_apply(const wx_expfilter* h, const void* q, void* out, const double* sqrtG, int nvar, size_t nelem,
                              wx_dtype dtype, int* nan_flag, wx_stream stream) {
+    return expfilter_apply_impl(h, q, out, sqrtG, nvar, nelem, 1, dtype, nan_flag, stream);
+}
+
+wx_status wx_expfilter_apply_stacked(const wx_expfilter* h, const void* q, void* out, const double* sqrtG, int nvar,
+                                     size_t nelem, int npanels, wx_dtype dtype, int* nan_flag, wx_stream stream) {
+    if (npanels < 1 || npanels > 65535) return fail(WX_ERR_INVALID, "npanels %d not in 1..65535", npanels);
+    return expfilter_apply_impl(h, q, out, sqrtG, nvar, nelem, npanels, dtype, nan_flag, stream);
+}
+
+static wx_status expfilter_apply_impl(const wx_expfilter* h, const void* q, void* out, const double* sqrtG, int nvar,
+                                      size_t nelem, int npanels, wx_dtype dtype, int* nan_flag, wx_stream stream) {
     if (!h || !q || !out || !sqrtG) return fail(WX_ERR_INVALID, "wx_expfilter_apply: null argument");
     if (nvar < 1 || nvar > kFilterMaxVar) return fail(WX_ERR_INVALID, "nvar %d not in 1..%d", nvar, kFilterMaxVar);
     if (nelem == 0) return WX_OK;
     if (nelem > 0x7fffffffu) return fail(WX_ERR_INVALID, "too many elements for one launch");
     hipStream_t st = static_cast<hipStream_t>(stream);
     // the filter is linear with real coefficients: dual numbers filter component-wise, like complex ones
-    if (dtype == WX_F64) return dispatch_filter<double>(h->n, q, out, sqrtG, h->filter, nvar, nelem, nan_flag, st);
+    if (dtype == WX_F64) return dispatch_filter<double>(h->n, q, out, sqrtG, h->filter, nvar, nelem, nan_flag, npanels, st);
     if (dtype == WX_C128 || dtype == WX_DUAL128)
-        return dispatch_filter<cplx>(h->n, q, out, sqrtG, h->filter, nvar, nelem, nan_flag, st);
+        return dispatch_filter<cplx>(h->n, q, out, sqrtG, h->filter, nvar, nelem, nan_flag, npanels, st);
     return fail(WX_ERR_INVALID, "unknown dtype %d", (int)dtype);
 }
 

@@ -82,6 +82,11 @@ class ExpFilter3D:
             if s.dtype != torch.float64 or not s.is_cuda or s.numel() % self.n**3:
                 raise TypeError("sqrtG must be float64 device tensors of whole elements")
         self.nan_flag = nan_flag
+        # small tiles (launch-bound): one launch for all of them, on a stacked copy of sqrtG
+        self.sqrtG_all = None
+        if len(self.sqrtG) > 1 and sum(s.numel() for s in self.sqrtG) <= 12_000_000 \
+                and all(s.numel() == self.sqrtG[0].numel() for s in self.sqrtG):
+            self.sqrtG_all = torch.stack([s.reshape(-1) for s in self.sqrtG]).contiguous()
         self._h = ctypes.c_void_p()
         check(self.lib.wx_expfilter_create(ctypes.byref(self._h), self.n,
                                            F.ctypes.data_as(ctypes.POINTER(ctypes.c_double))), "wx_expfilter_create")
@@ -107,6 +112,13 @@ class ExpFilter3D:
         qf, of = Q.reshape(np_, per), out.reshape(np_, per)
         st = torch.cuda.current_stream(Q.device).cuda_stream
         flag = self.nan_flag.ptr() if self.nan_flag is not None else None
+        if self.sqrtG_all is not None and per % self.sqrtG[0].numel() == 0:
+            sg0 = self.sqrtG[0]
+            check(self.lib.wx_expfilter_apply_stacked(self._h, qf.data_ptr(), of.data_ptr(), self.sqrtG_all.data_ptr(),
+                                                      per // sg0.numel(), sg0.numel() // self.n**3, np_, _DT[Q.dtype], flag,
+                                                      st), "wx_expfilter_apply_stacked")
+            torch.autograd.graph.increment_version(out)
+            return out
         for i, sg in enumerate(self.sqrtG):
             nvar = per // sg.numel()
             if nvar * sg.numel() != per:

@@ -163,7 +163,9 @@ class StepLoop:
             filt.nan_flag = nan_flag
         # a pipelined SSP-RK3 can filter (and NaN-check) inside its last stage's kernel
         self.fused = False
-        if filt is not None and isinstance(stepper, Tvdrk3) and stepper.pipeline and not stepper.fused_filter \
+        small = bool(getattr(getattr(stepper, "rhs", None), "_small_tiles", lambda: False)())
+        # (small tiles are launch-bound: batched stages + one stacked filter launch beat the per-tile fused kernels)
+        if filt is not None and isinstance(stepper, Tvdrk3) and stepper.pipeline and not stepper.fused_filter and not small \
                 and hasattr(stepper.rhs, "set_exp_filter") and getattr(filt, "matrix", None) is not None:
             stepper.rhs.set_exp_filter(filt.matrix)
             stepper.final_filter, stepper.nan_flag, stepper.fused_filter = filt, nan_flag, True
