@@ -11,7 +11,7 @@ all five variables, already rotated and flipped by the pack kernel (wx_euler3d_e
   send/recv over xGMI on GPUs, gloo on CPU) issued asynchronously so the interior elements
   are computed while it is in flight.
 """
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Tuple
 
 import torch
 import torch.distributed as dist

@@ -10,7 +10,7 @@ import ctypes
 import math
 import os
 import weakref
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, Optional, Sequence
 
 import numpy
 import torch

@@ -6,14 +6,13 @@ configuration text.  With one tile per panel the global array is the panels stac
 (what process_topology.py:444-469 `gather_cube` produces on 6 ranks), so files written here restart a
 WxFactory run at any rank count and vice versa (reference tests/unit/restart/test_restart.py:107-151).
 """
-import io
 from typing import List, Optional, Tuple
 
 import numpy
 import torch
 import torch.distributed as dist
 
-from .panels import owner_of_panels, panels_of_rank
+from .panels import panels_of_rank
 
 
 def save_state(state, state_version, config_content: str, output_file_name: str) -> None:
