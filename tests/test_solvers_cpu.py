@@ -1,0 +1,160 @@
+"""Host logic of the Krylov solvers (wxfactory_amd/solvers.py) on CPU tensors against dense linear algebra:
+kiops (reference solvers/kiops.py:10-347) against the phi functions from one matrix exponential of the augmented
+matrix, fgmres (solvers/fgmres.py:97-276) against numpy.linalg.solve; on one rank and with the vectors split over
+two gloo ranks (the reference's MPI allreduce in global_operations.py:14-36)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from scipy.linalg import expm
+
+
+def _problem(n=96, p=3, seed=3):
+    rng = np.random.default_rng(seed)
+    A = -np.diag(rng.uniform(0.1, 6.0, n)) + 0.4 * rng.standard_normal((n, n)) / np.sqrt(n)
+    A = A + 2.0 * (np.triu(rng.standard_normal((n, n)), 1) - np.triu(rng.standard_normal((n, n)), 1).T) / np.sqrt(n)
+    u = rng.standard_normal((p + 1, n)) * (10.0 ** rng.uniform(-2, 2, (p + 1, 1)))
+    return A, u
+
+
+def _phi_exact(A, u, tau):
+    """sum_k tau^k phi_k(tau A) u_k = [I 0] exp(tau [[A, B], [0, K]]) [u_0; e_p]  (Al-Mohy & Higham 2011, thm 2.1)"""
+    n, p = A.shape[0], u.shape[0] - 1
+    big = np.zeros((n + p, n + p))
+    big[:n, :n] = A
+    big[:n, n:] = u[:0:-1].T
+    big[n:, n:] = np.diag(np.ones(p - 1), 1)
+    v = np.concatenate([u[0], np.zeros(p)])
+    v[-1] = 1.0
+    return (expm(tau * big) @ v)[:n]
+
+
+@pytest.mark.parametrize("p", [1, 3])
+@pytest.mark.parametrize("taus", [[1.0], [0.25, 0.6, 1.0]])
+def test_kiops_against_dense_phi(p, taus):
+    from wxfactory_amd.solvers import kiops
+
+    A, u = _problem(p=p)
+    At = torch.from_numpy(A)
+    calls = [0]
+
+    def matvec(v):
+        calls[0] += 1
+        return At @ v
+
+    w, stats = kiops(taus, matvec, torch.from_numpy(u), tol=1e-10, m_init=8, mmin=8, mmax=48)
+    assert w.shape == (len(taus), A.shape[0])
+    for k, tau in enumerate(taus):
+        ref = _phi_exact(A, u, tau)
+        err = np.abs(w[k].numpy() - ref).max() / np.abs(ref).max()
+        assert err < 1e-8, (k, tau, err, stats)
+    assert stats[2] == calls[0] and stats[0] >= 1 and stats[4] < 1e-8
+
+
+def test_kiops_single_vector_and_task1():
+    """u with one row (p = 0): exp(tau A) u_0; task1 divides each output by its tau (kiops.py:341-344)."""
+    from wxfactory_amd.solvers import kiops
+
+    A, u = _problem(p=1)
+    w, _ = kiops([0.5, 1.0], lambda v: torch.from_numpy(A) @ v, torch.from_numpy(u[:1]), tol=1e-10, m_init=10, mmax=40)
+    for k, tau in enumerate([0.5, 1.0]):
+        ref = expm(tau * A) @ u[0]
+        assert np.abs(w[k].numpy() - ref).max() < 1e-8 * np.abs(ref).max()
+    w1, _ = kiops([0.5, 1.0], lambda v: torch.from_numpy(A) @ v, torch.from_numpy(u[:1]), tol=1e-10, m_init=10, mmax=40,
+                  task1=True)
+    assert torch.allclose(w1[0] * 0.5, w[0], rtol=1e-12, atol=0) and torch.allclose(w1[1], w[1], rtol=1e-12, atol=0)
+
+
+def test_kiops_happy_breakdown():
+    """A Krylov space that closes after a few vectors (u in a 4-dimensional invariant subspace): the exact answer,
+    with fewer matvecs than the requested basis size."""
+    from wxfactory_amd.solvers import kiops
+
+    n = 40
+    lam = -np.linspace(0.5, 3.0, n)
+    u = np.zeros((2, n))
+    u[1, [1, 5, 9, 20]] = [1.0, -2.0, 0.5, 3.0]
+    calls = [0]
+
+    def matvec(v):
+        calls[0] += 1
+        return torch.from_numpy(lam) * v
+
+    w, stats = kiops([1.0], matvec, torch.from_numpy(u), tol=1e-9, m_init=12, mmin=12, mmax=30)
+    ref = (np.expm1(lam) / lam) * u[1]
+    assert np.abs(w[0].numpy() - ref).max() < 1e-10
+    assert stats[0] == 1 and stats[2] <= 6, stats
+
+
+def test_fgmres_against_dense_solve():
+    from wxfactory_amd.solvers import fgmres
+
+    A, u = _problem(n=80)
+    M = np.eye(80) - 0.3 * A
+    x, norm_r, norm_b, niter, flag, res = fgmres(lambda v: torch.from_numpy(M) @ v, torch.from_numpy(u[0]), tol=1e-11,
+                                                 restart=25, maxiter=20)
+    ref = np.linalg.solve(M, u[0])
+    assert flag == 0 and np.abs(x.numpy() - ref).max() < 1e-8 * np.abs(ref).max()
+    assert float(norm_r) / float(norm_b) < 1e-11 and 0 < niter <= len(res)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _split_worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from wxfactory_amd.solvers import fgmres, kiops
+
+        A, u = _problem(p=2)
+        n = A.shape[0]
+        lo, hi = rank * n // world, (rank + 1) * n // world
+        Arows = torch.from_numpy(A[lo:hi])
+
+        def gather(v):
+            parts = [torch.empty(((r + 1) * n // world - r * n // world,), dtype=v.dtype) for r in range(world)]
+            dist.all_gather(parts, v.contiguous())
+            return torch.cat(parts)
+
+        w, stats = kiops([0.5, 1.0], lambda v: Arows @ gather(v), torch.from_numpy(u[:, lo:hi].copy()), tol=1e-10,
+                         m_init=8, mmin=8, mmax=48)
+        for k, tau in enumerate([0.5, 1.0]):
+            ref = _phi_exact(A, u, tau)
+            err = np.abs(w[k].numpy() - ref[lo:hi]).max() / np.abs(ref).max()
+            assert err < 1e-8, (rank, k, err, stats)
+        Mrows = torch.from_numpy((np.eye(n) - 0.3 * A)[lo:hi])
+        x, norm_r, norm_b, niter, flag, _ = fgmres(lambda v: Mrows @ gather(v), torch.from_numpy(u[0, lo:hi].copy()),
+                                                   tol=1e-11, restart=25, maxiter=20)
+        ref = np.linalg.solve(np.eye(n) - 0.3 * A, u[0])
+        assert flag == 0 and np.abs(x.numpy() - ref[lo:hi]).max() < 1e-8 * np.abs(ref).max()
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok", stats))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, traceback.format_exc(), None))
+        raise
+
+
+def test_solvers_with_vectors_split_over_gloo_ranks():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_split_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=180) for _ in range(world)]
+    [p.join(timeout=60) for p in procs]
+    assert all(r[1] == "ok" for r in res), [r for r in res if r[1] != "ok"]
+    assert res[0][2] == res[1][2]  # every rank took the same adaptive decisions
