@@ -118,7 +118,8 @@ def ini_size_extras(dev, seed):
     from wxfactory_amd import synthetic
 
     out = {}
-    for label, case, n, H, V, ztop in (("dcmip31.ini", 31, 2, 12, 3, 10000.0), ("dcmip21.ini", 21, 3, 3, 4, 30000.0)):
+    for label, case, n, H, V, ztop, dt_ini in (("dcmip31.ini", 31, 2, 12, 3, 10000.0, 30.0),
+                                               ("dcmip21.ini", 21, 3, 3, 4, 30000.0, 25.0)):
         topo = topography_for_case(case, planet_for_case(case)[0])
         plans, q = {}, []
         for p in range(6):
@@ -143,6 +144,18 @@ def ini_size_extras(dev, seed):
         out[label] = {"n": n, "elements_per_panel": [H, H, V], "dof": Q.numel(), "rhs_us": clock(lambda: rhs(Q)),
                       "matvec_complex_us": clock(lambda: matvec_fun(v, 1.0, Q, R, rhs, "complex")),
                       "matvec_rat_us": clock(lambda: matvec_rat(v, 1.0, Q, R, rhs))}
+        # the step both files configure: time_integrator = epi2 (KIOPS + complex-step JVP), tolerance 1e-7, their dt
+        from wxfactory_amd.integrators import Epi
+
+        epi, Qs, ts = Epi(2, rhs, tol=1e-7), Q, []
+        for i in range(8):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            Qs = epi.step(Qs, dt_ini)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        out[label].update(epi2_dt_s=dt_ini, epi2_step_ms=round(sorted(ts[3:])[2] * 1e3, 2),
+                          epi2_krylov_vectors=int(epi.solver_info["iterations"]))
     return out
 
 

@@ -52,12 +52,14 @@ class _Basis:
             self.check = _lib.check
             self.work = torch.empty(int(self.lib.wx_multi_dot_workspace(V.shape[0])), dtype=torch.float64, device=V.device)
 
-    def dots(self, lo: int, hi: int, w: torch.Tensor) -> torch.Tensor:
-        """<V[k], w> for lo <= k < hi (device tensor)."""
+    def dots(self, lo: int, hi: int, w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """<V[k, :len(w)], w> for lo <= k < hi (device tensor; written to `out` when given)."""
         V = self.V
-        if not (self.gpu and w.is_contiguous()):
-            return V[lo:hi] @ w
-        out = torch.empty(hi - lo, dtype=torch.float64, device=V.device)
+        if not (self.gpu and w.is_contiguous() and (out is None or out.is_contiguous())):
+            Vw = V[lo:hi] if w.numel() == V.shape[1] else V[lo:hi, : w.numel()]
+            return torch.mv(Vw, w, out=out) if out is not None else Vw @ w
+        if out is None:
+            out = torch.empty(hi - lo, dtype=torch.float64, device=V.device)
         st = torch.cuda.current_stream(V.device).cuda_stream
         self.check(self.lib.wx_multi_dot(V[lo].data_ptr(), V.stride(0), hi - lo, w.data_ptr(), w.numel(), out.data_ptr(),
                                          self.work.data_ptr(), st), "wx_multi_dot")
@@ -127,11 +129,10 @@ def fgmres(A: Callable, b: torch.Tensor, x0: Optional[torch.Tensor] = None, tol:
             w = basis.subtract(w, 0, j + 1, h)
             h2 = _allreduce(basis.dots(0, j + 1, w), group)
             w = basis.subtract(w, 0, j + 1, h2)
-            h = h + h2
-            hn = float(global_norm(w, group))
-            hj = h.tolist() + [hn]
-            if hn != 0.0:
-                torch.div(w, hn, out=V[j + 1])
+            hn_d = global_norm(w, group)
+            torch.div(w, hn_d, out=V[j + 1])  # (enqueued before the one host read of this iteration; void if hn == 0)
+            hj = torch.cat((h + h2, hn_d.reshape(1))).tolist()
+            hn = hj[-1]
             for i in range(j):  # previous rotations
                 t = cs[i] * hj[i] + sn[i] * hj[i + 1]
                 hj[i + 1] = -sn[i] * hj[i] + cs[i] * hj[i + 1]
@@ -176,6 +177,28 @@ def fgmres(A: Callable, b: torch.Tensor, x0: Optional[torch.Tensor] = None, tol:
     return x, norm_r, norm_b, niter, (0 if norm_r < tol_abs else -1), residuals
 
 
+_blas_threads = None
+
+
+def _expm(M):
+    """scipy.linalg.expm of a small dense matrix with the BLAS thread pool held to one thread: these matrices are
+    at most 129 x 129, and waking a many-thread pool for them costs up to 1000x the computation on a busy host."""
+    global _blas_threads
+    from scipy.linalg import expm
+
+    if _blas_threads is None:
+        try:
+            from threadpoolctl import ThreadpoolController
+
+            _blas_threads = ThreadpoolController()
+        except ImportError:  # pragma: no cover
+            _blas_threads = False
+    if not _blas_threads:
+        return expm(M)
+    with _blas_threads.limit(limits=1, user_api="blas"):
+        return expm(M)
+
+
 def _log(x: float) -> float:
     """numpy.log on a float: -inf at 0, nan below, inf at inf (math.log raises instead; the reference's adaptivity
     formulas rely on the IEEE behaviour when an error estimate under- or overflows)."""
@@ -202,14 +225,16 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
 
     Same signature, adaptivity rules and `stats` tuple as reference wx_factory/solvers/kiops.py:10-347
     (KIOPS: Gaudreault, Rainwater, Tokman, J. Comput. Phys. 2018; after phipm, Niesen & Wright 2012).
-    Layout here: the n-long parts of the Krylov basis live on the GPU (`Vd`), the p augmented
-    components and the Hessenberg matrix on the host; each Krylov vector costs one matvec (= one
-    RHS evaluation through `A`), two fused reductions (iop dot products, norm) and no other sync;
-    the (m+1)x(m+1) matrix exponential runs on the host (scipy), as in the reference.
+    Layout here: the Krylov basis (the n-long parts and the p augmented components, rows of n+p) and the
+    Hessenberg matrix (transposed: a column's entries are contiguous) live on the GPU; building a Krylov
+    vector costs one matvec (= one RHS evaluation through `A`), two fused reductions (iop dot products,
+    norm) and a few vector kernels, with NO host synchronisation: the host reads the new Hessenberg columns
+    once per pass of m vectors and detects a happy breakdown then (vectors built past it are discarded).
+    With the vectors split over ranks the augmented components are replicated and enter the products once,
+    after the all-reduce.  The (m+1)x(m+1) matrix exponential runs on the host (scipy), as in the reference.
     Returns (w, (steps, rejected, krylov_steps, exps, error_estimate, last_m)).
     """
     import numpy as np
-    from scipy.linalg import expm
 
     dev, dtype = u.device, u.dtype
     tau_out = [float(t) for t in tau_out]
@@ -219,10 +244,20 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
         p = 1
         u = torch.cat((u, torch.zeros((1, n), dtype=dtype, device=dev)))
     m = max(mmin, min(m_init, mmax))
-    Vd = torch.zeros((mmax + 1, n), dtype=dtype, device=dev)
+    Vd = torch.empty((mmax + 1, n + p), dtype=dtype, device=dev)  # (every row is written before it is read)
     basis = _Basis(Vd)
-    Va = np.zeros((mmax + 1, p))
+    Ht = torch.empty((mmax + 1, mmax + 1), dtype=dtype, device=dev)  # Ht[c, r] = H[r, c], written entries only
+    nrm2 = torch.empty(1, dtype=dtype, device=dev)
     H = np.zeros((mmax + 1, mmax + 1))
+    split = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+    def products(lo: int, hi: int, j: int, out: torch.Tensor):
+        """out[k - lo] = <V[k], V[j]> over the n + p components, lo <= k < hi"""
+        if not split:
+            return basis.dots(lo, hi, Vd[j], out=out)
+        t = _allreduce(basis.dots(lo, hi, Vd[j, :n]), group)
+        return torch.addmv(t, Vd[lo:hi, n:], Vd[j, n:], out=out)
+
     step = krystep = ireject = reject = exps = 0
     sgn = math.copysign(1.0, tau_out[-1])
     tau_now, tau_end = 0.0, abs(tau_out[-1])
@@ -238,7 +273,8 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
         nu, mu = 2.0 ** (-ex), 2.0 ** ex
     else:
         nu = mu = 1.0
-    u_flip = nu * torch.flipud(u[1:])
+    u_flip_t = (nu * torch.flipud(u[1:])).t()
+    shift = torch.diag(torch.ones(p - 1, dtype=dtype, device=dev), 1)
     tau = tau_end
     gamma, gamma_mmax = (0.2, 0.1) if tau_end > 1 else (0.9, 0.6)
     delta = 1.4
@@ -249,37 +285,42 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
     beta = 1.0
     while tau_now < tau_end:
         if j == 0:
-            Vd[0] = w[l]
-            Va[0, :] = 0.0
+            va0 = np.zeros(p)
             for k in range(p - 1):
                 i = p - k + 1
-                Va[0, k] = (tau_now ** i) / math.factorial(i) * mu
-            Va[0, p - 1] = mu
-            beta = math.sqrt(float(global_dotprod(Vd[0], Vd[0], group)) + float(Va[0] @ Va[0]))
+                va0[k] = (tau_now ** i) / math.factorial(i) * mu
+            va0[p - 1] = mu
+            Vd[0, :n] = w[l]
+            Vd[0, n:] = torch.as_tensor(va0, dtype=dtype, device=dev)
+            beta = math.sqrt(float(global_dotprod(Vd[0, :n], Vd[0, :n], group)) + float(va0 @ va0))
             Vd[0] /= beta
-            Va[0] /= beta
+        j0 = j
         while j < m:
             j += 1
-            Vd[j] = A(Vd[j - 1]) + torch.as_tensor(Va[j - 1], dtype=dtype, device=dev) @ u_flip
-            Va[j, : p - 1] = Va[j - 1, 1:p]
-            Va[j, p - 1] = 0.0
+            torch.addmv(A(Vd[j - 1, :n]), u_flip_t, Vd[j - 1, n:], out=Vd[j, :n])
+            torch.mv(shift, Vd[j - 1, n:], out=Vd[j, n:])  # augmented components: up by one, zero at the end
             ilow = max(0, j - iop)
-            hcol = _allreduce(basis.dots(ilow, j, Vd[j]), group).cpu().numpy() + Va[ilow:j] @ Va[j]
-            H[ilow:j, j - 1] = hcol
-            basis.subtract(Vd[j], ilow, j, torch.as_tensor(hcol, dtype=dtype, device=dev))
-            Va[j] -= hcol @ Va[ilow:j]
-            nrm = math.sqrt(float(global_dotprod(Vd[j], Vd[j], group)) + float(Va[j] @ Va[j]))
-            if nrm < tol:
-                happy = True
-                break
-            H[j, j - 1] = nrm
-            Vd[j] /= nrm
-            Va[j] /= nrm
-            krystep += 1
+            hcol = Ht[j - 1]  # column j-1 of H: entries ilow..j-1, then the norm at j
+            products(ilow, j, j, hcol[ilow:j])
+            basis.subtract(Vd[j], ilow, j, hcol[ilow:j])
+            products(j, j + 1, j, nrm2)
+            torch.sqrt(nrm2, out=hcol[j : j + 1])
+            Vd[j] /= hcol[j]
+        if j > j0:
+            Hh = Ht[j0:j, : j + 1].cpu().numpy()  # the one synchronisation of the pass
+            for c in range(j0, j):
+                il = max(0, c + 1 - iop)
+                H[il : c + 1, c] = Hh[c - j0, il : c + 1]
+                if Hh[c - j0, c + 1] < tol:  # happy breakdown at vector c+1: the rest of the pass is void
+                    happy = True
+                    j = c + 1
+                    break
+                H[c + 1, c] = Hh[c - j0, c + 1]
+                krystep += 1
         H[0, j] = 1.0
         nrm = H[j, j - 1]
         H[j, j - 1] = 0.0
-        F = expm(sgn * tau * H[: j + 1, : j + 1])
+        F = _expm(sgn * tau * H[: j + 1, : j + 1])
         exps += 1
         H[j, j - 1] = nrm
         if happy:
@@ -337,10 +378,10 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
             if blown != 0:
                 w[l + blown] = w[l]
                 for k in range(blown):
-                    F2 = expm(sgn * (tau_out[l + k] - tau_now) * H[:j, :j])
-                    w[l + k] = torch.as_tensor(beta * F2[:j, 0], dtype=dtype, device=dev) @ Vd[:j]
+                    F2 = _expm(sgn * (tau_out[l + k] - tau_now) * H[:j, :j])
+                    w[l + k] = torch.as_tensor(beta * F2[:j, 0], dtype=dtype, device=dev) @ Vd[:j, :n]
                 l += blown
-            w[l] = torch.as_tensor(beta * F[:j, 0], dtype=dtype, device=dev) @ Vd[:j]
+            w[l] = torch.as_tensor(beta * F[:j, 0], dtype=dtype, device=dev) @ Vd[:j, :n]
             tau_now += tau
             j = 0
             ireject = 0
