@@ -190,6 +190,33 @@ def extras(dev, seed):
                               "bound (5.5 MB of state per panel)"}}
 
 
+def e7_v1_extras(dev, seed, n=8, H=60):
+    """E7 is reported at V in {1, 8}; the headline is V = 8, this is the whole-sphere R(Q) at V = 1
+    (one vertical element, 8 levels; 6 x 1.8 M points: the six panels go in one launch per phase)."""
+    from wxfactory_amd import synthetic
+    from wxfactory_amd.geometry3d import CubedSphere3DTile, metric3d_torch
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D
+
+    ops = synthetic.dfr_ops(n)
+    plans = {p: Euler3DPlan(n, H, 1, 31, p, ops, metric3d_torch(CubedSphere3DTile(n, H, 1, p, 10000.0, 31), dev))
+             for p in range(6)}
+    Q = torch.stack([synthetic.euler3d_state(n, H, 1, p, dev, seed) for p in range(6)])
+    rhs = RhsEuler3D(plans)
+    for _ in range(5):
+        rhs(Q)
+    torch.cuda.synchronize()
+    reps = 50
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        rhs(Q)
+    torch.cuda.synchronize()
+    te = (time.perf_counter() - t0) / reps
+    pts = 6 * H * H * n**3
+    return {"workload": f"E7 at V=1: n={n}, {H}x{H}x1 elements/panel, 6 panels ({5*pts} DOF), whole-sphere R(Q)",
+            "ms_per_eval": round(te * 1e3, 4), "dof_updates_per_s": 5 * pts / te,
+            "algorithmic_GBps": round(plans[0].bytes_per_point * pts / te / 1e9, 1)}
+
+
 def caller_extras(rhs, qs, reps=5):
     """the JVP variants and one explicit step on the SAME plans / metric as the headline (N = 1)."""
     from wxfactory_amd.integrators import Tvdrk3
@@ -392,6 +419,9 @@ def main():
             line["extra"] = extras(dev, args.seed)
             line["extra"]["euler_callers"] = caller_extras(rhs, qs)
             line["extra"]["euler_ini_sizes"] = ini_size_extras(dev, args.seed)
+            del rhs, qs, plans, out
+            torch.cuda.empty_cache()
+            line["extra"]["euler_e7_v1"] = e7_v1_extras(dev, args.seed)
         if args.gpus == 1 and not args.no_cpu_baseline:
             sample_H = 30
             v, secs = cpu_baseline(n, V, sample_H, reps=3, seed=args.seed)

@@ -780,6 +780,10 @@ CASES = {
     "euler3d_c31_n8_h2_v2": lambda nm: euler_case(
         nm, "dcmip31.ini", dict(num_solpts=8, num_elements_horizontal=2, num_elements_vertical=2),
         metric_panels=(0, 4), phase_panels=()),
+    # one vertical element (E7 is reported at V in {1, 8}): both vertical faces of every element are walls
+    "euler3d_c31p_n5_h2_v1": lambda nm: euler_case(
+        nm, "dcmip31.ini", dict(num_solpts=5, num_elements_horizontal=2, num_elements_vertical=1),
+        metric_panels=(1, 5), phase_panels=(), perturb=0.01),
     # topography + Rayleigh damping (Schaer mountain), even n
     "euler3d_c21_n4_h3_v4": lambda nm: euler_case(
         nm, "dcmip21.ini", dict(num_solpts=4, num_elements_horizontal=3, num_elements_vertical=4),

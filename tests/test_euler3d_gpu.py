@@ -247,7 +247,8 @@ def _scale_tile(g, t, topo):
     return o.cancel_scale(want)
 
 
-@pytest.mark.parametrize("name,ztop", [("euler3d_c21_n4_h3_v4", 30000.0), ("euler3d_c31p_n8_h2_v2", 10000.0)])
+@pytest.mark.parametrize("name,ztop", [("euler3d_c21_n4_h3_v4", 30000.0), ("euler3d_c31p_n8_h2_v2", 10000.0),
+                                       ("euler3d_c31p_n5_h2_v1", 10000.0)])
 def test_rhs_with_own_geometry_and_metric(name, ztop):
     """End to end without any reference-supplied array but the state: geometry3d builds the metric of all six
     panels (Schaer mountain + sponge for case 21), the kernels evaluate R(Q), the reference's R is the check."""

@@ -11,6 +11,7 @@ EULER_FIXTURES = [
     "euler3d_c31p_n8_h2_v2",
     "euler3d_c31_n8_h2_v2",
     "euler3d_c21_n4_h3_v4",
+    "euler3d_c31p_n5_h2_v1",
 ]
 
 _cache = {}
