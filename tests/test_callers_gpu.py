@@ -266,3 +266,28 @@ def test_hipgraph_captured_matvec(setup):
         # launch-bound at this size.  (With the tiles batched into two launches per product the eager call is
         # already down from ~190 us to ~30 us; the replay then saves only the Python / ctypes overhead.)
         assert tg < 2.0 * te
+
+
+@pytest.mark.parametrize("order", [3, 4, 6])
+def test_multistep_epi_orders(built_lib, order):
+    """EPI of orders 3, 4 and 6 (integrators/epi.py:28-141): start-up steps by EPI2, then two regular steps whose
+    phi-vectors are assembled from the previous states; KIOPS runs with 2-4 augmented components on the GPU.
+    Against the reference's own epi.py + kiops.py from the same state (both sides converge each step to tol 1e-7)."""
+    from tests.gpu_util import device_metric
+    from wxfactory_amd.integrators import Epi
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D
+
+    g = Golden("epi_multistep_n3_h2_v2")
+    plans = {p: Euler3DPlan(g.n, g.H, g.V, g.case, p, g.ops, device_metric(g, p, DEV)) for p in range(6)}
+    rhs = RhsEuler3D(plans)
+    stack = lambda key: torch.from_numpy(np.stack([g[f"p{p}/{key}"] for p in range(6)])).to(DEV)  # noqa: E731
+    Q0, dt = stack("Q"), float(g["meta/dt"])
+    epi, Q = Epi(order, rhs, tol=1e-7), Q0
+    assert epi.n_prev == {3: 1, 4: 2, 6: 4}[order] and epi.max_phi == {3: 2, 4: 3, 6: 4}[order]
+    for _ in range(int(g[f"meta/steps_epi{order}"])):
+        Q = epi.step(Q, dt)
+    ref, q0 = stack(f"epi{order}").cpu().numpy(), Q0.cpu().numpy()
+    ax = (0, 2, 3, 4, 5)
+    upd = np.abs(ref - q0).max(axis=ax)
+    err = np.abs(Q.cpu().numpy() - ref).max(axis=ax)
+    assert (err <= 2e-5 * upd + 1e-13 * np.abs(ref).max(axis=ax)).all(), (err / upd)
