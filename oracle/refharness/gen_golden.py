@@ -497,7 +497,7 @@ def callers_case(name, ini, overrides, dt_rk=2.0, dt_jvp=30.0, perturb=0.01, see
     _run6(name, work)
 
 
-def epi_case(name, ini, overrides, orders=(3, 4, 6), extra_steps=2, dt=30.0, perturb=0.01, seed=999):
+def epi_case(name, ini, overrides, orders=(3, 4, 5, 6), extra_steps=2, dt=30.0, perturb=0.01, seed=999):
     """Multistep EPI integrators (integrators/epi.py:28-141): for each order, n_prev start-up steps (EPI2) plus
     `extra_steps` regular steps from the same perturbed state; pins the coefficient tables, the phi-vector
     assembly from previous states and KIOPS with several phi functions."""
@@ -855,7 +855,7 @@ CASES = {
     # callers: one SSP-RK3 step, JVPs (complex step / finite difference), Rosenbrock operator, Ros2 step
     "callers_euler3d_n3_h3_v2": lambda nm: callers_case(
         nm, "dcmip31.ini", dict(num_solpts=3, num_elements_horizontal=3, num_elements_vertical=2)),
-    # multistep exponential integrators (orders 3, 4, 6) over their start-up and two regular steps
+    # multistep exponential integrators (orders 3 to 6) over their start-up and two regular steps
     "epi_multistep_n3_h2_v2": lambda nm: epi_case(
         nm, "dcmip31.ini", dict(num_solpts=3, num_elements_horizontal=2, num_elements_vertical=2)),
     "state_file_v": state_file_case,

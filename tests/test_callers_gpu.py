@@ -268,9 +268,9 @@ def test_hipgraph_captured_matvec(setup):
         assert tg < 2.0 * te
 
 
-@pytest.mark.parametrize("order", [3, 4, 6])
+@pytest.mark.parametrize("order", [3, 4, 5, 6])
 def test_multistep_epi_orders(built_lib, order):
-    """EPI of orders 3, 4 and 6 (integrators/epi.py:28-141): start-up steps by EPI2, then two regular steps whose
+    """EPI of orders 3 to 6 (integrators/epi.py:28-141): start-up steps by EPI2, then two regular steps whose
     phi-vectors are assembled from the previous states; KIOPS runs with 2-4 augmented components on the GPU.
     Against the reference's own epi.py + kiops.py from the same state (both sides converge each step to tol 1e-7)."""
     from tests.gpu_util import device_metric
@@ -283,7 +283,7 @@ def test_multistep_epi_orders(built_lib, order):
     stack = lambda key: torch.from_numpy(np.stack([g[f"p{p}/{key}"] for p in range(6)])).to(DEV)  # noqa: E731
     Q0, dt = stack("Q"), float(g["meta/dt"])
     epi, Q = Epi(order, rhs, tol=1e-7), Q0
-    assert epi.n_prev == {3: 1, 4: 2, 6: 4}[order] and epi.max_phi == {3: 2, 4: 3, 6: 4}[order]
+    assert epi.n_prev == {3: 1, 4: 2, 5: 3, 6: 4}[order] and epi.max_phi == {3: 2, 4: 3, 5: 4, 6: 4}[order]
     for _ in range(int(g[f"meta/steps_epi{order}"])):
         Q = epi.step(Q, dt)
     ref, q0 = stack(f"epi{order}").cpu().numpy(), Q0.cpu().numpy()
