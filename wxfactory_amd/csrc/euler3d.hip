@@ -255,10 +255,19 @@ __device__ __forceinline__ void load_state<dual>(const EulerParams<dual>& P, siz
     }
 }
 
+#ifndef WX_NT_STORE
+#define WX_NT_STORE 0   // 1: the RHS output leaves with non-temporal stores (measured: see DESIGN 4.1)
+#endif
 template <typename T>
 __device__ __forceinline__ void store_r(const EulerParams<T>& P, size_t i, T r) {
     P.rhs[i] = r;
 }
+#if WX_NT_STORE
+template <>
+__device__ __forceinline__ void store_r<double>(const EulerParams<double>& P, size_t i, double r) {
+    __builtin_nontemporal_store(r, &P.rhs[i]);
+}
+#endif
 template <>
 __device__ __forceinline__ void store_r<dual>(const EulerParams<dual>& P, size_t i, dual r) {
     if (P.jvp) P.out_tan[i] = P.jvp_scale * r.im;
