@@ -158,3 +158,27 @@ def test_solvers_with_vectors_split_over_gloo_ranks():
     [p.join(timeout=60) for p in procs]
     assert all(r[1] == "ok" for r in res), [r for r in res if r[1] != "ok"]
     assert res[0][2] == res[1][2]  # every rank took the same adaptive decisions
+
+
+def test_fgmres_reorthogonalises_after_cancellation(monkeypatch):
+    """An operator close to the identity: A v is almost v, the first Gram-Schmidt pass cancels four digits and
+    the second pass must run (twice the dot-product sweeps); a well-separated operator takes one pass."""
+    from wxfactory_amd import solvers
+
+    calls = [0]
+    orig = solvers._Basis.dots
+
+    def counting(self, lo, hi, w, out=None):
+        calls[0] += 1
+        return orig(self, lo, hi, w, out=out)
+
+    monkeypatch.setattr(solvers._Basis, "dots", counting)
+    A, u = _problem(n=80)
+    for scale, passes in ((1e-4, 2), (1.0, 1)):
+        M = np.eye(80) - scale * A
+        calls[0] = 0
+        x, norm_r, norm_b, niter, flag, _ = solvers.fgmres(lambda v: torch.from_numpy(M) @ v, torch.from_numpy(u[0]),
+                                                          tol=1e-12, restart=30, maxiter=10)
+        ref = np.linalg.solve(M, u[0])
+        assert flag == 0 and np.abs(x.numpy() - ref).max() < 1e-9 * np.abs(ref).max()
+        assert passes * niter - 2 <= calls[0] <= passes * niter, (scale, calls[0], niter)

@@ -35,3 +35,44 @@ for k in (1, 4, 8, 12):
     read = (k + 1) * n * 8 / 1e9
     print(f"{k:2d} rows: multi_dot {td:6.2f} ms ({read / td:5.2f} TB/s; torch mv {tt:6.2f} ms)   "
           f"multi_axpy {ta:6.2f} ms ({(read + n * 8 / 1e9) / ta:5.2f} TB/s; torch w - h @ V {tu:6.2f} ms)", flush=True)
+
+
+if "fgmres" in sys.argv[1:]:
+    # one restart cycle of FGMRES on the Rosenbrock operator of the E7 sphere (matvec_rat; synthetic metric)
+    del V, w, basis
+    torch.cuda.empty_cache()
+    from wxfactory_amd import synthetic  # noqa: E402
+    from wxfactory_amd.matvec import MatvecOpRat  # noqa: E402
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D  # noqa: E402
+    from wxfactory_amd.solvers import fgmres  # noqa: E402
+
+    nn, H, Vv = 8, 60, 8
+    ops = synthetic.dfr_ops(nn)
+    plans = {p: Euler3DPlan(nn, H, Vv, 31, p, ops, synthetic.euler3d_metric(nn, H, Vv, p, dev)) for p in range(6)}
+    Q = torch.stack([synthetic.euler3d_state(nn, H, Vv, p, dev) for p in range(6)])
+    rhs = RhsEuler3D(plans)
+    R = rhs(Q)
+    dt = 0.05
+    A = MatvecOpRat(dt, Q, R, rhs)
+    b = A(Q.flatten()) + R.flatten() * dt
+    from wxfactory_amd import solvers  # noqa: E402
+
+    calls = [0]
+    orig = solvers._Basis.dots
+
+    def counting(self, lo, hi, w, out=None):
+        calls[0] += 1
+        return orig(self, lo, hi, w, out=out)
+
+    solvers._Basis.dots = counting
+    for label, eta in (("warm-up", solvers._REORTH), ("second pass on cancellation", solvers._REORTH),
+                       ("second pass always", 1e30)):
+        solvers._REORTH = eta
+        calls[0] = 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        x, nr, nb, it, flag, res = fgmres(A, b, x0=Q.flatten(), tol=1e-30, restart=20, maxiter=1)
+        torch.cuda.synchronize()
+        t = time.perf_counter() - t0
+        print(f"fgmres restart 20, {label}: {it} iterations, {calls[0]} dot sweeps, {t*1e3:.0f} ms = {t/it*1e3:.1f} ms "
+              f"per iteration (incl. 2 residual evaluations), residual {nr/nb:.3e}", flush=True)

@@ -3,9 +3,10 @@
 global_norm / global_dotprod mirror reference wx_factory/solvers/global_operations.py:14-36 with the
 MPI allreduce replaced by torch.distributed (RCCL).  fgmres keeps the reference's signature and return
 tuple (solvers/fgmres.py:97-276): restarted flexible GMRES, Givens-updated residual, same
-stagnation/convergence flags.  Orthogonalisation is classical Gram-Schmidt applied twice on the
-device (two small fused reductions per Krylov vector) instead of the reference's lagged 1-sync
-variant - the same Krylov iterates up to rounding.
+stagnation/convergence flags.  Orthogonalisation is classical Gram-Schmidt on the device with a
+second pass only after heavy cancellation (one sweep over the basis for the dot products, one for
+the update, one host read per Krylov vector) instead of the reference's lagged 1-sync variant -
+the same Krylov iterates up to rounding.
 """
 import math
 from time import time
@@ -77,6 +78,9 @@ class _Basis:
         return w
 
 
+_REORTH = 0.1  # fgmres: re-orthogonalise when |w - V V^T w| < _REORTH |w| (orthogonality kept to ~1e-15 / _REORTH)
+
+
 def _rotg(a: float, b: float):
     """solvers/fgmres.py:75-94"""
     if b == 0.0:
@@ -124,15 +128,27 @@ def fgmres(A: Callable, b: torch.Tensor, x0: Optional[torch.Tensor] = None, tol:
             if preconditioner is not None:
                 Z[j] = M(V[j])
             w = A(Z[j])
-            # classical Gram-Schmidt, twice; each pass = one sweep for the dots, one for the update
+            # classical Gram-Schmidt, one sweep for the dots and one for the update; a second pass only when the
+            # first one cancelled more than a factor 1/_REORTH of w (then its rounding errors, relative to what is
+            # left, threaten the orthogonality of the basis: Daniel, Gragg, Kaufman & Stewart 1976).  The decision
+            # uses all-reduced numbers, so every rank takes the same one.
+            ww = global_dotprod(w, w, group)
             h = _allreduce(basis.dots(0, j + 1, w), group)
             w = basis.subtract(w, 0, j + 1, h)
-            h2 = _allreduce(basis.dots(0, j + 1, w), group)
-            w = basis.subtract(w, 0, j + 1, h2)
-            hn_d = global_norm(w, group)
-            torch.div(w, hn_d, out=V[j + 1])  # (enqueued before the one host read of this iteration; void if hn == 0)
-            hj = torch.cat((h + h2, hn_d.reshape(1))).tolist()
-            hn = hj[-1]
+            hn2 = global_dotprod(w, w, group)
+            torch.div(w, torch.sqrt(hn2), out=V[j + 1])  # (enqueued before the host read below; void if hn == 0)
+            hj = torch.cat((h, ww.reshape(1), hn2.reshape(1))).tolist()  # the iteration's one host read
+            hn2_h, ww_h = hj.pop(), hj.pop()
+            if hn2_h < _REORTH * _REORTH * ww_h:
+                h2 = _allreduce(basis.dots(0, j + 1, w), group)
+                w = basis.subtract(w, 0, j + 1, h2)
+                hn2 = global_dotprod(w, w, group)
+                torch.div(w, torch.sqrt(hn2), out=V[j + 1])
+                h2 = torch.cat((h2, hn2.reshape(1))).tolist()
+                hn2_h = h2.pop()
+                hj = [a + b for a, b in zip(hj, h2)]
+            hn = math.sqrt(hn2_h)
+            hj.append(hn)
             for i in range(j):  # previous rotations
                 t = cs[i] * hj[i] + sn[i] * hj[i + 1]
                 hj[i + 1] = -sn[i] * hj[i] + cs[i] * hj[i + 1]
