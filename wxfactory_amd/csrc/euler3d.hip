@@ -78,7 +78,33 @@ struct Cfg {
     static constexpr int NP = (N % 2 == 0) ? N + 1 : N;
     static constexpr int LE = N2 * NP;  // doubles per element image
     __host__ __device__ static constexpr int lidx(int kl, int jl, int il) { return (kl * N + jl) * NP + il; }
+    // Alternative image for n = 8 (WX_K2_SWIZZLE): same padded rows, column il of row (kl, jl) kept at
+    // il ^ (jl & 4).  A wave is one k-level of 8 x 8 nodes; its 64 k-line reads (and its plane writes) then fall
+    // on every bank pair exactly twice instead of up to three times (SQ_LDS_BANK_CONFLICT: 25 % of the LDS cycles
+    // of the padded image), while i- and j-line reads stay conflict-free.
+    __host__ __device__ static constexpr int lidx_swz(int kl, int jl, int il) {
+        return (kl * N + jl) * NP + (il ^ (jl & (N / 2)));
+    }
 };
+
+// Node m of the line through node (kl, jl, il) along direction d sits at (m < N/2 ? lo : hi) + m * stride of the
+// element's LDS image; lo == hi in the plain padded image, the swizzled one moves half of an i- or j-line.
+struct LdsLine { int lo, hi, stride; };
+template <int N, bool SWZ>
+__device__ __forceinline__ LdsLine lds_line(int d, int kl, int jl, int il) {
+    using C = Cfg<N>;
+    LdsLine L;
+    if (d == 0) {
+        const int r = (kl * N + jl) * C::NP, sft = SWZ ? (jl & (N / 2)) : 0;
+        L.lo = r + sft; L.hi = r - sft; L.stride = 1;
+    } else if (d == 1) {
+        L.lo = kl * N * C::NP + il; L.hi = kl * N * C::NP + (SWZ ? (il ^ (N / 2)) : il); L.stride = C::NP;
+    } else {
+        L.lo = L.hi = jl * C::NP + (SWZ ? (il ^ (jl & (N / 2))) : il); L.stride = N * C::NP;
+    }
+    return L;
+}
+#define WX_LINE_AT(L, m) (((m) < N / 2 ? (L).lo : (L).hi) + (m) * (L).stride)
 
 enum { F_W = 0, F_E = 1, F_S = 2, F_N = 3, F_B = 4, F_T = 5 };
 // values per face point in the interface buffer and in the edge messages.  5 = the prognostic
@@ -90,6 +116,9 @@ enum { F_W = 0, F_E = 1, F_S = 2, F_N = 3, F_B = 4, F_T = 5 };
 #endif
 #ifndef WX_K2_OWN_FORM
 #define WX_K2_OWN_FORM 0   // 1: Rusanov flux in own/neighbour form (rusanov_own) instead of left/right copies
+#endif
+#ifndef WX_K2_SWIZZLE
+#define WX_K2_SWIZZLE 0   // 1: XOR-swizzled LDS image in the fused kernel's directional passes (n = 8, plain stage)
 #endif
 #ifndef WX_K1_WAVES
 #define WX_K1_WAVES 1   // minimum waves per SIMD requested for the extrapolation kernel (register cap = 512 / waves)
@@ -650,7 +679,8 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
     const bool active = (le < EPB) && el.valid;
     const int kl = pt / N2, jl = (pt / N) % N, il = pt % N;
     const int lb = (le < EPB ? le : 0) * C::LE;  // LDS base of this thread's element
-    const int lpt = lb + C::lidx(kl, jl, il);    // this thread's node in the padded LDS image
+    constexpr bool SWZ = WX_K2_SWIZZLE && N == 8 && !PIPE && !is_complex<T>::value;
+    const int lpt = lb + (SWZ ? C::lidx_swz(kl, jl, il) : C::lidx(kl, jl, il));  // this thread's node in the LDS image
     const size_t o = (size_t)el.e * N3 + pt;
 
     T q0 = T(1.0), q1 = T(0.0), q2 = T(0.0), q3 = T(0.0), q4 = T(1.0);
@@ -809,10 +839,12 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
         }
         __syncthreads();
 
-        int base, stride, idx, fp;
-        if (d == 0) { base = lb + C::lidx(kl, jl, 0); stride = 1; idx = il; fp = kl * N + jl; }
-        else if (d == 1) { base = lb + C::lidx(kl, 0, il); stride = C::NP; idx = jl; fp = kl * N + il; }
-        else { base = lb + C::lidx(0, jl, il); stride = N * C::NP; idx = kl; fp = jl * N + il; }
+        int idx, fp;
+        if (d == 0) { idx = il; fp = kl * N + jl; }
+        else if (d == 1) { idx = jl; fp = kl * N + il; }
+        else { idx = kl; fp = jl * N + il; }
+        LdsLine ln = lds_line<N, SWZ>(d, kl, jl, il);
+        ln.lo += lb; ln.hi += lb;
 
         double dm[N];
 #pragma unroll
@@ -831,7 +863,7 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
                 if (c < 7) {
                     T a = cm * fr[lf][2 * d][c][fp] + cp * fr[lf][2 * d + 1][c][fp];
 #pragma unroll
-                    for (int m = 0; m < N; ++m) a += dm[m] * fld[c][base + m * stride];
+                    for (int m = 0; m < N; ++m) a += dm[m] * fld[c][WX_LINE_AT(ln, m)];
                     // W^d = [A@D + A*@C] + p [B@D + B*@C] + p B [log p@D + log p^@C]  (rhs_dfr.py:113-136)
                     if (c == 0) acc0 += a;
                     else if (c == 1) acc1 += a;
@@ -845,7 +877,7 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
         }
         if (d == 2) {
 #pragma unroll
-            for (int m = 0; m < N; ++m) hf += sHF[idx * N + m] * fld[7][base + m * stride];
+            for (int m = 0; m < N; ++m) hf += sHF[idx * N + m] * fld[7][WX_LINE_AT(ln, m)];
         }
         WX_STAMP(3 + d);
     }
