@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 // tuning knobs (A/B-tested on MI355X; defaults are the measured best)
@@ -54,6 +55,13 @@
 #endif
 #ifndef WX_K2_EARLY_LOADS
 #define WX_K2_EARLY_LOADS 1   // issue the point loads before the face stage
+#endif
+
+#ifndef WX_K2_MFMA
+#define WX_K2_MFMA 1      // n = 8, float64: the derivative contractions of the fused kernel on v_mfma_f64_16x16x4_f64
+#endif
+#ifndef WX_K2_MFMA_CORR
+#define WX_K2_MFMA_CORR 1 // ... with the two face corrections riding along as a third k-step (D | cm | cp is 8 x 10)
 #endif
 
 #if WX_K2_NT_METRIC
@@ -635,6 +643,91 @@ __device__ __forceinline__ void face_problem(const EulerParams<T>& P, const Elem
 }
 
 // ------------------------------------------------------------------------------------------------
+// Derivative contractions on the matrix cores (n = 8, float64).
+//
+// One directional pass of the fused kernel is  out[i'] = sum_m D[i'][m] F[m] + cm[i'] F*_minus + cp[i'] F*_plus  on
+// every line of 8 nodes of every staged field: an 8 x 10 operator applied to 64 lines x 7 fields.  On
+// v_mfma_f64_16x16x4_f64 (A 16 x 4, B 4 x 16, one f64 per lane each; C/D 16 x 16, 4 f64 per lane) one "job" is
+//   A = the operator, rows 0..7 (rows 8..15 are zero: the tile's unavoidable padding for an 8-row operator),
+//   B = 16 lines of one field, 3 k-steps: nodes {2a} , nodes {2a+1}, the two common face values (slots 2, 3 zero),
+// and leaves in lane (a = lane >> 4, c = lane & 15), registers 0 and 1, the results at nodes 2a and 2a + 1 of line c:
+// the row order of A and the k order of A and B are permuted (row m <-> node 2 (m & 3) + (m >> 2)) so that a lane
+// reads and writes two NEIGHBOURING nodes.  Every nodal value is read from LDS once per direction (eight times on
+// the vector pipe) and the 70 f64 FMAs per point and direction of the contraction leave the VALU.
+// Results go back IN PLACE (a job reads its 16 lines before it writes them; jobs touch disjoint lines), the point
+// threads then pick up their own node.  LDS image: node (kl, jl, il) of a field at kl*72 + jl*8 + (il ^ jl):
+// conflict-free for all six access patterns (point threads: plane of 64; jobs: 2 nodes x 16 lines reads,
+// 1 node x 16 lines writes, along i, j and k), found by exhaustive search over paddings and XOR swizzles.
+// Lines of a job: u = c & 7, v = 2 t + (c >> 3)  with (jl, kl) / (il, kl) / (il, jl) = (u, v) for d = 0 / 1 / 2,
+// t = wave & 3; fields c0 = wave >> 2, c0 + 2, c0 + 4, c0 + 6.
+// ------------------------------------------------------------------------------------------------
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+constexpr int kMfLE = 8 * 72;        // doubles per field image
+constexpr int kMfFS = 7 * 64 + 16;   // doubles per face in the face-flux image: faces 2d and 2d+1 land on different banks
+__device__ __forceinline__ int mf_idx(int kl, int jl, int il) { return kl * 72 + jl * 8 + (il ^ jl); }
+// permuted row / k-slot order of the operator tile
+__device__ __forceinline__ int mf_node(int m) { return ((m & 3) << 1) | (m >> 2); }
+
+// The A operands of this lane: D|cm|cp (3 k-steps) and HF (2 k-steps), from the plan's constants.
+struct MfOps { double a0, a1, a2, h0, h1; };
+__device__ __forceinline__ MfOps mf_load_ops(const EulerConsts* K, int lane) {
+    const int a = lane >> 4, c = lane & 15;
+    MfOps o{0.0, 0.0, 0.0, 0.0, 0.0};
+    if (c < 8) {
+        const int row = mf_node(c);
+        o.a0 = K->D[row * 8 + 2 * a]; o.a1 = K->D[row * 8 + 2 * a + 1];
+        o.a2 = a == 0 ? K->cm[row] : (a == 1 ? K->cp[row] : 0.0);
+        o.h0 = K->HF[row * 8 + 2 * a]; o.h1 = K->HF[row * 8 + 2 * a + 1];
+    }
+    return o;
+}
+
+// One directional pass over the staged fields of one element (one workgroup of 8 waves).  fld: field images
+// (kMfLE apart), frs: face-flux image [6 faces][kMfFS] with quantity c of face point fp at c*64 + fp.
+// NFLD = 7 (d < 2) or 8 (d = 2: field 7 = sqrtG rho takes the vertical high-filter HF instead of D, no faces).
+template <int D, bool CORR>
+__device__ __forceinline__ void mf_dir_pass(double* fld, const double* frs, const MfOps& op, int wave, int lane) {
+    const int a = lane >> 4, c = lane & 15, u = c & 7;
+    const int v = 2 * (wave & 3) + (c >> 3);
+    const int m0 = 2 * a, m1 = 2 * a + 1;
+    int i0, i1;
+    if (D == 0) { i0 = mf_idx(v, u, m0); i1 = mf_idx(v, u, m1); }
+    else if (D == 1) { i0 = mf_idx(v, m0, u); i1 = mf_idx(v, m1, u); }
+    else { i0 = mf_idx(m0, v, u); i1 = mf_idx(m1, v, u); }
+    const int fo = (2 * D + (a & 1)) * kMfFS + 16 * (wave & 3) + c;   // face point of line (u, v) = 8 v + u
+    const int c0 = wave >> 2;
+    constexpr int NJ = 4;
+    double b0[NJ], b1[NJ], b2[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int f = c0 + 2 * j;
+        if (f < 7 || D == 2) {
+            b0[j] = fld[f * kMfLE + i0];
+            b1[j] = fld[f * kMfLE + i1];
+            if (CORR && f < 7) b2[j] = frs[fo + f * 64];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int f = c0 + 2 * j;
+        if (f < 7) {
+            mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(op.a0, b0[j], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(op.a1, b1[j], acc, 0, 0, 0);
+            if (CORR) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(op.a2, b2[j], acc, 0, 0, 0);
+            fld[f * kMfLE + i0] = acc[0];
+            fld[f * kMfLE + i1] = acc[1];
+        } else if (D == 2) {
+            mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(op.h0, b0[j], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(op.h1, b1[j], acc, 0, 0, 0);
+            fld[f * kMfLE + i0] = acc[0];
+            fld[f * kMfLE + i1] = acc[1];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2: fused phases 3-8
 // ------------------------------------------------------------------------------------------------
 template <int N, typename T, bool PIPE>
@@ -643,8 +736,14 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
     constexpr int N2 = C::N2, N3 = C::N3, EPB = C::EPB, BS = C::BS;
     constexpr int NF = 8;   // staged fields: 4 F rows, A, B (per direction) + log p + sqrtG*rho
     constexpr int NC = 7;   // face quantities, see rusanov_face
+    // matrix-core path for the derivative contractions (n = 8, float64); everything else keeps the vector path
+    constexpr bool MF = WX_K2_MFMA && N == 8 && std::is_same<T, double>::value;
+    constexpr bool MFC = MF && WX_K2_MFMA_CORR;   // face corrections inside the MFMA (third k-step)
+    static_assert(!MF || (EPB == 1 && C::LE == kMfLE), "the MFMA pass owns one n = 8 element per workgroup");
+    constexpr int FST = NC * N2 + (MF ? kMfFS - 7 * 64 : 0);   // doubles per face in the face-flux image
     __shared__ T fld[NF][EPB * C::LE];
-    __shared__ T fr[EPB][6][NC][N2];
+    __shared__ T frs[EPB * 6 * FST];
+#define WX_FR(le_, f_, c_, fp_) frs[((le_) * 6 + (f_)) * FST + (c_) * N2 + (fp_)]
     __shared__ double sD[N * N], sHF[N * N], sCm[N], sCp[N];
     __shared__ double sEF[PIPE ? N * N : 1];
 
@@ -679,8 +778,11 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
     const bool active = (le < EPB) && el.valid;
     const int kl = pt / N2, jl = (pt / N) % N, il = pt % N;
     const int lb = (le < EPB ? le : 0) * C::LE;  // LDS base of this thread's element
-    constexpr bool SWZ = WX_K2_SWIZZLE && N == 8 && !PIPE && !is_complex<T>::value;
+    constexpr bool SWZ = WX_K2_SWIZZLE && N == 8 && !PIPE && !is_complex<T>::value && !MF;
     const int lpt = lb + (SWZ ? C::lidx_swz(kl, jl, il) : C::lidx(kl, jl, il));  // this thread's node in the LDS image
+    const int lptm = mf_idx(kl, jl, il);   // ... and in the image of the matrix-core passes
+    MfOps mops{0.0, 0.0, 0.0, 0.0, 0.0};
+    if (MF) mops = mf_load_ops(P.K, tid & 63);
     const size_t o = (size_t)el.e * N3 + pt;
 
     T q0 = T(1.0), q1 = T(0.0), q2 = T(0.0), q3 = T(0.0), q4 = T(1.0);
@@ -731,7 +833,7 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
         T out[NC];
         face_problem<N, T, WX_K2_OWN_FORM != 0>(P, el, f, fp, out);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) fr[le][f][c][fp] = out[c];
+        for (int c = 0; c < NC; ++c) WX_FR(le, f, c, fp) = out[c];
     }
 
     WX_STAMP(1);
@@ -744,8 +846,9 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
     const T u1 = q1 * rinv, u2 = q2 * rinv, u3 = q3 * rinv;
     const T glog = kGamma * w_log(kRdOverP0 * q4);
     const T p = kP0 * w_exp(glog);
-    if (le < EPB) {
-        fld[6][lpt] = kLogP0 + glog;  // log p, without a second logarithm
+    const T logp = kLogP0 + glog;  // log p, without a second logarithm
+    if (!MF && le < EPB) {
+        fld[6][lpt] = logp;
         fld[7][lpt] = sg * q0;
     }
 
@@ -805,8 +908,9 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
     T hf = T(0.0);
 
 #if WX_K2_SKELETON
+    if (MF) fld[6][lpt] = logp;
     __syncthreads();
-    acc0 += fr[le < EPB ? le : 0][0][0][pt % N2] + fld[6][lpt];
+    acc0 += WX_FR(le < EPB ? le : 0, 0, 0, pt % N2) + fld[6][lpt];
 #endif
 #if WX_K2_UNROLL_DIRS
 #pragma unroll
@@ -828,6 +932,47 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
 #endif
         const T sgu = sg * ud;
         const T Bd = T(sg * hd2);
+        if constexpr (MF) {
+            // matrix-core pass (see mf_dir_pass): each thread stages its own node, the 8 waves contract all lines
+            // in place, each thread picks its own node up again - no barrier between a thread's read and its next write
+            double* fm = reinterpret_cast<double*>(&fld[0][0]);
+            const double* fq = reinterpret_cast<const double*>(&frs[0]);
+            fm[0 * kMfLE + lptm] = sgu * q0;
+            fm[1 * kMfLE + lptm] = sgu * q1 + (sg * hd0) * p;
+            fm[2 * kMfLE + lptm] = sgu * q2 + (sg * hd1) * p;
+            fm[3 * kMfLE + lptm] = sgu * q4;
+            fm[4 * kMfLE + lptm] = sgu * q3;
+            fm[5 * kMfLE + lptm] = Bd;
+            fm[6 * kMfLE + lptm] = logp;
+            if (d == 2) fm[7 * kMfLE + lptm] = sg * q0;
+            __syncthreads();
+            const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+            if (d == 0) mf_dir_pass<0, MFC>(fm, fq, mops, wave, tid & 63);
+            else if (d == 1) mf_dir_pass<1, MFC>(fm, fq, mops, wave, tid & 63);
+            else mf_dir_pass<2, MFC>(fm, fq, mops, wave, tid & 63);
+            __syncthreads();
+            double r0 = fm[0 * kMfLE + lptm], r1 = fm[1 * kMfLE + lptm], r2 = fm[2 * kMfLE + lptm],
+                   r3 = fm[3 * kMfLE + lptm], r4 = fm[4 * kMfLE + lptm], r5 = fm[5 * kMfLE + lptm],
+                   r6 = fm[6 * kMfLE + lptm];
+            if (!MFC) {   // face corrections on the vector pipe
+                const int fpm = d == 0 ? kl * N + jl : (d == 1 ? kl * N + il : jl * N + il);
+                const int ix = d == 0 ? il : (d == 1 ? jl : kl);
+                const double cm = sCm[ix], cp = sCp[ix];
+                r0 += cm * fq[(2 * d) * FST + 0 * N2 + fpm] + cp * fq[(2 * d + 1) * FST + 0 * N2 + fpm];
+                r1 += cm * fq[(2 * d) * FST + 1 * N2 + fpm] + cp * fq[(2 * d + 1) * FST + 1 * N2 + fpm];
+                r2 += cm * fq[(2 * d) * FST + 2 * N2 + fpm] + cp * fq[(2 * d + 1) * FST + 2 * N2 + fpm];
+                r3 += cm * fq[(2 * d) * FST + 3 * N2 + fpm] + cp * fq[(2 * d + 1) * FST + 3 * N2 + fpm];
+                r4 += cm * fq[(2 * d) * FST + 4 * N2 + fpm] + cp * fq[(2 * d + 1) * FST + 4 * N2 + fpm];
+                r5 += cm * fq[(2 * d) * FST + 5 * N2 + fpm] + cp * fq[(2 * d + 1) * FST + 5 * N2 + fpm];
+                r6 += cm * fq[(2 * d) * FST + 6 * N2 + fpm] + cp * fq[(2 * d + 1) * FST + 6 * N2 + fpm];
+            }
+            // W^d = [A@D + A*@C] + p [B@D + B*@C] + p B [log p@D + log p^@C]  (rhs_dfr.py:113-136)
+            acc0 += r0; acc1 += r1; acc2 += r2; acc4 += r3;
+            accw += r4 + p * r5 + (p * Bd) * r6;
+            if (d == 2) hf = fm[7 * kMfLE + lptm];
+            WX_STAMP(3 + d);
+            continue;
+        }
         if (d > 0) __syncthreads();  // previous direction's reads are done
         if (le < EPB) {
             fld[0][lpt] = sgu * q0;
@@ -861,7 +1006,7 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
             for (int cc = 0; cc < FB; ++cc) {
                 const int c = c0 + cc;
                 if (c < 7) {
-                    T a = cm * fr[lf][2 * d][c][fp] + cp * fr[lf][2 * d + 1][c][fp];
+                    T a = cm * WX_FR(lf, 2 * d, c, fp) + cp * WX_FR(lf, 2 * d + 1, c, fp);
 #pragma unroll
                     for (int m = 0; m < N; ++m) a += dm[m] * fld[c][WX_LINE_AT(ln, m)];
                     // W^d = [A@D + A*@C] + p [B@D + B*@C] + p B [log p@D + log p^@C]  (rhs_dfr.py:113-136)
@@ -953,6 +1098,7 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
                            P.nsend_w, P.nsend_e);
     }
 #undef WX_STAMP
+#undef WX_FR
 }
 
 template <int N, typename T, bool PIPE>
