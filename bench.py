@@ -63,19 +63,42 @@ def cpu_baseline(n, V, sample_H, reps, seed):
     return dof / dt, dt
 
 
+KERNEL_SOURCES = ("wxfactory_amd/csrc/euler3d.hip", "wxfactory_amd/csrc/wx_math.h", "wxfactory_amd/csrc/wx_common.h",
+                  "wxfactory_amd/csrc/wx_panels.h")
+
+
+def kernel_source_hash():
+    """sha256 over the sources of the 3-D Euler kernels: PMC summaries carry the hash of the build they were measured on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+PMC_SUMMARIES = {384.0: "r02_pmc_summary.json", 312.0: "r02_pmc_rotzero_summary.json"}
+
+
 def pmc_traffic(region, n, H, V, bpp=ALGO_BYTES_PER_POINT):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
-    WRITE_SIZE runs of tools/kbench.py on one E7 panel, gfx950 corrections applied by tools/pmc_summary.py):
-    profiles/r01_v5_pmc_summary.json for the 27-Christoffel-field configuration (384 B/point),
-    profiles/r01_v6_pmc_rotzero_summary.json for a non-rotating planet (312 B/point).  Counters cannot be read
-    from inside this process, so the number is only reported for the configurations it was measured on."""
-    name = {384.0: "r01_v5_pmc_summary.json", 312.0: "r01_v6_pmc_rotzero_summary.json"}.get(float(bpp))
+    WRITE_SIZE runs of tools/kbench.py on one E7 panel, gfx950 corrections applied by tools/pmc_summary.py).
+    Counters cannot be read from inside this process, so the figure comes from profiles/<name> - and is REFUSED
+    (None, with the reason) unless that summary was measured on exactly the kernel sources this run was built from.
+    Returns (bytes or None, provenance dict)."""
+    name = PMC_SUMMARIES.get(float(bpp))
     if name is None or region != 0 or (n, H, V) != (8, 60, 8):
-        return None
+        return None, {"reason": "no PMC pass for this launch shape"}
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]["wx::euler_rhs_kernel<8, double, false>"]["hbm_bytes"]
-    except (OSError, KeyError, ValueError):
-        return None
+        doc = json.load(open(os.path.join(ROOT, "profiles", name)))
+        prov = {"profile": "profiles/" + name, "commit": doc.get("commit"), "source_sha256": doc.get("source_sha256")}
+        if doc.get("source_sha256") != kernel_source_hash():
+            prov["reason"] = "kernel sources changed since the PMC pass: traffic refused"
+            return None, prov
+        return doc["kernels"]["wx::euler_rhs_kernel<8, double, false>"]["hbm_bytes"], prov
+    except (OSError, KeyError, ValueError) as e:
+        return None, {"reason": f"{type(e).__name__}: {e}"}
 
 
 def k2_full_metric(dev, seed, n=8, H=60, V=8, reps=20):
@@ -104,7 +127,7 @@ def k2_full_metric(dev, seed, n=8, H=60, V=8, reps=20):
     gbs = bpp * V * H * H * n**3 / tk / 1e9
     return {"workload": "one E7 panel, seeded synthetic metric (SURVEY 8d)", "launch_ms": round(tk * 1e3, 4),
             "algorithmic_bytes_per_point": bpp, "achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
-            "traffic": pmc_traffic(0, n, H, V, bpp)}
+            "traffic": pmc_traffic(0, n, H, V, bpp)[0], "traffic_source": pmc_traffic(0, n, H, V, bpp)[1]}
 
 
 def ini_size_extras(dev, seed):
@@ -186,8 +209,56 @@ def extras(dev, seed):
     return {"euler_k2_all_27_christoffel": k2_full_metric(dev, seed), "sw_s7": {"workload": "shallow water, n=8, H=60, 6 panels on 1 GPU (1244160 DOF), whole-sphere R(Q)",
                       "us_per_eval": te * 1e6, "dof_updates_per_s": dof / te,
                       "algorithmic_GBps": 156.0 * 6 * H * H * n * n / te / 1e9,
+                      "roofline": {"bound": "hbm", "kernels": "sw_extrap_batch_kernel + sw_rhs_batch_kernel (one R(Q) = both)",
+                                   "algorithmic_bytes_per_point": 156.0, "achieved": round(156.0 * 6 * H * H * n * n / te / 1e9, 1),
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(156.0 * 6 * H * H * n * n / te / 1e9 / HBM_PEAK_GBS, 4),
+                                   "profile": "profiles/r02_sw_s7_kernel_stats.csv"},
                       "note": "all six panels in one launch per phase (wx_sw_batch_*): 2 launches per R(Q); launch-latency "
                               "bound (5.5 MB of state per panel)"}}
+
+
+def rhs_benchmark_matrix(dev, seed):
+    """The reference's own RHS benchmark matrix (tests/rhs_benchmark/run.sh:67-71): 3-D Euler, DCMIP 3-1, 6 ranks,
+    (num_solpts, horizontal, vertical elements per panel) = (2,30,30) (3,20,20) (4,15,15) (5,12,12) (6,10,10), i.e.
+    60^3 points per panel at every order; here all six panels on one GPU, whole-sphere R(Q) and the complex-step
+    matvec the benchmark's epi2 + KIOPS integrator calls."""
+    from wxfactory_amd import synthetic
+    from wxfactory_amd.geometry3d import CubedSphere3DTile, metric3d_torch
+    from wxfactory_amd.initial import initial_state
+    from wxfactory_amd.matvec import matvec_fun
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D
+
+    rows = []
+    for n, H, V in ((2, 30, 30), (3, 20, 20), (4, 15, 15), (5, 12, 12), (6, 10, 10)):
+        plans, q = {}, []
+        for p in range(6):
+            t = CubedSphere3DTile(n, H, V, p, 10000.0, 31)
+            plans[p] = Euler3DPlan(n, H, V, 31, p, synthetic.dfr_ops(n), metric3d_torch(t, dev))
+            q.append(torch.from_numpy(initial_state(t)).to(dev))
+        Q = torch.stack(q)
+        rhs = RhsEuler3D(plans)
+        R = rhs(Q)
+        v = (torch.rand(Q.shape, device=dev, dtype=Q.dtype) - 0.5).flatten()
+
+        def clock(fn, reps=50):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / reps
+
+        te, tj = clock(lambda: rhs(Q)), clock(lambda: matvec_fun(v, 1.0, Q, R, rhs, "complex"))
+        pts = 6 * V * H * H * n**3
+        rows.append({"num_solpts": n, "elements": [H, H, V], "dof": 5 * pts, "rhs_ms": round(te * 1e3, 4),
+                     "dof_updates_per_s": 5 * pts / te, "matvec_complex_ms": round(tj * 1e3, 4),
+                     "algorithmic_GBps": round(plans[0].bytes_per_point * pts / te / 1e9, 1)})
+        del rhs, plans, Q, R, v, q
+        torch.cuda.empty_cache()
+    return rows
 
 
 def e7_v1_extras(dev, seed, n=8, H=60):
@@ -257,6 +328,31 @@ def caller_extras(rhs, qs, reps=5):
     return {k: (round(x, 3) if isinstance(x, float) else x) for k, x in out.items()}
 
 
+def spawn_ranks(n, argv):
+    """One process per GPU on this node: python -m torch.distributed.run --nproc-per-node n bench.py <argv>."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def decomposition(world, H, tiles_per_side=0, whole_panels=False):
+    """(k, owner of each of the 6 k^2 tiles): the reference's own tiling (process_topology.py:69-94) with the smallest
+    k that spreads the tiles evenly over the ranks - k = 1 (whole panels) for 1, 2, 3, 6 GPUs, k = 2 for 4 and 8."""
+    from wxfactory_amd.panels import CubeTopology, owner_of_tiles, tiles_per_side_for
+
+    k = tiles_per_side or (1 if whole_panels else tiles_per_side_for(world))
+    if H % k:
+        raise SystemExit(f"H={H} is not divisible by {k} tiles per panel side")
+    return k, owner_of_tiles(world, CubeTopology(k).ntiles)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -276,14 +372,18 @@ def main():
                          "(default, SURVEY 8d) or SURVEY's seeded synthetic fields; values do not affect speed")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` typed as is: start one rank per GPU through torch.distributed.run as a CHILD
+        # (nothing has touched the GPU yet: never re-exec a process that has), relay its output, exit with its code
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -294,7 +394,7 @@ def main():
 
     from wxfactory_amd import _lib, synthetic
     from wxfactory_amd.exchange import PanelExchange
-    from wxfactory_amd.panels import CubeTopology, tiles_of_rank, tiles_per_side_for
+    from wxfactory_amd.panels import CubeTopology
     from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D
 
     _lib.load()
@@ -302,12 +402,10 @@ def main():
     ops = synthetic.dfr_ops(n)
     # the sphere is cut into 6 k^2 tiles (the reference's own decomposition, process_topology.py:69-94) with the
     # smallest k that spreads evenly over the ranks: k = 1 (whole panels) for 1, 2, 3, 6 GPUs, k = 2 for 4 and 8
-    k = args.tiles_per_side or (1 if args.whole_panels else tiles_per_side_for(world))
-    if H % k:
-        raise SystemExit(f"H={H} is not divisible by {k} tiles per panel side")
+    k, owner = decomposition(world, H, args.tiles_per_side, args.whole_panels)
     topo = CubeTopology(k)
     Ht = H // k
-    mine = tiles_of_rank(rank, world, topo.ntiles)
+    mine = [t for t, r in enumerate(owner) if r == rank]
     plans, qs = {}, {}
     t_setup = time.perf_counter()
     for t in mine:
@@ -338,8 +436,21 @@ def main():
         if recording[0]:
             ev.append((a, b, region))
 
+    ev1 = []
+    orig_pack = Euler3DPlan.extrap_pack
+
+    def timed_pack(self, q, send):
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        orig_pack(self, q, send)
+        b.record()
+        if recording[0]:
+            ev1.append((a, b))
+
     recording = [False]
     Euler3DPlan.rhs = timed_rhs
+    Euler3DPlan.extrap_pack = timed_pack
 
     def barrier():
         if world > 1:
@@ -368,6 +479,27 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    ranks_seen = dist.get_world_size() if world > 1 else 1
+
+    # per-rank phase times (outside the timed region): the reference's nine RHS timestamps (rhs/rhs.py:88-118) on
+    # HIP events of the launch stream, five more evaluations
+    Euler3DPlan.rhs, Euler3DPlan.extrap_pack = orig_rhs, orig_pack
+    rhs.timed = True
+    rhs.clear_timings()
+    for _ in range(5):
+        rhs(qs)
+    torch.cuda.synchronize()
+    rhs.retrieve_last_times()
+    rhs.timed = False
+    tm = rhs.timings[1:] or rhs.timings
+    mean = lambda i: round(sum(t[i] for t in tm) / len(tm) * 1e3, 4) if tm else None  # noqa: E731
+    mine_phase = {"rank": rank, "tiles": len(mine), "pack_ms": mean(0), "exchange_start_ms": mean(1), "interior_ms": mean(2),
+                  "exchange_ms": mean(4), "boundary_ms": mean(5), "total_ms": mean(8)}
+    per_rank = [mine_phase]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine_phase)
+    barrier()
 
     pts_panel = V * H * H * n**3
     evals_per_s = args.steps / dt
@@ -390,12 +522,23 @@ def main():
         bpp = next(iter(plans.values())).bytes_per_point if plans else ALGO_BYTES_PER_POINT
         bytes_launch = bpp * (pts_panel / (k * k)) * frac_of_panel[region]
         achieved = bytes_launch / tk / 1e9
+        traffic, traffic_src = pmc_traffic(region, n, Ht, V, bpp)
         roof = {"bound": "hbm", "kernel": "euler_rhs_kernel<8,double>", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic(region, n, Ht, V, bpp), "launch_ms": round(tk * 1e3, 4),
+                "traffic": traffic, "traffic_source": traffic_src, "launch_ms": round(tk * 1e3, 4),
                 "algorithmic_bytes_per_launch": bytes_launch, "algorithmic_bytes_per_point": bpp,
                 "survey_bytes_per_point": ALGO_BYTES_PER_POINT,
                 "region": {0: "all", 1: "interior", 2: "boundary"}[region]}
+        if ev1:
+            roof["extrap_kernel_launch_ms"] = round(sum(a.elapsed_time(b) for a, b in ev1) / len(ev1), 4)
+        # the whole sweep (extrapolation kernel + exchange + fused kernel, every local tile): compulsory bytes of one
+        # R(Q) of this rank's tiles (each static field and Q read once, R written once) over the step time
+        sweep_bytes = bpp * (pts_panel / (k * k)) * len(mine)
+        sweep = sweep_bytes / (dt / args.steps) / 1e9
+        roof["sweep"] = {"algorithmic_bytes": sweep_bytes, "achieved": round(sweep, 1), "frac": round(sweep / HBM_PEAK_GBS, 4),
+                         "note": "rank 0's tiles; the interface buffer's round trip through HBM and the extrapolation "
+                                 "kernel's second read of Q are not compulsory bytes"}
+        roof["sweep_frac"] = roof["sweep"]["frac"]
 
     if rank == 0:
         line = {
@@ -403,7 +546,7 @@ def main():
             "value": dof_per_s, "unit": "DOF-updates/s", "n_gpus": args.gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "rhs_evals_per_s": evals_per_s,
+            "rhs_evals_per_s": evals_per_s, "ranks_seen": ranks_seen, "per_rank": per_rank,
             "config": {"workload": f"E7: 3-D Euler RHS, n={n} (p={n-1}), H={H}x{H} elem/panel, V={V}, 6 panels "
                                    f"({5*pts_panel*6} DOF), halo exchange included",
                        "n": n, "H": H, "V": V, "tiles": topo.ntiles, "tile_H": Ht, "tiles_per_gpu": len(mine),
@@ -415,13 +558,13 @@ def main():
             "roofline": roof,
         }
         if args.gpus == 1 and not args.no_extras:
-            Euler3DPlan.rhs = orig_rhs
             line["extra"] = extras(dev, args.seed)
             line["extra"]["euler_callers"] = caller_extras(rhs, qs)
             line["extra"]["euler_ini_sizes"] = ini_size_extras(dev, args.seed)
             del rhs, qs, plans, out
             torch.cuda.empty_cache()
             line["extra"]["euler_e7_v1"] = e7_v1_extras(dev, args.seed)
+            line["extra"]["rhs_benchmark_matrix"] = rhs_benchmark_matrix(dev, args.seed)
         if args.gpus == 1 and not args.no_cpu_baseline:
             sample_H = 30
             v, secs = cpu_baseline(n, V, sample_H, reps=3, seed=args.seed)

@@ -30,7 +30,19 @@ if __name__ == "__main__":
         wb = write.get(k, 0.0) * 1024.0
         res[k] = {"fetch_bytes": fb, "write_bytes": wb, "hbm_bytes": fb + wb,
                   "raw_FETCH_SIZE_KiB": fetch.get(k), "raw_WRITE_SIZE_KiB": write.get(k)}
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from bench import kernel_source_hash  # the hash bench.py checks before it quotes these bytes
+
+    try:
+        commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
+    except Exception:
+        commit = os.environ.get("WX_COMMIT")  # the GPU box has no .git: pass the commit in
     json.dump({"unit": "bytes per launch (mean over launches)", "correction": "FETCH_SIZE x2 (gfx950), KiB -> B",
+               "commit": commit, "source_sha256": kernel_source_hash(),
                "kernels": res}, open(sys.argv[3], "w"), indent=1)
     for k, v in res.items():
         print(f"{k:50s} fetch {v['fetch_bytes']/1e9:7.3f} GB  write {v['write_bytes']/1e9:7.3f} GB  total {v['hbm_bytes']/1e9:7.3f} GB")
