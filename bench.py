@@ -30,37 +30,77 @@ ALGO_BYTES_PER_POINT = 384.0  # 360 B/point fields + 24 B/
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def cpu_baseline(n, V, sample_H, reps, seed):
-    """Time the CPU oracle (oracle/euler3d.py, NumPy, 1 thread) on one tile of the same
-    workload with sample_H x sample_H x V elements.  Checker used as a *reported* baseline."""
-    import numpy as np
+def host_cpu():
+    """(model name, physical cores available to this process, logical CPUs available)."""
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    logical = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        import psutil
 
-    from oracle.euler3d import Euler3DOracle
-    from wxfactory_amd import synthetic
+        phys = psutil.cpu_count(logical=False) or logical
+    except Exception:
+        phys = logical
+    return model, min(phys, logical), logical
 
-    m = synthetic.euler3d_metric(n, sample_H, V, 0, "cpu", seed)
-    q = synthetic.euler3d_state(n, sample_H, V, 0, "cpu", seed).numpy()
-    om = {
-        "sqrtG_new": m["sqrtG"].numpy(), "inv_sqrtG_new": (1.0 / m["sqrtG"]).numpy(),
-        "h_contra_new": m["h_contra"].numpy(), "christoffel": m["christoffel"].numpy(),
-        "inv_dzdeta_new": m["inv_dzdeta"].numpy(),
-    }
-    for d in "ijk":
-        om[f"sqrtG_itf_{d}_new"] = m[f"sqrtG_itf_{d}"].numpy()
-        om[f"h_contra_itf_{d}_new"] = m[f"h_contra_itf_{d}"].numpy()
-    bsn = np.tile(m["boundary_sn"].numpy().reshape(sample_H, 1, n), (1, n, 1))
-    o = Euler3DOracle(n, sample_H, V, 31, synthetic.dfr_ops(n), om, bsn, bsn, panel=0)
-    itf = o.extrapolate(q)
-    halo = o.pack_edges(itf)  # any finite halo: timing only
-    o.rhs(q, halo)  # warm-up
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        itf = o.extrapolate(q)
-        o.pack_edges(itf)
-        o.rhs(q, halo, itf=itf)
-    dt = (time.perf_counter() - t0) / reps
-    dof = 5 * V * sample_H * sample_H * n**3
-    return dof / dt, dt
+
+def cpu_baseline_run(flavour, n, H, V, reps, threads, seed, procs=6):
+    """one cube panel per process, `procs` processes at once, `threads` OMP/BLAS threads each,
+    each timing the CPU restatement (oracle/cpu_bench.py) on an H x H x V-element tile of the E7 workload.  The
+    whole-sphere rate is all panels' DOF over the slowest worker's time per evaluation."""
+    import subprocess
+
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), OPENBLAS_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads),
+               HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    ws = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_bench", "--flavour", flavour, "--n", str(n), "--H", str(H),
+                            "--V", str(V), "--reps", str(reps), "--threads", str(threads), "--panel", str(p), "--seed",
+                            str(seed)], cwd=ROOT, env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+          for p in range(procs)]
+    try:
+        for w in ws:   # setup (synthetic metric, warm-up evaluation) finished everywhere ...
+            if w.stdout.readline().strip() != "READY":
+                raise RuntimeError("cpu_bench worker failed during setup")
+        for w in ws:   # ... then all timed loops start together
+            w.stdin.write("go\n")
+            w.stdin.flush()
+        res = [json.loads(w.stdout.readline()) for w in ws]
+    finally:
+        for w in ws:
+            try:
+                w.wait(timeout=30)
+            except Exception:
+                w.kill()
+    slow = max(r["s_per_eval"] for r in res)
+    return {"dof_updates_per_s": sum(r["dof"] for r in res) / slow, "s_per_eval": round(slow, 4),
+            "processes": procs, "threads_per_process": threads, "finite": all(r["finite"] for r in res),
+            "tile": f"n={n}, {H}x{H}x{V} elements per process ({res[0]['dof']} DOF)", "evals_timed": reps}
+
+
+def cpu_baseline(n, V, seed):
+    """The CPU path beside the GPU figure, both flavours, six processes (one cube panel each):
+    (2) the optimised C++/OpenMP restatement - `value`; (1) the reference-style dense-Kronecker NumPy restatement."""
+    model, phys, logical = host_cpu()
+    threads = max(1, min(phys, 16) // 6)   # a one-GPU box's CPU share is 16 cores, whatever the host has
+    cpp = cpu_baseline_run("cpp", n, 30, V, 3, threads, seed)
+    dense = cpu_baseline_run("dense", n, 30, 1, 2, threads, seed)
+    return {"value": cpp["dof_updates_per_s"], "unit": "DOF-updates/s", "cores": 6 * threads, "kind": "port",
+            "cpu_model": model, "physical_cores": phys, "logical_cpus": logical, "processes": 6,
+            "threads_per_process": threads,
+            "sample": f"oracle/c/euler3d_port.cpp (sum-factorised C++/OpenMP, pinned by tests/test_oracle_c.py): six "
+                      f"processes x {threads} thread(s), each one 30x30x{V}-element tile of the n={n} workload (a quarter "
+                      f"panel), 3 evals, {cpp['s_per_eval']} s/eval on the slowest",
+            "flavours": {"cpp_openmp_sum_factorised": cpp,
+                         "numpy_dense_kronecker_reference_style": dict(dense, note="oracle/euler3d_dense.py: dense n^3 x n^3 "
+                                                                       "operators applied with @ as the reference does "
+                                                                       "(operators.py:157-183); E7 at V = 1 per SURVEY 8d")},
+            "survey_time_reference": "BASELINE.md section 2: the actual reference, n=8 H=10 V=4, 1.7 M DOF-updates/s per rank "
+                                     "(measured in the survey container, not on this host)"}
 
 
 KERNEL_SOURCES = ("wxfactory_amd/csrc/euler3d.hip", "wxfactory_amd/csrc/wx_math.h", "wxfactory_amd/csrc/wx_common.h",
@@ -566,13 +606,7 @@ def main():
             line["extra"]["euler_e7_v1"] = e7_v1_extras(dev, args.seed)
             line["extra"]["rhs_benchmark_matrix"] = rhs_benchmark_matrix(dev, args.seed)
         if args.gpus == 1 and not args.no_cpu_baseline:
-            sample_H = 30
-            v, secs = cpu_baseline(n, V, sample_H, reps=3, seed=args.seed)
-            line["cpu_baseline"] = {
-                "value": v, "unit": "DOF-updates/s", "cores": 1, "kind": "port",
-                "sample": f"oracle/euler3d.py (NumPy, 1 thread) on one {sample_H}x{sample_H}x{V}-element tile of the "
-                          f"same n={n} workload, 3 evals, {secs:.2f} s/eval",
-            }
+            line["cpu_baseline"] = cpu_baseline(n, V, args.seed)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

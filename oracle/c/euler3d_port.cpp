@@ -1,0 +1,287 @@
+// CPU restatement ("port") of the 3-D Euler RHS on one cubed-sphere tile: sum-factorised, element-blocked C++ with
+// OpenMP.  TEST INFRASTRUCTURE - only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may build,
+// load or call this; the product (wxfactory_amd/) never does.  Parity status: PINNED - tests/test_oracle_c.py checks
+// it against the golden vectors produced by running the reference itself (oracle/refharness/gen_golden.py).
+//
+// Follows, phase by phase (reference wx_factory/...):
+//   wxo_euler3d_extrapolate   rhs/rhs_dfr.py:50-71 (log-space for rho and rho*theta)
+//   wxo_euler3d_rhs           pointwise fluxes            pde/pde_euler_cubesphere.py:72-124
+//                             interior derivatives        rhs/rhs_dfr.py:89-104 (Kronecker operators of
+//                                                         geometry/operators.py:157-183 in sum-factorised form)
+//                             halo-padded interfaces, BCs rhs/rhs_dfr.py:203-268, pde_euler_cubesphere.py:150-156
+//                             Rusanov fluxes              pde/fluxes.py:150-222, 326-403, 507-582
+//                             corrections + assembly      rhs/rhs_dfr.py:106-139
+//                             forcing                     pde_euler_cubesphere.py:12-25, 203-290; init/dcmip.py:676-757
+// The tile-edge pack (rotation, flip) stays in oracle/euler3d.py::pack_edges, which accepts these face arrays.
+//
+// Layouts as in the reference (geometry/cubed_sphere_3d.py:187-205): q, rhs (5, V, H, H, n^3), point
+// (kl n + jl) n + il; faces (5, V, H, H, 2 n^2) per direction, [0, n^2) minus side, [n^2, 2 n^2) plus side;
+// halos (5, V, H, n^2) per lateral edge; interface metric halo-padded along its direction.
+#include <cmath>
+#include <cstddef>
+#include <cstring>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+constexpr double kGravity = 9.80616, kP0 = 100000.0, kRd = 287.05, kCpd = 1005.46;
+constexpr double kCvd = kCpd - kRd, kGamma = kCpd / kCvd;
+constexpr int MAXN = 8, MAXN2 = MAXN * MAXN, MAXN3 = MAXN * MAXN * MAXN;
+
+inline double pressure_of(double rho_theta) { return kP0 * std::exp(kGamma * std::log(rho_theta * (kRd / kP0))); }
+
+// what one side of a face contributes to its Riemann problem
+struct Side {
+    double q[5], un, p, sg, h[3];
+};
+
+// out: F* of the five rows, A* (advective rho-w flux), and 1/2 (P_L + P_R) before the division by the side's pressure
+inline void rusanov(const Side& L, const Side& R, int d, bool advection_only, double* fstar, double& astar, double& pavg) {
+    double eL = std::fabs(L.un), eR = std::fabs(R.un);
+    if (!advection_only) {
+        eL += std::sqrt(L.h[d] * kGamma * L.p / L.q[0]);
+        eR += std::sqrt(R.h[d] * kGamma * R.p / R.q[0]);
+    }
+    const double eig = (eL > eR || eL != eL) ? eL : eR;   // numpy.maximum propagates NaN
+    const int mom[3] = {1, 2, 3};
+    double fL[5], fR[5];
+    for (int v = 0; v < 5; ++v) {
+        fL[v] = L.sg * L.un * L.q[v];
+        fR[v] = R.sg * R.un * R.q[v];
+    }
+    const double aL = fL[3], aR = fR[3];
+    for (int i = 0; i < 3; ++i) {
+        fL[mom[i]] += L.sg * L.h[i] * L.p;
+        fR[mom[i]] += R.sg * R.h[i] * R.p;
+    }
+    for (int v = 0; v < 5; ++v) fstar[v] = 0.5 * (fL[v] + fR[v] - eig * L.sg * (R.q[v] - L.q[v]));
+    astar = 0.5 * (aL + aR - eig * L.sg * (R.q[3] - L.q[3]));
+    pavg = 0.5 * (L.sg * L.h[2] * L.p + R.sg * R.h[2] * R.p);
+}
+
+struct Tile {
+    int n, n2, n3, H, V;
+    size_t fs;    // field stride of point arrays
+    size_t ffs;   // field stride of face arrays
+};
+
+}  // namespace
+
+extern "C" {
+
+// q (5, V, H, H, n^3) -> itf_d (5, V, H, H, 2 n^2), d = i, j, k
+int wxo_euler3d_extrapolate(int n, int H, int V, const double* em, const double* ep, const double* q, double* itf_i,
+                            double* itf_j, double* itf_k, int nthreads) {
+    if (n < 2 || n > MAXN) return 1;
+    const int n2 = n * n, n3 = n2 * n;
+    const size_t nelem = (size_t)V * H * H, fs = nelem * n3, ffs = nelem * 2 * n2;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(static)
+    for (long e = 0; e < (long)nelem; ++e) {
+        double a[MAXN3];
+        for (int v = 0; v < 5; ++v) {
+            const double* src = q + v * fs + (size_t)e * n3;
+            const bool lg = (v == 0 || v == 4);
+            for (int p = 0; p < n3; ++p) a[p] = lg ? std::log(src[p]) : src[p];
+            double* fi = itf_i + v * ffs + (size_t)e * 2 * n2;
+            double* fj = itf_j + v * ffs + (size_t)e * 2 * n2;
+            double* fk = itf_k + v * ffs + (size_t)e * 2 * n2;
+            for (int x = 0; x < n; ++x)
+                for (int y = 0; y < n; ++y) {
+                    double mi = 0, pi = 0, mj = 0, pj = 0, mk = 0, pk = 0;
+                    for (int m = 0; m < n; ++m) {
+                        const double vi = a[(x * n + y) * n + m];   // (kl = x, jl = y, il = m)
+                        const double vj = a[(x * n + m) * n + y];   // (kl = x, jl = m, il = y)
+                        const double vk = a[(m * n + x) * n + y];   // (kl = m, jl = x, il = y)
+                        mi += em[m] * vi; pi += ep[m] * vi;
+                        mj += em[m] * vj; pj += ep[m] * vj;
+                        mk += em[m] * vk; pk += ep[m] * vk;
+                    }
+                    const int fp = x * n + y;
+                    fi[fp] = lg ? std::exp(mi) : mi; fi[n2 + fp] = lg ? std::exp(pi) : pi;
+                    fj[fp] = lg ? std::exp(mj) : mj; fj[n2 + fp] = lg ? std::exp(pj) : pj;
+                    fk[fp] = lg ? std::exp(mk) : mk; fk[n2 + fp] = lg ? std::exp(pk) : pk;
+                }
+        }
+    }
+    return 0;
+}
+
+int wxo_euler3d_rhs(int n, int H, int V, int case_number, const double* D, const double* C, const double* HF, const double* q,
+                    const double* itf_i, const double* itf_j, const double* itf_k, const double* halo_s,
+                    const double* halo_n, const double* halo_w, const double* halo_e, const double* sg, const double* h,
+                    const double* chr, const double* idz, const double* sgi, const double* sgj, const double* sgk,
+                    const double* hi, const double* hj, const double* hk, const double* dcoef, const double* duref,
+                    double* rhs, int nthreads) {
+    if (n < 2 || n > MAXN) return 1;
+    const bool advection_only = case_number < 13;
+    const bool damp = (case_number == 21 || case_number == 22) && dcoef && duref;
+    Tile T{n, n * n, n * n * n, H, V, (size_t)V * H * H * n * n * n, (size_t)V * H * H * 2 * n * n};
+    const int n2 = T.n2, n3 = T.n3;
+    const size_t fs = T.fs, ffs = T.ffs;
+    const size_t hs = (size_t)V * H * n2;   // variable stride of a halo face
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int ek = 0; ek < V; ++ek)
+        for (int ej = 0; ej < H; ++ej)
+            for (int ei = 0; ei < H; ++ei) {
+                const size_t e = ((size_t)ek * H + ej) * H + ei;
+                // ---- common fluxes on the six faces: [face][quantity][face point]
+                //      quantities 0..4 F*, 5 A*, 6 1/2 (P_L + P_R) / p_own, 7 log p_own
+                double fr[6][8][MAXN2];
+                for (int f = 0; f < 6; ++f) {
+                    const int d = f >> 1, plus = f & 1;
+                    const double* itf = d == 0 ? itf_i : (d == 1 ? itf_j : itf_k);
+                    const double *sgp, *hp;
+                    size_t hfs, oL, oR;   // interface metric: field stride, offsets of the L and R slots of this face
+                    const int lo = plus ? 1 : 0;   // padded index of the element left of the face is e_d + lo
+                    if (d == 0) {
+                        hfs = (size_t)V * H * (H + 2) * 2 * n2;
+                        const size_t row = ((size_t)ek * H + ej) * (H + 2);
+                        oL = (row + ei + lo) * 2 * n2 + n2; oR = (row + ei + lo + 1) * 2 * n2;
+                        sgp = sgi; hp = hi + 0 * 3 * hfs;
+                    } else if (d == 1) {
+                        hfs = (size_t)V * (H + 2) * H * 2 * n2;
+                        oL = (((size_t)ek * (H + 2) + ej + lo) * H + ei) * 2 * n2 + n2;
+                        oR = (((size_t)ek * (H + 2) + ej + lo + 1) * H + ei) * 2 * n2;
+                        sgp = sgj; hp = hj + 1 * 3 * hfs;
+                    } else {
+                        hfs = (size_t)(V + 2) * H * H * 2 * n2;
+                        oL = ((((size_t)ek + lo) * H + ej) * H + ei) * 2 * n2 + n2;
+                        oR = ((((size_t)ek + lo + 1) * H + ej) * H + ei) * 2 * n2;
+                        sgp = sgk; hp = hk + 2 * 3 * hfs;
+                    }
+                    // the neighbour across the face: an element of the tile, a received halo, or (vertical ends) the wall
+                    const int c = d == 0 ? ei : (d == 1 ? ej : ek), cn = c + (plus ? 1 : -1), ext = d == 2 ? V : H;
+                    const bool inside = cn >= 0 && cn < ext;
+                    const size_t estr = d == 0 ? 1 : (d == 1 ? (size_t)H : (size_t)H * H);
+                    const double* halo = nullptr;
+                    size_t ho = 0;
+                    if (!inside && d == 0) { halo = plus ? halo_e : halo_w; ho = ((size_t)ek * H + ej) * n2; }
+                    if (!inside && d == 1) { halo = plus ? halo_n : halo_s; ho = ((size_t)ek * H + ei) * n2; }
+                    for (int fp = 0; fp < n2; ++fp) {
+                        Side own, nbr;
+                        for (int v = 0; v < 5; ++v) {
+                            own.q[v] = itf[v * ffs + e * 2 * n2 + plus * n2 + fp];
+                            if (inside) nbr.q[v] = itf[v * ffs + (plus ? e + estr : e - estr) * 2 * n2 + (1 - plus) * n2 + fp];
+                            else if (halo) nbr.q[v] = halo[v * hs + ho + fp];
+                            else nbr.q[v] = own.q[v];   // ground / top: the ghost slot copies the state (rhs_dfr.py:257-268)
+                        }
+                        own.un = own.q[1 + d] / own.q[0];
+                        nbr.un = nbr.q[1 + d] / nbr.q[0];
+                        if (!inside && d == 2) nbr.un = -own.un;   // no-flow wall: odd w (pde_euler_cubesphere.py:150-156)
+                        own.p = pressure_of(own.q[4]);
+                        nbr.p = pressure_of(nbr.q[4]);
+                        Side& L = plus ? own : nbr;
+                        Side& R = plus ? nbr : own;
+                        L.sg = sgp[oL + fp]; R.sg = sgp[oR + fp];
+                        for (int r = 0; r < 3; ++r) { L.h[r] = hp[r * hfs + oL + fp]; R.h[r] = hp[r * hfs + oR + fp]; }
+                        double fstar[5], astar, pavg;
+                        rusanov(L, R, d, advection_only, fstar, astar, pavg);
+                        for (int v = 0; v < 5; ++v) fr[f][v][fp] = fstar[v];
+                        fr[f][5][fp] = astar;
+                        fr[f][6][fp] = pavg / own.p;
+                        fr[f][7][fp] = std::log(own.p);
+                    }
+                }
+                // ---- nodal quantities
+                double qq[5][MAXN3], u[3][MAXN3], p[MAXN3], lp[MAXN3], sgv[MAXN3], hv[9][MAXN3];
+                for (int v = 0; v < 5; ++v) std::memcpy(qq[v], q + v * fs + e * n3, sizeof(double) * n3);
+                std::memcpy(sgv, sg + e * n3, sizeof(double) * n3);
+                for (int r = 0; r < 9; ++r) std::memcpy(hv[r], h + r * fs + e * n3, sizeof(double) * n3);
+                for (int pt = 0; pt < n3; ++pt) {
+                    for (int i = 0; i < 3; ++i) u[i][pt] = qq[1 + i][pt] / qq[0][pt];
+                    p[pt] = pressure_of(qq[4][pt]);
+                    lp[pt] = std::log(p[pt]);
+                }
+                double tot[5][MAXN3], wtot[MAXN3];
+                std::memset(tot, 0, sizeof(tot));
+                std::memset(wtot, 0, sizeof(wtot));
+                for (int d = 0; d < 3; ++d) {
+                    // fields to differentiate along d: 0..4 F^d, 5 A^d, 6 B^d, 7 log p
+                    double g[8][MAXN3];
+                    for (int pt = 0; pt < n3; ++pt) {
+                        const double sgu = sgv[pt] * u[d][pt];
+                        for (int v = 0; v < 5; ++v) g[v][pt] = sgu * qq[v][pt];
+                        g[5][pt] = g[3][pt];
+                        for (int i = 0; i < 3; ++i) g[1 + i][pt] += sgv[pt] * hv[3 * d + i][pt] * p[pt];
+                        g[6][pt] = sgv[pt] * hv[3 * d + 2][pt];
+                        g[7][pt] = lp[pt];
+                    }
+                    const int stride = d == 0 ? 1 : (d == 1 ? n : n2);
+                    for (int kl = 0; kl < n; ++kl)
+                        for (int jl = 0; jl < n; ++jl)
+                            for (int il = 0; il < n; ++il) {
+                                const int pt = (kl * n + jl) * n + il;
+                                const int ix = d == 0 ? il : (d == 1 ? jl : kl);
+                                const int base = pt - ix * stride;
+                                const int fp = d == 0 ? kl * n + jl : (d == 1 ? kl * n + il : jl * n + il);
+                                const double cm = C[2 * ix], cp = C[2 * ix + 1];
+                                double r[8];
+                                for (int c = 0; c < 8; ++c) {
+                                    double a = 0.0;
+                                    for (int m = 0; m < n; ++m) a += D[ix * n + m] * g[c][base + m * stride];
+                                    r[c] = a + cm * fr[2 * d][c][fp] + cp * fr[2 * d + 1][c][fp];
+                                }
+                                for (int v = 0; v < 5; ++v) tot[v][pt] += r[v];
+                                // W^d = [A@D + A*@C] + p [B@D + B*@C] + p B [log p@D + log p^@C]  (rhs_dfr.py:113-136)
+                                wtot[pt] += r[5] + p[pt] * r[6] + p[pt] * g[6][pt] * r[7];
+                            }
+                }
+                // ---- assembly, forcing
+                for (int kl = 0; kl < n; ++kl)
+                    for (int jl = 0; jl < n; ++jl)
+                        for (int il = 0; il < n; ++il) {
+                            const int pt = (kl * n + jl) * n + il;
+                            const size_t o = e * n3 + pt;
+                            const double isg = 1.0 / sgv[pt], rho = qq[0][pt];
+                            double R[5];
+                            for (int v = 0; v < 5; ++v) R[v] = -isg * tot[v][pt];
+                            R[3] = -isg * wtot[pt];
+                            double force[3];
+                            const double u1 = u[0][pt], u2 = u[1][pt], u3 = u[2][pt], pp = p[pt];
+                            for (int i = 0; i < 3; ++i) {
+                                const double* c = chr + (size_t)(i * 9) * fs + o;
+                                force[i] = 2.0 * rho * (c[0] * u1 + c[fs] * u2 + c[2 * fs] * u3) +
+                                           c[3 * fs] * (rho * u1 * u1 + hv[0][pt] * pp) +
+                                           2.0 * c[4 * fs] * (rho * u1 * u2 + hv[1][pt] * pp) +
+                                           2.0 * c[5 * fs] * (rho * u1 * u3 + hv[2][pt] * pp) +
+                                           c[6 * fs] * (rho * u2 * u2 + hv[4][pt] * pp) +
+                                           2.0 * c[7 * fs] * (rho * u2 * u3 + hv[5][pt] * pp) +
+                                           c[8 * fs] * (rho * u3 * u3 + hv[8][pt] * pp);
+                            }
+                            double hfv = 0.0;   // vertical high-filter of sqrtG rho (operators.py:75-80)
+                            for (int m = 0; m < n; ++m) {
+                                const int pm = (m * n + jl) * n + il;
+                                hfv += HF[kl * n + m] * sgv[pm] * qq[0][pm];
+                            }
+                            force[2] += idz[o] * kGravity * isg * hfv;
+                            if (damp) {
+                                const double dw = dcoef[o] * rho;
+                                force[0] += dw * (u1 - duref[o]);
+                                force[1] += dw * (u2 - duref[fs + o]);
+                                force[2] += dw * (u3 - duref[2 * fs + o]);
+                            }
+                            for (int i = 0; i < 3; ++i) R[1 + i] -= force[i];
+                            for (int v = 0; v < 5; ++v) rhs[v * fs + o] = advection_only ? 0.0 : R[v];
+                        }
+            }
+    return 0;
+}
+
+int wxo_max_threads() {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+}  // extern "C"

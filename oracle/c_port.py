@@ -1,0 +1,93 @@
+"""ctypes front end of the C++/OpenMP CPU restatement (oracle/c/euler3d_port.cpp).
+
+TEST INFRASTRUCTURE - only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+Same call shape as oracle.euler3d.Euler3DOracle (extrapolate / pack_edges / rhs), float64 only; pack_edges is the
+NumPy oracle's.  Built by `make -C oracle port` (or build() below, which bench.py and __graft_entry__.build() call).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy
+
+from .euler3d import Euler3DOracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "c", "libwxoracle.so")
+_P = ctypes.POINTER(ctypes.c_double)
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(HERE, "c", "euler3d_port.cpp")
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", HERE, "port"])
+    return LIB
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        # -march=native code does not travel between hosts: rebuild when the library was built elsewhere
+        stamp = LIB + ".host"
+        host = open("/proc/cpuinfo").read().split("model name", 2)[1].split("\n", 1)[0] if os.path.exists("/proc/cpuinfo") else ""
+        if not os.path.exists(LIB) or not os.path.exists(stamp) or open(stamp).read() != host:
+            build(force=True)
+            open(stamp, "w").write(host)
+        _lib = ctypes.CDLL(LIB)
+        _lib.wxo_euler3d_extrapolate.restype = ctypes.c_int
+        _lib.wxo_euler3d_rhs.restype = ctypes.c_int
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_P) if a is not None else None
+
+
+def _c(a):
+    return numpy.ascontiguousarray(a, dtype=numpy.float64)
+
+
+class Euler3DPortC(Euler3DOracle):
+    """The NumPy oracle's interface over the C++ kernels (extrapolate, rhs); threads = OpenMP threads per call."""
+
+    def __init__(self, *args, threads: int = 0, **kw):
+        super().__init__(*args, **kw)
+        self.threads = int(threads)
+        self.lib = load()
+        self._mc = None   # contiguous copies of the metric, made on the first rhs() (extrapolation needs none)
+        self._ops = [_c(x) for x in (self.em, self.ep, self.D, self.C, self.HF)]
+
+    def extrapolate(self, q):
+        n, H, V = self.n, self.H, self.V
+        q = _c(q)
+        itf = [numpy.empty((5, V, H, H, 2 * n * n)) for _ in range(3)]
+        rc = self.lib.wxo_euler3d_extrapolate(n, H, V, _p(self._ops[0]), _p(self._ops[1]), _p(q), _p(itf[0]), _p(itf[1]),
+                                              _p(itf[2]), self.threads)
+        assert rc == 0
+        return itf
+
+    def rhs(self, q, halo, itf=None, want=None):
+        n, H, V = self.n, self.H, self.V
+        q = _c(q)
+        if itf is None:
+            itf = self.extrapolate(q)
+        halo = [_c(x) for x in halo]
+        if self._mc is None:
+            m = self.m
+            self._mc = {k: _c(m[k]) for k in ("sqrtG_new", "h_contra_new", "christoffel", "inv_dzdeta_new", "sqrtG_itf_i_new",
+                                                "sqrtG_itf_j_new", "sqrtG_itf_k_new", "h_contra_itf_i_new",
+                                                "h_contra_itf_j_new", "h_contra_itf_k_new")}
+            self._damp = (_c(m["damp_coef"]), _c(m["damp_uref"])) if self.case_number in (21, 22) else (None, None)
+        mc = self._mc
+        out = numpy.empty_like(q)
+        rc = self.lib.wxo_euler3d_rhs(
+            n, H, V, self.case_number, _p(self._ops[2]), _p(self._ops[3]), _p(self._ops[4]), _p(q), _p(itf[0]), _p(itf[1]),
+            _p(itf[2]), _p(halo[0]), _p(halo[1]), _p(halo[2]), _p(halo[3]), _p(mc["sqrtG_new"]), _p(mc["h_contra_new"]),
+            _p(mc["christoffel"]), _p(mc["inv_dzdeta_new"]), _p(mc["sqrtG_itf_i_new"]), _p(mc["sqrtG_itf_j_new"]),
+            _p(mc["sqrtG_itf_k_new"]), _p(mc["h_contra_itf_i_new"]), _p(mc["h_contra_itf_j_new"]),
+            _p(mc["h_contra_itf_k_new"]), _p(self._damp[0]), _p(self._damp[1]), _p(out), self.threads)
+        assert rc == 0
+        return out
