@@ -355,6 +355,16 @@ size_t wx_multi_dot_workspace(int m);
 wx_status wx_multi_dot(const double* V, size_t ldv, int m, const double* w, size_t n, double* out, double* workspace,
                        wx_stream stream);
 wx_status wx_multi_axpy(double* w, const double* V, size_t ldv, int m, const double* h, size_t n, wx_stream stream);
+/* The low-synchronisation Gram-Schmidt step of solvers/fgmres.py:16-73 (_ortho_1_sync_igs: all rows against the last
+ * two in ONE fused reduction, then both rows corrected, scaled and orthogonalised against each other):
+ *   wx_multi_dot2   out[k] = <V[k], a>, out[m + k] = <V[k], b>, k < m, one pass over the rows
+ *                   (workspace: wx_multi_dot_workspace(2 m) doubles)
+ *   wx_pair_update  a -= sum_k ha[k] V[k];  b -= sum_k hb[k] V[k];  a *= scale_a;  b = (b - cross a) * scale_b
+ *                   in one pass (m may be 0; ha, hb: m doubles on the device) */
+wx_status wx_multi_dot2(const double* V, size_t ldv, int m, const double* a, const double* b, size_t n, double* out,
+                        double* workspace, wx_stream stream);
+wx_status wx_pair_update(double* a, double* b, const double* V, size_t ldv, int m, const double* ha, const double* hb,
+                         size_t n, double scale_a, double cross, double scale_b, wx_stream stream);
 
 #ifdef __cplusplus
 }

@@ -106,7 +106,7 @@ def _damping_fields(geom, metric, case_number, shape):
     return coef, uref
 
 
-def euler_case(name, ini, overrides, metric_panels, phase_panels, perturb=0.0, seed=1234):
+def euler_case(name, ini, overrides, metric_panels, phase_panels, perturb=0.0, seed=1234, monolith=False):
     cfg_probe = _config(ini, overrides)
     n = cfg_probe.num_solpts
     print(f"[{name}] {ini} n={n} H={cfg_probe.num_elements_horizontal} V={cfg_probe.num_elements_vertical}",
@@ -142,6 +142,20 @@ def euler_case(name, ini, overrides, metric_panels, phase_panels, perturb=0.0, s
         out["Q"] = Q.copy()
         R = rhs.full(Q)
         out["R"] = R.copy()
+        if monolith:
+            # the reference's one-function RHS (rhs/rhs_euler.py:158-517, dead code there) on the
+            # same state.  Its import of ProcessTopology from wx_mpi is stale at this commit: give the module the
+            # name it asks for (SURVEY 8c's workaround; no reference file is touched).
+            import process_topology
+            import wx_mpi
+
+            if not hasattr(wx_mpi, "ProcessTopology"):
+                wx_mpi.ProcessTopology = process_topology.ProcessTopology
+            from rhs.rhs_euler import RhsEuler
+
+            mono = RhsEuler(Q.shape, geom, ops, metric, pt, cfg.num_solpts, cfg.num_elements_horizontal,
+                            cfg.num_elements_vertical, cfg.case_number)
+            out["R_mono"] = numpy.array(mono(Q.copy()), copy=True)
         r = rhs.full
         want = set(EULER_LIGHT_ATTRS)
         if rank in phase_panels:
@@ -840,6 +854,13 @@ CASES = {
     "euler3d_c31p_n5_h2_v1": lambda nm: euler_case(
         nm, "dcmip31.ini", dict(num_solpts=5, num_elements_horizontal=2, num_elements_vertical=1),
         metric_panels=(1, 5), phase_panels=(), perturb=0.01),
+    # a11: the monolithic rhs_euler.py evaluated beside the DFR path (perturbed gravity wave; Schaer mountain + sponge)
+    "euler3d_mono_c31p_n4_h2_v2": lambda nm: euler_case(
+        nm, "dcmip31.ini", dict(num_solpts=4, num_elements_horizontal=2, num_elements_vertical=2),
+        metric_panels=(0, 4), phase_panels=(), perturb=0.01, monolith=True),
+    "euler3d_mono_c21_n3_h2_v3": lambda nm: euler_case(
+        nm, "dcmip21.ini", dict(num_solpts=3, num_elements_horizontal=2, num_elements_vertical=3),
+        metric_panels=(1, 5), phase_panels=(), monolith=True),
     # topography + Rayleigh damping (Schaer mountain), even n
     "euler3d_c21_n4_h3_v4": lambda nm: euler_case(
         nm, "dcmip21.ini", dict(num_solpts=4, num_elements_horizontal=3, num_elements_vertical=4),

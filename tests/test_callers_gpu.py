@@ -100,20 +100,23 @@ def _pipeline_against_plain(plain, piped, stack, dt):
     assert ((Qc - Qd).abs() <= 1e-13 * scale).all()
 
 
-def test_ros2_fgmres_step(setup):
+@pytest.mark.parametrize("ortho", ["igs", "cgs"])
+def test_ros2_fgmres_step(setup, ortho):
+    """One Ros2 step (integrators/ros2.py:24-81) through fgmres with the reference's one-synchronisation
+    Gram-Schmidt (the default) and with the classical variant: the reference needed 151 iterations for 1e-9."""
     from wxfactory_amd.integrators import Ros2
 
     g, rhs, stack = setup
-    ros = Ros2(rhs, tol=1e-9, gmres_restart=30)
+    ros = Ros2(rhs, tol=1e-9, gmres_restart=30, ortho=ortho)
     Qn = ros.step(stack("Q"), float(g["meta/dt_jvp"]))
     info = ros.solver_info
     assert info["flag"] == 0 and info["rel_residual"] < 1e-9
-    assert 100 <= info["iterations"] <= 220  # the reference's 1-sync variant needed 151
+    assert abs(info["iterations"] - 151) <= 2, info["iterations"]
     ref, q0 = stack("ros2").cpu().numpy(), stack("Q").cpu().numpy()
     ax = (0, 2, 3, 4, 5)
     upd = np.abs(ref - q0).max(axis=ax)
     err = np.abs(Qn.cpu().numpy() - ref).max(axis=ax)
-    assert (err <= 2e-4 * upd + 1e-12 * np.abs(ref).max(axis=ax)).all(), (err / upd)
+    assert (err <= 1e-7 * upd).all(), (err / upd)
 
 
 def test_kiops_and_epi2_step(setup):
@@ -130,15 +133,17 @@ def test_kiops_and_epi2_step(setup):
     vec[1] = R.flatten()
     phiv, stats = kiops([1], lambda v: matvec_fun(v, dt, Q, R, rhs, "complex"), vec, tol=1e-7, m_init=1, mmin=16, mmax=64)
     ref_stats = g["p0/kiops_stats"]
-    assert stats[0] == int(ref_stats[0]) and abs(stats[2] - int(ref_stats[2])) <= 6, (stats, ref_stats)
+    # the adaptive controller takes the reference's decisions: steps, rejections, Krylov vectors, exponentials, last m
+    assert [int(stats[i]) for i in (0, 1, 2, 3, 5)] == [int(ref_stats[i]) for i in (0, 1, 2, 3, 5)], (stats, ref_stats)
+    assert abs(float(stats[4]) - float(ref_stats[4])) <= 1e-3 * float(ref_stats[4])
     ref = stack("kiops_phiv").cpu().numpy()
     ax = (0, 2, 3, 4, 5)
     err = np.abs(phiv.cpu().numpy().reshape(ref.shape) - ref).max(axis=ax) / np.abs(ref).max(axis=ax)
-    assert (err < 1e-5).all(), err  # both sides converge to tol=1e-7 of the same phi_1(dt J) R
+    assert (err < 1e-8).all(), err
     Qn = Epi(2, rhs, tol=1e-7).step(Q, dt)
     refq, q0 = stack("epi2").cpu().numpy(), Q.cpu().numpy()
     upd = np.abs(refq - q0).max(axis=ax)
-    assert (np.abs(Qn.cpu().numpy() - refq).max(axis=ax) <= 1e-5 * upd).all()
+    assert (np.abs(Qn.cpu().numpy() - refq).max(axis=ax) <= 1e-7 * upd).all()
 
 
 def test_complex_step_jvp_with_dual_arithmetic(setup):
@@ -236,8 +241,6 @@ def test_krylov_vector_kernels(built_lib, m, n):
 def test_hipgraph_captured_matvec(setup):
     """BASELINE config 5, "hipGraph-captured matvec": the complex-step and the finite-difference Jacobian-vector
     products captured once and replayed with one host call."""
-    import time
-
     from wxfactory_amd.graph import GraphedFunction
     from wxfactory_amd.matvec import matvec_fun
 
@@ -251,21 +254,8 @@ def test_hipgraph_captured_matvec(setup):
             v = (scale * V).flatten()
             assert torch.equal(graphed(v), eager(v)), method
 
-        def clock(fn, reps=200):
-            v = V.flatten()
-            fn(v)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                fn(v)
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / reps * 1e6
-
-        te, tg = clock(eager), clock(graphed)
-        print(f"matvec_fun {method}: eager {te:.0f} us, graph replay {tg:.0f} us")
-        # launch-bound at this size.  (With the tiles batched into two launches per product the eager call is
-        # already down from ~190 us to ~30 us; the replay then saves only the Python / ctypes overhead.)
-        assert tg < 2.0 * te
+    # (replay against eager timings are reported by bench.py: extra.euler_ini_sizes - no timing assertion in the
+    # parity suite)
 
 
 @pytest.mark.parametrize("order", [3, 4, 5, 6])

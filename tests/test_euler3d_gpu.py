@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import EDGE_FIELDS, EULER_FIXTURES, golden, halo7, make_oracle, var_err, var_max
+from tests.util import EDGE_FIELDS, EULER_FIXTURES, MONOLITH_FIXTURES, golden, halo7, make_oracle, var_err, var_max
 
 pytestmark = pytest.mark.gpu
 
@@ -85,6 +85,27 @@ def test_rhs_matches_reference(name, cplx):
             tight = "31p" in name  # see tests/test_oracle_euler3d.py on max() tie-breaks
             ierr = var_err(R.imag, ref.imag) / np.maximum(var_max(ref.imag), g.eps * s * 1e-3)
             assert (ierr <= (1e-10 if tight else 1e-3)).all(), (name, p, ierr)
+        plan.close()
+
+
+@pytest.mark.parametrize("name", MONOLITH_FIXTURES)
+def test_rhs_matches_the_reference_monolith(name):
+    """the HIP path against R from the reference's one-function rhs/rhs_euler.py:158-517."""
+    from tests.gpu_util import make_plan, to_dev
+
+    g = golden(name)
+    for p in g.metric_panels():
+        plan = make_plan(g, p)
+        q = to_dev(g.q(p))
+        halo = [to_dev(halo7(h)) for h in g.halo(p)]
+        out = torch.full_like(q, float("nan"))
+        plan.extrap_pack(q, None)
+        plan.rhs(q, [h.data_ptr() for h in halo], out)
+        torch.cuda.synchronize()
+        mono = g[f"p{p}/R_mono"]
+        scale = np.maximum(var_max(mono), _scale(g, p, False))
+        err = var_err(out.cpu().numpy(), mono)
+        assert (err <= TOL * scale).all(), (name, p, err / scale)
         plan.close()
 
 
@@ -373,20 +394,6 @@ def test_batched_launch_equals_per_tile_launches(name):
     ref = np.stack([g.r(p) for p in range(6)])
     assert np.isfinite(rhs(Q).cpu().numpy()).all() and rhs(Q).shape == ref.shape
 
-    def clock(reps=200):
-        rhs(Q)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            rhs(Q)
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / reps * 1e6
-
-    tb = clock()
-    rhs.batched = False
-    tp = clock()
-    print(f"{name}: R(Q) of six panels: batched {tb:.0f} us, per-panel launches {tp:.0f} us")
-    assert tb < tp
 
 
 def test_whole_sphere_of_24_tiles_batched():

@@ -5,7 +5,7 @@ import pytest
 
 from oracle import cubed_sphere as cs
 from oracle.c_port import Euler3DPortC
-from tests.util import EULER_FIXTURES, golden, make_oracle, var_err, var_max
+from tests.util import EULER_FIXTURES, MONOLITH_FIXTURES, golden, make_oracle, var_err, var_max
 
 TOL = 1e-10
 
@@ -29,7 +29,7 @@ def test_port_faces_and_exchange(name):
             assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max(), (p, e)
 
 
-@pytest.mark.parametrize("name", EULER_FIXTURES)
+@pytest.mark.parametrize("name", EULER_FIXTURES + MONOLITH_FIXTURES)
 def test_port_rhs_matches_reference(name):
     g = golden(name)
     for p in g.metric_panels():

@@ -14,6 +14,9 @@ EULER_FIXTURES = [
     "euler3d_c31p_n5_h2_v1",
 ]
 
+# fixtures that also hold R from the reference's monolithic rhs/rhs_euler.py ("R_mono")
+MONOLITH_FIXTURES = ["euler3d_mono_c31p_n4_h2_v2", "euler3d_mono_c21_n3_h2_v3"]
+
 _cache = {}
 
 

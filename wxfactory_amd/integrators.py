@@ -56,8 +56,10 @@ class Tvdrk3:
 
 
 class Ros2:
-    def __init__(self, rhs_handle: Callable, tol: float = 1e-7, gmres_restart: int = 20, verbose: int = 0):
+    def __init__(self, rhs_handle: Callable, tol: float = 1e-7, gmres_restart: int = 20, verbose: int = 0,
+                 ortho: str = "igs"):
         self.rhs_handle, self.tol, self.gmres_restart, self.verbose = rhs_handle, tol, gmres_restart, verbose
+        self.ortho = ortho   # fgmres orthogonalisation: "igs" = the reference's one-synchronisation variant, "cgs"
         self.solver_info = None
         self.failure_flag = 0
 
@@ -69,7 +71,7 @@ class Ros2:
         t0 = time()
         Qnew, norm_r, norm_b, num_iter, flag, residuals = fgmres(
             A, b, x0=Q_flat, tol=self.tol, restart=self.gmres_restart, maxiter=20000 // self.gmres_restart,
-            verbose=self.verbose)
+            verbose=self.verbose, ortho=self.ortho)
         self.solver_info = dict(flag=flag, time=time() - t0, iterations=num_iter, residuals=residuals,
                                 rel_residual=norm_r / norm_b)
         self.failure_flag = flag

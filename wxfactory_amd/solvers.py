@@ -3,10 +3,14 @@
 global_norm / global_dotprod mirror reference wx_factory/solvers/global_operations.py:14-36 with the
 MPI allreduce replaced by torch.distributed (RCCL).  fgmres keeps the reference's signature and return
 tuple (solvers/fgmres.py:97-276): restarted flexible GMRES, Givens-updated residual, same
-stagnation/convergence flags.  Orthogonalisation is classical Gram-Schmidt on the device with a
-second pass only after heavy cancellation (one sweep over the basis for the dot products, one for
-the update, one host read per Krylov vector) instead of the reference's lagged 1-sync variant -
-the same Krylov iterates up to rounding.
+stagnation/convergence flags.  Orthogonalisation (argument `ortho`):
+  "igs"  (default) the reference's lagged one-synchronisation iterated Gram-Schmidt (fgmres.py:16-73): one fused
+         reduction per Krylov vector (every basis row against the last two rows: wx_multi_dot2), the small
+         recurrences on the host, one fused update of the two rows (wx_pair_update) - the reference's iterates;
+  "cgs"  classical Gram-Schmidt with a second pass only after heavy cancellation: fewer bytes per vector (one
+         sweep for the dot products, one for the update), the same Krylov space, iterates equal up to rounding.
+Every decision that changes the control flow is taken from all-reduced numbers, and a rank may own an empty
+slice (ranks 6, 7 of an 8-GPU node with whole panels): all ranks make the same collective calls.
 """
 import math
 from time import time
@@ -33,7 +37,7 @@ def global_norm(a: torch.Tensor, group=None) -> torch.Tensor:
 
 
 def global_inf_norm(a: torch.Tensor, group=None) -> torch.Tensor:
-    m = a.abs().max().reshape(1)
+    m = a.abs().max().reshape(1) if a.numel() else torch.zeros(1, dtype=a.real.dtype, device=a.device)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
     return m[0]
@@ -78,6 +82,77 @@ class _Basis:
         return w
 
 
+    def dots2(self, m: int, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        """[<V[k], a> for k < m] + [<V[k], b> for k < m] in one pass over the rows (device tensor of 2 m)."""
+        V = self.V
+        if not (self.gpu and a.is_contiguous() and b.is_contiguous()) or a.numel() == 0:
+            return torch.cat((V[:m] @ a, V[:m] @ b))
+        if self.work.numel() < int(self.lib.wx_multi_dot_workspace(2 * m)):
+            self.work = torch.empty(int(self.lib.wx_multi_dot_workspace(2 * V.shape[0])), dtype=torch.float64, device=V.device)
+        out = torch.empty(2 * m, dtype=torch.float64, device=V.device)
+        st = torch.cuda.current_stream(V.device).cuda_stream
+        self.check(self.lib.wx_multi_dot2(V.data_ptr(), V.stride(0), m, a.data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(),
+                                          self.work.data_ptr(), st), "wx_multi_dot2")
+        return out
+
+    def pair_update(self, a: torch.Tensor, b: torch.Tensor, m: int, ha, hb, scale_a: float, cross: float, scale_b: float):
+        """a -= sum_{k<m} ha[k] V[k];  b -= sum_{k<m} hb[k] V[k];  a *= scale_a;  b = (b - cross a) * scale_b."""
+        V = self.V
+        if not (self.gpu and a.is_contiguous() and b.is_contiguous()) or a.numel() == 0:
+            if m:
+                a -= torch.as_tensor(ha, dtype=a.dtype, device=a.device) @ V[:m]
+                b -= torch.as_tensor(hb, dtype=b.dtype, device=b.device) @ V[:m]
+            a *= scale_a
+            b -= cross * a
+            b *= scale_b
+            return
+        hab = torch.as_tensor(list(ha) + list(hb), dtype=torch.float64).to(V.device, non_blocking=True) if m else None
+        st = torch.cuda.current_stream(V.device).cuda_stream
+        self.check(self.lib.wx_pair_update(a.data_ptr(), b.data_ptr(), V.data_ptr(), V.stride(0), m,
+                                           hab.data_ptr() if m else None, hab[m:].data_ptr() if m else None, a.numel(),
+                                           scale_a, cross, scale_b, st), "wx_pair_update")
+
+
+class _LowSyncGramSchmidt:
+    """The reference's one-synchronisation iterated Gram-Schmidt with lagged normalisation (solvers/fgmres.py:16-73;
+    the low-synch GMRES family of Swirydowicz, Langou, Ananthan, Yang & Thomas 2020).  step(j) makes row j-1 of the
+    basis orthogonal to rows 0..j-2 and finishes row j-2 (second correction, normalisation) with ONE reduction:
+    the products of every row with rows j-2 and j-1.  R collects the Hessenberg columns, T the second-pass
+    corrections (also what turns a basis row back into the vector A was applied to), K the lagged products."""
+
+    def __init__(self, basis: "_Basis", rows: int, group=None):
+        import numpy
+
+        self.np = numpy
+        self.basis, self.group = basis, group
+        self.R = numpy.zeros((rows, rows))
+        self.T = numpy.zeros((rows, rows))
+        self.K = numpy.zeros((rows, rows))
+
+    def step(self, j: int) -> float:
+        np, R, T, K = self.np, self.R, self.T, self.K
+        V = self.basis.V
+        a, b = V[j - 2], V[j - 1]
+        gram = _allreduce(self.basis.dots2(j, a, b), self.group).tolist()   # the step's one reduction and host read
+        ga, gb = np.asarray(gram[:j]), np.asarray(gram[j:])
+        s = ga[: j - 2]                       # <V[k], a>, k < j-2: what the first pass left in a
+        R[: j - 1, j - 1] = gb[: j - 1]
+        norm = math.sqrt(ga[j - 2] - s @ s) if ga[j - 2] - s @ s >= 0.0 else math.nan
+        R[j - 2, j - 2] = norm
+        R[j - 2, j - 1] = (R[j - 2, j - 1] - s @ R[: j - 2, j - 1]) / norm
+        T[: j - 2, j - 2] = s / norm
+        if j > 2:
+            L = np.tril(T[: j - 2, : j - 2].T, -1) + np.eye(j - 2)
+            r3 = np.linalg.solve(L, s)
+            R[: j - 2, j - 2] = K[: j - 2, j - 3] + r3
+            K[: j - 1, j - 2] = (R[: j - 1, j - 1] - R[: j - 1, 1: j - 1] @ r3) / norm
+            self.basis.pair_update(a, b, j - 2, s, R[: j - 2, j - 1], 1.0 / norm, R[j - 2, j - 1], 1.0 / norm)
+        else:
+            K[: j - 1, j - 2] = R[: j - 1, j - 1] / norm
+            self.basis.pair_update(a, b, 0, (), (), 1.0 / norm, R[j - 2, j - 1], 1.0 / norm)
+        return norm
+
+
 _REORTH = 0.1  # fgmres: re-orthogonalise when |w - V V^T w| < _REORTH |w| (orthogonality kept to ~1e-15 / _REORTH)
 
 
@@ -93,17 +168,38 @@ def _rotg(a: float, b: float):
     return a / r, b / r, r
 
 
+def _global_len(b: torch.Tensor, group=None) -> int:
+    t = torch.tensor([b.numel()], dtype=torch.int64, device=b.device)
+    return int(_allreduce(t, group)[0])
+
+
+def _stagnated(update: torch.Tensor, x: torch.Tensor, group=None) -> bool:
+    """fgmres.py:263-268: largest relative change of a non-zero component below 1e-12 - decided from an all-reduced
+    number (a rank whose slice of x is empty or all zero contributes inf to the MIN, 0 to the MAX)."""
+    nz = x != 0
+    rel = torch.where(nz, update / torch.where(nz, x, torch.ones_like(x)), torch.zeros_like(x))
+    stat = torch.stack((global_inf_norm(rel, group).to(torch.float64),
+                        global_inf_norm(nz.to(torch.float64), group)))   # (largest change, any non-zero anywhere)
+    change, any_nz = stat.tolist()
+    return any_nz > 0.0 and change < 1e-12
+
+
 def fgmres(A: Callable, b: torch.Tensor, x0: Optional[torch.Tensor] = None, tol: float = 1e-5, restart: int = 20,
-           maxiter: Optional[int] = None, preconditioner: Optional[Callable] = None, verbose: int = 0, group=None
-           ) -> Tuple[torch.Tensor, float, float, int, int, List[Tuple[float, float, float]]]:
+           maxiter: Optional[int] = None, preconditioner: Optional[Callable] = None, verbose: int = 0, group=None,
+           ortho: str = "igs") -> Tuple[torch.Tensor, float, float, int, int, List[Tuple[float, float, float]]]:
     """Solve A x = b.  Returns (x, norm_r, norm_b, num_iter, flag, residuals) like the reference."""
-    if b.numel() <= restart:
+    n_global = _global_len(b, group)
+    if n_global <= restart:
         raise ValueError("The b vector should be longer than the number of restart")
+    if ortho not in ("igs", "cgs"):
+        raise ValueError("ortho must be 'igs' (the reference's one-synchronisation variant) or 'cgs'")
+    if ortho == "igs":
+        return _fgmres_low_sync(A, b, x0, tol, restart, maxiter, preconditioner, verbose, group, n_global)
     t0 = time()
     M = preconditioner if preconditioner is not None else (lambda v: v)
     n = b.numel()
     if maxiter is None:
-        maxiter = n * 10
+        maxiter = n_global * 10
     x = torch.zeros_like(b) if x0 is None else x0.clone()
     norm_b = float(global_norm(b, group))
     if norm_b == 0.0:
@@ -182,12 +278,102 @@ def fgmres(A: Callable, b: torch.Tensor, x0: Optional[torch.Tensor] = None, tol:
         residuals.append((norm_r / norm_b, time() - t0, 0.0))
         if verbose > 0:
             print(f"res: {norm_r/norm_b:.2e} (iter {niter})", flush=True)
-        # largest relative change of a non-zero component (fgmres.py:263-268), without index arrays
-        update.div_(torch.where(x != 0, x, torch.full_like(x, math.inf)))
-        if bool((x != 0).any()):
-            change = float(global_inf_norm(update, group))
-            if change < 1e-12:
-                return x, norm_r, norm_b, niter, -1, residuals
+        if _stagnated(update, x, group):
+            return x, norm_r, norm_b, niter, -1, residuals
+        if norm_r < tol_abs:
+            return x, norm_r, norm_b, niter, 0, residuals
+    return x, norm_r, norm_b, niter, (0 if norm_r < tol_abs else -1), residuals
+
+
+def _fgmres_low_sync(A, b, x0, tol, restart, maxiter, preconditioner, verbose, group, n_global):
+    """fgmres with the reference's lagged one-synchronisation Gram-Schmidt (solvers/fgmres.py:160-276).  A Krylov
+    vector is handed to A before it is normalised (scaled by the norm of its predecessor and back, as the reference
+    does for its finite-difference operators), and finished one step later.  Without a preconditioner no second set
+    of vectors is kept: the vector A was applied to is the finished basis row plus the second-pass correction
+    recorded in T, so  sum_i y_i z_i = V^T (y + T y)  (row 0: scaled by its norm R[0, 0])."""
+    t0 = time()
+    n = b.numel()
+    if maxiter is None:
+        maxiter = n_global * 10
+    x = torch.zeros_like(b) if x0 is None else x0.clone()
+    norm_b = float(global_norm(b, group))
+    if norm_b == 0.0:
+        return torch.zeros_like(b), 0.0, 0.0, 0, 0, [(0.0, time() - t0, 0.0)]
+    tol_abs = tol * norm_b
+    r = b - A(x)
+    norm_r = float(global_norm(r, group))
+    residuals = [(norm_r / norm_b, time() - t0, 0.0)]
+    niter = 0
+    V = torch.empty((restart + 2, n), dtype=b.dtype, device=b.device)
+    Z = torch.empty((restart + 1, n), dtype=b.dtype, device=b.device) if preconditioner is not None else None
+    basis = _Basis(V)
+    for _outer in range(maxiter):
+        gs = _LowSyncGramSchmidt(basis, restart + 2, group)
+        Hm = [[0.0] * (restart + 2) for _ in range(restart)]   # Hm[j][i] = h_{i,j} after the rotations
+        cs, sn = [], []
+        g = [0.0] * (restart + 2)
+        g[0] = norm_r
+        torch.div(r, norm_r, out=V[0])
+        if Z is not None:
+            Z[0] = preconditioner(V[0])
+            V[1] = A(Z[0])
+        else:
+            V[1] = A(V[0])
+        v_norm = gs.step(2)
+        k = 0
+        for j in range(restart):
+            niter += 1
+            zj = preconditioner(V[j + 1]) if Z is not None else V[j + 1]
+            if Z is not None:
+                Z[j + 1] = zj
+            w = A(zj / v_norm)
+            torch.mul(w, v_norm, out=V[j + 2])
+            v_norm = gs.step(j + 3)
+            if Z is not None:
+                Z[j + 1] /= v_norm
+            hj = gs.R[: j + 2, j + 1].tolist()
+            for i in range(j):  # previous rotations
+                t = cs[i] * hj[i] + sn[i] * hj[i + 1]
+                hj[i + 1] = -sn[i] * hj[i] + cs[i] * hj[i + 1]
+                hj[i] = t
+            if hj[j + 1] != 0.0:
+                c, s_, rr = _rotg(hj[j], hj[j + 1])
+                hj[j], hj[j + 1] = c * hj[j] + s_ * hj[j + 1], 0.0
+                g[j], g[j + 1] = c * g[j] + s_ * g[j + 1], -s_ * g[j] + c * g[j + 1]
+            else:
+                c, s_ = 1.0, 0.0
+            cs.append(c)
+            sn.append(s_)
+            Hm[j][: j + 2] = hj
+            k = j + 1
+            if j < restart - 1:
+                norm_r = abs(g[j + 1])
+                residuals.append((norm_r / norm_b, time() - t0, 0.0))
+                if norm_r < tol_abs or norm_r != norm_r:
+                    break
+        y = [0.0] * k
+        for i in range(k - 1, -1, -1):
+            acc = g[i]
+            for l in range(i + 1, k):
+                acc -= Hm[l][i] * y[l]
+            y[i] = acc / Hm[i][i]
+        if Z is not None:
+            update = torch.as_tensor(y, dtype=b.dtype, device=b.device) @ Z[:k]
+        else:
+            import numpy
+
+            yv = numpy.asarray(y)
+            yh = yv + gs.T[:k, :k] @ yv
+            yh[0] += (gs.R[0, 0] - 1.0) * yv[0]
+            update = torch.as_tensor(yh, dtype=b.dtype, device=b.device) @ V[:k]
+        x += update
+        r = b - A(x)
+        norm_r = float(global_norm(r, group))
+        residuals.append((norm_r / norm_b, time() - t0, 0.0))
+        if verbose > 0:
+            print(f"res: {norm_r/norm_b:.2e} (iter {niter})", flush=True)
+        if _stagnated(update, x, group):
+            return x, norm_r, norm_b, niter, -1, residuals
         if norm_r < tol_abs:
             return x, norm_r, norm_b, niter, 0, residuals
     return x, norm_r, norm_b, niter, (0 if norm_r < tol_abs else -1), residuals
