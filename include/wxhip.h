@@ -11,8 +11,17 @@
  *   - every call returns a wx_status; wx_last_error() gives the message (thread local).
  *   - all array arguments are DEVICE pointers unless marked [host]; the caller owns them
  *     (same ownership rule as the reference's pybind module, pde/interface.hpp:158-171).
- *   - all work is enqueued on the caller's hipStream_t; no entry point synchronises the
- *     device, allocates after plan creation, or keeps a pointer to q / rhs / halo.
+ *   - all work is enqueued on the caller's hipStream_t; no evaluation entry point synchronises the
+ *     device, allocates after plan creation, or keeps a pointer to q / rhs / halo.  The stream's
+ *     device is made current for the duration of a call (and restored), so a process may drive
+ *     several GPUs, or call with another current device, without invalid-handle errors.
+ *   - SETUP-TIME calls are the exception: wx_*_plan_create*, wx_*_batch_create, wx_expfilter_create and
+ *     wx_euler3d_set_exp_filter allocate, use the null stream and blocking copies, and SYNCHRONISE THE
+ *     DEVICE first (so that static fields still being produced on a non-blocking stream are complete,
+ *     and no kernel is still reading constants about to be replaced).  Do not call them while a
+ *     stream is being captured into a graph.
+ *   - device flags (nan_flag arguments) are only ever raised to 1 by plain stores from many threads - one
+ *     value, so no atomic is needed - and never cleared by the library.
  *   - arrays are C-contiguous float64 (WX_F64) or complex128 (WX_C128, interleaved
  *     re,im) in the reference's element-blocked layout (geometry/cubed_sphere_3d.py:187-205):
  *         state     q[var][ek][ej][ei][p],  p = (kl*n + jl)*n + il

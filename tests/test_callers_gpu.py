@@ -100,6 +100,38 @@ def _pipeline_against_plain(plain, piped, stack, dt):
     assert ((Qc - Qd).abs() <= 1e-13 * scale).all()
 
 
+def test_pipeline_contract_invalidate_and_debug_check(setup):
+    """A write the version counter cannot see (here through `.data`, as a raw-pointer kernel would) must be announced
+    with invalidate_faces(); check_faces turns a forgotten announcement into an error instead of stale faces."""
+    from wxfactory_amd.integrators import Tvdrk3
+
+    g, rhs, stack = setup
+    dt = float(g["meta/dt_rk"])
+    plain, piped = Tvdrk3(rhs, pipeline=False), Tvdrk3(rhs, pipeline=True)
+    rhs.batched = False
+    try:
+        Qa, Qb = plain.step(stack("Q"), dt), piped.step(stack("Q"), dt)
+        v0 = Qb._version
+        Qa.data.mul_(1.0 + 1e-3)
+        Qb.data.mul_(1.0 + 1e-3)
+        assert Qb._version == v0   # invisible to torch
+        rhs.check_faces = True
+        with pytest.raises(RuntimeError, match="invalidate_faces"):
+            piped.step(Qb, dt)
+        rhs.check_faces = False
+        rhs.invalidate_faces()
+        Qa2, Qb2 = plain.step(Qa, dt), piped.step(Qb, dt)
+        scale = Qa2.abs().amax(dim=(0, 2, 3, 4, 5), keepdim=True)
+        assert ((Qa2 - Qb2).abs() <= 1e-14 * scale).all()
+        # an honest chain passes the check
+        rhs.check_faces = True
+        Qb3 = piped.step(Qb2, dt)
+        assert ((plain.step(Qa2, dt) - Qb3).abs() <= 1e-14 * scale).all()
+    finally:
+        rhs.check_faces = False
+        rhs.batched = True
+
+
 @pytest.mark.parametrize("ortho", ["igs", "cgs"])
 def test_ros2_fgmres_step(setup, ortho):
     """One Ros2 step (integrators/ros2.py:24-81) through fgmres with the reference's one-synchronisation

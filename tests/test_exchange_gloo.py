@@ -176,17 +176,23 @@ def test_panel_rhs_orchestration_over_gloo(world):
     assert all(r[1] == "ok" for r in res), [r for r in res if r[1] != "ok"]
 
 
-def _state_worker(rank, world, port, q):
+def _state_worker(rank, world, port, q, k):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        from wxfactory_amd.panels import panels_of_rank
+        from wxfactory_amd.panels import CubeTopology, tiles_of_rank
         from wxfactory_amd.state import distribute_cube, gather_cube
 
-        glob = torch.arange(6 * 3 * 2 * 2 * 4, dtype=torch.float64).reshape(6, 3, 2, 2, 4)
-        local = distribute_cube(glob if rank == 0 else None, rank, world)
-        assert torch.equal(local, glob[panels_of_rank(rank, world)])
-        back = gather_cube(local, rank, world)
+        Ht, V, n3 = 2, 3, 4
+        glob = torch.arange(6 * 5 * V * (k * Ht) * (k * Ht) * n3, dtype=torch.float64).reshape(6, 5, V, k * Ht, k * Ht, n3)
+        local = distribute_cube(glob if rank == 0 else None, rank, world, tiles_per_side=k, tile_shape=(5, V, Ht, Ht, n3))
+        topo = CubeTopology(k)
+        mine = tiles_of_rank(rank, world, topo.ntiles)
+        assert local.shape == (len(mine), 5, V, Ht, Ht, n3)
+        for i, t in enumerate(mine):   # tile (panel, row, col) = rows along axis -3, columns along axis -2
+            p, r, c = topo.locate(t)
+            assert torch.equal(local[i], glob[p, :, :, r * Ht:(r + 1) * Ht, c * Ht:(c + 1) * Ht, :])
+        back = gather_cube(local, rank, world, tiles_per_side=k)
         assert (back is None) == (rank != 0)
         if rank == 0:
             assert torch.equal(back, glob)
@@ -200,12 +206,14 @@ def _state_worker(rank, world, port, q):
         raise
 
 
-@pytest.mark.parametrize("world", [2, 8])
-def test_checkpoint_layout_is_rank_count_independent(world):
+@pytest.mark.parametrize("world,k", [(2, 1), (8, 1), (4, 2), (8, 2)])
+def test_checkpoint_layout_is_rank_count_independent(world, k):
+    """gather_cube / distribute_cube (process_topology.py:444-539) for whole panels and for the 24-tile layout the
+    benchmark uses on 4 and 8 GPUs; only rank 0 holds the global array (tensor gather / scatter)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_state_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_state_worker, args=(r, world, port, q, k)) for r in range(world)]
     [p.start() for p in procs]
     res = [q.get(timeout=180) for _ in range(world)]
     [p.join(timeout=60) for p in procs]

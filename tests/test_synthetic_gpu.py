@@ -145,3 +145,62 @@ def test_mass_conservation_at_full_size(n, H, V):
     Q2 = stepper.step(Q1, 0.02)  # second step starts from faces prepared by the first
     m0, m2 = mass(Q), mass(Q2)
     assert float((Q2 - Q).abs().max()) > 0 and abs(m2 - m0) <= 1e-12 * abs(m0), (m0, m2)
+
+
+def test_shallow_water_mass_conservation_at_s7():
+    """The S7 workload of BASELINE.json's galewsky line at FULL size (shallow water, n = 8, 60 x 60 elements per panel,
+    6 panels, 1.24 M DOF) through its size-independent property: the continuity row is in flux form, so the quadrature
+    of sqrtG * R[h] over the closed sphere telescopes to zero - every AUSM interface flux, across rotated and flipped
+    panel edges too, is the same number from both sides.  Own cubed-sphere metric, seeded state; one evaluation with
+    all panels in one launch per phase and one through the per-panel launches."""
+    import numpy as np
+
+    from wxfactory_amd import synthetic
+    from wxfactory_amd.geometry import CubedSphereTile2D, metric2d_torch
+    from wxfactory_amd.rhs_sw import RhsShallowWater, SwPlan
+
+    dev = "cuda:0"
+    n, H = 8, 60
+    w1 = np.polynomial.legendre.leggauss(n)[1]
+    w2 = torch.from_numpy(np.einsum("j,i->ji", w1, w1).reshape(-1)).to(dev)
+    plans, sg = {}, []
+    for p in range(6):
+        m = metric2d_torch(CubedSphereTile2D(n, H, p, phi0=0.7853981633974483), dev)
+        sg.append(m["sqrtG"])
+        plans[p] = SwPlan(n, H, p, synthetic.dfr_ops(n), m)
+    Q = torch.stack([synthetic.sw_state(n, H, p, dev, 5) for p in range(6)])
+    rhs = RhsShallowWater(plans)
+    SG = torch.stack(sg).reshape(6, H, H, n * n)
+    for batched in (True, False):
+        rhs.batched = batched
+        R = rhs(Q)
+        dens = SG * R[:, 0].reshape(6, H, H, n * n) * w2
+        total, gross = float(dens.sum()), float(dens.abs().sum())
+        assert gross > 0 and abs(total) <= 1e-11 * gross, (batched, total, gross)
+
+
+def test_checkpoint_round_trip_from_device_tensors(tmp_path):
+    """SURVEY 8f-4 on the GPU: the stacked states of the 24-tile layout (device tensors) -> global array ->
+    the reference's file format -> back to device tiles, bit for bit; the global array is the same one the
+    6-tile layout of the same sphere produces (rank-count independence, tests/unit/restart/test_restart.py:107-151)."""
+    from wxfactory_amd.panels import CubeTopology
+    from wxfactory_amd.state import distribute_cube, gather_cube, load_state, save_state
+
+    dev = "cuda:0"
+    n3, V, H = 27, 2, 4
+    gen = torch.Generator(device=dev).manual_seed(3)
+    glob = torch.rand((6, 5, V, H, H, n3), generator=gen, device=dev, dtype=torch.float64)
+    tiles24 = distribute_cube(glob, tiles_per_side=2, device=dev)
+    assert tiles24.is_cuda and tiles24.shape == (24, 5, V, H // 2, H // 2, n3)
+    topo = CubeTopology(2)
+    p, r, c = topo.locate(13)
+    assert torch.equal(tiles24[13], glob[p, :, :, r * 2:(r + 1) * 2, c * 2:(c + 1) * 2, :])
+    back = gather_cube(tiles24, tiles_per_side=2)
+    assert back.is_cuda and torch.equal(back, glob)
+    assert torch.equal(gather_cube(distribute_cube(glob, tiles_per_side=1, device=dev)), glob)
+    f = tmp_path / "state.npy"
+    save_state(back, "v", "[General]\nequations = Euler\n", str(f))
+    state, version, config = load_state(str(f))
+    assert version == "v" and "equations = Euler" in config
+    again = distribute_cube(state, tiles_per_side=2, device=dev)
+    assert again.is_cuda and torch.equal(again, tiles24)

@@ -285,7 +285,7 @@ wx_status wx_pointwise_eulercartesian_2d(const void* q, void* flux_x1, void* flu
     if (num_elem_x1 < 1 || num_elem_x3 < 1 || num_solpts_tot < 1) return fail(WX_ERR_INVALID, "bad sizes");
     const size_t npts = (size_t)num_elem_x1 * num_elem_x3 * num_solpts_tot;
     const int grid = (int)((npts + 255) / 256);
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    WX_STREAM(st, stream);
     if (dtype == WX_F64)
         hipLaunchKernelGGL((cart2d_pointwise_kernel<double>), dim3(grid), dim3(256), 0, st, (const double*)q,
                            (double*)flux_x1, (double*)flux_x3, npts);
@@ -309,7 +309,7 @@ wx_status wx_riemann_eulercartesian_ausm_2d(const void* q_itf_x1, const void* q_
     if (num_elem_x1 < 1 || num_elem_x3 < 1 || num_solpts < 1) return fail(WX_ERR_INVALID, "bad sizes");
     const int total = num_elem_x1 * num_elem_x3 * num_solpts;
     const int grid = (total + 255) / 256;
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    WX_STREAM(st, stream);
     if (dtype == WX_F64)
         hipLaunchKernelGGL((cart2d_riemann_kernel<double>), dim3(grid), dim3(256), 0, st, (const double*)q_itf_x1,
                            (const double*)q_itf_x3, (double*)flux_itf_x1, (double*)flux_itf_x3, num_elem_x1, num_elem_x3,
@@ -336,7 +336,7 @@ wx_status wx_forcing_euler_cubesphere_3d(const void* q, const void* pressure, co
         return fail(WX_ERR_INVALID, "wx_forcing_euler_cubesphere_3d: null argument");
     const size_t npts = (size_t)num_elem_x1 * num_elem_x2 * num_elem_x3 * num_solpts;
     const int grid = (int)((npts + 127) / 128);
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    WX_STREAM(st, stream);
     if (dtype == WX_F64)
         hipLaunchKernelGGL((euler3d_forcing_kernel<double>), dim3(grid), dim3(128), 0, st, (const double*)q,
                            (const double*)pressure, h, christoffel, (double*)forcing, npts);
@@ -392,7 +392,7 @@ wx_status wx_cart2d_plan_destroy(wx_cart2d_plan* pl) {
 
 wx_status wx_cart2d_rhs(wx_cart2d_plan* pl, const void* q, void* rhs, wx_stream stream) {
     if (!pl || !q || !rhs) return fail(WX_ERR_INVALID, "wx_cart2d_rhs: null argument");
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    WX_STREAM(st, stream);
     if (pl->dtype == WX_F64) {
         CartParams<double> P{pl->nx, pl->nz, -2.0 / pl->dx1, -2.0 / pl->dx3, (const double*)q, (double*)rhs, pl->consts};
         return cart_dispatch<double>(pl->n, P, st);

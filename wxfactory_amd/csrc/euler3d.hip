@@ -1072,7 +1072,7 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
         if (active && P.nan_flag != nullptr &&
             (w_real(r0) != w_real(r0) || w_real(r1) != w_real(r1) || w_real(r2) != w_real(r2) ||
              w_real(r3) != w_real(r3) || w_real(r4) != w_real(r4)))
-            *P.nan_flag = 1;
+            *P.nan_flag = 1;   // many writers, one value: a plain store is as good as an atomic OR (never cleared here)
     }
     if (active) {
         store_r<T>(P, o, r0);
@@ -1353,7 +1353,7 @@ __global__ __launch_bounds__(256) void any_nonzero_kernel(const double* __restri
     bool any = false;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
         any = any || (x[i] != 0.0);
-    if (any) *flag = 1;
+    if (any) *flag = 1;   // many writers, one value: benign
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1576,9 +1576,9 @@ wx_status wx_euler3d_plan_create_tile(wx_euler3d_plan** out, int n, int H, int V
     pl->itf_bytes = pl->nelem * 6 * NQ * n * n * esz;
     hipError_t e = hipMalloc(&pl->itf, pl->itf_bytes);
     if (e != hipSuccess) {
+        const size_t want = pl->itf_bytes;
         delete pl;
-        return fail(WX_ERR_NOMEM, "hipMalloc(%zu bytes) for the interface buffer failed: %s", pl->itf_bytes,
-                    hipGetErrorString(e));
+        return fail(WX_ERR_NOMEM, "hipMalloc(%zu bytes) for the interface buffer failed: %s", want, hipGetErrorString(e));
     }
     EulerParams<double>& b = pl->base;
     b.H = H; b.V = V; b.nelem = (int)pl->nelem; b.count = 0; b.region = 0;
@@ -1590,6 +1590,9 @@ wx_status wx_euler3d_plan_create_tile(wx_euler3d_plan** out, int n, int H, int V
     b.bsn = m->boundary_sn; b.bwe = m->boundary_we;
     {   // static-field specialisation: are the nine rotation Christoffel symbols identically zero (cases on a
         // non-rotating planet: DCMIP 2-x, 3-1)?  One pass over them now saves 72 B/point in every evaluation.
+        // Plan creation is a SETUP-TIME call: it synchronises the device first (the metric may still be in the making
+        // on a non-blocking stream, which the null stream used here does not wait for) and must not be captured.
+        (void)hipDeviceSynchronize();
         int* flag = nullptr;
         int any = 1;
         e = hipMalloc((void**)&flag, sizeof(int));
@@ -1667,7 +1670,7 @@ size_t wx_euler3d_edge_count(const wx_euler3d_plan* pl) {
 
 wx_status wx_euler3d_extrap_pack(wx_euler3d_plan* pl, const void* q, void* const send[4], wx_stream stream) {
     if (!pl || !q) return fail(WX_ERR_INVALID, "wx_euler3d_extrap_pack: null argument");
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    WX_STREAM(st, stream);
     switch (pl->dtype) {
         case WX_F64: return run_extrap<double>(pl, q, send, st);
         case WX_C128: return run_extrap<cplx>(pl, q, send, st);
@@ -1688,7 +1691,7 @@ static wx_status euler3d_rhs_impl(wx_euler3d_plan* pl, const void* q, const void
         for (int e = 0; e < 4; ++e)
             if (!halo[e]) return fail(WX_ERR_INVALID, "wx_euler3d_rhs: halo[%d] is null", e);
     }
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    WX_STREAM(st, stream);
     switch (pl->dtype) {
         case WX_F64: return run_rhs<double>(pl, q, halo, out, region, st, axpy, y, ca, cb, cc, z, cd);
         case WX_C128: return run_rhs<cplx>(pl, q, halo, out, region, st, axpy, y, ca, cb, cc, z, cd);
@@ -1718,7 +1721,8 @@ wx_status wx_euler3d_jvp_extrap_pack(wx_euler3d_plan* pl, const double* q, const
         P.send_s = static_cast<dual*>(send[0]); P.send_n = static_cast<dual*>(send[1]);
         P.send_w = static_cast<dual*>(send[2]); P.send_e = static_cast<dual*>(send[3]);
     }
-    return dispatch_extrap<dual>(pl->n, P, static_cast<hipStream_t>(stream));
+    WX_STREAM(st, stream);
+    return dispatch_extrap<dual>(pl->n, P, st);
 }
 
 wx_status wx_euler3d_jvp(wx_euler3d_plan* pl, const double* q, const double* v, double eps, const void* const halo[4],
@@ -1740,8 +1744,8 @@ wx_status wx_euler3d_jvp(wx_euler3d_plan* pl, const double* q, const double* v, 
         P.halo_w = static_cast<const dual*>(halo[2]); P.halo_e = static_cast<const dual*>(halo[3]);
     }
     static const bool lean = [] { const char* e = getenv("WXHIP_JVP_LEAN"); return !(e && e[0] == '0'); }();
-    if (!lean) return dispatch_rhs<dual>(pl->n, P, static_cast<hipStream_t>(stream));
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    WX_STREAM(st, stream);
+    if (!lean) return dispatch_rhs<dual>(pl->n, P, st);
     switch (pl->n) {
         case 2: return launch_jvp<2>(P, st);
         case 3: return launch_jvp<3>(P, st);
@@ -1771,7 +1775,8 @@ wx_status wx_euler3d_shifted_extrap_pack(wx_euler3d_plan* pl, const double* q, c
         P.send_s = static_cast<double*>(send[0]); P.send_n = static_cast<double*>(send[1]);
         P.send_w = static_cast<double*>(send[2]); P.send_e = static_cast<double*>(send[3]);
     }
-    return dispatch_extrap<double>(pl->n, P, static_cast<hipStream_t>(stream));
+    WX_STREAM(st, stream);
+    return dispatch_extrap<double>(pl->n, P, st);
 }
 
 wx_status wx_euler3d_shifted_rhs_axpy2(wx_euler3d_plan* pl, const double* q, const double* v, double eps,
@@ -1795,7 +1800,8 @@ wx_status wx_euler3d_shifted_rhs_axpy2(wx_euler3d_plan* pl, const double* q, con
         P.halo_s = static_cast<const double*>(halo[0]); P.halo_n = static_cast<const double*>(halo[1]);
         P.halo_w = static_cast<const double*>(halo[2]); P.halo_e = static_cast<const double*>(halo[3]);
     }
-    return dispatch_rhs<double>(pl->n, P, static_cast<hipStream_t>(stream));
+    WX_STREAM(st, stream);
+    return dispatch_rhs<double>(pl->n, P, st);
 }
 
 static wx_status ensure_slot1(wx_euler3d_plan* pl) {
@@ -1811,7 +1817,7 @@ wx_status wx_euler3d_extrap_pack_slot(wx_euler3d_plan* pl, const void* q, void* 
     if (!pl || !q) return fail(WX_ERR_INVALID, "wx_euler3d_extrap_pack_slot: null argument");
     if (slot != 0 && slot != 1) return fail(WX_ERR_INVALID, "interface slot %d not in {0,1}", slot);
     if (slot == 1) { wx_status s1 = ensure_slot1(pl); if (s1 != WX_OK) return s1; }
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    WX_STREAM(st, stream);
     switch (pl->dtype) {
         case WX_F64: return run_extrap<double>(pl, q, send, st, slot);
         case WX_C128: return run_extrap<cplx>(pl, q, send, st, slot);
@@ -1824,6 +1830,8 @@ wx_status wx_euler3d_set_exp_filter(wx_euler3d_plan* pl, const double* filter) {
     if (!pl || !filter) return fail(WX_ERR_INVALID, "wx_euler3d_set_exp_filter: null argument");
     double ef[kMaxN * kMaxN] = {0.0};
     for (int i = 0; i < pl->n * pl->n; ++i) ef[i] = filter[i];
+    // setup-time call: kernels still reading the old matrix on any stream (a non-blocking one included) finish first
+    WX_HIP_TRY(hipDeviceSynchronize());
     WX_HIP_TRY(hipMemcpy(pl->consts->EF, ef, sizeof(ef), hipMemcpyHostToDevice));
     return WX_OK;
 }
@@ -1842,7 +1850,7 @@ wx_status wx_euler3d_stage(wx_euler3d_plan* pl, const void* q, const void* const
             if (!halo[e]) return fail(WX_ERR_INVALID, "wx_euler3d_stage: halo[%d] is null", e);
     }
     if (prepare_next || itf_in == 1) { wx_status s1 = ensure_slot1(pl); if (s1 != WX_OK) return s1; }
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    WX_STREAM(st, stream);
     const bool ep = prepare_next != 0, ef = prepare_next == 2;
     switch (pl->dtype) {
         case WX_F64: return run_rhs<double>(pl, q, halo, out, region, st, 1, y, a, b, c, z, d, itf_in, next_send, ep, ef, nan_flag);
@@ -1979,7 +1987,7 @@ wx_status wx_euler3d_batch_extrap_pack(const wx_euler3d_batch* b, const void* q,
                                        size_t panel_stride, wx_stream stream) {
     if (!b || !q) return fail(WX_ERR_INVALID, "wx_euler3d_batch_extrap_pack: null argument");
     if (v && b->dtype == WX_C128) return fail(WX_ERR_INVALID, "a shift / tangent vector needs a WX_F64 or WX_DUAL128 batch");
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    WX_STREAM(st, stream);
     switch (b->dtype) {
         case WX_F64: return batch_extrap<double>(b, q, v, eps, panel_stride, st);
         case WX_C128: return batch_extrap<cplx>(b, q, nullptr, 0.0, panel_stride, st);
@@ -1999,7 +2007,7 @@ wx_status wx_euler3d_batch_jvp(const wx_euler3d_batch* b, const double* q, const
     dyn.stride_re = panel_stride;
     dyn.region = region; dyn.count = region_count(region, b->H, b->V);
     const EulerParams<dual>* t = static_cast<const EulerParams<dual>*>(b->table);
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    WX_STREAM(st, stream);
     switch (b->n) {
         case 2: return launch_jvp_batch<2>(t, dyn, b->count, st);
         case 3: return launch_jvp_batch<3>(t, dyn, b->count, st);
@@ -2020,7 +2028,7 @@ wx_status wx_euler3d_batch_rhs_axpy2(const wx_euler3d_batch* b, const void* q, c
     if (out == q) return fail(WX_ERR_INVALID, "wx_euler3d_batch_rhs_axpy2: output must not alias the state");
     if (region != WX_REGION_ALL && region != WX_REGION_INTERIOR && region != WX_REGION_BOUNDARY)
         return fail(WX_ERR_INVALID, "unknown region %d", (int)region);
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    WX_STREAM(st, stream);
     switch (b->dtype) {
         case WX_F64: return batch_rhs<double>(b, q, v, eps, y, z, out, panel_stride, axpy, a, bq, c, d, region, st);
         case WX_C128: return batch_rhs<cplx>(b, q, nullptr, 0.0, y, z, out, panel_stride, axpy, a, bq, c, d, region, st);

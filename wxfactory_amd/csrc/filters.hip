@@ -190,7 +190,7 @@ static wx_status expfilter_apply_impl(const wx_expfilter* h, const void* q, void
     if (nvar < 1 || nvar > kFilterMaxVar) return fail(WX_ERR_INVALID, "nvar %d not in 1..%d", nvar, kFilterMaxVar);
     if (nelem == 0) return WX_OK;
     if (nelem > 0x7fffffffu) return fail(WX_ERR_INVALID, "too many elements for one launch");
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    WX_STREAM(st, stream);
     // the filter is linear with real coefficients: dual numbers filter component-wise, like complex ones
     if (dtype == WX_F64) return dispatch_filter<double>(h->n, q, out, sqrtG, h->filter, nvar, nelem, nan_flag, npanels, st);
     if (dtype == WX_C128 || dtype == WX_DUAL128)
@@ -206,7 +206,8 @@ wx_status wx_check_nan(const void* q, size_t count, wx_dtype dtype, int* flag, w
     const size_t doubles = count * (dtype == WX_F64 ? 1 : 2);
     size_t grid = (doubles + 256 * 8 - 1) / (256 * 8);
     if (grid > 256 * 16) grid = 256 * 16;
-    hipLaunchKernelGGL(nan_kernel, dim3((unsigned)grid), dim3(256), 0, static_cast<hipStream_t>(stream),
+    WX_STREAM(st, stream);
+    hipLaunchKernelGGL(nan_kernel, dim3((unsigned)grid), dim3(256), 0, st,
                        static_cast<const double*>(q), doubles, flag);
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
@@ -216,7 +217,7 @@ wx_status wx_cart2d_sponge(void* rho_w, const double* beta, double dt, size_t co
     if (count == 0) return WX_OK;
     if (!rho_w || !beta) return fail(WX_ERR_INVALID, "wx_cart2d_sponge: null argument");
     const unsigned grid = (unsigned)((count + 255) / 256);
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    WX_STREAM(st, stream);
     if (dtype == WX_F64) hipLaunchKernelGGL(sponge_kernel<double>, dim3(grid), dim3(256), 0, st, static_cast<double*>(rho_w), beta, dt, count);
     else if (dtype == WX_C128 || dtype == WX_DUAL128)
         hipLaunchKernelGGL(sponge_kernel<cplx>, dim3(grid), dim3(256), 0, st, static_cast<cplx*>(rho_w), beta, dt, count);

@@ -178,7 +178,7 @@ wx_status wx_multi_dot(const double* V, size_t ldv, int m, const double* w, size
     if (m <= 0) return WX_OK;
     if (!V || !w || !out || !workspace) return fail(WX_ERR_INVALID, "wx_multi_dot: null argument");
     if (ldv < n) return fail(WX_ERR_INVALID, "wx_multi_dot: row stride %zu shorter than the vectors (%zu)", ldv, n);
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    WX_STREAM(st, stream);
     int r = 0;
     for (; r + kRowsPerPass <= m; r += kRowsPerPass) launch_dot<kRowsPerPass>(V, ldv, r, w, n, workspace, m, st);
     switch (m - r) {
@@ -201,7 +201,7 @@ wx_status wx_multi_dot2(const double* V, size_t ldv, int m, const double* a, con
     if (m <= 0) return WX_OK;
     if (!V || !a || !b || !out || !workspace) return fail(WX_ERR_INVALID, "wx_multi_dot2: null argument");
     if (ldv < n) return fail(WX_ERR_INVALID, "wx_multi_dot2: row stride %zu shorter than the vectors (%zu)", ldv, n);
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    WX_STREAM(st, stream);
     int r = 0;
     for (; r + kRowsPerPass2 <= m; r += kRowsPerPass2) launch_dot2<kRowsPerPass2>(V, ldv, r, a, b, n, workspace, m, st);
     switch (m - r) {
@@ -220,7 +220,7 @@ wx_status wx_pair_update(double* a, double* b, const double* V, size_t ldv, int 
     if (n == 0) return WX_OK;
     if (!a || !b || (m > 0 && (!V || !ha || !hb))) return fail(WX_ERR_INVALID, "wx_pair_update: null argument");
     if (m > 0 && ldv < n) return fail(WX_ERR_INVALID, "wx_pair_update: row stride %zu shorter than the vectors (%zu)", ldv, n);
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    WX_STREAM(st, stream);
     int r = 0;
     for (; r + kRowsPerPass2 < m; r += kRowsPerPass2)   // (strictly less: the last batch carries the scalings)
         launch_pair<kRowsPerPass2>(a, b, V, ldv, r, ha, hb, n, 0, 1.0, 0.0, 1.0, st);
@@ -239,7 +239,7 @@ wx_status wx_multi_axpy(double* w, const double* V, size_t ldv, int m, const dou
     if (m <= 0 || n == 0) return WX_OK;
     if (!V || !w || !h) return fail(WX_ERR_INVALID, "wx_multi_axpy: null argument");
     if (ldv < n) return fail(WX_ERR_INVALID, "wx_multi_axpy: row stride %zu shorter than the vectors (%zu)", ldv, n);
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    WX_STREAM(st, stream);
     int r = 0;
     for (; r + kRowsPerPass <= m; r += kRowsPerPass) launch_axpy<kRowsPerPass>(w, V, ldv, r, h, n, st);
     switch (m - r) {

@@ -554,7 +554,7 @@ size_t wx_sw_edge_count(const wx_sw_plan* pl) { return pl ? (size_t)3 * pl->H * 
 
 wx_status wx_sw_extrap_pack(wx_sw_plan* pl, const void* q, void* const send[4], wx_stream stream) {
     if (!pl || !q) return fail(WX_ERR_INVALID, "wx_sw_extrap_pack: null argument");
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    WX_STREAM(st, stream);
     switch (pl->dtype) {
         case WX_F64: return sw_run<double>(pl, true, q, send, nullptr, nullptr, 0, 0, st);
         case WX_C128: return sw_run<cplx>(pl, true, q, send, nullptr, nullptr, 0, 0, st);
@@ -574,7 +574,7 @@ wx_status wx_sw_rhs(wx_sw_plan* pl, const void* q, const void* const halo[4], vo
             if (!halo[e]) return fail(WX_ERR_INVALID, "wx_sw_rhs: halo[%d] is null", e);
     }
     const int count = sw_region_count(region, pl->H);
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    WX_STREAM(st, stream);
     switch (pl->dtype) {
         case WX_F64: return sw_run<double>(pl, false, q, nullptr, halo, rhs, region, count, st);
         case WX_C128: return sw_run<cplx>(pl, false, q, nullptr, halo, rhs, region, count, st);
@@ -601,7 +601,7 @@ wx_status wx_sw_rhs_axpy(wx_sw_plan* pl, const void* q, const void* const halo[4
     wx_status ok = sw_check_rhs_args(pl, q, out, halo, region);
     if (ok != WX_OK) return ok;
     const int count = sw_region_count(region, pl->H);
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    WX_STREAM(st, stream);
     switch (pl->dtype) {
         case WX_F64: return sw_run<double>(pl, false, q, nullptr, halo, out, region, count, st, 1, y, a, b, c);
         case WX_C128: return sw_run<cplx>(pl, false, q, nullptr, halo, out, region, count, st, 1, y, a, b, c);
@@ -615,7 +615,7 @@ wx_status wx_sw_batch_rhs_axpy(wx_sw_batch* bt, const void* q, const void* y, vo
     if (out == q) return fail(WX_ERR_INVALID, "wx_sw_batch_rhs_axpy: output must not alias the state");
     if (region != WX_REGION_ALL && region != WX_REGION_INTERIOR && region != WX_REGION_BOUNDARY)
         return fail(WX_ERR_INVALID, "unknown region %d", (int)region);
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    WX_STREAM(st, stream);
     switch (bt->dtype) {
         case WX_F64: return sw_batch_run<double>(bt, false, q, out, panel_stride, region, st, 1, y, a, b, c);
         case WX_C128: return sw_batch_run<cplx>(bt, false, q, out, panel_stride, region, st, 1, y, a, b, c);
@@ -662,7 +662,7 @@ wx_status wx_sw_batch_destroy(wx_sw_batch* b) {
 
 wx_status wx_sw_batch_extrap_pack(wx_sw_batch* b, const void* q, size_t panel_stride, wx_stream stream) {
     if (!b || !q) return fail(WX_ERR_INVALID, "wx_sw_batch_extrap_pack: null argument");
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    WX_STREAM(st, stream);
     switch (b->dtype) {
         case WX_F64: return sw_batch_run<double>(b, true, q, nullptr, panel_stride, 0, st);
         case WX_C128: return sw_batch_run<cplx>(b, true, q, nullptr, panel_stride, 0, st);
@@ -675,7 +675,7 @@ wx_status wx_sw_batch_rhs(wx_sw_batch* b, const void* q, void* rhs, size_t panel
     if (!b || !q || !rhs) return fail(WX_ERR_INVALID, "wx_sw_batch_rhs: null argument");
     if (region != WX_REGION_ALL && region != WX_REGION_INTERIOR && region != WX_REGION_BOUNDARY)
         return fail(WX_ERR_INVALID, "unknown region %d", (int)region);
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    WX_STREAM(st, stream);
     switch (b->dtype) {
         case WX_F64: return sw_batch_run<double>(b, false, q, rhs, panel_stride, region, st);
         case WX_C128: return sw_batch_run<cplx>(b, false, q, rhs, panel_stride, region, st);

@@ -178,6 +178,9 @@ class StepLoop:
         Q = self.stepper.step(Q, dt)
         if self.filt is not None and not self.fused:
             Q = self.filt(Q, out=Q)  # the stepper returned fresh storage: filter it in place
+            inv = getattr(getattr(self.stepper, "rhs", None), "invalidate_faces", None)
+            if inv is not None:
+                inv()  # the stage pipeline's prepared faces belong to the unfiltered state
         self.step_id += 1
         if self.nan_flag is not None:
             scanned = self.fused or (self.filt is not None and self.filt.nan_flag is self.nan_flag)

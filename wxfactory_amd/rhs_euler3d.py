@@ -334,10 +334,14 @@ class RhsEuler3D(PanelRhs):
     def stage(self, Q: torch.Tensor, Y, a: float, b: float, c: float, filtered: bool = False, nan_flag=None) -> torch.Tensor:
         """One explicit Runge-Kutta stage  a*Y + b*Q + c*R(Q)  on stacked states with the stage pipeline:
         the kernel that produces the result also extrapolates it to the element faces, so the NEXT call
-        whose Q is that result (same storage, not modified in between) starts without the
-        extrapolation pass.  Two sets of interface / edge buffers alternate.  "Not modified" is judged by
-        torch's version counter: code that writes a state through a raw pointer must call
-        torch.autograd.graph.increment_version on it (filters.ExpFilter3D does)."""
+        whose Q is that result starts without the extrapolation pass.  Two sets of interface / edge buffers
+        alternate.  CONTRACT: the prepared faces are used only for the very tensor the previous stage returned
+        (same object, still alive, same storage) while nobody has called invalidate_faces() and no other call of
+        this object has rewritten an interface buffer.  Whoever modifies that tensor in between must call
+        invalidate_faces() - as StepLoop does after a filter that is not fused into the stage.  torch's version
+        counter is kept as a second line of defence for in-place torch operations, nothing more; a write through a
+        raw pointer is invisible to it.  check_faces = True (or WXHIP_PIPE_CHECK=1) turns every reuse into a
+        verification: the faces are extrapolated again and the edge messages compared with the prepared ones."""
         np_ = len(self.panels)
         dtype = Q.dtype
         fresh = dtype not in self._plans
@@ -362,7 +366,15 @@ class RhsEuler3D(PanelRhs):
         ex, exn = st["ex"][cur], st["ex"][1 - cur]
         last = st["ready"][0]() if st["ready"] is not None else None  # alive => its storage was not recycled
         epochs = lambda: tuple(plans[p].faces_epoch for p in self.panels)  # noqa: E731
-        if last is None or st["ready"][1:] != (Q.data_ptr(), Q._version, Q.numel(), epochs()):
+        reuse = last is Q and st["ready"][1:] == (Q.data_ptr(), Q._version, Q.numel(), epochs())
+        if reuse and (self.check_faces or os.environ.get("WXHIP_PIPE_CHECK") == "1"):
+            prepared = ex.send_buf.clone()
+            for i, p in enumerate(self.panels):
+                plans[p].extrap_pack_slot(Qs[i], ex.send_views(p), cur)
+            if not torch.equal(prepared, ex.send_buf):
+                raise RuntimeError("stage pipeline: the prepared faces do not belong to this state - it was modified "
+                                   "after the stage that produced it without a call of invalidate_faces()")
+        elif not reuse:
             for i, p in enumerate(self.panels):
                 plans[p].extrap_pack_slot(Qs[i], ex.send_views(p), cur)
 
@@ -375,6 +387,14 @@ class RhsEuler3D(PanelRhs):
         st["slot"] = 1 - cur
         st["ready"] = (weakref.ref(res), res.data_ptr(), res._version, res.numel(), epochs())
         return res
+
+    check_faces = False  # debug: verify prepared faces on every reuse (see stage)
+
+    def invalidate_faces(self):
+        """Forget the faces the last stage prepared: the next stage() extrapolates its state itself.  To be called
+        by any code that modifies a state returned by stage() before handing it back."""
+        for st in getattr(self, "_pipe", {}).values():
+            st["ready"] = None
 
     supports_shift = True
 
