@@ -216,6 +216,13 @@ wx_status wx_euler3d_batch_rhs_axpy2(const wx_euler3d_batch* batch, const void* 
                                      double d, wx_region region, wx_stream stream);
 wx_status wx_euler3d_batch_jvp(const wx_euler3d_batch* batch, const double* q, const double* v, double eps, double* out,
                                double scale, size_t panel_stride, wx_region region, wx_stream stream);
+/* One Krylov vector of KIOPS with the complex-step Jacobian from one host call (solvers/kiops.py:170-207 with
+ * solvers/matvec.py:56-61): aw = scale Im R(q + i eps V[j-1][:n]) through the two batched JVP launches, then
+ * wx_kiops_finish on row j (see there for V, uflip, hcol, workspace).  WX_DUAL128 batch of a rank that owns the whole
+ * sphere (no exchange between the launches); n = tiles x panel_stride; aw: n doubles of scratch on the device. */
+wx_status wx_euler3d_batch_kiops_vector(const wx_euler3d_batch* b, const double* q, double* V, size_t ldv, int j, size_t n,
+                                        int p, int iop, double eps, double scale, const double* uflip, double* hcol,
+                                        double* aw, double* workspace, size_t panel_stride, wx_stream stream);
 
 /* Complex-step Jacobian-vector product (solvers/matvec.py:56-61) with no complex array in HBM.
  * The plan must be WX_DUAL128.  q and v are REAL (n-double) arrays in the state layout; the kernels form
@@ -370,6 +377,15 @@ wx_status wx_multi_axpy(double* w, const double* V, size_t ldv, int m, const dou
  *                   (workspace: wx_multi_dot_workspace(2 m) doubles)
  *   wx_pair_update  a -= sum_k ha[k] V[k];  b -= sum_k hb[k] V[k];  a *= scale_a;  b = (b - cross a) * scale_b
  *                   in one pass (m may be 0; ha, hb: m doubles on the device) */
+/* One Krylov vector of KIOPS (solvers/kiops.py:170-207) finished in three short launches instead of the seven or more
+ * of the array-expression form, for SHORT vectors (launch-bound sizes such as the shipped .ini files): row j of the
+ * basis V (rows of n + p doubles, stride ldv), aw = the matvec's output A V[j-1][:n]:
+ *   V[j][:n] = aw + uflip (n x p row-major) @ V[j-1][n:];  V[j][n:] = V[j-1][n+1:], 0;
+ *   hcol[r] = <V[r], V[j]>, max(0, j - iop) <= r < j;  V[j] -= sum_r hcol[r] V[r];  hcol[j] = |V[j]|;  V[j] /= hcol[j]
+ * p <= 16, iop <= 4; workspace: wx_kiops_finish_workspace(n + p) doubles on the device.  Deterministic reductions. */
+size_t wx_kiops_finish_workspace(size_t len);
+wx_status wx_kiops_finish(double* V, size_t ldv, int j, size_t n, int p, int iop, const double* aw, const double* uflip,
+                          double* hcol, double* workspace, wx_stream stream);
 wx_status wx_multi_dot2(const double* V, size_t ldv, int m, const double* a, const double* b, size_t n, double* out,
                         double* workspace, wx_stream stream);
 wx_status wx_pair_update(double* a, double* b, const double* V, size_t ldv, int m, const double* ha, const double* hb,

@@ -76,6 +76,9 @@ SIGNATURES = {
     "wx_multi_dot_workspace": (c_size_t, [c_int]),
     "wx_multi_dot": (c_int, [c_void_p, c_size_t, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "wx_multi_axpy": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_size_t, c_void_p]),
+    "wx_kiops_finish_workspace": (c_size_t, [c_size_t]),
+    "wx_kiops_finish": (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_void_p]),
     "wx_multi_dot2": (c_int, [c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "wx_pair_update": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_size_t, c_double,
                                c_double, c_double, c_void_p]),
@@ -92,6 +95,8 @@ SIGNATURES = {
     "wx_euler3d_batch_rhs_axpy2": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_size_t,
                                            c_int, c_double, c_double, c_double, c_double, c_int, c_void_p]),
     "wx_euler3d_batch_jvp": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_double, c_size_t, c_int, c_void_p]),
+    "wx_euler3d_batch_kiops_vector": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_size_t, c_int, c_int, c_double,
+                                              c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wx_euler3d_jvp_extrap_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_double, POINTER(c_void_p), c_void_p]),
     "wx_euler3d_jvp": (c_int, [c_void_p, c_void_p, c_void_p, c_double, POINTER(c_void_p), c_void_p, c_double, c_int,
                                c_void_p]),

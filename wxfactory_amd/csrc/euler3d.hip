@@ -2020,6 +2020,26 @@ wx_status wx_euler3d_batch_jvp(const wx_euler3d_batch* b, const double* q, const
     return fail(WX_ERR_UNSUPPORTED, "num_solpts %d not in 2..8", b->n);
 }
 
+// One Krylov vector of KIOPS with the complex-step Jacobian (solvers/kiops.py:170-207 + solvers/matvec.py:56-61) from
+// ONE host call: the two launches of the dual-number JVP of all tiles (aw = scale Im R(q + i eps v), v = V[j-1][:n]) and
+// the three of wx_kiops_finish.  For a rank that owns the whole sphere (halos alias the packed edges: no exchange
+// between the two JVP launches) at launch-bound sizes - the shipped .ini files - where the host side of five separate
+// calls costs more than the kernels.
+wx_status wx_euler3d_batch_kiops_vector(const wx_euler3d_batch* b, const double* q, double* V, size_t ldv, int j, size_t n,
+                                        int p, int iop, double eps, double scale, const double* uflip, double* hcol,
+                                        double* aw, double* workspace, size_t panel_stride, wx_stream stream) {
+    if (!b || !q || !V || !aw) return fail(WX_ERR_INVALID, "wx_euler3d_batch_kiops_vector: null argument");
+    if (b->dtype != WX_DUAL128) return fail(WX_ERR_INVALID, "wx_euler3d_batch_kiops_vector: the batch must be WX_DUAL128");
+    if (j < 1 || n != (size_t)b->count * panel_stride)
+        return fail(WX_ERR_INVALID, "wx_euler3d_batch_kiops_vector: vector length %zu != %d tiles x %zu", n, b->count, panel_stride);
+    const double* v = V + (size_t)(j - 1) * ldv;
+    wx_status s = wx_euler3d_batch_extrap_pack(b, q, v, eps, panel_stride, stream);
+    if (s != WX_OK) return s;
+    s = wx_euler3d_batch_jvp(b, q, v, eps, aw, scale, panel_stride, WX_REGION_ALL, stream);
+    if (s != WX_OK) return s;
+    return wx_kiops_finish(V, ldv, j, n, p, iop, aw, uflip, hcol, workspace, stream);
+}
+
 wx_status wx_euler3d_batch_rhs_axpy2(const wx_euler3d_batch* b, const void* q, const double* v, double eps, const void* y,
                                      const void* z, void* out, size_t panel_stride, int axpy, double a, double bq, double c,
                                      double d, wx_region region, wx_stream stream) {

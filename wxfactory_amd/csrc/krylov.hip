@@ -140,6 +140,103 @@ __global__ __launch_bounds__(256) void pair_update_kernel(double* __restrict__ a
     }
 }
 
+// One Krylov vector of KIOPS finished in three short launches, for vectors so short that the generic path (solvers/
+// kiops.py:170-207 as array expressions: a rocBLAS gemv for the augmented update alone takes 70 us at n = 17 k, the
+// 2048-partial reductions of wx_multi_dot another 9 us each) costs far more than the arithmetic.  Row j of V
+// (n + p doubles per row, row stride ldv), G = ceil((n + p) / 1024) workgroups, partial sums in a caller workspace:
+//   a) V[j][:n] = aw + uflip (n x p, row-major) @ V[j-1][n:];  V[j][n:] = V[j-1][n+1:], 0;
+//      partial <V[r], V[j]>, max(0, j - iop) <= r < j
+//   b) h[r] = sum of the partials (every workgroup, same order);  V[j] -= sum_r h[r] V[r];  partial |V[j]|^2
+//   c) hcol[r] = h[r];  hcol[j] = |V[j]|;  V[j] /= hcol[j]           (hcol = column j-1 of the Hessenberg matrix)
+constexpr int kFinishThreads = 256;
+constexpr int kFinishChunk = 1024;   // elements per workgroup
+constexpr int kFinishMaxIop = 4;
+constexpr int kFinishMaxP = 16;
+
+__device__ __forceinline__ double wg_sum256(double v, double* red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();   // red is free again
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(kFinishThreads) void kiops_finish_a(double* __restrict__ V, size_t ldv, int j, size_t n, int p,
+                                                                 int iop, const double* __restrict__ aw,
+                                                                 const double* __restrict__ uflip, double* __restrict__ part) {
+    __shared__ double red[4];
+    __shared__ double aug[kFinishMaxP];
+    double* vj = V + (size_t)j * ldv;
+    const double* vp = V + (size_t)(j - 1) * ldv;
+    if (threadIdx.x < p) aug[threadIdx.x] = vp[n + threadIdx.x];
+    __syncthreads();
+    const int ilow = j - iop > 0 ? j - iop : 0, nr = j - ilow;
+    const size_t len = n + (size_t)p, lo = (size_t)blockIdx.x * kFinishChunk;
+    double acc[kFinishMaxIop] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int it = 0; it < kFinishChunk / kFinishThreads; ++it) {
+        const size_t i = lo + it * kFinishThreads + threadIdx.x;
+        if (i < len) {
+            double w;
+            if (i < n) {
+                w = aw[i];
+                for (int k = 0; k < p; ++k) w += uflip[i * p + k] * aug[k];
+            } else {
+                const int k = (int)(i - n);
+                w = k + 1 < p ? aug[k + 1] : 0.0;
+            }
+            vj[i] = w;
+            for (int r = 0; r < nr; ++r) acc[r] += V[(size_t)(ilow + r) * ldv + i] * w;
+        }
+    }
+    for (int r = 0; r < nr; ++r) {
+        const double t = wg_sum256(acc[r], red);
+        if (threadIdx.x == 0) part[(size_t)blockIdx.x * (kFinishMaxIop + 1) + r] = t;
+    }
+}
+
+__global__ __launch_bounds__(kFinishThreads) void kiops_finish_b(double* __restrict__ V, size_t ldv, int j, size_t n, int p,
+                                                                 int iop, double* __restrict__ part, double* __restrict__ hcol) {
+    __shared__ double red[4];
+    double* vj = V + (size_t)j * ldv;
+    const int ilow = j - iop > 0 ? j - iop : 0, nr = j - ilow;
+    double h[kFinishMaxIop] = {0.0, 0.0, 0.0, 0.0};
+    // every workgroup sums all partials itself, one per thread (gridDim.x <= 256), in the same tree: same h everywhere
+    for (int r = 0; r < nr; ++r)
+        h[r] = wg_sum256(threadIdx.x < gridDim.x ? part[(size_t)threadIdx.x * (kFinishMaxIop + 1) + r] : 0.0, red);
+    const size_t len = n + (size_t)p, lo = (size_t)blockIdx.x * kFinishChunk;
+    double nn = 0.0;
+#pragma unroll
+    for (int it = 0; it < kFinishChunk / kFinishThreads; ++it) {
+        const size_t i = lo + it * kFinishThreads + threadIdx.x;
+        if (i < len) {
+            double w = vj[i];
+            for (int r = 0; r < nr; ++r) w -= h[r] * V[(size_t)(ilow + r) * ldv + i];
+            vj[i] = w;
+            nn += w * w;
+        }
+    }
+    const double t = wg_sum256(nn, red);
+    if (threadIdx.x == 0) part[(size_t)blockIdx.x * (kFinishMaxIop + 1) + kFinishMaxIop] = t;
+    if (blockIdx.x == 0 && (int)threadIdx.x < nr) hcol[ilow + threadIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(kFinishThreads) void kiops_finish_c(double* __restrict__ V, size_t ldv, int j, size_t n, int p,
+                                                                 const double* __restrict__ part, double* __restrict__ hcol) {
+    __shared__ double red[4];
+    double* vj = V + (size_t)j * ldv;
+    const double nrm =
+        sqrt(wg_sum256(threadIdx.x < gridDim.x ? part[(size_t)threadIdx.x * (kFinishMaxIop + 1) + kFinishMaxIop] : 0.0, red));
+    const size_t len = n + (size_t)p, lo = (size_t)blockIdx.x * kFinishChunk;
+#pragma unroll
+    for (int it = 0; it < kFinishChunk / kFinishThreads; ++it) {
+        const size_t i = lo + it * kFinishThreads + threadIdx.x;
+        if (i < len) vj[i] /= nrm;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) hcol[j] = nrm;
+}
+
 template <int R>
 static void launch_dot2(const double* V, size_t ldv, int row0, const double* a, const double* b, size_t n, double* partial,
                         int m, hipStream_t st) {
@@ -192,6 +289,23 @@ wx_status wx_multi_dot(const double* V, size_t ldv, int m, const double* w, size
         default: break;
     }
     hipLaunchKernelGGL(multi_dot_finish_kernel, dim3(m), dim3(64), 0, st, workspace, kDotBlocks, m, out);
+    WX_HIP_TRY(hipGetLastError());
+    return WX_OK;
+}
+
+size_t wx_kiops_finish_workspace(size_t len) { return ((len + kFinishChunk - 1) / kFinishChunk) * (kFinishMaxIop + 1); }
+
+wx_status wx_kiops_finish(double* V, size_t ldv, int j, size_t n, int p, int iop, const double* aw, const double* uflip,
+                          double* hcol, double* workspace, wx_stream stream) {
+    if (!V || !aw || !uflip || !hcol || !workspace) return fail(WX_ERR_INVALID, "wx_kiops_finish: null argument");
+    if (j < 1 || p < 1 || p > kFinishMaxP || iop < 1 || iop > kFinishMaxIop || ldv < n + (size_t)p ||
+        n + (size_t)p > (size_t)kFinishChunk * kFinishThreads)
+        return fail(WX_ERR_INVALID, "wx_kiops_finish: bad shape (j=%d p=%d iop=%d ldv=%zu n=%zu)", j, p, iop, ldv, n);
+    WX_STREAM(st, stream);
+    const unsigned G = (unsigned)((n + p + kFinishChunk - 1) / kFinishChunk);
+    hipLaunchKernelGGL(kiops_finish_a, dim3(G), dim3(kFinishThreads), 0, st, V, ldv, j, n, p, iop, aw, uflip, workspace);
+    hipLaunchKernelGGL(kiops_finish_b, dim3(G), dim3(kFinishThreads), 0, st, V, ldv, j, n, p, iop, workspace, hcol);
+    hipLaunchKernelGGL(kiops_finish_c, dim3(G), dim3(kFinishThreads), 0, st, V, ldv, j, n, p, workspace, hcol);
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
 }

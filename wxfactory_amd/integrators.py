@@ -9,7 +9,7 @@ from typing import Callable
 
 import torch
 
-from .matvec import MatvecOpRat
+from .matvec import ComplexStepOperator, MatvecOpRat
 from .solvers import fgmres
 
 
@@ -99,6 +99,13 @@ class Epi:
         if order not in self._A:
             raise ValueError(f"Unsupported order {order} for EPI method")
         self.rhs, self.tol, self.jacobian_method = rhs, tol, jacobian_method
+        # Replay whole KIOPS passes as HIP graphs (one GPU, launch-bound sizes).  Off by default: measured at the size of
+        # config/dcmip31.ini the adaptive basis size m changes almost every step, so passes are re-captured (8 ms each)
+        # more often than replayed, and with a Krylov vector built from ONE host call (wx_euler3d_batch_kiops_vector) the
+        # eager pass is GPU-bound already (tools/kiopsgraph.py).
+        self.graph_passes = False
+        self._static = None
+        self._ws = None
         self.A = self._A[order]
         k = len(self.A)
         self.n_prev = len(self.A[0])
@@ -136,8 +143,26 @@ class Epi:
             r = (self.previous_rhs[i] - rhs).flatten() - JdQ
             for k, row in enumerate(self.A, start=2):
                 vec[k] += row[i] * r
-        phiv, stats = kiops([1], lambda v: matvec_fun(v, dt, Q, rhs, self.rhs, self.jacobian_method), vec,
-                            tol=self.tol, m_init=self.krylov_size, mmin=16, mmax=64, task1=False)
+        ws, token, Qm, Rm = None, None, Q, rhs
+        if Q.is_cuda and Q.dtype == torch.float64:
+            from .solvers import KiopsWorkspace
+
+            if self._ws is None:
+                self._ws = KiopsWorkspace()   # basis, Hessenberg columns and scratch survive from step to step
+            ws = self._ws
+            if self.graph_passes and bool(getattr(self.rhs, "_small_tiles", lambda: False)()) \
+                    and getattr(self.rhs, "world", 1) == 1:
+                # replay whole Krylov passes as HIP graphs: the matvec then has to read the linearisation state from
+                # fixed addresses (static copies of Q and R(Q)); a pass is re-captured whenever (j0, m) is new
+                if self._static is None or self._static[0].shape != Q.shape:
+                    self._static = (torch.empty_like(Q), torch.empty_like(rhs))
+                Qm, Rm = self._static
+                Qm.copy_(Q)
+                Rm.copy_(rhs)
+                token = (Qm.data_ptr(), Rm.data_ptr(), float(dt), self.jacobian_method)
+        phiv, stats = kiops([1], ComplexStepOperator(dt, Qm, Rm, self.rhs, self.jacobian_method), vec,
+                            tol=self.tol, m_init=self.krylov_size, mmin=16, mmax=64, task1=False, workspace=ws,
+                            graph_token=token)
         self.krylov_size = math.floor(0.7 * stats[5] + 0.3 * self.krylov_size)
         self.solver_info = dict(substeps=stats[0], rejected=stats[1], iterations=stats[2], exps=stats[3],
                                 error=stats[4], krylov_size=stats[5])

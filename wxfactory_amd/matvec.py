@@ -71,6 +71,22 @@ class MatvecOp:
         return self.matvec(vec)
 
 
+class ComplexStepOperator:
+    """v -> matvec_fun(v, dt, Q, rhs, rhs_handle, "complex") as an object, so that a solver can ask it for more than a
+    product: `kiops_vector` (when the RHS offers it) builds a whole Krylov vector of KIOPS - JVP, augmented update,
+    orthogonalisation, normalisation - from one host call at launch-bound sizes."""
+
+    def __init__(self, dt: float, Q: torch.Tensor, rhs: torch.Tensor, rhs_handle: Callable, method: str = "complex"):
+        self.dt, self.Q, self.rhs, self.rhs_handle, self.method = dt, Q, rhs, rhs_handle, method
+        self.kiops_vector = None
+        fn = getattr(rhs_handle, "kiops_vector_fn", None)
+        if method == "complex" and fn is not None and getattr(rhs_handle, "fused_jvp", True) and Q.is_cuda:
+            self.kiops_vector = fn(Q, EPS_COMPLEX, dt / EPS_COMPLEX)
+
+    def __call__(self, vec: torch.Tensor) -> torch.Tensor:
+        return matvec_fun(vec, self.dt, self.Q, self.rhs, self.rhs_handle, self.method)
+
+
 class MatvecOpRat(MatvecOp):
     """solvers/matvec.py:71-73"""
 

@@ -258,6 +258,14 @@ class Euler3DBatch:
         check(self.lib.wx_euler3d_batch_jvp(self._h, q.data_ptr(), v.data_ptr(), eps, out.data_ptr(), scale, self.stride,
                                             region, st), "wx_euler3d_batch_jvp")
 
+    def kiops_vector(self, q, V, j: int, n: int, p: int, iop: int, eps: float, scale: float, uflip, hcol, aw, work):
+        """dual batches on a rank that owns the whole sphere: Krylov vector j of KIOPS from one host call
+        (wx_euler3d_batch_kiops_vector)."""
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.wx_euler3d_batch_kiops_vector(self._h, q.data_ptr(), V.data_ptr(), V.stride(0), j, n, p, iop, eps, scale,
+                                                     uflip.data_ptr(), hcol.data_ptr(), aw.data_ptr(), work.data_ptr(),
+                                                     self.stride, st), "wx_euler3d_batch_kiops_vector")
+
     def close(self):
         if self._h:
             self.lib.wx_euler3d_batch_destroy(self._h)
@@ -424,6 +432,27 @@ class RhsEuler3D(PanelRhs):
 
         self._exchange_and_launch(ex, launch)
         return out.reshape(Q.shape)
+
+    def kiops_vector_fn(self, Q: torch.Tensor, eps: float, scale: float):
+        """A callable (V, j, n, p, iop, uflip, hcol, aw, work) that builds Krylov vector j of KIOPS for the complex-step
+        Jacobian at Q with one host call, or None when that shortcut does not apply (several ranks, large tiles)."""
+        if not (self._small_tiles() and self.world == 1 and Q.is_contiguous() and Q.dtype == torch.float64
+                and os.environ.get("WXHIP_JVP_LEAN") != "0" and os.environ.get("WXHIP_KIOPS_VECTOR", "1") != "0"):
+            return None
+        if "jvp" not in self._plans:
+            self._plans["jvp"] = {p: pl.twin(torch.complex128, dual=True) for p, pl in self.plans.items()}
+        plans = self._plans["jvp"]
+        ex = self.exchange_for(torch.complex128)
+        if ex.needs_comm:
+            return None
+        bt = self._batch_for("jvp", plans, ex)
+        for pl in plans.values():
+            pl.faces_epoch += 1
+
+        def build(V, j, n, p, iop, uflip, hcol, aw, work):
+            bt.kiops_vector(Q, V, j, n, p, iop, eps, scale, uflip, hcol, aw, work)
+
+        return build
 
     def jvp(self, Q: torch.Tensor, v: torch.Tensor, eps: float, scale: float) -> torch.Tensor:
         """scale * Im R(Q + i eps v) for stacked real Q, v -> real tensor shaped like Q.  The dual state is

@@ -13,6 +13,7 @@ Every decision that changes the control flow is taken from all-reduced numbers, 
 slice (ranks 6, 7 of an 8-GPU node with whole panels): all ranks make the same collective calls.
 """
 import math
+import os
 from time import time
 from typing import Callable, List, Optional, Tuple
 
@@ -421,8 +422,82 @@ def _ceil_clamped(x: float, lo: float, hi: float) -> int:
     return int(min(hi, max(lo, math.ceil(x))))
 
 
+class KiopsWorkspace:
+    """Buffers of kiops that survive from one call to the next (basis, Hessenberg columns, the augmented-part operators)
+    and the HIP graphs of its Krylov passes.  A pass - the vectors j0+1 .. m built back to back with no host
+    synchronisation: matvec, augmented update, wx_multi_dot, wx_multi_axpy, norm, scaling per vector - is the same
+    sequence of launches on the same addresses every time (j0, m) recurs, PROVIDED the operator reads its state from
+    the same buffers: then it is captured once (on its second occurrence) and replayed with one host call.  The
+    caller vouches for the operator with `graph_token` (anything hashable that changes when the operator's buffers
+    or constants change: Epi passes the addresses of its static copies of Q and R(Q), dt and the JVP method)."""
+
+    max_graph_points = 4_000_000   # longer vectors are not launch-bound: no graphs
+    max_fused_len = 262_144        # vectors up to this length are finished by the one-workgroup kernel wx_kiops_finish
+
+    def __init__(self):
+        self.key = None
+        self.token = None
+        self.graphs = {}
+        self.seen = {}
+        self.replays = self.captures = 0
+
+    def ensure(self, n, p, mmax, dev, dtype):
+        key = (n, p, mmax, str(dev), dtype)
+        if key != self.key:
+            self.key = key
+            self.Vd = torch.empty((mmax + 1, n + p), dtype=dtype, device=dev)  # (every row is written before it is read)
+            self.basis = _Basis(self.Vd)
+            self.Ht = torch.empty((mmax + 1, mmax + 1), dtype=dtype, device=dev)  # Ht[c, r] = H[r, c], written entries only
+            self.nrm2 = torch.empty(1, dtype=dtype, device=dev)
+            self.u_flip_t = torch.empty((n, p), dtype=dtype, device=dev)
+            self.shift = torch.diag(torch.ones(p - 1, dtype=dtype, device=dev), 1)
+            self.finish_work = None
+            self.aw = torch.empty(n, dtype=dtype, device=dev)   # the matvec's output in the one-call vector build
+            if self.basis.gpu:
+                self.finish_work = torch.empty(int(self.basis.lib.wx_kiops_finish_workspace(n + p)), dtype=dtype, device=dev)
+            self.graphs.clear()
+            self.seen.clear()
+        return self
+
+    def set_token(self, token):
+        if token != self.token:
+            self.token = token
+            self.graphs.clear()
+            self.seen.clear()
+
+    def run_pass(self, j0: int, m: int, build, use_graphs: bool):
+        """build(j) enqueues the construction of vector j."""
+        if not use_graphs:
+            for j in range(j0 + 1, m + 1):
+                build(j)
+            return
+        key = (j0, m)
+        g = self.graphs.get(key)
+        if g is not None:
+            g.replay()
+            self.replays += 1
+            return
+        self.seen[key] = self.seen.get(key, 0) + 1
+        if self.seen[key] < 2:   # first occurrence: eager (it also builds every lazy resource of the operator)
+            for j in range(j0 + 1, m + 1):
+                build(j)
+            return
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                for j in range(j0 + 1, m + 1):
+                    build(j)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graphs[key] = g
+        self.captures += 1
+        g.replay()   # (capture records, it does not execute)
+        self.replays += 1
+
+
 def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int = 10, mmin: int = 10, mmax: int = 128,
-          iop: int = 2, task1: bool = False, group=None):
+          iop: int = 2, task1: bool = False, group=None, workspace: Optional[KiopsWorkspace] = None, graph_token=None):
     """w(i) = sum_k phi_k(tau_i A) u[k]  by the adaptive Krylov method with incomplete orthogonalisation.
 
     Same signature, adaptivity rules and `stats` tuple as reference wx_factory/solvers/kiops.py:10-347
@@ -446,12 +521,18 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
         p = 1
         u = torch.cat((u, torch.zeros((1, n), dtype=dtype, device=dev)))
     m = max(mmin, min(m_init, mmax))
-    Vd = torch.empty((mmax + 1, n + p), dtype=dtype, device=dev)  # (every row is written before it is read)
-    basis = _Basis(Vd)
-    Ht = torch.empty((mmax + 1, mmax + 1), dtype=dtype, device=dev)  # Ht[c, r] = H[r, c], written entries only
-    nrm2 = torch.empty(1, dtype=dtype, device=dev)
+    ws = (workspace if workspace is not None else KiopsWorkspace()).ensure(n, p, mmax, dev, dtype)
+    Vd, basis, Ht, nrm2 = ws.Vd, ws.basis, ws.Ht, ws.nrm2
     H = np.zeros((mmax + 1, mmax + 1))
     split = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    # HIP graphs of whole passes: single rank (no collective inside), launch-bound sizes, an operator the caller vouches for
+    use_graphs = (workspace is not None and graph_token is not None and not split and Vd.is_cuda
+                  and n <= KiopsWorkspace.max_graph_points)
+    if workspace is not None:
+        ws.set_token(graph_token)
+    fused_finish = (basis.gpu and not split and n + p <= KiopsWorkspace.max_fused_len and p <= 16 and iop <= 4
+                    and os.environ.get("WXHIP_KIOPS_FUSED", "1") != "0")
+    fused_vector = getattr(A, "kiops_vector", None) if fused_finish else None
 
     def products(lo: int, hi: int, j: int, out: torch.Tensor):
         """out[k - lo] = <V[k], V[j]> over the n + p components, lo <= k < hi"""
@@ -475,8 +556,8 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
         nu, mu = 2.0 ** (-ex), 2.0 ** ex
     else:
         nu = mu = 1.0
-    u_flip_t = (nu * torch.flipud(u[1:])).t()
-    shift = torch.diag(torch.ones(p - 1, dtype=dtype, device=dev), 1)
+    u_flip_t, shift = ws.u_flip_t, ws.shift
+    u_flip_t.copy_((nu * torch.flipud(u[1:])).t())
     tau = tau_end
     gamma, gamma_mmax = (0.2, 0.1) if tau_end > 1 else (0.9, 0.6)
     delta = 1.4
@@ -497,8 +578,17 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
             beta = math.sqrt(float(global_dotprod(Vd[0, :n], Vd[0, :n], group)) + float(va0 @ va0))
             Vd[0] /= beta
         j0 = j
-        while j < m:
-            j += 1
+
+        def build(j):
+            if fused_vector is not None:   # ... and the matvec too, all from one host call
+                fused_vector(Vd, j, n, p, iop, u_flip_t, Ht[j - 1], ws.aw, ws.finish_work)
+                return
+            if fused_finish:   # short vectors: everything after the matvec in three short launches (wx_kiops_finish)
+                aw = A(Vd[j - 1, :n])
+                basis.check(basis.lib.wx_kiops_finish(Vd.data_ptr(), Vd.stride(0), j, n, p, iop, aw.data_ptr(),
+                                                      u_flip_t.data_ptr(), Ht[j - 1].data_ptr(), ws.finish_work.data_ptr(),
+                                                      torch.cuda.current_stream(dev).cuda_stream), "wx_kiops_finish")
+                return
             torch.addmv(A(Vd[j - 1, :n]), u_flip_t, Vd[j - 1, n:], out=Vd[j, :n])
             torch.mv(shift, Vd[j - 1, n:], out=Vd[j, n:])  # augmented components: up by one, zero at the end
             ilow = max(0, j - iop)
@@ -506,8 +596,12 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
             products(ilow, j, j, hcol[ilow:j])
             basis.subtract(Vd[j], ilow, j, hcol[ilow:j])
             products(j, j + 1, j, nrm2)
-            torch.sqrt(nrm2, out=hcol[j : j + 1])
+            torch.sqrt(nrm2, out=hcol[j: j + 1])
             Vd[j] /= hcol[j]
+
+        if m > j:
+            ws.run_pass(j, m, build, use_graphs)
+            j = m
         if j > j0:
             Hh = Ht[j0:j, : j + 1].cpu().numpy()  # the one synchronisation of the pass
             for c in range(j0, j):
