@@ -233,6 +233,23 @@ wx_status wx_euler3d_jvp_extrap_pack(wx_euler3d_plan* plan, const double* q, con
                                      void* const send[4], wx_stream stream);
 wx_status wx_euler3d_jvp(wx_euler3d_plan* plan, const double* q, const double* v, double eps, const void* const halo[4],
                          double* out, double scale, wx_region region, wx_stream stream);
+/* Prepared complex-step JVP: one linearisation state q, many products (every matvec of an FGMRES / KIOPS solve,
+ * solvers/matvec.py:56-61 called from solvers/fgmres.py:150-200 and solvers/kiops.py:170-207).  WX_DUAL128 plans.
+ *   wx_euler3d_jvp_prepare              face VALUES of q into the plan's cache (exactly the float64 extrapolation) and the
+ *                                       value edge messages into send_val (REAL, wx_euler3d_edge_count doubles each): the
+ *                                       caller exchanges them once and keeps the received value halos
+ *   wx_euler3d_jvp_tangent_extrap_pack  per product: only the face TANGENTS of (q, eps v) and the tangent edge messages
+ *                                       (REAL); reads v and the two log-extrapolated rows of q
+ *   wx_euler3d_jvp_prepared             out = scale * Im R(q + i eps v) from cached values + this product's tangents;
+ *                                       halo_val / halo_tan: the four received REAL edge messages of each kind
+ * Same results as wx_euler3d_jvp_extrap_pack + wx_euler3d_jvp, bit for bit, with 60 B/point less HBM traffic per
+ * product and half the exchange volume. */
+wx_status wx_euler3d_jvp_prepare(wx_euler3d_plan* pl, const double* q, void* const send_val[4], wx_stream stream);
+wx_status wx_euler3d_jvp_tangent_extrap_pack(wx_euler3d_plan* pl, const double* q, const double* v, double eps,
+                                             void* const send_tan[4], wx_stream stream);
+wx_status wx_euler3d_jvp_prepared(wx_euler3d_plan* pl, const double* q, const double* v, double eps,
+                                  const void* const halo_val[4], const void* const halo_tan[4], double* out, double scale,
+                                  wx_region region, wx_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Shallow water on a cubed-sphere tile.

@@ -270,6 +270,43 @@ def test_krylov_vector_kernels(built_lib, m, n):
     assert not _Basis(V).gpu
 
 
+def test_prepared_jvp_equals_unprepared(setup):
+    """wx_euler3d_jvp_prepare: the face values of the linearisation state cached once, only tangents extrapolated and
+    exchanged per product - the same Jacobian-vector product as the unprepared path (bit for bit), against the
+    reference's complex-step value; a modified or different Q falls back to the unprepared path."""
+    from wxfactory_amd.matvec import ComplexStepOperator, matvec_fun
+
+    g, rhs, stack = setup
+    Q, V, R = stack("Q"), stack("V"), stack("R")
+    dt = float(g["meta/dt_jvp"])
+    rhs.batched = False   # (tiles this small would take the batched launches; the prepared path is the large-tile one)
+    try:
+        rhs.jvp_release()
+        plain = matvec_fun(V.flatten(), dt, Q, R, rhs, "complex")
+        op = ComplexStepOperator(dt, Q, R, rhs)
+        assert rhs._jvp_is_prepared(Q)
+        for scale in (1.0, -0.37):
+            a = op((scale * V).flatten())
+            rhs.jvp_release()
+            b = matvec_fun((scale * V).flatten(), dt, Q, R, rhs, "complex")
+            rhs.jvp_prepare(Q)
+            assert torch.equal(a, b)
+        assert (_rel(op(V.flatten()), stack("jvp_complex").cpu().numpy()) < 1e-9).all()
+        # another state, or the same one modified in place: not the prepared one
+        Q2 = Q * (1.0 + 1e-3)
+        assert not rhs._jvp_is_prepared(Q2)
+        c = matvec_fun(V.flatten(), dt, Q2, R, rhs, "complex")
+        rhs.jvp_release()
+        assert torch.equal(c, matvec_fun(V.flatten(), dt, Q2, R, rhs, "complex"))
+        rhs.jvp_prepare(Q)
+        Q.mul_(1.0)   # version bump
+        assert not rhs._jvp_is_prepared(Q)
+        assert torch.equal(matvec_fun(V.flatten(), dt, Q, R, rhs, "complex"), plain)
+    finally:
+        rhs.jvp_release()
+        rhs.batched = True
+
+
 def test_kiops_vector_kernels_and_graph_replayed_passes(setup):
     """Launch-bound sizes (the shipped .ini files): a Krylov vector of KIOPS is built by wx_kiops_finish (three short
     launches instead of the array-expression recurrence) or, with the complex-step operator, from ONE host call

@@ -38,6 +38,10 @@ def timeit(label, fn, reps=5):
 rhs = RhsEuler3D(plans)
 R = timeit("R(Q)  real RHS", lambda: rhs(Q))
 ref = timeit("matvec_fun complex: fused dual JVP (wx_euler3d_jvp)", lambda: matvec_fun(v.flatten(), dt, Q, R, rhs, "complex"))
+rhs.jvp_prepare(Q)
+pre = timeit("matvec_fun complex: PREPARED (face values cached, tangents only)", lambda: matvec_fun(v.flatten(), dt, Q, R, rhs, "complex"))
+rhs.jvp_release()
+print("prepared == unprepared bit for bit:", bool(torch.equal(pre, ref)))
 rhs.fused_jvp = False
 rhs_d = RhsEuler3D(plans, complex_arith="dual")
 rhs_d.fused_jvp = False

@@ -97,6 +97,10 @@ SIGNATURES = {
     "wx_euler3d_batch_jvp": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_double, c_size_t, c_int, c_void_p]),
     "wx_euler3d_batch_kiops_vector": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_size_t, c_int, c_int, c_double,
                                               c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wx_euler3d_jvp_prepare": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p]),
+    "wx_euler3d_jvp_tangent_extrap_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_double, POINTER(c_void_p), c_void_p]),
+    "wx_euler3d_jvp_prepared": (c_int, [c_void_p, c_void_p, c_void_p, c_double, POINTER(c_void_p), POINTER(c_void_p), c_void_p,
+                                        c_double, c_int, c_void_p]),
     "wx_euler3d_jvp_extrap_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_double, POINTER(c_void_p), c_void_p]),
     "wx_euler3d_jvp": (c_int, [c_void_p, c_void_p, c_void_p, c_double, POINTER(c_void_p), c_void_p, c_double, c_int,
                                c_void_p]),

@@ -174,6 +174,13 @@ struct EulerParams {
     const double *q_re, *q_tan;
     double* out_tan;
     double jvp_eps, jvp_scale;
+    // prepared JVP (wx_euler3d_jvp_prepare): the face VALUES of the linearisation state stay in fv (real,
+    // [elem][6][5][n^2]) and in the value halos hv_* for a whole Krylov solve; per product only the face TANGENTS are
+    // extrapolated (ft, real, same layout; tangent edge messages through send_* / halo_* as REAL arrays)
+    int split;   // 0: off; 1: the JVP kernel reads (fv, ft); 2: the extrapolation kernel writes tangents only (ft)
+    double* ft;
+    const double* fv;
+    const double *hv_s, *hv_n, *hv_w, *hv_e;
     const T* q;
     T* rhs;
     T* itf;  // [elem][6 faces][NQ = 5 vars + pressure + log pressure][N2]
@@ -281,7 +288,12 @@ __device__ __forceinline__ void load_state<double>(const EulerParams<double>& P,
 template <>
 __device__ __forceinline__ void load_state<dual>(const EulerParams<dual>& P, size_t o, size_t fs, dual& a0, dual& a1, dual& a2,
                                                  dual& a3, dual& a4) {
-    if (P.jvp) {
+    if (P.jvp && P.split == 2) {   // tangent-only extrapolation: values of the log-extrapolated rows only
+        const double *r = P.q_re, *t = P.q_tan;
+        const double e = P.jvp_eps;
+        a0 = dual(r[o], e * t[o]); a1 = dual(0.0, e * t[fs + o]); a2 = dual(0.0, e * t[2 * fs + o]);
+        a3 = dual(0.0, e * t[3 * fs + o]); a4 = dual(r[4 * fs + o], e * t[4 * fs + o]);
+    } else if (P.jvp) {
         const double *r = P.q_re, *t = P.q_tan;
         const double e = P.jvp_eps;
         a0 = dual(r[o], e * t[o]); a1 = dual(r[fs + o], e * t[fs + o]); a2 = dual(r[2 * fs + o], e * t[2 * fs + o]);
@@ -358,11 +370,22 @@ __device__ __forceinline__ void extrap_faces(const EulerParams<T>& P, T (*fld)[C
         const T glog = kGamma * (s4log + kLogRdOverP0);
         const T pf = kP0 * w_exp(glog);
         const T lpf = kLogP0 + glog;
-        T* dst = itf_dst + ((size_t)el.e * 6 + f) * NQ * N2 + fp;
+        bool tan_only = false;
+        if constexpr (std::is_same<T, dual>::value) tan_only = P.split == 2;
+        if constexpr (std::is_same<T, dual>::value) {
+            if (tan_only) {   // prepared JVP: only the tangents of the face values travel (real arrays)
+                double* dt = P.ft + ((size_t)el.e * 6 + f) * 5 * N2 + fp;
 #pragma unroll
-        for (int v = 0; v < 5; ++v) dst[v * N2] = s[v];
-        if (NQ > 5) dst[5 * N2] = pf;
-        if (NQ > 6) dst[6 * N2] = lpf;
+                for (int v = 0; v < 5; ++v) dt[v * N2] = s[v].im;
+            }
+        }
+        if (!tan_only) {
+            T* dst = itf_dst + ((size_t)el.e * 6 + f) * NQ * N2 + fp;
+#pragma unroll
+            for (int v = 0; v < 5; ++v) dst[v * N2] = s[v];
+            if (NQ > 5) dst[5 * N2] = pf;
+            if (NQ > 6) dst[6 * N2] = lpf;
+        }
 
         // outward faces of the tile edge: rotate into the neighbour's basis, flip, pack
         int edge = -1, along = 0;
@@ -381,8 +404,17 @@ __device__ __forceinline__ void extrap_faces(const EulerParams<T>& P, T (*fld)[C
             rotate_contra<T>(P.K->rot[edge], X, s[1], s[2]);
             int al = along, bb = b;
             if (P.K->flip[edge]) { al = H - 1 - along; bb = N - 1 - b; }
-            T* out = sendp + ((size_t)el.ek * H + al) * N2 + a * N + bb;
+            const size_t eo = ((size_t)el.ek * H + al) * N2 + a * N + bb;
             const size_t vs = (size_t)V * H * N2;
+            if constexpr (std::is_same<T, dual>::value) {
+                if (tan_only) {
+                    double* out = reinterpret_cast<double*>(sendp) + eo;
+#pragma unroll
+                    for (int v = 0; v < 5; ++v) out[v * vs] = s[v].im;
+                    continue;
+                }
+            }
+            T* out = sendp + eo;
 #pragma unroll
             for (int v = 0; v < 5; ++v) out[v * vs] = s[v];
             if (NQ > 5) out[5 * vs] = pf;
@@ -577,10 +609,35 @@ __device__ __forceinline__ void face_load(const EulerParams<T>& P, const Elem& e
             sgp = P.sgk + o;
             hp = P.hk + 2 * 3 * hfs + o;
         }
+    bool split = false;
+    if constexpr (std::is_same<T, dual>::value) split = P.split == 1;
+    if constexpr (std::is_same<T, dual>::value) {
+        if (split) {
+            // prepared JVP: values from the cache of the linearisation state, tangents from this product's buffers.
+            // The pointers computed above index [..][5][n^2] arrays of T; the same offsets address the real arrays.
+            const size_t oo = (size_t)(own - P.itf);
+            const double *ov = P.fv + oo, *ot = P.ft + oo, *nv, *nt;
+            if (mirror) { nv = ov; nt = ot; }
+            else if (nstride == (size_t)N2) { const size_t no = (size_t)(nbr - P.itf); nv = P.fv + no; nt = P.ft + no; }
+            else {
+                const T* hb = d == 0 ? (plus ? P.halo_e : P.halo_w) : (plus ? P.halo_n : P.halo_s);
+                const double* hvb = d == 0 ? (plus ? P.hv_e : P.hv_w) : (plus ? P.hv_n : P.hv_s);
+                const size_t no = (size_t)(nbr - hb);
+                nv = hvb + no; nt = reinterpret_cast<const double*>(hb) + no;
+            }
 #pragma unroll
-    for (int v = 0; v < 5; ++v) {
-        in.qo[v] = own[v * N2];
-        in.qn[v] = nbr[v * nstride];
+            for (int v = 0; v < 5; ++v) {
+                in.qo[v] = dual(ov[v * N2], ot[v * N2]);
+                in.qn[v] = dual(nv[v * nstride], nt[v * nstride]);
+            }
+        }
+    }
+    if (!split) {
+#pragma unroll
+        for (int v = 0; v < 5; ++v) {
+            in.qo[v] = own[v * N2];
+            in.qn[v] = nbr[v * nstride];
+        }
     }
     in.sg = *sgp; in.h0 = hp[0]; in.h1 = hp[hfs]; in.h2 = hp[2 * hfs];
     in.mirror = mirror;
@@ -1435,6 +1492,7 @@ struct wx_euler3d_plan {
     size_t itf_bytes;
     EulerConsts* consts;  // device
     unsigned long long* stamps = nullptr;  // device, diagnostic builds only
+    double* face_val = nullptr;   // prepared JVP: face values of the linearisation state, [elem][6][5][n^2] doubles
     EulerParams<double> base;  // pointer-free parts + metric pointers (q/rhs/halo/send filled per call)
 };
 
@@ -1452,6 +1510,7 @@ EulerParams<T> make_params(const wx_euler3d_plan* pl) {
     P.itf_out = nullptr; P.nsend_s = P.nsend_n = P.nsend_w = P.nsend_e = nullptr;
     P.efilter = 0; P.nan_flag = nullptr;
     P.jvp = 0; P.q_re = P.q_tan = nullptr; P.out_tan = nullptr; P.jvp_eps = 0.0; P.jvp_scale = 1.0;
+    P.split = 0; P.ft = nullptr; P.fv = nullptr; P.hv_s = P.hv_n = P.hv_w = P.hv_e = nullptr;
     P.halo_s = P.halo_n = P.halo_w = P.halo_e = nullptr;
     P.send_s = P.send_n = P.send_w = P.send_e = nullptr;
     P.K = pl->consts;
@@ -1641,6 +1700,7 @@ wx_status wx_euler3d_plan_destroy(wx_euler3d_plan* pl) {
     if (!pl) return WX_OK;
     hipError_t e = hipFree(pl->itf);
     if (pl->itf2) (void)hipFree(pl->itf2);
+    if (pl->face_val) (void)hipFree(pl->face_val);
     hipError_t e2 = hipFree(pl->consts);
     if (e == hipSuccess) e = e2;
     delete pl;
@@ -1746,6 +1806,87 @@ wx_status wx_euler3d_jvp(wx_euler3d_plan* pl, const double* q, const double* v, 
     static const bool lean = [] { const char* e = getenv("WXHIP_JVP_LEAN"); return !(e && e[0] == '0'); }();
     WX_STREAM(st, stream);
     if (!lean) return dispatch_rhs<dual>(pl->n, P, st);
+    switch (pl->n) {
+        case 2: return launch_jvp<2>(P, st);
+        case 3: return launch_jvp<3>(P, st);
+        case 4: return launch_jvp<4>(P, st);
+        case 5: return launch_jvp<5>(P, st);
+        case 6: return launch_jvp<6>(P, st);
+        case 7: return launch_jvp<7>(P, st);
+        case 8: return launch_jvp<8>(P, st);
+    }
+    return fail(WX_ERR_UNSUPPORTED, "num_solpts %d not in 2..8", pl->n);
+}
+
+// ---- prepared complex-step JVP: one linearisation state, many products (a Krylov solve).
+// wx_euler3d_jvp_prepare: the face VALUES of q (the plain float64 extrapolation: bit for bit what a float64 plan's
+// wx_euler3d_extrap_pack writes) into the plan's value cache, and the value edge messages into send_val (real,
+// wx_euler3d_edge_count doubles each) for the caller to exchange ONCE and keep.
+wx_status wx_euler3d_jvp_prepare(wx_euler3d_plan* pl, const double* q, void* const send_val[4], wx_stream stream) {
+    if (!pl || !q) return fail(WX_ERR_INVALID, "wx_euler3d_jvp_prepare: null argument");
+    if (pl->dtype != WX_DUAL128) return fail(WX_ERR_INVALID, "wx_euler3d_jvp_*: the plan must be WX_DUAL128");
+    static_assert(NQ == 5, "the value cache holds the five prognostic face values");
+    if (!pl->face_val) {
+        hipError_t e = hipMalloc((void**)&pl->face_val, pl->itf_bytes / 2);
+        if (e != hipSuccess) return fail(WX_ERR_NOMEM, "hipMalloc(%zu bytes) for the face-value cache failed: %s",
+                                         pl->itf_bytes / 2, hipGetErrorString(e));
+    }
+    EulerParams<double> P = make_params<double>(pl);
+    P.itf = pl->face_val;
+    P.q = q;
+    if (send_val) {
+        P.send_s = static_cast<double*>(send_val[0]); P.send_n = static_cast<double*>(send_val[1]);
+        P.send_w = static_cast<double*>(send_val[2]); P.send_e = static_cast<double*>(send_val[3]);
+    }
+    WX_STREAM(st, stream);
+    return dispatch_extrap<double>(pl->n, P, st);
+}
+
+// Per product: only the TANGENTS of the face values (real; the plan's interface buffer serves as their store) and the
+// tangent edge messages (send_tan: real, wx_euler3d_edge_count doubles each).  Reads v, and of q the two rows that are
+// extrapolated in log space.
+wx_status wx_euler3d_jvp_tangent_extrap_pack(wx_euler3d_plan* pl, const double* q, const double* v, double eps,
+                                             void* const send_tan[4], wx_stream stream) {
+    if (!pl || !q || !v) return fail(WX_ERR_INVALID, "wx_euler3d_jvp_tangent_extrap_pack: null argument");
+    if (pl->dtype != WX_DUAL128) return fail(WX_ERR_INVALID, "wx_euler3d_jvp_*: the plan must be WX_DUAL128");
+    if (!pl->face_val) return fail(WX_ERR_INVALID, "wx_euler3d_jvp_tangent_extrap_pack: call wx_euler3d_jvp_prepare first");
+    EulerParams<dual> P = make_params<dual>(pl);
+    P.jvp = 1; P.q_re = q; P.q_tan = v; P.jvp_eps = eps;
+    P.split = 2; P.ft = static_cast<double*>(pl->itf); P.fv = pl->face_val;
+    if (send_tan) {
+        P.send_s = static_cast<dual*>(send_tan[0]); P.send_n = static_cast<dual*>(send_tan[1]);
+        P.send_w = static_cast<dual*>(send_tan[2]); P.send_e = static_cast<dual*>(send_tan[3]);
+    }
+    WX_STREAM(st, stream);
+    return dispatch_extrap<dual>(pl->n, P, st);
+}
+
+// out (real) = scale * Im R(q + i eps v) from the cached face values (+ value halos the caller kept) and this product's
+// face tangents (+ tangent halos).  halo_val / halo_tan: four REAL edge messages each (may be null for INTERIOR).
+wx_status wx_euler3d_jvp_prepared(wx_euler3d_plan* pl, const double* q, const double* v, double eps,
+                                  const void* const halo_val[4], const void* const halo_tan[4], double* out, double scale,
+                                  wx_region region, wx_stream stream) {
+    if (!pl || !q || !v || !out) return fail(WX_ERR_INVALID, "wx_euler3d_jvp_prepared: null argument");
+    if (pl->dtype != WX_DUAL128) return fail(WX_ERR_INVALID, "wx_euler3d_jvp_*: the plan must be WX_DUAL128");
+    if (!pl->face_val) return fail(WX_ERR_INVALID, "wx_euler3d_jvp_prepared: call wx_euler3d_jvp_prepare first");
+    if (region != WX_REGION_ALL && region != WX_REGION_INTERIOR && region != WX_REGION_BOUNDARY)
+        return fail(WX_ERR_INVALID, "unknown region %d", (int)region);
+    if (region != WX_REGION_INTERIOR) {
+        if (!halo_val || !halo_tan) return fail(WX_ERR_INVALID, "wx_euler3d_jvp_prepared: halos are required for this region");
+        for (int e = 0; e < 4; ++e)
+            if (!halo_val[e] || !halo_tan[e]) return fail(WX_ERR_INVALID, "wx_euler3d_jvp_prepared: halo[%d] is null", e);
+    }
+    EulerParams<dual> P = make_params<dual>(pl);
+    P.jvp = 1; P.q_re = q; P.q_tan = v; P.jvp_eps = eps; P.out_tan = out; P.jvp_scale = scale;
+    P.split = 1; P.ft = static_cast<double*>(pl->itf); P.fv = pl->face_val;
+    P.region = region; P.count = region_count(region, pl->H, pl->V);
+    if (halo_val && halo_tan) {
+        P.halo_s = static_cast<const dual*>(halo_tan[0]); P.halo_n = static_cast<const dual*>(halo_tan[1]);
+        P.halo_w = static_cast<const dual*>(halo_tan[2]); P.halo_e = static_cast<const dual*>(halo_tan[3]);
+        P.hv_s = static_cast<const double*>(halo_val[0]); P.hv_n = static_cast<const double*>(halo_val[1]);
+        P.hv_w = static_cast<const double*>(halo_val[2]); P.hv_e = static_cast<const double*>(halo_val[3]);
+    }
+    WX_STREAM(st, stream);
     switch (pl->n) {
         case 2: return launch_jvp<2>(P, st);
         case 3: return launch_jvp<3>(P, st);

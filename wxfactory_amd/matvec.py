@@ -79,6 +79,9 @@ class ComplexStepOperator:
     def __init__(self, dt: float, Q: torch.Tensor, rhs: torch.Tensor, rhs_handle: Callable, method: str = "complex"):
         self.dt, self.Q, self.rhs, self.rhs_handle, self.method = dt, Q, rhs, rhs_handle, method
         self.kiops_vector = None
+        prep = getattr(rhs_handle, "jvp_prepare", None)
+        if method == "complex" and prep is not None and getattr(rhs_handle, "fused_jvp", True) and isinstance(Q, torch.Tensor):
+            prep(Q)   # every product of this operator linearises about Q: cache its face values once
         fn = getattr(rhs_handle, "kiops_vector_fn", None)
         if method == "complex" and fn is not None and getattr(rhs_handle, "fused_jvp", True) and Q.is_cuda:
             self.kiops_vector = fn(Q, EPS_COMPLEX, dt / EPS_COMPLEX)

@@ -199,6 +199,28 @@ class Euler3DPlan:
         check(self.lib.wx_euler3d_jvp(self._h, q.data_ptr(), v.data_ptr(), eps, _ptr_array(halo), out.data_ptr(), scale,
                                       region, st), "wx_euler3d_jvp")
 
+    def jvp_prepare(self, q, send_val):
+        """dual plans: cache the face values of the linearisation state q (and pack its value edge messages)."""
+        self._check_real(q)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.wx_euler3d_jvp_prepare(self._h, q.data_ptr(), _ptr_array(send_val), st), "wx_euler3d_jvp_prepare")
+
+    def jvp_tangent_pack(self, q, v, eps: float, send_tan):
+        self._check_real(q)
+        self._check_real(v)
+        self.faces_epoch += 1
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.wx_euler3d_jvp_tangent_extrap_pack(self._h, q.data_ptr(), v.data_ptr(), eps, _ptr_array(send_tan), st),
+              "wx_euler3d_jvp_tangent_extrap_pack")
+
+    def jvp_prepared(self, q, v, eps: float, halo_val, halo_tan, out, scale: float, region: int = _lib.WX_REGION_ALL):
+        for t in (q, v, out):
+            self._check_real(t)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.wx_euler3d_jvp_prepared(self._h, q.data_ptr(), v.data_ptr(), eps, _ptr_array(halo_val),
+                                               _ptr_array(halo_tan), out.data_ptr(), scale, region, st),
+              "wx_euler3d_jvp_prepared")
+
     def close(self):
         if self._h:
             self.lib.wx_euler3d_plan_destroy(self._h)
@@ -454,6 +476,42 @@ class RhsEuler3D(PanelRhs):
 
         return build
 
+    def _jvp_plans(self):
+        if "jvp" not in self._plans:
+            self._plans["jvp"] = {p: pl.twin(torch.complex128, dual=True) for p, pl in self.plans.items()}
+        return self._plans["jvp"]
+
+    def jvp_prepare(self, Q: torch.Tensor):
+        """Declare Q the linearisation state of the Jacobian-vector products to come (every matvec of one FGMRES / KIOPS
+        solve): its face values are extrapolated and exchanged ONCE and cached; jvp(Q, v, ...) then extrapolates and
+        exchanges only tangents (wx_euler3d_jvp_prepare).  Holds until jvp_release(), another jvp_prepare(), or a jvp()
+        with a different or modified Q (then the unprepared path runs).  Large tiles only (small ones take the batched
+        launches); collective like an evaluation."""
+        if self._small_tiles() or not (Q.is_cuda and Q.dtype == torch.float64 and Q.is_contiguous()) or not self.panels:
+            self._jvp_lin = None
+            return False
+        np_ = len(self.panels)
+        Qs = Q.reshape((np_,) + tuple(self.panel_shape))
+        plans = self._jvp_plans()
+        if getattr(self, "_ex_val", None) is None:
+            mk = lambda: PanelExchange(self.edge_count, self.device, rank=self.rank, world_size=self.world, group=self.group,  # noqa: E731
+                                       tiles_per_side=self.tiles_per_side)
+            self._ex_val, self._ex_tan = mk(), mk()
+        ex = self._ex_val
+        for i, p in enumerate(self.panels):
+            plans[p].jvp_prepare(Qs[i], ex.send_views(p))
+        ex.start()
+        ex.wait()
+        self._jvp_lin = (weakref.ref(Q), Q.data_ptr(), Q._version)
+        return True
+
+    def jvp_release(self):
+        self._jvp_lin = None
+
+    def _jvp_is_prepared(self, Q) -> bool:
+        lin = getattr(self, "_jvp_lin", None)
+        return lin is not None and lin[0]() is Q and lin[1:] == (Q.data_ptr(), Q._version)
+
     def jvp(self, Q: torch.Tensor, v: torch.Tensor, eps: float, scale: float) -> torch.Tensor:
         """scale * Im R(Q + i eps v) for stacked real Q, v -> real tensor shaped like Q.  The dual state is
         formed inside the kernels and only the tangent is stored: the complex-step JVP of
@@ -461,10 +519,15 @@ class RhsEuler3D(PanelRhs):
         np_ = len(self.panels)
         Qs = Q.reshape((np_,) + tuple(self.panel_shape))
         vs = v.reshape((np_,) + tuple(self.panel_shape))
-        if "jvp" not in self._plans:
-            base = self.plans
-            self._plans["jvp"] = {p: pl.twin(torch.complex128, dual=True) for p, pl in base.items()}
-        plans = self._plans["jvp"]
+        plans = self._jvp_plans()
+        if self._jvp_is_prepared(Q) and v.is_contiguous():
+            exv, ext = self._ex_val, self._ex_tan
+            out = torch.empty_like(Qs)
+            for i, p in enumerate(self.panels):
+                plans[p].jvp_tangent_pack(Qs[i], vs[i], eps, ext.send_views(p))
+            self._exchange_and_launch(ext, lambda i, p, halo, region: plans[p].jvp_prepared(
+                Qs[i], vs[i], eps, exv.halo_views(p) if halo is not None else None, halo, out[i], scale, region))
+            return out.reshape(Q.shape)
         ex = self.exchange_for(torch.complex128)
         out = torch.empty_like(Qs)
         if self._small_tiles() and Q.is_contiguous() and v.is_contiguous() and Q.dtype == torch.float64 \
