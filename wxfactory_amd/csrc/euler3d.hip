@@ -60,6 +60,10 @@
 #ifndef WX_K2_MFMA
 #define WX_K2_MFMA 1      // n = 8, float64: the derivative contractions of the fused kernel on v_mfma_f64_16x16x4_f64
 #endif
+#ifndef WX_K2_MFMA_SHAPE
+#define WX_K2_MFMA_SHAPE 4   // 16: v_mfma_f64_16x16x4_f64 (half of each tile is padding for an 8-row operator);
+                             //  4: v_mfma_f64_4x4x4_4b_f64 (four 4x4x4 blocks per instruction, no padding: half the pipe time)
+#endif
 #ifndef WX_K2_MFMA_CORR
 #define WX_K2_MFMA_CORR 1 // ... with the two face corrections riding along as a third k-step (D | cm | cp is 8 x 10)
 #endif
@@ -137,6 +141,12 @@ enum { F_W = 0, F_E = 1, F_S = 2, F_N = 3, F_B = 4, F_T = 5 };
 #endif
 #ifndef WX_K2_SKELETON
 #define WX_K2_SKELETON 0   // diagnostic build: K2 keeps its loads, LDS writes and stores but skips the arithmetic
+#endif
+#ifndef WX_K2_SKEL_FACE
+#define WX_K2_SKEL_FACE WX_K2_SKELETON   // ... only the Riemann arithmetic of the face stage
+#endif
+#ifndef WX_K2_SKEL_DIRS
+#define WX_K2_SKEL_DIRS WX_K2_SKELETON   // ... only the three directional passes
 #endif
 #ifndef WX_EULER_NQ
 #define WX_EULER_NQ 5   // 7: state + p + log p;  6: state + p;  5: state only (pressures redone per side)
@@ -658,7 +668,7 @@ __device__ __forceinline__ void face_flux(const FaceIn<T>& in, int f, bool advec
     qo[5] = kP0 * w_exp(go); qn[5] = kP0 * w_exp(gn);
     qo[6] = kLogP0 + go; qn[6] = kLogP0 + gn;
     const double sg = in.sg, h0 = in.h0, h1 = in.h1, h2 = in.h2;
-#if WX_K2_SKELETON
+#if WX_K2_SKEL_FACE
     {   // diagnostic: every load consumed, no Riemann arithmetic
         T sum = T(sg + h0 + h1 + h2);
 #pragma unroll
@@ -784,6 +794,53 @@ __device__ __forceinline__ void mf_dir_pass(double* fld, const double* frs, cons
     }
 }
 
+// The same pass on v_mfma_f64_4x4x4_4b_f64: four independent 4 x 4 x 4 products per instruction, 16 cycles each, no
+// padding - the 8 x 10 operator is cut into 4 x 4 blocks (output half I, input quarter M; the face pair is a third
+// k-step with two zero columns), so a field's 64 lines cost 24 instructions x 16 cycles instead of 12 x 64.
+// Lane maps (found with tools/mfma_f64_4x4_probe.hip): lane l, k = l >> 4, block g = (l >> 2) & 3, x = l & 3:
+//   A_g[i = x][k],  B_g[k][j = x],  result D_g[i][j] in lane 16 i + 4 g + j.
+// Block g = I + 2 L works on output half I (nodes 4 I .. 4 I + 3) of the four lines u = 4 L .. 4 L + 3 of one
+// octet of lines (u = 0..7, v fixed); wave w owns octet v = w of every field.  The lane ends up with node
+// 4 I + (l >> 4) of line u = 4 L + (l & 3).
+struct MfOps4 { double a0, a1, af, h0, h1; };
+__device__ __forceinline__ MfOps4 mf4_load_ops(const EulerConsts* K, int lane) {
+    const int k = lane >> 4, I = (lane >> 2) & 1, x = lane & 3, row = 4 * I + x;
+    MfOps4 o;
+    o.a0 = K->D[row * 8 + k]; o.a1 = K->D[row * 8 + 4 + k];
+    o.af = k == 0 ? K->cm[row] : (k == 1 ? K->cp[row] : 0.0);
+    o.h0 = K->HF[row * 8 + k]; o.h1 = K->HF[row * 8 + 4 + k];
+    return o;
+}
+
+template <int D, bool CORR>
+__device__ __forceinline__ void mf4_dir_pass(double* fld, const double* frs, const MfOps4& op, int wave, int lane) {
+    const int k = lane >> 4, g = (lane >> 2) & 3, I = g & 1, u = 4 * (g >> 1) + (lane & 3), v = wave;
+    int r0, r1, wo;   // operand nodes k, 4 + k of line (u, v); result node 4 I + k
+    if (D == 0) { r0 = mf_idx(v, u, k); r1 = mf_idx(v, u, 4 + k); wo = mf_idx(v, u, 4 * I + k); }
+    else if (D == 1) { r0 = mf_idx(v, k, u); r1 = mf_idx(v, 4 + k, u); wo = mf_idx(v, 4 * I + k, u); }
+    else { r0 = mf_idx(k, v, u); r1 = mf_idx(4 + k, v, u); wo = mf_idx(4 * I + k, v, u); }
+    const int fo = (2 * D + (k & 1)) * kMfFS + 8 * v + u;
+    constexpr int NFLD = D == 2 ? 8 : 7;
+    double b0[NFLD], b1[NFLD], bf[7];
+#pragma unroll
+    for (int f = 0; f < NFLD; ++f) {
+        b0[f] = fld[f * kMfLE + r0];
+        b1[f] = fld[f * kMfLE + r1];
+        if (CORR && f < 7) bf[f] = frs[fo + f * 64];
+    }
+    double acc[NFLD];
+#pragma unroll
+    for (int f = 0; f < NFLD; ++f) acc[f] = __builtin_amdgcn_mfma_f64_4x4x4f64(f < 7 ? op.a0 : op.h0, b0[f], 0.0, 0, 0, 0);
+#pragma unroll
+    for (int f = 0; f < NFLD; ++f) acc[f] = __builtin_amdgcn_mfma_f64_4x4x4f64(f < 7 ? op.a1 : op.h1, b1[f], acc[f], 0, 0, 0);
+    if (CORR) {
+#pragma unroll
+        for (int f = 0; f < 7; ++f) acc[f] = __builtin_amdgcn_mfma_f64_4x4x4f64(op.af, bf[f], acc[f], 0, 0, 0);
+    }
+#pragma unroll
+    for (int f = 0; f < NFLD; ++f) fld[f * kMfLE + wo] = acc[f];
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2: fused phases 3-8
 // ------------------------------------------------------------------------------------------------
@@ -839,7 +896,9 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
     const int lpt = lb + (SWZ ? C::lidx_swz(kl, jl, il) : C::lidx(kl, jl, il));  // this thread's node in the LDS image
     const int lptm = mf_idx(kl, jl, il);   // ... and in the image of the matrix-core passes
     MfOps mops{0.0, 0.0, 0.0, 0.0, 0.0};
-    if (MF) mops = mf_load_ops(P.K, tid & 63);
+    MfOps4 mops4{0.0, 0.0, 0.0, 0.0, 0.0};
+    if (MF && WX_K2_MFMA_SHAPE == 16) mops = mf_load_ops(P.K, tid & 63);
+    if (MF && WX_K2_MFMA_SHAPE == 4) mops4 = mf4_load_ops(P.K, tid & 63);
     const size_t o = (size_t)el.e * N3 + pt;
 
     T q0 = T(1.0), q1 = T(0.0), q2 = T(0.0), q3 = T(0.0), q4 = T(1.0);
@@ -964,7 +1023,7 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
     T acc0 = T(0.0), acc1 = sg * fc0, acc2 = sg * fc1, acc4 = T(0.0), accw = sg * fc2;
     T hf = T(0.0);
 
-#if WX_K2_SKELETON
+#if WX_K2_SKEL_DIRS
     if (MF) fld[6][lpt] = logp;
     __syncthreads();
     acc0 += WX_FR(le < EPB ? le : 0, 0, 0, pt % N2) + fld[6][lpt];
@@ -974,7 +1033,7 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
 #else
 #pragma unroll 1
 #endif
-    for (int d = 0; d < (WX_K2_SKELETON ? 0 : 3); ++d) {
+    for (int d = 0; d < (WX_K2_SKEL_DIRS ? 0 : 3); ++d) {
         const T ud = w_sel(d == 0, u1, w_sel(d == 1, u2, u3));
 #if WX_K2_RELOAD_H
         double hd0 = 0, hd1 = 0, hd2 = 0;
@@ -1004,9 +1063,15 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
             if (d == 2) fm[7 * kMfLE + lptm] = sg * q0;
             __syncthreads();
             const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-            if (d == 0) mf_dir_pass<0, MFC>(fm, fq, mops, wave, tid & 63);
-            else if (d == 1) mf_dir_pass<1, MFC>(fm, fq, mops, wave, tid & 63);
-            else mf_dir_pass<2, MFC>(fm, fq, mops, wave, tid & 63);
+            if (WX_K2_MFMA_SHAPE == 4) {
+                if (d == 0) mf4_dir_pass<0, MFC>(fm, fq, mops4, wave, tid & 63);
+                else if (d == 1) mf4_dir_pass<1, MFC>(fm, fq, mops4, wave, tid & 63);
+                else mf4_dir_pass<2, MFC>(fm, fq, mops4, wave, tid & 63);
+            } else {
+                if (d == 0) mf_dir_pass<0, MFC>(fm, fq, mops, wave, tid & 63);
+                else if (d == 1) mf_dir_pass<1, MFC>(fm, fq, mops, wave, tid & 63);
+                else mf_dir_pass<2, MFC>(fm, fq, mops, wave, tid & 63);
+            }
             __syncthreads();
             double r0 = fm[0 * kMfLE + lptm], r1 = fm[1 * kMfLE + lptm], r2 = fm[2 * kMfLE + lptm],
                    r3 = fm[3 * kMfLE + lptm], r4 = fm[4 * kMfLE + lptm], r5 = fm[5 * kMfLE + lptm],
