@@ -812,33 +812,44 @@ __device__ __forceinline__ MfOps4 mf4_load_ops(const EulerConsts* K, int lane) {
     return o;
 }
 
-template <int D, bool CORR>
+// NDF fields carry the operator D | cm | cp (image f, face quantity f, f < NDF); with HFLD the image NDF takes HF (no
+// faces) when D == 2.  FS: doubles per face in the face image.  FB: fields whose operands are in flight together.
+template <int D, bool CORR, int NDF = 7, bool HFLD = true, int FS = kMfFS, int FB = 8>
 __device__ __forceinline__ void mf4_dir_pass(double* fld, const double* frs, const MfOps4& op, int wave, int lane) {
     const int k = lane >> 4, g = (lane >> 2) & 3, I = g & 1, u = 4 * (g >> 1) + (lane & 3), v = wave;
     int r0, r1, wo;   // operand nodes k, 4 + k of line (u, v); result node 4 I + k
     if (D == 0) { r0 = mf_idx(v, u, k); r1 = mf_idx(v, u, 4 + k); wo = mf_idx(v, u, 4 * I + k); }
     else if (D == 1) { r0 = mf_idx(v, k, u); r1 = mf_idx(v, 4 + k, u); wo = mf_idx(v, 4 * I + k, u); }
     else { r0 = mf_idx(k, v, u); r1 = mf_idx(4 + k, v, u); wo = mf_idx(4 * I + k, v, u); }
-    const int fo = (2 * D + (k & 1)) * kMfFS + 8 * v + u;
-    constexpr int NFLD = D == 2 ? 8 : 7;
-    double b0[NFLD], b1[NFLD], bf[7];
+    const int fo = (2 * D + (k & 1)) * FS + 8 * v + u;
+    constexpr int NFLD = NDF + ((D == 2 && HFLD) ? 1 : 0);
 #pragma unroll
-    for (int f = 0; f < NFLD; ++f) {
-        b0[f] = fld[f * kMfLE + r0];
-        b1[f] = fld[f * kMfLE + r1];
-        if (CORR && f < 7) bf[f] = frs[fo + f * 64];
+    for (int f0 = 0; f0 < NFLD; f0 += FB) {
+        double b0[FB], b1[FB], bf[FB], acc[FB];
+#pragma unroll
+        for (int i = 0; i < FB; ++i) {
+            const int f = f0 + i;
+            if (f < NFLD) {
+                b0[i] = fld[f * kMfLE + r0];
+                b1[i] = fld[f * kMfLE + r1];
+                if (CORR && f < NDF) bf[i] = frs[fo + f * 64];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < FB; ++i)
+            if (f0 + i < NFLD) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(f0 + i < NDF ? op.a0 : op.h0, b0[i], 0.0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < FB; ++i)
+            if (f0 + i < NFLD) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(f0 + i < NDF ? op.a1 : op.h1, b1[i], acc[i], 0, 0, 0);
+        if (CORR) {
+#pragma unroll
+            for (int i = 0; i < FB; ++i)
+                if (f0 + i < NDF) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(op.af, bf[i], acc[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < FB; ++i)
+            if (f0 + i < NFLD) fld[(f0 + i) * kMfLE + wo] = acc[i];
     }
-    double acc[NFLD];
-#pragma unroll
-    for (int f = 0; f < NFLD; ++f) acc[f] = __builtin_amdgcn_mfma_f64_4x4x4f64(f < 7 ? op.a0 : op.h0, b0[f], 0.0, 0, 0, 0);
-#pragma unroll
-    for (int f = 0; f < NFLD; ++f) acc[f] = __builtin_amdgcn_mfma_f64_4x4x4f64(f < 7 ? op.a1 : op.h1, b1[f], acc[f], 0, 0, 0);
-    if (CORR) {
-#pragma unroll
-        for (int f = 0; f < 7; ++f) acc[f] = __builtin_amdgcn_mfma_f64_4x4x4f64(op.af, bf[f], acc[f], 0, 0, 0);
-    }
-#pragma unroll
-    for (int f = 0; f < NFLD; ++f) fld[f * kMfLE + wo] = acc[f];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1456,9 +1467,141 @@ __device__ __forceinline__ void euler_jvp_body(const EulerParams<dual>& P) {
     }
 }
 
+// The same kernel with the contractions on the matrix cores (n = 8; mf4_dir_pass, the layout and the in-place scheme of
+// the fused RHS kernel).  Nine real planes per direction: the five flux tangents, B (metric), log p value and tangent -
+// eight take D | cm | cp with their face pairs as the third k-step - and the tangent of sqrtG rho for the vertical
+// high-filter; the tangent of B* has no nodal part and keeps its two-term correction on the vector pipe.
+#ifndef WX_JVP_MFMA
+#define WX_JVP_MFMA 1
+#endif
+#ifndef WX_JVP_MFMA_FB
+#define WX_JVP_MFMA_FB 4   // planes whose operands are in flight together in a matrix-core pass
+#endif
+constexpr int kJvFS = 9 * 64 + 16;   // doubles per face of the JVP kernel's face image (9 quantities)
+
+__device__ __forceinline__ void euler_jvp_body_mf(const EulerParams<dual>& P) {
+    using T = dual;
+    constexpr int N = 8, N2 = 64, N3 = 512;
+    __shared__ double pl[9 * kMfLE];   // 0-4 flux tangents (rho, rho u1, rho u2, rho theta, A); 5 B; 6, 7 log p (value, tangent); 8 (sqrtG rho)'
+    __shared__ double fq[6 * kJvFS];   // per face: 0-4 tangents of F*; 5 B*.re; 6, 7 log p_own (value, tangent); 8 B*.im
+    __shared__ double sCm[N], sCp[N];
+    const int tid = threadIdx.x;
+    const int H = P.H, V = P.V;
+    const size_t fs = (size_t)P.nelem * N3;
+    if (tid < N) {
+        sCm[tid] = P.K->cm[tid];
+        sCp[tid] = P.K->cp[tid];
+    }
+    const MfOps4 mops = mf4_load_ops(P.K, tid & 63);
+    const Elem el = decode_elem(block_slot(gridDim.x), P.count, P.region, H, V);
+    const bool active = el.valid;
+    const int kl = tid / N2, jl = (tid / N) % N, il = tid % N;
+    const int lptm = mf_idx(kl, jl, il);
+    const size_t o = (size_t)el.e * N3 + tid;
+
+    // ---- face stage
+    for (int fi = tid; fi < 6 * N2; fi += 512) {
+        const int f = fi / N2, fp = fi % N2;
+        if (!el.valid) continue;
+        T out[7];
+        face_problem<N, T, true>(P, el, f, fp, out);
+        double* q = fq + f * kJvFS + fp;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) q[c * N2] = out[c].im;
+        q[5 * N2] = out[5].re; q[8 * N2] = out[5].im;
+        q[6 * N2] = out[6].re; q[7 * N2] = out[6].im;
+    }
+
+    T q0 = T(1.0), q1 = T(0.0), q2 = T(0.0), q3 = T(0.0), q4 = T(1.0);
+    double sg = 1.0, h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0;
+    if (active) {
+        load_state<T>(P, o, fs, q0, q1, q2, q3, q4);
+        sg = WX_LDM(P.sg + o);
+        h00 = WX_LDM(P.h + 0 * fs + o); h01 = WX_LDM(P.h + 1 * fs + o); h02 = WX_LDM(P.h + 2 * fs + o);
+        h11 = WX_LDM(P.h + 4 * fs + o); h12 = WX_LDM(P.h + 5 * fs + o); h22 = WX_LDM(P.h + 8 * fs + o);
+    }
+    const T rinv = 1.0 / q0;
+    const T u1 = q1 * rinv, u2 = q2 * rinv, u3 = q3 * rinv;
+    const T glog = kGamma * w_log(kRdOverP0 * q4);
+    const T p = kP0 * w_exp(glog);
+    const T lp = kLogP0 + glog;
+
+    // ---- forcing (tangent), one row of Christoffel symbols at a time
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc4 = 0.0, accw = 0.0, hf = 0.0, gcoef = 0.0;
+    if (active) {
+#pragma unroll 1
+        for (int i = 0; i < 3; ++i) {
+            const double* c = P.chr + (size_t)(i * 9) * fs + o;
+            double c01 = 0.0, c02 = 0.0, c03 = 0.0;
+            if (!P.rot_zero) { c01 = WX_LDM(c); c02 = WX_LDM(c + fs); c03 = WX_LDM(c + 2 * fs); }
+            const double c11 = WX_LDM(c + 3 * fs), c12 = WX_LDM(c + 4 * fs), c13 = WX_LDM(c + 5 * fs),
+                         c22 = WX_LDM(c + 6 * fs), c23 = WX_LDM(c + 7 * fs), c33 = WX_LDM(c + 8 * fs);
+            T f = 2.0 * q0 * (c01 * u1 + c02 * u2 + c03 * u3) + c11 * (q0 * u1 * u1 + h00 * p) +
+                  2.0 * c12 * (q0 * u1 * u2 + h01 * p) + 2.0 * c13 * (q0 * u1 * u3 + h02 * p) +
+                  c22 * (q0 * u2 * u2 + h11 * p) + 2.0 * c23 * (q0 * u2 * u3 + h12 * p) +
+                  c33 * (q0 * u3 * u3 + h22 * p);
+            if (P.has_damp) f += (P.dcoef[o] * q0) * ((i == 0 ? u1 : (i == 1 ? u2 : u3)) - P.duref[(size_t)i * fs + o]);
+            if (i == 0) acc1 = sg * f.im;
+            else if (i == 1) acc2 = sg * f.im;
+            else accw = sg * f.im;
+        }
+        gcoef = WX_LDM(P.idz + o) * kGravity;
+    }
+
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const T ud = w_sel(d == 0, u1, w_sel(d == 1, u2, u3));
+        const double hd0 = d == 0 ? h00 : (d == 1 ? h01 : h02);
+        const double hd1 = d == 0 ? h01 : (d == 1 ? h11 : h12);
+        const double hd2 = d == 0 ? h02 : (d == 1 ? h12 : h22);
+        const T sgu = sg * ud;
+        const double Bd = sg * hd2;
+        // each thread stages its own node of the nine planes, the eight waves contract all lines in place, each thread
+        // picks its own node up again (no barrier between a thread's read and its next write)
+        pl[0 * kMfLE + lptm] = (sgu * q0).im;
+        pl[1 * kMfLE + lptm] = (sgu * q1 + (sg * hd0) * p).im;
+        pl[2 * kMfLE + lptm] = (sgu * q2 + (sg * hd1) * p).im;
+        pl[3 * kMfLE + lptm] = (sgu * q4).im;
+        pl[4 * kMfLE + lptm] = (sgu * q3).im;
+        pl[5 * kMfLE + lptm] = Bd;
+        pl[6 * kMfLE + lptm] = lp.re;
+        pl[7 * kMfLE + lptm] = lp.im;
+        if (d == 2) pl[8 * kMfLE + lptm] = sg * q0.im;
+        __syncthreads();
+        if (d == 0) mf4_dir_pass<0, true, 8, true, kJvFS, WX_JVP_MFMA_FB>(pl, fq, mops, wave, tid & 63);
+        else if (d == 1) mf4_dir_pass<1, true, 8, true, kJvFS, WX_JVP_MFMA_FB>(pl, fq, mops, wave, tid & 63);
+        else mf4_dir_pass<2, true, 8, true, kJvFS, WX_JVP_MFMA_FB>(pl, fq, mops, wave, tid & 63);
+        __syncthreads();
+        acc0 += pl[0 * kMfLE + lptm];
+        acc1 += pl[1 * kMfLE + lptm];
+        acc2 += pl[2 * kMfLE + lptm];
+        acc4 += pl[3 * kMfLE + lptm];
+        accw += pl[4 * kMfLE + lptm];
+        // W^d = [A@D + A*@C] + p [B@D + B*@C] + p B [log p@D + log p^@C]  (rhs_dfr.py:113-136): tangent of the two products
+        const int fp = d == 0 ? kl * N + jl : (d == 1 ? kl * N + il : jl * N + il);
+        const int ix = d == 0 ? il : (d == 1 ? jl : kl);
+        const T a5(pl[5 * kMfLE + lptm], sCm[ix] * fq[(2 * d) * kJvFS + 8 * N2 + fp] + sCp[ix] * fq[(2 * d + 1) * kJvFS + 8 * N2 + fp]);
+        const T a6(pl[6 * kMfLE + lptm], pl[7 * kMfLE + lptm]);
+        accw += (a5 * p).im + (a6 * (p * Bd)).im;
+        if (d == 2) hf = pl[8 * kMfLE + lptm];
+    }
+
+    if (active) {
+        const double sc = P.advection_only ? 0.0 : -P.jvp_scale / sg;
+        accw += gcoef * hf;  // gravity: inv_dzdeta * g * 1/sqrtG * HF_k(sqrtG rho)
+        P.out_tan[o] = sc * acc0;
+        P.out_tan[fs + o] = sc * acc1;
+        P.out_tan[2 * fs + o] = sc * acc2;
+        P.out_tan[3 * fs + o] = sc * accw;
+        P.out_tan[4 * fs + o] = sc * acc4;
+    }
+}
+
 template <int N>
 __global__ __launch_bounds__(Cfg<N>::BS, WX_JVP_WAVES) void euler_jvp_kernel(const EulerParams<dual> P) {
-    euler_jvp_body<N>(P);
+    if constexpr (N == 8 && WX_JVP_MFMA) euler_jvp_body_mf(P);
+    else euler_jvp_body<N>(P);
 }
 
 template <int N>
