@@ -103,8 +103,8 @@ def cpu_baseline(n, V, seed):
                                      "(measured in the survey container, not on this host)"}
 
 
-KERNEL_SOURCES = ("wxfactory_amd/csrc/euler3d.hip", "wxfactory_amd/csrc/wx_math.h", "wxfactory_amd/csrc/wx_common.h",
-                  "wxfactory_amd/csrc/wx_panels.h")
+KERNEL_SOURCES = ("wxfactory_amd/csrc/euler3d.hip", "wxfactory_amd/csrc/wx_math.h", "wxfactory_amd/csrc/wx_mfma.h",
+                  "wxfactory_amd/csrc/wx_common.h", "wxfactory_amd/csrc/wx_panels.h")
 
 
 def kernel_source_hash():

@@ -10,12 +10,18 @@
 // All three are single-pass streaming kernels (HBM-bound: 8 (2 nvar + 1) B per point for the filter).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "wx_common.h"
 #include "wx_math.h"
+#include "wx_mfma.h"
 
 namespace wx {
 
 constexpr int kFilterMaxVar = 5;
+#ifndef WX_FILTER_MFMA
+#define WX_FILTER_MFMA 1   // n = 8, float64: the filter's three passes on v_mfma_f64_4x4x4_4b_f64
+#endif
 
 template <int N>
 struct FCfg {
@@ -57,8 +63,30 @@ __global__ __launch_bounds__(FCfg<N>::BS) void expfilter_kernel(const T* __restr
 #pragma unroll
     for (int f = 0; f < kFilterMaxVar; ++f) v[f] = (active && f < nvar) ? sg * q[(size_t)f * fs + o] : T(0.0);
 
+    // n = 8, float64: the three passes on the matrix cores (wx_mfma.h: in place, every thread stages and picks up its
+    // own node, the eight waves contract one octet of lines each); the filter matrix is the operator, no face step
+    constexpr bool MF = N == 8 && std::is_same<T, double>::value && WX_FILTER_MFMA;
+    if constexpr (MF) {
+        static_assert(C::LE == kMfLE && EPB == 1, "the matrix-core pass owns one n = 8 element per workgroup");
+        double* fm = reinterpret_cast<double*>(&fld[0][0]);
+        const int lptm = mf_idx(kl, jl, il);
+        const MfOps4 ops = mf4_load_ops(filter, nullptr, nullptr, nullptr, tid & 63);
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
+        for (int d = 0; d < 3; ++d) {
+#pragma unroll
+            for (int f = 0; f < kFilterMaxVar; ++f) fm[f * kMfLE + lptm] = v[f];
+            __syncthreads();
+            if (d == 0) mf4_dir_pass<0, false, kFilterMaxVar, false>(fm, fm, ops, wave, tid & 63);
+            else if (d == 1) mf4_dir_pass<1, false, kFilterMaxVar, false>(fm, fm, ops, wave, tid & 63);
+            else mf4_dir_pass<2, false, kFilterMaxVar, false>(fm, fm, ops, wave, tid & 63);
+            __syncthreads();
+#pragma unroll
+            for (int f = 0; f < kFilterMaxVar; ++f) v[f] = fm[f * kMfLE + lptm];
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < (MF ? 0 : 3); ++d) {
         if (d > 0) __syncthreads();
         if (le < EPB) {
 #pragma unroll
