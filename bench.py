@@ -87,6 +87,9 @@ def cpu_baseline(n, V, seed):
     (2) the optimised C++/OpenMP restatement - `value`; (1) the reference-style dense-Kronecker NumPy restatement."""
     model, phys, logical = host_cpu()
     threads = max(1, min(phys, 16) // 6)   # a one-GPU box's CPU share is 16 cores, whatever the host has
+    from oracle import c_port
+
+    c_port.load()   # (re)build the C++ port for THIS host once, before six workers would each try to
     cpp = cpu_baseline_run("cpp", n, 30, V, 3, threads, seed)
     dense = cpu_baseline_run("dense", n, 30, 1, 2, threads, seed)
     return {"value": cpp["dof_updates_per_s"], "unit": "DOF-updates/s", "cores": 6 * threads, "kind": "port",

@@ -18,9 +18,13 @@ _P = ctypes.POINTER(ctypes.c_double)
 
 
 def build(force: bool = False) -> str:
+    """Compile into a private file and rename it into place: several processes may find the library stale at once
+    (bench.py starts six workers), and none of them must ever load a half-written file."""
     src = os.path.join(HERE, "c", "euler3d_port.cpp")
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-s", "-C", HERE, "port"])
+        tmp = f"{LIB}.{os.getpid()}.tmp"
+        subprocess.check_call(["g++", "-O3", "-march=native", "-fopenmp", "-shared", "-std=c++17", "-fPIC", src, "-o", tmp])
+        os.replace(tmp, LIB)
     return LIB
 
 
@@ -35,7 +39,9 @@ def load():
         host = open("/proc/cpuinfo").read().split("model name", 2)[1].split("\n", 1)[0] if os.path.exists("/proc/cpuinfo") else ""
         if not os.path.exists(LIB) or not os.path.exists(stamp) or open(stamp).read() != host:
             build(force=True)
-            open(stamp, "w").write(host)
+            with open(f"{stamp}.{os.getpid()}.tmp", "w") as f:
+                f.write(host)
+            os.replace(f"{stamp}.{os.getpid()}.tmp", stamp)
         _lib = ctypes.CDLL(LIB)
         _lib.wxo_euler3d_extrapolate.restype = ctypes.c_int
         _lib.wxo_euler3d_rhs.restype = ctypes.c_int
