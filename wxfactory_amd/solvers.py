@@ -422,6 +422,86 @@ def _ceil_clamped(x: float, lo: float, hi: float) -> int:
     return int(min(hi, max(lo, math.ceil(x))))
 
 
+class _SubstepControl:
+    """Sub-step size tau and Krylov basis size m of the adaptive phi-function evaluation (the controller of phipm,
+    Niesen & Wright 2012, section 3.3-3.4, with the KIOPS modifications of Gaudreault, Rainwater & Tokman 2018,
+    section 4: what solvers/kiops.py:209-347 implements and what has to be reproduced decision for decision to obtain
+    the reference's `stats`).  State: the attempt being judged (tau, m), the one before it, and two running estimates -
+    `order`, the exponent q in error ~ tau^q, and `gain`, the factor by which one more basis vector divides the error.
+    Each estimate is measured only from two consecutive attempts of the SAME sub-step that differ in exactly one of
+    (tau, m); otherwise it falls back to its a-priori value (q = j / 4, gain = 2) or keeps the last measurement."""
+
+    ACCEPT = 1.4   # a sub-step is accepted when its scaled error omega does not exceed this
+
+    def __init__(self, horizon: float, tol: float, m: int, mmin: int, mmax: int):
+        self.horizon, self.tol, self.mmin, self.mmax = horizon, tol, mmin, mmax
+        self.tau, self.m = horizon, m
+        self.prev_tau, self.prev_m = math.nan, -1
+        self.omega = math.nan
+        self.order, self.gain = 1.0, 2.0
+        self.order_apriori = self.gain_apriori = True
+        # target for the scaled error of the next attempt (and the stricter one used when the basis is full)
+        self.target, self.target_full = (0.2, 0.1) if horizon > 1 else (0.9, 0.6)
+        self.retries = 0   # rejected attempts of the current sub-step
+
+    def scaled_error(self, err: float) -> float:
+        return self.horizon * err / (self.tau * self.tol)
+
+    def _measure(self, omega: float, last: float, j: int):
+        tau, m, ptau, pm, retried = self.tau, self.m, self.prev_tau, self.prev_m, self.retries >= 1
+        if retried and m == pm and tau != ptau:        # same basis, other step: the order shows
+            q = _log(omega / last) / _log(tau / ptau) if last > 0 else math.nan
+            self.order = max(1.0, q) if q == q and q != math.inf else 1.0
+            self.order_apriori = False
+        else:
+            if self.order_apriori or not retried:
+                self.order = j / 4
+            self.order_apriori = True
+        if retried and m != pm and tau == ptau:        # same step, other basis: the gain per vector shows
+            self.gain = max(1.1, (omega / last) ** (1 / (pm - m)))
+            self.gain_apriori = False
+        else:
+            if self.gain_apriori or not retried:
+                self.gain = 2
+            self.gain_apriori = True
+
+    def judge(self, err: float, j: int, t_now: float) -> bool:
+        """Take the error estimate of the attempt (tau, m) that built j vectors; decide acceptance and choose the next
+        attempt.  Returns True when the sub-step is accepted."""
+        last, omega = self.omega, self.scaled_error(err)
+        self.omega = omega
+        self._measure(omega, last, j)
+        tau, m = self.tau, self.m
+        ok = omega <= self.ACCEPT
+        left = self.horizon - (t_now + tau) if ok else self.horizon - t_now   # what the next attempt may cover
+        keep_tau = min(left, tau)
+        best_tau = tau * (self.target / omega) ** (1 / self.order)
+        best_tau = min(left, max(tau / 5, min(5 * tau, best_tau)))
+        best_m = _ceil_clamped(j + _log(omega / self.target) / _log(self.gain), math.floor(3 / 4 * m), math.ceil(4 / 3 * m))
+        best_m = max(self.mmin, min(self.mmax, best_m))
+        if j == self.mmax:          # the basis cannot grow: only the step can answer
+            if ok:
+                nxt = (best_tau, m)
+            else:
+                t = tau * (self.target_full / omega) ** (1 / self.order)
+                nxt = (min(self.horizon - t_now, max(tau / 5, t)), j)
+        else:                       # KIOPS: change the basis size, keep the step
+            nxt = (keep_tau, best_m)
+        self._advance(nxt, ok)
+        return ok
+
+    def breakdown(self, t_now: float) -> bool:
+        """Happy breakdown: the Krylov space is invariant, the attempt is exact; same basis, no larger step."""
+        self.omega = 0.0
+        self._advance((min(self.horizon - (t_now + self.tau), self.tau), self.m), True)
+        return True
+
+    def _advance(self, nxt, accepted: bool):
+        self.prev_tau, self.prev_m = self.tau, self.m
+        self.tau, self.m = nxt[0], int(nxt[1])
+        self.retries = 0 if accepted else self.retries + 1
+
+
 class KiopsWorkspace:
     """Buffers of kiops that survive from one call to the next (basis, Hessenberg columns, the augmented-part operators)
     and the HIP graphs of its Krylov passes.  A pass - the vectors j0+1 .. m built back to back with no host
@@ -541,7 +621,7 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
         t = _allreduce(basis.dots(lo, hi, Vd[j, :n]), group)
         return torch.addmv(t, Vd[lo:hi, n:], Vd[j, n:], out=out)
 
-    step = krystep = ireject = reject = exps = 0
+    step = krystep = reject = exps = 0
     sgn = math.copysign(1.0, tau_out[-1])
     tau_now, tau_end = 0.0, abs(tau_out[-1])
     happy = False
@@ -558,12 +638,7 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
         nu = mu = 1.0
     u_flip_t, shift = ws.u_flip_t, ws.shift
     u_flip_t.copy_((nu * torch.flipud(u[1:])).t())
-    tau = tau_end
-    gamma, gamma_mmax = (0.2, 0.1) if tau_end > 1 else (0.9, 0.6)
-    delta = 1.4
-    oldm, oldtau, omega = -1, math.nan, math.nan
-    orderold = kestold = True
-    order, kest = 1.0, 2.0
+    ctl = _SubstepControl(tau_end, tol, m, mmin, mmax)
     l = 0
     beta = 1.0
     while tau_now < tau_end:
@@ -616,55 +691,20 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
         H[0, j] = 1.0
         nrm = H[j, j - 1]
         H[j, j - 1] = 0.0
+        tau = ctl.tau
         F = _expm(sgn * tau * H[: j + 1, : j + 1])
         exps += 1
         H[j, j - 1] = nrm
+        retries = ctl.retries
         if happy:
-            omega = 0.0
             err = 0.0
-            tau_new = min(tau_end - (tau_now + tau), tau)
-            m_new = m
+            accepted = ctl.breakdown(tau_now)
             happy = False
         else:
             err = abs(beta * nrm * F[j - 1, j])
-            oldomega = omega
-            omega = tau_end * err / (tau * tol)
-            if m == oldm and tau != oldtau and ireject >= 1:
-                o = _log(omega / oldomega) / _log(tau / oldtau) if oldomega > 0 and tau != oldtau else math.nan
-                order = max(1.0, o) if o == o and o != math.inf else 1.0
-                orderold = False
-            elif orderold or ireject == 0:
-                orderold = True
-                order = j / 4
-            else:
-                orderold = True
-            if m != oldm and tau == oldtau and ireject >= 1:
-                kest = max(1.1, (omega / oldomega) ** (1 / (oldm - m)))
-                kestold = False
-            elif kestold or ireject == 0:
-                kestold = True
-                kest = 2
-            else:
-                kestold = True
-            remaining = tau_end - tau_now if omega > delta else tau_end - (tau_now + tau)
-            same_tau = min(remaining, tau)
-            tau_opt = tau * (gamma / omega) ** (1 / order)
-            tau_opt = min(remaining, max(tau / 5, min(5 * tau, tau_opt)))
-            m_opt = _ceil_clamped(j + _log(omega / gamma) / _log(kest), math.floor(3 / 4 * m), math.ceil(4 / 3 * m))
-            m_opt = max(mmin, min(mmax, m_opt))
-            if j == mmax:
-                if omega > delta:
-                    m_new = j
-                    tau_new = tau * (gamma_mmax / omega) ** (1 / order)
-                    tau_new = min(tau_end - tau_now, max(tau / 5, tau_new))
-                else:
-                    tau_new = tau_opt
-                    m_new = m
-            else:
-                m_new = m_opt
-                tau_new = same_tau
-        if omega <= delta:
-            reject += ireject
+            accepted = ctl.judge(err, j, tau_now)
+        if accepted:
+            reject += retries
             step += 1
             blown = 0
             next_t = tau_now + tau
@@ -680,13 +720,10 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
             w[l] = torch.as_tensor(beta * F[:j, 0], dtype=dtype, device=dev) @ Vd[:j, :n]
             tau_now += tau
             j = 0
-            ireject = 0
             conv += err
         else:
-            ireject += 1
             H[0, j] = 0.0
-        oldtau, tau = tau, tau_new
-        oldm, m = m, int(m_new)
+        m = ctl.m
     if task1:
         for k in range(num_steps):
             w[k] /= tau_out[k]
