@@ -65,6 +65,9 @@
 #define WX_K2_MFMA_SHAPE 4   // 16: v_mfma_f64_16x16x4_f64 (half of each tile is padding for an 8-row operator);
                              //  4: v_mfma_f64_4x4x4_4b_f64 (four 4x4x4 blocks per instruction, no padding: half the pipe time)
 #endif
+#ifndef WX_K2_MF_FB
+#define WX_K2_MF_FB 8   // fields whose operands are in flight together in a matrix-core pass of the fused kernel
+#endif
 #ifndef WX_K2_MFMA_CORR
 #define WX_K2_MFMA_CORR 1 // ... with the two face corrections riding along as a third k-step (D | cm | cp is 8 x 10)
 #endif
@@ -724,16 +727,22 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
     constexpr bool MFC = MF && WX_K2_MFMA_CORR;   // face corrections inside the MFMA (third k-step)
     static_assert(!MF || (EPB == 1 && C::LE == kMfLE), "the MFMA pass owns one n = 8 element per workgroup");
     constexpr int FST = NC * N2 + (MF ? kMfFS - 7 * 64 : 0);   // doubles per face in the face-flux image
-    __shared__ T fld[NF][EPB * C::LE];
-    __shared__ T frs[EPB * 6 * FST];
+    // One LDS block: the field images, then the face-flux image.  Matrix-core path: 7 images suffice - the eighth field
+    // (sqrtG rho, vertical pass only) lands on the face fluxes of the first direction, which are dead by then - and the
+    // operator tables are not needed (they sit in the lanes' MFMA operands): 54.5 KB, three workgroups per CU fit.
+    constexpr int NFI = MF ? 7 : NF;
+    constexpr bool NEED_OPS = !MF || !MFC;
+    __shared__ T smem[NFI * EPB * C::LE + EPB * 6 * FST];
+    T(*fld)[EPB * C::LE] = reinterpret_cast<T(*)[EPB * C::LE]>(smem);
+    T* frs = smem + NFI * EPB * C::LE;
 #define WX_FR(le_, f_, c_, fp_) frs[((le_) * 6 + (f_)) * FST + (c_) * N2 + (fp_)]
-    __shared__ double sD[N * N], sHF[N * N], sCm[N], sCp[N];
-    __shared__ double sEF[PIPE ? N * N : 1];
+    __shared__ double sD[NEED_OPS ? N * N : 1], sHF[NEED_OPS ? N * N : 1], sCm[NEED_OPS ? N : 1], sCp[NEED_OPS ? N : 1];
+    __shared__ double sEF[(PIPE && !MF) ? N * N : 1];
 
     const int tid = threadIdx.x;
     const int H = P.H, V = P.V;
     const size_t fs = (size_t)P.nelem * N3;
-    if (PIPE && P.efilter)
+    if (PIPE && !MF && P.efilter)
         for (int i = tid; i < N * N; i += BS) sEF[i] = P.K->EF[i];
 #if WX_K2_STAMPS
 #define WX_STAMP(i)                                                                           \
@@ -746,13 +755,15 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
 #endif
     WX_STAMP(0);
 
-    for (int i = tid; i < N * N; i += BS) {
-        sD[i] = P.K->D[i];
-        sHF[i] = P.K->HF[i];
-    }
-    if (tid < N) {
-        sCm[tid] = P.K->cm[tid];
-        sCp[tid] = P.K->cp[tid];
+    if (NEED_OPS) {
+        for (int i = tid; i < N * N; i += BS) {
+            sD[i] = P.K->D[i];
+            sHF[i] = P.K->HF[i];
+        }
+        if (tid < N) {
+            sCm[tid] = P.K->cm[tid];
+            sCp[tid] = P.K->cp[tid];
+        }
     }
 
     // ---- point loads first: in flight while the face stage computes
@@ -933,9 +944,9 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
             __syncthreads();
             const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
             if (WX_K2_MFMA_SHAPE == 4) {
-                if (d == 0) mf4_dir_pass<0, MFC>(fm, fq, mops4, wave, tid & 63);
-                else if (d == 1) mf4_dir_pass<1, MFC>(fm, fq, mops4, wave, tid & 63);
-                else mf4_dir_pass<2, MFC>(fm, fq, mops4, wave, tid & 63);
+                if (d == 0) mf4_dir_pass<0, MFC, 7, true, kMfFS, WX_K2_MF_FB>(fm, fq, mops4, wave, tid & 63);
+                else if (d == 1) mf4_dir_pass<1, MFC, 7, true, kMfFS, WX_K2_MF_FB>(fm, fq, mops4, wave, tid & 63);
+                else mf4_dir_pass<2, MFC, 7, true, kMfFS, WX_K2_MF_FB>(fm, fq, mops4, wave, tid & 63);
             } else {
                 if (d == 0) mf_dir_pass<0, MFC>(fm, fq, mops, wave, tid & 63);
                 else if (d == 1) mf_dir_pass<1, MFC>(fm, fq, mops, wave, tid & 63);
@@ -1109,8 +1120,15 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
 #undef WX_FR
 }
 
+#ifndef WX_K2_WAVES_MF
+#define WX_K2_WAVES_MF WX_K2_WAVES   // waves per SIMD requested for the matrix-core instantiation (6 = three workgroups per CU)
+#endif
+template <int N, typename T>
+constexpr int k2_waves() {
+    return is_complex<T>::value ? 2 : ((N == 8 && std::is_same<T, double>::value && WX_K2_MFMA) ? WX_K2_WAVES_MF : WX_K2_WAVES);
+}
 template <int N, typename T, bool PIPE>
-__global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES)) void euler_rhs_kernel(const EulerParams<T> P) {
+__global__ __launch_bounds__(Cfg<N>::BS, (k2_waves<N, T>())) void euler_rhs_kernel(const EulerParams<T> P) {
     euler_rhs_body<N, T, PIPE>(P);
 }
 
