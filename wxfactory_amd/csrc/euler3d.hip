@@ -65,6 +65,9 @@
 #define WX_K2_MFMA_SHAPE 4   // 16: v_mfma_f64_16x16x4_f64 (half of each tile is padding for an 8-row operator);
                              //  4: v_mfma_f64_4x4x4_4b_f64 (four 4x4x4 blocks per instruction, no padding: half the pipe time)
 #endif
+#ifndef WX_K2_FACE_FIRST
+#define WX_K2_FACE_FIRST 1
+#endif
 #ifndef WX_K2_MF_FB
 #define WX_K2_MF_FB 8   // fields whose operands are in flight together in a matrix-core pass of the fused kernel
 #endif
@@ -794,6 +797,16 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
         h11 = WX_LDM(P.h + 4 * fs + o); h12 = WX_LDM(P.h + 5 * fs + o); h22 = WX_LDM(P.h + 8 * fs + o);    \
     }
 #define WX_POINT_LOADS() WX_Q_LOADS() WX_PMETRIC_LOADS()
+    // n = 8: one face point per thread (384 of 512).  WX_K2_FACE_FIRST issues the face loads BEFORE the point loads:
+    // vector-memory results return in issue order, so the face stage (the first consumer) no longer waits for the
+    // twelve point loads queued in front of its own fourteen
+    constexpr bool FACE_FIRST = WX_K2_FACE_FIRST && N == 8 && EPB == 1 && WX_K2_EARLY_LOADS;
+    FaceIn<T> fin_first;
+    int ff_first = 0;
+    if constexpr (FACE_FIRST) {
+        ff_first = __builtin_amdgcn_readfirstlane(tid / N2);
+        if (tid < 6 * N2 && el.valid) face_load<N, T>(P, el, ff_first, tid % N2, fin_first);
+    }
 #if WX_K2_EARLY_LOADS
     WX_POINT_LOADS()
 #endif
@@ -816,7 +829,15 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
 #endif
 
     // ---- face stage: Riemann problems of all 6 faces of the block's elements -> LDS
-    for (int fi = tid; fi < EPB * 6 * N2; fi += BS) {
+    if constexpr (FACE_FIRST) {
+        if (tid < 6 * N2 && el.valid) {
+            T out[NC];
+            face_flux<T, WX_K2_OWN_FORM != 0>(fin_first, ff_first, P.advection_only, out);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) WX_FR(0, ff_first, c, tid % N2) = out[c];
+        }
+    }
+    for (int fi = tid; fi < (FACE_FIRST ? 0 : EPB * 6 * N2); fi += BS) {
         const int le = fi / (6 * N2);
         const int r = fi % (6 * N2);
         int f = r / N2;
