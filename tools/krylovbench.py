@@ -65,13 +65,14 @@ if "fgmres" in sys.argv[1:]:
         return orig(self, lo, hi, w, out=out)
 
     solvers._Basis.dots = counting
-    for label, eta in (("warm-up", solvers._REORTH), ("second pass on cancellation", solvers._REORTH),
-                       ("second pass always", 1e30)):
+    for label, eta, ortho in (("warm-up", solvers._REORTH, "cgs"), ("cgs, second pass on cancellation", solvers._REORTH, "cgs"),
+                              ("cgs, second pass always", 1e30, "cgs"), ("igs warm-up", 0.1, "igs"),
+                              ("igs: the reference's one-synchronisation Gram-Schmidt (default)", 0.1, "igs")):
         solvers._REORTH = eta
         calls[0] = 0
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        x, nr, nb, it, flag, res = fgmres(A, b, x0=Q.flatten(), tol=1e-30, restart=20, maxiter=1)
+        x, nr, nb, it, flag, res = fgmres(A, b, x0=Q.flatten(), tol=1e-30, restart=20, maxiter=1, ortho=ortho)
         torch.cuda.synchronize()
         t = time.perf_counter() - t0
         print(f"fgmres restart 20, {label}: {it} iterations, {calls[0]} dot sweeps, {t*1e3:.0f} ms = {t/it*1e3:.1f} ms "

@@ -44,11 +44,18 @@ def matvec_fun(vec: torch.Tensor, dt: float, Q: torch.Tensor, rhs: torch.Tensor,
     return jac.flatten()
 
 
-def matvec_rat(vec: torch.Tensor, dt: float, Q: torch.Tensor, rhs: torch.Tensor, rhs_handle: Callable) -> torch.Tensor:
+def matvec_rat(vec: torch.Tensor, dt: float, Q: torch.Tensor, rhs: torch.Tensor, rhs_handle: Callable,
+               scale: float = 1.0, out=None) -> torch.Tensor:
+    """scale != 1: matvec_rat(vec / scale) * scale - what fgmres' lagged normalisation asks for (solvers/fgmres.py:172:
+    `A(Z / v_norm) * v_norm`; not the same as matvec_rat(vec) for a finite-difference operator) - with the two
+    scalings folded into the shift and the store coefficients of the fused kernels instead of two passes over the vector."""
     if _can_shift(rhs_handle, Q):
         v = vec.reshape(Q.shape).contiguous()
-        c = 0.5 * dt / EPS_FD
-        return rhs_handle.shifted_axpy(Q, v, EPS_FD, v, 1.0, 0.0, -c, rhs.reshape(Q.shape).contiguous(), c).flatten()
+        c = 0.5 * dt / EPS_FD * scale
+        return rhs_handle.shifted_axpy(Q, v, EPS_FD / scale, v, 1.0, 0.0, -c, rhs.reshape(Q.shape).contiguous(), c,
+                                       out=out).flatten()
+    if scale != 1.0:
+        return matvec_rat(vec / scale, dt, Q, rhs, rhs_handle) * scale
     if getattr(rhs_handle, "supports_axpy2", False) and isinstance(Q, torch.Tensor) and Q.dtype == torch.float64:
         # v - dt/(2 eps) (R(Q + eps v) - R(Q)) formed in the RHS kernel's store
         v = vec.reshape(Q.shape)
@@ -95,6 +102,8 @@ class MatvecOpRat(MatvecOp):
 
     def __init__(self, dt, Q, rhs_vec, rhs_handle):
         super().__init__(lambda vec: matvec_rat(vec, dt, Q, rhs_vec, rhs_handle), Q.dtype, Q.shape)
+        # A(vec / s) * s without passes over the vector for the scalings (used by fgmres' lagged normalisation)
+        self.scaled = lambda vec, s, out=None: matvec_rat(vec, dt, Q, rhs_vec, rhs_handle, scale=s, out=out)
 
 
 class MatvecOpBasic(MatvecOp):

@@ -429,7 +429,7 @@ class RhsEuler3D(PanelRhs):
     supports_shift = True
 
     def shifted_axpy(self, Q: torch.Tensor, v: torch.Tensor, eps: float, Y, a: float, b: float, c: float, Z=None,
-                     d: float = 0.0) -> torch.Tensor:
+                     d: float = 0.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """a*Y + b*(Q + eps v) + c*R(Q + eps v) + d*Z for stacked real states; Q + eps v is formed inside the
         kernels (the finite-difference Jacobian products of solvers/matvec.py:62-66, 76-88 in two launches per
         panel and no pass over the state besides them)."""
@@ -439,7 +439,11 @@ class RhsEuler3D(PanelRhs):
         Ys = Y.reshape(shp) if Y is not None else None
         Zs = Z.reshape(shp) if Z is not None else None
         plans, ex = self.plans_for(torch.float64), self.exchange_for(torch.float64)
-        out = torch.empty_like(Qs)
+        if out is not None and out.is_contiguous() and out.numel() == Qs.numel() and out.dtype == Qs.dtype \
+                and out.data_ptr() not in (Q.data_ptr(), v.data_ptr()):
+            out = out.view(shp)   # the caller's storage (a row of a Krylov basis): no copy afterwards
+        else:
+            out = torch.empty_like(Qs)
         if self._small_tiles() and all(t is None or t.is_contiguous() for t in (Q, v, Y, Z)):
             bt = self._batch_for(torch.float64, plans, ex)
             bt.extrap_pack(Qs, vs, eps)

@@ -308,6 +308,7 @@ def _fgmres_low_sync(A, b, x0, tol, restart, maxiter, preconditioner, verbose, g
     V = torch.empty((restart + 2, n), dtype=b.dtype, device=b.device)
     Z = torch.empty((restart + 1, n), dtype=b.dtype, device=b.device) if preconditioner is not None else None
     basis = _Basis(V)
+    scaled = getattr(A, "scaled", None)
     for _outer in range(maxiter):
         gs = _LowSyncGramSchmidt(basis, restart + 2, group)
         Hm = [[0.0] * (restart + 2) for _ in range(restart)]   # Hm[j][i] = h_{i,j} after the rotations
@@ -327,8 +328,13 @@ def _fgmres_low_sync(A, b, x0, tol, restart, maxiter, preconditioner, verbose, g
             zj = preconditioner(V[j + 1]) if Z is not None else V[j + 1]
             if Z is not None:
                 Z[j + 1] = zj
-            w = A(zj / v_norm)
-            torch.mul(w, v_norm, out=V[j + 2])
+            if scaled is not None:
+                w = scaled(zj, v_norm, out=V[j + 2])   # A(zj / v_norm) * v_norm, scalings folded into the kernels,
+                if w.data_ptr() != V[j + 2].data_ptr():  # written straight into the basis row when the operator can
+                    V[j + 2] = w
+            else:
+                w = A(zj / v_norm)
+                torch.mul(w, v_norm, out=V[j + 2])
             v_norm = gs.step(j + 3)
             if Z is not None:
                 Z[j + 1] /= v_norm
