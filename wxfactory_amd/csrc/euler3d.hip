@@ -652,8 +652,14 @@ __device__ __forceinline__ void face_load(const EulerParams<T>& P, const Elem& e
     if (!split) {
 #pragma unroll
         for (int v = 0; v < 5; ++v) {
+#ifdef WX_K2_FAKE_OWN   /* diagnostic build (wrong results): the own-side face values are never loaded - what the kernel
+                           would gain, in time and in HBM bytes, if they came for free */
+            in.qn[v] = nbr[v * nstride];
+            in.qo[v] = in.qn[v] * 1.0000001;
+#else
             in.qo[v] = own[v * N2];
             in.qn[v] = nbr[v * nstride];
+#endif
         }
     }
     in.sg = *sgp; in.h0 = hp[0]; in.h1 = hp[hfs]; in.h2 = hp[2 * hfs];
