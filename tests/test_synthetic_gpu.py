@@ -204,3 +204,34 @@ def test_checkpoint_round_trip_from_device_tensors(tmp_path):
     assert version == "v" and "equations = Euler" in config
     again = distribute_cube(state, tiles_per_side=2, device=dev)
     assert again.is_cuda and torch.equal(again, tiles24)
+
+
+@pytest.mark.parametrize("n,H,V", [(3, 1, 1), (4, 2, 1), (8, 1, 2)])
+def test_prepared_jvp_on_ragged_tiles(n, H, V):
+    """The prepared complex-step JVP (face values cached, tangents per product) on the smallest tiles - every lateral
+    face a halo (H = 1), every vertical face a wall (V = 1) - equals the unprepared one bit for bit."""
+    from wxfactory_amd.geometry3d import CubedSphere3DTile, metric3d_torch
+    from wxfactory_amd.initial import initial_state
+    from wxfactory_amd.matvec import matvec_fun
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D
+    from wxfactory_amd.synthetic import dfr_ops
+
+    dev = "cuda:0"
+    plans, qs = {}, []
+    gen = torch.Generator(device=dev).manual_seed(5)
+    for p in range(6):
+        t = CubedSphere3DTile(n, H, V, p, 10000.0, 31)
+        plans[p] = Euler3DPlan(n, H, V, 31, p, dfr_ops(n), metric3d_torch(t, dev))
+        q = torch.from_numpy(np.array(initial_state(t))).to(dev)
+        qs.append(q * (1.0 + 0.01 * (torch.rand(q.shape, generator=gen, device=dev, dtype=q.dtype) - 0.5)))
+    Q = torch.stack(qs)
+    rhs = RhsEuler3D(plans)
+    rhs.batched = False   # per-tile launches: the path the prepared JVP lives on
+    R = rhs(Q)
+    v = (torch.rand(Q.shape, generator=gen, device=dev, dtype=Q.dtype) - 0.5) * Q.abs().amax(dim=(0, 2, 3, 4, 5), keepdim=True)
+    plain = matvec_fun(v.flatten(), 2.0, Q, R, rhs, "complex")
+    assert rhs.jvp_prepare(Q)
+    prepared = matvec_fun(v.flatten(), 2.0, Q, R, rhs, "complex")
+    rhs.jvp_release()
+    assert torch.isfinite(plain).all() and float(plain.abs().max()) > 0
+    assert torch.equal(plain, prepared)

@@ -598,13 +598,13 @@ __device__ __forceinline__ void face_load(const EulerParams<T>& P, const Elem& e
         const T* own = P.itf + ((size_t)el.e * 6 + f) * NQ * N2 + fp;
         const T* nbr;
         size_t nstride = N2;
-        bool mirror = false;
+        bool mirror = false, from_halo = false;
         const double *sgp, *hp;
         size_t hfs;  // field stride of the h_contra_itf array
         if (d == 0) {
             const int ne = el.ei + (plus ? 1 : -1);
             if (ne >= 0 && ne < H) nbr = P.itf + ((size_t)(el.e + (plus ? 1 : -1)) * 6 + (f ^ 1)) * NQ * N2 + fp;
-            else { nbr = (plus ? P.halo_e : P.halo_w) + ((size_t)el.ek * H + el.ej) * N2 + fp; nstride = vsh; }
+            else { nbr = (plus ? P.halo_e : P.halo_w) + ((size_t)el.ek * H + el.ej) * N2 + fp; nstride = vsh; from_halo = true; }
             const size_t o = (((size_t)el.ek * H + el.ej) * (H + 2) + el.ei + 1) * 2 * N2 + plus * N2 + fp;
             hfs = (size_t)V * H * (H + 2) * 2 * N2;
             sgp = P.sgi + o;
@@ -612,7 +612,7 @@ __device__ __forceinline__ void face_load(const EulerParams<T>& P, const Elem& e
         } else if (d == 1) {
             const int ne = el.ej + (plus ? 1 : -1);
             if (ne >= 0 && ne < H) nbr = P.itf + ((size_t)(el.e + (plus ? H : -H)) * 6 + (f ^ 1)) * NQ * N2 + fp;
-            else { nbr = (plus ? P.halo_n : P.halo_s) + ((size_t)el.ek * H + el.ei) * N2 + fp; nstride = vsh; }
+            else { nbr = (plus ? P.halo_n : P.halo_s) + ((size_t)el.ek * H + el.ei) * N2 + fp; nstride = vsh; from_halo = true; }
             const size_t o = (((size_t)el.ek * (H + 2) + el.ej + 1) * H + el.ei) * 2 * N2 + plus * N2 + fp;
             hfs = (size_t)V * (H + 2) * H * 2 * N2;
             sgp = P.sgj + o;
@@ -635,7 +635,7 @@ __device__ __forceinline__ void face_load(const EulerParams<T>& P, const Elem& e
             const size_t oo = (size_t)(own - P.itf);
             const double *ov = P.fv + oo, *ot = P.ft + oo, *nv, *nt;
             if (mirror) { nv = ov; nt = ot; }
-            else if (nstride == (size_t)N2) { const size_t no = (size_t)(nbr - P.itf); nv = P.fv + no; nt = P.ft + no; }
+            else if (!from_halo) { const size_t no = (size_t)(nbr - P.itf); nv = P.fv + no; nt = P.ft + no; }
             else {
                 const T* hb = d == 0 ? (plus ? P.halo_e : P.halo_w) : (plus ? P.halo_n : P.halo_s);
                 const double* hvb = d == 0 ? (plus ? P.hv_e : P.hv_w) : (plus ? P.hv_n : P.hv_s);
