@@ -130,6 +130,87 @@ class _CpuPlan:
         out.copy_(torch.from_numpy(self.o.rhs(q.numpy(), h5, itf=self.itf)))
 
 
+class _CpuJvpPlan(_CpuPlan):
+    """... plus the prepared complex-step JVP interface (jvp_prepare / jvp_tangent_pack / jvp_prepared) and twin(), so that
+    RhsEuler3D.jvp_prepare / jvp can be driven over gloo: value halos exchanged once, tangent halos per product."""
+
+    def twin(self, dtype, dual=False):
+        return self
+
+    def jvp_prepare(self, q, send_val):
+        self.itf_val = self.o.extrapolate(q.numpy())
+        for e, s_ in enumerate(self.o.pack_edges(self.itf_val)):
+            send_val[e].copy_(torch.from_numpy(np.ascontiguousarray(s_).reshape(-1)))
+        self.calls.append("prepare")
+
+    def jvp_tangent_pack(self, q, v, eps, send_tan):
+        self.itf_c = self.o.extrapolate(q.numpy() + 1j * eps * v.numpy())
+        for d in range(3):   # the cached values are what the product uses for the real parts
+            assert np.abs(self.itf_c[d].real - self.itf_val[d]).max() <= 1e-13 * np.abs(self.itf_val[d]).max()
+        for e, s_ in enumerate(self.o.pack_edges(self.itf_c)):
+            send_tan[e].copy_(torch.from_numpy(np.ascontiguousarray(s_.imag).reshape(-1)))
+        self.calls.append("tangent_pack")
+
+    def jvp_prepared(self, q, v, eps, halo_val, halo_tan, out, scale, region=0):
+        self.calls.append(("jvp", region))
+        if region == 1:
+            return
+        shp = (5, self.g.V, self.g.H, self.g.n**2)
+        halos = [hv.numpy().reshape(shp) + 1j * ht.numpy().reshape(shp) for hv, ht in zip(halo_val, halo_tan)]
+        R = self.o.rhs(q.numpy() + 1j * eps * v.numpy(), halos, itf=self.itf_c)
+        out.copy_(torch.from_numpy(scale * R.imag))
+
+
+def _jvp_worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from wxfactory_amd.panels import panels_of_rank
+        from wxfactory_amd.rhs_euler3d import RhsEuler3D
+
+        g = golden("euler3d_c31p_n3_h4_v2")
+        mine = panels_of_rank(rank, world)
+        plans = {p: _CpuJvpPlan(g, p) for p in mine}
+        rhs = RhsEuler3D(plans, rank=rank, world_size=world, device="cpu", edge_count=5 * g.V * g.H * g.n**2)
+        rhs.batched = False
+        shp = (len(mine), 5, g.V, g.H, g.H, g.n**3)
+        Q = torch.from_numpy(np.stack([g.q(p) for p in mine])) if mine else torch.zeros((0,) + shp[1:], dtype=torch.float64)
+        V = torch.from_numpy(np.stack([g[f"p{p}/V"] for p in mine])) if mine else torch.zeros_like(Q)
+        assert rhs.jvp_prepare(Q)   # collective: value faces exchanged once
+        for rep in range(2):        # two products on the prepared state: tangents only
+            out = rhs.jvp(Q, V, g.eps, 1.0 / g.eps)
+            for i, p in enumerate(mine):
+                ref = g.r(p, True).imag / g.eps
+                err = np.abs(out[i].numpy() - ref).max(axis=(1, 2, 3, 4)) / np.abs(ref).max(axis=(1, 2, 3, 4))
+                assert (err < 1e-9).all(), (rank, p, rep, err)
+        for p in mine:
+            assert plans[p].calls == ["prepare"] + ["tangent_pack", ("jvp", 1), ("jvp", 2)] * 2, plans[p].calls
+        rhs.jvp_release()
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, traceback.format_exc()))
+        raise
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_prepared_jvp_orchestration_over_gloo(world):
+    """RhsEuler3D.jvp_prepare + jvp across ranks (whole panels on 2 ranks; 8 ranks, two of them idle): the value halos
+    travel once, the tangent halos once per product through their own exchange, interior before boundary, and the
+    product equals the reference's complex-step R (CPU test double of the plan, gloo)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_jvp_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=240) for _ in range(world)]
+    [p.join(timeout=60) for p in procs]
+    assert all(r[1] == "ok" for r in res), [r for r in res if r[1] != "ok"]
+
+
 def _rhs_worker(rank, world, port, q):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))

@@ -389,11 +389,17 @@ class RhsEuler3D(PanelRhs):
             words = self.edge_count * (2 if dtype.is_complex else 1)
             st["ex"][1] = PanelExchange(words, self.device, rank=self.rank, world_size=self.world, group=self.group,
                                         loopback=st["ex"][0].loopback, tiles_per_side=self.tiles_per_side)
+        cur = st["slot"]
+        ex, exn = st["ex"][cur], st["ex"][1 - cur]
+        if not self.panels:   # a rank that owns no tile: the exchange of this stage, and the same slot flip as the others
+            if ex.needs_comm:
+                ex.start()
+                ex.wait()
+            st["slot"] = 1 - cur
+            return torch.empty_like(Q)
         Qs = Q.reshape((np_,) + tuple(self.panel_shape))
         Ys = Y.reshape((np_,) + tuple(self.panel_shape)) if Y is not None else None
         out = torch.empty_like(Qs)
-        cur = st["slot"]
-        ex, exn = st["ex"][cur], st["ex"][1 - cur]
         last = st["ready"][0]() if st["ready"] is not None else None  # alive => its storage was not recycled
         epochs = lambda: tuple(plans[p].faces_epoch for p in self.panels)  # noqa: E731
         reuse = last is Q and st["ready"][1:] == (Q.data_ptr(), Q._version, Q.numel(), epochs())
@@ -434,6 +440,12 @@ class RhsEuler3D(PanelRhs):
         kernels (the finite-difference Jacobian products of solvers/matvec.py:62-66, 76-88 in two launches per
         panel and no pass over the state besides them)."""
         np_ = len(self.panels)
+        if not self.panels:   # a rank that owns no tile only takes part in the exchange
+            ex = self.exchange_for(torch.float64)
+            if ex.needs_comm:
+                ex.start()
+                ex.wait()
+            return torch.empty_like(Q)
         shp = (np_,) + tuple(self.panel_shape)
         Qs, vs = Q.reshape(shp), v.reshape(shp)
         Ys = Y.reshape(shp) if Y is not None else None
@@ -491,22 +503,32 @@ class RhsEuler3D(PanelRhs):
         exchanges only tangents (wx_euler3d_jvp_prepare).  Holds until jvp_release(), another jvp_prepare(), or a jvp()
         with a different or modified Q (then the unprepared path runs).  Large tiles only (small ones take the batched
         launches); collective like an evaluation."""
-        if self._small_tiles() or not (Q.is_cuda and Q.dtype == torch.float64 and Q.is_contiguous()) or not self.panels:
+        dev = torch.device(self.device) if self.device is not None else Q.device
+        can = 1   # a rank that owns no tile goes along with the others
+        if self.panels:
+            can = int(not self._small_tiles() and Q.device.type == dev.type and Q.dtype == torch.float64 and Q.is_contiguous())
+        if self.world > 1:   # one decision for all ranks: the value exchange below is collective
+            import torch.distributed as dist
+
+            flag = torch.tensor([can], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            can = int(flag.item())
+        if not can:
             self._jvp_lin = None
             return False
-        np_ = len(self.panels)
-        Qs = Q.reshape((np_,) + tuple(self.panel_shape))
-        plans = self._jvp_plans()
         if getattr(self, "_ex_val", None) is None:
             mk = lambda: PanelExchange(self.edge_count, self.device, rank=self.rank, world_size=self.world, group=self.group,  # noqa: E731
                                        tiles_per_side=self.tiles_per_side)
             self._ex_val, self._ex_tan = mk(), mk()
         ex = self._ex_val
-        for i, p in enumerate(self.panels):
-            plans[p].jvp_prepare(Qs[i], ex.send_views(p))
+        if self.panels:
+            Qs = Q.reshape((len(self.panels),) + tuple(self.panel_shape))
+            plans = self._jvp_plans()
+            for i, p in enumerate(self.panels):
+                plans[p].jvp_prepare(Qs[i], ex.send_views(p))
         ex.start()
         ex.wait()
-        self._jvp_lin = (weakref.ref(Q), Q.data_ptr(), Q._version)
+        self._jvp_lin = (weakref.ref(Q), Q.data_ptr(), Q._version) if self.panels else ("idle",)
         return True
 
     def jvp_release(self):
@@ -514,13 +536,23 @@ class RhsEuler3D(PanelRhs):
 
     def _jvp_is_prepared(self, Q) -> bool:
         lin = getattr(self, "_jvp_lin", None)
-        return lin is not None and lin[0]() is Q and lin[1:] == (Q.data_ptr(), Q._version)
+        if lin is None:
+            return False
+        if lin[0] == "idle":
+            return True
+        return lin[0]() is Q and lin[1:] == (Q.data_ptr(), Q._version)
 
     def jvp(self, Q: torch.Tensor, v: torch.Tensor, eps: float, scale: float) -> torch.Tensor:
         """scale * Im R(Q + i eps v) for stacked real Q, v -> real tensor shaped like Q.  The dual state is
         formed inside the kernels and only the tangent is stored: the complex-step JVP of
         solvers/matvec.py:56-61 without a complex array in HBM."""
         np_ = len(self.panels)
+        if not self.panels:   # a rank that owns no tile only takes part in the exchange of the product
+            ex = self._ex_tan if self._jvp_is_prepared(Q) else self.exchange_for(torch.complex128)
+            if ex.needs_comm:
+                ex.start()
+                ex.wait()
+            return torch.empty_like(Q)
         Qs = Q.reshape((np_,) + tuple(self.panel_shape))
         vs = v.reshape((np_,) + tuple(self.panel_shape))
         plans = self._jvp_plans()
