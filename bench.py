@@ -367,6 +367,14 @@ def caller_extras(rhs, qs, reps=5):
     def step():
         state["q"] = stepper.step(state["q"], 1e-3)
 
+    # 424 B/point compulsory for a complex-step / dual JVP (Q, v, Jv, 35 static fields, interface metric);
+    # minus 72 B/point where the plan skips the nine identically-zero rotation Christoffel fields
+    pts = Q.numel() // 5
+    bpp = 424.0 - (384.0 - next(iter(rhs.plans.values())).bytes_per_point)
+    gbs = bpp * pts / (out["matvec_fun_complex_prepared_ms"] * 1e-3) / 1e9
+    out["matvec_roofline"] = {"bound": "hbm", "what": "whole-sphere prepared complex-step matvec (tangent extrapolation + JVP kernel, "
+                              "6 panels)", "algorithmic_bytes_per_point": bpp, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
     out["tvdrk3_step_ms"] = timeit(step)
     out["tvdrk3_mode"] = "pipelined" if stepper.pipeline else ("fused" if stepper.fused else "plain")
     out["note"] = ("whole sphere, same plans as the headline: complex-step JVP = fused dual-number kernels (wx_euler3d_jvp), "
