@@ -423,6 +423,9 @@ def main():
     ap.add_argument("--whole-panels", action="store_true", help="one tile per panel even when 6 does not divide N")
     ap.add_argument("--tiles-per-side", type=int, default=0, help="force k (6 k^2 tiles); default: chosen from N")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary (shallow-water S7) measurement")
+    ap.add_argument("--loopback", action="store_true",
+                    help="rehearsal on one GPU: route every edge message through the RCCL collective (1-rank group) and split "
+                         "the evaluation into INTERIOR / BOUNDARY launches, as a multi-GPU run does")
     ap.add_argument("--metric", choices=("true", "synthetic"), default="true",
                     help="static metric fields: the cubed-sphere metric of the DCMIP 3-1 planet from wxfactory_amd.geometry3d "
                          "(default, SURVEY 8d) or SURVEY's seeded synthetic fields; values do not affect speed")
@@ -444,9 +447,14 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.loopback:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from wxfactory_amd import _lib, synthetic
     from wxfactory_amd.exchange import PanelExchange
@@ -476,7 +484,7 @@ def main():
         qs[t] = synthetic.euler3d_state(n, Ht, V, t, dev, args.seed)
     t_setup = time.perf_counter() - t_setup
     edge_doubles = 5 * V * Ht * n * n  # WX_EULER3D_EDGE_FIELDS
-    ex = PanelExchange(edge_doubles, dev, rank=rank, world_size=world, tiles_per_side=k)
+    ex = PanelExchange(edge_doubles, dev, rank=rank, world_size=world, tiles_per_side=k, loopback=args.loopback)
     rhs = RhsEuler3D(plans, ex, overlap=not args.no_overlap)
 
     # live timing of the dominant kernel: HIP events on the launch stream around every K2 launch
@@ -624,7 +632,7 @@ def main():
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, V, args.seed)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or args.loopback:
         dist.destroy_process_group()
 
 
