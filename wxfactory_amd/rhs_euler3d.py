@@ -310,8 +310,10 @@ class RhsEuler3D(PanelRhs):
     supports_jvp = True
     supports_pipeline = True
     batched = True  # stacked states of several SMALL tiles: one launch per phase for all of them (Euler3DBatch)
-    batch_max_points = 2_000_000  # per tile; above this a launch is far from launch-bound and per-tile launches
-    #                               keep each tile's streams together (E7: 8.47 vs 8.70 ms per stage)
+    batch_max_points = 4_000_000  # per tile.  Whole E7 panels (14.7 M points) are faster launched one by one (7.07 vs 7.16 ms
+    #                               per sphere, 7.01 vs 7.31 ms with the INTERIOR / BOUNDARY split); the 3.7 M-point tiles of the
+    #                               24-tile layout are not (7.13 vs 7.08 ms, and 7.39 vs 7.14 ms with the split: one ring launch
+    #                               for all local tiles instead of one of 928 workgroups per tile) - tools/tilebench.py
 
     def _run(self, qs, ys, coef, dtype, zs=None):
         np_ = len(self.panels)
