@@ -201,6 +201,26 @@ def test_rccl_exchange_path_on_one_gpu():
         torch.cuda.synchronize()
         scale = P3.abs().amax(dim=(0, 2, 3, 4, 5), keepdim=True)
         assert ((Q3 - P3).abs() <= 1e-14 * scale).all()
+        # a rank's tiles stacked in one tensor: ONE launch per phase for all of them (what the ranks of a 4- or 8-GPU run
+        # do with their 24-tile layout), the collective between the INTERIOR and the BOUNDARY launch
+        shared = RhsEuler3D(plans, ex, overlap=True)
+        assert shared._small_tiles()
+        c = shared(Q)
+        torch.cuda.synchronize()
+        assert all(torch.equal(c[i], b[p]) for i, p in enumerate(range(6)))
+        # the prepared complex-step JVP over the collective: value halos once, tangent halos per product
+        from wxfactory_amd.matvec import matvec_fun
+
+        R = plain(Q)
+        v = to_dev(np.stack([g[f"p{p}/V"] for p in range(6)]))
+        for r_ in (piped, plain):
+            r_.batched = False
+        j_plain = matvec_fun(v.flatten(), 1.0, Q, R, plain, "complex")
+        assert piped.jvp_prepare(Q)
+        j_coll = matvec_fun(v.flatten(), 1.0, Q, R, piped, "complex")
+        piped.jvp_release()
+        torch.cuda.synchronize()
+        assert torch.equal(j_plain, j_coll)
     finally:
         dist.destroy_process_group()
 
