@@ -136,6 +136,19 @@ wx_status wx_euler3d_plan_destroy(wx_euler3d_plan* plan);
  * they are identically zero (non-rotating planets: DCMIP 2-x / 3-1), the kernels never read them (312 B). */
 double wx_euler3d_bytes_per_point(const wx_euler3d_plan* plan);
 
+/* Which engine the derivative-matrix x nodal-field contractions (geometry/operators.py:157-183 in sum-factorised
+ * form) of a launch on this plan run on: 1 = the matrix cores (v_mfma_f64_4x4x4_4b_f64), 0 = the vector pipe, < 0 on
+ * a bad argument.  A compile-time property of the instantiation the library selects for (n, dtype, kernel); the parity
+ * tests assert it so that "the matrix-core kernels are pinned to the reference" is a checked statement. */
+typedef enum {
+    WX_KERNEL_RHS = 0,       /* wx_euler3d_rhs / _rhs_axpy* / _shifted_rhs_axpy2 */
+    WX_KERNEL_STAGE = 1,     /* wx_euler3d_stage with prepare_next != 0 (incl. the fused exponential filter) */
+    WX_KERNEL_JVP = 2,       /* wx_euler3d_jvp / _jvp_prepared */
+    WX_KERNEL_BATCH_RHS = 3, /* wx_euler3d_batch_rhs_axpy2 */
+    WX_KERNEL_BATCH_JVP = 4  /* wx_euler3d_batch_jvp / _batch_kiops_vector */
+} wx_kernel;
+int wx_euler3d_uses_matrix_cores(const wx_euler3d_plan* plan, wx_kernel kernel);
+
 /* Number of ELEMENTS of dtype in one edge message: 5*V*H*n^2, layout [var][ek][along][n^2] =
  * exactly the reference's q_itf_{s,n,w,e} after ExchangeRequest.wait(). */
 size_t wx_euler3d_edge_count(const wx_euler3d_plan* plan);
@@ -369,6 +382,8 @@ wx_status wx_cart2d_rhs(wx_cart2d_plan* plan, const void* q, void* rhs, wx_strea
 typedef struct wx_expfilter wx_expfilter;
 wx_status wx_expfilter_create(wx_expfilter** out, int n, const double* filter);
 wx_status wx_expfilter_destroy(wx_expfilter* h);
+/* 1 when wx_expfilter_apply* of this dtype runs its three passes on the matrix cores (see wx_euler3d_uses_matrix_cores) */
+int wx_expfilter_uses_matrix_cores(const wx_expfilter* h, wx_dtype dtype);
 wx_status wx_expfilter_apply(const wx_expfilter* h, const void* q, void* out, const double* sqrtG, int nvar, size_t nelem,
                              wx_dtype dtype, int* nan_flag, wx_stream stream);
 /* The same filter on npanels stacked panels in one launch: q, out (npanels, nvar, nelem, n^3), sqrtG (npanels, nelem, n^3). */

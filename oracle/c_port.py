@@ -31,16 +31,32 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def _host_stamp() -> str:
+    """What decides whether a -march=native build can be reused here: the CPU's instruction-set flags (the model-name
+    string is shared by different micro-architectures on virtual machines) and the source text."""
+    import hashlib
+
+    flags = ""
+    if os.path.exists("/proc/cpuinfo"):
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                flags = " ".join(sorted(line.split(":", 1)[1].split()))
+                break
+    src = open(os.path.join(HERE, "c", "euler3d_port.cpp"), "rb").read()
+    return hashlib.sha256(flags.encode() + b"\0" + src).hexdigest()
+
+
 def load():
     global _lib
     if _lib is None:
-        # -march=native code does not travel between hosts: rebuild when the library was built elsewhere
+        # -march=native code does not travel between hosts: rebuild when the library was built elsewhere or from
+        # another source text (the stamp is written here only, so a library made by `make port` is rebuilt once)
         stamp = LIB + ".host"
-        host = open("/proc/cpuinfo").read().split("model name", 2)[1].split("\n", 1)[0] if os.path.exists("/proc/cpuinfo") else ""
-        if not os.path.exists(LIB) or not os.path.exists(stamp) or open(stamp).read() != host:
+        want = _host_stamp()
+        if not os.path.exists(LIB) or not os.path.exists(stamp) or open(stamp).read() != want:
             build(force=True)
             with open(f"{stamp}.{os.getpid()}.tmp", "w") as f:
-                f.write(host)
+                f.write(want)
             os.replace(f"{stamp}.{os.getpid()}.tmp", stamp)
         _lib = ctypes.CDLL(LIB)
         _lib.wxo_euler3d_extrapolate.restype = ctypes.c_int

@@ -834,6 +834,97 @@ def steploop_case(name, ini, overrides, nsteps=5, dt=None, perturb=0.01, seed=27
     print(f"   -> {path}  {os.path.getsize(path)/1e6:.2f} MB  ({time.time()-t0:.1f}s)", flush=True)
 
 
+# ---------------------------------------------------------------------------------------------
+# BASELINE config 5's own combination: config/dcmip21.ini (Schaer mountain: topography + Rayleigh sponge),
+# EPI2 + KIOPS with the complex-step JVP, followed by the per-step exponential filter - the body of
+# Simulation.step (simulation.py:147-155) with integrators/epi.py:81-360 as the stepper.
+# ---------------------------------------------------------------------------------------------
+def config5_case(name, ini, overrides, nsteps=2, dt=None, perturb=0.01, seed=5150):
+    print(f"[{name}] {ini}", flush=True)
+    import integrators.epi as epi_mod
+    import threading
+
+    stats_log = {}
+    lock = threading.Lock()
+    real_kiops = epi_mod.kiops
+
+    def logging_kiops(*a, **k):
+        phiv, stats = real_kiops(*a, **k)
+        with lock:
+            stats_log.setdefault(MPI.COMM_WORLD.rank, []).append([float(x) for x in stats])
+        return phiv, stats
+
+    def work(rank):
+        from device import CpuDevice
+        from process_topology import ProcessTopology
+        from geometry import CubedSphere3D, DFROperators
+        from init.init_state_vars import init_state_vars
+        from rhs.rhs_selector import RhsBundle
+        from integrators import Epi
+
+        cfg = _config(ini, overrides)
+        cfg.verbose_solver = 0
+        cfg.exponential_solver = "kiops"   # BASELINE config 5 (the schema's default is pmex)
+        assert cfg.time_integrator == "epi2" and cfg.jacobian_method == "complex"
+        step = float(dt if dt is not None else cfg.dt)
+        comm = MPI.COMM_WORLD
+        dev = CpuDevice(comm)
+        pt = ProcessTopology(dev, comm=comm)
+        geom = CubedSphere3D(cfg.num_elements_horizontal, cfg.num_elements_vertical, cfg.num_solpts,
+                             cfg.lambda0, cfg.phi0, cfg.alpha0, cfg.ztop, pt, cfg, dev)
+        ops = DFROperators(geom, cfg, dev)
+        Q, topo, metric = init_state_vars(geom, ops, cfg)
+        rhs = RhsBundle(geom, ops, metric, topo, pt, cfg, Q.shape, False)
+        rng = numpy.random.default_rng(seed + rank)
+        Q = Q * (1.0 + perturb * rng.uniform(-1.0, 1.0, Q.shape))
+        out = {"Q": Q.copy()}
+        stepper = Epi(cfg, 2, rhs.full, device=dev)
+        assert ops.expfilter_apply
+        for i in range(nsteps):
+            Q = stepper.step(Q, step)
+            out[f"Q{i + 1}_unfiltered"] = Q.copy()
+            Q = ops.apply_filters(Q, geom, metric, step)
+            assert not numpy.any(numpy.isnan(Q))
+            out[f"Q{i + 1}"] = Q.copy()
+        if rank == 0:
+            out["ops/expfilter"] = numpy.array(ops.expfilter, copy=True)
+            out["meta/case_number"] = numpy.int64(cfg.case_number)
+            out["meta/n"] = numpy.int64(cfg.num_solpts)
+            out["meta/H"] = numpy.int64(cfg.num_elements_horizontal)
+            out["meta/V"] = numpy.int64(cfg.num_elements_vertical)
+            out["meta/ztop"] = numpy.float64(cfg.ztop)
+            out["meta/dt"] = numpy.float64(step)
+            out["meta/nsteps"] = numpy.int64(nsteps)
+            out["meta/tolerance"] = numpy.float64(cfg.tolerance)
+            out["meta/expfilter_strength"] = numpy.float64(cfg.expfilter_strength)
+            out["meta/expfilter_order"] = numpy.int64(cfg.expfilter_order)
+            out["meta/expfilter_cutoff"] = numpy.float64(cfg.expfilter_cutoff)
+        return out
+
+    t0 = time.time()
+    epi_mod.kiops = logging_kiops
+    try:
+        MPI.reset_world(6)
+        res, err = MPI.run_ranks(work, 6)
+    finally:
+        epi_mod.kiops = real_kiops
+    for e in err:
+        if e:
+            print(e)
+            raise SystemExit(1)
+    flat = {}
+    for p, d in enumerate(res):
+        for k, v in d.items():
+            flat[k if k.startswith(("meta/", "ops/")) else f"p{p}/{k}"] = v
+    st = numpy.array(stats_log[0])
+    for r in range(1, 6):
+        assert numpy.array_equal(st, numpy.array(stats_log[r])), "KIOPS statistics differ between ranks"
+    flat["meta/kiops_stats"] = st   # one row per step: the reference's `stats` tuple
+    path = os.path.join(GOLDEN, name + ".npz")
+    numpy.savez_compressed(path, **flat)
+    print(f"   -> {path}  {os.path.getsize(path)/1e6:.2f} MB  ({time.time()-t0:.1f}s)  kiops stats {st.tolist()}", flush=True)
+
+
 CASES = {
     # balanced gravity-wave state, small n: all panels carry metrics + phases (exchange coverage)
     "euler3d_c31_n3_h4_v2": lambda nm: euler_case(
@@ -906,6 +997,18 @@ CASES = {
                                                dict(num_solpts=5, num_elements_horizontal=7, num_elements_vertical=9)),
     "cart2d_bubble_n4": lambda nm: cart2d_case(nm, "gaussian_bubble.ini",
                                                dict(num_solpts=4, num_elements_horizontal=5, num_elements_vertical=6)),
+    # --- round 3: the benchmark order n = 8 for every caller (the matrix-core instantiations of the JVP, stage and
+    # filter kernels), and BASELINE config 5's own combination (dcmip21 + EPI2 + KIOPS + filter)
+    "callers_euler3d_n8_h2_v2": lambda nm: callers_case(
+        nm, "dcmip31.ini", dict(num_solpts=8, num_elements_horizontal=2, num_elements_vertical=2), dt_rk=0.5),
+    "filters_c21_n8_h2_v2": lambda nm: filters_case(
+        nm, "dcmip21.ini", dict(num_solpts=8, num_elements_horizontal=2, num_elements_vertical=2)),
+    "steploop_c21_n8_h2_v2": lambda nm: steploop_case(
+        nm, "dcmip21_rk3.ini", dict(num_solpts=8, num_elements_horizontal=2, num_elements_vertical=2), nsteps=3, dt=0.02),
+    "config5_c21_n4_h2_v3": lambda nm: config5_case(
+        nm, "dcmip21.ini", dict(num_solpts=4, num_elements_horizontal=2, num_elements_vertical=3)),
+    "config5_c21_n8_h2_v2": lambda nm: config5_case(
+        nm, "dcmip21.ini", dict(num_solpts=8, num_elements_horizontal=2, num_elements_vertical=2), nsteps=1),
 }
 
 

@@ -9,7 +9,7 @@ import pytest
 
 from tests.util import GOLDEN
 
-FIXTURES = ["filters_c21_n4_h3_v4", "filters_c21_n5_h2_v2"]
+FIXTURES = ["filters_c21_n4_h3_v4", "filters_c21_n5_h2_v2", "filters_c21_n8_h2_v2"]   # n = 8: the matrix-core instantiation
 
 
 def _load(name):
@@ -63,6 +63,9 @@ def test_gpu_expfilter_matches_reference(built_lib, name, cplx):
     sg = [torch.from_numpy(g[f"p{p}/metric/sqrtG_new"]).to(dev) for p in range(6)]
     flag = NanFlag(dev)
     filt = ExpFilter3D(g["ops/expfilter"], sg, flag)
+    # n = 8, float64: the three passes run on the matrix cores (complex states keep the vector pipe)
+    assert int(filt.lib.wx_expfilter_uses_matrix_cores(filt._h, 0)) == int(int(g["meta/n"]) == 8)
+    assert int(filt.lib.wx_expfilter_uses_matrix_cores(filt._h, 1)) == 0
     Q = np.stack([g[f"p{p}/Q"] for p in range(6)])
     R = np.stack([g[f"p{p}/R"] for p in range(6)])
     if cplx:  # linear operator: the imaginary part filters like the real one
@@ -171,9 +174,10 @@ def test_gpu_step_loop_filters_and_flags(built_lib):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["steploop_c21_n4_h2_v3", "steploop_c21_n8_h2_v2"])
 @pytest.mark.parametrize("pipeline", [False, True])
-def test_gpu_time_loop_matches_reference_run(built_lib, pipeline):
-    """Five steps of the reference's own loop (Tvdrk3.step + apply_filters, simulation.py:147-155) on the Schaer
+def test_gpu_time_loop_matches_reference_run(built_lib, pipeline, name):
+    """Five (n = 8: three) steps of the reference's own loop (Tvdrk3.step + apply_filters, simulation.py:147-155) on the Schaer
     mountain case, reproduced with nothing reference-supplied but the initial state: geometry3d metric + sponge,
     pipelined SSP-RK3 stages, the filter kernel with its NaN flag."""
     import torch
@@ -185,7 +189,7 @@ def test_gpu_time_loop_matches_reference_run(built_lib, pipeline):
     from wxfactory_amd.synthetic import dfr_ops
 
     dev = "cuda:0"
-    g = _load("steploop_c21_n4_h2_v3")
+    g = _load(name)
     n, H, V, case = (int(g[f"meta/{k}"]) for k in ("n", "H", "V", "case_number"))
     topo = topography_for_case(case, planet_for_case(case)[0])
     metrics, plans = {}, {}
@@ -201,6 +205,8 @@ def test_gpu_time_loop_matches_reference_run(built_lib, pipeline):
     loop = StepLoop(Tvdrk3(rhs, pipeline=pipeline), ExpFilter3D(F, [metrics[p]["sqrtG"] for p in range(6)]),
                     flag, check_every=5)
     assert loop.fused == pipeline
+    if pipeline:   # n = 8: the stage kernel and its fused filter are the matrix-core instantiation
+        assert int(plans[0].lib.wx_euler3d_uses_matrix_cores(plans[0]._h, 1)) == int(n == 8)
     stack = lambda key: np.stack([g[f"p{p}/{key}"] for p in range(6)])  # noqa: E731
     Q0 = torch.from_numpy(stack("Q")).to(dev)
     dt, nsteps = float(g["meta/dt"]), int(g["meta/nsteps"])

@@ -90,6 +90,31 @@ def test_kiops_happy_breakdown():
     assert stats[0] == 1 and stats[2] <= 6, stats
 
 
+@pytest.mark.parametrize("ortho", ["igs", "cgs"])
+def test_fgmres_happy_breakdown(ortho):
+    """A Krylov space that closes early: A = c I (one vector spans it: the lagged norm of the second row is exactly
+    zero), and an operator with three distinct eigenvalues (closes after three vectors, up to rounding).  Both
+    orthogonalisations return the exact solution with flag 0 instead of dividing by the vanished norm."""
+    from wxfactory_amd.solvers import fgmres
+
+    rng = np.random.default_rng(8)
+    b = torch.from_numpy(rng.uniform(-1.0, 1.0, 64))
+    x, norm_r, norm_b, niter, flag, _ = fgmres(lambda v: 2.0 * v, b, tol=1e-12, restart=10)
+    assert flag == 0 and niter <= 2 and torch.allclose(x, b / 2.0, rtol=1e-14, atol=0) and norm_r <= 1e-12 * norm_b
+    lam = torch.from_numpy(np.repeat([1.5, -0.7, 4.0], [20, 20, 24]))
+    x, norm_r, norm_b, niter, flag, _ = fgmres(lambda v: lam * v, b, tol=1e-12, restart=10)
+    assert flag == 0 and niter <= 5, (flag, niter)
+    assert torch.allclose(x, b / lam, rtol=1e-11, atol=1e-13)
+    # with a preconditioner (a second set of vectors is kept) and a non-zero first guess
+    x, norm_r, norm_b, niter, flag, _ = fgmres(lambda v: lam * v, b, x0=0.3 * b, tol=1e-12, restart=10,
+                                               preconditioner=lambda v: 0.5 * v, ortho=ortho)
+    assert flag == 0 and torch.allclose(x, b / lam, rtol=1e-11, atol=1e-13)
+    x, *_, flag, _ = fgmres(lambda v: 2.0 * v, b, tol=1e-12, restart=10, ortho=ortho)
+    assert flag == 0 and torch.allclose(x, b / 2.0, rtol=1e-14, atol=0)
+    x, *_, flag, _ = fgmres(lambda v: lam * v, b, tol=1e-12, restart=10, ortho=ortho)
+    assert flag == 0 and torch.allclose(x, b / lam, rtol=1e-11, atol=1e-13)
+
+
 def test_fgmres_against_dense_solve():
     from wxfactory_amd.solvers import fgmres
 

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("WXHIP_LIB") or os.path.join(PKG, "lib", "libwxhip.so"
 WX_OK = 0
 WX_F64, WX_C128, WX_DUAL128 = 0, 1, 2
 WX_REGION_ALL, WX_REGION_INTERIOR, WX_REGION_BOUNDARY = 0, 1, 2
+WX_KERNEL_RHS, WX_KERNEL_STAGE, WX_KERNEL_JVP, WX_KERNEL_BATCH_RHS, WX_KERNEL_BATCH_JVP = 0, 1, 2, 3, 4
 
 
 class WxError(RuntimeError):
@@ -60,6 +61,7 @@ SIGNATURES = {
     "wx_euler3d_plan_destroy": (c_int, [c_void_p]),
     "wx_euler3d_edge_count": (c_size_t, [c_void_p]),
     "wx_euler3d_bytes_per_point": (c_double, [c_void_p]),
+    "wx_euler3d_uses_matrix_cores": (c_int, [c_void_p, c_int]),
     "wx_euler3d_extrap_pack": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p]),
     "wx_euler3d_rhs": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_int, c_void_p]),
     "wx_euler3d_rhs_axpy": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_double, c_double,
@@ -84,6 +86,7 @@ SIGNATURES = {
                                c_double, c_double, c_void_p]),
     "wx_expfilter_create": (c_int, [POINTER(c_void_p), c_int, POINTER(c_double)]),
     "wx_expfilter_destroy": (c_int, [c_void_p]),
+    "wx_expfilter_uses_matrix_cores": (c_int, [c_void_p, c_int]),
     "wx_expfilter_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_int, c_void_p, c_void_p]),
     "wx_expfilter_apply_stacked": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_int, c_int, c_void_p,
                                            c_void_p]),

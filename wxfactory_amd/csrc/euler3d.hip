@@ -1530,7 +1530,8 @@ __global__ __launch_bounds__(Cfg<N>::BS, WX_JVP_WAVES) void euler_jvp_batch_kern
     EulerParams<dual> P = table[blockIdx.y];
     batch_state<dual>(P, dyn);
     P.region = dyn.region; P.count = dyn.count;
-    euler_jvp_body<N>(P);
+    if constexpr (N == 8 && WX_JVP_MFMA) euler_jvp_body_mf(P);
+    else euler_jvp_body<N>(P);
 }
 
 // plan-time scan of a static field: raises *flag when any value differs from (+/-) zero
@@ -1852,6 +1853,23 @@ double wx_euler3d_bytes_per_point(const wx_euler3d_plan* pl) {
     return 8.0 * (5 + 5 + 1 + 6 + gammas + 1) + 3.0 * 2 * 4 * 8 / n + (pl->base.has_damp ? 32.0 : 0.0);
 }
 
+static bool jvp_lean() {
+    static const bool lean = [] { const char* e = getenv("WXHIP_JVP_LEAN"); return !(e && e[0] == '0'); }();
+    return lean;
+}
+
+int wx_euler3d_uses_matrix_cores(const wx_euler3d_plan* pl, wx_kernel kernel) {
+    if (!pl) return -1;
+    const bool rhs_mf = WX_K2_MFMA && pl->n == 8 && pl->dtype == WX_F64;
+    const bool jvp_mf = WX_JVP_MFMA && pl->n == 8 && pl->dtype == WX_DUAL128;
+    switch (kernel) {
+        case WX_KERNEL_RHS: case WX_KERNEL_STAGE: case WX_KERNEL_BATCH_RHS: return rhs_mf ? 1 : 0;
+        case WX_KERNEL_JVP: return (jvp_mf && jvp_lean()) ? 1 : 0;   // WXHIP_JVP_LEAN=0: the generic dual instantiation
+        case WX_KERNEL_BATCH_JVP: return jvp_mf ? 1 : 0;
+    }
+    return -1;
+}
+
 size_t wx_euler3d_edge_count(const wx_euler3d_plan* pl) {
     return pl ? (size_t)NQ * pl->V * pl->H * pl->n * pl->n : 0;
 }
@@ -1931,9 +1949,8 @@ wx_status wx_euler3d_jvp(wx_euler3d_plan* pl, const double* q, const double* v, 
         P.halo_s = static_cast<const dual*>(halo[0]); P.halo_n = static_cast<const dual*>(halo[1]);
         P.halo_w = static_cast<const dual*>(halo[2]); P.halo_e = static_cast<const dual*>(halo[3]);
     }
-    static const bool lean = [] { const char* e = getenv("WXHIP_JVP_LEAN"); return !(e && e[0] == '0'); }();
     WX_STREAM(st, stream);
-    if (!lean) return dispatch_rhs<dual>(pl->n, P, st);
+    if (!jvp_lean()) return dispatch_rhs<dual>(pl->n, P, st);
     switch (pl->n) {
         case 2: return launch_jvp<2>(P, st);
         case 3: return launch_jvp<3>(P, st);

@@ -198,6 +198,11 @@ wx_status wx_expfilter_destroy(wx_expfilter* h) {
     return WX_OK;
 }
 
+int wx_expfilter_uses_matrix_cores(const wx_expfilter* h, wx_dtype dtype) {
+    if (!h) return -1;
+    return (WX_FILTER_MFMA && h->n == 8 && dtype == WX_F64) ? 1 : 0;
+}
+
 static wx_status expfilter_apply_impl(const wx_expfilter* h, const void* q, void* out, const double* sqrtG, int nvar,
                                       size_t nelem, int npanels, wx_dtype dtype, int* nan_flag, wx_stream stream);
 

@@ -138,7 +138,17 @@ class _LowSyncGramSchmidt:
         ga, gb = np.asarray(gram[:j]), np.asarray(gram[j:])
         s = ga[: j - 2]                       # <V[k], a>, k < j-2: what the first pass left in a
         R[: j - 1, j - 1] = gb[: j - 1]
-        norm = math.sqrt(ga[j - 2] - s @ s) if ga[j - 2] - s @ s >= 0.0 else math.nan
+        d = ga[j - 2] - s @ s
+        # (happy) breakdown: nothing but rounding is left of row j-2 once it is orthogonal to its predecessors - the
+        # Krylov space is exhausted (A = c I after one vector).  The lagged norm is then taken as exactly zero, the
+        # Hessenberg column is completed without dividing by it, and the caller ends the cycle with the rows it has.
+        if d == d and d <= _BREAKDOWN * _BREAKDOWN * ga[j - 2]:
+            R[j - 2, j - 2] = 0.0
+            if j > 2:
+                L = np.tril(T[: j - 2, : j - 2].T, -1) + np.eye(j - 2)
+                R[: j - 2, j - 2] = K[: j - 2, j - 3] + np.linalg.solve(L, s)
+            return 0.0
+        norm = math.sqrt(d) if d >= 0.0 else math.nan
         R[j - 2, j - 2] = norm
         R[j - 2, j - 1] = (R[j - 2, j - 1] - s @ R[: j - 2, j - 1]) / norm
         T[: j - 2, j - 2] = s / norm
@@ -154,6 +164,7 @@ class _LowSyncGramSchmidt:
         return norm
 
 
+_BREAKDOWN = 1e-14  # low-sync Gram-Schmidt: a row whose orthogonal part is below this fraction of its length has vanished
 _REORTH = 0.1  # fgmres: re-orthogonalise when |w - V V^T w| < _REORTH |w| (orthogonality kept to ~1e-15 / _REORTH)
 
 
@@ -336,7 +347,7 @@ def _fgmres_low_sync(A, b, x0, tol, restart, maxiter, preconditioner, verbose, g
                 w = A(zj / v_norm)
                 torch.mul(w, v_norm, out=V[j + 2])
             v_norm = gs.step(j + 3)
-            if Z is not None:
+            if Z is not None and v_norm != 0.0:
                 Z[j + 1] /= v_norm
             hj = gs.R[: j + 2, j + 1].tolist()
             for i in range(j):  # previous rotations
@@ -353,11 +364,11 @@ def _fgmres_low_sync(A, b, x0, tol, restart, maxiter, preconditioner, verbose, g
             sn.append(s_)
             Hm[j][: j + 2] = hj
             k = j + 1
-            if j < restart - 1:
+            if j < restart - 1 or v_norm == 0.0:
                 norm_r = abs(g[j + 1])
                 residuals.append((norm_r / norm_b, time() - t0, 0.0))
-                if norm_r < tol_abs or norm_r != norm_r:
-                    break
+                if norm_r < tol_abs or norm_r != norm_r or v_norm == 0.0:
+                    break   # converged, NaN, or breakdown (row j+1 vanished: h_{j+1,j} = 0, the least-squares residual is exact)
         y = [0.0] * k
         for i in range(k - 1, -1, -1):
             acc = g[i]
