@@ -17,7 +17,13 @@
 // Layouts as in the reference (geometry/cubed_sphere_3d.py:187-205): q, rhs (5, V, H, H, n^3), point
 // (kl n + jl) n + il; faces (5, V, H, H, 2 n^2) per direction, [0, n^2) minus side, [n^2, 2 n^2) plus side;
 // halos (5, V, H, n^2) per lateral edge; interface metric halo-padded along its direction.
+//
+// Scalar type: float64 (wxo_euler3d_*) or complex128 (wxo_euler3d_*_c: the state, faces, halos and the result are
+// interleaved (re, im) pairs; the metric stays real) with NumPy's rules where complex numbers have no natural order -
+// abs() is the real modulus, maximum() compares lexicographically (real part first) - so that Im R(Q + i eps v) / eps is
+// the reference's complex-step Jacobian-vector product (solvers/matvec.py:56-61) term by term.
 #include <cmath>
+#include <complex>
 #include <cstddef>
 #include <cstring>
 
@@ -31,28 +37,43 @@ constexpr double kGravity = 9.80616, kP0 = 100000.0, kRd = 287.05, kCpd = 1005.4
 constexpr double kCvd = kCpd - kRd, kGamma = kCpd / kCvd;
 constexpr int MAXN = 8, MAXN2 = MAXN * MAXN, MAXN3 = MAXN * MAXN * MAXN;
 
-inline double pressure_of(double rho_theta) { return kP0 * std::exp(kGamma * std::log(rho_theta * (kRd / kP0))); }
+using cplx = std::complex<double>;
+
+inline double s_abs(double x) { return std::fabs(x); }
+inline double s_abs(const cplx& x) { return std::abs(x); }   // numpy.abs: the modulus, a real number
+inline bool s_isnan(double x) { return x != x; }
+inline bool s_isnan(const cplx& x) { return x.real() != x.real() || x.imag() != x.imag(); }
+inline bool s_greater(double a, double b) { return a > b; }
+inline bool s_greater(const cplx& a, const cplx& b) {   // numpy's lexicographic order of complex numbers
+    return a.real() > b.real() || (a.real() == b.real() && a.imag() > b.imag());
+}
+
+template <typename S>
+inline S pressure_of(S rho_theta) { return kP0 * std::exp(kGamma * std::log(rho_theta * (kRd / kP0))); }
 
 // what one side of a face contributes to its Riemann problem
+template <typename S>
 struct Side {
-    double q[5], un, p, sg, h[3];
+    S q[5], un, p;
+    double sg, h[3];
 };
 
 // out: F* of the five rows, A* (advective rho-w flux), and 1/2 (P_L + P_R) before the division by the side's pressure
-inline void rusanov(const Side& L, const Side& R, int d, bool advection_only, double* fstar, double& astar, double& pavg) {
-    double eL = std::fabs(L.un), eR = std::fabs(R.un);
+template <typename S>
+inline void rusanov(const Side<S>& L, const Side<S>& R, int d, bool advection_only, S* fstar, S& astar, S& pavg) {
+    S eL = S(s_abs(L.un)), eR = S(s_abs(R.un));
     if (!advection_only) {
         eL += std::sqrt(L.h[d] * kGamma * L.p / L.q[0]);
         eR += std::sqrt(R.h[d] * kGamma * R.p / R.q[0]);
     }
-    const double eig = (eL > eR || eL != eL) ? eL : eR;   // numpy.maximum propagates NaN
+    const S eig = (s_greater(eL, eR) || s_isnan(eL)) ? eL : eR;   // numpy.maximum propagates NaN
     const int mom[3] = {1, 2, 3};
-    double fL[5], fR[5];
+    S fL[5], fR[5];
     for (int v = 0; v < 5; ++v) {
         fL[v] = L.sg * L.un * L.q[v];
         fR[v] = R.sg * R.un * R.q[v];
     }
-    const double aL = fL[3], aR = fR[3];
+    const S aL = fL[3], aR = fR[3];
     for (int i = 0; i < 3; ++i) {
         fL[mom[i]] += L.sg * L.h[i] * L.p;
         fR[mom[i]] += R.sg * R.h[i] * R.p;
@@ -68,13 +89,12 @@ struct Tile {
     size_t ffs;   // field stride of face arrays
 };
 
-}  // namespace
 
-extern "C" {
 
 // q (5, V, H, H, n^3) -> itf_d (5, V, H, H, 2 n^2), d = i, j, k
-int wxo_euler3d_extrapolate(int n, int H, int V, const double* em, const double* ep, const double* q, double* itf_i,
-                            double* itf_j, double* itf_k, int nthreads) {
+template <typename S>
+int extrapolate_impl(int n, int H, int V, const double* em, const double* ep, const S* q, S* itf_i, S* itf_j, S* itf_k,
+                     int nthreads) {
     if (n < 2 || n > MAXN) return 1;
     const int n2 = n * n, n3 = n2 * n;
     const size_t nelem = (size_t)V * H * H, fs = nelem * n3, ffs = nelem * 2 * n2;
@@ -83,21 +103,21 @@ int wxo_euler3d_extrapolate(int n, int H, int V, const double* em, const double*
 #endif
 #pragma omp parallel for schedule(static)
     for (long e = 0; e < (long)nelem; ++e) {
-        double a[MAXN3];
+        S a[MAXN3];
         for (int v = 0; v < 5; ++v) {
-            const double* src = q + v * fs + (size_t)e * n3;
+            const S* src = q + v * fs + (size_t)e * n3;
             const bool lg = (v == 0 || v == 4);
             for (int p = 0; p < n3; ++p) a[p] = lg ? std::log(src[p]) : src[p];
-            double* fi = itf_i + v * ffs + (size_t)e * 2 * n2;
-            double* fj = itf_j + v * ffs + (size_t)e * 2 * n2;
-            double* fk = itf_k + v * ffs + (size_t)e * 2 * n2;
+            S* fi = itf_i + v * ffs + (size_t)e * 2 * n2;
+            S* fj = itf_j + v * ffs + (size_t)e * 2 * n2;
+            S* fk = itf_k + v * ffs + (size_t)e * 2 * n2;
             for (int x = 0; x < n; ++x)
                 for (int y = 0; y < n; ++y) {
-                    double mi = 0, pi = 0, mj = 0, pj = 0, mk = 0, pk = 0;
+                    S mi = 0, pi = 0, mj = 0, pj = 0, mk = 0, pk = 0;
                     for (int m = 0; m < n; ++m) {
-                        const double vi = a[(x * n + y) * n + m];   // (kl = x, jl = y, il = m)
-                        const double vj = a[(x * n + m) * n + y];   // (kl = x, jl = m, il = y)
-                        const double vk = a[(m * n + x) * n + y];   // (kl = m, jl = x, il = y)
+                        const S vi = a[(x * n + y) * n + m];   // (kl = x, jl = y, il = m)
+                        const S vj = a[(x * n + m) * n + y];   // (kl = x, jl = m, il = y)
+                        const S vk = a[(m * n + x) * n + y];   // (kl = m, jl = x, il = y)
                         mi += em[m] * vi; pi += ep[m] * vi;
                         mj += em[m] * vj; pj += ep[m] * vj;
                         mk += em[m] * vk; pk += ep[m] * vk;
@@ -112,12 +132,12 @@ int wxo_euler3d_extrapolate(int n, int H, int V, const double* em, const double*
     return 0;
 }
 
-int wxo_euler3d_rhs(int n, int H, int V, int case_number, const double* D, const double* C, const double* HF, const double* q,
-                    const double* itf_i, const double* itf_j, const double* itf_k, const double* halo_s,
-                    const double* halo_n, const double* halo_w, const double* halo_e, const double* sg, const double* h,
-                    const double* chr, const double* idz, const double* sgi, const double* sgj, const double* sgk,
-                    const double* hi, const double* hj, const double* hk, const double* dcoef, const double* duref,
-                    double* rhs, int nthreads) {
+template <typename S>
+int rhs_impl(int n, int H, int V, int case_number, const double* D, const double* C, const double* HF, const S* q,
+             const S* itf_i, const S* itf_j, const S* itf_k, const S* halo_s, const S* halo_n, const S* halo_w,
+             const S* halo_e, const double* sg, const double* h, const double* chr, const double* idz, const double* sgi,
+             const double* sgj, const double* sgk, const double* hi, const double* hj, const double* hk,
+             const double* dcoef, const double* duref, S* rhs, int nthreads) {
     if (n < 2 || n > MAXN) return 1;
     const bool advection_only = case_number < 13;
     const bool damp = (case_number == 21 || case_number == 22) && dcoef && duref;
@@ -135,10 +155,10 @@ int wxo_euler3d_rhs(int n, int H, int V, int case_number, const double* D, const
                 const size_t e = ((size_t)ek * H + ej) * H + ei;
                 // ---- common fluxes on the six faces: [face][quantity][face point]
                 //      quantities 0..4 F*, 5 A*, 6 1/2 (P_L + P_R) / p_own, 7 log p_own
-                double fr[6][8][MAXN2];
+                S fr[6][8][MAXN2];
                 for (int f = 0; f < 6; ++f) {
                     const int d = f >> 1, plus = f & 1;
-                    const double* itf = d == 0 ? itf_i : (d == 1 ? itf_j : itf_k);
+                    const S* itf = d == 0 ? itf_i : (d == 1 ? itf_j : itf_k);
                     const double *sgp, *hp;
                     size_t hfs, oL, oR;   // interface metric: field stride, offsets of the L and R slots of this face
                     const int lo = plus ? 1 : 0;   // padded index of the element left of the face is e_d + lo
@@ -162,12 +182,12 @@ int wxo_euler3d_rhs(int n, int H, int V, int case_number, const double* D, const
                     const int c = d == 0 ? ei : (d == 1 ? ej : ek), cn = c + (plus ? 1 : -1), ext = d == 2 ? V : H;
                     const bool inside = cn >= 0 && cn < ext;
                     const size_t estr = d == 0 ? 1 : (d == 1 ? (size_t)H : (size_t)H * H);
-                    const double* halo = nullptr;
+                    const S* halo = nullptr;
                     size_t ho = 0;
                     if (!inside && d == 0) { halo = plus ? halo_e : halo_w; ho = ((size_t)ek * H + ej) * n2; }
                     if (!inside && d == 1) { halo = plus ? halo_n : halo_s; ho = ((size_t)ek * H + ei) * n2; }
                     for (int fp = 0; fp < n2; ++fp) {
-                        Side own, nbr;
+                        Side<S> own, nbr;
                         for (int v = 0; v < 5; ++v) {
                             own.q[v] = itf[v * ffs + e * 2 * n2 + plus * n2 + fp];
                             if (inside) nbr.q[v] = itf[v * ffs + (plus ? e + estr : e - estr) * 2 * n2 + (1 - plus) * n2 + fp];
@@ -179,11 +199,11 @@ int wxo_euler3d_rhs(int n, int H, int V, int case_number, const double* D, const
                         if (!inside && d == 2) nbr.un = -own.un;   // no-flow wall: odd w (pde_euler_cubesphere.py:150-156)
                         own.p = pressure_of(own.q[4]);
                         nbr.p = pressure_of(nbr.q[4]);
-                        Side& L = plus ? own : nbr;
-                        Side& R = plus ? nbr : own;
+                        Side<S>& L = plus ? own : nbr;
+                        Side<S>& R = plus ? nbr : own;
                         L.sg = sgp[oL + fp]; R.sg = sgp[oR + fp];
                         for (int r = 0; r < 3; ++r) { L.h[r] = hp[r * hfs + oL + fp]; R.h[r] = hp[r * hfs + oR + fp]; }
-                        double fstar[5], astar, pavg;
+                        S fstar[5], astar, pavg;
                         rusanov(L, R, d, advection_only, fstar, astar, pavg);
                         for (int v = 0; v < 5; ++v) fr[f][v][fp] = fstar[v];
                         fr[f][5][fp] = astar;
@@ -192,8 +212,10 @@ int wxo_euler3d_rhs(int n, int H, int V, int case_number, const double* D, const
                     }
                 }
                 // ---- nodal quantities
-                double qq[5][MAXN3], u[3][MAXN3], p[MAXN3], lp[MAXN3], sgv[MAXN3], hv[9][MAXN3];
-                for (int v = 0; v < 5; ++v) std::memcpy(qq[v], q + v * fs + e * n3, sizeof(double) * n3);
+                S qq[5][MAXN3], u[3][MAXN3], p[MAXN3], lp[MAXN3];
+                double sgv[MAXN3], hv[9][MAXN3];
+                for (int v = 0; v < 5; ++v)
+                    for (int pt = 0; pt < n3; ++pt) qq[v][pt] = q[v * fs + e * n3 + pt];
                 std::memcpy(sgv, sg + e * n3, sizeof(double) * n3);
                 for (int r = 0; r < 9; ++r) std::memcpy(hv[r], h + r * fs + e * n3, sizeof(double) * n3);
                 for (int pt = 0; pt < n3; ++pt) {
@@ -201,14 +223,16 @@ int wxo_euler3d_rhs(int n, int H, int V, int case_number, const double* D, const
                     p[pt] = pressure_of(qq[4][pt]);
                     lp[pt] = std::log(p[pt]);
                 }
-                double tot[5][MAXN3], wtot[MAXN3];
-                std::memset(tot, 0, sizeof(tot));
-                std::memset(wtot, 0, sizeof(wtot));
+                S tot[5][MAXN3], wtot[MAXN3];
+                for (int pt = 0; pt < n3; ++pt) {
+                    for (int v = 0; v < 5; ++v) tot[v][pt] = 0.0;
+                    wtot[pt] = 0.0;
+                }
                 for (int d = 0; d < 3; ++d) {
                     // fields to differentiate along d: 0..4 F^d, 5 A^d, 6 B^d, 7 log p
-                    double g[8][MAXN3];
+                    S g[8][MAXN3];
                     for (int pt = 0; pt < n3; ++pt) {
-                        const double sgu = sgv[pt] * u[d][pt];
+                        const S sgu = sgv[pt] * u[d][pt];
                         for (int v = 0; v < 5; ++v) g[v][pt] = sgu * qq[v][pt];
                         g[5][pt] = g[3][pt];
                         for (int i = 0; i < 3; ++i) g[1 + i][pt] += sgv[pt] * hv[3 * d + i][pt] * p[pt];
@@ -224,9 +248,9 @@ int wxo_euler3d_rhs(int n, int H, int V, int case_number, const double* D, const
                                 const int base = pt - ix * stride;
                                 const int fp = d == 0 ? kl * n + jl : (d == 1 ? kl * n + il : jl * n + il);
                                 const double cm = C[2 * ix], cp = C[2 * ix + 1];
-                                double r[8];
+                                S r[8];
                                 for (int c = 0; c < 8; ++c) {
-                                    double a = 0.0;
+                                    S a = 0.0;
                                     for (int m = 0; m < n; ++m) a += D[ix * n + m] * g[c][base + m * stride];
                                     r[c] = a + cm * fr[2 * d][c][fp] + cp * fr[2 * d + 1][c][fp];
                                 }
@@ -241,12 +265,13 @@ int wxo_euler3d_rhs(int n, int H, int V, int case_number, const double* D, const
                         for (int il = 0; il < n; ++il) {
                             const int pt = (kl * n + jl) * n + il;
                             const size_t o = e * n3 + pt;
-                            const double isg = 1.0 / sgv[pt], rho = qq[0][pt];
-                            double R[5];
+                            const double isg = 1.0 / sgv[pt];
+                            const S rho = qq[0][pt];
+                            S R[5];
                             for (int v = 0; v < 5; ++v) R[v] = -isg * tot[v][pt];
                             R[3] = -isg * wtot[pt];
-                            double force[3];
-                            const double u1 = u[0][pt], u2 = u[1][pt], u3 = u[2][pt], pp = p[pt];
+                            S force[3];
+                            const S u1 = u[0][pt], u2 = u[1][pt], u3 = u[2][pt], pp = p[pt];
                             for (int i = 0; i < 3; ++i) {
                                 const double* c = chr + (size_t)(i * 9) * fs + o;
                                 force[i] = 2.0 * rho * (c[0] * u1 + c[fs] * u2 + c[2 * fs] * u3) +
@@ -257,23 +282,61 @@ int wxo_euler3d_rhs(int n, int H, int V, int case_number, const double* D, const
                                            2.0 * c[7 * fs] * (rho * u2 * u3 + hv[5][pt] * pp) +
                                            c[8 * fs] * (rho * u3 * u3 + hv[8][pt] * pp);
                             }
-                            double hfv = 0.0;   // vertical high-filter of sqrtG rho (operators.py:75-80)
+                            S hfv = 0.0;   // vertical high-filter of sqrtG rho (operators.py:75-80)
                             for (int m = 0; m < n; ++m) {
                                 const int pm = (m * n + jl) * n + il;
                                 hfv += HF[kl * n + m] * sgv[pm] * qq[0][pm];
                             }
                             force[2] += idz[o] * kGravity * isg * hfv;
                             if (damp) {
-                                const double dw = dcoef[o] * rho;
+                                const S dw = dcoef[o] * rho;
                                 force[0] += dw * (u1 - duref[o]);
                                 force[1] += dw * (u2 - duref[fs + o]);
                                 force[2] += dw * (u3 - duref[2 * fs + o]);
                             }
                             for (int i = 0; i < 3; ++i) R[1 + i] -= force[i];
-                            for (int v = 0; v < 5; ++v) rhs[v * fs + o] = advection_only ? 0.0 : R[v];
+                            for (int v = 0; v < 5; ++v) rhs[v * fs + o] = advection_only ? S(0.0) : R[v];
                         }
             }
     return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wxo_euler3d_extrapolate(int n, int H, int V, const double* em, const double* ep, const double* q, double* itf_i,
+                            double* itf_j, double* itf_k, int nthreads) {
+    return extrapolate_impl<double>(n, H, V, em, ep, q, itf_i, itf_j, itf_k, nthreads);
+}
+
+// complex128 arrays as interleaved (re, im) doubles
+int wxo_euler3d_extrapolate_c(int n, int H, int V, const double* em, const double* ep, const double* q, double* itf_i,
+                              double* itf_j, double* itf_k, int nthreads) {
+    return extrapolate_impl<cplx>(n, H, V, em, ep, reinterpret_cast<const cplx*>(q), reinterpret_cast<cplx*>(itf_i),
+                                  reinterpret_cast<cplx*>(itf_j), reinterpret_cast<cplx*>(itf_k), nthreads);
+}
+
+int wxo_euler3d_rhs(int n, int H, int V, int case_number, const double* D, const double* C, const double* HF, const double* q,
+                    const double* itf_i, const double* itf_j, const double* itf_k, const double* halo_s,
+                    const double* halo_n, const double* halo_w, const double* halo_e, const double* sg, const double* h,
+                    const double* chr, const double* idz, const double* sgi, const double* sgj, const double* sgk,
+                    const double* hi, const double* hj, const double* hk, const double* dcoef, const double* duref,
+                    double* rhs, int nthreads) {
+    return rhs_impl<double>(n, H, V, case_number, D, C, HF, q, itf_i, itf_j, itf_k, halo_s, halo_n, halo_w, halo_e, sg, h, chr,
+                            idz, sgi, sgj, sgk, hi, hj, hk, dcoef, duref, rhs, nthreads);
+}
+
+int wxo_euler3d_rhs_c(int n, int H, int V, int case_number, const double* D, const double* C, const double* HF, const double* q,
+                      const double* itf_i, const double* itf_j, const double* itf_k, const double* halo_s,
+                      const double* halo_n, const double* halo_w, const double* halo_e, const double* sg, const double* h,
+                      const double* chr, const double* idz, const double* sgi, const double* sgj, const double* sgk,
+                      const double* hi, const double* hj, const double* hk, const double* dcoef, const double* duref,
+                      double* rhs, int nthreads) {
+    auto c = [](const double* x) { return reinterpret_cast<const cplx*>(x); };
+    return rhs_impl<cplx>(n, H, V, case_number, D, C, HF, c(q), c(itf_i), c(itf_j), c(itf_k), c(halo_s), c(halo_n), c(halo_w),
+                          c(halo_e), sg, h, chr, idz, sgi, sgj, sgk, hi, hj, hk, dcoef, duref, reinterpret_cast<cplx*>(rhs),
+                          nthreads);
 }
 
 int wxo_max_threads() {

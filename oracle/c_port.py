@@ -1,7 +1,7 @@
 """ctypes front end of the C++/OpenMP CPU restatement (oracle/c/euler3d_port.cpp).
 
 TEST INFRASTRUCTURE - only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
-Same call shape as oracle.euler3d.Euler3DOracle (extrapolate / pack_edges / rhs), float64 only; pack_edges is the
+Same call shape as oracle.euler3d.Euler3DOracle (extrapolate / pack_edges / rhs), float64 and complex128; pack_edges is the
 NumPy oracle's.  Built by `make -C oracle port` (or build() below, which bench.py and __graft_entry__.build() call).
 """
 import ctypes
@@ -59,21 +59,23 @@ def load():
                 f.write(want)
             os.replace(f"{stamp}.{os.getpid()}.tmp", stamp)
         _lib = ctypes.CDLL(LIB)
-        _lib.wxo_euler3d_extrapolate.restype = ctypes.c_int
-        _lib.wxo_euler3d_rhs.restype = ctypes.c_int
+        for fn in ("wxo_euler3d_extrapolate", "wxo_euler3d_rhs", "wxo_euler3d_extrapolate_c", "wxo_euler3d_rhs_c"):
+            getattr(_lib, fn).restype = ctypes.c_int
     return _lib
 
 
 def _p(a):
-    return a.ctypes.data_as(_P) if a is not None else None
+    return a.ctypes.data_as(_P) if a is not None else None   # (complex128 arrays: interleaved re, im doubles)
 
 
-def _c(a):
-    return numpy.ascontiguousarray(a, dtype=numpy.float64)
+def _c(a, dtype=numpy.float64):
+    return numpy.ascontiguousarray(a, dtype=dtype)
 
 
 class Euler3DPortC(Euler3DOracle):
-    """The NumPy oracle's interface over the C++ kernels (extrapolate, rhs); threads = OpenMP threads per call."""
+    """The NumPy oracle's interface over the C++ kernels (extrapolate, rhs); threads = OpenMP threads per call.
+    float64 or complex128 states (the complex instantiation follows NumPy's abs / maximum rules, so that
+    Im R(Q + i eps v) / eps is the reference's complex-step JVP)."""
 
     def __init__(self, *args, threads: int = 0, **kw):
         super().__init__(*args, **kw)
@@ -84,19 +86,22 @@ class Euler3DPortC(Euler3DOracle):
 
     def extrapolate(self, q):
         n, H, V = self.n, self.H, self.V
-        q = _c(q)
-        itf = [numpy.empty((5, V, H, H, 2 * n * n)) for _ in range(3)]
-        rc = self.lib.wxo_euler3d_extrapolate(n, H, V, _p(self._ops[0]), _p(self._ops[1]), _p(q), _p(itf[0]), _p(itf[1]),
-                                              _p(itf[2]), self.threads)
+        dt = numpy.complex128 if numpy.iscomplexobj(q) else numpy.float64
+        q = _c(q, dt)
+        itf = [numpy.empty((5, V, H, H, 2 * n * n), dtype=dt) for _ in range(3)]
+        fn = self.lib.wxo_euler3d_extrapolate_c if dt is numpy.complex128 else self.lib.wxo_euler3d_extrapolate
+        rc = fn(n, H, V, _p(self._ops[0]), _p(self._ops[1]), _p(q), _p(itf[0]), _p(itf[1]), _p(itf[2]), self.threads)
         assert rc == 0
         return itf
 
     def rhs(self, q, halo, itf=None, want=None):
         n, H, V = self.n, self.H, self.V
-        q = _c(q)
+        dt = numpy.complex128 if numpy.iscomplexobj(q) else numpy.float64
+        q = _c(q, dt)
         if itf is None:
             itf = self.extrapolate(q)
-        halo = [_c(x) for x in halo]
+        itf = [_c(x, dt) for x in itf]
+        halo = [_c(x, dt) for x in halo]
         if self._mc is None:
             m = self.m
             self._mc = {k: _c(m[k]) for k in ("sqrtG_new", "h_contra_new", "christoffel", "inv_dzdeta_new", "sqrtG_itf_i_new",
@@ -105,7 +110,8 @@ class Euler3DPortC(Euler3DOracle):
             self._damp = (_c(m["damp_coef"]), _c(m["damp_uref"])) if self.case_number in (21, 22) else (None, None)
         mc = self._mc
         out = numpy.empty_like(q)
-        rc = self.lib.wxo_euler3d_rhs(
+        fn = self.lib.wxo_euler3d_rhs_c if dt is numpy.complex128 else self.lib.wxo_euler3d_rhs
+        rc = fn(
             n, H, V, self.case_number, _p(self._ops[2]), _p(self._ops[3]), _p(self._ops[4]), _p(q), _p(itf[0]), _p(itf[1]),
             _p(itf[2]), _p(halo[0]), _p(halo[1]), _p(halo[2]), _p(halo[3]), _p(mc["sqrtG_new"]), _p(mc["h_contra_new"]),
             _p(mc["christoffel"]), _p(mc["inv_dzdeta_new"]), _p(mc["sqrtG_itf_i_new"]), _p(mc["sqrtG_itf_j_new"]),

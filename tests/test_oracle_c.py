@@ -43,6 +43,31 @@ def test_port_rhs_matches_reference(name):
         assert (err <= TOL * scale).all(), (name, p, err / scale)
 
 
+@pytest.mark.parametrize("name", ["euler3d_c31p_n3_h4_v2", "euler3d_c31p_n8_h2_v2", "euler3d_c21_n4_h3_v4", "euler3d_c31p_n5_h2_v1"])
+def test_port_complex_step_matches_reference(name):
+    """The complex128 instantiation against R(Q + i eps V) of the reference (solvers/matvec.py:56-61 on rhs_dfr.py):
+    faces and routed halos, real part at the 1e-10 bound, tangent Im R at 1e-10 of its own size."""
+    g = golden(name)
+    for p in g.metric_panels():   # (the perturbation V is stored for these panels only)
+        o = make_port(g, p)
+        sends = o.pack_edges(o.extrapolate(g.q(p, True)))
+        for e, got in enumerate(sends):
+            ref = g.halo(cs.NEIGHBOR[p][e], True)[cs.landing_edge(p, e)]
+            assert np.abs(got.real - ref.real).max() <= 1e-13 * np.abs(ref.real).max(), (p, e)
+            assert np.abs(got.imag - ref.imag).max() <= 1e-12 * np.abs(ref.imag).max(), (p, e)
+    tight = "31p" in name   # see tests/test_oracle_euler3d.py on numpy.maximum's tie-break on symmetric states
+    for p in g.metric_panels():
+        o, ref_o = make_port(g, p), make_oracle(g, p)
+        want = {}
+        ref_o.rhs(g.q(p, True), g.halo(p, True), want=want)
+        R = o.rhs(g.q(p, True), g.halo(p, True))
+        ref = g.r(p, True)
+        s = ref_o.cancel_scale(want)
+        assert (var_err(R.real, ref.real) <= TOL * np.maximum(var_max(ref.real), s)).all(), (name, p)
+        ierr = var_err(R.imag, ref.imag) / np.maximum(var_max(ref.imag), g.eps * s * 1e-3)
+        assert (ierr <= (1e-10 if tight else 1e-3)).all(), (name, p, ierr)
+
+
 def test_thread_count_does_not_change_the_result():
     g = golden("euler3d_c31p_n8_h2_v2")
     p = g.metric_panels()[0]
