@@ -77,27 +77,32 @@ def cpu_baseline_run(flavour, n, H, V, reps, threads, seed, procs=6):
             except Exception:
                 w.kill()
     slow = max(r["s_per_eval"] for r in res)
+    pts = res[0]["dof"] // 5
     return {"dof_updates_per_s": sum(r["dof"] for r in res) / slow, "s_per_eval": round(slow, 4),
             "processes": procs, "threads_per_process": threads, "finite": all(r["finite"] for r in res),
+            # what one process moves, on the SURVEY 8d byte count of the synthetic (27-Christoffel) metric: a weak port shows here
+            "algorithmic_GBps_per_process": round(ALGO_BYTES_PER_POINT * pts / slow / 1e9, 2),
             "tile": f"n={n}, {H}x{H}x{V} elements per process ({res[0]['dof']} DOF)", "evals_timed": reps}
 
 
-def cpu_baseline(n, V, seed):
-    """The CPU path beside the GPU figure, both flavours, six processes (one cube panel each):
-    (2) the optimised C++/OpenMP restatement - `value`; (1) the reference-style dense-Kronecker NumPy restatement."""
+def cpu_baseline(n, V, seed, H=60):
+    """The CPU path beside the GPU figure, as SURVEY.md section 8d writes it: six processes at once, one WHOLE cube panel
+    each (H x H x V elements), OMP/BLAS threads = floor(physical cores / 6), both flavours:
+    (2) the optimised C++/OpenMP restatement - `value`; (1) the reference-style dense-Kronecker NumPy restatement (V = 1)."""
     model, phys, logical = host_cpu()
-    threads = max(1, min(phys, 16) // 6)   # a one-GPU box's CPU share is 16 cores, whatever the host has
+    threads = max(1, phys // 6)
     from oracle import c_port
 
     c_port.load()   # (re)build the C++ port for THIS host once, before six workers would each try to
-    cpp = cpu_baseline_run("cpp", n, 30, V, 3, threads, seed)
-    dense = cpu_baseline_run("dense", n, 30, 1, 2, threads, seed)
+    cpp = cpu_baseline_run("cpp", n, H, V, 5, threads, seed)
+    dense = cpu_baseline_run("dense", n, H, 1, 3, threads, seed)
     return {"value": cpp["dof_updates_per_s"], "unit": "DOF-updates/s", "cores": 6 * threads, "kind": "port",
             "cpu_model": model, "physical_cores": phys, "logical_cpus": logical, "processes": 6,
             "threads_per_process": threads,
             "sample": f"oracle/c/euler3d_port.cpp (sum-factorised C++/OpenMP, pinned by tests/test_oracle_c.py): six "
-                      f"processes x {threads} thread(s), each one 30x30x{V}-element tile of the n={n} workload (a quarter "
-                      f"panel), 3 evals, {cpp['s_per_eval']} s/eval on the slowest",
+                      f"processes x {threads} thread(s) = floor({phys} physical cores / 6), each one whole {H}x{H}x{V}-element "
+                      f"panel of the n={n} workload (the E7 sphere), 5 evals after a warm-up, {cpp['s_per_eval']} s/eval on the "
+                      f"slowest, {cpp['algorithmic_GBps_per_process']} GB/s per process",
             "flavours": {"cpp_openmp_sum_factorised": cpp,
                          "numpy_dense_kronecker_reference_style": dict(dense, note="oracle/euler3d_dense.py: dense n^3 x n^3 "
                                                                        "operators applied with @ as the reference does "
@@ -331,6 +336,47 @@ def e7_v1_extras(dev, seed, n=8, H=60):
             "algorithmic_GBps": round(plans[0].bytes_per_point * pts / te / 1e9, 1)}
 
 
+def jvp_kernel_rooflines(rhs, Q, v, reps=10):
+    """Per-kernel roofline blocks of the prepared complex-step matvec (solvers/matvec.py:56-61), kernel time from HIP
+    events on the launch stream, one panel per launch: euler_jvp_kernel (reads Q, v, the static fields, cached face
+    values and this product's face tangents; stores the real tangent) and the tangent extrapolation in front of it."""
+    from wxfactory_amd import _lib
+
+    eps = 1.4901161193847656e-08
+    rhs.jvp_prepare(Q)
+    try:
+        plans, exv, ext = rhs._jvp_plans(), rhs._ex_val, rhs._ex_tan
+        p = rhs.panels[0]
+        shp = (len(rhs.panels),) + tuple(rhs.panel_shape)
+        q0, v0 = Q.reshape(shp)[0], v.reshape(shp)[0]
+        out = torch.empty_like(q0)
+        t1, t2 = [], []
+        for it in range(reps + 2):
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record()
+            plans[p].jvp_tangent_pack(q0, v0, eps, ext.send_views(p))
+            e1.record()
+            plans[p].jvp_prepared(q0, v0, eps, exv.halo_views(p), ext.halo_views(p), out, 1.0 / eps, _lib.WX_REGION_ALL)
+            e2.record()
+            torch.cuda.synchronize()
+            if it >= 2:
+                t1.append(e0.elapsed_time(e1))
+                t2.append(e1.elapsed_time(e2))
+        pts = q0.numel() // 5
+        n = plans[p].n
+        static = plans[p].bytes_per_point - 80.0          # the RHS kernel's static fields of this plan
+        blocks = {}
+        for name, ms, bpp in (("euler_jvp_kernel", sum(t2) / len(t2), 40.0 + 40.0 + static + 40.0),
+                              ("tangent_extrapolation (euler_extrap_kernel<dual>)", sum(t1) / len(t1), 16.0 + 40.0 + 240.0 / n)):
+            gbs = bpp * pts / (ms * 1e-3) / 1e9
+            blocks[name] = {"bound": "hbm", "launch_ms": round(ms, 4), "algorithmic_bytes_per_point": bpp,
+                            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                            "matrix_cores": bool(plans[p].lib.wx_euler3d_uses_matrix_cores(plans[p]._h, _lib.WX_KERNEL_JVP))}
+        return blocks
+    finally:
+        rhs.jvp_release()
+
+
 def caller_extras(rhs, qs, reps=5):
     """the JVP variants and one explicit step on the SAME plans / metric as the headline (N = 1)."""
     from wxfactory_amd.integrators import Tvdrk3
@@ -375,6 +421,7 @@ def caller_extras(rhs, qs, reps=5):
     out["matvec_roofline"] = {"bound": "hbm", "what": "whole-sphere prepared complex-step matvec (tangent extrapolation + JVP kernel, "
                               "6 panels)", "algorithmic_bytes_per_point": bpp, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    out["jvp_kernels"] = jvp_kernel_rooflines(rhs, Q, v)
     out["tvdrk3_step_ms"] = timeit(step)
     out["tvdrk3_mode"] = "pipelined" if stepper.pipeline else ("fused" if stepper.fused else "plain")
     out["note"] = ("whole sphere, same plans as the headline: complex-step JVP = fused dual-number kernels (wx_euler3d_jvp), "
@@ -451,7 +498,12 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
+            if "MASTER_PORT" not in os.environ:   # a free port, as the tests pick theirs
+                import socket
+
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         else:
             dist.init_process_group("nccl", device_id=dev)
@@ -656,7 +708,7 @@ def main():
             line["extra"]["euler_e7_v1"] = e7_v1_extras(dev, args.seed)
             line["extra"]["rhs_benchmark_matrix"] = rhs_benchmark_matrix(dev, args.seed)
         if args.gpus == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(n, V, args.seed)
+            line["cpu_baseline"] = cpu_baseline(n, V, args.seed, H)
         print(json.dumps(line), flush=True)
     if world > 1 or args.loopback:
         dist.destroy_process_group()
