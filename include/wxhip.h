@@ -127,8 +127,7 @@ wx_status wx_euler3d_plan_create_tile(wx_euler3d_plan** plan, int n, int H, int 
 wx_status wx_euler3d_plan_destroy(wx_euler3d_plan* plan);
 
 /* Values per face point in an edge message: the 5 prognostic variables the reference exchanges
- * (rho, rho u1, rho u2, rho w, rho theta).  (Builds with -DWX_EULER_NQ=6/7 append the face pressure and
- * its logarithm; wx_euler3d_edge_count() always reports the size in use.) */
+ * (rho, rho u1, rho u2, rho w, rho theta). */
 #define WX_EULER3D_EDGE_FIELDS 5
 /* Compulsory HBM bytes per solution point of one wx_euler3d_rhs launch on this plan (SURVEY.md 8d figure:
  * 8 (5 Q + 5 R + sqrtG + 6 h + 27 Gamma + inv_dzdeta) + interface metric = 384 B at n = 8), after the plan-time

@@ -83,13 +83,9 @@ EDGE_FIELDS = 5  # WX_EULER3D_EDGE_FIELDS of the default build
 
 
 def halo7(h5, fields=EDGE_FIELDS):
-    """Edge message of the HIP path from the reference's 5-variable halo face.  The default build
-    exchanges exactly those 5; -DWX_EULER_NQ=6/7 builds append the face pressure and its log
-    (pde_euler_cubesphere.py:158, rhs_dfr.py:113)."""
-    from oracle.euler3d import Rd, cpd, cvd, p0
-
-    p = p0 * np.exp((cpd / cvd) * np.log(h5[4] * (Rd / p0)))
-    return np.concatenate((h5, p[None], np.log(p)[None]), axis=0)[:fields]
+    """Edge message of the HIP path from the reference's halo face: exactly its five variables (the name dates from
+    round-1 builds that also carried the face pressure and its logarithm)."""
+    return np.ascontiguousarray(h5[:fields])
 
 
 SW_FIXTURES = ["sw_c6_n5_h4", "sw_c5_n4_h3", "sw_c2p_n8_h3"]  # (+ sw_tiles24_c5_n4_h2: 24 ranks, tests/test_sw_gpu.py)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: phase timeline of the fused RHS kernel from in-kernel wall-clock stamps
-(needs a library built with -DWX_K2_STAMPS=1; shares, not absolute speed)."""
+(needs a library built with -DWX_K2_DIAG=1; shares, not absolute speed)."""
 import ctypes
 import os
 import sys

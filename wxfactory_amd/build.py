@@ -26,7 +26,7 @@ def _stale():
 
 
 def build(force: bool = False, verbose: bool = False, defines=(), out: str = LIB) -> str:
-    """defines/out: build an experiment variant (e.g. defines=["WX_K2_WAVES=2"], out=".../libwxhip_w2.so");
+    """defines/out: build an experiment variant (e.g. defines=["WX_MFMA=0"], out=".../libwxhip_valu.so");
     pick it at run time with the WXHIP_LIB environment variable."""
     if out == LIB and not force and not _stale():
         return LIB

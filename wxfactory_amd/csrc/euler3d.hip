@@ -11,7 +11,18 @@
 //                           the interface buffer; writes R.  Nothing else touches HBM.
 // Both are element-blocked: a workgroup owns EPB whole elements, one thread per solution
 // point, so every global access is a contiguous n^3 (or n^2) run of doubles.  The dense
-// Kronecker operators of the reference become 1-D contractions staged through LDS.
+// Kronecker operators of the reference become 1-D contractions: on the matrix cores for n = 8 float64
+// (wx_mfma.h), staged through LDS on the vector pipe otherwise.
+//
+// Build-time switches - two, both for measurements, never for behaviour:
+//   WX_MFMA     (wx_mfma.h) 1: n = 8 contractions on v_mfma_f64_4x4x4_4b_f64 (default); 0: vector pipe everywhere -
+//               the A/B build of profiles/r02_k2_valu_*
+//   WX_K2_DIAG  0: the product (default).  Diagnostic builds of the fused kernel, wrong results / extra stores:
+//               1 per-workgroup phase stamps (tools/kstamps.py); 2 skeleton: every load, LDS write and store but no
+//               arithmetic; 3 without the Riemann arithmetic only; 4 without the three directional passes only
+// Everything else that was A/B-tested in rounds 1-2 (LDS swizzles, element orders, load orders, own/neighbour flux
+// forms, non-temporal stores, extra face fields, the 16x16x4 MFMA shape ...) is decided and gone: DESIGN.md 4.1
+// keeps the measurements.
 #include "wx_common.h"
 #include "wx_math.h"
 #include "wx_mfma.h"
@@ -23,67 +34,28 @@
 #include <type_traits>
 #include <vector>
 
-// tuning knobs (A/B-tested on MI355X; defaults are the measured best)
-#ifndef WX_K2_WAVES
-#define WX_K2_WAVES 4   // min waves per SIMD requested for the fused kernel (real dtype)
-#endif
-#ifndef WX_K2_RELOAD_H
-#define WX_K2_RELOAD_H 0   // re-read h_contra rows per direction (L2 hits) instead of holding 6 values
-#endif
-#ifndef WX_K2_EARLY_GAMMA
-#define WX_K2_EARLY_GAMMA 0   // also issue the 27 Christoffel loads before the face stage
-#endif
-#ifndef WX_K2_GAMMA_ROLLED
-#define WX_K2_GAMMA_ROLLED 0  // forcing rows one at a time (9 Christoffel loads in flight, not 27)
-#endif
-#ifndef WX_K2_FIELD_BATCH
-#define WX_K2_FIELD_BATCH 3   // derivative fields contracted per (rolled) batch (7 = fully unrolled: spills)
-#endif
-#ifndef WX_K2_FIELD_BATCH_WIDE
-#define WX_K2_FIELD_BATCH_WIDE 4   // same for the 16-byte dtypes (1 workgroup/CU: a little more ILP pays)
-#endif
-#ifndef WX_ELEM_ORDER
-#define WX_ELEM_ORDER 0   // processing order of elements: 0 = memory order (ek,ej,ei); 1 = vertical columns first
-#endif
-#ifndef WX_XCD_CHUNK
-#define WX_XCD_CHUNK 0    // 1: give each XCD (blockIdx % 8) a contiguous run of the processing order
-#endif
-#ifndef WX_K2_NT_METRIC
-#define WX_K2_NT_METRIC 1 // 1: non-temporal loads for the streamed-once metric fields
-#endif
-#ifndef WX_K2_STAMPS
-#define WX_K2_STAMPS 0   // diagnostic build: per-workgroup phase timestamps (never in the product build)
-#endif
-#ifndef WX_K2_EARLY_LOADS
-#define WX_K2_EARLY_LOADS 1   // issue the point loads before the face stage
-#endif
-
-#ifndef WX_K2_MFMA
-#define WX_K2_MFMA 1      // n = 8, float64: the derivative contractions of the fused kernel on v_mfma_f64_16x16x4_f64
-#endif
-#ifndef WX_K2_MFMA_SHAPE
-#define WX_K2_MFMA_SHAPE 4   // 16: v_mfma_f64_16x16x4_f64 (half of each tile is padding for an 8-row operator);
-                             //  4: v_mfma_f64_4x4x4_4b_f64 (four 4x4x4 blocks per instruction, no padding: half the pipe time)
-#endif
-#ifndef WX_K2_FACE_FIRST
-#define WX_K2_FACE_FIRST 1
-#endif
-#ifndef WX_K2_MF_FB
-#define WX_K2_MF_FB 8   // fields whose operands are in flight together in a matrix-core pass of the fused kernel
-#endif
-#ifndef WX_K2_MFMA_CORR
-#define WX_K2_MFMA_CORR 1 // ... with the two face corrections riding along as a third k-step (D | cm | cp is 8 x 10)
-#endif
-
-#if WX_K2_NT_METRIC
-#define WX_LDM(p) __builtin_nontemporal_load(p)
-#else
-#define WX_LDM(p) (*(p))
+#ifndef WX_K2_DIAG
+#define WX_K2_DIAG 0
 #endif
 
 namespace wx {
 
 constexpr int kMaxN = 8;
+constexpr int NQ = 5;   // values per face point in the interface buffer and in the edge messages: the prognostic variables
+
+// measured optima (A/B on MI355X): compile-time constants, not build knobs
+constexpr int kK1Waves = 1;           // min waves per SIMD requested for the extrapolation kernel
+constexpr int kK2Waves = 4;           // ... for the fused kernel, 8-byte dtypes (n = 8: two workgroups of 8 waves per CU)
+constexpr int kJvpWaves = 4;          // ... for the JVP kernel
+constexpr int kFieldBatch = 3;        // vector-pipe passes: fields contracted per rolled batch (all 7 at once: 241 VGPRs)
+constexpr int kFieldBatchWide = 4;    // ... 16-byte dtypes (one workgroup per CU: a little more ILP pays)
+constexpr int kMfFieldBatch = 8;      // matrix-core passes of the fused kernel: fields whose operands are in flight together
+constexpr int kJvpMfFieldBatch = 4;   // ... of the JVP kernel
+constexpr bool kSkelFace = WX_K2_DIAG == 2 || WX_K2_DIAG == 3;
+constexpr bool kSkelDirs = WX_K2_DIAG == 2 || WX_K2_DIAG == 4;
+
+// the streamed-once static fields go through non-temporal loads
+__device__ __forceinline__ double ldm(const double* p) { return __builtin_nontemporal_load(p); }
 
 template <int N>
 struct Cfg {
@@ -97,68 +69,9 @@ struct Cfg {
     static constexpr int NP = (N % 2 == 0) ? N + 1 : N;
     static constexpr int LE = N2 * NP;  // doubles per element image
     __host__ __device__ static constexpr int lidx(int kl, int jl, int il) { return (kl * N + jl) * NP + il; }
-    // Alternative image for n = 8 (WX_K2_SWIZZLE): same padded rows, column il of row (kl, jl) kept at
-    // il ^ (jl & 4).  A wave is one k-level of 8 x 8 nodes; its 64 k-line reads (and its plane writes) then fall
-    // on every bank pair exactly twice instead of up to three times (SQ_LDS_BANK_CONFLICT: 25 % of the LDS cycles
-    // of the padded image), while i- and j-line reads stay conflict-free.
-    __host__ __device__ static constexpr int lidx_swz(int kl, int jl, int il) {
-        return (kl * N + jl) * NP + (il ^ (jl & (N / 2)));
-    }
 };
 
-// Node m of the line through node (kl, jl, il) along direction d sits at (m < N/2 ? lo : hi) + m * stride of the
-// element's LDS image; lo == hi in the plain padded image, the swizzled one moves half of an i- or j-line.
-struct LdsLine { int lo, hi, stride; };
-template <int N, bool SWZ>
-__device__ __forceinline__ LdsLine lds_line(int d, int kl, int jl, int il) {
-    using C = Cfg<N>;
-    LdsLine L;
-    if (d == 0) {
-        const int r = (kl * N + jl) * C::NP, sft = SWZ ? (jl & (N / 2)) : 0;
-        L.lo = r + sft; L.hi = r - sft; L.stride = 1;
-    } else if (d == 1) {
-        L.lo = kl * N * C::NP + il; L.hi = kl * N * C::NP + (SWZ ? (il ^ (N / 2)) : il); L.stride = C::NP;
-    } else {
-        L.lo = L.hi = jl * C::NP + (SWZ ? (il ^ (jl & (N / 2))) : il); L.stride = N * C::NP;
-    }
-    return L;
-}
-#define WX_LINE_AT(L, m) (((m) < N / 2 ? (L).lo : (L).hi) + (m) * (L).stride)
-
 enum { F_W = 0, F_E = 1, F_S = 2, F_N = 3, F_B = 4, F_T = 5 };
-// values per face point in the interface buffer and in the edge messages.  5 = the prognostic
-// variables, exactly the reference's q_itf (default: measured fastest - the kernel is HBM-bound and
-// the two extra streams cost more than redoing exp(gamma*log(.)) on both sides of a face);
-// 6 / 7 additionally carry the face pressure / its logarithm (pde_euler_cubesphere.py:158-160).
-#ifndef WX_UNIFORM_FACE
-#define WX_UNIFORM_FACE 1  // 1: face index made wave-uniform (readfirstlane) where a face is whole waves (n = 8)
-#endif
-#ifndef WX_K2_OWN_FORM
-#define WX_K2_OWN_FORM 0   // 1: Rusanov flux in own/neighbour form (rusanov_own) instead of left/right copies
-#endif
-#ifndef WX_K2_SWIZZLE
-#define WX_K2_SWIZZLE 0   // 1: XOR-swizzled LDS image in the fused kernel's directional passes (n = 8, plain stage)
-#endif
-#ifndef WX_K1_WAVES
-#define WX_K1_WAVES 1   // minimum waves per SIMD requested for the extrapolation kernel (register cap = 512 / waves)
-#endif
-#ifndef WX_K2_UNROLL_DIRS
-#define WX_K2_UNROLL_DIRS 1  // 1: one copy of the directional pass per direction: constant LDS strides, so the
-                             // reads pair up as ds_read2_b64 with immediate offsets (half the LDS instructions)
-#endif
-#ifndef WX_K2_SKELETON
-#define WX_K2_SKELETON 0   // diagnostic build: K2 keeps its loads, LDS writes and stores but skips the arithmetic
-#endif
-#ifndef WX_K2_SKEL_FACE
-#define WX_K2_SKEL_FACE WX_K2_SKELETON   // ... only the Riemann arithmetic of the face stage
-#endif
-#ifndef WX_K2_SKEL_DIRS
-#define WX_K2_SKEL_DIRS WX_K2_SKELETON   // ... only the three directional passes
-#endif
-#ifndef WX_EULER_NQ
-#define WX_EULER_NQ 5   // 7: state + p + log p;  6: state + p;  5: state only (pressures redone per side)
-#endif
-constexpr int NQ = WX_EULER_NQ;
 
 // 1-D operator pieces and the tile's edge tables, in device memory (one copy per plan): dynamic
 // indexing into a by-value kernel argument would force the whole struct into scratch.
@@ -200,14 +113,14 @@ struct EulerParams {
     const double *hv_s, *hv_n, *hv_w, *hv_e;
     const T* q;
     T* rhs;
-    T* itf;  // [elem][6 faces][NQ = 5 vars + pressure + log pressure][N2]
+    T* itf;  // [elem][6 faces][NQ vars][N2]
     const T *halo_s, *halo_n, *halo_w, *halo_e;
     T *send_s, *send_n, *send_w, *send_e;
     const double *sg, *h, *chr, *idz;
     const double *sgi, *sgj, *sgk, *hi, *hj, *hk;
     const double *dcoef, *duref, *bsn, *bwe;
     const EulerConsts* K;  // device memory
-    unsigned long long* stamps;  // diagnostic builds only (WX_K2_STAMPS), else null
+    unsigned long long* stamps;  // WX_K2_DIAG == 1 only, else null
 };
 
 struct Elem {
@@ -215,33 +128,15 @@ struct Elem {
     bool valid;
 };
 
-// workgroup -> position in the processing order.  Workgroups are dealt round-robin to the 8 XCDs
-// (speed only, never correctness): with WX_XCD_CHUNK each XCD walks a contiguous run, so the two
-// elements that read a face (owner and neighbour) tend to share an L2.
-__device__ __forceinline__ int block_slot(int nblocks) {
-#if WX_XCD_CHUNK
-    const int b = blockIdx.x, per = nblocks / 8;
-    return b < per * 8 ? (b % 8) * per + b / 8 : b;  // bijection; the ragged tail (< 8 blocks) maps to itself
-#else
-    return blockIdx.x;
-#endif
-}
-
-// slot (position in this launch's processing order) -> element of the tile
+// slot (position in this launch's processing order = memory order of the region's elements) -> element of the tile
 __device__ __forceinline__ Elem decode_elem(int slot, int count, int region, int H, int V) {
     Elem r;
     r.valid = slot < count;
     if (!r.valid) slot = 0;
     if (region == WX_REGION_ALL) {
-#if WX_ELEM_ORDER == 1
-        r.ek = slot % V;
-        r.ei = (slot / V) % H;
-        r.ej = slot / (V * H);
-#else
         r.ei = slot % H;
         r.ej = (slot / H) % H;
         r.ek = slot / (H * H);
-#endif
     } else if (region == WX_REGION_INTERIOR) {
         const int w = H - 2;
         r.ei = 1 + slot % w;
@@ -321,19 +216,10 @@ __device__ __forceinline__ void load_state<dual>(const EulerParams<dual>& P, siz
     }
 }
 
-#ifndef WX_NT_STORE
-#define WX_NT_STORE 0   // 1: the RHS output leaves with non-temporal stores (measured: see DESIGN 4.1)
-#endif
 template <typename T>
 __device__ __forceinline__ void store_r(const EulerParams<T>& P, size_t i, T r) {
     P.rhs[i] = r;
 }
-#if WX_NT_STORE
-template <>
-__device__ __forceinline__ void store_r<double>(const EulerParams<double>& P, size_t i, double r) {
-    __builtin_nontemporal_store(r, &P.rhs[i]);
-}
-#endif
 template <>
 __device__ __forceinline__ void store_r<dual>(const EulerParams<dual>& P, size_t i, dual r) {
     if (P.jvp) P.out_tan[i] = P.jvp_scale * r.im;
@@ -355,11 +241,9 @@ __device__ __forceinline__ void extrap_faces(const EulerParams<T>& P, T (*fld)[C
         const int r = fi % (6 * N2);
         int f = r / N2;
         const int fp = r % N2;
-#if WX_UNIFORM_FACE
         // a face is a whole number of waves when n^2 is a multiple of 64 (n = 8): tell the compiler, so that the
         // face's direction, strides and weights live in scalar registers
         if (N2 % 64 == 0 && BS % 64 == 0) f = __builtin_amdgcn_readfirstlane(f);
-#endif
         const Elem el = decode_elem(slot0 + le, count, region, H, V);
         if (!el.valid) continue;
         const int d = f >> 1, plus = f & 1;
@@ -379,14 +263,8 @@ __device__ __forceinline__ void extrap_faces(const EulerParams<T>& P, T (*fld)[C
 #pragma unroll
             for (int v = 0; v < 5; ++v) s[v] += wm * fld[v][le * C::LE + base + m * stride];
         }
-        const T s4log = s[4];
         s[0] = w_exp(s[0]);
         s[4] = w_exp(s[4]);
-        // face pressure p0*exp(gamma*log(rho_theta*Rd/p0)) (pde_euler_cubesphere.py:158) and its log
-        // (rhs_dfr.py:113-115); log(rho_theta) is the extrapolated value itself, so no logarithm is needed
-        const T glog = kGamma * (s4log + kLogRdOverP0);
-        const T pf = kP0 * w_exp(glog);
-        const T lpf = kLogP0 + glog;
         bool tan_only = false;
         if constexpr (std::is_same<T, dual>::value) tan_only = P.split == 2;
         if constexpr (std::is_same<T, dual>::value) {
@@ -400,8 +278,6 @@ __device__ __forceinline__ void extrap_faces(const EulerParams<T>& P, T (*fld)[C
             T* dst = itf_dst + ((size_t)el.e * 6 + f) * NQ * N2 + fp;
 #pragma unroll
             for (int v = 0; v < 5; ++v) dst[v * N2] = s[v];
-            if (NQ > 5) dst[5 * N2] = pf;
-            if (NQ > 6) dst[6 * N2] = lpf;
         }
 
         // outward faces of the tile edge: rotate into the neighbour's basis, flip, pack
@@ -434,8 +310,6 @@ __device__ __forceinline__ void extrap_faces(const EulerParams<T>& P, T (*fld)[C
             T* out = sendp + eo;
 #pragma unroll
             for (int v = 0; v < 5; ++v) out[v * vs] = s[v];
-            if (NQ > 5) out[5 * vs] = pf;
-            if (NQ > 6) out[6 * vs] = lpf;
         }
     }
 }
@@ -446,7 +320,7 @@ __device__ __forceinline__ void extrap_faces(const EulerParams<T>& P, T (*fld)[C
 template <int N, typename T>
 __device__ __forceinline__ void euler_extrap_body(const EulerParams<T>& P) {
     using C = Cfg<N>;
-    constexpr int N2 = C::N2, N3 = C::N3, EPB = C::EPB, BS = C::BS;
+    constexpr int N2 = C::N2, N3 = C::N3, EPB = C::EPB;
     __shared__ T fld[5][EPB * C::LE];
 
     const int tid = threadIdx.x;
@@ -474,7 +348,7 @@ __device__ __forceinline__ void euler_extrap_body(const EulerParams<T>& P) {
 }
 
 template <int N, typename T>
-__global__ __launch_bounds__(Cfg<N>::BS, WX_K1_WAVES) void euler_extrap_kernel(const EulerParams<T> P) {
+__global__ __launch_bounds__(Cfg<N>::BS, kK1Waves) void euler_extrap_kernel(const EulerParams<T> P) {
     euler_extrap_body<N, T>(P);
 }
 
@@ -506,8 +380,8 @@ __device__ __forceinline__ void batch_state(EulerParams<T>& P, const EulerBatchD
 }
 
 template <int N, typename T>
-__global__ __launch_bounds__(Cfg<N>::BS, WX_K1_WAVES) void euler_extrap_batch_kernel(const EulerParams<T>* table,
-                                                                                     const EulerBatchDyn<T> dyn) {
+__global__ __launch_bounds__(Cfg<N>::BS, kK1Waves) void euler_extrap_batch_kernel(const EulerParams<T>* table,
+                                                                                  const EulerBatchDyn<T> dyn) {
     EulerParams<T> P = table[blockIdx.y];
     batch_state<T>(P, dyn);
     euler_extrap_body<N, T>(P);
@@ -589,43 +463,42 @@ struct FaceIn {
 // interface metric.  Separate from the arithmetic so that a kernel can issue them early.
 template <int N, typename T>
 __device__ __forceinline__ void face_load(const EulerParams<T>& P, const Elem& el, int f, int fp, FaceIn<T>& in) {
-    static_assert(NQ == 5, "face_load reads the five prognostic face values");
     constexpr int N2 = N * N;
     const int H = P.H, V = P.V;
-        const int d = f >> 1, plus = f & 1;
-        const size_t vsh = (size_t)V * H * N2;  // var stride in a halo edge message
+    const int d = f >> 1, plus = f & 1;
+    const size_t vsh = (size_t)V * H * N2;  // var stride in a halo edge message
 
-        const T* own = P.itf + ((size_t)el.e * 6 + f) * NQ * N2 + fp;
-        const T* nbr;
-        size_t nstride = N2;
-        bool mirror = false, from_halo = false;
-        const double *sgp, *hp;
-        size_t hfs;  // field stride of the h_contra_itf array
-        if (d == 0) {
-            const int ne = el.ei + (plus ? 1 : -1);
-            if (ne >= 0 && ne < H) nbr = P.itf + ((size_t)(el.e + (plus ? 1 : -1)) * 6 + (f ^ 1)) * NQ * N2 + fp;
-            else { nbr = (plus ? P.halo_e : P.halo_w) + ((size_t)el.ek * H + el.ej) * N2 + fp; nstride = vsh; from_halo = true; }
-            const size_t o = (((size_t)el.ek * H + el.ej) * (H + 2) + el.ei + 1) * 2 * N2 + plus * N2 + fp;
-            hfs = (size_t)V * H * (H + 2) * 2 * N2;
-            sgp = P.sgi + o;
-            hp = P.hi + 0 * 3 * hfs + o;
-        } else if (d == 1) {
-            const int ne = el.ej + (plus ? 1 : -1);
-            if (ne >= 0 && ne < H) nbr = P.itf + ((size_t)(el.e + (plus ? H : -H)) * 6 + (f ^ 1)) * NQ * N2 + fp;
-            else { nbr = (plus ? P.halo_n : P.halo_s) + ((size_t)el.ek * H + el.ei) * N2 + fp; nstride = vsh; from_halo = true; }
-            const size_t o = (((size_t)el.ek * (H + 2) + el.ej + 1) * H + el.ei) * 2 * N2 + plus * N2 + fp;
-            hfs = (size_t)V * (H + 2) * H * 2 * N2;
-            sgp = P.sgj + o;
-            hp = P.hj + 1 * 3 * hfs + o;
-        } else {
-            const int ne = el.ek + (plus ? 1 : -1);
-            if (ne >= 0 && ne < V) nbr = P.itf + ((size_t)(el.e + (plus ? H * H : -H * H)) * 6 + (f ^ 1)) * NQ * N2 + fp;
-            else { nbr = own; mirror = true; }
-            const size_t o = ((((size_t)el.ek + 1) * H + el.ej) * H + el.ei) * 2 * N2 + plus * N2 + fp;
-            hfs = (size_t)(V + 2) * H * H * 2 * N2;
-            sgp = P.sgk + o;
-            hp = P.hk + 2 * 3 * hfs + o;
-        }
+    const T* own = P.itf + ((size_t)el.e * 6 + f) * NQ * N2 + fp;
+    const T* nbr;
+    size_t nstride = N2;
+    bool mirror = false, from_halo = false;
+    const double *sgp, *hp;
+    size_t hfs;  // field stride of the h_contra_itf array
+    if (d == 0) {
+        const int ne = el.ei + (plus ? 1 : -1);
+        if (ne >= 0 && ne < H) nbr = P.itf + ((size_t)(el.e + (plus ? 1 : -1)) * 6 + (f ^ 1)) * NQ * N2 + fp;
+        else { nbr = (plus ? P.halo_e : P.halo_w) + ((size_t)el.ek * H + el.ej) * N2 + fp; nstride = vsh; from_halo = true; }
+        const size_t o = (((size_t)el.ek * H + el.ej) * (H + 2) + el.ei + 1) * 2 * N2 + plus * N2 + fp;
+        hfs = (size_t)V * H * (H + 2) * 2 * N2;
+        sgp = P.sgi + o;
+        hp = P.hi + 0 * 3 * hfs + o;
+    } else if (d == 1) {
+        const int ne = el.ej + (plus ? 1 : -1);
+        if (ne >= 0 && ne < H) nbr = P.itf + ((size_t)(el.e + (plus ? H : -H)) * 6 + (f ^ 1)) * NQ * N2 + fp;
+        else { nbr = (plus ? P.halo_n : P.halo_s) + ((size_t)el.ek * H + el.ei) * N2 + fp; nstride = vsh; from_halo = true; }
+        const size_t o = (((size_t)el.ek * (H + 2) + el.ej + 1) * H + el.ei) * 2 * N2 + plus * N2 + fp;
+        hfs = (size_t)V * (H + 2) * H * 2 * N2;
+        sgp = P.sgj + o;
+        hp = P.hj + 1 * 3 * hfs + o;
+    } else {
+        const int ne = el.ek + (plus ? 1 : -1);
+        if (ne >= 0 && ne < V) nbr = P.itf + ((size_t)(el.e + (plus ? H * H : -H * H)) * 6 + (f ^ 1)) * NQ * N2 + fp;
+        else { nbr = own; mirror = true; }
+        const size_t o = ((((size_t)el.ek + 1) * H + el.ej) * H + el.ei) * 2 * N2 + plus * N2 + fp;
+        hfs = (size_t)(V + 2) * H * H * 2 * N2;
+        sgp = P.sgk + o;
+        hp = P.hk + 2 * 3 * hfs + o;
+    }
     bool split = false;
     if constexpr (std::is_same<T, dual>::value) split = P.split == 1;
     if constexpr (std::is_same<T, dual>::value) {
@@ -652,14 +525,8 @@ __device__ __forceinline__ void face_load(const EulerParams<T>& P, const Elem& e
     if (!split) {
 #pragma unroll
         for (int v = 0; v < 5; ++v) {
-#ifdef WX_K2_FAKE_OWN   /* diagnostic build (wrong results): the own-side face values are never loaded - what the kernel
-                           would gain, in time and in HBM bytes, if they came for free */
-            in.qn[v] = nbr[v * nstride];
-            in.qo[v] = in.qn[v] * 1.0000001;
-#else
             in.qo[v] = own[v * N2];
             in.qn[v] = nbr[v * nstride];
-#endif
         }
     }
     in.sg = *sgp; in.h0 = hp[0]; in.h1 = hp[hfs]; in.h2 = hp[2 * hfs];
@@ -681,8 +548,7 @@ __device__ __forceinline__ void face_flux(const FaceIn<T>& in, int f, bool advec
     qo[5] = kP0 * w_exp(go); qn[5] = kP0 * w_exp(gn);
     qo[6] = kLogP0 + go; qn[6] = kLogP0 + gn;
     const double sg = in.sg, h0 = in.h0, h1 = in.h1, h2 = in.h2;
-#if WX_K2_SKEL_FACE
-    {   // diagnostic: every load consumed, no Riemann arithmetic
+    if (kSkelFace) {   // diagnostic builds: every load consumed, no Riemann arithmetic
         T sum = T(sg + h0 + h1 + h2);
 #pragma unroll
         for (int v = 0; v < 5; ++v) sum += in.qo[v] + in.qn[v];
@@ -690,7 +556,6 @@ __device__ __forceinline__ void face_flux(const FaceIn<T>& in, int f, bool advec
         for (int c = 0; c < 7; ++c) out[c] = sum;
         return;
     }
-#endif
     const double hdd = d == 0 ? h0 : (d == 1 ? h1 : h2);
     const T ro = 1.0 / qo[0], rn = 1.0 / qn[0];
     // (explicit selects: a run-time index into a register array of 16-byte values goes to scratch)
@@ -723,8 +588,74 @@ __device__ __forceinline__ void face_problem(const EulerParams<T>& P, const Elem
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: fused phases 3-8
+// K2: fused phases 3-8.  The body is a sequence of stages, each a device function below:
+//   face loads (n = 8: issued first)  ->  point loads  ->  face stage (Riemann problems -> LDS)  ->  pointwise
+//   quantities + forcing  ->  three directional passes (matrix cores or vector pipe)  ->  epilogue (scaling, fused
+//   stage update, optional filter + NaN flag, store, optional extrapolation of the output for the next stage).
 // ------------------------------------------------------------------------------------------------
+// what a thread holds of its solution point after the loads
+template <typename T>
+struct PointIn {
+    T q0, q1, q2, q3, q4;
+    double sg, h00, h01, h02, h11, h12, h22;
+};
+
+template <typename T>
+__device__ __forceinline__ void k2_point_loads(const EulerParams<T>& P, bool active, size_t o, size_t fs, PointIn<T>& S) {
+    S.q0 = T(1.0); S.q1 = T(0.0); S.q2 = T(0.0); S.q3 = T(0.0); S.q4 = T(1.0);
+    S.sg = 1.0; S.h00 = S.h01 = S.h02 = S.h11 = S.h12 = S.h22 = 0.0;
+    if (active) {
+        load_state<T>(P, o, fs, S.q0, S.q1, S.q2, S.q3, S.q4);
+        S.sg = ldm(P.sg + o);
+        S.h00 = ldm(P.h + 0 * fs + o); S.h01 = ldm(P.h + 1 * fs + o); S.h02 = ldm(P.h + 2 * fs + o);
+        S.h11 = ldm(P.h + 4 * fs + o); S.h12 = ldm(P.h + 5 * fs + o); S.h22 = ldm(P.h + 8 * fs + o);
+    }
+}
+
+// forcing of the three momentum rows, all but the gravity filter (pde_euler_cubesphere.py:12-25, 203-290), from the 27
+// (18 on a non-rotating planet) Christoffel fields, all loads in flight together; gcoef = inv_dzdeta * g
+template <typename T>
+__device__ __forceinline__ void k2_forcing(const EulerParams<T>& P, bool active, size_t o, size_t fs, const PointIn<T>& S, T u1,
+                                           T u2, T u3, T p, T& fc0, T& fc1, T& fc2, double& gcoef) {
+    double cg[27], idzv = 0.0;
+    if (active && P.rot_zero) {   // non-rotating planet: the 9 rotation symbols are identically zero
+#pragma unroll
+        for (int i = 0; i < 27; ++i) cg[i] = (i % 9) < 3 ? 0.0 : ldm(P.chr + (size_t)i * fs + o);
+        idzv = ldm(P.idz + o);
+    } else if (active) {
+#pragma unroll
+        for (int i = 0; i < 27; ++i) cg[i] = ldm(P.chr + (size_t)i * fs + o);
+        idzv = ldm(P.idz + o);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 27; ++i) cg[i] = 0.0;
+    }
+    fc0 = T(0.0); fc1 = T(0.0); fc2 = T(0.0);
+    gcoef = 0.0;
+    if (active) {
+        const T q0 = S.q0;
+        T fc[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double* c = cg + i * 9;
+            const double c01 = c[0], c02 = c[1], c03 = c[2], c11 = c[3], c12 = c[4], c13 = c[5],
+                         c22 = c[6], c23 = c[7], c33 = c[8];
+            fc[i] = 2.0 * q0 * (c01 * u1 + c02 * u2 + c03 * u3) + c11 * (q0 * u1 * u1 + S.h00 * p) +
+                    2.0 * c12 * (q0 * u1 * u2 + S.h01 * p) + 2.0 * c13 * (q0 * u1 * u3 + S.h02 * p) +
+                    c22 * (q0 * u2 * u2 + S.h11 * p) + 2.0 * c23 * (q0 * u2 * u3 + S.h12 * p) +
+                    c33 * (q0 * u3 * u3 + S.h22 * p);
+        }
+        if (P.has_damp) {
+            const T dw = P.dcoef[o] * q0;
+            fc[0] += dw * (u1 - P.duref[o]);
+            fc[1] += dw * (u2 - P.duref[fs + o]);
+            fc[2] += dw * (u3 - P.duref[2 * fs + o]);
+        }
+        fc0 = fc[0]; fc1 = fc[1]; fc2 = fc[2];
+        gcoef = idzv * kGravity;
+    }
+}
+
 template <int N, typename T, bool PIPE>
 __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
     using C = Cfg<N>;
@@ -732,20 +663,18 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
     constexpr int NF = 8;   // staged fields: 4 F rows, A, B (per direction) + log p + sqrtG*rho
     constexpr int NC = 7;   // face quantities, see rusanov_face
     // matrix-core path for the derivative contractions (n = 8, float64); everything else keeps the vector path
-    constexpr bool MF = WX_K2_MFMA && N == 8 && std::is_same<T, double>::value;
-    constexpr bool MFC = MF && WX_K2_MFMA_CORR;   // face corrections inside the MFMA (third k-step)
+    constexpr bool MF = WX_MFMA && N == 8 && std::is_same<T, double>::value;
     static_assert(!MF || (EPB == 1 && C::LE == kMfLE), "the MFMA pass owns one n = 8 element per workgroup");
     constexpr int FST = NC * N2 + (MF ? kMfFS - 7 * 64 : 0);   // doubles per face in the face-flux image
     // One LDS block: the field images, then the face-flux image.  Matrix-core path: 7 images suffice - the eighth field
     // (sqrtG rho, vertical pass only) lands on the face fluxes of the first direction, which are dead by then - and the
-    // operator tables are not needed (they sit in the lanes' MFMA operands): 54.5 KB, three workgroups per CU fit.
+    // operator tables are not needed (they sit in the lanes' MFMA operands): 54.5 KB.
     constexpr int NFI = MF ? 7 : NF;
-    constexpr bool NEED_OPS = !MF || !MFC;
     __shared__ T smem[NFI * EPB * C::LE + EPB * 6 * FST];
     T(*fld)[EPB * C::LE] = reinterpret_cast<T(*)[EPB * C::LE]>(smem);
     T* frs = smem + NFI * EPB * C::LE;
 #define WX_FR(le_, f_, c_, fp_) frs[((le_) * 6 + (f_)) * FST + (c_) * N2 + (fp_)]
-    __shared__ double sD[NEED_OPS ? N * N : 1], sHF[NEED_OPS ? N * N : 1], sCm[NEED_OPS ? N : 1], sCp[NEED_OPS ? N : 1];
+    __shared__ double sD[MF ? 1 : N * N], sHF[MF ? 1 : N * N], sCm[MF ? 1 : N], sCp[MF ? 1 : N];
     __shared__ double sEF[(PIPE && !MF) ? N * N : 1];
 
     const int tid = threadIdx.x;
@@ -753,7 +682,7 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
     const size_t fs = (size_t)P.nelem * N3;
     if (PIPE && !MF && P.efilter)
         for (int i = tid; i < N * N; i += BS) sEF[i] = P.K->EF[i];
-#if WX_K2_STAMPS
+#if WX_K2_DIAG == 1
 #define WX_STAMP(i)                                                                           \
     do {                                                                                      \
         __syncthreads();                                                                      \
@@ -764,7 +693,7 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
 #endif
     WX_STAMP(0);
 
-    if (NEED_OPS) {
+    if (!MF) {
         for (int i = tid; i < N * N; i += BS) {
             sD[i] = P.K->D[i];
             sHF[i] = P.K->HF[i];
@@ -775,95 +704,55 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
         }
     }
 
-    // ---- point loads first: in flight while the face stage computes
     const int le = tid / N3, pt = tid % N3;
-    const Elem el = decode_elem(block_slot(gridDim.x) * EPB + le, P.count, P.region, H, V);
+    const Elem el = decode_elem(blockIdx.x * EPB + le, P.count, P.region, H, V);
     const bool active = (le < EPB) && el.valid;
     const int kl = pt / N2, jl = (pt / N) % N, il = pt % N;
     const int lb = (le < EPB ? le : 0) * C::LE;  // LDS base of this thread's element
-    constexpr bool SWZ = WX_K2_SWIZZLE && N == 8 && !PIPE && !is_complex<T>::value && !MF;
-    const int lpt = lb + (SWZ ? C::lidx_swz(kl, jl, il) : C::lidx(kl, jl, il));  // this thread's node in the LDS image
-    const int lptm = mf_idx(kl, jl, il);   // ... and in the image of the matrix-core passes
-    MfOps mops{0.0, 0.0, 0.0, 0.0, 0.0};
+    const int lpt = lb + C::lidx(kl, jl, il);    // this thread's node in the LDS image
+    const int lptm = mf_idx(kl, jl, il);         // ... and in the image of the matrix-core passes
     MfOps4 mops4{0.0, 0.0, 0.0, 0.0, 0.0};
-    if (MF && WX_K2_MFMA_SHAPE == 16) mops = mf_load_ops(P.K->D, P.K->cm, P.K->cp, P.K->HF, tid & 63);
-    if (MF && WX_K2_MFMA_SHAPE == 4) mops4 = mf4_load_ops(P.K->D, P.K->cm, P.K->cp, P.K->HF, tid & 63);
+    if (MF) mops4 = mf4_load_ops(P.K->D, P.K->cm, P.K->cp, P.K->HF, tid & 63);
     const size_t o = (size_t)el.e * N3 + pt;
 
-    T q0 = T(1.0), q1 = T(0.0), q2 = T(0.0), q3 = T(0.0), q4 = T(1.0);
-    double sg = 1.0, h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0;
-#define WX_Q_LOADS()                                                                                       \
-    if (active) {                                                                                          \
-        load_state<T>(P, o, fs, q0, q1, q2, q3, q4);                                                       \
-    }
-#define WX_PMETRIC_LOADS()                                                                                 \
-    if (active) {                                                                                          \
-        sg = WX_LDM(P.sg + o);                                                                             \
-        h00 = WX_LDM(P.h + 0 * fs + o); h01 = WX_LDM(P.h + 1 * fs + o); h02 = WX_LDM(P.h + 2 * fs + o);    \
-        h11 = WX_LDM(P.h + 4 * fs + o); h12 = WX_LDM(P.h + 5 * fs + o); h22 = WX_LDM(P.h + 8 * fs + o);    \
-    }
-#define WX_POINT_LOADS() WX_Q_LOADS() WX_PMETRIC_LOADS()
-    // n = 8: one face point per thread (384 of 512).  WX_K2_FACE_FIRST issues the face loads BEFORE the point loads:
-    // vector-memory results return in issue order, so the face stage (the first consumer) no longer waits for the
-    // twelve point loads queued in front of its own fourteen
-    constexpr bool FACE_FIRST = WX_K2_FACE_FIRST && N == 8 && EPB == 1 && WX_K2_EARLY_LOADS;
+    // ---- loads.  n = 8: one face point per thread (384 of 512) and the face loads go FIRST: vector-memory results return
+    // in issue order, so the face stage (the first consumer) does not wait for the twelve point loads queued behind
+    constexpr bool FACE_FIRST = N == 8 && EPB == 1;
     FaceIn<T> fin_first;
     int ff_first = 0;
     if constexpr (FACE_FIRST) {
         ff_first = __builtin_amdgcn_readfirstlane(tid / N2);
         if (tid < 6 * N2 && el.valid) face_load<N, T>(P, el, ff_first, tid % N2, fin_first);
     }
-#if WX_K2_EARLY_LOADS
-    WX_POINT_LOADS()
-#endif
-#if !WX_K2_GAMMA_ROLLED
-    double cg[27], idzv = 0.0;
-#define WX_GAMMA_LOADS()                                                        \
-    if (active && P.rot_zero) { /* non-rotating planet: the 9 rotation symbols are identically zero */ \
-        _Pragma("unroll") for (int i = 0; i < 27; ++i)                          \
-            cg[i] = (i % 9) < 3 ? 0.0 : WX_LDM(P.chr + (size_t)i * fs + o);     \
-        idzv = WX_LDM(P.idz + o);                                               \
-    } else if (active) {                                                        \
-        _Pragma("unroll") for (int i = 0; i < 27; ++i) cg[i] = WX_LDM(P.chr + (size_t)i * fs + o); \
-        idzv = WX_LDM(P.idz + o);                                               \
-    } else {                                                                    \
-        _Pragma("unroll") for (int i = 0; i < 27; ++i) cg[i] = 0.0;             \
-    }
-#if WX_K2_EARLY_GAMMA
-    WX_GAMMA_LOADS()
-#endif
-#endif
+    PointIn<T> S;
+    k2_point_loads<T>(P, active, o, fs, S);   // in flight while the face stage computes
+    const T q0 = S.q0, q1 = S.q1, q2 = S.q2, q3 = S.q3, q4 = S.q4;
+    const double sg = S.sg;
 
     // ---- face stage: Riemann problems of all 6 faces of the block's elements -> LDS
     if constexpr (FACE_FIRST) {
         if (tid < 6 * N2 && el.valid) {
             T out[NC];
-            face_flux<T, WX_K2_OWN_FORM != 0>(fin_first, ff_first, P.advection_only, out);
+            face_flux<T>(fin_first, ff_first, P.advection_only, out);
 #pragma unroll
             for (int c = 0; c < NC; ++c) WX_FR(0, ff_first, c, tid % N2) = out[c];
         }
     }
     for (int fi = tid; fi < (FACE_FIRST ? 0 : EPB * 6 * N2); fi += BS) {
-        const int le = fi / (6 * N2);
+        const int fle = fi / (6 * N2);
         const int r = fi % (6 * N2);
         int f = r / N2;
         const int fp = r % N2;
-#if WX_UNIFORM_FACE
         if (N2 % 64 == 0 && BS % 64 == 0) f = __builtin_amdgcn_readfirstlane(f);
-#endif
-        const Elem el = decode_elem(block_slot(gridDim.x) * EPB + le, P.count, P.region, H, V);
-        if (!el.valid) continue;
+        const Elem fel = decode_elem(blockIdx.x * EPB + fle, P.count, P.region, H, V);
+        if (!fel.valid) continue;
         T out[NC];
-        face_problem<N, T, WX_K2_OWN_FORM != 0>(P, el, f, fp, out);
+        face_problem<N, T>(P, fel, f, fp, out);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) WX_FR(le, f, c, fp) = out[c];
+        for (int c = 0; c < NC; ++c) WX_FR(fle, f, c, fp) = out[c];
     }
-
     WX_STAMP(1);
-#if !WX_K2_EARLY_LOADS
-    WX_POINT_LOADS()
-#endif
-#undef WX_POINT_LOADS
+
     // ---- pointwise quantities
     const T rinv = 1.0 / q0;
     const T u1 = q1 * rinv, u2 = q2 * rinv, u3 = q3 * rinv;
@@ -875,89 +764,35 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
         fld[7][lpt] = sg * q0;
     }
 
-    // ---- forcing, all but the gravity filter (pde_euler_cubesphere.py:12-25, 203-290)
-    T fc0 = T(0.0), fc1 = T(0.0), fc2 = T(0.0);
-    double gcoef = 0.0;
-#if WX_K2_GAMMA_ROLLED
-    if (active) {
-#pragma unroll 1
-        for (int i = 0; i < 3; ++i) {
-            const double* c = P.chr + (size_t)(i * 9) * fs + o;
-            const double c01 = c[0], c02 = c[fs], c03 = c[2 * fs], c11 = c[3 * fs], c12 = c[4 * fs], c13 = c[5 * fs],
-                         c22 = c[6 * fs], c23 = c[7 * fs], c33 = c[8 * fs];
-            T f = 2.0 * q0 * (c01 * u1 + c02 * u2 + c03 * u3) + c11 * (q0 * u1 * u1 + h00 * p) +
-                  2.0 * c12 * (q0 * u1 * u2 + h01 * p) + 2.0 * c13 * (q0 * u1 * u3 + h02 * p) +
-                  c22 * (q0 * u2 * u2 + h11 * p) + 2.0 * c23 * (q0 * u2 * u3 + h12 * p) +
-                  c33 * (q0 * u3 * u3 + h22 * p);
-            if (P.has_damp) f += (P.dcoef[o] * q0) * ((i == 0 ? u1 : (i == 1 ? u2 : u3)) - P.duref[(size_t)i * fs + o]);
-            if (i == 0) fc0 = f;
-            else if (i == 1) fc1 = f;
-            else fc2 = f;
-        }
-        gcoef = P.idz[o] * kGravity;
-    }
-#else
-#if !WX_K2_EARLY_GAMMA
-    WX_GAMMA_LOADS()
-#endif
-#undef WX_GAMMA_LOADS
-    if (active) {
-        T fc[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const double* c = cg + i * 9;
-            const double c01 = c[0], c02 = c[1], c03 = c[2], c11 = c[3], c12 = c[4], c13 = c[5],
-                         c22 = c[6], c23 = c[7], c33 = c[8];
-            fc[i] = 2.0 * q0 * (c01 * u1 + c02 * u2 + c03 * u3) + c11 * (q0 * u1 * u1 + h00 * p) +
-                    2.0 * c12 * (q0 * u1 * u2 + h01 * p) + 2.0 * c13 * (q0 * u1 * u3 + h02 * p) +
-                    c22 * (q0 * u2 * u2 + h11 * p) + 2.0 * c23 * (q0 * u2 * u3 + h12 * p) +
-                    c33 * (q0 * u3 * u3 + h22 * p);
-        }
-        if (P.has_damp) {
-            const T dw = P.dcoef[o] * q0;
-            fc[0] += dw * (u1 - P.duref[o]);
-            fc[1] += dw * (u2 - P.duref[fs + o]);
-            fc[2] += dw * (u3 - P.duref[2 * fs + o]);
-        }
-        fc0 = fc[0]; fc1 = fc[1]; fc2 = fc[2];
-        gcoef = idzv * kGravity;
-    }
-#endif
-
+    // ---- forcing
+    T fc0, fc1, fc2;
+    double gcoef;
+    k2_forcing<T>(P, active, o, fs, S, u1, u2, u3, p, fc0, fc1, fc2, gcoef);
     WX_STAMP(2);
+
     // accumulators of sum_d dF^d; the forcing is folded in as sqrtG*f so that the final
     // -1/sqrtG scaling yields  -1/sqrtG sum_d dF^d - f  (keeps 4 values out of the hot loop)
     T acc0 = T(0.0), acc1 = sg * fc0, acc2 = sg * fc1, acc4 = T(0.0), accw = sg * fc2;
     T hf = T(0.0);
 
-#if WX_K2_SKEL_DIRS
-    if (MF) fld[6][lpt] = logp;
-    __syncthreads();
-    acc0 += WX_FR(le < EPB ? le : 0, 0, 0, pt % N2) + fld[6][lpt];
-#endif
-#if WX_K2_UNROLL_DIRS
+    if (kSkelDirs) {   // diagnostic builds: the staged data consumed, no passes
+        if (MF) fld[6][lpt] = logp;
+        __syncthreads();
+        acc0 += WX_FR(le < EPB ? le : 0, 0, 0, pt % N2) + fld[6][lpt];
+    }
+    // ---- three directional passes, one copy per direction (constant LDS strides: the reads pair up as ds_read2_b64)
 #pragma unroll
-#else
-#pragma unroll 1
-#endif
-    for (int d = 0; d < (WX_K2_SKEL_DIRS ? 0 : 3); ++d) {
+    for (int d = 0; d < (kSkelDirs ? 0 : 3); ++d) {
         const T ud = w_sel(d == 0, u1, w_sel(d == 1, u2, u3));
-#if WX_K2_RELOAD_H
-        double hd0 = 0, hd1 = 0, hd2 = 0;
-        if (active) {
-            const double* hr = P.h + (size_t)(3 * d) * fs + o;
-            hd0 = hr[0]; hd1 = hr[fs]; hd2 = hr[2 * fs];
-        }
-#else
-        const double hd0 = d == 0 ? h00 : (d == 1 ? h01 : h02);
-        const double hd1 = d == 0 ? h01 : (d == 1 ? h11 : h12);
-        const double hd2 = d == 0 ? h02 : (d == 1 ? h12 : h22);
-#endif
+        const double hd0 = d == 0 ? S.h00 : (d == 1 ? S.h01 : S.h02);
+        const double hd1 = d == 0 ? S.h01 : (d == 1 ? S.h11 : S.h12);
+        const double hd2 = d == 0 ? S.h02 : (d == 1 ? S.h12 : S.h22);
         const T sgu = sg * ud;
         const T Bd = T(sg * hd2);
         if constexpr (MF) {
-            // matrix-core pass (see mf_dir_pass): each thread stages its own node, the 8 waves contract all lines
-            // in place, each thread picks its own node up again - no barrier between a thread's read and its next write
+            // matrix-core pass (mf4_dir_pass): each thread stages its own node, the 8 waves contract all lines in place -
+            // D | cm | cp with the two common face values as a third k-step -, each thread picks its own node up again:
+            // no barrier between a thread's read and its next write
             double* fm = reinterpret_cast<double*>(&fld[0][0]);
             const double* fq = reinterpret_cast<const double*>(&frs[0]);
             fm[0 * kMfLE + lptm] = sgu * q0;
@@ -970,31 +805,13 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
             if (d == 2) fm[7 * kMfLE + lptm] = sg * q0;
             __syncthreads();
             const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-            if (WX_K2_MFMA_SHAPE == 4) {
-                if (d == 0) mf4_dir_pass<0, MFC, 7, true, kMfFS, WX_K2_MF_FB>(fm, fq, mops4, wave, tid & 63);
-                else if (d == 1) mf4_dir_pass<1, MFC, 7, true, kMfFS, WX_K2_MF_FB>(fm, fq, mops4, wave, tid & 63);
-                else mf4_dir_pass<2, MFC, 7, true, kMfFS, WX_K2_MF_FB>(fm, fq, mops4, wave, tid & 63);
-            } else {
-                if (d == 0) mf_dir_pass<0, MFC>(fm, fq, mops, wave, tid & 63);
-                else if (d == 1) mf_dir_pass<1, MFC>(fm, fq, mops, wave, tid & 63);
-                else mf_dir_pass<2, MFC>(fm, fq, mops, wave, tid & 63);
-            }
+            if (d == 0) mf4_dir_pass<0, true, 7, true, kMfFS, kMfFieldBatch>(fm, fq, mops4, wave, tid & 63);
+            else if (d == 1) mf4_dir_pass<1, true, 7, true, kMfFS, kMfFieldBatch>(fm, fq, mops4, wave, tid & 63);
+            else mf4_dir_pass<2, true, 7, true, kMfFS, kMfFieldBatch>(fm, fq, mops4, wave, tid & 63);
             __syncthreads();
-            double r0 = fm[0 * kMfLE + lptm], r1 = fm[1 * kMfLE + lptm], r2 = fm[2 * kMfLE + lptm],
-                   r3 = fm[3 * kMfLE + lptm], r4 = fm[4 * kMfLE + lptm], r5 = fm[5 * kMfLE + lptm],
-                   r6 = fm[6 * kMfLE + lptm];
-            if (!MFC) {   // face corrections on the vector pipe
-                const int fpm = d == 0 ? kl * N + jl : (d == 1 ? kl * N + il : jl * N + il);
-                const int ix = d == 0 ? il : (d == 1 ? jl : kl);
-                const double cm = sCm[ix], cp = sCp[ix];
-                r0 += cm * fq[(2 * d) * FST + 0 * N2 + fpm] + cp * fq[(2 * d + 1) * FST + 0 * N2 + fpm];
-                r1 += cm * fq[(2 * d) * FST + 1 * N2 + fpm] + cp * fq[(2 * d + 1) * FST + 1 * N2 + fpm];
-                r2 += cm * fq[(2 * d) * FST + 2 * N2 + fpm] + cp * fq[(2 * d + 1) * FST + 2 * N2 + fpm];
-                r3 += cm * fq[(2 * d) * FST + 3 * N2 + fpm] + cp * fq[(2 * d + 1) * FST + 3 * N2 + fpm];
-                r4 += cm * fq[(2 * d) * FST + 4 * N2 + fpm] + cp * fq[(2 * d + 1) * FST + 4 * N2 + fpm];
-                r5 += cm * fq[(2 * d) * FST + 5 * N2 + fpm] + cp * fq[(2 * d + 1) * FST + 5 * N2 + fpm];
-                r6 += cm * fq[(2 * d) * FST + 6 * N2 + fpm] + cp * fq[(2 * d + 1) * FST + 6 * N2 + fpm];
-            }
+            const double r0 = fm[0 * kMfLE + lptm], r1 = fm[1 * kMfLE + lptm], r2 = fm[2 * kMfLE + lptm],
+                         r3 = fm[3 * kMfLE + lptm], r4 = fm[4 * kMfLE + lptm], r5 = fm[5 * kMfLE + lptm],
+                         r6 = fm[6 * kMfLE + lptm];
             // W^d = [A@D + A*@C] + p [B@D + B*@C] + p B [log p@D + log p^@C]  (rhs_dfr.py:113-136)
             acc0 += r0; acc1 += r1; acc2 += r2; acc4 += r3;
             accw += r4 + p * r5 + (p * Bd) * r6;
@@ -1013,12 +830,10 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
         }
         __syncthreads();
 
-        int idx, fp;
-        if (d == 0) { idx = il; fp = kl * N + jl; }
-        else if (d == 1) { idx = jl; fp = kl * N + il; }
-        else { idx = kl; fp = jl * N + il; }
-        LdsLine ln = lds_line<N, SWZ>(d, kl, jl, il);
-        ln.lo += lb; ln.hi += lb;
+        int idx, fp, base, stride;
+        if (d == 0) { idx = il; fp = kl * N + jl; base = lb + C::lidx(kl, jl, 0); stride = 1; }
+        else if (d == 1) { idx = jl; fp = kl * N + il; base = lb + C::lidx(kl, 0, il); stride = C::NP; }
+        else { idx = kl; fp = jl * N + il; base = lb + C::lidx(0, jl, il); stride = N * C::NP; }
 
         double dm[N];
 #pragma unroll
@@ -1027,7 +842,7 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
         const int lf = le < EPB ? le : 0;
         // rolled over field batches: bounds the LDS reads in flight (register pressure); fully
         // unrolled, the compiler clusters 70 LDS reads and needs 241 VGPRs (1 workgroup/CU)
-        constexpr int FB = is_complex<T>::value ? WX_K2_FIELD_BATCH_WIDE : WX_K2_FIELD_BATCH;
+        constexpr int FB = is_complex<T>::value ? kFieldBatchWide : kFieldBatch;
         const T pB = p * Bd;
 #pragma unroll 1
         for (int c0 = 0; c0 < 7; c0 += FB) {
@@ -1037,7 +852,7 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
                 if (c < 7) {
                     T a = cm * WX_FR(lf, 2 * d, c, fp) + cp * WX_FR(lf, 2 * d + 1, c, fp);
 #pragma unroll
-                    for (int m = 0; m < N; ++m) a += dm[m] * fld[c][WX_LINE_AT(ln, m)];
+                    for (int m = 0; m < N; ++m) a += dm[m] * fld[c][base + m * stride];
                     // W^d = [A@D + A*@C] + p [B@D + B*@C] + p B [log p@D + log p^@C]  (rhs_dfr.py:113-136)
                     if (c == 0) acc0 += a;
                     else if (c == 1) acc1 += a;
@@ -1051,11 +866,12 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
         }
         if (d == 2) {
 #pragma unroll
-            for (int m = 0; m < N; ++m) hf += sHF[idx * N + m] * fld[7][WX_LINE_AT(ln, m)];
+            for (int m = 0; m < N; ++m) hf += sHF[idx * N + m] * fld[7][base + m * stride];
         }
         WX_STAMP(3 + d);
     }
 
+    // ---- epilogue
     const double inv_sg = 1.0 / sg;
     accw += gcoef * hf;  // gravity: inv_dzdeta * g * 1/sqrtG * HF_k(sqrtG rho)
     T r0 = -inv_sg * acc0, r1 = -inv_sg * acc1, r2 = -inv_sg * acc2, r3 = -inv_sg * accw, r4 = -inv_sg * acc4;
@@ -1140,28 +956,23 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
             fld[4][lpt] = active ? w_log(r4) : T(0.0);
         }
         __syncthreads();
-        extrap_faces<N, T>(P, fld, block_slot(gridDim.x) * EPB, P.count, P.region, P.itf_out, P.nsend_s, P.nsend_n,
-                           P.nsend_w, P.nsend_e);
+        extrap_faces<N, T>(P, fld, blockIdx.x * EPB, P.count, P.region, P.itf_out, P.nsend_s, P.nsend_n, P.nsend_w, P.nsend_e);
     }
 #undef WX_STAMP
 #undef WX_FR
 }
 
-#ifndef WX_K2_WAVES_MF
-#define WX_K2_WAVES_MF WX_K2_WAVES   // waves per SIMD requested for the matrix-core instantiation (6 = three workgroups per CU)
-#endif
 template <int N, typename T>
-constexpr int k2_waves() {
-    return is_complex<T>::value ? 2 : ((N == 8 && std::is_same<T, double>::value && WX_K2_MFMA) ? WX_K2_WAVES_MF : WX_K2_WAVES);
-}
+constexpr int k2_waves() { return is_complex<T>::value ? 2 : kK2Waves; }
+
 template <int N, typename T, bool PIPE>
 __global__ __launch_bounds__(Cfg<N>::BS, (k2_waves<N, T>())) void euler_rhs_kernel(const EulerParams<T> P) {
     euler_rhs_body<N, T, PIPE>(P);
 }
 
 template <int N, typename T>
-__global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES)) void euler_rhs_batch_kernel(
-    const EulerParams<T>* table, const EulerBatchDyn<T> dyn) {
+__global__ __launch_bounds__(Cfg<N>::BS, (k2_waves<N, T>())) void euler_rhs_batch_kernel(const EulerParams<T>* table,
+                                                                                         const EulerBatchDyn<T> dyn) {
     EulerParams<T> P = table[blockIdx.y];
     const size_t off = (size_t)blockIdx.y * dyn.stride;
     batch_state<T>(P, dyn);
@@ -1180,27 +991,37 @@ __global__ __launch_bounds__(Cfg<N>::BS, (is_complex<T>::value ? 2 : WX_K2_WAVES
 // rows, the advective rho*w flux, sqrtG*rho), one is a pure metric quantity with no tangent (B = sqrtG h^{d3})
 // and one needs both (log p, multiplied by p B afterwards).  The same holds for the face quantities.  LDS per
 // element 118 KB -> 70 KB and half the registers in the accumulators: TWO workgroups per CU instead of one,
-// and 40 % fewer LDS bytes and contraction flops.  Arithmetic is the generic kernel's, term by term.
+// and 40 % fewer LDS bytes and contraction flops.  Arithmetic is the generic kernel's, term by term; the Riemann
+// problems use the own / neighbour form (rusanov_own) and the Christoffel rows are read one at a time (rolled loop):
+// with everything in flight the compiler wanted 184 VGPRs.  WXHIP_JVP_LEAN=0 (environment, read once) sends
+// wx_euler3d_jvp through the generic kernel instead.
 // ------------------------------------------------------------------------------------------------
-// 127 VGPRs, 70 KB LDS: two workgroups per CU, where the generic dual-number instantiation (152 VGPRs, 118 KB) gets
-// one; an E7-sphere JVP takes 11.2 ms instead of 12.9 ms.  The reads of the B / log p planes go one plane at a
-// time (rolled loop): with all of them in flight the compiler wanted 184 VGPRs.  WXHIP_JVP_LEAN=0 (environment,
-// read once) sends wx_euler3d_jvp through the generic kernel instead.
-#ifndef WX_JVP_WAVES
-#define WX_JVP_WAVES 4
-#endif
-#ifndef WX_JVP_UNROLL_DIRS
-#define WX_JVP_UNROLL_DIRS 1
-#endif
-#ifndef WX_JVP_FIELD_BATCH
-#define WX_JVP_FIELD_BATCH 3
-#endif
-#ifndef WX_JVP_EARLY_LOADS
-#define WX_JVP_EARLY_LOADS 0
-#endif
-#ifndef WX_JVP_GAMMA_ROLLED
-#define WX_JVP_GAMMA_ROLLED 1
-#endif
+// tangent of the forcing of the three momentum rows, times sqrtG (.f1, .f2, .fw), and gcoef = inv_dzdeta * g
+struct JvpForcing { double f1, f2, fw, gcoef; };
+__device__ __forceinline__ JvpForcing jvp_forcing(const EulerParams<dual>& P, size_t o, size_t fs, double sg, double h00,
+                                                  double h01, double h02, double h11, double h12, double h22, dual q0,
+                                                  dual u1, dual u2, dual u3, dual p) {
+    JvpForcing r{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+    for (int i = 0; i < 3; ++i) {
+        const double* c = P.chr + (size_t)(i * 9) * fs + o;
+        double c01 = 0.0, c02 = 0.0, c03 = 0.0;
+        if (!P.rot_zero) { c01 = ldm(c); c02 = ldm(c + fs); c03 = ldm(c + 2 * fs); }
+        const double c11 = ldm(c + 3 * fs), c12 = ldm(c + 4 * fs), c13 = ldm(c + 5 * fs),
+                     c22 = ldm(c + 6 * fs), c23 = ldm(c + 7 * fs), c33 = ldm(c + 8 * fs);
+        dual f = 2.0 * q0 * (c01 * u1 + c02 * u2 + c03 * u3) + c11 * (q0 * u1 * u1 + h00 * p) +
+                 2.0 * c12 * (q0 * u1 * u2 + h01 * p) + 2.0 * c13 * (q0 * u1 * u3 + h02 * p) +
+                 c22 * (q0 * u2 * u2 + h11 * p) + 2.0 * c23 * (q0 * u2 * u3 + h12 * p) +
+                 c33 * (q0 * u3 * u3 + h22 * p);
+        if (P.has_damp) f += (P.dcoef[o] * q0) * ((i == 0 ? u1 : (i == 1 ? u2 : u3)) - P.duref[(size_t)i * fs + o]);
+        if (i == 0) r.f1 = sg * f.im;
+        else if (i == 1) r.f2 = sg * f.im;
+        else r.fw = sg * f.im;
+    }
+    r.gcoef = ldm(P.idz + o) * kGravity;
+    return r;
+}
+
 template <int N>
 __device__ __forceinline__ void euler_jvp_body(const EulerParams<dual>& P) {
     using C = Cfg<N>;
@@ -1225,33 +1046,19 @@ __device__ __forceinline__ void euler_jvp_body(const EulerParams<dual>& P) {
     }
 
     const int le = tid / N3, pt = tid % N3;
-    const Elem el = decode_elem(block_slot(gridDim.x) * EPB + le, P.count, P.region, H, V);
+    const Elem el = decode_elem(blockIdx.x * EPB + le, P.count, P.region, H, V);
     const bool active = (le < EPB) && el.valid;
     const int kl = pt / N2, jl = (pt / N) % N, il = pt % N;
     const int lb = (le < EPB ? le : 0) * C::LE;
     const int lpt = lb + C::lidx(kl, jl, il);
     const size_t o = (size_t)el.e * N3 + pt;
 
-    // point loads first: in flight while the face stage computes
-    T q0 = T(1.0), q1 = T(0.0), q2 = T(0.0), q3 = T(0.0), q4 = T(1.0);
-    double sg = 1.0, h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0;
-#define WX_JVP_POINT_LOADS()                                                                               \
-    if (active) {                                                                                          \
-        load_state<T>(P, o, fs, q0, q1, q2, q3, q4);                                                       \
-        sg = WX_LDM(P.sg + o);                                                                             \
-        h00 = WX_LDM(P.h + 0 * fs + o); h01 = WX_LDM(P.h + 1 * fs + o); h02 = WX_LDM(P.h + 2 * fs + o);    \
-        h11 = WX_LDM(P.h + 4 * fs + o); h12 = WX_LDM(P.h + 5 * fs + o); h22 = WX_LDM(P.h + 8 * fs + o);    \
-    }
-#if WX_JVP_EARLY_LOADS
-    WX_JVP_POINT_LOADS()
-#endif
-
     // ---- face stage
     for (int fi = tid; fi < EPB * 6 * N2; fi += BS) {
         const int fle = fi / (6 * N2);
         const int r = fi % (6 * N2);
         const int f = r / N2, fp = r % N2;
-        const Elem fel = decode_elem(block_slot(gridDim.x) * EPB + fle, P.count, P.region, H, V);
+        const Elem fel = decode_elem(blockIdx.x * EPB + fle, P.count, P.region, H, V);
         if (!fel.valid) continue;
         T out[7];
         face_problem<N, T, true>(P, fel, f, fp, out);
@@ -1261,10 +1068,10 @@ __device__ __forceinline__ void euler_jvp_body(const EulerParams<dual>& P) {
         frf[fle][f][1][fp] = out[6];
     }
 
-#if !WX_JVP_EARLY_LOADS
-    WX_JVP_POINT_LOADS()
-#endif
-#undef WX_JVP_POINT_LOADS
+    PointIn<T> S;
+    k2_point_loads<T>(P, active, o, fs, S);
+    const T q0 = S.q0, q1 = S.q1, q2 = S.q2, q3 = S.q3, q4 = S.q4;
+    const double sg = S.sg;
     // ---- pointwise quantities
     const T rinv = 1.0 / q0;
     const T u1 = q1 * rinv, u2 = q2 * rinv, u3 = q3 * rinv;
@@ -1277,42 +1084,19 @@ __device__ __forceinline__ void euler_jvp_body(const EulerParams<dual>& P) {
         ft[5][lpt] = sg * q0.im;
     }
 
-    // ---- forcing (tangent), one row of Christoffel symbols at a time: 9 (6) loads in flight, few registers
+    // ---- forcing (tangent)
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc4 = 0.0, accw = 0.0, hf = 0.0, gcoef = 0.0;
     if (active) {
-#if WX_JVP_GAMMA_ROLLED
-#pragma unroll 1
-#else
-#pragma unroll
-#endif
-        for (int i = 0; i < 3; ++i) {
-            const double* c = P.chr + (size_t)(i * 9) * fs + o;
-            double c01 = 0.0, c02 = 0.0, c03 = 0.0;
-            if (!P.rot_zero) { c01 = WX_LDM(c); c02 = WX_LDM(c + fs); c03 = WX_LDM(c + 2 * fs); }
-            const double c11 = WX_LDM(c + 3 * fs), c12 = WX_LDM(c + 4 * fs), c13 = WX_LDM(c + 5 * fs),
-                         c22 = WX_LDM(c + 6 * fs), c23 = WX_LDM(c + 7 * fs), c33 = WX_LDM(c + 8 * fs);
-            T f = 2.0 * q0 * (c01 * u1 + c02 * u2 + c03 * u3) + c11 * (q0 * u1 * u1 + h00 * p) +
-                  2.0 * c12 * (q0 * u1 * u2 + h01 * p) + 2.0 * c13 * (q0 * u1 * u3 + h02 * p) +
-                  c22 * (q0 * u2 * u2 + h11 * p) + 2.0 * c23 * (q0 * u2 * u3 + h12 * p) +
-                  c33 * (q0 * u3 * u3 + h22 * p);
-            if (P.has_damp) f += (P.dcoef[o] * q0) * ((i == 0 ? u1 : (i == 1 ? u2 : u3)) - P.duref[(size_t)i * fs + o]);
-            if (i == 0) acc1 = sg * f.im;
-            else if (i == 1) acc2 = sg * f.im;
-            else accw = sg * f.im;
-        }
-        gcoef = WX_LDM(P.idz + o) * kGravity;
+        const JvpForcing F = jvp_forcing(P, o, fs, sg, S.h00, S.h01, S.h02, S.h11, S.h12, S.h22, q0, u1, u2, u3, p);
+        acc1 = F.f1; acc2 = F.f2; accw = F.fw; gcoef = F.gcoef;
     }
 
-#if WX_JVP_UNROLL_DIRS
 #pragma unroll
-#else
-#pragma unroll 1
-#endif
     for (int d = 0; d < 3; ++d) {
         const T ud = w_sel(d == 0, u1, w_sel(d == 1, u2, u3));
-        const double hd0 = d == 0 ? h00 : (d == 1 ? h01 : h02);
-        const double hd1 = d == 0 ? h01 : (d == 1 ? h11 : h12);
-        const double hd2 = d == 0 ? h02 : (d == 1 ? h12 : h22);
+        const double hd0 = d == 0 ? S.h00 : (d == 1 ? S.h01 : S.h02);
+        const double hd1 = d == 0 ? S.h01 : (d == 1 ? S.h11 : S.h12);
+        const double hd2 = d == 0 ? S.h02 : (d == 1 ? S.h12 : S.h22);
         const T sgu = sg * ud;
         const double Bd = sg * hd2;
         __syncthreads();  // face stage / previous direction's reads are done
@@ -1335,7 +1119,7 @@ __device__ __forceinline__ void euler_jvp_body(const EulerParams<dual>& P) {
         for (int m = 0; m < N; ++m) dm[m] = sD[idx * N + m];
         const double cm = sCm[idx], cp = sCp[idx];
         const int lf = le < EPB ? le : 0;
-        constexpr int FB = WX_JVP_FIELD_BATCH;
+        constexpr int FB = kFieldBatch;
 #pragma unroll 1
         for (int c0 = 0; c0 < 5; c0 += FB) {
 #pragma unroll
@@ -1391,12 +1175,6 @@ __device__ __forceinline__ void euler_jvp_body(const EulerParams<dual>& P) {
 // the fused RHS kernel).  Nine real planes per direction: the five flux tangents, B (metric), log p value and tangent -
 // eight take D | cm | cp with their face pairs as the third k-step - and the tangent of sqrtG rho for the vertical
 // high-filter; the tangent of B* has no nodal part and keeps its two-term correction on the vector pipe.
-#ifndef WX_JVP_MFMA
-#define WX_JVP_MFMA 1
-#endif
-#ifndef WX_JVP_MFMA_FB
-#define WX_JVP_MFMA_FB 4   // planes whose operands are in flight together in a matrix-core pass
-#endif
 constexpr int kJvFS = 9 * 64 + 16;   // doubles per face of the JVP kernel's face image (9 quantities)
 
 __device__ __forceinline__ void euler_jvp_body_mf(const EulerParams<dual>& P) {
@@ -1413,7 +1191,7 @@ __device__ __forceinline__ void euler_jvp_body_mf(const EulerParams<dual>& P) {
         sCp[tid] = P.K->cp[tid];
     }
     const MfOps4 mops = mf4_load_ops(P.K->D, P.K->cm, P.K->cp, P.K->HF, tid & 63);
-    const Elem el = decode_elem(block_slot(gridDim.x), P.count, P.region, H, V);
+    const Elem el = decode_elem(blockIdx.x, P.count, P.region, H, V);
     const bool active = el.valid;
     const int kl = tid / N2, jl = (tid / N) % N, il = tid % N;
     const int lptm = mf_idx(kl, jl, il);
@@ -1432,49 +1210,30 @@ __device__ __forceinline__ void euler_jvp_body_mf(const EulerParams<dual>& P) {
         q[6 * N2] = out[6].re; q[7 * N2] = out[6].im;
     }
 
-    T q0 = T(1.0), q1 = T(0.0), q2 = T(0.0), q3 = T(0.0), q4 = T(1.0);
-    double sg = 1.0, h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0;
-    if (active) {
-        load_state<T>(P, o, fs, q0, q1, q2, q3, q4);
-        sg = WX_LDM(P.sg + o);
-        h00 = WX_LDM(P.h + 0 * fs + o); h01 = WX_LDM(P.h + 1 * fs + o); h02 = WX_LDM(P.h + 2 * fs + o);
-        h11 = WX_LDM(P.h + 4 * fs + o); h12 = WX_LDM(P.h + 5 * fs + o); h22 = WX_LDM(P.h + 8 * fs + o);
-    }
+    PointIn<T> S;
+    k2_point_loads<T>(P, active, o, fs, S);
+    const T q0 = S.q0, q1 = S.q1, q2 = S.q2, q3 = S.q3, q4 = S.q4;
+    const double sg = S.sg;
     const T rinv = 1.0 / q0;
     const T u1 = q1 * rinv, u2 = q2 * rinv, u3 = q3 * rinv;
     const T glog = kGamma * w_log(kRdOverP0 * q4);
     const T p = kP0 * w_exp(glog);
     const T lp = kLogP0 + glog;
 
-    // ---- forcing (tangent), one row of Christoffel symbols at a time
+    // ---- forcing (tangent)
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc4 = 0.0, accw = 0.0, hf = 0.0, gcoef = 0.0;
     if (active) {
-#pragma unroll 1
-        for (int i = 0; i < 3; ++i) {
-            const double* c = P.chr + (size_t)(i * 9) * fs + o;
-            double c01 = 0.0, c02 = 0.0, c03 = 0.0;
-            if (!P.rot_zero) { c01 = WX_LDM(c); c02 = WX_LDM(c + fs); c03 = WX_LDM(c + 2 * fs); }
-            const double c11 = WX_LDM(c + 3 * fs), c12 = WX_LDM(c + 4 * fs), c13 = WX_LDM(c + 5 * fs),
-                         c22 = WX_LDM(c + 6 * fs), c23 = WX_LDM(c + 7 * fs), c33 = WX_LDM(c + 8 * fs);
-            T f = 2.0 * q0 * (c01 * u1 + c02 * u2 + c03 * u3) + c11 * (q0 * u1 * u1 + h00 * p) +
-                  2.0 * c12 * (q0 * u1 * u2 + h01 * p) + 2.0 * c13 * (q0 * u1 * u3 + h02 * p) +
-                  c22 * (q0 * u2 * u2 + h11 * p) + 2.0 * c23 * (q0 * u2 * u3 + h12 * p) +
-                  c33 * (q0 * u3 * u3 + h22 * p);
-            if (P.has_damp) f += (P.dcoef[o] * q0) * ((i == 0 ? u1 : (i == 1 ? u2 : u3)) - P.duref[(size_t)i * fs + o]);
-            if (i == 0) acc1 = sg * f.im;
-            else if (i == 1) acc2 = sg * f.im;
-            else accw = sg * f.im;
-        }
-        gcoef = WX_LDM(P.idz + o) * kGravity;
+        const JvpForcing F = jvp_forcing(P, o, fs, sg, S.h00, S.h01, S.h02, S.h11, S.h12, S.h22, q0, u1, u2, u3, p);
+        acc1 = F.f1; acc2 = F.f2; accw = F.fw; gcoef = F.gcoef;
     }
 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const T ud = w_sel(d == 0, u1, w_sel(d == 1, u2, u3));
-        const double hd0 = d == 0 ? h00 : (d == 1 ? h01 : h02);
-        const double hd1 = d == 0 ? h01 : (d == 1 ? h11 : h12);
-        const double hd2 = d == 0 ? h02 : (d == 1 ? h12 : h22);
+        const double hd0 = d == 0 ? S.h00 : (d == 1 ? S.h01 : S.h02);
+        const double hd1 = d == 0 ? S.h01 : (d == 1 ? S.h11 : S.h12);
+        const double hd2 = d == 0 ? S.h02 : (d == 1 ? S.h12 : S.h22);
         const T sgu = sg * ud;
         const double Bd = sg * hd2;
         // each thread stages its own node of the nine planes, the eight waves contract all lines in place, each thread
@@ -1489,9 +1248,9 @@ __device__ __forceinline__ void euler_jvp_body_mf(const EulerParams<dual>& P) {
         pl[7 * kMfLE + lptm] = lp.im;
         if (d == 2) pl[8 * kMfLE + lptm] = sg * q0.im;
         __syncthreads();
-        if (d == 0) mf4_dir_pass<0, true, 8, true, kJvFS, WX_JVP_MFMA_FB>(pl, fq, mops, wave, tid & 63);
-        else if (d == 1) mf4_dir_pass<1, true, 8, true, kJvFS, WX_JVP_MFMA_FB>(pl, fq, mops, wave, tid & 63);
-        else mf4_dir_pass<2, true, 8, true, kJvFS, WX_JVP_MFMA_FB>(pl, fq, mops, wave, tid & 63);
+        if (d == 0) mf4_dir_pass<0, true, 8, true, kJvFS, kJvpMfFieldBatch>(pl, fq, mops, wave, tid & 63);
+        else if (d == 1) mf4_dir_pass<1, true, 8, true, kJvFS, kJvpMfFieldBatch>(pl, fq, mops, wave, tid & 63);
+        else mf4_dir_pass<2, true, 8, true, kJvFS, kJvpMfFieldBatch>(pl, fq, mops, wave, tid & 63);
         __syncthreads();
         acc0 += pl[0 * kMfLE + lptm];
         acc1 += pl[1 * kMfLE + lptm];
@@ -1519,19 +1278,20 @@ __device__ __forceinline__ void euler_jvp_body_mf(const EulerParams<dual>& P) {
 }
 
 template <int N>
-__global__ __launch_bounds__(Cfg<N>::BS, WX_JVP_WAVES) void euler_jvp_kernel(const EulerParams<dual> P) {
-    if constexpr (N == 8 && WX_JVP_MFMA) euler_jvp_body_mf(P);
+__global__ __launch_bounds__(Cfg<N>::BS, kJvpWaves) void euler_jvp_kernel(const EulerParams<dual> P) {
+    if constexpr (N == 8 && WX_MFMA) euler_jvp_body_mf(P);
     else euler_jvp_body<N>(P);
 }
 
+// (the batched form keeps the vector-pipe body at n = 8 too: with its parameters in vector registers - they come from
+// a device table, not from the kernel arguments - the matrix-core body spills 124 dwords per lane)
 template <int N>
-__global__ __launch_bounds__(Cfg<N>::BS, WX_JVP_WAVES) void euler_jvp_batch_kernel(const EulerParams<dual>* table,
-                                                                                   const EulerBatchDyn<dual> dyn) {
+__global__ __launch_bounds__(Cfg<N>::BS, kJvpWaves) void euler_jvp_batch_kernel(const EulerParams<dual>* table,
+                                                                                const EulerBatchDyn<dual> dyn) {
     EulerParams<dual> P = table[blockIdx.y];
     batch_state<dual>(P, dyn);
     P.region = dyn.region; P.count = dyn.count;
-    if constexpr (N == 8 && WX_JVP_MFMA) euler_jvp_body_mf(P);
-    else euler_jvp_body<N>(P);
+    euler_jvp_body<N>(P);
 }
 
 // plan-time scan of a static field: raises *flag when any value differs from (+/-) zero
@@ -1616,7 +1376,7 @@ struct wx_euler3d_plan {
     int n, H, V, case_number, panel;
     wx_dtype dtype;
     size_t nelem;
-    void* itf;         // device: [elem][6][NQ][n^2] of dtype (interface slot 0)
+    void* itf;         // device: [elem][6][5][n^2] of dtype (interface slot 0)
     void* itf2 = nullptr;  // interface slot 1, allocated on first use of the stage pipeline
     size_t itf_bytes;
     EulerConsts* consts;  // device
@@ -1860,12 +1620,12 @@ static bool jvp_lean() {
 
 int wx_euler3d_uses_matrix_cores(const wx_euler3d_plan* pl, wx_kernel kernel) {
     if (!pl) return -1;
-    const bool rhs_mf = WX_K2_MFMA && pl->n == 8 && pl->dtype == WX_F64;
-    const bool jvp_mf = WX_JVP_MFMA && pl->n == 8 && pl->dtype == WX_DUAL128;
+    const bool rhs_mf = WX_MFMA && pl->n == 8 && pl->dtype == WX_F64;
+    const bool jvp_mf = WX_MFMA && pl->n == 8 && pl->dtype == WX_DUAL128;
     switch (kernel) {
         case WX_KERNEL_RHS: case WX_KERNEL_STAGE: case WX_KERNEL_BATCH_RHS: return rhs_mf ? 1 : 0;
         case WX_KERNEL_JVP: return (jvp_mf && jvp_lean()) ? 1 : 0;   // WXHIP_JVP_LEAN=0: the generic dual instantiation
-        case WX_KERNEL_BATCH_JVP: return jvp_mf ? 1 : 0;
+        case WX_KERNEL_BATCH_JVP: return 0;   // (vector-pipe body: see euler_jvp_batch_kernel)
     }
     return -1;
 }

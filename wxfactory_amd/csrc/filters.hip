@@ -19,9 +19,6 @@
 namespace wx {
 
 constexpr int kFilterMaxVar = 5;
-#ifndef WX_FILTER_MFMA
-#define WX_FILTER_MFMA 1   // n = 8, float64: the filter's three passes on v_mfma_f64_4x4x4_4b_f64
-#endif
 
 template <int N>
 struct FCfg {
@@ -65,7 +62,7 @@ __global__ __launch_bounds__(FCfg<N>::BS) void expfilter_kernel(const T* __restr
 
     // n = 8, float64: the three passes on the matrix cores (wx_mfma.h: in place, every thread stages and picks up its
     // own node, the eight waves contract one octet of lines each); the filter matrix is the operator, no face step
-    constexpr bool MF = N == 8 && std::is_same<T, double>::value && WX_FILTER_MFMA;
+    constexpr bool MF = N == 8 && std::is_same<T, double>::value && WX_MFMA;
     if constexpr (MF) {
         static_assert(C::LE == kMfLE && EPB == 1, "the matrix-core pass owns one n = 8 element per workgroup");
         double* fm = reinterpret_cast<double*>(&fld[0][0]);
@@ -200,7 +197,7 @@ wx_status wx_expfilter_destroy(wx_expfilter* h) {
 
 int wx_expfilter_uses_matrix_cores(const wx_expfilter* h, wx_dtype dtype) {
     if (!h) return -1;
-    return (WX_FILTER_MFMA && h->n == 8 && dtype == WX_F64) ? 1 : 0;
+    return (WX_MFMA && h->n == 8 && dtype == WX_F64) ? 1 : 0;
 }
 
 static wx_status expfilter_apply_impl(const wx_expfilter* h, const void* q, void* out, const double* sqrtG, int nvar,
