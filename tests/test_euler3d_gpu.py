@@ -221,6 +221,36 @@ def test_rccl_exchange_path_on_one_gpu():
         piped.jvp_release()
         torch.cuda.synchronize()
         assert torch.equal(j_plain, j_coll)
+        assert piped._ex_tan.needs_comm and piped._ex_tan.loopback   # (the tangent halos did travel through RCCL)
+
+        # BASELINE config 5 over RCCL ("hipGraph-captured matvec" on several GPUs): whole evaluations INCLUDING the
+        # collective - R(Q), and the Krylov matvec "tangent extrapolation -> exchange -> JVP kernels" - captured into ONE
+        # HIP graph each and replayed; the exchange runs in its stream-ordered form (PanelRhs.set_inline_exchange)
+        from wxfactory_amd.graph import GraphedFunction
+        from wxfactory_amd.matvec import ComplexStepOperator
+
+        graphs = []
+        try:
+            for batched in (True, False):
+                gr = RhsEuler3D(plans, PanelExchange(plans[0].edge_count, DEV, rank=0, world_size=1, loopback=True), overlap=True)
+                gr.batched = batched
+                g_rhs = GraphedFunction(gr, Q, rhs=gr)
+                graphs.append(g_rhs)
+                assert gr.ex.is_inline and gr.ex.needs_comm
+                for scale in (1.0, 1.01):
+                    assert torch.equal(g_rhs(Q * scale), plain(Q * scale)), (batched, scale)
+                op = ComplexStepOperator(1.0, Q, R, gr)    # (prepares the linearisation state when the tiles are large)
+                assert gr._jvp_is_prepared(Q) == (not batched)
+                g_mv = GraphedFunction(op, v.flatten(), rhs=gr)
+                graphs.append(g_mv)
+                for scale in (1.0, -0.37):
+                    got = g_mv((scale * v).flatten())
+                    assert torch.equal(got, matvec_fun((scale * v).flatten(), 1.0, Q, R, plain, "complex")), (batched, scale)
+                gr.jvp_release()
+        finally:
+            del graphs[:]   # graphs that hold RCCL nodes go before the process group does
+            g_rhs = g_mv = None
+            torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()
 

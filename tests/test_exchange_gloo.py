@@ -370,3 +370,79 @@ def test_tile_exchange_over_gloo(world):
     res = [q.get(timeout=240) for _ in range(world)]
     [p.join(timeout=60) for p in procs]
     assert all(r[1] == "ok" for r in res), [r for r in res if r[1] != "ok"]
+
+
+def test_inline_exchange_is_capture_safe_by_construction(monkeypatch):
+    """The stream-ordered ("inline") form of the halo exchange a HIP-graph capture needs (BASELINE config 5 on several
+    GPUs): the collective is issued with async_op=False on buffers that never move, no work handle is kept, the views
+    the kernels were given keep their addresses, and an RHS object falls back from INTERIOR / BOUNDARY to one launch.
+    No process group: the collective itself is replaced by a recorder."""
+    import torch.distributed as dist
+
+    from wxfactory_amd.exchange import PanelExchange
+    from wxfactory_amd.panel_rhs import PanelRhs
+
+    calls = []
+
+    def fake_all_to_all_single(recv, send, output_split_sizes=None, input_split_sizes=None, group=None, async_op=False):
+        calls.append((recv.data_ptr(), recv.numel(), send.data_ptr(), send.numel(), tuple(output_split_sizes),
+                      tuple(input_split_sizes), async_op))
+        return object() if async_op else None
+
+    monkeypatch.setattr(dist, "all_to_all_single", fake_all_to_all_single)
+    for world, rank, k in ((2, 1, 1), (6, 4, 1), (8, 3, 2), (1, 0, 1)):
+        mode = {"inline": False}
+        ex = PanelExchange(40, "cpu", rank=rank, world_size=world, loopback=(world == 1), tiles_per_side=k, mode=mode)
+        assert ex.needs_comm
+        ptrs = {(p, e): (ex.send_view(p, e).data_ptr(), ex.halo_view(p, e).data_ptr()) for p in ex.local for e in range(4)}
+        del calls[:]
+        ex.start()
+        assert ex._work is not None and calls[-1][-1] is True      # the overlapping form keeps a handle
+        ex._work = None
+        mode["inline"] = True
+        assert ex.is_inline
+        for _ in range(3):
+            ex.start()
+            assert ex._work is None and calls[-1][-1] is False     # stream-ordered, nothing kept
+            ex.wait()                                              # nothing to wait for
+        assert len({c[:6] for c in calls}) == 1                    # same buffers, same splits, every time
+        assert calls[-1][1] == ex.n_remote_in * 40 and calls[-1][3] == ex.n_remote_out * 40
+        assert ptrs == {(p, e): (ex.send_view(p, e).data_ptr(), ex.halo_view(p, e).data_ptr())
+                        for p in ex.local for e in range(4)}
+
+    # an RHS object: the shared switch reaches every exchange it owns or creates, and the phase order becomes
+    # pack -> exchange -> ALL (recorded through a test double of the plan)
+    order = []
+
+    class Plan:
+        dtype, shape, device, edge_count = torch.float64, (5, 1, 2, 2, 8), torch.device("cpu"), 40
+
+        def __init__(self, p):
+            self.p = p
+
+        def extrap_pack(self, q, send):
+            order.append(("pack", self.p))
+
+        def rhs(self, q, halo, out, region):
+            order.append(("rhs", self.p, region, halo is not None))
+            out.zero_()
+
+        def twin(self, dtype, dual=False):
+            return self
+
+    ex = PanelExchange(40, "cpu", rank=0, world_size=2)
+    rhs = PanelRhs({p: Plan(p) for p in ex.local}, ex)
+    assert ex.mode is rhs.comm_mode
+    q = {p: torch.zeros(Plan.shape, dtype=torch.float64) for p in ex.local}
+    del calls[:]
+    monkeypatch.setattr(ex, "wait", lambda: order.append(("wait",)))
+    rhs(q)
+    assert [o for o in order if o[0] == "rhs"][0][2] == 1 and calls[-1][-1] is True    # INTERIOR first, async collective
+    del order[:]
+    rhs.set_inline_exchange(True)
+    rhs(q)
+    assert calls[-1][-1] is False
+    kinds = [o[0] for o in order]
+    assert kinds == ["pack"] * len(ex.local) + ["wait"] + ["rhs"] * len(ex.local)
+    assert all(o[2] == 0 and o[3] for o in order if o[0] == "rhs")                     # region ALL, halos given
+    assert rhs.exchange_for(torch.complex128).is_inline                                # a later-created exchange too

@@ -9,7 +9,13 @@ all five variables, already rotated and flipped by the pack kernel (wx_euler3d_e
   send slot;
 * neighbours on other ranks: one torch.distributed.all_to_all_single (RCCL grouped
   send/recv over xGMI on GPUs, gloo on CPU) issued asynchronously so the interior elements
-  are computed while it is in flight.
+  are computed while it is in flight;
+* `inline` mode (HIP-graph capture, BASELINE config 5): the same collective enqueued in stream order with no
+  work handle kept - between the pack and the evaluation launches - on buffers that never move, so that a
+  whole Krylov matvec (tangent extrapolation -> exchange -> JVP kernels) records into ONE graph.  Measured
+  on MI355X / RCCL 2.26: a collective whose wait is deferred behind other launches of the capturing stream
+  (the fork / join the overlap needs) crashes hipStreamEndCapture; the stream-ordered form captures and
+  replays bit-identically (tools/graphcoll_probe.py).
 """
 from typing import Dict, List, Tuple
 
@@ -21,10 +27,13 @@ from .panels import CubeTopology, owner_of_tiles
 
 class PanelExchange:
     def __init__(self, edge_doubles: int, device, rank: int = 0, world_size: int = 1, group=None,
-                 loopback: bool = False, tiles_per_side: int = 1):
+                 loopback: bool = False, tiles_per_side: int = 1, mode: dict = None):
         """edge_doubles: float64 words per edge message (5*V*H*n^2, doubled for complex128);
-        buffers are float64 (complex payloads travel as interleaved re/im, which RCCL accepts)."""
+        buffers are float64 (complex payloads travel as interleaved re/im, which RCCL accepts).
+        mode: a dict shared by all exchanges of one RHS object; mode["inline"] switches them together."""
         dtype = torch.float64
+        self.inline = False          # stream-ordered collective, no work handle (graph capture)
+        self.mode = mode
         self.edge_count = int(edge_doubles)
         # loopback (tests): route same-rank messages through the collective too, so that a single
         # process exercises the RCCL path (split sizes, slot order, async wait) end to end
@@ -108,17 +117,24 @@ class PanelExchange:
     def needs_comm(self) -> bool:
         return self.world > 1 or self.loopback
 
+    @property
+    def is_inline(self) -> bool:
+        return self.inline or bool(self.mode and self.mode.get("inline"))
+
     def start(self):
-        """Post the exchange of everything the pack kernels wrote (stream-ordered after them)."""
+        """Post the exchange of everything the pack kernels wrote (stream-ordered after them).  Inline mode: the
+        collective is complete, in stream order, when this returns - nothing to wait for, nothing kept."""
         if not self.needs_comm:
             return
         ec = self.edge_count
         send = self.send_buf[: self.n_remote_out * ec]
         recv = self.recv_buf[: self.n_remote_in * ec]
-        self._work = dist.all_to_all_single(
+        inline = self.is_inline
+        work = dist.all_to_all_single(
             recv, send, output_split_sizes=self.recv_splits, input_split_sizes=self.send_splits,
-            group=self.group, async_op=True,
+            group=self.group, async_op=not inline,
         )
+        self._work = None if inline else work
 
     def wait(self):
         """Make the current stream (GPU) / the caller (CPU) wait for the halos."""

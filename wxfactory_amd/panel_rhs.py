@@ -38,7 +38,10 @@ class PanelRhs:
         self.device = first.device if first is not None else device
         self._plans = {first.dtype if first is not None else torch.float64: plans}
         self._ex = {}
+        # shared by every exchange this object creates: {"inline": True} makes them all stream-ordered (graph capture)
+        self.comm_mode = {"inline": False}
         if exchange is not None:
+            exchange.mode = self.comm_mode
             self._ex[first.dtype if first is not None else torch.float64] = exchange
             self.rank, self.world, self.group = exchange.rank, exchange.world, exchange.group
         self.edge_count = first.edge_count if first is not None else edge_count
@@ -55,9 +58,15 @@ class PanelRhs:
         if dtype not in self._ex:
             words = self.edge_count * (2 if dtype.is_complex else 1)
             dev = self.device if self.device is not None else "cpu"
+            loop = any(e.loopback for e in self._ex.values())   # (a rehearsal's loopback applies to every dtype)
             self._ex[dtype] = PanelExchange(words, dev, rank=self.rank, world_size=self.world, group=self.group,
-                                            tiles_per_side=self.tiles_per_side)
+                                            tiles_per_side=self.tiles_per_side, mode=self.comm_mode, loopback=loop)
         return self._ex[dtype]
+
+    def set_inline_exchange(self, inline: bool = True):
+        """Stream-ordered halo exchange without work handles (and therefore without the INTERIOR / BOUNDARY overlap):
+        what a HIP-graph capture of an evaluation over several GPUs needs (graph.GraphedFunction sets it)."""
+        self.comm_mode["inline"] = bool(inline)
 
     @property
     def supports_axpy(self) -> bool:
@@ -143,7 +152,7 @@ class PanelRhs:
         travels (all neighbours on this rank: the halos alias the packed buffers) one launch covers ALL.
         `launch(i, tile, halo_or_None, region)` enqueues one tile's kernel."""
         self._stamp(1)
-        if ex.needs_comm and self.overlap:
+        if ex.needs_comm and self.overlap and not ex.is_inline:
             ex.start()
             self._stamp(2)
             for i, p in enumerate(self.panels):

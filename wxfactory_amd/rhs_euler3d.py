@@ -337,7 +337,7 @@ class RhsEuler3D(PanelRhs):
 
     def _batched_phases(self, ex, launch):
         """launch(region) enqueues one kernel for all tiles."""
-        if ex.needs_comm and self.overlap:
+        if ex.needs_comm and self.overlap and not ex.is_inline:
             ex.start()
             launch(_lib.WX_REGION_INTERIOR)
             ex.wait()
@@ -390,7 +390,8 @@ class RhsEuler3D(PanelRhs):
         if st["ex"][1] is None:
             words = self.edge_count * (2 if dtype.is_complex else 1)
             st["ex"][1] = PanelExchange(words, self.device, rank=self.rank, world_size=self.world, group=self.group,
-                                        loopback=st["ex"][0].loopback, tiles_per_side=self.tiles_per_side)
+                                        loopback=st["ex"][0].loopback, tiles_per_side=self.tiles_per_side,
+                                        mode=self.comm_mode)
         cur = st["slot"]
         ex, exn = st["ex"][cur], st["ex"][1 - cur]
         if not self.panels:   # a rank that owns no tile: the exchange of this stage, and the same slot flip as the others
@@ -519,8 +520,9 @@ class RhsEuler3D(PanelRhs):
             self._jvp_lin = None
             return False
         if getattr(self, "_ex_val", None) is None:
+            loop = any(e.loopback for e in self._ex.values())
             mk = lambda: PanelExchange(self.edge_count, self.device, rank=self.rank, world_size=self.world, group=self.group,  # noqa: E731
-                                       tiles_per_side=self.tiles_per_side)
+                                       tiles_per_side=self.tiles_per_side, mode=self.comm_mode, loopback=loop)
             self._ex_val, self._ex_tan = mk(), mk()
         ex = self._ex_val
         if self.panels:
