@@ -153,6 +153,34 @@ def test_whole_sphere_on_one_gpu():
         assert Rs[p].shape == qs[p].shape and Rs[p].dtype == qs[p].dtype
 
 
+def _graphs_over_rccl(plans, Q, R, v, plain):
+    """BASELINE config 5 over RCCL ("hipGraph-captured matvec" on several GPUs): whole evaluations INCLUDING the
+    collective - R(Q), and the Krylov matvec "tangent extrapolation -> exchange -> JVP kernels" - captured into ONE HIP
+    graph each and replayed; the exchange runs in its stream-ordered form (PanelRhs.set_inline_exchange).  Graphs that
+    hold RCCL nodes must be gone before the process group is."""
+    from wxfactory_amd.exchange import PanelExchange
+    from wxfactory_amd.graph import GraphedFunction
+    from wxfactory_amd.matvec import ComplexStepOperator, matvec_fun
+    from wxfactory_amd.rhs_euler3d import RhsEuler3D
+
+    for batched in (True, False):
+        gr = RhsEuler3D(plans, PanelExchange(plans[0].edge_count, DEV, rank=0, world_size=1, loopback=True), overlap=True)
+        gr.batched = batched
+        g_rhs = GraphedFunction(gr, Q, rhs=gr)
+        ok = gr.ex.is_inline and gr.ex.needs_comm
+        for scale in (1.0, 1.01):
+            ok = ok and bool(torch.equal(g_rhs(Q * scale), plain(Q * scale)))
+        op = ComplexStepOperator(1.0, Q, R, gr)    # (prepares the linearisation state when the tiles are large)
+        ok = ok and gr._jvp_is_prepared(Q) == (not batched)
+        g_mv = GraphedFunction(op, v.flatten(), rhs=gr)
+        for scale in (1.0, -0.37):
+            ok = ok and bool(torch.equal(g_mv((scale * v).flatten()), matvec_fun((scale * v).flatten(), 1.0, Q, R, plain, "complex")))
+        gr.jvp_release()
+        del g_rhs, g_mv, op, gr
+        torch.cuda.synchronize()
+        assert ok, batched
+
+
 def test_rccl_exchange_path_on_one_gpu():
     """The N>1 code path end to end on one GPU: a 1-rank RCCL process group with the exchange in
     loopback mode, so every edge message goes through all_to_all_single on device buffers,
@@ -223,34 +251,11 @@ def test_rccl_exchange_path_on_one_gpu():
         assert torch.equal(j_plain, j_coll)
         assert piped._ex_tan.needs_comm and piped._ex_tan.loopback   # (the tangent halos did travel through RCCL)
 
-        # BASELINE config 5 over RCCL ("hipGraph-captured matvec" on several GPUs): whole evaluations INCLUDING the
-        # collective - R(Q), and the Krylov matvec "tangent extrapolation -> exchange -> JVP kernels" - captured into ONE
-        # HIP graph each and replayed; the exchange runs in its stream-ordered form (PanelRhs.set_inline_exchange)
-        from wxfactory_amd.graph import GraphedFunction
-        from wxfactory_amd.matvec import ComplexStepOperator
+        _graphs_over_rccl(plans, Q, R, v, plain)   # (in a function of its own: nothing of a graph outlives the call)
+        import gc
 
-        graphs = []
-        try:
-            for batched in (True, False):
-                gr = RhsEuler3D(plans, PanelExchange(plans[0].edge_count, DEV, rank=0, world_size=1, loopback=True), overlap=True)
-                gr.batched = batched
-                g_rhs = GraphedFunction(gr, Q, rhs=gr)
-                graphs.append(g_rhs)
-                assert gr.ex.is_inline and gr.ex.needs_comm
-                for scale in (1.0, 1.01):
-                    assert torch.equal(g_rhs(Q * scale), plain(Q * scale)), (batched, scale)
-                op = ComplexStepOperator(1.0, Q, R, gr)    # (prepares the linearisation state when the tiles are large)
-                assert gr._jvp_is_prepared(Q) == (not batched)
-                g_mv = GraphedFunction(op, v.flatten(), rhs=gr)
-                graphs.append(g_mv)
-                for scale in (1.0, -0.37):
-                    got = g_mv((scale * v).flatten())
-                    assert torch.equal(got, matvec_fun((scale * v).flatten(), 1.0, Q, R, plain, "complex")), (batched, scale)
-                gr.jvp_release()
-        finally:
-            del graphs[:]   # graphs that hold RCCL nodes go before the process group does
-            g_rhs = g_mv = None
-            torch.cuda.synchronize()
+        gc.collect()
+        torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()
 

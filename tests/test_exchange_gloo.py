@@ -186,6 +186,23 @@ def _jvp_worker(rank, world, port, q):
         for p in mine:
             assert plans[p].calls == ["prepare"] + ["tangent_pack", ("jvp", 1), ("jvp", 2)] * 2, plans[p].calls
         rhs.jvp_release()
+        # the production path: Epi -> kiops -> ComplexStepOperator -> matvec_fun, on every rank, idle ones included
+        # (they own no tile, take part in every exchange, and must choose the same exchange as the others)
+        from wxfactory_amd.matvec import ComplexStepOperator, matvec_fun
+
+        R = torch.zeros_like(Q)
+        op = ComplexStepOperator(2.0, Q, R, rhs)          # prepares (collective)
+        assert rhs._jvp_lin is not None
+        for scale in (1.0, -0.5):
+            out = op((scale * V).flatten()).reshape(Q.shape)
+            for i, p in enumerate(mine):
+                ref = scale * 2.0 * g.r(p, True).imag / g.eps
+                assert np.abs(out[i].numpy() - ref).max() <= 1e-9 * np.abs(ref).max(), (rank, p)
+        # a declared linearisation state is binding across ranks: another state is an error, not a silent fall-back
+        if mine:
+            with pytest.raises(RuntimeError, match="jvp_release"):
+                matvec_fun(V.flatten(), 2.0, Q.clone(), R, rhs, "complex")
+        rhs.jvp_release()
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok"))

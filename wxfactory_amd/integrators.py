@@ -129,6 +129,9 @@ class Epi:
             self.previous_Q.clear()
             self.previous_rhs.clear()
         self.dt = dt
+        release = getattr(self.rhs, "jvp_release", None)
+        if release is not None:
+            release()   # the previous step's linearisation state is history (all ranks pass here together)
         if len(self.previous_Q) < self.n_prev:
             self.previous_Q.appendleft(Q)
             self.previous_rhs.appendleft(self.rhs(Q))

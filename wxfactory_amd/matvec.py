@@ -24,7 +24,8 @@ def _can_shift(rhs_handle, Q) -> bool:
 def matvec_fun(vec: torch.Tensor, dt: float, Q: torch.Tensor, rhs: torch.Tensor, rhs_handle: Callable,
                method: str = "complex") -> torch.Tensor:
     if method == "complex" and getattr(rhs_handle, "supports_jvp", False) and getattr(rhs_handle, "fused_jvp", True) \
-            and isinstance(Q, torch.Tensor) and Q.dtype == torch.float64 and Q.is_contiguous() and rhs_handle.panels:
+            and isinstance(Q, torch.Tensor) and Q.dtype == torch.float64 and Q.is_contiguous() \
+            and (rhs_handle.panels or getattr(rhs_handle, "world", 1) > 1):   # (a rank without tiles joins the exchanges)
         # dual-number kernels: (Q, eps v) formed on load, dt/eps * tangent stored - no complex arrays
         return rhs_handle.jvp(Q, vec.reshape(Q.shape).contiguous(), EPS_COMPLEX, dt / EPS_COMPLEX).flatten()
     if method == "complex":

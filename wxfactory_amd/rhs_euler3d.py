@@ -551,8 +551,19 @@ class RhsEuler3D(PanelRhs):
         formed inside the kernels and only the tangent is stored: the complex-step JVP of
         solvers/matvec.py:56-61 without a complex array in HBM."""
         np_ = len(self.panels)
+        prepared = self._jvp_is_prepared(Q)
+        if self.world > 1:
+            # Several ranks: which exchange a product uses (tangents only, or dual faces) must be the same decision on
+            # every rank, and a rank cannot see that ANOTHER rank's state was modified.  So the declaration is binding:
+            # between jvp_prepare(Q) and jvp_release() - both collective - every product linearises about that Q, and a
+            # different or modified state is an error here instead of a silent fall-back (which would deadlock the ranks)
+            declared = getattr(self, "_jvp_lin", None) is not None
+            if declared and not prepared:
+                raise RuntimeError("jvp: the state differs from the one declared by jvp_prepare(); over several ranks call "
+                                   "jvp_release() or jvp_prepare(Q) again on all ranks first")
+            prepared = declared
         if not self.panels:   # a rank that owns no tile only takes part in the exchange of the product
-            ex = self._ex_tan if self._jvp_is_prepared(Q) else self.exchange_for(torch.complex128)
+            ex = self._ex_tan if prepared else self.exchange_for(torch.complex128)
             if ex.needs_comm:
                 ex.start()
                 ex.wait()
@@ -560,7 +571,10 @@ class RhsEuler3D(PanelRhs):
         Qs = Q.reshape((np_,) + tuple(self.panel_shape))
         vs = v.reshape((np_,) + tuple(self.panel_shape))
         plans = self._jvp_plans()
-        if self._jvp_is_prepared(Q) and v.is_contiguous():
+        if prepared and not v.is_contiguous():
+            v = v.contiguous()
+            vs = v.reshape((np_,) + tuple(self.panel_shape))
+        if prepared:
             exv, ext = self._ex_val, self._ex_tan
             out = torch.empty_like(Qs)
             for i, p in enumerate(self.panels):

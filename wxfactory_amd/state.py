@@ -83,32 +83,43 @@ def gather_cube(local: torch.Tensor, rank: int = 0, world_size: int = 1, group=N
 def distribute_cube(global_state, rank: int = 0, world_size: int = 1, device="cpu", group=None,
                     tiles_per_side: int = 1, tile_shape=None, dtype=torch.float64) -> torch.Tensor:
     """Global (6, ...) array on rank 0 -> this rank's tiles stacked in tile order on `device`
-    (process_topology.py:471-539).  Collective.  Ranks other than 0 pass None and, when world_size > 1, the shape of
-    one tile (`tile_shape`, e.g. (5, V, Ht, Ht, n^3)) and the dtype."""
+    (process_topology.py:471-539).  Collective.  Ranks other than 0 pass None; the tile shape and dtype come from rank 0
+    (the `tile_shape` / `dtype` arguments are accepted for compatibility and ignored over several ranks)."""
     topo, per_rank, width = _layout(world_size, tiles_per_side)
     k = tiles_per_side
     scatter = None
+    # Rank 0 validates and tells everybody the outcome (and the tile shape / dtype) BEFORE the scatter, so that a bad
+    # array raises on all ranks together instead of leaving the others waiting in the collective.
+    err, g = None, None
     if rank == 0:
         g = global_state if isinstance(global_state, torch.Tensor) else torch.from_numpy(numpy.ascontiguousarray(global_state))
         if g.shape[0] != 6 or g.shape[-2] != g.shape[-3]:
-            raise ValueError(f"This is not a cube with square panels: {tuple(g.shape)}")
-        if g.shape[-2] % k:
+            err = f"This is not a cube with square panels: {tuple(g.shape)}"
+        elif g.shape[-2] % k:
             ok = [6 * i * i for i in range(1, g.shape[-2] + 1) if g.shape[-2] % i == 0]
-            raise ValueError(f"shape {tuple(g.shape)} cannot be cut into {k} x {k} tiles per panel; "
-                             f"acceptable numbers of tiles are {ok}")
-        Ht = g.shape[-2] // k
+            err = (f"shape {tuple(g.shape)} cannot be cut into {k} x {k} tiles per panel; "
+                   f"acceptable numbers of tiles are {ok}")
+        else:
+            Ht = g.shape[-2] // k
+            tile_shape, dtype = tuple(g.shape[1:-3]) + (Ht, Ht, g.shape[-1]), g.dtype
+    if world_size > 1:
+        head = [err, tuple(tile_shape) if tile_shape is not None else None, dtype]
+        dist.broadcast_object_list(head, src=0, group=group)
+        err, tile_shape, dtype = head
+    if err is not None:
+        raise ValueError(err)
+    if rank == 0:
+        Ht = tile_shape[-2]
         g = g.to(device)
-        tile_shape, dtype = tuple(g.shape[1:-3]) + (Ht, Ht, g.shape[-1]), g.dtype
         scatter = []
-        for tiles in per_rank:
-            buf = g.new_zeros((width,) + tile_shape)
+        for tiles in per_rank:   # one padded buffer per destination rank (this rank's own is the result)
+            buf = g.new_zeros((width,) + tuple(tile_shape))
             for i, t in enumerate(tiles):
                 buf[i] = g[_tile_slices(topo, t, Ht)]
             scatter.append(buf)
+        del g
     if world_size == 1:
         return scatter[0][: len(per_rank[0])].contiguous()
-    if tile_shape is None:
-        raise ValueError("distribute_cube: ranks other than 0 need tile_shape (and dtype)")
     mine = torch.empty((width,) + tuple(tile_shape), dtype=dtype, device=device)
     dist.scatter(mine, scatter, src=0, group=group)
     return mine[: len(per_rank[rank])].contiguous()
