@@ -126,7 +126,7 @@ def kernel_source_hash():
     return h.hexdigest()
 
 
-PMC_SUMMARIES = {384.0: "r02_pmc_summary.json", 312.0: "r02_pmc_rotzero_summary.json"}
+PMC_SUMMARIES = {384.0: "r03_pmc_full_summary.json", 312.0: "r03_pmc_rotzero_summary.json"}
 
 
 def pmc_traffic(region, n, H, V, bpp=ALGO_BYTES_PER_POINT):
@@ -143,6 +143,13 @@ def pmc_traffic(region, n, H, V, bpp=ALGO_BYTES_PER_POINT):
         prov = {"profile": "profiles/" + name, "commit": doc.get("commit"), "source_sha256": doc.get("source_sha256")}
         if doc.get("source_sha256") != kernel_source_hash():
             prov["reason"] = "kernel sources changed since the PMC pass: traffic refused"
+            return None, prov
+        from wxfactory_amd import _lib
+
+        build = _lib.load().wx_build_info().decode()
+        prov["build_info"] = doc.get("build_info")
+        if doc.get("build_info") != build:   # an A/B or diagnostic variant (-DWX_MFMA=0, -DWX_K2_DIAG=..) is another kernel
+            prov["reason"] = f"PMC pass taken on build '{doc.get('build_info')}', this run is '{build}': traffic refused"
             return None, prov
         return doc["kernels"]["wx::euler_rhs_kernel<8, double, false>"]["hbm_bytes"], prov
     except (OSError, KeyError, ValueError) as e:

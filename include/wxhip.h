@@ -68,6 +68,9 @@ typedef enum {
 const char* wx_last_error(void);
 /* "wxhip <version> gfx950" */
 const char* wx_version(void);
+/* the build-time switches of this library, e.g. "WX_MFMA=1 WX_K2_DIAG=0" (product build); A/B and diagnostic variants
+ * differ here, so that a measurement can name the variant it was taken on */
+const char* wx_build_info(void);
 /* number of HIP devices visible; <0 on error.  Does not create a context. */
 int wx_device_count(void);
 

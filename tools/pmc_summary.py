@@ -41,8 +41,10 @@ if __name__ == "__main__":
         commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
     except Exception:
         commit = os.environ.get("WX_COMMIT")  # the GPU box has no .git: pass the commit in
+    from wxfactory_amd import _lib   # the library the profiled program loaded (WXHIP_LIB selects a variant)
+
     json.dump({"unit": "bytes per launch (mean over launches)", "correction": "FETCH_SIZE x2 (gfx950), KiB -> B",
-               "commit": commit, "source_sha256": kernel_source_hash(),
+               "commit": commit, "source_sha256": kernel_source_hash(), "build_info": _lib.load().wx_build_info().decode(),
                "kernels": res}, open(sys.argv[3], "w"), indent=1)
     for k, v in res.items():
         print(f"{k:50s} fetch {v['fetch_bytes']/1e9:7.3f} GB  write {v['write_bytes']/1e9:7.3f} GB  total {v['hbm_bytes']/1e9:7.3f} GB")

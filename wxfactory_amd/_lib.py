@@ -53,6 +53,7 @@ class SwMetric(ctypes.Structure):
 SIGNATURES = {
     "wx_last_error": (c_char_p, []),
     "wx_version": (c_char_p, []),
+    "wx_build_info": (c_char_p, []),
     "wx_device_count": (c_int, []),
     "wx_euler3d_plan_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int,
                                        POINTER(DfrOps), POINTER(Euler3DMetric)]),
