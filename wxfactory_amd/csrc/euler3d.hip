@@ -704,7 +704,7 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
         }
     }
 
-    const int le = tid / N3, pt = MF ? mf_point(tid) : tid % N3;   // (matrix-core image: see mf_point)
+    const int le = tid / N3, pt = tid % N3;
     const Elem el = decode_elem(blockIdx.x * EPB + le, P.count, P.region, H, V);
     const bool active = (le < EPB) && el.valid;
     const int kl = pt / N2, jl = (pt / N) % N, il = pt % N;
@@ -1193,10 +1193,9 @@ __device__ __forceinline__ void euler_jvp_body_mf(const EulerParams<dual>& P) {
     const MfOps4 mops = mf4_load_ops(P.K->D, P.K->cm, P.K->cp, P.K->HF, tid & 63);
     const Elem el = decode_elem(blockIdx.x, P.count, P.region, H, V);
     const bool active = el.valid;
-    const int pt = mf_point(tid);
-    const int kl = pt / N2, jl = (pt / N) % N, il = pt % N;
+    const int kl = tid / N2, jl = (tid / N) % N, il = tid % N;
     const int lptm = mf_idx(kl, jl, il);
-    const size_t o = (size_t)el.e * N3 + pt;
+    const size_t o = (size_t)el.e * N3 + tid;
 
     // ---- face stage
     for (int fi = tid; fi < 6 * N2; fi += 512) {

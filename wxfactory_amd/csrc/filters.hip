@@ -48,8 +48,7 @@ __global__ __launch_bounds__(FCfg<N>::BS) void expfilter_kernel(const T* __restr
     __shared__ double sF[N * N];
     const int tid = threadIdx.x;
     for (int i = tid; i < N * N; i += C::BS) sF[i] = filter[i];
-    constexpr bool MF = N == 8 && std::is_same<T, double>::value && WX_MFMA;
-    const int le = tid / N3, pt = MF ? mf_point(tid) : tid % N3;   // (matrix-core image: see mf_point)
+    const int le = tid / N3, pt = tid % N3;
     const size_t e = (size_t)blockIdx.x * EPB + le;
     const bool active = le < EPB && e < nelem;
     const int kl = pt / N2, jl = (pt / N) % N, il = pt % N;
@@ -63,6 +62,7 @@ __global__ __launch_bounds__(FCfg<N>::BS) void expfilter_kernel(const T* __restr
 
     // n = 8, float64: the three passes on the matrix cores (wx_mfma.h: in place, every thread stages and picks up its
     // own node, the eight waves contract one octet of lines each); the filter matrix is the operator, no face step
+    constexpr bool MF = N == 8 && std::is_same<T, double>::value && WX_MFMA;
     if constexpr (MF) {
         static_assert(C::LE == kMfLE && EPB == 1, "the matrix-core pass owns one n = 8 element per workgroup");
         double* fm = reinterpret_cast<double*>(&fld[0][0]);

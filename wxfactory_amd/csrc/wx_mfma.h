@@ -17,24 +17,18 @@ namespace wx {
 // per field; A/B and counters in DESIGN.md 4.1 and profiles/r02_k2_mfma_*.)  Every nodal value is read from LDS once per
 // direction (eight times on the vector pipe) and the 70 f64 FMAs per point and direction leave the VALU.
 // Results go back IN PLACE (a wave reads its lines before it writes them; waves touch disjoint lines), the point
-// threads then pick up their own node.
-// LDS image: node (kl, jl, il) of a field at P(kl)*72 + P(jl)*8 + (il ^ jl), P = the index with bits 1 and 2 swapped
-// (planes and rows in the order 0 1 4 5 2 3 6 7), and the point thread t of a plane's wave owns row jl = P(t >> 3)
-// (mf_point).  An LDS access of 8 bytes per lane is served 32 lanes at a time; the 32 result lanes of a 4 x 4 x 4 block
-// quadruple hold nodes {0,1,4,5} (then {2,3,6,7}) of eight lines, so rows / planes 0,1,4,5 have to start on four
-// different 8-double bank groups: in the plain order rows 0 and 4 (32 doubles apart) share one, and every result write
-// took two turns (SQ_LDS_BANK_CONFLICT = 15 % of the LDS cycles of round 2's kernel).  With P all ten access patterns of
-// a pass are conflict-free (tools/lds_image_search.py models them).
+// threads then pick up their own node.  LDS image: node (kl, jl, il) of a field at kl*72 + jl*8 + (il ^ jl).
+// (SQ_LDS_BANK_CONFLICT reads 1.17 cycles per LDS instruction on this kernel.  That is the counter's floor for 64 lanes x
+// 8 bytes, not a conflict of the image: a build without the passes - plain stores of 64 consecutive doubles only -
+// reads 1.33, and an image re-ordered so that each half-wave of the result writes lands on 32 different bank pairs
+// changed neither the count, to the last digit, nor the time: profiles/r03_lds_bank_conflict_ab.txt.)
 // ------------------------------------------------------------------------------------------------
 #ifndef WX_MFMA
 #define WX_MFMA 1   // 0: the vector-pipe contractions for n = 8 too (A/B builds)
 #endif
 constexpr int kMfLE = 8 * 72;        // doubles per field image
 constexpr int kMfFS = 7 * 64 + 16;   // doubles per face in the face-flux image: faces 2d and 2d+1 land on different banks
-__device__ __forceinline__ int mf_perm(int x) { return (x & 1) | ((x & 4) >> 1) | ((x & 2) << 1); }
-__device__ __forceinline__ int mf_idx(int kl, int jl, int il) { return mf_perm(kl) * 72 + mf_perm(jl) * 8 + (il ^ jl); }
-// the solution point (kl, jl, il) = (pt >> 6, (pt >> 3) & 7, pt & 7) thread tid of an n = 8 element's workgroup owns
-__device__ __forceinline__ int mf_point(int tid) { return (tid & ~0x30) | ((tid & 0x10) << 1) | ((tid & 0x20) >> 1); }
+__device__ __forceinline__ int mf_idx(int kl, int jl, int il) { return kl * 72 + jl * 8 + (il ^ jl); }
 
 // Lane maps (found with tools/mfma_f64_4x4_probe.hip): lane l, k = l >> 4, block g = (l >> 2) & 3, x = l & 3:
 //   A_g[i = x][k],  B_g[k][j = x],  result D_g[i][j] in lane 16 i + 4 g + j.
