@@ -270,6 +270,39 @@ def test_krylov_vector_kernels(built_lib, m, n):
     assert not _Basis(V).gpu
 
 
+@pytest.mark.parametrize("m,n", [(0, 513), (1, 1000), (5, 4097), (16, 65536), (17, 30011), (35, 100003)])
+def test_two_vector_krylov_kernels(built_lib, m, n):
+    """wx_multi_dot2 / wx_pair_update (the one-synchronisation Gram-Schmidt step of fgmres, solvers/fgmres.py:16-73) against
+    torch, for row counts below, at and beyond one pass (16 rows), and the streaming combination sum_i y_i V[i]."""
+    from wxfactory_amd.solvers import _Basis
+
+    gen = torch.Generator(device=DEV).manual_seed(m * 7919 + n)
+    V = torch.randn((m + 3, n), generator=gen, device=DEV, dtype=torch.float64)
+    basis = _Basis(V)
+    assert basis.gpu
+    a, b = V[m], V[m + 1]
+    a0, b0 = a.clone(), b.clone()
+    if m:
+        g = basis.dots2(m, a, b)
+        ref = torch.cat((V[:m] @ a0, V[:m] @ b0))
+        assert torch.allclose(g, ref, rtol=1e-12, atol=1e-12 * float(ref.abs().max()))
+        assert torch.equal(g, basis.dots2(m, a, b))   # deterministic reduction
+    ha = torch.randn(m, generator=gen, device=DEV, dtype=torch.float64).cpu().numpy()
+    hb = torch.randn(m, generator=gen, device=DEV, dtype=torch.float64).cpu().numpy()
+    basis.pair_update(a, b, m, ha, hb, 0.7, -0.3, 1.9)
+    ra = a0 - (torch.from_numpy(ha).to(DEV) @ V[:m] if m else 0.0)
+    rb = b0 - (torch.from_numpy(hb).to(DEV) @ V[:m] if m else 0.0)
+    ra = ra * 0.7
+    rb = (rb - (-0.3) * ra) * 1.9
+    scale = float(max(ra.abs().max(), rb.abs().max()))
+    assert float((a - ra).abs().max()) <= 1e-13 * scale and float((b - rb).abs().max()) <= 1e-13 * scale
+    if m:
+        y = torch.randn(m, generator=gen, device=DEV, dtype=torch.float64).cpu().tolist()
+        comb = basis.combine(m, y)
+        refc = torch.tensor(y, dtype=torch.float64, device=DEV) @ V[:m]
+        assert float((comb - refc).abs().max()) <= 1e-13 * float(refc.abs().max())
+
+
 def test_prepared_jvp_equals_unprepared(setup):
     """wx_euler3d_jvp_prepare: the face values of the linearisation state cached once, only tangents extrapolated and
     exchanged per product - the same Jacobian-vector product as the unprepared path (bit for bit), against the

@@ -34,25 +34,27 @@ te = (time.perf_counter() - t0) / reps
 dof = 3 * 6 * H * H * n * n
 print(f"S7 eager : {te*1e6:8.1f} us per whole-sphere RHS  -> {dof/te/1e9:7.2f} G DOF-updates/s  (chk {float(R.abs().max()):.6e})")
 
-# graph capture of the 12 launches
-g = torch.cuda.CUDAGraph()
-Rg = torch.empty_like(Q)
-s = torch.cuda.Stream()
-s.wait_stream(torch.cuda.current_stream())
-with torch.cuda.stream(s):
-    for _ in range(3):
-        Rg.copy_(rhs(Q))
-    torch.cuda.synchronize()
-    with torch.cuda.graph(g, stream=s):
-        Rg.copy_(rhs(Q))
-torch.cuda.synchronize()
+# graph capture of the whole evaluation (2 launches: all panels per phase).  Round 2's version of this benchmark captured
+# `Rg.copy_(rhs(Q))` - a third kernel copying 33 MB - which is what made its replay slower than the eager call.
+from wxfactory_amd.graph import GraphedFunction  # noqa: E402
+
+gf = GraphedFunction(rhs, Q)
 for _ in range(5):
-    g.replay()
+    Rg = gf(Q)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(reps):
-    g.replay()
+    Rg = gf(Q)
 torch.cuda.synchronize()
 tg = (time.perf_counter() - t0) / reps
 print(f"S7 graph : {tg*1e6:8.1f} us per whole-sphere RHS  -> {dof/tg/1e9:7.2f} G DOF-updates/s  (match {bool(torch.equal(R, Rg))})")
-print(f"algorithmic bytes 156 B/point: {156.0*6*H*H*n*n/tg/1e9:.1f} GB/s")
+print(f"algorithmic bytes 156 B/point: eager {156.0*6*H*H*n*n/te/1e9:.1f} GB/s, graph {156.0*6*H*H*n*n/tg/1e9:.1f} GB/s")
+# the two launches separately (HIP events)
+bt = rhs._batch if hasattr(rhs, "_batch") else None
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+ev[0].record()
+for _ in range(reps):
+    rhs(Q)
+ev[1].record()
+torch.cuda.synchronize()
+print(f"S7 GPU time per evaluation (events around {reps} back-to-back evaluations): {ev[0].elapsed_time(ev[1])/reps*1e3:.1f} us")

@@ -16,8 +16,11 @@ namespace wx {
 
 constexpr int kDotBlocks = 2048;   // partial sums per row
 constexpr int kDotThreads = 256;
-constexpr int kRowsPerPass = 8;    // accumulators per thread
-constexpr int kRowsPerPass2 = 4;   // rows per pass of the two-vector kernels (2 accumulators / coefficients per row)
+// Rows per pass.  Every pass re-reads the vector(s) the rows are applied to (and the update kernels re-write them), so a
+// basis of j rows costs j + ceil(j / R) (+ writes) vector sweeps: at R = 4 the two-vector kernels of an FGMRES cycle of
+// 20 moved 38 vectors per Krylov vector on average, at R = 16 they move 26 (round 3; profiles/r03_fgmres_*).
+constexpr int kRowsPerPass = 16;    // accumulators per thread
+constexpr int kRowsPerPass2 = 16;   // rows per pass of the two-vector kernels (2 accumulators / coefficients per row)
 
 template <int R>
 __global__ __launch_bounds__(kDotThreads) void multi_dot_kernel(const double* __restrict__ V, size_t ldv, int row0,
@@ -262,6 +265,31 @@ static void launch_axpy(double* w, const double* V, size_t ldv, int row0, const 
     hipLaunchKernelGGL((multi_axpy_kernel<R>), dim3(grid), dim3(256), 0, st, w, V, ldv, row0, h, n);
 }
 
+// launch the instantiation for `rem` rows (1 <= rem <= R)
+template <int R>
+static void dispatch_dot(int rem, const double* V, size_t ldv, int row0, const double* w, size_t n, double* partial, int m,
+                         hipStream_t st) {
+    if (rem == R) launch_dot<R>(V, ldv, row0, w, n, partial, m, st);
+    else if constexpr (R > 1) dispatch_dot<R - 1>(rem, V, ldv, row0, w, n, partial, m, st);
+}
+template <int R>
+static void dispatch_axpy(int rem, double* w, const double* V, size_t ldv, int row0, const double* h, size_t n, hipStream_t st) {
+    if (rem == R) launch_axpy<R>(w, V, ldv, row0, h, n, st);
+    else if constexpr (R > 1) dispatch_axpy<R - 1>(rem, w, V, ldv, row0, h, n, st);
+}
+template <int R>
+static void dispatch_dot2(int rem, const double* V, size_t ldv, int row0, const double* a, const double* b, size_t n,
+                          double* partial, int m, hipStream_t st) {
+    if (rem == R) launch_dot2<R>(V, ldv, row0, a, b, n, partial, m, st);
+    else if constexpr (R > 1) dispatch_dot2<R - 1>(rem, V, ldv, row0, a, b, n, partial, m, st);
+}
+template <int R>
+static void dispatch_pair(int rem, double* a, double* b, const double* V, size_t ldv, int row0, const double* ha,
+                          const double* hb, size_t n, int last, double sa, double cross, double sb, hipStream_t st) {
+    if (rem == R) launch_pair<R>(a, b, V, ldv, row0, ha, hb, n, last, sa, cross, sb, st);
+    else if constexpr (R > 0) dispatch_pair<R - 1>(rem, a, b, V, ldv, row0, ha, hb, n, last, sa, cross, sb, st);
+}
+
 }  // namespace wx
 
 using namespace wx;
@@ -276,18 +304,8 @@ wx_status wx_multi_dot(const double* V, size_t ldv, int m, const double* w, size
     if (!V || !w || !out || !workspace) return fail(WX_ERR_INVALID, "wx_multi_dot: null argument");
     if (ldv < n) return fail(WX_ERR_INVALID, "wx_multi_dot: row stride %zu shorter than the vectors (%zu)", ldv, n);
     WX_STREAM(st, stream);
-    int r = 0;
-    for (; r + kRowsPerPass <= m; r += kRowsPerPass) launch_dot<kRowsPerPass>(V, ldv, r, w, n, workspace, m, st);
-    switch (m - r) {
-        case 1: launch_dot<1>(V, ldv, r, w, n, workspace, m, st); break;
-        case 2: launch_dot<2>(V, ldv, r, w, n, workspace, m, st); break;
-        case 3: launch_dot<3>(V, ldv, r, w, n, workspace, m, st); break;
-        case 4: launch_dot<4>(V, ldv, r, w, n, workspace, m, st); break;
-        case 5: launch_dot<5>(V, ldv, r, w, n, workspace, m, st); break;
-        case 6: launch_dot<6>(V, ldv, r, w, n, workspace, m, st); break;
-        case 7: launch_dot<7>(V, ldv, r, w, n, workspace, m, st); break;
-        default: break;
-    }
+    for (int r = 0; r < m; r += kRowsPerPass)
+        dispatch_dot<kRowsPerPass>(m - r < kRowsPerPass ? m - r : kRowsPerPass, V, ldv, r, w, n, workspace, m, st);
     hipLaunchKernelGGL(multi_dot_finish_kernel, dim3(m), dim3(64), 0, st, workspace, kDotBlocks, m, out);
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
@@ -316,14 +334,8 @@ wx_status wx_multi_dot2(const double* V, size_t ldv, int m, const double* a, con
     if (!V || !a || !b || !out || !workspace) return fail(WX_ERR_INVALID, "wx_multi_dot2: null argument");
     if (ldv < n) return fail(WX_ERR_INVALID, "wx_multi_dot2: row stride %zu shorter than the vectors (%zu)", ldv, n);
     WX_STREAM(st, stream);
-    int r = 0;
-    for (; r + kRowsPerPass2 <= m; r += kRowsPerPass2) launch_dot2<kRowsPerPass2>(V, ldv, r, a, b, n, workspace, m, st);
-    switch (m - r) {
-        case 1: launch_dot2<1>(V, ldv, r, a, b, n, workspace, m, st); break;
-        case 2: launch_dot2<2>(V, ldv, r, a, b, n, workspace, m, st); break;
-        case 3: launch_dot2<3>(V, ldv, r, a, b, n, workspace, m, st); break;
-        default: break;
-    }
+    for (int r = 0; r < m; r += kRowsPerPass2)
+        dispatch_dot2<kRowsPerPass2>(m - r < kRowsPerPass2 ? m - r : kRowsPerPass2, V, ldv, r, a, b, n, workspace, m, st);
     hipLaunchKernelGGL(multi_dot_finish_kernel, dim3(2 * m), dim3(64), 0, st, workspace, kDotBlocks, 2 * m, out);
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
@@ -338,13 +350,7 @@ wx_status wx_pair_update(double* a, double* b, const double* V, size_t ldv, int 
     int r = 0;
     for (; r + kRowsPerPass2 < m; r += kRowsPerPass2)   // (strictly less: the last batch carries the scalings)
         launch_pair<kRowsPerPass2>(a, b, V, ldv, r, ha, hb, n, 0, 1.0, 0.0, 1.0, st);
-    switch (m - r) {
-        case 0: launch_pair<0>(a, b, V, ldv, r, ha, hb, n, 1, scale_a, cross, scale_b, st); break;
-        case 1: launch_pair<1>(a, b, V, ldv, r, ha, hb, n, 1, scale_a, cross, scale_b, st); break;
-        case 2: launch_pair<2>(a, b, V, ldv, r, ha, hb, n, 1, scale_a, cross, scale_b, st); break;
-        case 3: launch_pair<3>(a, b, V, ldv, r, ha, hb, n, 1, scale_a, cross, scale_b, st); break;
-        default: launch_pair<4>(a, b, V, ldv, r, ha, hb, n, 1, scale_a, cross, scale_b, st); break;
-    }
+    dispatch_pair<kRowsPerPass2>(m - r, a, b, V, ldv, r, ha, hb, n, 1, scale_a, cross, scale_b, st);
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
 }
@@ -354,18 +360,8 @@ wx_status wx_multi_axpy(double* w, const double* V, size_t ldv, int m, const dou
     if (!V || !w || !h) return fail(WX_ERR_INVALID, "wx_multi_axpy: null argument");
     if (ldv < n) return fail(WX_ERR_INVALID, "wx_multi_axpy: row stride %zu shorter than the vectors (%zu)", ldv, n);
     WX_STREAM(st, stream);
-    int r = 0;
-    for (; r + kRowsPerPass <= m; r += kRowsPerPass) launch_axpy<kRowsPerPass>(w, V, ldv, r, h, n, st);
-    switch (m - r) {
-        case 1: launch_axpy<1>(w, V, ldv, r, h, n, st); break;
-        case 2: launch_axpy<2>(w, V, ldv, r, h, n, st); break;
-        case 3: launch_axpy<3>(w, V, ldv, r, h, n, st); break;
-        case 4: launch_axpy<4>(w, V, ldv, r, h, n, st); break;
-        case 5: launch_axpy<5>(w, V, ldv, r, h, n, st); break;
-        case 6: launch_axpy<6>(w, V, ldv, r, h, n, st); break;
-        case 7: launch_axpy<7>(w, V, ldv, r, h, n, st); break;
-        default: break;
-    }
+    for (int r = 0; r < m; r += kRowsPerPass)
+        dispatch_axpy<kRowsPerPass>(m - r < kRowsPerPass ? m - r : kRowsPerPass, w, V, ldv, r, h, n, st);
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
 }

@@ -83,6 +83,15 @@ class _Basis:
         return w
 
 
+    def combine(self, k: int, y) -> torch.Tensor:
+        """sum_{i<k} y[i] V[i] as a new vector: one sweep over the rows (wx_multi_axpy into a zeroed vector) instead of a
+        (1 x k) @ (k x n) product, which rocBLAS serves with a GEMM kernel at a fifth of the streaming rate."""
+        V = self.V
+        if not self.gpu:
+            return torch.as_tensor(y, dtype=V.dtype, device=V.device) @ V[:k]
+        out = torch.zeros(V.shape[1], dtype=V.dtype, device=V.device)
+        return self.subtract(out, 0, k, -torch.as_tensor(y, dtype=torch.float64).to(V.device))
+
     def dots2(self, m: int, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
         """[<V[k], a> for k < m] + [<V[k], b> for k < m] in one pass over the rows (device tensor of 2 m)."""
         V = self.V
@@ -283,7 +292,7 @@ def fgmres(A: Callable, b: torch.Tensor, x0: Optional[torch.Tensor] = None, tol:
             for l in range(i + 1, k):
                 acc -= H[l][i] * y[l]
             y[i] = acc / H[i][i]
-        update = torch.as_tensor(y, dtype=b.dtype, device=b.device) @ Z[:k]
+        update = basis.combine(k, y) if Z is V else torch.as_tensor(y, dtype=b.dtype, device=b.device) @ Z[:k]
         x += update
         r = b - A(x)
         norm_r = float(global_norm(r, group))
@@ -383,7 +392,7 @@ def _fgmres_low_sync(A, b, x0, tol, restart, maxiter, preconditioner, verbose, g
             yv = numpy.asarray(y)
             yh = yv + gs.T[:k, :k] @ yv
             yh[0] += (gs.R[0, 0] - 1.0) * yv[0]
-            update = torch.as_tensor(yh, dtype=b.dtype, device=b.device) @ V[:k]
+            update = basis.combine(k, yh)
         x += update
         r = b - A(x)
         norm_r = float(global_norm(r, group))
