@@ -75,6 +75,24 @@ const char* wx_build_info(void);
 int wx_device_count(void);
 
 /* ------------------------------------------------------------------------------------------
+ * The reference's per-evaluation timing row without torch: RHS.timestamps / retrieve_last_times (rhs/rhs.py:39-41, 68-118;
+ * device.timestamp / device.elapsed, device/device.py) - nine device timestamps per evaluation, consumed as eight
+ * intervals + total (rhs.py:191-200, output/solver_stats.py:158-175: the `rhs_timing` table).
+ *   wx_phase_timer_stamp(t, slot, stream)   records an event on `stream` for slot 0..8 (a caller that drives the two
+ *       kernels itself - INTEGRATION.md section 4, the MPI route - stamps: 0 start, 1 after wx_euler3d_extrap_pack,
+ *       2 exchange posted, 3 = 4 after the INTERIOR launch, 5 exchange complete, 6 = 7 = 8 after the BOUNDARY / ALL
+ *       launch: pointwise fluxes + divergence, and Riemann + correction + forcing, are one kernel each here)
+ *   wx_phase_timer_elapsed(t, out[9])       synchronises on the last stamp and writes the eight intervals between
+ *       consecutive stamps and their total, in SECONDS like device.elapsed; slots never stamped repeat their predecessor
+ *       (interval 0).  Returns WX_ERR_INVALID when slot 0 or 8 was not stamped.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct wx_phase_timer wx_phase_timer;
+wx_status wx_phase_timer_create(wx_phase_timer** timer);
+wx_status wx_phase_timer_destroy(wx_phase_timer* timer);
+wx_status wx_phase_timer_stamp(wx_phase_timer* timer, int slot, wx_stream stream);
+wx_status wx_phase_timer_elapsed(wx_phase_timer* timer, double seconds[9]);
+
+/* ------------------------------------------------------------------------------------------
  * 3-D Euler on a cubed-sphere tile.
  * Replaces  rhs/rhs_dfr.py:48-313  (RHSDirecFluxReconstruction_mpi, phases 1-8 of
  *           rhs/rhs.py:75-122) together with pde/pde_euler_cubesphere.py:72-290 and

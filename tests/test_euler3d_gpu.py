@@ -409,6 +409,47 @@ def test_rhs_timing_interface():
     assert rhs.timings == [] and rhs.timestamps == []
 
 
+def test_phase_timer_of_the_c_abi():
+    """The reference's nine-stamp timing row (rhs/rhs.py:88-118, device.elapsed) for a caller that drives the two kernels
+    itself, without torch: wx_phase_timer_* on the launch stream."""
+    import ctypes
+
+    from tests.gpu_util import make_plan, to_dev
+    from wxfactory_amd import _lib
+    from wxfactory_amd._lib import check
+
+    lib = _lib.load()
+    g = golden("euler3d_c31p_n3_h4_v2")
+    p = g.metric_panels()[0]
+    plan = make_plan(g, p)
+    q = to_dev(g.q(p))
+    halo = [to_dev(halo7(h)) for h in g.halo(p)]
+    out = torch.empty_like(q)
+    t = ctypes.c_void_p()
+    check(lib.wx_phase_timer_create(ctypes.byref(t)), "wx_phase_timer_create")
+    st = torch.cuda.current_stream().cuda_stream
+    row = (ctypes.c_double * 9)()
+    assert lib.wx_phase_timer_elapsed(t, row) != 0          # nothing stamped yet
+    for _ in range(2):
+        check(lib.wx_phase_timer_stamp(t, 0, st), "stamp")
+        plan.extrap_pack(q, None)
+        check(lib.wx_phase_timer_stamp(t, 1, st), "stamp")
+        check(lib.wx_phase_timer_stamp(t, 2, st), "stamp")    # (exchange posted: nothing travels here)
+        plan.rhs(q, None, out, _lib.WX_REGION_INTERIOR)
+        check(lib.wx_phase_timer_stamp(t, 4, st), "stamp")    # slot 3 shares its kernel with slot 4
+        check(lib.wx_phase_timer_stamp(t, 5, st), "stamp")
+        plan.rhs(q, halo, out, _lib.WX_REGION_BOUNDARY)
+        check(lib.wx_phase_timer_stamp(t, 8, st), "stamp")    # slots 6, 7 share their kernel with slot 8
+        check(lib.wx_phase_timer_elapsed(t, row), "wx_phase_timer_elapsed")
+        vals = list(row)
+        assert all(v >= 0.0 for v in vals) and vals[2] == 0.0 and vals[5] == 0.0 and vals[6] == 0.0
+        assert vals[0] > 0.0 and vals[3] > 0.0 and vals[7] > 0.0
+        assert abs(sum(vals[:8]) - vals[8]) <= 1e-4 and vals[8] > 0.0
+    assert lib.wx_phase_timer_stamp(t, 9, st) != 0
+    check(lib.wx_phase_timer_destroy(t), "wx_phase_timer_destroy")
+    plan.close()
+
+
 @pytest.mark.parametrize("name", ["euler3d_c31p_n3_h4_v2", "euler3d_c21_n4_h3_v4", "euler3d_c31p_n8_h2_v2"])
 def test_batched_launch_equals_per_tile_launches(name):
     """Stacked states go through ONE launch per phase for all tiles (wx_euler3d_batch_*): identical bits to the

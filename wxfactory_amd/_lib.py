@@ -55,6 +55,10 @@ SIGNATURES = {
     "wx_version": (c_char_p, []),
     "wx_build_info": (c_char_p, []),
     "wx_device_count": (c_int, []),
+    "wx_phase_timer_create": (c_int, [POINTER(c_void_p)]),
+    "wx_phase_timer_destroy": (c_int, [c_void_p]),
+    "wx_phase_timer_stamp": (c_int, [c_void_p, c_int, c_void_p]),
+    "wx_phase_timer_elapsed": (c_int, [c_void_p, POINTER(c_double)]),
     "wx_euler3d_plan_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int,
                                        POINTER(DfrOps), POINTER(Euler3DMetric)]),
     "wx_euler3d_plan_create_tile": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_int),

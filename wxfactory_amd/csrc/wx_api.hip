@@ -2,6 +2,8 @@
 #include "wx_common.h"
 #include "wx_mfma.h"
 
+#include <new>
+
 #ifndef WX_K2_DIAG
 #define WX_K2_DIAG 0
 #endif
@@ -29,6 +31,70 @@ int wx_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return -1;
     return n;
+}
+
+}  // extern "C"
+
+// ---- the nine-stamp timing row of the reference's RHS (rhs/rhs.py:39-41, 68-118) for callers without torch
+struct wx_phase_timer {
+    hipEvent_t ev[9];
+    bool set[9];
+};
+
+extern "C" {
+
+wx_status wx_phase_timer_create(wx_phase_timer** out) {
+    if (!out) return wx::fail(WX_ERR_INVALID, "wx_phase_timer_create: null argument");
+    *out = nullptr;
+    wx_phase_timer* t = new (std::nothrow) wx_phase_timer();
+    if (!t) return wx::fail(WX_ERR_NOMEM, "out of host memory");
+    for (int i = 0; i < 9; ++i) {
+        t->set[i] = false;
+        hipError_t e = hipEventCreate(&t->ev[i]);
+        if (e != hipSuccess) {
+            for (int k = 0; k < i; ++k) (void)hipEventDestroy(t->ev[k]);
+            delete t;
+            return wx::fail(WX_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(e));
+        }
+    }
+    *out = t;
+    return WX_OK;
+}
+
+wx_status wx_phase_timer_destroy(wx_phase_timer* t) {
+    if (!t) return WX_OK;
+    for (int i = 0; i < 9; ++i) (void)hipEventDestroy(t->ev[i]);
+    delete t;
+    return WX_OK;
+}
+
+wx_status wx_phase_timer_stamp(wx_phase_timer* t, int slot, wx_stream stream) {
+    if (!t || slot < 0 || slot > 8) return wx::fail(WX_ERR_INVALID, "wx_phase_timer_stamp: bad timer or slot %d", slot);
+    WX_STREAM(st, stream);
+    if (slot == 0)
+        for (int i = 0; i < 9; ++i) t->set[i] = false;   // a new evaluation
+    WX_HIP_TRY(hipEventRecord(t->ev[slot], st));
+    t->set[slot] = true;
+    return WX_OK;
+}
+
+wx_status wx_phase_timer_elapsed(wx_phase_timer* t, double seconds[9]) {
+    if (!t || !seconds) return wx::fail(WX_ERR_INVALID, "wx_phase_timer_elapsed: null argument");
+    if (!t->set[0] || !t->set[8]) return wx::fail(WX_ERR_INVALID, "wx_phase_timer_elapsed: slots 0 and 8 must be stamped");
+    WX_HIP_TRY(hipEventSynchronize(t->ev[8]));
+    int prev = 0;
+    for (int i = 1; i <= 8; ++i) {
+        seconds[i - 1] = 0.0;
+        if (!t->set[i]) continue;   // this phase shares its kernel with the next stamped one
+        float ms = 0.0f;
+        WX_HIP_TRY(hipEventElapsedTime(&ms, t->ev[prev], t->ev[i]));
+        seconds[i - 1] = 1e-3 * ms;
+        prev = i;
+    }
+    float total = 0.0f;
+    WX_HIP_TRY(hipEventElapsedTime(&total, t->ev[0], t->ev[8]));
+    seconds[8] = 1e-3 * total;
+    return WX_OK;
 }
 
 }  // extern "C"
