@@ -1228,8 +1228,13 @@ __device__ __forceinline__ void euler_jvp_body_mf(const EulerParams<dual>& P) {
     }
 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (kSkelDirs) {   // diagnostic builds: the staged data consumed, no passes
+        pl[lptm] = lp.im;
+        __syncthreads();
+        acc0 += fq[tid & 63] + pl[lptm] + u1.im + u2.im + u3.im;
+    }
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
+    for (int d = 0; d < (kSkelDirs ? 0 : 3); ++d) {
         const T ud = w_sel(d == 0, u1, w_sel(d == 1, u2, u3));
         const double hd0 = d == 0 ? S.h00 : (d == 1 ? S.h01 : S.h02);
         const double hd1 = d == 0 ? S.h01 : (d == 1 ? S.h11 : S.h12);
