@@ -1,9 +1,13 @@
 #!/bin/bash
 # Collect the evidence bench.py and DESIGN.md quote, on the GPU box (development tool):
-#   tools/collect_profiles.sh <tag>        -> gpurun_out/<tag>/...
-# 1. bench.py as the driver runs it; 2. the same command under rocprofv3 --kernel-trace --stats; 3. separate --pmc
-# FETCH_SIZE / WRITE_SIZE passes over one E7 panel (27-field and rot-zero metric) + tools/pmc_summary.py;
-# 4. kernel stats of the shallow-water S7 workload.  Each profiler run has the program right after "--".
+#   WX_COMMIT=<short hash> tools/collect_profiles.sh <tag>        -> gpurun_out/<tag>/...
+# 1. separate --pmc FETCH_SIZE / WRITE_SIZE passes over one E7 panel, K1 + K2 (27-field and rot-zero metric) and the JVP
+#    kernels, + tools/pmc_summary.py (bench.py quotes roofline.traffic from the K2 summaries once they are copied to
+#    profiles/ - so run this BEFORE the bench whose line is to carry the figure);
+# 2. bench.py as the driver runs it; 3. the same command under rocprofv3 --kernel-trace --stats with the extras, so that
+#    every hot kernel (RHS, JVP, tangent extrapolation, filter, Krylov vector kernels, shallow water) has a stats row;
+# 4. SQ / MFMA counter passes of K2 and of the JVP kernel; 5. the reference's benchmark matrix, shallow water S7.
+# Each profiler run has the program (python3) right after "--".
 set -e
 TAG=${1:-prof}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -11,13 +15,39 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd "$ROOT"
-python3 bench.py > "$OUT/bench.json.log" 2> "$OUT/bench.err" || { tail -20 "$OUT/bench.err"; exit 1; }
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-extras > "$OUT/bench_profiled.json.log" 2> "$OUT/stats.err")
-for mode in rotzero full; do
-  extra=""; [ $mode = rotzero ] && extra="--rot-zero"
-  (cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_${mode}_fetch" -- python3 "$ROOT/tools/kbench.py" --child --reps 5 $extra > "$OUT/pmc_${mode}_fetch.log" 2>&1)
-  (cd /tmp && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_${mode}_write" -- python3 "$ROOT/tools/kbench.py" --child --reps 5 $extra > "$OUT/pmc_${mode}_write.log" 2>&1)
-  python3 tools/pmc_summary.py "$OUT/pmc_${mode}_fetch" "$OUT/pmc_${mode}_write" "$OUT/pmc_${mode}_summary.json" > "$OUT/pmc_${mode}_summary.txt"
-done
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/sw_stats" -- python3 "$ROOT/tools/swbench.py" > "$OUT/swbench.log" 2> "$OUT/sw_stats.err") || echo "swbench profile failed"
+pmc() {  # pmc <name> <program> [args]: FETCH_SIZE and WRITE_SIZE passes + summary
+  local name=$1; shift
+  for c in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_${name}_$c" -- python3 "$@" > "$OUT/pmc_${name}_$c.log" 2>&1) || echo "pmc $name $c failed"
+  done
+  python3 tools/pmc_summary.py "$OUT/pmc_${name}_FETCH_SIZE" "$OUT/pmc_${name}_WRITE_SIZE" "$OUT/pmc_${name}_summary.json" > "$OUT/pmc_${name}_summary.txt" || true
+}
+pmc rotzero "$ROOT/tools/kbench.py" --child --reps 5 --rot-zero
+pmc full "$ROOT/tools/kbench.py" --child --reps 5
+pmc jvp "$ROOT/tools/jvpkbench.py" --reps 5
+pmc sw "$ROOT/tools/swbench.py"
+pmc matrix "$ROOT/tools/matrixbench.py" --orders 4,6 --reps 10
+echo "== pmc done"; cat "$OUT"/pmc_rotzero_summary.txt "$OUT"/pmc_jvp_summary.txt
+if [ "$2" != "--pmc-only" ]; then
+  python3 bench.py > "$OUT/bench.json.log" 2> "$OUT/bench.err" || { tail -20 "$OUT/bench.err"; exit 1; }
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --no-cpu-baseline > "$OUT/bench_profiled.json.log" 2> "$OUT/stats.err") || echo "bench stats failed"
+  sq() {  # sq <name> <program> [args]
+    local name=$1; shift; local i=0
+    for set in \
+      "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD" \
+      "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" \
+      "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_VALU_FMA_F64" \
+      "GRBM_GUI_ACTIVE" ; do
+      i=$((i+1))
+      (cd /tmp && rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/sq_$name/pass$i" -- python3 "$@" > "$OUT/sq_${name}_pass$i.log" 2>&1) || echo "sq $name pass $i failed"
+    done
+    python3 tools/sq_summary.py "$OUT/sq_$name" "$OUT/sq_${name}_counters.json" > "$OUT/sq_${name}_counters.txt" 2>&1 || true
+  }
+  sq k2 "$ROOT/tools/kbench.py" --child --reps 5 --rot-zero
+  sq jvp "$ROOT/tools/jvpkbench.py" --reps 5
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/matrix_stats" -- python3 "$ROOT/tools/matrixbench.py" --reps 20 > "$OUT/matrixbench_profiled.log" 2>&1) || echo "matrix stats failed"
+  python3 tools/matrixbench.py > "$OUT/matrixbench.log" 2>&1 || true
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/sw_stats" -- python3 "$ROOT/tools/swbench.py" > "$OUT/swbench_profiled.log" 2>&1) || echo "swbench profile failed"
+  python3 tools/swbench.py > "$OUT/swbench.log" 2>&1 || true
+fi
 find "$OUT" -name "*kernel_stats.csv" | head
