@@ -30,8 +30,29 @@ ALGO_BYTES_PER_POINT = 384.0  # 360 B/point fields + 24 B/
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def cpu_quota():
+    """(cores this process may use at once under its cgroup CPU bandwidth limit, where that was read) - or (None, None).
+    A container sees every CPU of the host in /proc/cpuinfo and in its affinity mask and is still throttled to its
+    quota: on the MI355X boxes of this pool /sys/fs/cgroup/cpu.max reads "1600000 100000" = 16 cores of a 128-core
+    host, and 32 or 64 busy processes get 16 CPU-seconds per second between them (measured)."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if quota != "max":
+            return float(quota) / float(period), f"/sys/fs/cgroup/cpu.max = {quota} {period}"
+    except (OSError, ValueError):
+        pass
+    try:
+        quota = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())           # cgroup v1
+        period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if quota > 0:
+            return quota / period, f"cpu.cfs_quota_us / cpu.cfs_period_us = {quota:.0f} / {period:.0f}"
+    except (OSError, ValueError):
+        pass
+    return None, None
+
+
 def host_cpu():
-    """(model name, physical cores available to this process, logical CPUs available)."""
+    """(model name, physical cores of the host visible to this process, logical CPUs in its affinity mask)."""
     model = "unknown"
     try:
         for ln in open("/proc/cpuinfo"):
@@ -87,10 +108,13 @@ def cpu_baseline_run(flavour, n, H, V, reps, threads, seed, procs=6):
 
 def cpu_baseline(n, V, seed, H=60):
     """The CPU path beside the GPU figure, as SURVEY.md section 8d writes it: six processes at once, one WHOLE cube panel
-    each (H x H x V elements), OMP/BLAS threads = floor(physical cores / 6), both flavours:
+    each (H x H x V elements), OMP/BLAS threads = floor(cores / 6) with cores = the physical cores this process can really
+    use (the host's count, capped by the container's cgroup CPU quota: cpu_quota), both flavours:
     (2) the optimised C++/OpenMP restatement - `value`; (1) the reference-style dense-Kronecker NumPy restatement (V = 1)."""
     model, phys, logical = host_cpu()
-    threads = max(1, phys // 6)
+    quota, quota_src = cpu_quota()
+    usable = int(min(phys, quota)) if quota else phys      # cores the six processes can really occupy together
+    threads = max(1, usable // 6)
     from oracle import c_port
 
     c_port.load()   # (re)build the C++ port for THIS host once, before six workers would each try to
@@ -98,9 +122,11 @@ def cpu_baseline(n, V, seed, H=60):
     dense = cpu_baseline_run("dense", n, H, 1, 3, threads, seed)
     return {"value": cpp["dof_updates_per_s"], "unit": "DOF-updates/s", "cores": 6 * threads, "kind": "port",
             "cpu_model": model, "physical_cores": phys, "logical_cpus": logical, "processes": 6,
-            "threads_per_process": threads,
+            "threads_per_process": threads, "usable_cores": usable,
+            "cpu_quota": {"cores": quota, "source": quota_src} if quota else None,
             "sample": f"oracle/c/euler3d_port.cpp (sum-factorised C++/OpenMP, pinned by tests/test_oracle_c.py): six "
-                      f"processes x {threads} thread(s) = floor({phys} physical cores / 6), each one whole {H}x{H}x{V}-element "
+                      f"processes x {threads} thread(s) = floor({usable} usable cores / 6) ({phys} physical cores on the host"
+                      + (f", cgroup CPU quota {quota:g} cores" if quota else "") + f"), each one whole {H}x{H}x{V}-element "
                       f"panel of the n={n} workload (the E7 sphere), 5 evals after a warm-up, {cpp['s_per_eval']} s/eval on the "
                       f"slowest, {cpp['algorithmic_GBps_per_process']} GB/s per process",
             "flavours": {"cpp_openmp_sum_factorised": cpp,

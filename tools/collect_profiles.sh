@@ -50,4 +50,9 @@ if [ "$2" != "--pmc-only" ]; then
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/sw_stats" -- python3 "$ROOT/tools/swbench.py" > "$OUT/swbench_profiled.log" 2>&1) || echo "swbench profile failed"
   python3 tools/swbench.py > "$OUT/swbench.log" 2>&1 || true
 fi
+# keep what is quoted (stats, counter tables, summaries); drop the bulky raw traces: gpurun copies back at most 64 MiB
+find "$OUT" -name "*kernel_trace.csv" -delete
+find "$OUT/sq_k2" "$OUT/sq_jvp" -name "*counter_collection.csv" -delete 2>/dev/null || true
+find "$OUT" -name "*agent_info.csv" -delete
+du -sh "$OUT"
 find "$OUT" -name "*kernel_stats.csv" | head
