@@ -403,8 +403,9 @@ def jvp_kernel_rooflines(rhs, Q, v, reps=10):
                               ("tangent_extrapolation (euler_extrap_kernel<dual>)", sum(t1) / len(t1), 16.0 + 40.0 + 240.0 / n)):
             gbs = bpp * pts / (ms * 1e-3) / 1e9
             blocks[name] = {"bound": "hbm", "launch_ms": round(ms, 4), "algorithmic_bytes_per_point": bpp,
-                            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                            "matrix_cores": bool(plans[p].lib.wx_euler3d_uses_matrix_cores(plans[p]._h, _lib.WX_KERNEL_JVP))}
+                            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        blocks["euler_jvp_kernel"]["matrix_cores"] = bool(
+            plans[p].lib.wx_euler3d_uses_matrix_cores(plans[p]._h, _lib.WX_KERNEL_JVP))
         return blocks
     finally:
         rhs.jvp_release()

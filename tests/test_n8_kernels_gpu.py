@@ -37,7 +37,7 @@ def test_matrix_core_instantiations_are_selected(built_lib):
     for k in (_lib.WX_KERNEL_RHS, _lib.WX_KERNEL_STAGE, _lib.WX_KERNEL_BATCH_RHS):
         assert _mc(p8, k) == 1 and _mc(p3, k) == 0
     d8 = p8.twin(torch.complex128, dual=True)
-    assert _mc(d8, _lib.WX_KERNEL_BATCH_JVP) == 0   # (the batched JVP keeps the vector-pipe body: register budget)
+    assert _mc(d8, _lib.WX_KERNEL_BATCH_JVP) == 1
     assert _mc(d8, _lib.WX_KERNEL_JVP) == (0 if os.environ.get("WXHIP_JVP_LEAN") == "0" else 1)
     assert _mc(p8.twin(torch.complex128), _lib.WX_KERNEL_RHS) == 0   # true complex arithmetic: vector pipe
     assert _mc(p3.twin(torch.complex128, dual=True), _lib.WX_KERNEL_JVP) == 0
@@ -260,7 +260,8 @@ def test_n8_matvecs_match_reference(callers8, batched):
         assert (_rel(rhs(Q), R.cpu().numpy()) < 1e-11).all()
         jc = matvec_fun(V.flatten(), dt, Q, R, rhs, "complex")
         dual = rhs._jvp_plans()[0]
-        assert batched or _mc(dual, _lib.WX_KERNEL_JVP) == 1 or os.environ.get("WXHIP_JVP_LEAN") == "0"
+        assert _mc(dual, _lib.WX_KERNEL_BATCH_JVP if batched else _lib.WX_KERNEL_JVP) == 1 \
+            or os.environ.get("WXHIP_JVP_LEAN") == "0"
         ref = stack("jvp_complex").cpu().numpy()
         assert (_rel(jc, ref) < 1e-9).all(), _rel(jc, ref)
         jf = matvec_fun(V.flatten(), dt, Q, R, rhs, "fd")

@@ -61,12 +61,25 @@ def main():
             torch.cuda.synchronize()
             t1.append(e0.elapsed_time(e1))
             t2.append(e1.elapsed_time(e2))
+        # the complex-step matvec the benchmark's epi2 + KIOPS integrator calls once per Krylov vector
+        from wxfactory_amd.matvec import matvec_fun
+
+        R = rhs(Q)
+        v = (torch.rand(Q.shape, device=dev, dtype=Q.dtype) - 0.5).flatten()
+        for _ in range(5):
+            matvec_fun(v, 1.0, Q, R, rhs, "complex")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.reps):
+            matvec_fun(v, 1.0, Q, R, rhs, "complex")
+        torch.cuda.synchronize()
+        mv = (time.perf_counter() - t0) / a.reps
         pts = 6 * V * H * H * n**3
         bpp = plans[0].bytes_per_point
         k1, k2 = sorted(t1)[len(t1) // 2], sorted(t2)[len(t2) // 2]
         print(f"n={n} {H}x{H}x{V}: wall {wall*1e3:7.4f} ms/eval = {bpp*pts/wall/1e9:7.1f} GB/s ({bpp:.0f} B/pt); "
               f"extrap {k1*1e3:6.1f} us, rhs kernel {k2*1e3:6.1f} us = {bpp*pts/(k2*1e-3)/1e9:7.1f} GB/s "
-              f"({bpp*pts/(k2*1e-3)/1e9/80:.1f}% of 8 TB/s)", flush=True)
+              f"({bpp*pts/(k2*1e-3)/1e9/80:.1f}% of 8 TB/s); complex-step matvec {mv*1e3:7.4f} ms = {mv/wall:.2f} x R(Q)", flush=True)
         del rhs, plans, Q, q, out, bt
         torch.cuda.empty_cache()
 

@@ -379,12 +379,29 @@ __device__ __forceinline__ void batch_state(EulerParams<T>& P, const EulerBatchD
     P.jvp = dyn.jvp; P.jvp_eps = dyn.eps; P.jvp_scale = dyn.scale;
 }
 
+// The parameters of tile blockIdx.y for a batched launch: the table entry goes to LDS (one 8-byte word per thread), one
+// thread patches in the per-launch fields, and the body reads what it needs where it needs it.  (Round 2 copied the
+// entry into registers - `EulerParams<T> P = table[blockIdx.y]` -: about 120 values live for the whole kernel, which no
+// register file holds beside the kernel's own state.  The batched JVP kernels spilled 470-600 bytes per lane and took
+// 2.6 x the batched RHS kernel at the reference's benchmark sizes.)
+template <typename T, typename Patch>
+__device__ __forceinline__ const EulerParams<T>& batch_params(EulerParams<T>& sP, const EulerParams<T>* table, Patch patch) {
+    static_assert(sizeof(EulerParams<T>) % 8 == 0, "copied in 8-byte words");
+    constexpr int W = sizeof(EulerParams<T>) / 8;
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(table + blockIdx.y);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&sP);
+    for (int i = threadIdx.x; i < W; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+    if (threadIdx.x == 0) patch(sP);
+    __syncthreads();
+    return sP;
+}
+
 template <int N, typename T>
 __global__ __launch_bounds__(Cfg<N>::BS, kK1Waves) void euler_extrap_batch_kernel(const EulerParams<T>* table,
                                                                                   const EulerBatchDyn<T> dyn) {
-    EulerParams<T> P = table[blockIdx.y];
-    batch_state<T>(P, dyn);
-    euler_extrap_body<N, T>(P);
+    __shared__ EulerParams<T> sP;
+    euler_extrap_body<N, T>(batch_params<T>(sP, table, [&](EulerParams<T>& P) { batch_state<T>(P, dyn); }));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -973,15 +990,16 @@ __global__ __launch_bounds__(Cfg<N>::BS, (k2_waves<N, T>())) void euler_rhs_kern
 template <int N, typename T>
 __global__ __launch_bounds__(Cfg<N>::BS, (k2_waves<N, T>())) void euler_rhs_batch_kernel(const EulerParams<T>* table,
                                                                                          const EulerBatchDyn<T> dyn) {
-    EulerParams<T> P = table[blockIdx.y];
-    const size_t off = (size_t)blockIdx.y * dyn.stride;
-    batch_state<T>(P, dyn);
-    P.rhs = dyn.rhs ? dyn.rhs + off : nullptr;
-    P.y = dyn.y ? dyn.y + off : nullptr;
-    P.z = dyn.z ? dyn.z + off : nullptr;
-    P.region = dyn.region; P.count = dyn.count;
-    P.axpy = dyn.axpy; P.ca = dyn.ca; P.cb = dyn.cb; P.cc = dyn.cc; P.cd = dyn.cd;
-    euler_rhs_body<N, T, false>(P);
+    __shared__ EulerParams<T> sP;
+    euler_rhs_body<N, T, false>(batch_params<T>(sP, table, [&](EulerParams<T>& P) {
+        const size_t off = (size_t)blockIdx.y * dyn.stride;
+        batch_state<T>(P, dyn);
+        P.rhs = dyn.rhs ? dyn.rhs + off : nullptr;
+        P.y = dyn.y ? dyn.y + off : nullptr;
+        P.z = dyn.z ? dyn.z + off : nullptr;
+        P.region = dyn.region; P.count = dyn.count;
+        P.axpy = dyn.axpy; P.ca = dyn.ca; P.cb = dyn.cb; P.cc = dyn.cc; P.cd = dyn.cd;
+    }));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1288,15 +1306,16 @@ __global__ __launch_bounds__(Cfg<N>::BS, kJvpWaves) void euler_jvp_kernel(const 
     else euler_jvp_body<N>(P);
 }
 
-// (the batched form keeps the vector-pipe body at n = 8 too: with its parameters in vector registers - they come from
-// a device table, not from the kernel arguments - the matrix-core body spills 124 dwords per lane)
 template <int N>
 __global__ __launch_bounds__(Cfg<N>::BS, kJvpWaves) void euler_jvp_batch_kernel(const EulerParams<dual>* table,
                                                                                 const EulerBatchDyn<dual> dyn) {
-    EulerParams<dual> P = table[blockIdx.y];
-    batch_state<dual>(P, dyn);
-    P.region = dyn.region; P.count = dyn.count;
-    euler_jvp_body<N>(P);
+    __shared__ EulerParams<dual> sP;
+    const EulerParams<dual>& P = batch_params<dual>(sP, table, [&](EulerParams<dual>& Q) {
+        batch_state<dual>(Q, dyn);
+        Q.region = dyn.region; Q.count = dyn.count;
+    });
+    if constexpr (N == 8 && WX_MFMA) euler_jvp_body_mf(P);
+    else euler_jvp_body<N>(P);
 }
 
 // plan-time scan of a static field: raises *flag when any value differs from (+/-) zero
@@ -1630,7 +1649,7 @@ int wx_euler3d_uses_matrix_cores(const wx_euler3d_plan* pl, wx_kernel kernel) {
     switch (kernel) {
         case WX_KERNEL_RHS: case WX_KERNEL_STAGE: case WX_KERNEL_BATCH_RHS: return rhs_mf ? 1 : 0;
         case WX_KERNEL_JVP: return (jvp_mf && jvp_lean()) ? 1 : 0;   // WXHIP_JVP_LEAN=0: the generic dual instantiation
-        case WX_KERNEL_BATCH_JVP: return 0;   // (vector-pipe body: see euler_jvp_batch_kernel)
+        case WX_KERNEL_BATCH_JVP: return jvp_mf ? 1 : 0;
     }
     return -1;
 }
