@@ -400,8 +400,14 @@ __device__ __forceinline__ const EulerParams<T>& batch_params(EulerParams<T>& sP
 template <int N, typename T>
 __global__ __launch_bounds__(Cfg<N>::BS, kK1Waves) void euler_extrap_batch_kernel(const EulerParams<T>* table,
                                                                                   const EulerBatchDyn<T> dyn) {
-    __shared__ EulerParams<T> sP;
-    euler_extrap_body<N, T>(batch_params<T>(sP, table, [&](EulerParams<T>& P) { batch_state<T>(P, dyn); }));
+    if constexpr (std::is_same<T, double>::value) {   // (float64: the register copy fits - 66 VGPRs, nothing spills - and is faster)
+        EulerParams<T> P = table[blockIdx.y];
+        batch_state<T>(P, dyn);
+        euler_extrap_body<N, T>(P);
+    } else {
+        __shared__ EulerParams<T> sP;
+        euler_extrap_body<N, T>(batch_params<T>(sP, table, [&](EulerParams<T>& P) { batch_state<T>(P, dyn); }));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -990,8 +996,7 @@ __global__ __launch_bounds__(Cfg<N>::BS, (k2_waves<N, T>())) void euler_rhs_kern
 template <int N, typename T>
 __global__ __launch_bounds__(Cfg<N>::BS, (k2_waves<N, T>())) void euler_rhs_batch_kernel(const EulerParams<T>* table,
                                                                                          const EulerBatchDyn<T> dyn) {
-    __shared__ EulerParams<T> sP;
-    euler_rhs_body<N, T, false>(batch_params<T>(sP, table, [&](EulerParams<T>& P) {
+    auto patch = [&](EulerParams<T>& P) {
         const size_t off = (size_t)blockIdx.y * dyn.stride;
         batch_state<T>(P, dyn);
         P.rhs = dyn.rhs ? dyn.rhs + off : nullptr;
@@ -999,7 +1004,15 @@ __global__ __launch_bounds__(Cfg<N>::BS, (k2_waves<N, T>())) void euler_rhs_batc
         P.z = dyn.z ? dyn.z + off : nullptr;
         P.region = dyn.region; P.count = dyn.count;
         P.axpy = dyn.axpy; P.ca = dyn.ca; P.cb = dyn.cb; P.cc = dyn.cc; P.cd = dyn.cd;
-    }));
+    };
+    if constexpr (std::is_same<T, double>::value) {   // (float64: the register copy fits and is faster; 16-byte dtypes spilled)
+        EulerParams<T> P = table[blockIdx.y];
+        patch(P);
+        euler_rhs_body<N, T, false>(P);
+    } else {
+        __shared__ EulerParams<T> sP;
+        euler_rhs_body<N, T, false>(batch_params<T>(sP, table, patch));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
