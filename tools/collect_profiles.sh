@@ -26,7 +26,7 @@ pmc rotzero "$ROOT/tools/kbench.py" --child --reps 5 --rot-zero
 pmc full "$ROOT/tools/kbench.py" --child --reps 5
 pmc jvp "$ROOT/tools/jvpkbench.py" --reps 5
 pmc sw "$ROOT/tools/swbench.py"
-pmc matrix "$ROOT/tools/matrixbench.py" --orders 4,6 --reps 10
+# (a --pmc pass over tools/matrixbench.py crashes rocprofv3 itself on this image: kernel stats only, below)
 echo "== pmc done"; cat "$OUT"/pmc_rotzero_summary.txt "$OUT"/pmc_jvp_summary.txt
 if [ "$2" != "--pmc-only" ]; then
   python3 bench.py > "$OUT/bench.json.log" 2> "$OUT/bench.err" || { tail -20 "$OUT/bench.err"; exit 1; }
