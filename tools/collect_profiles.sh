@@ -22,15 +22,24 @@ pmc() {  # pmc <name> <program> [args]: FETCH_SIZE and WRITE_SIZE passes + summa
   done
   python3 tools/pmc_summary.py "$OUT/pmc_${name}_FETCH_SIZE" "$OUT/pmc_${name}_WRITE_SIZE" "$OUT/pmc_${name}_summary.json" > "$OUT/pmc_${name}_summary.txt" || true
 }
+if [ "$2" != "--stats-only" ]; then
 pmc rotzero "$ROOT/tools/kbench.py" --child --reps 5 --rot-zero
 pmc full "$ROOT/tools/kbench.py" --child --reps 5
 pmc jvp "$ROOT/tools/jvpkbench.py" --reps 5
 pmc sw "$ROOT/tools/swbench.py"
 # (a --pmc pass over tools/matrixbench.py crashes rocprofv3 itself on this image: kernel stats only, below)
 echo "== pmc done"; cat "$OUT"/pmc_rotzero_summary.txt "$OUT"/pmc_jvp_summary.txt
-if [ "$2" != "--pmc-only" ]; then
+fi
+if [ "$2" = "--stats-only" ]; then
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-extras > "$OUT/bench_profiled.json.log" 2> "$OUT/stats.err") || echo "bench stats failed"
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_extras" -- python3 "$ROOT/bench.py" --no-cpu-baseline > "$OUT/bench_extras_profiled.json.log" 2> "$OUT/stats_extras.err") || echo "bench extras stats failed"
+elif [ "$2" != "--pmc-only" ]; then
   python3 bench.py > "$OUT/bench.json.log" 2> "$OUT/bench.err" || { tail -20 "$OUT/bench.err"; exit 1; }
-  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --no-cpu-baseline > "$OUT/bench_profiled.json.log" 2> "$OUT/stats.err") || echo "bench stats failed"
+  # (a) the headline alone: the K2 / K1 averages of this stats file are the ones to hold against the HIP-event figures
+  #     of the line the same run printed; (b) with the extras: a stats row for every other hot kernel (JVP, tangent
+  #     extrapolation, stage / filter, Krylov vector kernels, shallow water, the benchmark matrix)
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-extras > "$OUT/bench_profiled.json.log" 2> "$OUT/stats.err") || echo "bench stats failed"
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_extras" -- python3 "$ROOT/bench.py" --no-cpu-baseline > "$OUT/bench_extras_profiled.json.log" 2> "$OUT/stats_extras.err") || echo "bench extras stats failed"
   sq() {  # sq <name> <program> [args]
     local name=$1; shift; local i=0
     for set in \
