@@ -997,6 +997,17 @@ CASES = {
                                                dict(num_solpts=5, num_elements_horizontal=7, num_elements_vertical=9)),
     "cart2d_bubble_n4": lambda nm: cart2d_case(nm, "gaussian_bubble.ini",
                                                dict(num_solpts=4, num_elements_horizontal=5, num_elements_vertical=6)),
+    # --- round 3: the remaining templated orders straight from the reference (n = 2 is what config/dcmip31.ini ships
+    # with; 6 was pinned through the oracle on synthetic tiles only)
+    "euler3d_c31p_n2_h4_v3": lambda nm: euler_case(
+        nm, "dcmip31.ini", dict(num_solpts=2, num_elements_horizontal=4, num_elements_vertical=3),
+        metric_panels=(2, 4), phase_panels=(), perturb=0.01),
+    "euler3d_c31p_n6_h2_v2": lambda nm: euler_case(
+        nm, "dcmip31.ini", dict(num_solpts=6, num_elements_horizontal=2, num_elements_vertical=2),
+        metric_panels=(1, 5), phase_panels=(), perturb=0.01),
+    # (n = 7 cannot be produced: the reference's own DFROperators raises on it - its skew-centrosymmetry check of the
+    # differentiation matrix, geometry/operators.py:140-141, fails at that order - so n = 7 stays pinned through the
+    # oracle on synthetic tiles, tests/test_synthetic_gpu.py)
     # --- round 3: the benchmark order n = 8 for every caller (the matrix-core instantiations of the JVP, stage and
     # filter kernels), and BASELINE config 5's own combination (dcmip21 + EPI2 + KIOPS + filter)
     "callers_euler3d_n8_h2_v2": lambda nm: callers_case(

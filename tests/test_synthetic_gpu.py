@@ -235,3 +235,59 @@ def test_prepared_jvp_on_ragged_tiles(n, H, V):
     rhs.jvp_release()
     assert torch.isfinite(plain).all() and float(plain.abs().max()) > 0
     assert torch.equal(plain, prepared)
+
+
+@pytest.mark.parametrize("n,Htot,V", [(4, 4, 2), (8, 4, 1)])
+def test_result_does_not_depend_on_the_decomposition(n, Htot, V):
+    """The reference's restart tests require a 6-rank and a 24-rank run of the same case to agree to 1e-15
+    (tests/unit/restart/test_restart.py:107-151): the RHS, and a time loop built on it, must not depend on how the
+    sphere is cut into tiles.  Same global state through 6 whole panels and through 24 tiles (interior tile edges
+    exchange unrotated / unflipped, panel edges as ever; own geometry per tile): R(Q), the complex-step matvec and three
+    pipelined SSP-RK3 steps, compared after gathering into the global layout of the checkpoint format."""
+    from wxfactory_amd.exchange import PanelExchange
+    from wxfactory_amd.geometry3d import CubedSphere3DTile, metric3d_torch
+    from wxfactory_amd.initial import initial_state
+    from wxfactory_amd.integrators import Tvdrk3
+    from wxfactory_amd.matvec import matvec_fun
+    from wxfactory_amd.panels import CubeTopology
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D
+    from wxfactory_amd.state import distribute_cube, gather_cube
+    from wxfactory_amd.synthetic import dfr_ops
+
+    dev = "cuda:0"
+    gen = torch.Generator(device=dev).manual_seed(77)
+    runs = {}
+    glob = None
+    for k in (1, 2):
+        topo = CubeTopology(k)
+        Ht = Htot // k
+        plans = {}
+        for t in range(topo.ntiles):
+            p, row, col = topo.locate(t)
+            tile = CubedSphere3DTile(n, Ht, V, p, 10000.0, 31, row=row, col=col, k=k)
+            plans[t] = Euler3DPlan(n, Ht, V, 31, p, dfr_ops(n), metric3d_torch(tile, dev), on_panel_edge=topo.on_panel_edge(t))
+            if k == 1 and glob is None:
+                pass
+        if glob is None:   # the global state, once, from the whole-panel tiles
+            qs = []
+            for p in range(6):
+                q = torch.from_numpy(np.array(initial_state(CubedSphere3DTile(n, Htot, V, p, 10000.0, 31)))).to(dev)
+                qs.append(q * (1.0 + 0.01 * (torch.rand(q.shape, generator=gen, device=dev, dtype=q.dtype) - 0.5)))
+            glob = torch.stack(qs)
+            vglob = (torch.rand(glob.shape, generator=gen, device=dev, dtype=glob.dtype) - 0.5) * \
+                glob.abs().amax(dim=(0, 2, 3, 4, 5), keepdim=True) * 1e-3
+        ex = PanelExchange(plans[0].edge_count, dev, rank=0, world_size=1, tiles_per_side=k)
+        rhs = RhsEuler3D(plans, ex)
+        Q = distribute_cube(glob, tiles_per_side=k, device=dev)
+        v = distribute_cube(vglob, tiles_per_side=k, device=dev)
+        R = rhs(Q)
+        J = matvec_fun(v.flatten(), 2.0, Q, R, rhs, "complex").reshape(Q.shape)
+        stepper = Tvdrk3(rhs)
+        Qn = Q
+        for _ in range(3):
+            Qn = stepper.step(Qn, 0.02)
+        runs[k] = tuple(gather_cube(x.contiguous(), tiles_per_side=k) for x in (R, J, Qn))
+    for a, b, what in zip(runs[1], runs[2], ("R", "J v", "Q after 3 steps")):
+        scale = a.abs().amax(dim=(0, 2, 3, 4, 5), keepdim=True)
+        err = ((a - b).abs() / scale).amax(dim=(0, 2, 3, 4, 5))
+        assert float(a.abs().max()) > 0 and (err <= 1e-13).all(), (what, err)

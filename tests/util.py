@@ -12,6 +12,8 @@ EULER_FIXTURES = [
     "euler3d_c31_n8_h2_v2",
     "euler3d_c21_n4_h3_v4",
     "euler3d_c31p_n5_h2_v1",
+    "euler3d_c31p_n2_h4_v3",
+    "euler3d_c31p_n6_h2_v2",
 ]
 
 # fixtures that also hold R from the reference's monolithic rhs/rhs_euler.py ("R_mono")
