@@ -438,6 +438,20 @@ wx_status wx_multi_axpy(double* w, const double* V, size_t ldv, int m, const dou
 size_t wx_kiops_finish_workspace(size_t len);
 wx_status wx_kiops_finish(double* V, size_t ldv, int j, size_t n, int p, int iop, const double* aw, const double* uflip,
                           double* hcol, double* workspace, wx_stream stream);
+/* The same Krylov vector for LONG vectors (the E7 sphere: 442 M doubles), in three streaming stages whose reductions the
+ * caller completes in between - over ranks (all-reduce: BASELINE config 5 runs KIOPS on 6 GPUs) and with the p replicated
+ * augmented components - 11 vector sweeps per Krylov vector instead of 14 and a tall-skinny gemv:
+ *   wx_kiops_long_a  V[j][:n] = aw + uflip @ V[j-1][n:];  V[j][n:] = V[j-1][n+1:], 0;
+ *                    dots[r - ilow] = <V[r][:n], V[j][:n]>,  ilow = max(0, j - iop) <= r < j      (dots: device, iop doubles)
+ *   wx_kiops_long_b  V[j][:] -= sum_r h[r - ilow] V[r][:]  (h: device, the completed products);  *nrm2 = |V[j][:n]|^2
+ *   wx_kiops_long_c  V[j][:] /= sqrt(*nrm2)  (nrm2: device, the completed squared norm);  hcol[j] = that root
+ * workspace: wx_kiops_long_workspace() doubles on the device.  p <= 16, iop <= 4.  Deterministic reductions. */
+size_t wx_kiops_long_workspace(void);
+wx_status wx_kiops_long_a(double* V, size_t ldv, int j, size_t n, int p, int iop, const double* aw, const double* uflip,
+                          double* dots, double* workspace, wx_stream stream);
+wx_status wx_kiops_long_b(double* V, size_t ldv, int j, size_t n, int p, int iop, const double* h, double* nrm2,
+                          double* workspace, wx_stream stream);
+wx_status wx_kiops_long_c(double* V, size_t ldv, int j, size_t n, int p, const double* nrm2, double* hcol, wx_stream stream);
 wx_status wx_multi_dot2(const double* V, size_t ldv, int m, const double* a, const double* b, size_t n, double* out,
                         double* workspace, wx_stream stream);
 wx_status wx_pair_update(double* a, double* b, const double* V, size_t ldv, int m, const double* ha, const double* hb,

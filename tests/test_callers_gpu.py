@@ -442,3 +442,41 @@ def test_multistep_epi_orders(built_lib, order):
     upd = np.abs(ref - q0).max(axis=ax)
     err = np.abs(Q.cpu().numpy() - ref).max(axis=ax)
     assert (err <= 2e-5 * upd + 1e-13 * np.abs(ref).max(axis=ax)).all(), (err / upd)
+
+
+@pytest.mark.parametrize("p,taus", [(1, [1.0]), (3, [0.4, 1.0])])
+def test_kiops_long_vector_build(built_lib, p, taus, monkeypatch):
+    """Vectors too long for the one-workgroup finish take the three streaming stages (wx_kiops_long_a/b/c): same
+    phi-vectors and the same adaptive decisions as the array-expression recurrence they replace (WXHIP_KIOPS_LONG=0),
+    and the exact result for a diagonal operator."""
+    from wxfactory_amd import solvers
+    from wxfactory_amd.solvers import kiops
+
+    monkeypatch.setattr(solvers.KiopsWorkspace, "max_fused_len", 4096)   # (make a modest length count as long)
+    n = 50_000
+    gen = torch.Generator(device=DEV).manual_seed(17 + p)
+    lam = -(0.2 + 2.5 * torch.rand(n, generator=gen, device=DEV, dtype=torch.float64))
+    u = torch.randn((p + 1, n), generator=gen, device=DEV, dtype=torch.float64)
+    A = lambda v: lam * v  # noqa: E731
+    args = dict(tol=1e-10, m_init=12, mmin=10, mmax=40)
+    w_long, st_long = kiops(taus, A, u, **args)
+    monkeypatch.setenv("WXHIP_KIOPS_LONG", "0")
+    w_expr, st_expr = kiops(taus, A, u, **args)
+    assert st_long[:4] == st_expr[:4] and st_long[5] == st_expr[5], (st_long, st_expr)
+    scale = float(w_expr.abs().max())
+    assert float((w_long - w_expr).abs().max()) <= 1e-11 * scale
+    # exact: w(tau) = sum_k tau^k phi_k(tau lam) u_k
+    import math
+
+    def phi(k, z):
+        if k == 0:
+            return torch.exp(z)
+        return (phi(k - 1, z) - 1.0 / math.factorial(k - 1)) / z
+
+    for i, tau in enumerate(taus):
+        ref = sum((tau ** k) * phi(k, tau * lam) * u[k] for k in range(p + 1))
+        assert float((w_long[i] - ref).abs().max()) <= 1e-8 * float(ref.abs().max())
+    # a NaN in the operator ends the solve with an error instead of an endless loop of rejections
+    bad = lambda v: lam * v * float("nan")  # noqa: E731
+    with pytest.raises(ValueError, match="NaN"):
+        kiops([1.0], bad, u[:2], **args)

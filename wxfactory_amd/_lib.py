@@ -86,6 +86,11 @@ SIGNATURES = {
     "wx_kiops_finish_workspace": (c_size_t, [c_size_t]),
     "wx_kiops_finish": (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p]),
+    "wx_kiops_long_workspace": (c_size_t, []),
+    "wx_kiops_long_a": (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_void_p]),
+    "wx_kiops_long_b": (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wx_kiops_long_c": (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_int, c_void_p, c_void_p, c_void_p]),
     "wx_multi_dot2": (c_int, [c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "wx_pair_update": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_size_t, c_double,
                                c_double, c_double, c_void_p]),

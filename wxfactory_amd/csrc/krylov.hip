@@ -240,6 +240,69 @@ __global__ __launch_bounds__(kFinishThreads) void kiops_finish_c(double* __restr
     if (blockIdx.x == 0 && threadIdx.x == 0) hcol[j] = nrm;
 }
 
+// The same Krylov vector for LONG vectors (E7: 442 M doubles), as three streaming kernels whose reductions leave through
+// small device buffers, so that the caller can complete them (all-reduce over ranks, the p replicated augmented
+// components) between the stages:
+//   long_a  V[j][:n] = aw + uflip @ V[j-1][n:];  V[j][n:] = V[j-1][n+1:], 0;  partial <V[r][:n], V[j][:n]>, ilow <= r < j
+//   long_b  V[j][:] -= sum_r h[r] V[r][:]  (h: device, the caller's completed products);  partial |V[j][:n]|^2
+//   long_c  V[j][:] /= sqrt(*nrm2)         (nrm2: device, the caller's completed squared norm);  hcol[j] = that root
+// Passes over memory per vector (p = 1, iop = 2): 5 + 4 + 2 = 11 vector sweeps, against 14 and a tall-skinny rocBLAS gemv
+// for the array-expression form; deterministic two-stage reductions (multi_dot_finish_kernel sums the partials).
+constexpr int kLongBlocks = 2048;
+
+__global__ __launch_bounds__(kFinishThreads) void kiops_long_a(double* __restrict__ V, size_t ldv, int j, size_t n, int p,
+                                                               int iop, const double* __restrict__ aw,
+                                                               const double* __restrict__ uflip, double* __restrict__ part) {
+    __shared__ double red[4];
+    __shared__ double aug[kFinishMaxP];
+    double* vj = V + (size_t)j * ldv;
+    const double* vp = V + (size_t)(j - 1) * ldv;
+    if (threadIdx.x < p) aug[threadIdx.x] = vp[n + threadIdx.x];
+    __syncthreads();
+    const int ilow = j - iop > 0 ? j - iop : 0, nr = j - ilow;
+    double acc[kFinishMaxIop] = {0.0, 0.0, 0.0, 0.0};
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double w = aw[i];
+        for (int k = 0; k < p; ++k) w += uflip[i * p + k] * aug[k];
+        vj[i] = w;
+        for (int r = 0; r < nr; ++r) acc[r] += V[(size_t)(ilow + r) * ldv + i] * w;
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < p) vj[n + threadIdx.x] = (int)threadIdx.x + 1 < p ? aug[threadIdx.x + 1] : 0.0;
+    for (int r = 0; r < kFinishMaxIop; ++r) {
+        const double t = wg_sum256(r < nr ? acc[r] : 0.0, red);
+        if (threadIdx.x == 0) part[(size_t)blockIdx.x * kFinishMaxIop + r] = t;
+    }
+}
+
+__global__ __launch_bounds__(kFinishThreads) void kiops_long_b(double* __restrict__ V, size_t ldv, int j, size_t n, int p,
+                                                               int iop, const double* __restrict__ h, double* __restrict__ part) {
+    __shared__ double red[4];
+    double* vj = V + (size_t)j * ldv;
+    const int ilow = j - iop > 0 ? j - iop : 0, nr = j - ilow;
+    double c[kFinishMaxIop] = {0.0, 0.0, 0.0, 0.0};
+    for (int r = 0; r < nr; ++r) c[r] = h[r];
+    const size_t len = n + (size_t)p, stride = (size_t)gridDim.x * blockDim.x;
+    double nn = 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) {
+        double w = vj[i];
+        for (int r = 0; r < nr; ++r) w -= c[r] * V[(size_t)(ilow + r) * ldv + i];
+        vj[i] = w;
+        if (i < n) nn += w * w;
+    }
+    const double t = wg_sum256(nn, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(kFinishThreads) void kiops_long_c(double* __restrict__ V, size_t ldv, int j, size_t len,
+                                                               const double* __restrict__ nrm2, double* __restrict__ hcol) {
+    double* vj = V + (size_t)j * ldv;
+    const double nrm = sqrt(*nrm2);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) vj[i] /= nrm;
+    if (blockIdx.x == 0 && threadIdx.x == 0) hcol[j] = nrm;
+}
+
 template <int R>
 static void launch_dot2(const double* V, size_t ldv, int row0, const double* a, const double* b, size_t n, double* partial,
                         int m, hipStream_t st) {
@@ -324,6 +387,48 @@ wx_status wx_kiops_finish(double* V, size_t ldv, int j, size_t n, int p, int iop
     hipLaunchKernelGGL(kiops_finish_a, dim3(G), dim3(kFinishThreads), 0, st, V, ldv, j, n, p, iop, aw, uflip, workspace);
     hipLaunchKernelGGL(kiops_finish_b, dim3(G), dim3(kFinishThreads), 0, st, V, ldv, j, n, p, iop, workspace, hcol);
     hipLaunchKernelGGL(kiops_finish_c, dim3(G), dim3(kFinishThreads), 0, st, V, ldv, j, n, p, workspace, hcol);
+    WX_HIP_TRY(hipGetLastError());
+    return WX_OK;
+}
+
+size_t wx_kiops_long_workspace(void) { return (size_t)kLongBlocks * kFinishMaxIop; }
+
+static wx_status kiops_long_check(const void* V, int j, int p, int iop, size_t ldv, size_t n, const char* who) {
+    if (!V) return fail(WX_ERR_INVALID, "%s: null argument", who);
+    if (j < 1 || p < 1 || p > kFinishMaxP || iop < 1 || iop > kFinishMaxIop || ldv < n + (size_t)p)
+        return fail(WX_ERR_INVALID, "%s: bad shape (j=%d p=%d iop=%d ldv=%zu n=%zu)", who, j, p, iop, ldv, n);
+    return WX_OK;
+}
+
+wx_status wx_kiops_long_a(double* V, size_t ldv, int j, size_t n, int p, int iop, const double* aw, const double* uflip,
+                          double* dots, double* workspace, wx_stream stream) {
+    wx_status s = kiops_long_check(V, j, p, iop, ldv, n, "wx_kiops_long_a");
+    if (s != WX_OK) return s;
+    if (!aw || !uflip || !dots || !workspace) return fail(WX_ERR_INVALID, "wx_kiops_long_a: null argument");
+    WX_STREAM(st, stream);
+    hipLaunchKernelGGL(kiops_long_a, dim3(kLongBlocks), dim3(kFinishThreads), 0, st, V, ldv, j, n, p, iop, aw, uflip, workspace);
+    const int nr = j - (j - iop > 0 ? j - iop : 0);
+    hipLaunchKernelGGL(multi_dot_finish_kernel, dim3(nr), dim3(64), 0, st, workspace, kLongBlocks, kFinishMaxIop, dots);
+    WX_HIP_TRY(hipGetLastError());
+    return WX_OK;
+}
+
+wx_status wx_kiops_long_b(double* V, size_t ldv, int j, size_t n, int p, int iop, const double* h, double* nrm2,
+                          double* workspace, wx_stream stream) {
+    wx_status s = kiops_long_check(V, j, p, iop, ldv, n, "wx_kiops_long_b");
+    if (s != WX_OK) return s;
+    if (!h || !nrm2 || !workspace) return fail(WX_ERR_INVALID, "wx_kiops_long_b: null argument");
+    WX_STREAM(st, stream);
+    hipLaunchKernelGGL(kiops_long_b, dim3(kLongBlocks), dim3(kFinishThreads), 0, st, V, ldv, j, n, p, iop, h, workspace);
+    hipLaunchKernelGGL(multi_dot_finish_kernel, dim3(1), dim3(64), 0, st, workspace, kLongBlocks, 1, nrm2);
+    WX_HIP_TRY(hipGetLastError());
+    return WX_OK;
+}
+
+wx_status wx_kiops_long_c(double* V, size_t ldv, int j, size_t n, int p, const double* nrm2, double* hcol, wx_stream stream) {
+    if (!V || !nrm2 || !hcol || j < 1 || p < 1 || ldv < n + (size_t)p) return fail(WX_ERR_INVALID, "wx_kiops_long_c: bad argument");
+    WX_STREAM(st, stream);
+    hipLaunchKernelGGL(kiops_long_c, dim3(kLongBlocks), dim3(kFinishThreads), 0, st, V, ldv, j, n + (size_t)p, nrm2, hcol);
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
 }

@@ -560,7 +560,9 @@ class KiopsWorkspace:
             self.finish_work = None
             self.aw = torch.empty(n, dtype=dtype, device=dev)   # the matvec's output in the one-call vector build
             if self.basis.gpu:
-                self.finish_work = torch.empty(int(self.basis.lib.wx_kiops_finish_workspace(n + p)), dtype=dtype, device=dev)
+                words = max(int(self.basis.lib.wx_kiops_finish_workspace(n + p)), int(self.basis.lib.wx_kiops_long_workspace()))
+                self.finish_work = torch.empty(words, dtype=dtype, device=dev)
+                self.dots = torch.empty(4, dtype=dtype, device=dev)   # the iop products of the long-vector build
             self.graphs.clear()
             self.seen.clear()
         return self
@@ -602,6 +604,18 @@ class KiopsWorkspace:
         self.replays += 1
 
 
+def _combine_rows(basis: "_Basis", Vd: torch.Tensor, j: int, n: int, coef) -> torch.Tensor:
+    """sum_{i<j} coef[i] Vd[i, :n]: one streaming sweep over the rows on the GPU (wx_multi_axpy into a zeroed vector; the
+    (1 x j) @ (j x n) product goes through a rocBLAS GEMM kernel at a fifth of that rate), the array expression elsewhere."""
+    if not (basis.gpu and n > KiopsWorkspace.max_fused_len):
+        return torch.as_tensor(coef, dtype=Vd.dtype, device=Vd.device) @ Vd[:j, :n]
+    out = torch.zeros(n, dtype=Vd.dtype, device=Vd.device)
+    h = (-torch.as_tensor(coef, dtype=torch.float64)).to(Vd.device)
+    st = torch.cuda.current_stream(Vd.device).cuda_stream
+    basis.check(basis.lib.wx_multi_axpy(out.data_ptr(), Vd.data_ptr(), Vd.stride(0), j, h.data_ptr(), n, st), "wx_multi_axpy")
+    return out
+
+
 def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int = 10, mmin: int = 10, mmax: int = 128,
           iop: int = 2, task1: bool = False, group=None, workspace: Optional[KiopsWorkspace] = None, graph_token=None):
     """w(i) = sum_k phi_k(tau_i A) u[k]  by the adaptive Krylov method with incomplete orthogonalisation.
@@ -639,6 +653,9 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
     fused_finish = (basis.gpu and not split and n + p <= KiopsWorkspace.max_fused_len and p <= 16 and iop <= 4
                     and os.environ.get("WXHIP_KIOPS_FUSED", "1") != "0")
     fused_vector = getattr(A, "kiops_vector", None) if fused_finish else None
+    # long vectors: three streaming kernels per Krylov vector; their reductions are completed here in between (all-reduce
+    # over the ranks, the replicated augmented components)
+    long_build = (basis.gpu and not fused_finish and p <= 16 and iop <= 4 and os.environ.get("WXHIP_KIOPS_LONG", "1") != "0")
 
     def products(lo: int, hi: int, j: int, out: torch.Tensor):
         """out[k - lo] = <V[k], V[j]> over the n + p components, lo <= k < hi"""
@@ -690,6 +707,27 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
                                                       u_flip_t.data_ptr(), Ht[j - 1].data_ptr(), ws.finish_work.data_ptr(),
                                                       torch.cuda.current_stream(dev).cuda_stream), "wx_kiops_finish")
                 return
+            if long_build:
+                lib, st = basis.lib, torch.cuda.current_stream(dev).cuda_stream
+                aw = A(Vd[j - 1, :n])
+                if not aw.is_contiguous():
+                    aw = aw.contiguous()
+                ilow = max(0, j - iop)
+                hcol = Ht[j - 1]
+                basis.check(lib.wx_kiops_long_a(Vd.data_ptr(), Vd.stride(0), j, n, p, iop, aw.data_ptr(), u_flip_t.data_ptr(),
+                                                ws.dots.data_ptr(), ws.finish_work.data_ptr(), st), "wx_kiops_long_a")
+                t = ws.dots[: j - ilow]
+                if split:
+                    t = _allreduce(t, group)
+                torch.addmv(t, Vd[ilow:j, n:], Vd[j, n:], out=hcol[ilow:j])   # + the augmented components, once
+                basis.check(lib.wx_kiops_long_b(Vd.data_ptr(), Vd.stride(0), j, n, p, iop, hcol[ilow:j].data_ptr(),
+                                                nrm2.data_ptr(), ws.finish_work.data_ptr(), st), "wx_kiops_long_b")
+                if split:
+                    _allreduce(nrm2, group)
+                nrm2.add_(torch.dot(Vd[j, n:], Vd[j, n:]))
+                basis.check(lib.wx_kiops_long_c(Vd.data_ptr(), Vd.stride(0), j, n, p, nrm2.data_ptr(), hcol.data_ptr(), st),
+                            "wx_kiops_long_c")
+                return
             torch.addmv(A(Vd[j - 1, :n]), u_flip_t, Vd[j - 1, n:], out=Vd[j, :n])
             torch.mv(shift, Vd[j - 1, n:], out=Vd[j, n:])  # augmented components: up by one, zero at the end
             ilow = max(0, j - iop)
@@ -728,6 +766,11 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
             happy = False
         else:
             err = abs(beta * nrm * F[j - 1, j])
+            if err != err:
+                # The reference's loop never ends on a NaN (`omega <= delta` is false forever, solvers/kiops.py:291): its
+                # NaN check sits after the step (simulation.py:399-408) and is never reached.  Every rank computes the same
+                # estimate from all-reduced numbers, so all of them raise here together.
+                raise ValueError("NaN in the KIOPS error estimate (the Krylov basis or the operator produced a NaN)")
             accepted = ctl.judge(err, j, tau_now)
         if accepted:
             reject += retries
@@ -741,9 +784,9 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
                 w[l + blown] = w[l]
                 for k in range(blown):
                     F2 = _expm(sgn * (tau_out[l + k] - tau_now) * H[:j, :j])
-                    w[l + k] = torch.as_tensor(beta * F2[:j, 0], dtype=dtype, device=dev) @ Vd[:j, :n]
+                    w[l + k] = _combine_rows(basis, Vd, j, n, beta * F2[:j, 0])
                 l += blown
-            w[l] = torch.as_tensor(beta * F[:j, 0], dtype=dtype, device=dev) @ Vd[:j, :n]
+            w[l] = _combine_rows(basis, Vd, j, n, beta * F[:j, 0])
             tau_now += tau
             j = 0
             conv += err
