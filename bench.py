@@ -342,6 +342,57 @@ def rhs_benchmark_matrix(dev, seed):
     return rows
 
 
+def epi2_kiops_e7_extras(dev, seed, n=8, H=60, V=2, dt=0.5, steps=3):
+    """BASELINE config 5 at the benchmark's resolution: EPI2 + KIOPS (complex-step JVP, tol 1e-7) on the whole sphere at
+    n = 8, 60 x 60 elements per panel, V = 2 vertical elements (a Krylov basis of 64 vectors of the V = 8 sphere does not
+    fit on one GPU beside the metric), DCMIP 3-1 + 1 % perturbation: time per step and per Krylov vector, beside the bare
+    prepared matvec - i.e. what the solver adds around the kernels (wx_kiops_long_*: 11 vector sweeps per Krylov vector)."""
+    from wxfactory_amd.geometry3d import CubedSphere3DTile, metric3d_torch
+    from wxfactory_amd.initial import initial_state
+    from wxfactory_amd.integrators import Epi
+    from wxfactory_amd.matvec import ComplexStepOperator
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D
+    from wxfactory_amd import synthetic
+
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    plans, qs = {}, []
+    for p in range(6):
+        t = CubedSphere3DTile(n, H, V, p, 10000.0, 31)
+        plans[p] = Euler3DPlan(n, H, V, 31, p, synthetic.dfr_ops(n), metric3d_torch(t, dev))
+        q = torch.from_numpy(initial_state(t)).to(dev)
+        qs.append(q * (1.0 + 0.01 * (torch.rand(q.shape, generator=gen, device=dev, dtype=q.dtype) - 0.5)))
+    Q = torch.stack(qs)
+    rhs = RhsEuler3D(plans)
+    R = rhs(Q)
+    op = ComplexStepOperator(dt, Q, R, rhs)
+    v = torch.randn(Q.numel(), generator=gen, device=dev, dtype=torch.float64)
+    for _ in range(3):
+        op(v)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        op(v)
+    torch.cuda.synchronize()
+    mv = (time.perf_counter() - t0) / 10
+    rhs.jvp_release()
+    del op, v
+    epi = Epi(2, rhs, tol=1e-7)
+    Q = epi.step(Q, dt)   # first step: basis and workspace allocation
+    rows = []
+    for _ in range(steps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        Q = epi.step(Q, dt)
+        torch.cuda.synchronize()
+        t = time.perf_counter() - t0
+        rows.append((t, int(epi.solver_info["iterations"])))
+    t, it = min(rows)
+    return {"workload": f"EPI2 + KIOPS, n={n}, {H}x{H}x{V} elements/panel, 6 panels ({Q.numel()} DOF), dt={dt} s, tol 1e-7",
+            "step_ms": round(t * 1e3, 1), "krylov_vectors": it, "ms_per_krylov_vector": round(t / it * 1e3, 3),
+            "prepared_matvec_ms": round(mv * 1e3, 3), "solver_overhead_over_matvec": round(t / it / mv - 1.0, 3),
+            "finite": bool(torch.isfinite(Q).all())}
+
+
 def e7_v1_extras(dev, seed, n=8, H=60):
     """E7 is reported at V in {1, 8}; the headline is V = 8, this is the whole-sphere R(Q) at V = 1
     (one vertical element, 8 levels; 6 x 1.8 M points: the six panels go in one launch per phase)."""
@@ -740,6 +791,7 @@ def main():
             del rhs, qs, plans, out
             torch.cuda.empty_cache()
             line["extra"]["euler_e7_v1"] = e7_v1_extras(dev, args.seed)
+            line["extra"]["epi2_kiops_e7"] = epi2_kiops_e7_extras(dev, args.seed)
             line["extra"]["rhs_benchmark_matrix"] = rhs_benchmark_matrix(dev, args.seed)
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, V, args.seed, H)
