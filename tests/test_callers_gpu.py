@@ -465,6 +465,13 @@ def test_kiops_long_vector_build(built_lib, p, taus, monkeypatch):
     assert st_long[:4] == st_expr[:4] and st_long[5] == st_expr[5], (st_long, st_expr)
     scale = float(w_expr.abs().max())
     assert float((w_long - w_expr).abs().max()) <= 1e-11 * scale
+    # the several-rank form of the same stages (products of the n-long parts all-reduced, the replicated augmented
+    # components added once afterwards), taken here on one rank
+    monkeypatch.delenv("WXHIP_KIOPS_LONG")
+    monkeypatch.setenv("WXHIP_KIOPS_SPLIT_TEST", "1")
+    w_split, st_split = kiops(taus, A, u, **args)
+    monkeypatch.delenv("WXHIP_KIOPS_SPLIT_TEST")
+    assert st_split[:4] == st_long[:4] and float((w_split - w_long).abs().max()) <= 1e-12 * scale
     # exact: w(tau) = sum_k tau^k phi_k(tau lam) u_k
     import math
 

@@ -645,6 +645,8 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
     Vd, basis, Ht, nrm2 = ws.Vd, ws.basis, ws.Ht, ws.nrm2
     H = np.zeros((mmax + 1, mmax + 1))
     split = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if os.environ.get("WXHIP_KIOPS_SPLIT_TEST") == "1":
+        split = True   # (tests: take the several-rank code paths - reductions completed after an all-reduce - on one rank)
     # HIP graphs of whole passes: single rank (no collective inside), launch-bound sizes, an operator the caller vouches for
     use_graphs = (workspace is not None and graph_token is not None and not split and Vd.is_cuda
                   and n <= KiopsWorkspace.max_graph_points)
