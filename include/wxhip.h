@@ -20,6 +20,10 @@
  *     DEVICE first (so that static fields still being produced on a non-blocking stream are complete,
  *     and no kernel is still reading constants about to be replaced).  Do not call them while a
  *     stream is being captured into a graph.
+ *   - two evaluation-time entry points allocate ONCE per plan, on their first use: wx_euler3d_jvp_prepare (the cache of
+ *     face values) and the stage pipeline (wx_euler3d_stage / wx_euler3d_extrap_pack_slot: the second interface slot).
+ *     Make that first call outside a stream capture (graph.py warms every captured function up for this reason); later
+ *     calls allocate nothing.
  *   - device flags (nan_flag arguments) are only ever raised to 1 by plain stores from many threads - one
  *     value, so no atomic is needed - and never cleared by the library.
  *   - arrays are C-contiguous float64 (WX_F64) or complex128 (WX_C128, interleaved

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import Golden, var_max
+from tests.util import Golden
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"

@@ -8,7 +8,7 @@ run at any rank count and vice versa (reference tests/unit/restart/test_restart.
 gather_cube / distribute_cube move TENSORS (torch.distributed gather / scatter to and from rank 0, RCCL
 on GPUs, gloo on CPU): only rank 0 ever holds the global state, as in the reference.
 """
-from typing import List, Optional, Tuple
+from typing import Optional, Tuple
 
 import numpy
 import torch
