@@ -291,3 +291,44 @@ def test_result_does_not_depend_on_the_decomposition(n, Htot, V):
         scale = a.abs().amax(dim=(0, 2, 3, 4, 5), keepdim=True)
         err = ((a - b).abs() / scale).amax(dim=(0, 2, 3, 4, 5))
         assert float(a.abs().max()) > 0 and (err <= 1e-13).all(), (what, err)
+
+
+def test_fifty_filtered_steps_at_benchmark_resolution_conserve_mass():
+    """A time loop of the benchmark's horizontal resolution (n = 8, 60 x 60 elements per panel, one vertical element,
+    55 M DOF): fifty pipelined SSP-RK3 steps, each followed by the exponential filter fused into the last stage, NaN flag
+    raised in the same kernels.  Properties that do not depend on the size: the total mass  sum w sqrtG rho  stays put to
+    rounding (flux form + a filter that leaves the element mean alone), the state stays finite, the flag stays down."""
+    from wxfactory_amd.filters import ExpFilter3D, NanFlag, make_filter
+    from wxfactory_amd.geometry3d import CubedSphere3DTile, metric3d_torch
+    from wxfactory_amd.initial import initial_state
+    from wxfactory_amd.integrators import StepLoop, Tvdrk3
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D
+    from wxfactory_amd.synthetic import dfr_ops
+
+    dev = "cuda:0"
+    n, H, V = 8, 60, 1
+    w1 = np.polynomial.legendre.leggauss(n)[1]
+    w3 = torch.from_numpy(np.einsum("k,j,i->kji", w1, w1, w1).reshape(-1)).to(dev)
+    plans, qs, sg = {}, [], []
+    gen = torch.Generator(device=dev).manual_seed(5)
+    for p in range(6):
+        t = CubedSphere3DTile(n, H, V, p, 10000.0, 31)
+        m = metric3d_torch(t, dev)
+        sg.append(m["sqrtG"])
+        plans[p] = Euler3DPlan(n, H, V, 31, p, dfr_ops(n), m)
+        q = torch.from_numpy(np.array(initial_state(t))).to(dev)
+        qs.append(q * (1.0 + 0.005 * (torch.rand(q.shape, generator=gen, device=dev, dtype=q.dtype) - 0.5)))
+    Q = torch.stack(qs)
+    SG = torch.stack(sg)
+    rhs = RhsEuler3D(plans)
+    rhs.batched = False   # per-panel launches: the stage kernels with prepared faces and the fused filter
+    flag = NanFlag(dev)
+    F = make_filter(1e-3, 4, 0.5, np.polynomial.legendre.leggauss(n)[0])
+    loop = StepLoop(Tvdrk3(rhs), ExpFilter3D(F, sg), flag, check_every=10)
+    assert loop.fused
+    mass = lambda X: float((SG * X[:, 0] * w3).sum())  # noqa: E731
+    m0 = mass(Q)
+    Qn = loop.run(Q, 0.01, 50)
+    flag.raise_if_set()
+    assert torch.isfinite(Qn).all() and float((Qn - Q).abs().max()) > 0
+    assert abs(mass(Qn) - m0) <= 1e-11 * abs(m0), (m0, mass(Qn))
