@@ -274,7 +274,7 @@ class _Recorder:
         return self._wrap(self._ss(*a, **k), "scalars")
 
 
-def sw_case(name, ini, overrides, perturb=0.0, seed=4321, n_ranks=6):
+def sw_case(name, ini, overrides, perturb=0.0, seed=4321, n_ranks=6, rk3=None):
     cfg_probe = _config(ini, overrides)
     print(f"[{name}] {ini} n={cfg_probe.num_solpts} H={cfg_probe.num_elements_horizontal} on {n_ranks} ranks", flush=True)
 
@@ -316,6 +316,18 @@ def sw_case(name, ini, overrides, perturb=0.0, seed=4321, n_ranks=6):
         out["Rc"] = Rc.copy()
         out["chalo"] = numpy.stack([numpy.stack([rec.scalars[e], rec.vectors[e][0], rec.vectors[e][1]])
                                     for e in range(4)])
+        if rk3 is not None:   # the explicit time loop of BASELINE configs 2 / 3: Tvdrk3.step + apply_filters (simulation.py:147-155)
+            from integrators import Tvdrk3
+
+            nsteps, dt_rk = rk3
+            stepper = Tvdrk3(cfg, rhs.full, device=dev)
+            Qs = Q.copy()
+            for i in range(nsteps):
+                Qs = stepper.step(Qs, dt_rk)
+                Qs = ops.apply_filters(Qs, geom, metric, dt_rk)
+                if i == 0:
+                    out["rk3_1"] = Qs.copy()
+            out["rk3_n"] = Qs.copy()
         for a in SW_METRIC_ATTRS:
             out["metric/" + a] = numpy.array(getattr(metric, a), copy=True)
         if topo is not None:
@@ -331,6 +343,8 @@ def sw_case(name, ini, overrides, perturb=0.0, seed=4321, n_ranks=6):
             out["meta/H"] = numpy.int64(cfg.num_elements_horizontal)
             out["meta/k"] = numpy.int64(per_line)
             out["meta/eps"] = numpy.float64(eps)
+            if rk3 is not None:
+                out["meta/rk3_steps"], out["meta/rk3_dt"] = numpy.int64(rk3[0]), numpy.float64(rk3[1])
             out["meta/grid_rotation"] = numpy.array([cfg.lambda0, cfg.phi0, cfg.alpha0], dtype=float)
             n = cfg.num_solpts
             u = numpy.random.default_rng(7).uniform(-1, 1, n * n)
@@ -366,7 +380,7 @@ def sw_case(name, ini, overrides, perturb=0.0, seed=4321, n_ranks=6):
 # ---------------------------------------------------------------------------------------------
 # 2-D Cartesian Euler (rhs_dfr.py:8-45 + pde_euler_cartesian.py + the reference's native pde_cpp)
 # ---------------------------------------------------------------------------------------------
-def cart2d_case(name, ini, overrides, seed=99):
+def cart2d_case(name, ini, overrides, seed=99, rk3=None):
     MPI.reset_world(1)
 
     def work(rank):
@@ -394,6 +408,19 @@ def cart2d_case(name, ini, overrides, seed=99):
         eps = numpy.sqrt(numpy.finfo(float).eps)
         out["V"] = v
         out["Rc"] = rhs.full(Q + 1j * eps * v).copy()
+        if rk3 is not None:   # BASELINE config 1's explicit time loop: Tvdrk3.step + apply_filters (simulation.py:147-155)
+            from integrators import Tvdrk3
+
+            nsteps, dt_rk = rk3
+            stepper = Tvdrk3(cfg, rhs.full, device=dev)
+            Qs = Q.copy()
+            for i in range(nsteps):
+                Qs = stepper.step(Qs, dt_rk)
+                Qs = ops.apply_filters(Qs, geom, metric, dt_rk)
+                if i == 0:
+                    out["rk3_1"] = Qs.copy()
+            out["rk3_n"] = Qs.copy()
+            out["meta/rk3_steps"], out["meta/rk3_dt"] = numpy.int64(nsteps), numpy.float64(dt_rk)
         out.update(_ops_1d(ops, geom))
         out["meta/n"] = numpy.int64(cfg.num_solpts)
         out["meta/nx"] = numpy.int64(cfg.num_elements_horizontal)
@@ -997,6 +1024,14 @@ CASES = {
                                                dict(num_solpts=5, num_elements_horizontal=7, num_elements_vertical=9)),
     "cart2d_bubble_n4": lambda nm: cart2d_case(nm, "gaussian_bubble.ini",
                                                dict(num_solpts=4, num_elements_horizontal=5, num_elements_vertical=6)),
+    # --- round 3: the explicit time loops of BASELINE configs 1-3 (SSP-RK3 on the 2-D Cartesian bubble and on the
+    # shallow-water sphere: config/case6.ini at p = 4 = config 2, and at p = 7 = the order of config 3, whose own
+    # galewsky.ini cannot initialise in the reference at this commit - BASELINE.md section 2)
+    "sw_rk3_c6_n5_h4": lambda nm: sw_case(nm, "case6.ini", dict(num_solpts=5, num_elements_horizontal=4), rk3=(5, 60.0)),
+    "sw_rk3_c6_n8_h3": lambda nm: sw_case(nm, "case6.ini", dict(num_solpts=8, num_elements_horizontal=3), rk3=(5, 40.0)),
+    "cart2d_rk3_bubble_n4": lambda nm: cart2d_case(nm, "gaussian_bubble.ini",
+                                                  dict(num_solpts=4, num_elements_horizontal=5, num_elements_vertical=6),
+                                                  rk3=(5, 0.01)),
     # --- round 3: the remaining templated orders straight from the reference (n = 2 is what config/dcmip31.ini ships
     # with; 6 was pinned through the oracle on synthetic tiles only)
     "euler3d_c31p_n2_h4_v3": lambda nm: euler_case(
