@@ -62,11 +62,14 @@ struct Cfg {
     static constexpr int N2 = N * N;
     static constexpr int N3 = N * N * N;
     // elements per workgroup: whole elements, <= 256 points unless one element is larger
-    static constexpr int EPB = (N3 >= 216) ? 1 : (256 / N3);
+    static constexpr int EPB = (N3 >= 216) ? 1 : (256 / N3);   // (n = 3 with 8 instead of 9 elements: fused kernel -5 %, extrapolation +9 %)
     static constexpr int BS = ((EPB * N3 + 63) / 64) * 64;
     // LDS image of one element's nodal field: rows of N nodes padded to an odd length so that
-    // line reads along i (lane stride = one row) do not pile onto a few banks (N=8: 8-way -> none)
-    static constexpr int NP = (N % 2 == 0) ? N + 1 : N;
+    // line reads along i (lane stride = one row) do not pile onto a few banks (N=8: 8-way -> none).
+    // Not for n = 2, 4: there the padding's LDS costs a workgroup per CU (n = 4: 42.3 KB -> 38.2 KB, 3 -> 4 workgroups,
+    // fused kernel 113 -> 99 us on the reference's benchmark size; n = 2 JVP kernel 1 -> 2 workgroups, matvec 0.48 -> 0.33 ms)
+    // and the conflicts it would avoid are at most two-way
+    static constexpr int NP = (N % 2 == 0 && N >= 6) ? N + 1 : N;
     static constexpr int LE = N2 * NP;  // doubles per element image
     __host__ __device__ static constexpr int lidx(int kl, int jl, int il) { return (kl * N + jl) * NP + il; }
 };
