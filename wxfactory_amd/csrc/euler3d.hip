@@ -110,7 +110,7 @@ struct EulerParams {
     // prepared JVP (wx_euler3d_jvp_prepare): the face VALUES of the linearisation state stay in fv (real,
     // [elem][6][5][n^2]) and in the value halos hv_* for a whole Krylov solve; per product only the face TANGENTS are
     // extrapolated (ft, real, same layout; tangent edge messages through send_* / halo_* as REAL arrays)
-    int split;   // 0: off; 1: the JVP kernel reads (fv, ft); 2: the extrapolation kernel writes tangents only (ft)
+    int split;   // 0: off; 1: the JVP kernel reads (fv, ft), written by euler_tan_extrap_kernel (split = 2 there: unused flag)
     double* ft;
     const double* fv;
     const double *hv_s, *hv_n, *hv_w, *hv_e;
@@ -203,12 +203,7 @@ __device__ __forceinline__ void load_state<double>(const EulerParams<double>& P,
 template <>
 __device__ __forceinline__ void load_state<dual>(const EulerParams<dual>& P, size_t o, size_t fs, dual& a0, dual& a1, dual& a2,
                                                  dual& a3, dual& a4) {
-    if (P.jvp && P.split == 2) {   // tangent-only extrapolation: values of the log-extrapolated rows only
-        const double *r = P.q_re, *t = P.q_tan;
-        const double e = P.jvp_eps;
-        a0 = dual(r[o], e * t[o]); a1 = dual(0.0, e * t[fs + o]); a2 = dual(0.0, e * t[2 * fs + o]);
-        a3 = dual(0.0, e * t[3 * fs + o]); a4 = dual(r[4 * fs + o], e * t[4 * fs + o]);
-    } else if (P.jvp) {
+    if (P.jvp) {
         const double *r = P.q_re, *t = P.q_tan;
         const double e = P.jvp_eps;
         a0 = dual(r[o], e * t[o]); a1 = dual(r[fs + o], e * t[fs + o]); a2 = dual(r[2 * fs + o], e * t[2 * fs + o]);
@@ -268,20 +263,9 @@ __device__ __forceinline__ void extrap_faces(const EulerParams<T>& P, T (*fld)[C
         }
         s[0] = w_exp(s[0]);
         s[4] = w_exp(s[4]);
-        bool tan_only = false;
-        if constexpr (std::is_same<T, dual>::value) tan_only = P.split == 2;
-        if constexpr (std::is_same<T, dual>::value) {
-            if (tan_only) {   // prepared JVP: only the tangents of the face values travel (real arrays)
-                double* dt = P.ft + ((size_t)el.e * 6 + f) * 5 * N2 + fp;
+        T* dst = itf_dst + ((size_t)el.e * 6 + f) * NQ * N2 + fp;
 #pragma unroll
-                for (int v = 0; v < 5; ++v) dt[v * N2] = s[v].im;
-            }
-        }
-        if (!tan_only) {
-            T* dst = itf_dst + ((size_t)el.e * 6 + f) * NQ * N2 + fp;
-#pragma unroll
-            for (int v = 0; v < 5; ++v) dst[v * N2] = s[v];
-        }
+        for (int v = 0; v < 5; ++v) dst[v * N2] = s[v];
 
         // outward faces of the tile edge: rotate into the neighbour's basis, flip, pack
         int edge = -1, along = 0;
@@ -302,14 +286,6 @@ __device__ __forceinline__ void extrap_faces(const EulerParams<T>& P, T (*fld)[C
             if (P.K->flip[edge]) { al = H - 1 - along; bb = N - 1 - b; }
             const size_t eo = ((size_t)el.ek * H + al) * N2 + a * N + bb;
             const size_t vs = (size_t)V * H * N2;
-            if constexpr (std::is_same<T, dual>::value) {
-                if (tan_only) {
-                    double* out = reinterpret_cast<double*>(sendp) + eo;
-#pragma unroll
-                    for (int v = 0; v < 5; ++v) out[v * vs] = s[v].im;
-                    continue;
-                }
-            }
             T* out = sendp + eo;
 #pragma unroll
             for (int v = 0; v < 5; ++v) out[v * vs] = s[v];
@@ -353,6 +329,95 @@ __device__ __forceinline__ void euler_extrap_body(const EulerParams<T>& P) {
 template <int N, typename T>
 __global__ __launch_bounds__(Cfg<N>::BS, kK1Waves) void euler_extrap_kernel(const EulerParams<T> P) {
     euler_extrap_body<N, T>(P);
+}
+
+// K1 for the prepared complex-step JVP (wx_euler3d_jvp_tangent_extrap_pack): only the TANGENTS of the face states of
+// (q, eps v) are wanted - the values are cached.  The same arithmetic as the dual-number instantiation above, term by
+// term, on seven real planes (log rho and log rho*theta; their tangents t / q; the three momentum tangents) instead of
+// five 16-byte ones: 32 KB of LDS instead of 46 (n = 8), no value parts carried for the momentum rows - 0.283 -> 0.235 ms per
+// E7 panel (5.4 TB/s, the float64 K1's rate), bit-identical tangents (the prepared and unprepared products still agree to
+// the last bit: tests/test_n8_kernels_gpu.py).
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::BS, kK1Waves) void euler_tan_extrap_kernel(const EulerParams<dual> P) {
+    using C = Cfg<N>;
+    constexpr int N2 = C::N2, N3 = C::N3, EPB = C::EPB, BS = C::BS;
+    __shared__ double pl[7][EPB * C::LE];
+    const int tid = threadIdx.x;
+    const int H = P.H, V = P.V;
+    const size_t fs = (size_t)P.nelem * N3;
+    {
+        const int le = tid / N3, pt = tid % N3;
+        const Elem el = decode_elem(blockIdx.x * EPB + le, P.nelem, WX_REGION_ALL, H, V);
+        if (le < EPB && el.valid) {
+            const size_t o = (size_t)el.e * N3 + pt;
+            const int lp = le * C::LE + C::lidx(pt / N2, (pt / N) % N, pt % N);
+            const double *r = P.q_re, *t = P.q_tan;
+            const double e = P.jvp_eps;
+            const double r0 = r[o], r4 = r[4 * fs + o];
+            pl[0][lp] = log(r0);
+            pl[1][lp] = (e * t[o]) / r0;
+            pl[2][lp] = e * t[fs + o];
+            pl[3][lp] = e * t[2 * fs + o];
+            pl[4][lp] = e * t[3 * fs + o];
+            pl[5][lp] = log(r4);
+            pl[6][lp] = (e * t[4 * fs + o]) / r4;
+        }
+    }
+    __syncthreads();
+    for (int fi = tid; fi < EPB * 6 * N2; fi += BS) {
+        const int le = fi / (6 * N2);
+        const int r = fi % (6 * N2);
+        int f = r / N2;
+        const int fp = r % N2;
+        if (N2 % 64 == 0 && BS % 64 == 0) f = __builtin_amdgcn_readfirstlane(f);
+        const Elem el = decode_elem(blockIdx.x * EPB + le, P.nelem, WX_REGION_ALL, H, V);
+        if (!el.valid) continue;
+        const int d = f >> 1, plus = f & 1;
+        const int a = fp / N, b = fp % N;
+        int base, stride;
+        if (d == 0) { base = C::lidx(a, b, 0); stride = 1; }
+        else if (d == 1) { base = C::lidx(a, 0, b); stride = C::NP; }
+        else { base = C::lidx(0, a, b); stride = N * C::NP; }
+        const double* w = plus ? P.K->ep : P.K->em;
+        double s[7];
+#pragma unroll
+        for (int v = 0; v < 7; ++v) s[v] = 0.0;
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+            const double wm = w[m];
+#pragma unroll
+            for (int v = 0; v < 7; ++v) s[v] += wm * pl[v][le * C::LE + base + m * stride];
+        }
+        double tn[5];
+        tn[0] = exp(s[0]) * s[1];
+        tn[1] = s[2]; tn[2] = s[3]; tn[3] = s[4];
+        tn[4] = exp(s[5]) * s[6];
+        double* dt = P.ft + ((size_t)el.e * 6 + f) * 5 * N2 + fp;
+#pragma unroll
+        for (int v = 0; v < 5; ++v) dt[v * N2] = tn[v];
+        int edge = -1, along = 0;
+        double X = 0.0;
+        if (d == 0 && ((plus && el.ei == H - 1) || (!plus && el.ei == 0))) {
+            edge = plus ? E_E : E_W;
+            along = el.ej;
+            X = P.bwe[el.ej * N + b];
+        } else if (d == 1 && ((plus && el.ej == H - 1) || (!plus && el.ej == 0))) {
+            edge = plus ? E_N : E_S;
+            along = el.ei;
+            X = P.bsn[el.ei * N + b];
+        }
+        dual* sendp = edge == E_S ? P.send_s : (edge == E_N ? P.send_n : (edge == E_W ? P.send_w : P.send_e));
+        if (edge >= 0 && sendp != nullptr) {
+            rotate_contra<double>(P.K->rot[edge], X, tn[1], tn[2]);
+            int al = along, bb = b;
+            if (P.K->flip[edge]) { al = H - 1 - along; bb = N - 1 - b; }
+            const size_t eo = ((size_t)el.ek * H + al) * N2 + a * N + bb;
+            const size_t vs = (size_t)V * H * N2;
+            double* out = reinterpret_cast<double*>(sendp) + eo;
+#pragma unroll
+            for (int v = 0; v < 5; ++v) out[v * vs] = tn[v];
+        }
+    }
 }
 
 // All tiles of a rank in one launch (blockIdx.y = tile): the static per-tile parameters come from a device table,
@@ -1803,7 +1868,19 @@ wx_status wx_euler3d_jvp_tangent_extrap_pack(wx_euler3d_plan* pl, const double* 
         P.send_w = static_cast<dual*>(send_tan[2]); P.send_e = static_cast<dual*>(send_tan[3]);
     }
     WX_STREAM(st, stream);
-    return dispatch_extrap<dual>(pl->n, P, st);
+    const int nelem = (int)pl->nelem;
+#define WX_TAN_CASE(NN)                                                                                                \
+    case NN:                                                                                                           \
+        hipLaunchKernelGGL((euler_tan_extrap_kernel<NN>), dim3((nelem + Cfg<NN>::EPB - 1) / Cfg<NN>::EPB),              \
+                           dim3(Cfg<NN>::BS), 0, st, P);                                                               \
+        break;
+    switch (pl->n) {
+        WX_TAN_CASE(2) WX_TAN_CASE(3) WX_TAN_CASE(4) WX_TAN_CASE(5) WX_TAN_CASE(6) WX_TAN_CASE(7) WX_TAN_CASE(8)
+        default: return fail(WX_ERR_UNSUPPORTED, "num_solpts %d not in 2..8", pl->n);
+    }
+#undef WX_TAN_CASE
+    WX_HIP_TRY(hipGetLastError());
+    return WX_OK;
 }
 
 // out (real) = scale * Im R(q + i eps v) from the cached face values (+ value halos the caller kept) and this product's
