@@ -451,7 +451,7 @@ def jvp_kernel_rooflines(rhs, Q, v, reps=10):
         static = plans[p].bytes_per_point - 80.0          # the RHS kernel's static fields of this plan
         blocks = {}
         for name, ms, bpp in (("euler_jvp_kernel", sum(t2) / len(t2), 40.0 + 40.0 + static + 40.0),
-                              ("tangent_extrapolation (euler_extrap_kernel<dual>)", sum(t1) / len(t1), 16.0 + 40.0 + 240.0 / n)):
+                              ("tangent_extrapolation (euler_tan_extrap_kernel)", sum(t1) / len(t1), 16.0 + 40.0 + 240.0 / n)):
             gbs = bpp * pts / (ms * 1e-3) / 1e9
             blocks[name] = {"bound": "hbm", "launch_ms": round(ms, 4), "algorithmic_bytes_per_point": bpp,
                             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
