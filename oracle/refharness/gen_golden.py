@@ -274,7 +274,7 @@ class _Recorder:
         return self._wrap(self._ss(*a, **k), "scalars")
 
 
-def sw_case(name, ini, overrides, perturb=0.0, seed=4321, n_ranks=6, rk3=None):
+def sw_case(name, ini, overrides, perturb=0.0, seed=4321, n_ranks=6, rk3=None, epi=None):
     cfg_probe = _config(ini, overrides)
     print(f"[{name}] {ini} n={cfg_probe.num_solpts} H={cfg_probe.num_elements_horizontal} on {n_ranks} ranks", flush=True)
 
@@ -328,6 +328,39 @@ def sw_case(name, ini, overrides, perturb=0.0, seed=4321, n_ranks=6, rk3=None):
                 if i == 0:
                     out["rk3_1"] = Qs.copy()
             out["rk3_n"] = Qs.copy()
+        if epi is not None:   # config/case6.ini as shipped: Epi (order 3) with the ini's exponential solver (pmex), complex step
+            import integrators.epi as epi_mod
+
+            order, nsteps, dt_epi = epi
+            cfg.verbose_solver = 0
+            solver_stats = []
+            real = getattr(epi_mod, cfg.exponential_solver)
+
+            def logging_solver(*a, **k):
+                phiv, stats = real(*a, **k)
+                solver_stats.append([float(x) for x in stats])
+                return phiv, stats
+
+            if rank == 0:
+                setattr(epi_mod, cfg.exponential_solver, logging_solver)   # (module attribute: every rank's calls pass here)
+            MPI.COMM_WORLD.Barrier()
+            try:
+                stepper = epi_mod.Epi(cfg, order, rhs.full, device=dev)
+                Qs = Q.copy()
+                for i in range(nsteps):
+                    Qs = stepper.step(Qs, dt_epi)
+                    Qs = ops.apply_filters(Qs, geom, metric, dt_epi)
+                    out[f"epi_{i + 1}"] = numpy.array(Qs, copy=True)
+            finally:
+                MPI.COMM_WORLD.Barrier()
+                if rank == 0:
+                    setattr(epi_mod, cfg.exponential_solver, real)
+            if rank == 0:
+                out["meta/epi_order"], out["meta/epi_steps"] = numpy.int64(order), numpy.int64(nsteps)
+                out["meta/epi_dt"], out["meta/epi_tol"] = numpy.float64(dt_epi), numpy.float64(cfg.tolerance)
+                out["meta/epi_solver"] = numpy.array(cfg.exponential_solver)
+                # one row per call of the solver, in order, all ranks' calls interleaved: rank 0's are rows 0, 6, 12, ...
+                out["meta/epi_solver_stats_all"] = numpy.array(solver_stats)
         for a in SW_METRIC_ATTRS:
             out["metric/" + a] = numpy.array(getattr(metric, a), copy=True)
         if topo is not None:
@@ -536,6 +569,147 @@ def callers_case(name, ini, overrides, dt_rk=2.0, dt_jvp=30.0, perturb=0.01, see
         return out
 
     _run6(name, work)
+
+
+
+def pmex_case(name, base, ini, overrides, dt_jvp=30.0, perturb=0.01, seed=777):
+    """solvers/pmex.py (the schema's default `exponential_solver`) on the state of the callers fixture `base` (same
+    configuration, seed and perturbation, so that file's Q, R and metric are this one's inputs: only pmex's outputs are
+    stored here, with max|Q| per panel as the consistency check): phi_1(dt J) R exactly as Epi calls it
+    (integrators/epi.py:314-315), a three-row call with two output times (the augmented block with p = 2 and the
+    intermediate outputs of solvers/pmex.py:318-333), and the EPI2 step with exponential_solver = pmex."""
+    print(f"[{name}] {ini} (inputs of {base})", flush=True)
+
+    def work(rank):
+        from device import CpuDevice
+        from process_topology import ProcessTopology
+        from geometry import CubedSphere3D, DFROperators
+        from init.init_state_vars import init_state_vars
+        from rhs.rhs_selector import RhsBundle
+        from integrators import Epi
+        from solvers.matvec import matvec_fun
+        from solvers.pmex import pmex
+
+        cfg = _config(ini, overrides)
+        cfg.verbose_solver = 0
+        comm = MPI.COMM_WORLD
+        dev = CpuDevice(comm)
+        pt = ProcessTopology(dev, comm=comm)
+        geom = CubedSphere3D(cfg.num_elements_horizontal, cfg.num_elements_vertical, cfg.num_solpts,
+                             cfg.lambda0, cfg.phi0, cfg.alpha0, cfg.ztop, pt, cfg, dev)
+        ops = DFROperators(geom, cfg, dev)
+        Q, topo, metric = init_state_vars(geom, ops, cfg)
+        rhs = RhsBundle(geom, ops, metric, topo, pt, cfg, Q.shape, False)
+        rng = numpy.random.default_rng(seed + rank)
+        Q = Q * (1.0 + perturb * rng.uniform(-1.0, 1.0, Q.shape))
+        v = rng.uniform(-1.0, 1.0, Q.shape) * numpy.abs(Q).max(axis=(1, 2, 3, 4), keepdims=True) * 1e-3
+        R = rhs.full(Q)
+        out = {"Q_absmax": numpy.abs(Q).max(axis=(1, 2, 3, 4)), "R_absmax": numpy.abs(R).max(axis=(1, 2, 3, 4))}
+        A = lambda x: matvec_fun(x, dt_jvp, Q, R, rhs.full, "complex")
+        vec = numpy.zeros((2, R.size))
+        vec[1, :] = R.flatten()
+        phiv, stats = pmex([1.0], A, vec, tol=1e-7, mmax=64, task1=False, device=dev)
+        out["pmex_phiv"] = numpy.asarray(phiv).reshape(Q.shape)
+        out["pmex_stats"] = numpy.array([float(x) for x in stats])
+        vec3 = numpy.zeros((3, R.size))
+        vec3[0, :] = v.flatten()
+        vec3[1, :] = R.flatten()
+        vec3[2, :] = 0.01 * A(v.flatten())
+        w3, stats3 = pmex([0.25, 0.6, 1.0], A, vec3, tol=1e-9, m_init=6, mmin=6, mmax=40, task1=True, device=dev)
+        out["pmex3_w"] = numpy.asarray(w3).reshape((3,) + Q.shape)
+        out["pmex3_stats"] = numpy.array([float(x) for x in stats3])
+        cfg.tolerance = 1e-7
+        cfg.exponential_solver = "pmex"
+        cfg.jacobian_method = "complex"
+        epi = Epi(cfg, 2, rhs.full, device=dev)
+        out["epi2_pmex"] = epi.step(Q.copy(), dt_jvp).copy()
+        if rank == 0:
+            out["meta/dt_jvp"] = numpy.float64(dt_jvp)
+            out["meta/base"] = numpy.array(base)
+        return out
+
+    t0 = time.time()
+    MPI.reset_world(6)
+    res, err = MPI.run_ranks(work, 6)
+    for e in err:
+        if e:
+            print(e)
+            raise SystemExit(1)
+    flat = {}
+    for p, d in enumerate(res):
+        for k, v in d.items():
+            flat[k if k.startswith("meta/") else f"p{p}/{k}"] = v
+    path = os.path.join(GOLDEN, name + ".npz")
+    numpy.savez_compressed(path, **flat)
+    print(f"   -> {path}  {os.path.getsize(path)/1e6:.2f} MB  ({time.time()-t0:.1f}s)  pmex stats "
+          f"{res[0]['pmex_stats'].tolist()}  three-row {res[0]['pmex3_stats'].tolist()}", flush=True)
+
+
+
+def solvers_dense_case(name):
+    """solvers/kiops.py and solvers/pmex.py on seeded dense operators (one rank): what a CPU-only test can hold the
+    host logic of both to - the projector, the norm estimate, both controllers, intermediate output times, task1,
+    a negative time, a happy breakdown and the reference's own unit-test problem (64 rows of a 64 x 64 matrix as `u`,
+    identity operator: tests/unit/solvers/test_pmex.py, test_kiops_pmex_tolerance_cpu.py).  Inputs and outputs only."""
+    from device import CpuDevice
+    from solvers.kiops import kiops
+    from solvers.pmex import pmex
+
+    MPI.reset_world(1)
+    rng = numpy.random.default_rng(20260401)
+
+    def stiff(n, scale, spread):
+        return scale * (-numpy.diag(rng.uniform(0.05, spread, n)) + 0.4 * rng.standard_normal((n, n)) / numpy.sqrt(n))
+
+    n = 160
+    problems = {}
+    problems["phi1"] = dict(A=stiff(n, 1.0, 6.0), u=numpy.vstack((numpy.zeros(n), rng.standard_normal(n))), tau=[1.0],
+                            kiops=dict(tol=1e-7, m_init=1, mmin=16, mmax=64, task1=False), pmex=dict(tol=1e-7, mmax=64, task1=False))
+    problems["phi3_outputs"] = dict(A=stiff(n, 1.0, 4.0), u=rng.standard_normal((4, n)), tau=[0.3, 0.7, 1.0],
+                                    kiops=dict(tol=1e-10, m_init=6, mmin=6, mmax=40, task1=True),
+                                    pmex=dict(tol=1e-10, m_init=6, mmin=6, mmax=40, task1=True))
+    problems["long_interval"] = dict(A=stiff(n, 12.0, 8.0), u=rng.standard_normal((3, n)), tau=[2.5],
+                                     kiops=dict(tol=1e-8, m_init=10, mmin=10, mmax=24, task1=False),
+                                     pmex=dict(tol=1e-8, m_init=10, mmin=10, mmax=24, task1=False))
+    problems["backwards"] = dict(A=stiff(n, 1.0, 3.0), u=rng.standard_normal((2, n)), tau=[-1.0],
+                                 kiops=dict(tol=1e-9, m_init=8, mmin=8, mmax=48, task1=False),
+                                 pmex=dict(tol=1e-9, m_init=8, mmin=8, mmax=48, task1=False))
+    basis = numpy.linalg.qr(rng.standard_normal((n, 5)))[0]                   # a 5-dimensional invariant subspace
+    inv = basis @ (-numpy.diag([0.5, 1.0, 1.5, 2.0, 2.5])) @ basis.T
+    # (a one-row `u` cannot be given to the reference: its p = 0 branch stacks a row of the wrong length, kiops.py:83)
+    problems["invariant_subspace"] = dict(A=inv, u=numpy.vstack((basis @ rng.standard_normal(5), numpy.zeros(n))), tau=[1.0],
+                                          kiops=dict(tol=1e-9, m_init=12, mmin=12, mmax=30, task1=False),
+                                          pmex=dict(tol=1e-9, m_init=12, mmin=12, mmax=30, task1=False))
+    problems["unit_test_identity"] = dict(A=numpy.eye(64), u=rng.uniform(-1000.0, 1000.0, (64, 64)), tau=[1.0],
+                                          kiops=dict(tol=1e-7), pmex=dict(tol=1e-7))
+
+    def work(rank):
+        dev = CpuDevice(MPI.COMM_WORLD)
+        out = {}
+        for key, pr in problems.items():
+            A = pr["A"]
+            for solver, fn in (("kiops", kiops), ("pmex", pmex)):
+                w, stats = fn(list(pr["tau"]), lambda v: A @ v, pr["u"].copy(), device=dev, **pr[solver])
+                out[f"{key}/{solver}_w"] = numpy.array(w, copy=True)
+                out[f"{key}/{solver}_stats"] = numpy.array([float(x) for x in stats])
+        return out
+
+    res, err = MPI.run_ranks(work, 1)
+    if err[0]:
+        print(err[0])
+        raise SystemExit(1)
+    flat = dict(res[0])
+    import json
+    for key, pr in problems.items():
+        flat[f"{key}/A"], flat[f"{key}/u"], flat[f"{key}/tau"] = pr["A"], pr["u"], numpy.array(pr["tau"])
+        flat[f"{key}/kiops_args"] = numpy.array(json.dumps(pr["kiops"]))
+        flat[f"{key}/pmex_args"] = numpy.array(json.dumps(pr["pmex"]))
+    path = os.path.join(GOLDEN, name + ".npz")
+    numpy.savez_compressed(path, **flat)
+    for key in problems:
+        print(f"   {key}: kiops {flat[key + '/kiops_stats'].tolist()}  pmex {flat[key + '/pmex_stats'].tolist()}")
+    print(f"[{name}] -> {path}  {os.path.getsize(path)/1e6:.2f} MB", flush=True)
+    MPI.reset_world(6)
 
 
 def epi_case(name, ini, overrides, orders=(3, 4, 5, 6), extra_steps=2, dt=30.0, perturb=0.01, seed=999):
@@ -1059,6 +1233,14 @@ CASES = {
     # (2 substeps, 6 rejections, 128 vectors, basis at mmax) is the same under perturbations of 1e-9)
     "config5_c21_n8_h2_v2": lambda nm: config5_case(
         nm, "dcmip21.ini", dict(num_solpts=8, num_elements_horizontal=2, num_elements_vertical=2), nsteps=2, dt=10.0),
+    "solvers_dense": solvers_dense_case,
+    # config/case6.ini's own integrator (epi3 + pmex, complex-step JVP, dt = 1800 s) on the shallow-water sphere
+    "sw_epi3_pmex_c6_n5_h4": lambda nm: sw_case(nm, "case6.ini", dict(num_solpts=5, num_elements_horizontal=4), epi=(3, 4, 1800.0)),
+    # pmex, the schema's default exponential solver (case6.ini, density_current.ini), on the callers fixtures' states
+    "pmex_euler3d_n3_h3_v2": lambda nm: pmex_case(
+        nm, "callers_euler3d_n3_h3_v2", "dcmip31.ini", dict(num_solpts=3, num_elements_horizontal=3, num_elements_vertical=2)),
+    "pmex_euler3d_n8_h2_v2": lambda nm: pmex_case(
+        nm, "callers_euler3d_n8_h2_v2", "dcmip31.ini", dict(num_solpts=8, num_elements_horizontal=2, num_elements_vertical=2)),
 }
 
 

@@ -1,0 +1,105 @@
+"""pmex - the schema's default `exponential_solver` (config-format.json; config/case6.ini, density_current.ini) - on
+the GPU against the reference's own solvers/pmex.py and integrators/epi.py, run on the states of the callers fixtures
+(tests/golden/pmex_euler3d_*.npz, made by oracle/refharness/gen_golden.py: the inputs are those of
+callers_euler3d_*.npz, checked by max|Q|, max|R| per panel and variable).  n = 3, and the benchmark order n = 8 (the
+matrix-core JVP kernel under the solver)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import Golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+AX = (0, 2, 3, 4, 5)
+
+
+@pytest.fixture(scope="module", params=["n3_h3_v2", "n8_h2_v2"])
+def setup(built_lib, request):
+    from tests.gpu_util import device_metric
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D
+
+    g = Golden("callers_euler3d_" + request.param)
+    px = np.load(os.path.join(os.path.dirname(__file__), "golden", f"pmex_euler3d_{request.param}.npz"))
+    assert str(px["meta/base"]) == "callers_euler3d_" + request.param
+    for p in range(6):   # same inputs as the callers fixture
+        assert np.array_equal(px[f"p{p}/Q_absmax"], np.abs(g[f"p{p}/Q"]).max(axis=(1, 2, 3, 4)))
+        assert np.array_equal(px[f"p{p}/R_absmax"], np.abs(g[f"p{p}/R"]).max(axis=(1, 2, 3, 4)))
+    plans = {p: Euler3DPlan(g.n, g.H, g.V, g.case, p, g.ops, device_metric(g, p, DEV)) for p in range(6)}
+    rhs = RhsEuler3D(plans)
+    stack = lambda key: torch.from_numpy(np.stack([g[f"p{p}/{key}"] for p in range(6)])).to(DEV)  # noqa: E731
+    pstack = lambda key: np.stack([px[f"p{p}/{key}"] for p in range(6)])  # noqa: E731
+    return g, px, rhs, stack, pstack
+
+
+def _same_decisions(stats, ref, tol):
+    # sub-steps, rejections, Krylov vectors, exponentials, last basis size, norms that needed their own reduction
+    assert [int(stats[i]) for i in (0, 1, 2, 3, 5, 6)] == [int(ref[i]) for i in (0, 1, 2, 3, 5, 6)], (stats, ref.tolist())
+    # the accumulated error estimate: 5 %, or 1 % of the tolerance where it sits far below it (at n = 8 the accepted
+    # sub-steps carry estimates of 1e-10 for a tolerance of 1e-7: the last entries of the exponential, rounding-sized)
+    assert abs(float(stats[4]) - float(ref[4])) <= max(0.05 * float(ref[4]), 0.01 * tol), (stats, ref.tolist())
+
+
+def test_pmex_phi1_as_epi_calls_it(setup):
+    """phi_1(dt J) R with the complex-step JVP, called as integrators/epi.py:314-315 calls it."""
+    from wxfactory_amd.matvec import ComplexStepOperator
+    from wxfactory_amd.solvers import pmex
+
+    g, px, rhs, stack, pstack = setup
+    Q, R = stack("Q"), stack("R")
+    dt = float(px["meta/dt_jvp"])
+    vec = torch.zeros((2, R.numel()), dtype=torch.float64, device=DEV)
+    vec[1] = R.flatten()
+    phiv, stats = pmex([1.0], ComplexStepOperator(dt, Q, R, rhs, "complex"), vec, tol=1e-7, mmax=64, task1=False)
+    _same_decisions(stats, px["p0/pmex_stats"], 1e-7)
+    ref = pstack("pmex_phiv")
+    err = np.abs(phiv.cpu().numpy().reshape(ref.shape) - ref).max(axis=AX) / np.abs(ref).max(axis=AX)
+    assert (err < 1e-8).all(), err
+
+
+def test_pmex_three_rows_and_intermediate_times(setup):
+    """u with three rows (phi_0 u_0 + phi_1 u_1 + phi_2 u_2: two augmented components), three output times, task1."""
+    from wxfactory_amd.matvec import matvec_fun
+    from wxfactory_amd.solvers import pmex
+
+    g, px, rhs, stack, pstack = setup
+    Q, R, V = stack("Q"), stack("R"), stack("V")
+    dt = float(px["meta/dt_jvp"])
+    A = lambda x: matvec_fun(x, dt, Q, R, rhs, "complex")  # noqa: E731
+    vec = torch.zeros((3, R.numel()), dtype=torch.float64, device=DEV)
+    vec[0] = V.flatten()
+    vec[1] = R.flatten()
+    vec[2] = 0.01 * A(V.flatten()).flatten()
+    w, stats = pmex([0.25, 0.6, 1.0], A, vec, tol=1e-9, m_init=6, mmin=6, mmax=40, task1=True)
+    _same_decisions(stats, px["p0/pmex3_stats"], 1e-9)
+    ref = np.stack([px[f"p{p}/pmex3_w"] for p in range(6)], axis=1)   # (time, panel, variable, ...)
+    got = w.cpu().numpy().reshape(ref.shape)
+    for k in range(3):
+        # How closely can two runs agree?  tools/pmex_sensitivity.py (profiles/r03_pmex_sensitivity.log) repeats this very
+        # call with every product of the operator multiplied by (1 + 1e-13 xi): same decisions, and results that differ
+        # from the unperturbed run by 2e-11 / 4e-7 / 2e-7 in the 2-norm at the three times (|w| = 84 / 31 / 19) at n = 8
+        # - the stiff operator amplifies the last digits of the products over 8 sub-steps and 320 vectors.  The
+        # reference's run (NumPy's complex arithmetic in the complex step, ours: dual numbers) differs from ours by
+        # 6e-10 / 5e-7 / 3e-7: the same thing.  Bound: 1e-7 of the result's norm, 1e-6 of each variable's maximum.
+        dn, rn = np.linalg.norm(got[k] - ref[k]), np.linalg.norm(ref[k])
+        assert dn <= 1e-7 * rn, (k, dn, rn)
+        err = np.abs(got[k] - ref[k]).max(axis=AX) / np.abs(ref[k]).max(axis=AX)
+        assert (err < 1e-6).all(), (k, err)
+
+
+def test_epi2_step_with_pmex(setup):
+    from wxfactory_amd.integrators import Epi
+
+    g, px, rhs, stack, pstack = setup
+    Q = stack("Q")
+    stepper = Epi(2, rhs, tol=1e-7, exponential_solver="pmex")
+    Qn = stepper.step(Q, float(px["meta/dt_jvp"]))
+    ref_stats = px["p0/pmex_stats"]
+    assert stepper.solver_info["iterations"] == int(ref_stats[2]) and stepper.solver_info["rejected"] == int(ref_stats[1])
+    refq, q0 = pstack("epi2_pmex"), Q.cpu().numpy()
+    upd = np.abs(refq - q0).max(axis=AX)
+    assert (np.abs(Qn.cpu().numpy() - refq).max(axis=AX) <= 1e-7 * upd).all()
+    with pytest.raises(ValueError, match="Unrecognized exponential solver"):
+        Epi(2, rhs, exponential_solver="exode")

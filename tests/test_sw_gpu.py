@@ -231,3 +231,32 @@ def test_rk3_time_loop_matches_reference(name, fused, batched, built_lib):
             moved = np.abs(ref - stack("Q")).max(axis=(0, 2, 3, 4))
             err = np.abs(Q.cpu().numpy() - ref).max(axis=(0, 2, 3, 4))
             assert (moved > 0).all() and (err <= 1e-9 * moved + 1e-14 * np.abs(ref).max(axis=(0, 2, 3, 4))).all(), (i, err, moved)
+
+
+def test_case6_ini_integrator_epi3_with_pmex(built_lib):
+    """config/case6.ini as shipped - Epi order 3 (one EPI2 start-up step, then the multistep form), exponential solver
+    pmex, complex-step JVP, tolerance 1e-7, dt = 1800 s - against the reference's own run of it (integrators/epi.py,
+    solvers/pmex.py on rhs/rhs_sw.py): the state after each of four steps and pmex's statistics of every step."""
+    from wxfactory_amd.integrators import Epi
+    from wxfactory_amd.rhs_sw import RhsShallowWater
+
+    g = golden_sw("sw_epi3_pmex_c6_n5_h4")
+    assert str(g["meta/epi_solver"]) == "pmex"
+    rhs = RhsShallowWater({p: _plan(g, p) for p in range(6)})
+    stepper = Epi(int(g["meta/epi_order"]), rhs, tol=float(g["meta/epi_tol"]), exponential_solver="pmex")
+    dt, nsteps = float(g["meta/epi_dt"]), int(g["meta/epi_steps"])
+    ref_stats = g["meta/epi_solver_stats_all"][::6]   # (all six emulated ranks logged each call)
+    stack = lambda key: np.stack([g[f"p{p}/{key}"] for p in range(6)])  # noqa: E731
+    Q = torch.stack([_dev(g.q(p)) for p in range(6)])
+    prev = stack("Q")
+    for i in range(nsteps):
+        Q = stepper.step(Q, dt)
+        info = stepper.solver_info
+        got = [info[k] for k in ("substeps", "rejected", "iterations", "exps", "krylov_size", "own_norms")]
+        assert got == [int(ref_stats[i][k]) for k in (0, 1, 2, 3, 5, 6)], (i, got, ref_stats[i])
+        ref = stack(f"epi_{i + 1}")
+        moved = np.abs(ref - prev).max(axis=(0, 2, 3, 4))
+        err = np.abs(Q.cpu().numpy() - ref).max(axis=(0, 2, 3, 4))
+        # both sides solve each step to the tolerance 1e-7 (relative to the update)
+        assert (moved > 0).all() and (err <= 1e-6 * moved).all(), (i, err, moved)
+        prev = ref

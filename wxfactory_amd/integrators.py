@@ -80,7 +80,7 @@ class Ros2:
 
 class Epi:
     """Exponential propagation iterative methods, orders 2-6 (integrators/epi.py:28-360), with the
-    phi-function evaluation by KIOPS (solvers/kiops.py) and the JVP by the RHS kernels
+    phi-function evaluation by KIOPS (solvers/kiops.py) or PMEX (solvers/pmex.py, the schema's default) and the JVP by the RHS kernels
     (matvec_fun: complex step by default, `jacobian_method` of config-format.json)."""
 
     _A = {
@@ -93,12 +93,18 @@ class Epi:
     }
 
     def __init__(self, order: int, rhs: Callable, tol: float = 1e-7, jacobian_method: str = "complex",
-                 init_substeps: int = 1, init_method=None):
+                 init_substeps: int = 1, init_method=None, exponential_solver: str = "kiops"):
         from collections import deque
 
         if order not in self._A:
             raise ValueError(f"Unsupported order {order} for EPI method")
+        if exponential_solver not in ("kiops", "pmex"):   # (the two the shipped configurations name, epi.py:314-348)
+            raise ValueError(f"Unrecognized exponential solver {exponential_solver}")
         self.rhs, self.tol, self.jacobian_method = rhs, tol, jacobian_method
+        self.exponential_solver = exponential_solver
+        # how a second sub-step of the phi solver restarts its augmented components: "reference" = as the reference
+        # computes them (its results), "phipm" = exact; they differ from order 3 on, see solvers._restart_tail
+        self.restart_powers = "reference"
         # Replay whole KIOPS passes as HIP graphs (one GPU, launch-bound sizes).  Off by default: measured at the size of
         # config/dcmip31.ini the adaptive basis size m changes almost every step, so passes are re-captured (8 ms each)
         # more often than replayed, and with a Krylov vector built from ONE host call (wx_euler3d_batch_kiops_vector) the
@@ -115,7 +121,8 @@ class Epi:
         self.krylov_size = 1
         self.previous_Q, self.previous_rhs = deque(), deque()
         self.dt = 0.0
-        self.init_method = init_method if (init_method or self.n_prev == 0) else Epi(2, rhs, tol, jacobian_method)
+        self.init_method = init_method if (init_method or self.n_prev == 0) else Epi(
+            2, rhs, tol, jacobian_method, exponential_solver=exponential_solver)
         self.init_substeps = init_substeps
         self.solver_info = None
 
@@ -137,6 +144,7 @@ class Epi:
             self.previous_rhs.appendleft(self.rhs(Q))
             for _ in range(self.init_substeps):
                 Q = self.init_method.step(Q, dt / self.init_substeps)
+            self.solver_info = getattr(self.init_method, "solver_info", None)
             return Q
         rhs = self.rhs(Q)
         vec = torch.zeros((self.max_phi + 1, rhs.numel()), dtype=Q.dtype, device=Q.device)
@@ -146,6 +154,14 @@ class Epi:
             r = (self.previous_rhs[i] - rhs).flatten() - JdQ
             for k, row in enumerate(self.A, start=2):
                 vec[k] += row[i] * r
+        if self.exponential_solver == "pmex":
+            from .solvers import pmex
+
+            phiv, stats = pmex([1.0], ComplexStepOperator(dt, Q, rhs, self.rhs, self.jacobian_method), vec, tol=self.tol,
+                               mmax=64, task1=False, restart_powers=self.restart_powers)
+            self.solver_info = dict(substeps=stats[0], rejected=stats[1], iterations=stats[2], exps=stats[3],
+                                    error=stats[4], krylov_size=stats[5], own_norms=stats[6])
+            return self._advance(Q, rhs, phiv, dt)
         ws, token, Qm, Rm = None, None, Q, rhs
         if Q.is_cuda and Q.dtype == torch.float64:
             from .solvers import KiopsWorkspace
@@ -165,10 +181,13 @@ class Epi:
                 token = (Qm.data_ptr(), Rm.data_ptr(), float(dt), self.jacobian_method)
         phiv, stats = kiops([1], ComplexStepOperator(dt, Qm, Rm, self.rhs, self.jacobian_method), vec,
                             tol=self.tol, m_init=self.krylov_size, mmin=16, mmax=64, task1=False, workspace=ws,
-                            graph_token=token)
+                            graph_token=token, restart_powers=self.restart_powers)
         self.krylov_size = math.floor(0.7 * stats[5] + 0.3 * self.krylov_size)
         self.solver_info = dict(substeps=stats[0], rejected=stats[1], iterations=stats[2], exps=stats[3],
                                 error=stats[4], krylov_size=stats[5])
+        return self._advance(Q, rhs, phiv, dt)
+
+    def _advance(self, Q, rhs, phiv, dt):
         if self.n_prev > 0:
             self.previous_Q.pop()
             self.previous_Q.appendleft(Q)

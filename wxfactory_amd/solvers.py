@@ -96,7 +96,8 @@ class _Basis:
         """[<V[k], a> for k < m] + [<V[k], b> for k < m] in one pass over the rows (device tensor of 2 m)."""
         V = self.V
         if not (self.gpu and a.is_contiguous() and b.is_contiguous()) or a.numel() == 0:
-            return torch.cat((V[:m] @ a, V[:m] @ b))
+            Vm = V[:m] if a.numel() == V.shape[1] else V[:m, : a.numel()]
+            return torch.cat((Vm @ a, Vm @ b))
         if self.work.numel() < int(self.lib.wx_multi_dot_workspace(2 * m)):
             self.work = torch.empty(int(self.lib.wx_multi_dot_workspace(2 * V.shape[0])), dtype=torch.float64, device=V.device)
         out = torch.empty(2 * m, dtype=torch.float64, device=V.device)
@@ -448,6 +449,29 @@ def _ceil_clamped(x: float, lo: float, hi: float) -> int:
     return int(min(hi, max(lo, math.ceil(x))))
 
 
+def _restart_tail(p: int, t: float, mu: float, powers: str = "reference"):
+    """The p augmented components of the first basis vector of a sub-step that starts at time t (phipm, Niesen & Wright
+    2012, eq. 3.2: component k, counted from 0, is t^i / i! with i = p - 1 - k, so the last one is 1; times the scaling mu).
+
+    "reference": the exponents as solvers/kiops.py:139-141 and solvers/pmex.py:137-139 compute them, i = p - k + 1 - two
+    more than phipm's (the MATLAB original counts k from 1 and says i = p - k).  It changes nothing for p = 1 (EPI2) or
+    while t = 0 (a single sub-step); with p >= 2 AND a second sub-step the result is not the phi-sum any more (10-30 % off
+    on the stiff dense problem of tests/test_solvers_cpu.py::test_restart_powers).  It is the default because the
+    reference's results - EPI orders 3 to 6 whenever the solver sub-steps - are what a drop-in has to return
+    (tests/golden/epi_multistep_*, pmex_euler3d_*, solvers_dense: `long_interval`).
+    "phipm": the exponents of the paper; exact (same test)."""
+    import numpy as np
+
+    if powers not in ("reference", "phipm"):
+        raise ValueError(f"restart_powers must be 'reference' or 'phipm', not {powers!r}")
+    tail = np.zeros(p)
+    for k in range(p - 1):
+        i = p - k + 1 if powers == "reference" else p - k - 1
+        tail[k] = (t ** i) / math.factorial(i) * mu
+    tail[p - 1] = mu
+    return tail
+
+
 class _SubstepControl:
     """Sub-step size tau and Krylov basis size m of the adaptive phi-function evaluation (the controller of phipm,
     Niesen & Wright 2012, section 3.3-3.4, with the KIOPS modifications of Gaudreault, Rainwater & Tokman 2018,
@@ -491,12 +515,16 @@ class _SubstepControl:
                 self.gain = 2
             self.gain_apriori = True
 
-    def judge(self, err: float, j: int, t_now: float) -> bool:
+    def judge(self, err: float, j: int, t_now: float, err_half: Optional[float] = None) -> bool:
         """Take the error estimate of the attempt (tau, m) that built j vectors; decide acceptance and choose the next
-        attempt.  Returns True when the sub-step is accepted."""
+        attempt.  Returns True when the sub-step is accepted.  (`err_half`: the estimate at half the step, for the
+        controllers that measure the order from it.)"""
         last, omega = self.omega, self.scaled_error(err)
         self.omega = omega
-        self._measure(omega, last, j)
+        if err_half is None:
+            self._measure(omega, last, j)
+        else:
+            self._measure(omega, last, j, err, err_half)
         tau, m = self.tau, self.m
         ok = omega <= self.ACCEPT
         left = self.horizon - (t_now + tau) if ok else self.horizon - t_now   # what the next attempt may cover
@@ -512,9 +540,12 @@ class _SubstepControl:
                 t = tau * (self.target_full / omega) ** (1 / self.order)
                 nxt = (min(self.horizon - t_now, max(tau / 5, t)), j)
         else:                       # KIOPS: change the basis size, keep the step
-            nxt = (keep_tau, best_m)
+            nxt = (keep_tau, self._basis_beside(keep_tau, best_m))
         self._advance(nxt, ok)
         return ok
+
+    def _basis_beside(self, keep_tau: float, best_m: int) -> int:
+        return best_m
 
     def breakdown(self, t_now: float) -> bool:
         """Happy breakdown: the Krylov space is invariant, the attempt is exact; same basis, no larger step."""
@@ -526,6 +557,31 @@ class _SubstepControl:
         self.prev_tau, self.prev_m = self.tau, self.m
         self.tau, self.m = nxt[0], int(nxt[1])
         self.retries = 0 if accepted else self.retries + 1
+
+
+class _PmexControl(_SubstepControl):
+    """The controller as solvers/pmex.py:262-311 runs it.  Against KIOPS: the order is measured on every attempt, from
+    the error estimates of the whole and of half the step (the exponential is formed as the square of the half step's,
+    so the second estimate is free); the gain per vector is kept from the last measurement while retries go on; and
+    when the end of the interval cuts the step the basis size is kept."""
+
+    def __init__(self, horizon: float, tol: float, m: int, mmin: int, mmax: int, accept: float):
+        super().__init__(horizon, tol, m, mmin, mmax)
+        self.ACCEPT = accept
+
+    def _measure(self, omega: float, last: float, j: int, err: float = math.nan, err_half: float = math.nan):
+        self.order = _log(err / err_half if err_half != 0 else math.inf) / math.log(2)
+        if self.m != self.prev_m and self.tau == self.prev_tau and self.retries >= 1:
+            self.gain = max(1.1, (omega / last) ** (1 / (self.prev_m - self.m)))
+            self.gain_apriori = False
+        elif self.gain_apriori or self.retries == 0:
+            self.gain = 2
+            self.gain_apriori = True
+        else:
+            self.gain_apriori = True   # (the measured value serves one more attempt)
+
+    def _basis_beside(self, keep_tau: float, best_m: int) -> int:
+        return self.m if keep_tau < self.tau else best_m
 
 
 class KiopsWorkspace:
@@ -617,7 +673,8 @@ def _combine_rows(basis: "_Basis", Vd: torch.Tensor, j: int, n: int, coef) -> to
 
 
 def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int = 10, mmin: int = 10, mmax: int = 128,
-          iop: int = 2, task1: bool = False, group=None, workspace: Optional[KiopsWorkspace] = None, graph_token=None):
+          iop: int = 2, task1: bool = False, group=None, workspace: Optional[KiopsWorkspace] = None, graph_token=None,
+          restart_powers: str = "reference"):
     """w(i) = sum_k phi_k(tau_i A) u[k]  by the adaptive Krylov method with incomplete orthogonalisation.
 
     Same signature, adaptivity rules and `stats` tuple as reference wx_factory/solvers/kiops.py:10-347
@@ -629,6 +686,8 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
     once per pass of m vectors and detects a happy breakdown then (vectors built past it are discarded).
     With the vectors split over ranks the augmented components are replicated and enter the products once,
     after the all-reduce.  The (m+1)x(m+1) matrix exponential runs on the host (scipy), as in the reference.
+    `restart_powers`: see _restart_tail - "reference" reproduces the reference's results, "phipm" is exact when the solver
+    sub-steps with more than one phi function.
     Returns (w, (steps, rejected, krylov_steps, exps, error_estimate, last_m)).
     """
     import numpy as np
@@ -688,11 +747,7 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
     beta = 1.0
     while tau_now < tau_end:
         if j == 0:
-            va0 = np.zeros(p)
-            for k in range(p - 1):
-                i = p - k + 1
-                va0[k] = (tau_now ** i) / math.factorial(i) * mu
-            va0[p - 1] = mu
+            va0 = _restart_tail(p, tau_now, mu, restart_powers)
             Vd[0, :n] = w[l]
             Vd[0, n:] = torch.as_tensor(va0, dtype=dtype, device=dev)
             beta = math.sqrt(float(global_dotprod(Vd[0, :n], Vd[0, :n], group)) + float(va0 @ va0))
@@ -799,3 +854,185 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
         for k in range(num_steps):
             w[k] /= tau_out[k]
     return w, (step, reject, krystep, exps, conv, m)
+
+
+class _GaussSeidelProjector:
+    """Coefficients of the low-synchronisation orthogonalisation of pmex (solvers/pmex.py:166-190): vector j is
+    projected against v_0 .. v_{j-1} with ONE reduction, the (j+1) x 2 block of products of the basis with v_{j-1}
+    (already orthonormalised: its products with the older vectors measure the orthogonality that was lost) and with the
+    new vector.  With L the strictly lower triangle of the Gram matrix V V^T as it has been observed so far, the
+    projection coefficients are  s = (I - L^T (I + L)^{-1}) g  - a two-step Gauss-Seidel sweep on the normal equations -
+    and (I + L)^{-1} grows by one row per vector.
+
+    The reference then passes s through scipy's solve_triangular with the unit LOWER triangular matrix I + L and the
+    default `lower=False`: that call reads the (empty) upper triangle only, so it is the identity, and `s` is what the
+    vector is corrected with (pmex.py:187-193).  Reproduced as such: the fixtures' statistics depend on it."""
+
+    def __init__(self, mmax: int):
+        import numpy as np
+
+        self.np = np
+        self.Linv = np.eye(mmax)            # (I + L)^{-1}, rows 0..j-1 valid
+        self.LT = np.zeros((mmax, mmax))    # L^T: column c holds the products of v_c with v_0 .. v_{c-1}
+
+    def coefficients(self, j: int, gram):
+        """gram: (j+1, 2) = [<v_k, v_{j-1}>, <v_k, w>] for k <= j (row j: v_j := w itself, not yet projected)."""
+        np = self.np
+        if j > 1:
+            c = gram[: j - 1, 0]
+            self.LT[: j - 1, j - 1] = c
+            self.Linv[j - 1, : j - 1] = -c @ self.Linv[: j - 1, : j - 1]
+        g = gram[:j, 1]
+        return g - self.LT[:j, :j] @ (self.Linv[:j, :j] @ g)
+
+
+def _norm_after_projection(gram_col, j: int):
+    """||w - sum_k g_k v_k|| from the same reduction, sqrt(<w, w> - sum g_k^2), with the squares accumulated in the
+    platform's extended precision as the reference does (numpy.float128, solvers/pmex.py:194-218); None when the
+    difference is negative (cancellation: the caller then measures the norm with a reduction of its own)."""
+    import numpy as np
+
+    g = np.asarray(gram_col[:j], dtype=np.longdouble)
+    s = np.sum(g * g)
+    if gram_col[j] < s:
+        return None
+    return float(np.sqrt(gram_col[j] - s))
+
+
+def pmex(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, delta: float = 1.2, m_init: int = 10, mmin: int = 10,
+         mmax: int = 128, reuse_info: bool = True, task1: bool = False, group=None, restart_powers: str = "reference"):
+    """w(i) = sum_k phi_k(tau_i A) u[k]  by the adaptive Krylov method with FULL orthogonalisation at one
+    synchronisation per vector: the schema's default `exponential_solver` (config-format.json; case6.ini,
+    density_current.ini), reference wx_factory/solvers/pmex.py:8-374 - same signature, decisions and `stats`
+    (steps, rejected, Krylov vectors, exponentials, error estimate, last m, norms that needed their own reduction).
+
+    A Krylov vector costs one matvec (= one RHS evaluation through `A`), ONE fused reduction over the basis
+    (wx_multi_dot2: the products of every basis vector with the previous and with the new vector, one sweep), the
+    all-reduce of that (j+1) x 2 block when the vectors are split over ranks (the replicated augmented components
+    enter once, afterwards), one fused update (wx_multi_axpy) and the scaling.  The host holds what the reference
+    holds there too: the projector's triangular factors, the Hessenberg matrix and its exponential.
+    `restart_powers`: see _restart_tail ("reference" by default)."""
+    import numpy as np
+
+    dev, dtype = u.device, u.dtype
+    tau_out = [float(t) for t in tau_out]
+    ppo, n = u.shape
+    p = ppo - 1
+    if p == 0:
+        p = 1
+        u = torch.cat((u, torch.zeros((1, n), dtype=dtype, device=dev)))
+    split = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    m = max(mmin, min(m_init, mmax))
+    Vd = torch.empty((mmax + 1, n + p), dtype=dtype, device=dev)   # (every row is written before it is read)
+    basis = _Basis(Vd)
+    H = np.zeros((mmax + 1, mmax + 1))
+    proj = _GaussSeidelProjector(mmax)
+    step = krystep = reject = exps = own_norms = 0
+    sgn = math.copysign(1.0, tau_out[-1])
+    tau_now, tau_end = 0.0, abs(tau_out[-1])
+    conv = 0.0
+    num_steps = len(tau_out)
+    w = torch.zeros((num_steps, n), dtype=dtype, device=dev)
+    w[0] = u[0]
+    normU = float(_allreduce(u[1:].abs().sum(dim=1), group).max())
+    if ppo > 1 and normU > 0:
+        ex = math.ceil(math.log2(normU))
+        nu, mu = 2.0 ** (-ex), 2.0 ** ex
+    else:
+        nu = mu = 1.0
+    u_flip_t = (nu * torch.flipud(u[1:])).t().contiguous()
+    shift = torch.diag(torch.ones(p - 1, dtype=dtype, device=dev), 1)
+    ctl = _PmexControl(tau_end, tol, m, mmin, mmax, delta)
+
+    def norm2(row: torch.Tensor) -> float:
+        """<row, row> over the n + p components (the augmented ones are replicated over the ranks)"""
+        if not split:
+            return float(torch.dot(row, row))
+        return float(global_dotprod(row[:n], row[:n], group)) + float(torch.dot(row[n:], row[n:]))
+
+    def gram(j: int):
+        """(j+1, 2) block <v_k, v_{j-1}>, <v_k, v_j>, k <= j, on the host: the synchronisation of vector j"""
+        if not split:
+            return basis.dots2(j + 1, Vd[j - 1], Vd[j]).reshape(2, j + 1).t().cpu().numpy()
+        g = _allreduce(basis.dots2(j + 1, Vd[j - 1, :n], Vd[j, :n]), group).reshape(2, j + 1).t()
+        return (g + Vd[: j + 1, n:] @ Vd[j - 1: j + 1, n:].t()).cpu().numpy()
+
+    l = 0
+    j = 0
+    beta = 1.0
+    happy = False
+    while tau_now < tau_end:
+        if j == 0:
+            H[:, :] = 0.0
+            va0 = _restart_tail(p, tau_now, mu, restart_powers)
+            Vd[0, :n] = w[l]
+            Vd[0, n:] = torch.as_tensor(va0, dtype=dtype, device=dev)
+            beta = math.sqrt(float(global_dotprod(Vd[0, :n], Vd[0, :n], group)) + float(va0 @ va0))
+            Vd[0] /= beta
+        while j < m:
+            j += 1
+            torch.addmv(A(Vd[j - 1, :n]), u_flip_t, Vd[j - 1, n:], out=Vd[j, :n])
+            torch.mv(shift, Vd[j - 1, n:], out=Vd[j, n:])   # augmented components: up by one, zero at the end
+            G = gram(j)
+            sol = proj.coefficients(j, G)
+            basis.subtract(Vd[j], 0, j, torch.as_tensor(sol, dtype=dtype).to(dev))
+            nrm_j = _norm_after_projection(G[:, 1], j)
+            if nrm_j is None:
+                nrm_j = math.sqrt(norm2(Vd[j]))
+                own_norms += 1
+            # (The reference stores this column only after its breakdown test, pmex.py:225-233: at a breakdown the
+            # projections of A v_{j-1} on the basis are then missing from H, and the result is wrong by their weight -
+            # 1e-4 on the invariant-subspace problem of tests/golden/solvers_dense.npz when the breakdown is seen at
+            # once.  Stored first here; nothing else differs.)
+            H[:j, j - 1] = sol
+            if nrm_j < tol:   # happy breakdown: the Krylov space is invariant
+                happy = True
+                break
+            Vd[j] /= nrm_j
+            H[j, j - 1] = nrm_j
+            krystep += 1
+        H[0, j] = 1.0
+        nrm = H[j, j - 1]
+        H[j, j - 1] = 0.0
+        tau = ctl.tau
+        F_half = _expm(sgn * 0.5 * tau * H[: j + 1, : j + 1])
+        F = F_half @ F_half
+        exps += 1
+        H[j, j - 1] = nrm
+        retries = ctl.retries
+        if happy:
+            err = 0.0
+            accepted = ctl.breakdown(tau_now)
+            happy = False
+        else:
+            err_half = abs(beta * nrm * F_half[j - 1, j])
+            err = abs(beta * nrm * F[j - 1, j])
+            if err != err:
+                # (as in kiops above: the reference's loop never ends on a NaN, and every rank sees the same estimate)
+                raise ValueError("NaN in the PMEX error estimate (the Krylov basis or the operator produced a NaN)")
+            accepted = ctl.judge(float(err), j, tau_now, float(err_half))
+        if accepted:
+            reject += retries
+            step += 1
+            blown = 0
+            next_t = tau_now + tau
+            for k in range(l, num_steps):
+                if abs(tau_out[k]) < abs(next_t):
+                    blown += 1
+            if blown != 0:
+                w[l + blown] = w[l]
+                for k in range(blown):
+                    F2 = _expm(sgn * (tau_out[l + k] - tau_now) * H[:j, :j])
+                    w[l + k] = _combine_rows(basis, Vd, j, n, beta * F2[:j, 0])
+                l += blown
+            w[l] = _combine_rows(basis, Vd, j, n, beta * F[:j, 0])
+            tau_now += tau
+            j = 0
+            conv += err
+        else:
+            H[0, j] = 0.0
+        m = ctl.m
+    if task1:
+        for k in range(num_steps):
+            w[k] /= tau_out[k]
+    return w, (step, reject, krystep, exps, float(conv), m, own_norms)
