@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""EPI2 + KIOPS steps at the benchmark's resolution (development tool): n = 8, 60 x 60 elements per panel, V vertical
+"""EPI2 + KIOPS (or, SOLVER=pmex, PMEX) steps at the benchmark's resolution (development tool): n = 8, 60 x 60 elements per panel, V vertical
 elements (default 2: a Krylov basis of 64 vectors of the V = 8 sphere would not fit beside the metric), whole sphere on
 one GPU.  Time per step, per Krylov vector, and what a bare prepared matvec costs - the overhead of everything around it."""
 import os
@@ -42,7 +42,9 @@ torch.cuda.synchronize()
 mv = (time.perf_counter() - t0) / 10
 rhs.jvp_release()
 del op, v
-epi = Epi(2, rhs, tol=1e-7)
+solver = os.environ.get("SOLVER", "kiops")   # or pmex
+epi = Epi(2, rhs, tol=1e-7, exponential_solver=solver)
+print("exponential solver", solver, flush=True)
 for i in range(3):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
