@@ -413,7 +413,7 @@ def sw_case(name, ini, overrides, perturb=0.0, seed=4321, n_ranks=6, rk3=None, e
 # ---------------------------------------------------------------------------------------------
 # 2-D Cartesian Euler (rhs_dfr.py:8-45 + pde_euler_cartesian.py + the reference's native pde_cpp)
 # ---------------------------------------------------------------------------------------------
-def cart2d_case(name, ini, overrides, seed=99, rk3=None):
+def cart2d_case(name, ini, overrides, seed=99, rk3=None, epi=None, wind=0.5):
     MPI.reset_world(1)
 
     def work(rank):
@@ -430,8 +430,8 @@ def cart2d_case(name, ini, overrides, seed=99, rk3=None):
         Q, topo, metric = init_state_vars(geom, ops, cfg)
         rng = numpy.random.default_rng(seed)
         Q = Q * (1.0 + 1e-3 * rng.uniform(-1, 1, Q.shape))
-        Q[1] += 0.5 * Q[0] * rng.uniform(-1, 1, Q[0].shape)   # some wind so that both AUSM branches are hit
-        Q[2] += 0.5 * Q[0] * rng.uniform(-1, 1, Q[0].shape)
+        Q[1] += wind * Q[0] * rng.uniform(-1, 1, Q[0].shape)   # some wind so that both AUSM branches are hit
+        Q[2] += wind * Q[0] * rng.uniform(-1, 1, Q[0].shape)
         rhs = RhsBundle(geom, ops, metric, topo, None, cfg, Q.shape, False)
         out = {"Q": Q.copy(), "R": rhs.full(Q).copy()}
         r = rhs.full
@@ -454,6 +454,34 @@ def cart2d_case(name, ini, overrides, seed=99, rk3=None):
                     out["rk3_1"] = Qs.copy()
             out["rk3_n"] = Qs.copy()
             out["meta/rk3_steps"], out["meta/rk3_dt"] = numpy.int64(nsteps), numpy.float64(dt_rk)
+        if epi is not None:   # the shipped bubble configurations' own integrator: Epi + the ini's exponential solver, complex step
+            import integrators.epi as epi_mod
+
+            order, nsteps, dt_epi, tol = epi
+            cfg.verbose_solver = 0
+            cfg.tolerance = tol
+            solver_stats = []
+            real = getattr(epi_mod, cfg.exponential_solver)
+
+            def logging_solver(*a, **k):
+                phiv, stats = real(*a, **k)
+                solver_stats.append([float(x) for x in stats])
+                return phiv, stats
+
+            setattr(epi_mod, cfg.exponential_solver, logging_solver)
+            try:
+                stepper = epi_mod.Epi(cfg, order, rhs.full, device=dev)
+                Qs = Q.copy()
+                for i in range(nsteps):
+                    Qs = stepper.step(Qs, dt_epi)
+                    Qs = ops.apply_filters(Qs, geom, metric, dt_epi)
+                    out[f"epi_{i + 1}"] = numpy.array(Qs, copy=True)
+            finally:
+                setattr(epi_mod, cfg.exponential_solver, real)
+            out["meta/epi_order"], out["meta/epi_steps"] = numpy.int64(order), numpy.int64(nsteps)
+            out["meta/epi_dt"], out["meta/epi_tol"] = numpy.float64(dt_epi), numpy.float64(tol)
+            out["meta/epi_solver"] = numpy.array(cfg.exponential_solver)
+            out["meta/epi_solver_stats"] = numpy.array(solver_stats)
         out.update(_ops_1d(ops, geom))
         out["meta/n"] = numpy.int64(cfg.num_solpts)
         out["meta/nx"] = numpy.int64(cfg.num_elements_horizontal)
@@ -1206,6 +1234,10 @@ CASES = {
     "cart2d_rk3_bubble_n4": lambda nm: cart2d_case(nm, "gaussian_bubble.ini",
                                                   dict(num_solpts=4, num_elements_horizontal=5, num_elements_vertical=6),
                                                   rk3=(5, 0.01)),
+    # config/gaussian_bubble.ini's own integrator (epi2, the default exponential solver pmex, complex step) at its own dt
+    "cart2d_epi2_pmex_bubble_n4": lambda nm: cart2d_case(nm, "gaussian_bubble.ini",
+                                                        dict(num_solpts=4, num_elements_horizontal=5, num_elements_vertical=6),
+                                                        epi=(2, 3, 5.0, 1e-9), wind=0.01),
     # --- round 3: the remaining templated orders straight from the reference (n = 2 is what config/dcmip31.ini ships
     # with; 6 was pinned through the oracle on synthetic tiles only)
     "euler3d_c31p_n2_h4_v3": lambda nm: euler_case(

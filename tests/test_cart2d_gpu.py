@@ -103,3 +103,30 @@ def test_rk3_time_loop_matches_reference(fused, built_lib):
             err = np.abs(Q.cpu().numpy() - ref).max(axis=(1, 2, 3))
             assert (moved > 0).all() and (err <= 1e-9 * moved + 1e-14 * np.abs(ref).max(axis=(1, 2, 3))).all(), (i, err, moved)
     rhs.close()
+
+
+def test_shipped_bubble_integrator_epi2_with_pmex(built_lib):
+    """config/gaussian_bubble.ini's own integrator - epi2, the schema's default exponential solver pmex, complex-step JVP,
+    dt = 5 s (integrators/epi.py + solvers/pmex.py on the 2-D Cartesian RHS) - against the reference's own run on a small
+    grid: the state after each of three steps and pmex's statistics of every step (5 sub-steps, 320 vectors each)."""
+    from wxfactory_amd.integrators import Epi
+    from wxfactory_amd.rhs_cart2d import RhsCart2D
+
+    g = golden_cart("cart2d_epi2_pmex_bubble_n4")
+    assert str(g["meta/epi_solver"]) == "pmex"
+    rhs = RhsCart2D(g.n, g.nx, g.nz, g.dx1, g.dx3, g.ops, DEV)
+    stepper = Epi(int(g["meta/epi_order"]), rhs, tol=float(g["meta/epi_tol"]), exponential_solver="pmex")
+    dt, nsteps = float(g["meta/epi_dt"]), int(g["meta/epi_steps"])
+    ref_stats = g["meta/epi_solver_stats"]
+    Q, prev = _dev(g["Q"]), g["Q"]
+    for i in range(nsteps):
+        Q = stepper.step(Q, dt)
+        info = stepper.solver_info
+        got = [info[k] for k in ("substeps", "rejected", "iterations", "exps", "krylov_size", "own_norms")]
+        assert got == [int(ref_stats[i][k]) for k in (0, 1, 2, 3, 5, 6)], (i, got, ref_stats[i])
+        ref = g[f"epi_{i + 1}"]
+        moved = np.abs(ref - prev).max(axis=(1, 2, 3))
+        err = np.abs(Q.cpu().numpy() - ref).max(axis=(1, 2, 3))
+        assert (moved > 0).all() and (err <= 1e-6 * moved).all(), (i, err, moved)
+        prev = ref
+    rhs.close()
