@@ -740,7 +740,8 @@ def solvers_dense_case(name):
     MPI.reset_world(6)
 
 
-def epi_case(name, ini, overrides, orders=(3, 4, 5, 6), extra_steps=2, dt=30.0, perturb=0.01, seed=999):
+def epi_case(name, ini, overrides, orders=(3, 4, 5, 6), extra_steps=2, dt=30.0, perturb=0.01, seed=999, stiff=False,
+             solver="kiops"):
     """Multistep EPI integrators (integrators/epi.py:28-141): for each order, n_prev start-up steps (EPI2) plus
     `extra_steps` regular steps from the same perturbed state; pins the coefficient tables, the phi-vector
     assembly from previous states and KIOPS with several phi functions."""
@@ -757,7 +758,7 @@ def epi_case(name, ini, overrides, orders=(3, 4, 5, 6), extra_steps=2, dt=30.0, 
         cfg = _config(ini, overrides)
         cfg.verbose_solver = 0
         cfg.tolerance = 1e-7
-        cfg.exponential_solver = "kiops"
+        cfg.exponential_solver = solver
         cfg.jacobian_method = "complex"
         comm = MPI.COMM_WORLD
         dev = CpuDevice(comm)
@@ -771,7 +772,12 @@ def epi_case(name, ini, overrides, orders=(3, 4, 5, 6), extra_steps=2, dt=30.0, 
         Q = Q * (1.0 + perturb * rng.uniform(-1.0, 1.0, Q.shape))
         out = {"Q": Q.copy()}
         for order in orders:
-            epi = Epi(cfg, order, rhs.full, device=dev)
+            if stiff:   # integrators/epi_stiff.py as simulation.py:336-340 builds it (config/dcmip20.ini: epi_stiff3)
+                from integrators import EpiStiff
+
+                epi = EpiStiff(cfg, order, rhs.full, init_substeps=10, device=dev)
+            else:
+                epi = Epi(cfg, order, rhs.full, device=dev)
             Qn = Q.copy()
             for _ in range(epi.n_prev + extra_steps):
                 Qn = epi.step(Qn, dt)
@@ -1199,6 +1205,10 @@ CASES = {
     # multistep exponential integrators (orders 3 to 6) over their start-up and two regular steps
     "epi_multistep_n3_h2_v2": lambda nm: epi_case(
         nm, "dcmip31.ini", dict(num_solpts=3, num_elements_horizontal=2, num_elements_vertical=2)),
+    # stiffness-resilient EPI (config/dcmip20.ini: epi_stiff3), with the start-up simulation.py gives it (10 EPI2 sub-steps)
+    "epi_stiff_n3_h2_v2": lambda nm: epi_case(
+        nm, "dcmip31.ini", dict(num_solpts=3, num_elements_horizontal=2, num_elements_vertical=2), orders=(3, 4), stiff=True,
+        solver="pmex"),
     "state_file_v": state_file_case,
     # five SSP-RK3 steps + exponential filter of the Schaer-mountain case (topography, sponge): the time loop
     "steploop_c21_n4_h2_v3": lambda nm: steploop_case(

@@ -444,6 +444,33 @@ def test_multistep_epi_orders(built_lib, order):
     assert (err <= 2e-5 * upd + 1e-13 * np.abs(ref).max(axis=ax)).all(), (err / upd)
 
 
+@pytest.mark.parametrize("order", [3, 4])
+def test_stiffness_resilient_epi(built_lib, order):
+    """integrators/epi_stiff.py (time_integrator = epi_stiff3 in config/dcmip20.ini) as simulation.py:336-340 builds it -
+    ten EPI2 sub-steps per start-up step, then regular steps whose remainders enter from phi_3 on - with the default
+    exponential solver pmex, against the reference's own run from the same state."""
+    from tests.gpu_util import device_metric
+    from wxfactory_amd.integrators import EpiStiff
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D
+
+    g = Golden("epi_stiff_n3_h2_v2")
+    plans = {p: Euler3DPlan(g.n, g.H, g.V, g.case, p, g.ops, device_metric(g, p, DEV)) for p in range(6)}
+    rhs = RhsEuler3D(plans)
+    stack = lambda key: torch.from_numpy(np.stack([g[f"p{p}/{key}"] for p in range(6)])).to(DEV)  # noqa: E731
+    Q0, dt = stack("Q"), float(g["meta/dt"])
+    epi, Q = EpiStiff(order, rhs, tol=1e-7, init_substeps=10, exponential_solver="pmex"), Q0
+    assert epi.n_prev == order - 2 and epi.max_phi == order and epi.first_row == 3
+    for _ in range(int(g[f"meta/steps_epi{order}"])):
+        Q = epi.step(Q, dt)
+    ref, q0 = stack(f"epi{order}").cpu().numpy(), Q0.cpu().numpy()
+    ax = (0, 2, 3, 4, 5)
+    upd = np.abs(ref - q0).max(axis=ax)
+    err = np.abs(Q.cpu().numpy() - ref).max(axis=ax)
+    assert (err <= 2e-5 * upd + 1e-13 * np.abs(ref).max(axis=ax)).all(), (err / upd)
+    with pytest.raises(ValueError, match="Unsupported order"):
+        EpiStiff(1, rhs)
+
+
 @pytest.mark.parametrize("p,taus", [(1, [1.0]), (3, [0.4, 1.0])])
 def test_kiops_long_vector_build(built_lib, p, taus, monkeypatch):
     """Vectors too long for the one-workgroup finish take the three streaming stages (wx_kiops_long_a/b/c): same

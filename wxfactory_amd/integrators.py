@@ -96,10 +96,10 @@ class Epi:
                  init_substeps: int = 1, init_method=None, exponential_solver: str = "kiops"):
         from collections import deque
 
-        if order not in self._A:
-            raise ValueError(f"Unsupported order {order} for EPI method")
         if exponential_solver not in ("kiops", "pmex"):   # (the two the shipped configurations name, epi.py:314-348)
             raise ValueError(f"Unrecognized exponential solver {exponential_solver}")
+        # A[k][i]: weight of the i-th previous state's remainder in phi-row first_row + k
+        self.A, self.first_row, self.n_prev, self.max_phi = self._tables(order)
         self.rhs, self.tol, self.jacobian_method = rhs, tol, jacobian_method
         self.exponential_solver = exponential_solver
         # how a second sub-step of the phi solver restarts its augmented components: "reference" = as the reference
@@ -112,12 +112,6 @@ class Epi:
         self.graph_passes = False
         self._static = None
         self._ws = None
-        self.A = self._A[order]
-        k = len(self.A)
-        self.n_prev = len(self.A[0])
-        if order == 2:
-            k -= 1
-        self.max_phi = k + 1
         self.krylov_size = 1
         self.previous_Q, self.previous_rhs = deque(), deque()
         self.dt = 0.0
@@ -126,11 +120,15 @@ class Epi:
         self.init_substeps = init_substeps
         self.solver_info = None
 
-    def step(self, Q: torch.Tensor, dt: float) -> torch.Tensor:
-        import math
+    def _tables(self, order: int):
+        if order not in self._A:
+            raise ValueError(f"Unsupported order {order} for EPI method")
+        A = self._A[order]
+        k = len(A) - (1 if order == 2 else 0)
+        return A, 2, len(A[0]), k + 1
 
+    def step(self, Q: torch.Tensor, dt: float) -> torch.Tensor:
         from .matvec import matvec_fun
-        from .solvers import kiops
 
         if self.dt and abs(self.dt - dt) > 1e-10:
             self.previous_Q.clear()
@@ -152,8 +150,14 @@ class Epi:
         for i in range(self.n_prev):
             JdQ = matvec_fun((self.previous_Q[i] - Q).flatten(), 1.0, Q, rhs, self.rhs, self.jacobian_method)
             r = (self.previous_rhs[i] - rhs).flatten() - JdQ
-            for k, row in enumerate(self.A, start=2):
+            for k, row in enumerate(self.A, start=self.first_row):
                 vec[k] += row[i] * r
+        return self._advance(Q, rhs, self._phi_sum(Q, rhs, vec, dt), dt)
+
+    def _phi_sum(self, Q, rhs, vec, dt):
+        """sum_k phi_k(dt J) vec[k] with the configured exponential solver; fills `solver_info`."""
+        import math
+
         if self.exponential_solver == "pmex":
             from .solvers import pmex
 
@@ -161,7 +165,9 @@ class Epi:
                                mmax=64, task1=False, restart_powers=self.restart_powers)
             self.solver_info = dict(substeps=stats[0], rejected=stats[1], iterations=stats[2], exps=stats[3],
                                     error=stats[4], krylov_size=stats[5], own_norms=stats[6])
-            return self._advance(Q, rhs, phiv, dt)
+            return phiv
+        from .solvers import kiops
+
         ws, token, Qm, Rm = None, None, Q, rhs
         if Q.is_cuda and Q.dtype == torch.float64:
             from .solvers import KiopsWorkspace
@@ -185,7 +191,7 @@ class Epi:
         self.krylov_size = math.floor(0.7 * stats[5] + 0.3 * self.krylov_size)
         self.solver_info = dict(substeps=stats[0], rejected=stats[1], iterations=stats[2], exps=stats[3],
                                 error=stats[4], krylov_size=stats[5])
-        return self._advance(Q, rhs, phiv, dt)
+        return phiv
 
     def _advance(self, Q, rhs, phiv, dt):
         if self.n_prev > 0:
@@ -194,6 +200,30 @@ class Epi:
             self.previous_rhs.pop()
             self.previous_rhs.appendleft(rhs)
         return Q + phiv.reshape(Q.shape) * dt
+
+
+class EpiStiff(Epi):
+    """Stiffness-resilient EPI of order >= 2 (integrators/epi_stiff.py:14-132; `time_integrator = epi_stiff<order>`,
+    config/dcmip20.ini): the remainders of the order - 2 previous states enter from phi_3 on, with the weights of
+    integrators/integrator.py:135-146 for the nodes 1, 2, ..., order - 2.  Start-up by EPI2 steps; simulation.py:336-340
+    builds it with init_substeps = 10."""
+
+    def _tables(self, order: int):
+        import math
+        from itertools import combinations
+
+        if order < 2:
+            raise ValueError("Unsupported order for EPI method")
+        c = [float(i) for i in range(1, order - 1)]
+        m = len(c)
+        A = [[0.0] * m for _ in range(m)]
+        for i in range(m):
+            others = c[:i] + c[i + 1:]
+            denom = c[i] ** 2 * math.prod(c[i] - cl for cl in others)
+            for k in range(m):
+                esym = sum(math.prod(v) for v in combinations(others, m - k - 1))   # elementary symmetric polynomial
+                A[k][i] = (-1) ** (m - k + 1) * math.factorial(k + 2) * esym / denom
+        return A, 3, m, (order if order > 2 else 1)
 
 
 class StepLoop:
