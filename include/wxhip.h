@@ -427,6 +427,15 @@ size_t wx_multi_dot_workspace(int m);
 wx_status wx_multi_dot(const double* V, size_t ldv, int m, const double* w, size_t n, double* out, double* workspace,
                        wx_stream stream);
 wx_status wx_multi_axpy(double* w, const double* V, size_t ldv, int m, const double* h, size_t n, wx_stream stream);
+/* ... and w = (w - sum_k h[k] V[k]) * scale in the same pass (the correction and the normalisation of a Krylov vector of
+ * solvers/pmex.py:193-233 when its norm is known from the products already). */
+wx_status wx_multi_axpy_scaled(double* w, const double* V, size_t ldv, int m, const double* h, size_t n, double scale,
+                               wx_stream stream);
+/* The augmented update of the phi-function Krylov methods (solvers/kiops.py:170-173, solvers/pmex.py:160-163) for row j of
+ * the basis V (rows of n + p doubles, row stride ldv):  V[j, :n] = aw + uflip @ V[j-1, n:n+p]  (uflip: n x p, row-major;
+ * aw: the operator's product with V[j-1, :n]),  V[j, n:n+p] = V[j-1, n+1:n+p], 0.  1 <= p <= 16. */
+wx_status wx_krylov_aug_update(double* V, size_t ldv, int j, size_t n, int p, const double* aw, const double* uflip,
+                               wx_stream stream);
 /* The low-synchronisation Gram-Schmidt step of solvers/fgmres.py:16-73 (_ortho_1_sync_igs: all rows against the last
  * two in ONE fused reduction, then both rows corrected, scaled and orthogonalised against each other):
  *   wx_multi_dot2   out[k] = <V[k], a>, out[m + k] = <V[k], b>, k < m, one pass over the rows

@@ -83,6 +83,8 @@ SIGNATURES = {
     "wx_multi_dot_workspace": (c_size_t, [c_int]),
     "wx_multi_dot": (c_int, [c_void_p, c_size_t, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "wx_multi_axpy": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_size_t, c_void_p]),
+    "wx_multi_axpy_scaled": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_size_t, c_double, c_void_p]),
+    "wx_krylov_aug_update": (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_int, c_void_p, c_void_p, c_void_p]),
     "wx_kiops_finish_workspace": (c_size_t, [c_size_t]),
     "wx_kiops_finish": (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p]),

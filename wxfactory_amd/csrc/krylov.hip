@@ -64,7 +64,7 @@ __global__ __launch_bounds__(64) void multi_dot_finish_kernel(const double* __re
 
 template <int R>
 __global__ __launch_bounds__(256) void multi_axpy_kernel(double* __restrict__ w, const double* __restrict__ V, size_t ldv,
-                                                         int row0, const double* __restrict__ h, size_t n) {
+                                                         int row0, const double* __restrict__ h, size_t n, double scale) {
     double c[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) c[r] = h[row0 + r];
@@ -73,8 +73,27 @@ __global__ __launch_bounds__(256) void multi_axpy_kernel(double* __restrict__ w,
         double s = w[i];
 #pragma unroll
         for (int r = 0; r < R; ++r) s -= c[r] * V[(size_t)(row0 + r) * ldv + i];
-        w[i] = s;
+        w[i] = s * scale;   // (1.0 on every pass but the last of wx_multi_axpy_scaled: exact)
     }
+}
+
+// Augmented update of the phi-function Krylov methods (solvers/kiops.py:170-173, pmex.py:160-163) as one streaming
+// kernel: V[j, :n] = aw + uflip (n x p, row-major) @ V[j-1, n:n+p];  V[j, n:] = V[j-1, n+1:], 0.
+// (torch.addmv hands the n x p product to a rocBLAS gemv that runs at a fraction of the streaming rate for p of 1-4.)
+__global__ __launch_bounds__(256) void aug_update_kernel(double* __restrict__ V, size_t ldv, int j, size_t n, int p,
+                                                         const double* __restrict__ aw, const double* __restrict__ uflip) {
+    __shared__ double aug[16];
+    double* vj = V + (size_t)j * ldv;
+    const double* vp = V + (size_t)(j - 1) * ldv;
+    if ((int)threadIdx.x < p) aug[threadIdx.x] = vp[n + threadIdx.x];
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double w = aw[i];
+        for (int k = 0; k < p; ++k) w += uflip[i * p + k] * aug[k];
+        vj[i] = w;
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < p) vj[n + threadIdx.x] = (int)threadIdx.x + 1 < p ? aug[threadIdx.x + 1] : 0.0;
 }
 
 // The two kernels of the low-synchronisation Gram-Schmidt step (solvers/fgmres.py:16-73: every basis row against the
@@ -322,10 +341,11 @@ static void launch_dot(const double* V, size_t ldv, int row0, const double* w, s
     hipLaunchKernelGGL((multi_dot_kernel<R>), dim3(kDotBlocks), dim3(kDotThreads), 0, st, V, ldv, row0, w, n, partial, m);
 }
 template <int R>
-static void launch_axpy(double* w, const double* V, size_t ldv, int row0, const double* h, size_t n, hipStream_t st) {
+static void launch_axpy(double* w, const double* V, size_t ldv, int row0, const double* h, size_t n, double scale,
+                        hipStream_t st) {
     const size_t want = (n + 255) / 256;
     const unsigned grid = (unsigned)(want < 8192 ? (want ? want : 1) : 8192);
-    hipLaunchKernelGGL((multi_axpy_kernel<R>), dim3(grid), dim3(256), 0, st, w, V, ldv, row0, h, n);
+    hipLaunchKernelGGL((multi_axpy_kernel<R>), dim3(grid), dim3(256), 0, st, w, V, ldv, row0, h, n, scale);
 }
 
 // launch the instantiation for `rem` rows (1 <= rem <= R)
@@ -336,9 +356,10 @@ static void dispatch_dot(int rem, const double* V, size_t ldv, int row0, const d
     else if constexpr (R > 1) dispatch_dot<R - 1>(rem, V, ldv, row0, w, n, partial, m, st);
 }
 template <int R>
-static void dispatch_axpy(int rem, double* w, const double* V, size_t ldv, int row0, const double* h, size_t n, hipStream_t st) {
-    if (rem == R) launch_axpy<R>(w, V, ldv, row0, h, n, st);
-    else if constexpr (R > 1) dispatch_axpy<R - 1>(rem, w, V, ldv, row0, h, n, st);
+static void dispatch_axpy(int rem, double* w, const double* V, size_t ldv, int row0, const double* h, size_t n, double scale,
+                          hipStream_t st) {
+    if (rem == R) launch_axpy<R>(w, V, ldv, row0, h, n, scale, st);
+    else if constexpr (R > 1) dispatch_axpy<R - 1>(rem, w, V, ldv, row0, h, n, scale, st);
 }
 template <int R>
 static void dispatch_dot2(int rem, const double* V, size_t ldv, int row0, const double* a, const double* b, size_t n,
@@ -460,13 +481,32 @@ wx_status wx_pair_update(double* a, double* b, const double* V, size_t ldv, int 
     return WX_OK;
 }
 
-wx_status wx_multi_axpy(double* w, const double* V, size_t ldv, int m, const double* h, size_t n, wx_stream stream) {
+wx_status wx_multi_axpy_scaled(double* w, const double* V, size_t ldv, int m, const double* h, size_t n, double scale,
+                               wx_stream stream) {
     if (m <= 0 || n == 0) return WX_OK;
     if (!V || !w || !h) return fail(WX_ERR_INVALID, "wx_multi_axpy: null argument");
     if (ldv < n) return fail(WX_ERR_INVALID, "wx_multi_axpy: row stride %zu shorter than the vectors (%zu)", ldv, n);
     WX_STREAM(st, stream);
     for (int r = 0; r < m; r += kRowsPerPass)
-        dispatch_axpy<kRowsPerPass>(m - r < kRowsPerPass ? m - r : kRowsPerPass, w, V, ldv, r, h, n, st);
+        dispatch_axpy<kRowsPerPass>(m - r < kRowsPerPass ? m - r : kRowsPerPass, w, V, ldv, r, h, n,
+                                    r + kRowsPerPass >= m ? scale : 1.0, st);
+    WX_HIP_TRY(hipGetLastError());
+    return WX_OK;
+}
+
+wx_status wx_multi_axpy(double* w, const double* V, size_t ldv, int m, const double* h, size_t n, wx_stream stream) {
+    return wx_multi_axpy_scaled(w, V, ldv, m, h, n, 1.0, stream);
+}
+
+wx_status wx_krylov_aug_update(double* V, size_t ldv, int j, size_t n, int p, const double* aw, const double* uflip,
+                               wx_stream stream) {
+    if (!V || !aw || !uflip) return fail(WX_ERR_INVALID, "wx_krylov_aug_update: null argument");
+    if (j < 1 || p < 1 || p > 16 || ldv < n + (size_t)p)
+        return fail(WX_ERR_INVALID, "wx_krylov_aug_update: j = %d, p = %d (1..16), row stride %zu, n = %zu", j, p, ldv, n);
+    WX_STREAM(st, stream);
+    const size_t want = (n + 255) / 256;
+    const unsigned grid = (unsigned)(want < 8192 ? (want ? want : 1) : 8192);
+    hipLaunchKernelGGL(aug_update_kernel, dim3(grid), dim3(256), 0, st, V, ldv, j, n, p, aw, uflip);
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
 }

@@ -71,16 +71,33 @@ class _Basis:
                                          self.work.data_ptr(), st), "wx_multi_dot")
         return out
 
-    def subtract(self, w: torch.Tensor, lo: int, hi: int, h: torch.Tensor) -> torch.Tensor:
-        """w -= sum_k h[k - lo] V[k], in place."""
+    def subtract(self, w: torch.Tensor, lo: int, hi: int, h: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+        """w = (w - sum_k h[k - lo] V[k]) * scale, in place (one pass over the rows)."""
         V = self.V
-        if not (self.gpu and w.is_contiguous() and h.is_cuda):
-            w -= h.to(w.device, w.dtype) @ V[lo:hi]
+        if not (self.gpu and w.is_contiguous() and h.is_cuda) or hi <= lo:
+            if hi > lo:
+                w -= h.to(w.device, w.dtype) @ (V[lo:hi] if w.numel() == V.shape[1] else V[lo:hi, : w.numel()])
+            if scale != 1.0:
+                w *= scale
             return w
         st = torch.cuda.current_stream(V.device).cuda_stream
-        self.check(self.lib.wx_multi_axpy(w.data_ptr(), V[lo].data_ptr(), V.stride(0), hi - lo, h.contiguous().data_ptr(),
-                                          w.numel(), st), "wx_multi_axpy")
+        self.check(self.lib.wx_multi_axpy_scaled(w.data_ptr(), V[lo].data_ptr(), V.stride(0), hi - lo,
+                                                 h.contiguous().data_ptr(), w.numel(), float(scale), st), "wx_multi_axpy")
         return w
+
+    def aug_update(self, j: int, n: int, aw: torch.Tensor, u_flip_t: torch.Tensor, shift: torch.Tensor):
+        """Row j from row j-1 of a basis of rows (n | p): V[j, :n] = aw + u_flip_t @ V[j-1, n:], V[j, n:] = the augmented
+        components moved up by one, zero at the end (solvers/kiops.py:170-173, pmex.py:160-163)."""
+        V = self.V
+        p = V.shape[1] - n
+        if not (self.gpu and p <= 16 and aw.is_cuda and aw.dtype == torch.float64 and u_flip_t.is_contiguous()):
+            torch.addmv(aw, u_flip_t, V[j - 1, n:], out=V[j, :n])
+            torch.mv(shift, V[j - 1, n:], out=V[j, n:])
+            return
+        aw = aw if aw.is_contiguous() else aw.contiguous()
+        st = torch.cuda.current_stream(V.device).cuda_stream
+        self.check(self.lib.wx_krylov_aug_update(V.data_ptr(), V.stride(0), j, n, p, aw.data_ptr(), u_flip_t.data_ptr(), st),
+                   "wx_krylov_aug_update")
 
 
     def combine(self, k: int, y) -> torch.Tensor:
@@ -971,12 +988,13 @@ def pmex(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, delta: float 
             Vd[0] /= beta
         while j < m:
             j += 1
-            torch.addmv(A(Vd[j - 1, :n]), u_flip_t, Vd[j - 1, n:], out=Vd[j, :n])
-            torch.mv(shift, Vd[j - 1, n:], out=Vd[j, n:])   # augmented components: up by one, zero at the end
+            basis.aug_update(j, n, A(Vd[j - 1, :n]).reshape(-1), u_flip_t, shift)
             G = gram(j)
             sol = proj.coefficients(j, G)
-            basis.subtract(Vd[j], 0, j, torch.as_tensor(sol, dtype=dtype).to(dev))
+            sol_d = torch.as_tensor(sol, dtype=dtype).to(dev)
             nrm_j = _norm_after_projection(G[:, 1], j)
+            scaled = nrm_j is not None and nrm_j >= tol   # the norm is known already: correct and normalise in one pass
+            basis.subtract(Vd[j], 0, j, sol_d, 1.0 / nrm_j if scaled else 1.0)
             if nrm_j is None:
                 nrm_j = math.sqrt(norm2(Vd[j]))
                 own_norms += 1
@@ -988,7 +1006,8 @@ def pmex(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, delta: float 
             if nrm_j < tol:   # happy breakdown: the Krylov space is invariant
                 happy = True
                 break
-            Vd[j] /= nrm_j
+            if not scaled:
+                Vd[j] /= nrm_j
             H[j, j - 1] = nrm_j
             krystep += 1
         H[0, j] = 1.0
