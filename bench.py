@@ -766,6 +766,14 @@ def main():
                          "note": "rank 0's tiles; the interface buffer's round trip through HBM and the extrapolation "
                                  "kernel's second read of Q are not compulsory bytes"}
         roof["sweep_frac"] = roof["sweep"]["frac"]
+        # BASELINE.md section 4 states the north star's target in the survey's accounting (384 B/point whatever the metric
+        # holds): >= 50 % of 8 TB/s  <=>  >= 52 G DOF-updates/s per GPU.  The same sweep in that accounting:
+        survey_sweep = ALGO_BYTES_PER_POINT * (pts_panel / (k * k)) * len(mine) / (dt / args.steps) / 1e9
+        roof["sweep"]["target"] = {"source": "BASELINE.md section 4 (north star: >= 50 % of HBM peak on the E7 sweep at "
+                                             "384 B/point = 52 G DOF-updates/s per GPU)",
+                                   "frac_at_survey_bytes_per_point": round(survey_sweep / HBM_PEAK_GBS, 4),
+                                   "dof_updates_per_s_this_rank": 5 * (pts_panel / (k * k)) * len(mine) / (dt / args.steps),
+                                   "met": bool(survey_sweep / HBM_PEAK_GBS >= 0.5)}
 
     if rank == 0:
         line = {
