@@ -103,3 +103,39 @@ def test_epi2_step_with_pmex(setup):
     assert (np.abs(Qn.cpu().numpy() - refq).max(axis=AX) <= 1e-7 * upd).all()
     with pytest.raises(ValueError, match="Unrecognized exponential solver"):
         Epi(2, rhs, exponential_solver="exode")
+
+
+@pytest.mark.parametrize("p,taus", [(1, [1.0]), (3, [0.4, 1.0])])
+def test_pmex_device_kernels_split_form_and_exact_result(built_lib, p, taus, monkeypatch):
+    """pmex on device vectors (wx_krylov_aug_update, wx_multi_dot2, wx_multi_axpy_scaled) against the same algorithm on CPU
+    tensors (torch expressions), the several-rank form of its reductions taken on one rank (products of the n-long parts
+    all-reduced, the replicated augmented components added once afterwards), and the exact result of a diagonal operator."""
+    import math
+
+    from wxfactory_amd.solvers import pmex
+
+    n = 50_000
+    gen = torch.Generator(device=DEV).manual_seed(23 + p)
+    lam = -(0.2 + 2.5 * torch.rand(n, generator=gen, device=DEV, dtype=torch.float64))
+    u = torch.randn((p + 1, n), generator=gen, device=DEV, dtype=torch.float64)
+    A = lambda v: lam * v  # noqa: E731
+    args = dict(tol=1e-10, m_init=12, mmin=10, mmax=40)
+    w_dev, st_dev = pmex(taus, A, u, **args)
+    lam_c, u_c = lam.cpu(), u.cpu()
+    w_cpu, st_cpu = pmex(taus, lambda v: lam_c * v, u_c, **args)
+    assert st_dev[:4] == st_cpu[:4] and st_dev[5:] == st_cpu[5:], (st_dev, st_cpu)
+    scale = float(w_cpu.abs().max())
+    assert float((w_dev.cpu() - w_cpu).abs().max()) <= 1e-11 * scale
+    monkeypatch.setenv("WXHIP_KIOPS_SPLIT_TEST", "1")
+    w_split, st_split = pmex(taus, A, u, **args)
+    monkeypatch.delenv("WXHIP_KIOPS_SPLIT_TEST")
+    assert st_split[:4] == st_dev[:4] and float((w_split - w_dev).abs().max()) <= 1e-12 * scale
+
+    def phi(k, z):
+        if k == 0:
+            return torch.exp(z)
+        return (phi(k - 1, z) - 1.0 / math.factorial(k - 1)) / z
+
+    for i, tau in enumerate(taus):   # exact: w(tau) = sum_k tau^k phi_k(tau lam) u_k
+        ref = sum((tau ** k) * phi(k, tau * lam) * u[k] for k in range(p + 1))
+        assert float((w_dev[i] - ref).abs().max()) <= 1e-8 * float(ref.abs().max())

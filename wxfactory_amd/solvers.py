@@ -939,6 +939,8 @@ def pmex(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, delta: float 
         p = 1
         u = torch.cat((u, torch.zeros((1, n), dtype=dtype, device=dev)))
     split = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if os.environ.get("WXHIP_KIOPS_SPLIT_TEST") == "1":
+        split = True   # (tests: the several-rank code paths - reductions completed after an all-reduce - on one rank)
     m = max(mmin, min(m_init, mmax))
     Vd = torch.empty((mmax + 1, n + p), dtype=dtype, device=dev)   # (every row is written before it is read)
     basis = _Basis(Vd)
