@@ -139,3 +139,33 @@ def test_pmex_device_kernels_split_form_and_exact_result(built_lib, p, taus, mon
     for i, tau in enumerate(taus):   # exact: w(tau) = sum_k tau^k phi_k(tau lam) u_k
         ref = sum((tau ** k) * phi(k, tau * lam) * u[k] for k in range(p + 1))
         assert float((w_dev[i] - ref).abs().max()) <= 1e-8 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("solver", ["kiops", "pmex"])
+def test_krylov_basis_is_sized_to_the_free_memory(built_lib, solver, monkeypatch):
+    """The reference asks for mmax = 64 whatever the problem size (integrators/epi.py:315, 334); 65 vectors of the whole E7
+    sphere are 230 GB.  The solvers take the largest basis that fits (all ranks the same), say so, and the controller
+    works within it; when not even mmin fits they raise."""
+    from wxfactory_amd import solvers
+
+    n = 20_000
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    lam = -(0.2 + 40.0 * torch.rand(n, generator=gen, device=DEV, dtype=torch.float64))
+    u = torch.randn((2, n), generator=gen, device=DEV, dtype=torch.float64)
+    fn = getattr(solvers, solver)
+    args = dict(tol=1e-10, m_init=30, mmin=10, mmax=64)
+    w_full, st_full = fn([1.0], lambda v: lam * v, u, **args)
+    row = (n + 1) * 8
+    real = torch.cuda.mem_get_info
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (27 * row, real(dev)[1]))
+    monkeypatch.setattr(torch.cuda, "memory_reserved", lambda dev=None: 0)
+    monkeypatch.setattr(torch.cuda, "memory_allocated", lambda dev=None: 0)
+    with pytest.warns(RuntimeWarning, match="limited to 18 vectors"):
+        w_small, st_small = fn([1.0], lambda v: lam * v, u, **args)
+    assert st_small[5] <= 18 and st_small[0] >= st_full[0]
+    ref = (torch.exp(lam) * u[0] + (torch.exp(lam) - 1.0) / lam * u[1])
+    for w in (w_full, w_small):
+        assert float((w[0] - ref).abs().max()) <= 1e-8 * float(ref.abs().max())
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (12 * row, real(dev)[1]))
+    with pytest.raises(MemoryError, match="mmin"):
+        fn([1.0], lambda v: lam * v, u, **args)

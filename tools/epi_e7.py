@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """EPI2 + KIOPS (or, SOLVER=pmex, PMEX) steps at the benchmark's resolution (development tool): n = 8, 60 x 60 elements per panel, V vertical
-elements (default 2: a Krylov basis of 64 vectors of the V = 8 sphere would not fit beside the metric), whole sphere on
+elements (default 2; V = 8, the whole benchmark sphere, runs with the Krylov basis sized to the free memory), whole sphere on
 one GPU.  Time per step, per Krylov vector, and what a bare prepared matvec costs - the overhead of everything around it."""
 import os
 import sys

@@ -601,6 +601,36 @@ class _PmexControl(_SubstepControl):
         return self.m if keep_tau < self.tau else best_m
 
 
+def _affordable_mmax(n: int, p: int, mmax: int, mmin: int, dev, dtype, group=None, what: str = "kiops") -> int:
+    """The largest Krylov basis (<= mmax) whose rows fit in the device memory that is free now.  The reference passes
+    mmax = 64 (integrators/epi.py:315, 334) whatever the problem size; a basis of 65 vectors of the whole E7 sphere is
+    230 GB, which one MI355X does not have beside the metric.  The controller then simply works with the smaller
+    limit (its `j == mmax` branch) - the decisions differ from the reference's only when it would have asked for more
+    vectors than fit.  All ranks take the same limit (all-reduce MIN).  Raises MemoryError when not even mmin fits."""
+    dev = torch.device(dev)
+    limit = mmax
+    if dev.type == "cuda":
+        free, _ = torch.cuda.mem_get_info(dev)
+        free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)   # (blocks the caching allocator can reuse)
+        row = (n + p) * torch.empty((), dtype=dtype).element_size()
+        # beside the basis: the operator's own temporaries, the result rows, the finish workspace - eight vectors' worth
+        rows = (free - 8 * row) // row
+        limit = int(min(mmax, rows - 1))
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        t = torch.tensor([limit], dtype=torch.int64, device=dev if dev.type == "cuda" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        limit = int(t.item())
+    if limit < mmax:
+        if limit < max(mmin, 2):
+            raise MemoryError(f"{what}: not even a Krylov basis of mmin = {mmin} vectors of {n + p} values fits in the free "
+                              f"device memory")
+        import warnings
+
+        warnings.warn(f"{what}: Krylov basis limited to {limit} vectors (mmax = {mmax} asked for; {n + p} values per vector) "
+                      f"by the free device memory", RuntimeWarning, stacklevel=3)
+    return limit
+
+
 class KiopsWorkspace:
     """Buffers of kiops that survive from one call to the next (basis, Hessenberg columns, the augmented-part operators)
     and the HIP graphs of its Krylov passes.  A pass - the vectors j0+1 .. m built back to back with no host
@@ -615,10 +645,20 @@ class KiopsWorkspace:
 
     def __init__(self):
         self.key = None
+        self.request = self.granted = None   # what kiops asked for (n, p, mmax, ...) and the basis size memory allowed
         self.token = None
         self.graphs = {}
         self.seen = {}
         self.replays = self.captures = 0
+
+    def release(self):
+        """Drop the buffers (and the graphs that hold their addresses)."""
+        self.key = self.request = self.granted = None
+        self.graphs.clear()
+        self.seen.clear()
+        for name in ("Vd", "basis", "Ht", "nrm2", "u_flip_t", "shift", "finish_work", "aw", "dots"):
+            if hasattr(self, name):
+                delattr(self, name)
 
     def ensure(self, n, p, mmax, dev, dtype):
         key = (n, p, mmax, str(dev), dtype)
@@ -716,8 +756,16 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
     if p == 0:
         p = 1
         u = torch.cat((u, torch.zeros((1, n), dtype=dtype, device=dev)))
+    request = (n, p, mmax, mmin, str(dev), dtype)
+    if workspace is not None and workspace.request == request:
+        mmax = workspace.granted   # (the basis it holds was sized for this very request)
+    else:
+        if workspace is not None:
+            workspace.release()    # its old basis counts as free memory for the new one
+        mmax = _affordable_mmax(n, p, mmax, mmin, dev, dtype, group, "kiops")
     m = max(mmin, min(m_init, mmax))
     ws = (workspace if workspace is not None else KiopsWorkspace()).ensure(n, p, mmax, dev, dtype)
+    ws.request, ws.granted = request, mmax
     Vd, basis, Ht, nrm2 = ws.Vd, ws.basis, ws.Ht, ws.nrm2
     H = np.zeros((mmax + 1, mmax + 1))
     split = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
@@ -941,6 +989,7 @@ def pmex(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, delta: float 
     split = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     if os.environ.get("WXHIP_KIOPS_SPLIT_TEST") == "1":
         split = True   # (tests: the several-rank code paths - reductions completed after an all-reduce - on one rank)
+    mmax = _affordable_mmax(n, p, mmax, mmin, dev, dtype, group, "pmex")
     m = max(mmin, min(m_init, mmax))
     Vd = torch.empty((mmax + 1, n + p), dtype=dtype, device=dev)   # (every row is written before it is read)
     basis = _Basis(Vd)
