@@ -436,6 +436,25 @@ wx_status wx_multi_axpy_scaled(double* w, const double* V, size_t ldv, int m, co
  * aw: the operator's product with V[j-1, :n]),  V[j, n:n+p] = V[j-1, n+1:n+p], 0.  1 <= p <= 16. */
 wx_status wx_krylov_aug_update(double* V, size_t ldv, int j, size_t n, int p, const double* aw, const double* uflip,
                                wx_stream stream);
+/* One Krylov vector of PMEX (solvers/pmex.py:157-233) from the operator's product `aw` with V[j-1, :n], with no host round
+ * trip: the augmented update, the (j+1) x 2 block of products, the coefficients of the reference's low-synchronisation
+ * projector (LT, Linv: ld x ld, row-major, persistent over the solve - LT zeros and Linv the identity at its start), the
+ * norm from the same reduction (squares accumulated in double-double where the reference uses the platform's extended
+ * precision) or, where that difference is negative, the corrected vector's own norm; the correction and the
+ * normalisation.  hcol[0 .. j-1] = the projection coefficients, hcol[j] = the norm (below `tol`: a happy breakdown, the
+ * vector is left unnormalised and the caller discards what follows), *own = 1 when the own norm was needed.
+ * 1 <= j <= mmax <= 128, mmax <= ld, 1 <= p <= 16.  workspace: wx_pmex_workspace(mmax) doubles. */
+size_t wx_pmex_workspace(int mmax);
+/* ... with the complex-step matvec of a dual batch in front (wx_euler3d_batch_extrap_pack + wx_euler3d_batch_jvp applied to
+ * V[j-1, :n]; aw: n doubles of scratch for the product), all from one host call: the PMEX twin of
+ * wx_euler3d_batch_kiops_vector, same conditions (the rank owns the whole sphere; n = tiles x panel_stride). */
+wx_status wx_euler3d_batch_pmex_vector(const wx_euler3d_batch* b, const double* q, double* V, size_t ldv, int j, size_t n,
+                                       int p, double eps, double scale, const double* uflip, double* LT, double* Linv, int ld,
+                                       double tol, double* hcol, double* own, double* aw, double* workspace, int mmax,
+                                       size_t panel_stride, wx_stream stream);
+wx_status wx_pmex_vector(double* V, size_t ldv, int j, size_t n, int p, const double* aw, const double* uflip, double* LT,
+                         double* Linv, int ld, double tol, double* hcol, double* own, double* workspace, int mmax,
+                         wx_stream stream);
 /* The low-synchronisation Gram-Schmidt step of solvers/fgmres.py:16-73 (_ortho_1_sync_igs: all rows against the last
  * two in ONE fused reduction, then both rows corrected, scaled and orthogonalised against each other):
  *   wx_multi_dot2   out[k] = <V[k], a>, out[m + k] = <V[k], b>, k < m, one pass over the rows

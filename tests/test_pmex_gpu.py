@@ -130,6 +130,13 @@ def test_pmex_device_kernels_split_form_and_exact_result(built_lib, p, taus, mon
     w_split, st_split = pmex(taus, A, u, **args)
     monkeypatch.delenv("WXHIP_KIOPS_SPLIT_TEST")
     assert st_split[:4] == st_dev[:4] and float((w_split - w_dev).abs().max()) <= 1e-12 * scale
+    # ... and the one-rank form with a host round trip per vector (the projector on the host, as the reference has it)
+    # against the default, whose vectors are built by wx_pmex_vector with none
+    monkeypatch.setenv("WXHIP_PMEX_DEVICE", "0")
+    w_host, st_host = pmex(taus, A, u, **args)
+    monkeypatch.delenv("WXHIP_PMEX_DEVICE")
+    assert st_host[:4] == st_dev[:4] and st_host[5:] == st_dev[5:], (st_host, st_dev)
+    assert float((w_host - w_dev).abs().max()) <= 1e-12 * scale
 
     def phi(k, z):
         if k == 0:
@@ -169,3 +176,22 @@ def test_krylov_basis_is_sized_to_the_free_memory(built_lib, solver, monkeypatch
     monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (12 * row, real(dev)[1]))
     with pytest.raises(MemoryError, match="mmin"):
         fn([1.0], lambda v: lam * v, u, **args)
+
+
+def test_pmex_happy_breakdown_on_the_device(built_lib, monkeypatch):
+    """An operator with five distinct eigenvalues: the Krylov space closes after six vectors.  The pass builds its vectors
+    without a host round trip, so the breakdown is seen when the columns are read: the vectors past it are discarded and the
+    result is exact (both with and without the round trip per vector)."""
+    from wxfactory_amd.solvers import pmex
+
+    n = 30_000
+    gen = torch.Generator(device=DEV).manual_seed(99)
+    lam = -torch.tensor([0.5, 1.0, 1.5, 2.0, 2.5], device=DEV, dtype=torch.float64)[torch.randint(0, 5, (n,), generator=gen, device=DEV)]
+    u = torch.zeros((2, n), device=DEV, dtype=torch.float64)
+    u[0] = torch.randn(n, generator=gen, device=DEV, dtype=torch.float64)
+    ref = torch.exp(lam) * u[0]
+    for device_pass in ("1", "0"):
+        monkeypatch.setenv("WXHIP_PMEX_DEVICE", device_pass)
+        w, st = pmex([1.0], lambda v: lam * v, u, tol=1e-9, m_init=12, mmin=12, mmax=30)
+        assert st[0] == 1 and st[1] == 0 and st[2] in (5, 6) and st[4] == 0.0, st   # (5 or 6: see tests/test_solvers_cpu.py)
+        assert float((w[0] - ref).abs().max()) <= 1e-10 * float(ref.abs().max()), (device_pass, st)

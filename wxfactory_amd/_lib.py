@@ -85,6 +85,12 @@ SIGNATURES = {
     "wx_multi_axpy": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_size_t, c_void_p]),
     "wx_multi_axpy_scaled": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_size_t, c_double, c_void_p]),
     "wx_krylov_aug_update": (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_int, c_void_p, c_void_p, c_void_p]),
+    "wx_pmex_workspace": (c_size_t, [c_int]),
+    "wx_euler3d_batch_pmex_vector": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_size_t, c_int, c_double, c_double,
+                                             c_void_p, c_void_p, c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p,
+                                             c_void_p, c_int, c_size_t, c_void_p]),
+    "wx_pmex_vector": (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                               c_double, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "wx_kiops_finish_workspace": (c_size_t, [c_size_t]),
     "wx_kiops_finish": (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p]),

@@ -374,6 +374,147 @@ static void dispatch_pair(int rem, double* a, double* b, const double* V, size_t
     else if constexpr (R > 0) dispatch_pair<R - 1>(rem, a, b, V, ldv, row0, ha, hb, n, last, sa, cross, sb, st);
 }
 
+
+// ---- one Krylov vector of PMEX (solvers/pmex.py:157-233) with no host round trip: the augmented update, the (j+1) x 2
+// block of products (multi_dot2), the projector's coefficients and the norm estimate in a one-workgroup kernel, the
+// correction (normalised in the same pass when the estimate stands), the vector's own norm where it does not, the
+// Hessenberg column.  The host reads the columns of a whole pass afterwards, as it does for KIOPS.
+constexpr int kPmexMaxM = 128;
+
+// error-free transformations for the sum of squares the reference accumulates in the platform's extended precision
+__device__ __forceinline__ void two_sum(double a, double b, double& s, double& e) {
+    s = a + b;
+    const double bb = s - a;
+    e = (a - (s - bb)) + (b - bb);
+}
+
+// G: [<v_k, v_{j-1}>, k <= j] then [<v_k, w>, k <= j] (2 (j+1) doubles).  LT / Linv: ld x ld row-major, persistent over the
+// solve (LT strictly upper: column c = products of v_c with the older vectors; Linv = (I + LT^T)^{-1}, unit lower).
+// sol[0:j] = g - LT (Linv g);  hcol[0:j] = sol;  scal[0] = factor for the correction pass (1 / norm estimate, or 1),
+// scal[1] = the estimate (-1: the difference came out negative), scal[2] = 1 when the estimate stands.
+__global__ __launch_bounds__(256) void pmex_project_kernel(const double* __restrict__ G, int j, double* __restrict__ LT,
+                                                           double* __restrict__ Linv, int ld, double tol,
+                                                           double* __restrict__ sol, double* __restrict__ hcol,
+                                                           double* __restrict__ scal) {
+    __shared__ double g[kPmexMaxM], t[kPmexMaxM], c[kPmexMaxM];
+    const int tid = threadIdx.x;
+    const double* g0 = G;            // products with v_{j-1}
+    const double* g1 = G + (j + 1);  // products with the new vector
+    for (int k = tid; k < j; k += blockDim.x) g[k] = g1[k];
+    if (j > 1) {
+        for (int k = tid; k < j - 1; k += blockDim.x) {
+            c[k] = g0[k];
+            LT[(size_t)k * ld + (j - 1)] = g0[k];
+        }
+        __syncthreads();
+        // row j-1 of Linv: -c^T Linv[0:j-1, 0:j-1]  (Linv unit lower triangular: rows i >= k contribute to column k)
+        for (int k = tid; k < j - 1; k += blockDim.x) {
+            double a = 0.0;
+            for (int i = k; i < j - 1; ++i) a += c[i] * Linv[(size_t)i * ld + k];
+            Linv[(size_t)(j - 1) * ld + k] = -a;
+        }
+    }
+    __syncthreads();
+    for (int r = tid; r < j; r += blockDim.x) {
+        double a = 0.0;
+        for (int k = 0; k <= r; ++k) a += Linv[(size_t)r * ld + k] * g[k];
+        t[r] = a;
+    }
+    __syncthreads();
+    for (int r = tid; r < j; r += blockDim.x) {
+        double a = 0.0;
+        for (int cc = r + 1; cc < j; ++cc) a += LT[(size_t)r * ld + cc] * t[cc];
+        const double v = g[r] - a;
+        sol[r] = v;
+        hcol[r] = v;
+    }
+    if (tid == 0) {
+        double hi = 0.0, lo = 0.0;   // sum of g_k^2 in double-double
+        for (int k = 0; k < j; ++k) {
+            const double pk = g[k] * g[k];
+            const double ek = fma(g[k], g[k], -pk);
+            double sk, e2;
+            two_sum(hi, pk, sk, e2);
+            lo += ek + e2;
+            hi = sk;
+        }
+        double d, e;
+        two_sum(g1[j], -hi, d, e);
+        const double diff = d + (e - lo);   // <w, w> - sum g_k^2
+        const bool stands = !(diff < 0.0);
+        const double est = stands ? sqrt(diff) : -1.0;
+        scal[0] = (stands && est >= tol) ? 1.0 / est : 1.0;
+        scal[1] = est;
+        scal[2] = stands ? 1.0 : 0.0;
+    }
+}
+
+// w = (w - sum_k h[k] V[row0 + k]) * (*scale or 1);  when `part` is given, the squared norm of what was written, per workgroup
+template <int R>
+__global__ __launch_bounds__(256) void multi_axpy_dev_kernel(double* __restrict__ w, const double* __restrict__ V, size_t ldv,
+                                                             int row0, const double* __restrict__ h, size_t n,
+                                                             const double* __restrict__ scale, double* __restrict__ part) {
+    __shared__ double red[4];
+    double cf[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) cf[r] = h[row0 + r];
+    const double sc = scale ? *scale : 1.0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    double nn = 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double s = w[i];
+#pragma unroll
+        for (int r = 0; r < R; ++r) s -= cf[r] * V[(size_t)(row0 + r) * ldv + i];
+        s *= sc;
+        w[i] = s;
+        nn += s * s;
+    }
+    if (part) {
+        const double tsum = wg_sum256(nn, red);
+        if (threadIdx.x == 0) part[blockIdx.x] = tsum;
+    }
+}
+
+// hcol[j] = the vector's norm - the estimate, or the root of the summed partials where the estimate fell;  scal[3] = the
+// factor still to be applied (1 when the correction pass normalised the vector already or at a breakdown);  own[0] = 1 when
+// the vector's own norm was needed (pmex's `reg_comm_nrm`)
+__global__ __launch_bounds__(256) void pmex_finish_kernel(const double* __restrict__ part, int nblocks, double tol,
+                                                          double* __restrict__ scal, double* __restrict__ hnorm,
+                                                          double* __restrict__ own) {
+    __shared__ double red[4];
+    double v = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) v += part[b];
+    const double total = wg_sum256(v, red);
+    if (threadIdx.x == 0) {
+        const bool stands = scal[2] != 0.0;
+        const double nrm = stands ? scal[1] : sqrt(total);
+        *hnorm = nrm;
+        *own = stands ? 0.0 : 1.0;
+        scal[3] = (!stands && nrm >= tol) ? 1.0 / nrm : 1.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_if_kernel(double* __restrict__ w, size_t n, const double* __restrict__ factor) {
+    const double f = *factor;
+    if (f == 1.0) return;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) w[i] *= f;
+}
+
+template <int R>
+static void launch_axpy_dev(double* w, const double* V, size_t ldv, int row0, const double* h, size_t n, const double* scale,
+                            double* part, unsigned grid, hipStream_t st) {
+    hipLaunchKernelGGL((multi_axpy_dev_kernel<R>), dim3(grid), dim3(256), 0, st, w, V, ldv, row0, h, n, scale, part);
+}
+template <int R>
+static void dispatch_axpy_dev(int rem, double* w, const double* V, size_t ldv, int row0, const double* h, size_t n,
+                              const double* scale, double* part, unsigned grid, hipStream_t st) {
+    if (rem == R) launch_axpy_dev<R>(w, V, ldv, row0, h, n, scale, part, grid, st);
+    else if constexpr (R > 1) dispatch_axpy_dev<R - 1>(rem, w, V, ldv, row0, h, n, scale, part, grid, st);
+}
+
+constexpr unsigned kPmexAxpyBlocks = 2048;
+
 }  // namespace wx
 
 using namespace wx;
@@ -509,6 +650,70 @@ wx_status wx_krylov_aug_update(double* V, size_t ldv, int j, size_t n, int p, co
     hipLaunchKernelGGL(aug_update_kernel, dim3(grid), dim3(256), 0, st, V, ldv, j, n, p, aw, uflip);
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
+}
+
+
+// doubles of scratch for wx_pmex_vector with a basis of at most mmax vectors
+size_t wx_pmex_workspace(int mmax) {
+    const int m = mmax > 0 ? mmax : 1;
+    return (size_t)kDotBlocks * 2 * (m + 1) + 2 * (size_t)(m + 1) + (size_t)m + 8 + kPmexAxpyBlocks;
+}
+
+wx_status wx_pmex_vector(double* V, size_t ldv, int j, size_t n, int p, const double* aw, const double* uflip, double* LT,
+                         double* Linv, int ld, double tol, double* hcol, double* own, double* workspace, int mmax,
+                         wx_stream stream) {
+    if (!V || !aw || !uflip || !LT || !Linv || !hcol || !own || !workspace)
+        return fail(WX_ERR_INVALID, "wx_pmex_vector: null argument");
+    if (j < 1 || j > mmax || mmax > kPmexMaxM || ld < mmax || p < 1 || p > 16 || ldv < n + (size_t)p)
+        return fail(WX_ERR_INVALID, "wx_pmex_vector: j = %d, mmax = %d (<= %d), ld = %d, p = %d (1..16), row stride %zu, n = %zu",
+                    j, mmax, kPmexMaxM, ld, p, ldv, n);
+    WX_STREAM(st, stream);
+    double* dotw = workspace;
+    double* G = dotw + (size_t)kDotBlocks * 2 * (mmax + 1);
+    double* sol = G + 2 * (size_t)(mmax + 1);
+    double* scal = sol + mmax;
+    double* part = scal + 8;
+    const size_t len = n + (size_t)p;
+    double* vj = V + (size_t)j * ldv;
+    {
+        const size_t want = (n + 255) / 256;
+        const unsigned grid = (unsigned)(want < 8192 ? (want ? want : 1) : 8192);
+        hipLaunchKernelGGL(aug_update_kernel, dim3(grid), dim3(256), 0, st, V, ldv, j, n, p, aw, uflip);
+    }
+    const int m = j + 1;
+    for (int r = 0; r < m; r += kRowsPerPass2)
+        dispatch_dot2<kRowsPerPass2>(m - r < kRowsPerPass2 ? m - r : kRowsPerPass2, V, ldv, r, V + (size_t)(j - 1) * ldv, vj, len,
+                                     dotw, m, st);
+    hipLaunchKernelGGL(multi_dot_finish_kernel, dim3(2 * m), dim3(64), 0, st, dotw, kDotBlocks, 2 * m, G);
+    hipLaunchKernelGGL(pmex_project_kernel, dim3(1), dim3(256), 0, st, G, j, LT, Linv, ld, tol, sol, hcol, scal);
+    const size_t want = (len + 255) / 256;
+    const unsigned grid = (unsigned)(want < kPmexAxpyBlocks ? (want ? want : 1) : kPmexAxpyBlocks);
+    for (int r = 0; r < j; r += kRowsPerPass) {
+        const bool last = r + kRowsPerPass >= j;
+        dispatch_axpy_dev<kRowsPerPass>(j - r < kRowsPerPass ? j - r : kRowsPerPass, vj, V, ldv, r, sol, len,
+                                        last ? scal : nullptr, last ? part : nullptr, grid, st);
+    }
+    hipLaunchKernelGGL(pmex_finish_kernel, dim3(1), dim3(256), 0, st, part, (int)grid, tol, scal, hcol + j, own);
+    hipLaunchKernelGGL(scale_if_kernel, dim3(grid), dim3(256), 0, st, vj, len, scal + 3);
+    WX_HIP_TRY(hipGetLastError());
+    return WX_OK;
+}
+
+// wx_pmex_vector with the complex-step matvec in front (wx_euler3d_batch_extrap_pack + wx_euler3d_batch_jvp on the previous
+// vector), from ONE host call: for a rank that owns the whole sphere at launch-bound sizes, where the host side of separate
+// calls costs more than the kernels (the PMEX twin of wx_euler3d_batch_kiops_vector).
+wx_status wx_euler3d_batch_pmex_vector(const wx_euler3d_batch* b, const double* q, double* V, size_t ldv, int j, size_t n,
+                                       int p, double eps, double scale, const double* uflip, double* LT, double* Linv, int ld,
+                                       double tol, double* hcol, double* own, double* aw, double* workspace, int mmax,
+                                       size_t panel_stride, wx_stream stream) {
+    if (!b || !q || !V || !aw) return fail(WX_ERR_INVALID, "wx_euler3d_batch_pmex_vector: null argument");
+    if (j < 1) return fail(WX_ERR_INVALID, "wx_euler3d_batch_pmex_vector: j = %d", j);
+    const double* v = V + (size_t)(j - 1) * ldv;
+    wx_status s = wx_euler3d_batch_extrap_pack(b, q, v, eps, panel_stride, stream);
+    if (s != WX_OK) return s;
+    s = wx_euler3d_batch_jvp(b, q, v, eps, aw, scale, panel_stride, WX_REGION_ALL, stream);
+    if (s != WX_OK) return s;
+    return wx_pmex_vector(V, ldv, j, n, p, aw, uflip, LT, Linv, ld, tol, hcol, own, workspace, mmax, stream);
 }
 
 }  // extern "C"

@@ -93,6 +93,8 @@ class ComplexStepOperator:
         fn = getattr(rhs_handle, "kiops_vector_fn", None)
         if method == "complex" and fn is not None and getattr(rhs_handle, "fused_jvp", True) and Q.is_cuda:
             self.kiops_vector = fn(Q, EPS_COMPLEX, dt / EPS_COMPLEX)
+        # ... and the same for a vector of PMEX (wx_euler3d_batch_pmex_vector)
+        self.pmex_vector = getattr(self.kiops_vector, "pmex", None)
 
     def __call__(self, vec: torch.Tensor) -> torch.Tensor:
         return matvec_fun(vec, self.dt, self.Q, self.rhs, self.rhs_handle, self.method)

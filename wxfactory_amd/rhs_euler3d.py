@@ -288,6 +288,15 @@ class Euler3DBatch:
                                                      uflip.data_ptr(), hcol.data_ptr(), aw.data_ptr(), work.data_ptr(),
                                                      self.stride, st), "wx_euler3d_batch_kiops_vector")
 
+    def pmex_vector(self, q, V, j: int, n: int, p: int, eps: float, scale: float, uflip, LT, Linv, tol: float, hcol_ptr: int,
+                    own_ptr: int, aw, work, mmax: int):
+        """... and Krylov vector j of PMEX (wx_euler3d_batch_pmex_vector)."""
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.wx_euler3d_batch_pmex_vector(self._h, q.data_ptr(), V.data_ptr(), V.stride(0), j, n, p, eps, scale,
+                                                    uflip.data_ptr(), LT.data_ptr(), Linv.data_ptr(), LT.shape[1], tol,
+                                                    hcol_ptr, own_ptr, aw.data_ptr(), work.data_ptr(), mmax, self.stride, st),
+              "wx_euler3d_batch_pmex_vector")
+
     def close(self):
         if self._h:
             self.lib.wx_euler3d_batch_destroy(self._h)
@@ -493,6 +502,10 @@ class RhsEuler3D(PanelRhs):
         def build(V, j, n, p, iop, uflip, hcol, aw, work):
             bt.kiops_vector(Q, V, j, n, p, iop, eps, scale, uflip, hcol, aw, work)
 
+        def build_pmex(V, j, n, p, uflip, LT, Linv, tol, hcol_ptr, own_ptr, aw, work, mmax):
+            bt.pmex_vector(Q, V, j, n, p, eps, scale, uflip, LT, Linv, tol, hcol_ptr, own_ptr, aw, work, mmax)
+
+        build.pmex = build_pmex
         return build
 
     def _jvp_plans(self):

@@ -1025,6 +1025,21 @@ def pmex(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, delta: float 
         g = _allreduce(basis.dots2(j + 1, Vd[j - 1, :n], Vd[j, :n]), group).reshape(2, j + 1).t()
         return (g + Vd[: j + 1, n:] @ Vd[j - 1: j + 1, n:].t()).cpu().numpy()
 
+    # One GPU, vectors not split over ranks: a Krylov vector is built by ONE host call with no round trip
+    # (wx_pmex_vector: the projector and the norm estimate run in a one-workgroup kernel), the host reads the Hessenberg
+    # columns of a whole pass afterwards and sees a happy breakdown then - the vectors built past it are discarded -, as
+    # kiops does.  (Several ranks: the all-reduce of the block of products needs the host between the two halves.)
+    device_pass = (basis.gpu and not split and p <= 16 and mmax <= 128 and os.environ.get("WXHIP_PMEX_DEVICE", "1") != "0")
+    if device_pass:
+        lib = basis.lib
+        LT = torch.zeros((mmax, mmax), dtype=dtype, device=dev)
+        Linv = torch.eye(mmax, dtype=dtype, device=dev)
+        Ht = torch.zeros((mmax + 1, mmax + 1), dtype=dtype, device=dev)   # Ht[c] = column c of H: coefficients, then the norm
+        own = torch.zeros(mmax + 1, dtype=dtype, device=dev)
+        work = torch.empty(int(lib.wx_pmex_workspace(mmax)), dtype=dtype, device=dev)
+        fused_vector = getattr(A, "pmex_vector", None)   # ... and the matvec too, from the same host call
+        aw_buf = torch.empty(n, dtype=dtype, device=dev) if fused_vector is not None else None
+        ht_ptr, ht_row, own_ptr = Ht.data_ptr(), Ht.stride(0) * Ht.element_size(), own.data_ptr()
     l = 0
     j = 0
     beta = 1.0
@@ -1037,7 +1052,30 @@ def pmex(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, delta: float 
             Vd[0, n:] = torch.as_tensor(va0, dtype=dtype, device=dev)
             beta = math.sqrt(float(global_dotprod(Vd[0, :n], Vd[0, :n], group)) + float(va0 @ va0))
             Vd[0] /= beta
-        while j < m:
+        if device_pass and m > j:
+            j0, st = j, torch.cuda.current_stream(dev).cuda_stream
+            for jj in range(j0 + 1, m + 1):
+                hcol_ptr, flag_ptr = ht_ptr + (jj - 1) * ht_row, own_ptr + (jj - 1) * 8
+                if fused_vector is not None:
+                    fused_vector(Vd, jj, n, p, u_flip_t, LT, Linv, tol, hcol_ptr, flag_ptr, aw_buf, work, mmax)
+                    continue
+                aw = A(Vd[jj - 1, :n]).reshape(-1)
+                aw = aw if aw.is_contiguous() else aw.contiguous()
+                basis.check(lib.wx_pmex_vector(Vd.data_ptr(), Vd.stride(0), jj, n, p, aw.data_ptr(), u_flip_t.data_ptr(),
+                                               LT.data_ptr(), Linv.data_ptr(), mmax, tol, hcol_ptr, flag_ptr, work.data_ptr(),
+                                               mmax, st), "wx_pmex_vector")
+            Hh, oh = Ht[j0:m, : m + 1].cpu().numpy(), own[j0:m].cpu().numpy()   # the one synchronisation of the pass
+            j = m
+            for c in range(j0, m):
+                H[: c + 1, c] = Hh[c - j0, : c + 1]
+                own_norms += int(oh[c - j0])
+                if Hh[c - j0, c + 1] < tol:   # happy breakdown at vector c + 1: the rest of the pass is void
+                    happy = True
+                    j = c + 1
+                    break
+                H[c + 1, c] = Hh[c - j0, c + 1]
+                krystep += 1
+        while j < m and not happy:
             j += 1
             basis.aug_update(j, n, A(Vd[j - 1, :n]).reshape(-1), u_flip_t, shift)
             G = gram(j)
