@@ -554,9 +554,10 @@ def main():
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--whole-panels", action="store_true", help="one tile per panel even when 6 does not divide N")
     ap.add_argument("--tiles-per-side", type=int, default=0, help="force k (6 k^2 tiles); default: chosen from N")
-    ap.add_argument("--event-every", type=int, default=4,
+    ap.add_argument("--event-every", type=int, default=1,
                     help="record HIP events around the kernel launches of every K-th timed step (the live kernel timing of "
-                         "the roofline block)")
+                         "the roofline block; 1 = every launch, so that the rocprofv3 average of the same command covers the "
+                         "same launches in the same state - with K > 1 the unmarked launches overlap their tails)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary (shallow-water S7) measurement")
     ap.add_argument("--loopback", action="store_true",
                     help="rehearsal on one GPU: route every edge message through the RCCL collective (1-rank group) and split "
@@ -696,8 +697,9 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        # HIP events around every kernel launch of every `event_every`-th timed step (each pair costs the stream two marker
-        # packets between kernels that would otherwise follow each other directly: 24 pairs per evaluation are 1 % of it)
+        # HIP events around every kernel launch of every `event_every`-th timed step (default: every step).  An event pair
+        # is two marker packets between kernels that would otherwise follow each other directly and overlap their tails:
+        # 24 pairs per evaluation cost it 0.3-0.4 % (measured, profiles/r03_v12_event_sampling.txt)
         recording[0] = i % args.event_every == 0
         out = rhs(state)
     torch.cuda.synchronize()
