@@ -342,6 +342,38 @@ def rhs_benchmark_matrix(dev, seed):
     return rows
 
 
+def column_metric_extras(plans, mine, state, out_general, edge_doubles, dev, k, general_s, steps):
+    """The same whole-sphere R(Q) with the plans' opt-in column form of the metric (Euler3DPlan(column_metric="auto"):
+    on the benchmark's shallow atmosphere without topography every metric array is the same on all levels, to rounding; the
+    fused kernel then reads one (n x n) slab per column and field instead of V n of them).  NOT the headline: the
+    headline kernels take the metric arrays as the reference hands them over, whatever they hold."""
+    from wxfactory_amd.exchange import PanelExchange
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D
+
+    col = {}
+    for t in mine:
+        p = plans[t]
+        col[t] = Euler3DPlan(p.n, p.H, p.V, p.case_number, p.panel, p._ops, p._metric, on_panel_edge=p.on_panel_edge,
+                             column_metric="auto")
+    if not all(pl.column_metric for pl in col.values()):
+        return {"applies": False, "note": "the metric arrays differ between levels"}
+    rhs = RhsEuler3D(col, PanelExchange(edge_doubles, dev, rank=0, world_size=1, tiles_per_side=k))
+    for _ in range(3):
+        o = rhs(state)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        o = rhs(state)
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / steps
+    scale = out_general.abs().amax(dim=(0, 2, 3, 4, 5), keepdim=True)
+    diff = float(((o - out_general).abs() / scale).max())
+    return {"applies": True, "ms_per_eval": round(t * 1e3, 4), "dof_updates_per_s": state.numel() / t,
+            "speedup_over_headline": round(general_s / t, 3), "max_rel_difference_from_headline_result": diff,
+            "note": "opt-in plan form for column-invariant geometries (include/wxhip.h: wx_euler3d_plan_set_column_metric); "
+                    "region ALL launches only; the JVP / stage kernels and split launches read the full arrays"}
+
+
 def epi2_kiops_e7_extras(dev, seed, n=8, H=60, V=2, dt=0.5, steps=3):
     """BASELINE config 5 at the benchmark's resolution: EPI2 + KIOPS (complex-step JVP, tol 1e-7) on the whole sphere at
     n = 8, 60 x 60 elements per panel, V = 2 vertical elements (a Krylov basis of 64 vectors of the V = 8 sphere does not
@@ -807,6 +839,9 @@ def main():
             line["extra"] = extras(dev, args.seed)
             line["extra"]["euler_callers"] = caller_extras(rhs, qs)
             line["extra"]["euler_ini_sizes"] = ini_size_extras(dev, args.seed)
+            if args.metric == "true" and not args.loopback:
+                line["extra"]["euler_column_metric"] = column_metric_extras(plans, mine, state, out, edge_doubles, dev, k,
+                                                                            dt / args.steps, args.steps)
             del rhs, qs, plans, out
             torch.cuda.empty_cache()
             line["extra"]["euler_e7_v1"] = e7_v1_extras(dev, args.seed)

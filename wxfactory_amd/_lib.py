@@ -66,6 +66,8 @@ SIGNATURES = {
     "wx_euler3d_plan_destroy": (c_int, [c_void_p]),
     "wx_euler3d_edge_count": (c_size_t, [c_void_p]),
     "wx_euler3d_bytes_per_point": (c_double, [c_void_p]),
+    "wx_euler3d_plan_set_column_metric": (c_int, [c_void_p, c_void_p]),
+    "wx_euler3d_plan_has_column_metric": (c_int, [c_void_p]),
     "wx_euler3d_uses_matrix_cores": (c_int, [c_void_p, c_int]),
     "wx_euler3d_extrap_pack": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p]),
     "wx_euler3d_rhs": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_int, c_void_p]),

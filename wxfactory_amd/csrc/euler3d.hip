@@ -56,6 +56,10 @@ constexpr bool kSkelDirs = WX_K2_DIAG == 2 || WX_K2_DIAG == 4;
 
 // the streamed-once static fields go through non-temporal loads
 __device__ __forceinline__ double ldm(const double* p) { return __builtin_nontemporal_load(p); }
+// ... unless they are REUSED: the column slabs of a column-invariant metric are read by all n levels of an element (the
+// same CU) and by the V elements of the column (the same XCD): cached loads
+template <bool CACHED>
+__device__ __forceinline__ double ldm_if(const double* p) { return CACHED ? *p : __builtin_nontemporal_load(p); }
 
 template <int N>
 struct Cfg {
@@ -165,6 +169,24 @@ __device__ __forceinline__ Elem decode_elem(int slot, int count, int region, int
     r.e = (r.ek * H + r.ej) * H + r.ei;
     return r;
 }
+
+// COLUMN form (float64 plans with a column-invariant metric, region ALL): the V elements of a column follow each other,
+// so that the column's metric - one (n x n) slab per field instead of V n of them - is fetched once and found in cache
+// by the rest of the column
+__device__ __forceinline__ Elem decode_elem_col(int slot, int count, int H, int V) {
+    Elem r;
+    r.valid = slot < count;
+    if (!r.valid) slot = 0;
+    const int c = slot / V;
+    r.ek = slot % V;
+    r.ei = c % H;
+    r.ej = c / H;
+    r.e = (r.ek * H + r.ej) * H + r.ei;
+    return r;
+}
+// (workgroups go to the eight XCDs round-robin: give each XCD a contiguous eighth of the launch, so that a column stays in
+// one L2; the launch has a multiple of eight workgroups, the surplus finds no element)
+__device__ __forceinline__ int xcd_slab_block(int b, int nblocks8) { return (b & 7) * nblocks8 + (b >> 3); }
 
 template <typename T>
 __device__ __forceinline__ T load_q(const EulerParams<T>& P, size_t i) {
@@ -552,7 +574,7 @@ struct FaceIn {
 // The loads of one face point of one element: own slot of the interface buffer; the neighbour element's slot,
 // the received halo on a lateral tile edge, or the own state again (mirrored later) at ground / top; the
 // interface metric.  Separate from the arithmetic so that a kernel can issue them early.
-template <int N, typename T>
+template <int N, typename T, bool COLM = false>
 __device__ __forceinline__ void face_load(const EulerParams<T>& P, const Elem& el, int f, int fp, FaceIn<T>& in) {
     constexpr int N2 = N * N;
     const int H = P.H, V = P.V;
@@ -569,24 +591,29 @@ __device__ __forceinline__ void face_load(const EulerParams<T>& P, const Elem& e
         const int ne = el.ei + (plus ? 1 : -1);
         if (ne >= 0 && ne < H) nbr = P.itf + ((size_t)(el.e + (plus ? 1 : -1)) * 6 + (f ^ 1)) * NQ * N2 + fp;
         else { nbr = (plus ? P.halo_e : P.halo_w) + ((size_t)el.ek * H + el.ej) * N2 + fp; nstride = vsh; from_halo = true; }
-        const size_t o = (((size_t)el.ek * H + el.ej) * (H + 2) + el.ei + 1) * 2 * N2 + plus * N2 + fp;
-        hfs = (size_t)V * H * (H + 2) * 2 * N2;
+        // (column form: the interface metric of a lateral face does not depend on the level - one row of n values per
+        // face side instead of V n of them; that of a horizontal face neither on the level nor on the side)
+        const size_t o = COLM ? (((size_t)el.ej * (H + 2) + el.ei + 1) * 2 + plus) * N + fp % N
+                              : (((size_t)el.ek * H + el.ej) * (H + 2) + el.ei + 1) * 2 * N2 + plus * N2 + fp;
+        hfs = COLM ? (size_t)H * (H + 2) * 2 * N : (size_t)V * H * (H + 2) * 2 * N2;
         sgp = P.sgi + o;
         hp = P.hi + 0 * 3 * hfs + o;
     } else if (d == 1) {
         const int ne = el.ej + (plus ? 1 : -1);
         if (ne >= 0 && ne < H) nbr = P.itf + ((size_t)(el.e + (plus ? H : -H)) * 6 + (f ^ 1)) * NQ * N2 + fp;
         else { nbr = (plus ? P.halo_n : P.halo_s) + ((size_t)el.ek * H + el.ei) * N2 + fp; nstride = vsh; from_halo = true; }
-        const size_t o = (((size_t)el.ek * (H + 2) + el.ej + 1) * H + el.ei) * 2 * N2 + plus * N2 + fp;
-        hfs = (size_t)V * (H + 2) * H * 2 * N2;
+        const size_t o = COLM ? ((((size_t)el.ej + 1) * H + el.ei) * 2 + plus) * N + fp % N
+                              : (((size_t)el.ek * (H + 2) + el.ej + 1) * H + el.ei) * 2 * N2 + plus * N2 + fp;
+        hfs = COLM ? (size_t)(H + 2) * H * 2 * N : (size_t)V * (H + 2) * H * 2 * N2;
         sgp = P.sgj + o;
         hp = P.hj + 1 * 3 * hfs + o;
     } else {
         const int ne = el.ek + (plus ? 1 : -1);
         if (ne >= 0 && ne < V) nbr = P.itf + ((size_t)(el.e + (plus ? H * H : -H * H)) * 6 + (f ^ 1)) * NQ * N2 + fp;
         else { nbr = own; mirror = true; }
-        const size_t o = ((((size_t)el.ek + 1) * H + el.ej) * H + el.ei) * 2 * N2 + plus * N2 + fp;
-        hfs = (size_t)(V + 2) * H * H * 2 * N2;
+        const size_t o = COLM ? ((size_t)el.ej * H + el.ei) * N2 + fp
+                              : ((((size_t)el.ek + 1) * H + el.ej) * H + el.ei) * 2 * N2 + plus * N2 + fp;
+        hfs = COLM ? (size_t)H * H * N2 : (size_t)(V + 2) * H * H * 2 * N2;
         sgp = P.sgk + o;
         hp = P.hk + 2 * 3 * hfs + o;
     }
@@ -671,10 +698,10 @@ __device__ __forceinline__ void face_flux(const FaceIn<T>& in, int f, bool advec
 }
 
 // One face point of one element, loads + arithmetic.  Shared by the fused RHS kernel and the JVP kernel.
-template <int N, typename T, bool OWN_FORM = false>
+template <int N, typename T, bool OWN_FORM = false, bool COLM = false>
 __device__ __forceinline__ void face_problem(const EulerParams<T>& P, const Elem& el, int f, int fp, T* out) {
     FaceIn<T> in;
-    face_load<N, T>(P, el, f, fp, in);
+    face_load<N, T, COLM>(P, el, f, fp, in);
     face_flux<T, OWN_FORM>(in, f, P.advection_only, out);
 }
 
@@ -691,32 +718,39 @@ struct PointIn {
     double sg, h00, h01, h02, h11, h12, h22;
 };
 
-template <typename T>
-__device__ __forceinline__ void k2_point_loads(const EulerParams<T>& P, bool active, size_t o, size_t fs, PointIn<T>& S) {
+// (om, fsm: offset and field stride of the point in the metric arrays - those of the state, or of the column slabs)
+template <typename T, bool CACHED = false>
+__device__ __forceinline__ void k2_point_loads(const EulerParams<T>& P, bool active, size_t o, size_t fs, PointIn<T>& S,
+                                               size_t om, size_t fsm) {
     S.q0 = T(1.0); S.q1 = T(0.0); S.q2 = T(0.0); S.q3 = T(0.0); S.q4 = T(1.0);
     S.sg = 1.0; S.h00 = S.h01 = S.h02 = S.h11 = S.h12 = S.h22 = 0.0;
     if (active) {
         load_state<T>(P, o, fs, S.q0, S.q1, S.q2, S.q3, S.q4);
-        S.sg = ldm(P.sg + o);
-        S.h00 = ldm(P.h + 0 * fs + o); S.h01 = ldm(P.h + 1 * fs + o); S.h02 = ldm(P.h + 2 * fs + o);
-        S.h11 = ldm(P.h + 4 * fs + o); S.h12 = ldm(P.h + 5 * fs + o); S.h22 = ldm(P.h + 8 * fs + o);
+        S.sg = ldm_if<CACHED>(P.sg + om);
+        S.h00 = ldm_if<CACHED>(P.h + 0 * fsm + om); S.h01 = ldm_if<CACHED>(P.h + 1 * fsm + om);
+        S.h02 = ldm_if<CACHED>(P.h + 2 * fsm + om); S.h11 = ldm_if<CACHED>(P.h + 4 * fsm + om);
+        S.h12 = ldm_if<CACHED>(P.h + 5 * fsm + om); S.h22 = ldm_if<CACHED>(P.h + 8 * fsm + om);
     }
+}
+template <typename T>
+__device__ __forceinline__ void k2_point_loads(const EulerParams<T>& P, bool active, size_t o, size_t fs, PointIn<T>& S) {
+    k2_point_loads<T, false>(P, active, o, fs, S, o, fs);
 }
 
 // forcing of the three momentum rows, all but the gravity filter (pde_euler_cubesphere.py:12-25, 203-290), from the 27
 // (18 on a non-rotating planet) Christoffel fields, all loads in flight together; gcoef = inv_dzdeta * g
-template <typename T>
+template <typename T, bool CACHED = false>
 __device__ __forceinline__ void k2_forcing(const EulerParams<T>& P, bool active, size_t o, size_t fs, const PointIn<T>& S, T u1,
-                                           T u2, T u3, T p, T& fc0, T& fc1, T& fc2, double& gcoef) {
+                                           T u2, T u3, T p, T& fc0, T& fc1, T& fc2, double& gcoef, size_t om, size_t fsm) {
     double cg[27], idzv = 0.0;
     if (active && P.rot_zero) {   // non-rotating planet: the 9 rotation symbols are identically zero
 #pragma unroll
-        for (int i = 0; i < 27; ++i) cg[i] = (i % 9) < 3 ? 0.0 : ldm(P.chr + (size_t)i * fs + o);
-        idzv = ldm(P.idz + o);
+        for (int i = 0; i < 27; ++i) cg[i] = (i % 9) < 3 ? 0.0 : ldm_if<CACHED>(P.chr + (size_t)i * fsm + om);
+        idzv = ldm_if<CACHED>(P.idz + om);
     } else if (active) {
 #pragma unroll
-        for (int i = 0; i < 27; ++i) cg[i] = ldm(P.chr + (size_t)i * fs + o);
-        idzv = ldm(P.idz + o);
+        for (int i = 0; i < 27; ++i) cg[i] = ldm_if<CACHED>(P.chr + (size_t)i * fsm + om);
+        idzv = ldm_if<CACHED>(P.idz + om);
     } else {
 #pragma unroll
         for (int i = 0; i < 27; ++i) cg[i] = 0.0;
@@ -746,10 +780,17 @@ __device__ __forceinline__ void k2_forcing(const EulerParams<T>& P, bool active,
         gcoef = idzv * kGravity;
     }
 }
+template <typename T>
+__device__ __forceinline__ void k2_forcing(const EulerParams<T>& P, bool active, size_t o, size_t fs, const PointIn<T>& S, T u1,
+                                           T u2, T u3, T p, T& fc0, T& fc1, T& fc2, double& gcoef) {
+    k2_forcing<T, false>(P, active, o, fs, S, u1, u2, u3, p, fc0, fc1, fc2, gcoef, o, fs);
+}
 
-template <int N, typename T, bool PIPE>
+template <int N, typename T, bool PIPE, bool COLM = false>
 __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
     using C = Cfg<N>;
+    static_assert(!COLM || (std::is_same<T, double>::value && !PIPE), "the column form: float64, plain kernel");
+    const int bx = COLM ? xcd_slab_block(blockIdx.x, gridDim.x >> 3) : (int)blockIdx.x;
     constexpr int N2 = C::N2, N3 = C::N3, EPB = C::EPB, BS = C::BS;
     constexpr int NF = 8;   // staged fields: 4 F rows, A, B (per direction) + log p + sqrtG*rho
     constexpr int NC = 7;   // face quantities, see rusanov_face
@@ -796,7 +837,7 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
     }
 
     const int le = tid / N3, pt = tid % N3;
-    const Elem el = decode_elem(blockIdx.x * EPB + le, P.count, P.region, H, V);
+    const Elem el = COLM ? decode_elem_col(bx * EPB + le, P.count, H, V) : decode_elem(bx * EPB + le, P.count, P.region, H, V);
     const bool active = (le < EPB) && el.valid;
     const int kl = pt / N2, jl = (pt / N) % N, il = pt % N;
     const int lb = (le < EPB ? le : 0) * C::LE;  // LDS base of this thread's element
@@ -813,10 +854,13 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
     int ff_first = 0;
     if constexpr (FACE_FIRST) {
         ff_first = __builtin_amdgcn_readfirstlane(tid / N2);
-        if (tid < 6 * N2 && el.valid) face_load<N, T>(P, el, ff_first, tid % N2, fin_first);
+        if (tid < 6 * N2 && el.valid) face_load<N, T, COLM>(P, el, ff_first, tid % N2, fin_first);
     }
     PointIn<T> S;
-    k2_point_loads<T>(P, active, o, fs, S);   // in flight while the face stage computes
+    // metric offsets: the point's own, or - column form - its place in the column's (n x n) slab
+    const size_t om = COLM ? ((size_t)el.ej * H + el.ei) * N2 + pt % N2 : o;
+    const size_t fsm = COLM ? (size_t)H * H * N2 : fs;
+    k2_point_loads<T, COLM>(P, active, o, fs, S, om, fsm);   // in flight while the face stage computes
     const T q0 = S.q0, q1 = S.q1, q2 = S.q2, q3 = S.q3, q4 = S.q4;
     const double sg = S.sg;
 
@@ -835,10 +879,10 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
         int f = r / N2;
         const int fp = r % N2;
         if (N2 % 64 == 0 && BS % 64 == 0) f = __builtin_amdgcn_readfirstlane(f);
-        const Elem fel = decode_elem(blockIdx.x * EPB + fle, P.count, P.region, H, V);
+        const Elem fel = COLM ? decode_elem_col(bx * EPB + fle, P.count, H, V) : decode_elem(bx * EPB + fle, P.count, P.region, H, V);
         if (!fel.valid) continue;
         T out[NC];
-        face_problem<N, T>(P, fel, f, fp, out);
+        face_problem<N, T, false, COLM>(P, fel, f, fp, out);
 #pragma unroll
         for (int c = 0; c < NC; ++c) WX_FR(fle, f, c, fp) = out[c];
     }
@@ -858,7 +902,7 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
     // ---- forcing
     T fc0, fc1, fc2;
     double gcoef;
-    k2_forcing<T>(P, active, o, fs, S, u1, u2, u3, p, fc0, fc1, fc2, gcoef);
+    k2_forcing<T, COLM>(P, active, o, fs, S, u1, u2, u3, p, fc0, fc1, fc2, gcoef, om, fsm);
     WX_STAMP(2);
 
     // accumulators of sum_d dF^d; the forcing is folded in as sqrtG*f so that the final
@@ -1419,6 +1463,34 @@ static wx_status launch_extrap(const EulerParams<T>& P, hipStream_t st) {
     return WX_OK;
 }
 
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::BS, kK2Waves) void euler_rhs_column_kernel(const EulerParams<double> P) {
+    euler_rhs_body<N, double, false, true>(P);
+}
+
+template <int N>
+static wx_status launch_rhs_column(const EulerParams<double>& P, hipStream_t st) {
+    using C = Cfg<N>;
+    if (P.count == 0) return WX_OK;
+    const int grid = (P.count + C::EPB - 1) / C::EPB;
+    hipLaunchKernelGGL((euler_rhs_column_kernel<N>), dim3(8 * ((grid + 7) / 8)), dim3(C::BS), 0, st, P);
+    WX_HIP_TRY(hipGetLastError());
+    return WX_OK;
+}
+
+static wx_status dispatch_rhs_column(int n, const EulerParams<double>& P, hipStream_t st) {
+    switch (n) {
+        case 2: return launch_rhs_column<2>(P, st);
+        case 3: return launch_rhs_column<3>(P, st);
+        case 4: return launch_rhs_column<4>(P, st);
+        case 5: return launch_rhs_column<5>(P, st);
+        case 6: return launch_rhs_column<6>(P, st);
+        case 7: return launch_rhs_column<7>(P, st);
+        case 8: return launch_rhs_column<8>(P, st);
+    }
+    return fail(WX_ERR_UNSUPPORTED, "num_solpts %d not in 2..8", n);
+}
+
 template <int N, typename T>
 static wx_status launch_rhs(const EulerParams<T>& P, hipStream_t st) {
     using C = Cfg<N>;
@@ -1488,6 +1560,10 @@ struct wx_euler3d_plan {
     unsigned long long* stamps = nullptr;  // device, diagnostic builds only
     double* face_val = nullptr;   // prepared JVP: face values of the linearisation state, [elem][6][5][n^2] doubles
     EulerParams<double> base;  // pointer-free parts + metric pointers (q/rhs/halo/send filled per call)
+    // column form (wx_euler3d_plan_set_column_metric): the metric of a column-invariant geometry as (n x n) slabs
+    bool column = false;
+    const double *c_sg = nullptr, *c_h = nullptr, *c_chr = nullptr, *c_idz = nullptr, *c_sgi = nullptr, *c_sgj = nullptr,
+                 *c_sgk = nullptr, *c_hi = nullptr, *c_hj = nullptr, *c_hk = nullptr;
 };
 
 namespace {
@@ -1580,6 +1656,14 @@ wx_status run_rhs(wx_euler3d_plan* pl, const void* q, const void* const halo[4],
     if (halo) {
         P.halo_s = static_cast<const T*>(halo[0]); P.halo_n = static_cast<const T*>(halo[1]);
         P.halo_w = static_cast<const T*>(halo[2]); P.halo_e = static_cast<const T*>(halo[3]);
+    }
+    if constexpr (std::is_same<T, double>::value) {
+        // column form: whole-tile launches of the plain kernel on a plan that holds the column slabs
+        if (pl->column && region == WX_REGION_ALL && !epilogue && itf_in == 0 && P.q_tan == nullptr) {
+            P.sg = pl->c_sg; P.h = pl->c_h; P.chr = pl->c_chr; P.idz = pl->c_idz;
+            P.sgi = pl->c_sgi; P.sgj = pl->c_sgj; P.sgk = pl->c_sgk; P.hi = pl->c_hi; P.hj = pl->c_hj; P.hk = pl->c_hk;
+            return dispatch_rhs_column(pl->n, P, st);
+        }
     }
     return dispatch_rhs<T>(pl->n, P, st);
 }
@@ -1708,6 +1792,22 @@ wx_status wx_euler3d_debug_set_stamps(wx_euler3d_plan* pl, void* dev_buffer) {
     pl->stamps = static_cast<unsigned long long*>(dev_buffer);
     return WX_OK;
 }
+
+wx_status wx_euler3d_plan_set_column_metric(wx_euler3d_plan* pl, const wx_euler3d_metric* cm) {
+    if (!pl) return fail(WX_ERR_INVALID, "wx_euler3d_plan_set_column_metric: null plan");
+    if (!cm) { pl->column = false; return WX_OK; }
+    if (pl->dtype != WX_F64) return fail(WX_ERR_INVALID, "wx_euler3d_plan_set_column_metric: the plan must be WX_F64");
+    if (!cm->sqrtG || !cm->h_contra || !cm->christoffel || !cm->inv_dzdeta || !cm->sqrtG_itf_i || !cm->sqrtG_itf_j ||
+        !cm->sqrtG_itf_k || !cm->h_contra_itf_i || !cm->h_contra_itf_j || !cm->h_contra_itf_k)
+        return fail(WX_ERR_INVALID, "wx_euler3d_plan_set_column_metric: the column metric has a null member");
+    pl->c_sg = cm->sqrtG; pl->c_h = cm->h_contra; pl->c_chr = cm->christoffel; pl->c_idz = cm->inv_dzdeta;
+    pl->c_sgi = cm->sqrtG_itf_i; pl->c_sgj = cm->sqrtG_itf_j; pl->c_sgk = cm->sqrtG_itf_k;
+    pl->c_hi = cm->h_contra_itf_i; pl->c_hj = cm->h_contra_itf_j; pl->c_hk = cm->h_contra_itf_k;
+    pl->column = true;
+    return WX_OK;
+}
+
+int wx_euler3d_plan_has_column_metric(const wx_euler3d_plan* pl) { return pl && pl->column ? 1 : 0; }
 
 double wx_euler3d_bytes_per_point(const wx_euler3d_plan* pl) {
     if (!pl) return 0.0;

@@ -27,13 +27,63 @@ def _dptr(a):
     return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
 
 
+def column_metric_slabs(metric: Dict[str, torch.Tensor], n: int, H: int, V: int, rtol: float = 1e-9):
+    """The metric arrays of a column-invariant geometry as one slab per column: {field: tensor}, or None when some array
+    differs between levels by more than rtol x its largest entry.  (A real difference - topography, a deep atmosphere -
+    is of order one.  What the reference's arrays show on a shallow atmosphere without topography is rounding: 1e-14 of
+    the components that do not vanish, and the whole value - 1e-12 absolute at the benchmark's resolution, 2e-10 of the
+    array's largest entry - of the Christoffel symbols that vanish analytically and hold second-difference noise.)
+    Shapes: point fields (.., V, H, H, n^3) -> (.., H, H, n^2), taken at the lowest level of the lowest element;
+    lateral interface fields (.., V, H[+2], H[+2], 2 n^2) -> (.., H[+2], H[+2], 2, n): the n values along the face's
+    horizontal direction; horizontal interface fields (.., V + 2, H, H, 2 n^2) -> (.., H, H, n^2): the faces between the
+    elements of a column (the two padding layers are not part of the comparison: no kernel reads them)."""
+    n2 = n * n
+    out = {}
+
+    def same(full, slab_b):
+        scale = float(full.abs().max())
+        return scale == 0.0 or float((full - slab_b).abs().max()) <= rtol * scale
+
+    for k in ("sqrtG", "h_contra", "christoffel", "inv_dzdeta"):
+        t = metric[k]
+        lead = t.shape[:-4]
+        v = t.reshape(*lead, V, H, H, n, n2)
+        slab = v[..., 0, :, :, 0, :]                       # (.., H, H, n2)
+        if not same(v, slab[..., None, :, :, None, :]):
+            return None
+        out[k] = slab.contiguous()
+    for k, hh in (("sqrtG_itf_i", (H, H + 2)), ("h_contra_itf_i", (H, H + 2)), ("sqrtG_itf_j", (H + 2, H)),
+                  ("h_contra_itf_j", (H + 2, H))):
+        t = metric[k]
+        lead = t.shape[:-4]
+        v = t.reshape(*lead, V, hh[0], hh[1], 2, n, n)     # (.., level, row, col, side, a = vertical index, b)
+        slab = v[..., 0, :, :, :, 0, :]                    # (.., row, col, side, b)
+        if not same(v, slab[..., None, :, :, :, None, :]):
+            return None
+        out[k] = slab.contiguous()
+    for k in ("sqrtG_itf_k", "h_contra_itf_k"):
+        t = metric[k]
+        lead = t.shape[:-4]
+        v = t.reshape(*lead, V + 2, H, H, 2, n2)[..., 1: V + 1, :, :, :, :]
+        slab = v[..., 0, :, :, 0, :]                       # (.., H, H, n2)
+        if not same(v, slab[..., None, :, :, None, :]):
+            return None
+        out[k] = slab.contiguous()
+    return out
+
+
 class Euler3DPlan:
     """One tile (= one cube panel).  Owns the native plan; borrows the metric tensors
     (kept alive here) exactly as the reference's pde module borrows NumPy/CuPy buffers."""
 
     def __init__(self, n: int, H: int, V: int, case_number: int, panel: int, ops: Dict[str, numpy.ndarray],
                  metric: Dict[str, torch.Tensor], dtype: torch.dtype = torch.float64, dual: bool = False,
-                 on_panel_edge=(True, True, True, True)):
+                 on_panel_edge=(True, True, True, True), column_metric=False):
+        """`column_metric` (float64 plans): False; True - the metric is column-invariant (a shallow atmosphere without
+        topography: every metric array takes the same values on all levels, which is what the reference's arrays hold
+        to rounding for config/dcmip31.ini and its own RHS benchmark), checked here, ValueError otherwise; or "auto" -
+        taken when the check passes.  Whole-tile launches then read the metric as one (n x n) slab per column and field
+        (`column_metric_slabs`) instead of V n of them."""
         self.lib = _lib.load()
         self.faces_epoch = 0  # bumped by every call that rewrites an interface buffer (pipeline validity)
         if dtype not in _DTYPES:
@@ -80,13 +130,27 @@ class Euler3DPlan:
             check(self.lib.wx_euler3d_plan_create_tile(ctypes.byref(self._h), n, H, V, case_number, wx_dtype, panel, flags,
                                                        ctypes.byref(o), ctypes.byref(m)), "wx_euler3d_plan_create_tile")
         self.edge_count = int(self.lib.wx_euler3d_edge_count(self._h))
+        self.column_metric = False
+        if column_metric and dtype == torch.float64:
+            slabs = column_metric_slabs(metric, n, H, V)
+            if slabs is None and column_metric is True:
+                raise ValueError("column_metric=True, but the metric arrays are not the same on all levels")
+            if slabs is not None:
+                cm = Euler3DMetric()
+                for k in _lib.EULER3D_METRIC_FIELDS:
+                    setattr(cm, k, slabs[k].data_ptr() if k in slabs else None)
+                self._keep.append(slabs)
+                check(self.lib.wx_euler3d_plan_set_column_metric(self._h, ctypes.byref(cm)),
+                      "wx_euler3d_plan_set_column_metric")
+                self.column_metric = True
 
     axpy_two = True  # rhs_axpy takes a second array (z, d)
 
     def twin(self, dtype, dual: bool = False):
         """Plan of another dtype over the same (borrowed) metric tensors."""
         return Euler3DPlan(self.n, self.H, self.V, self.case_number, self.panel, self._ops, self._metric, dtype=dtype,
-                           dual=dual, on_panel_edge=self.on_panel_edge)
+                           dual=dual, on_panel_edge=self.on_panel_edge,
+                           column_metric="auto" if (self.column_metric and dtype == torch.float64) else False)
 
     def _check_q(self, q):
         if q.dtype != self.dtype or q.numel() != 5 * self.V * self.H * self.H * self.n**3 or not q.is_contiguous() \
