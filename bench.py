@@ -368,8 +368,23 @@ def column_metric_extras(plans, mine, state, out_general, edge_doubles, dev, k, 
     t = (time.perf_counter() - t0) / steps
     scale = out_general.abs().amax(dim=(0, 2, 3, 4, 5), keepdim=True)
     diff = float(((o - out_general).abs() / scale).max())
+    # ... and the prepared complex-step matvec on the same plans (their dual twins take the slabs too)
+    from wxfactory_amd.matvec import ComplexStepOperator
+
+    op = ComplexStepOperator(1.0, state, o, rhs)
+    v = (torch.rand(state.shape, device=dev, dtype=state.dtype) - 0.5).flatten()
+    for _ in range(3):
+        op(v)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        op(v)
+    torch.cuda.synchronize()
+    tm = (time.perf_counter() - t0) / 10
+    rhs.jvp_release()
     return {"applies": True, "ms_per_eval": round(t * 1e3, 4), "dof_updates_per_s": state.numel() / t,
             "speedup_over_headline": round(general_s / t, 3), "max_rel_difference_from_headline_result": diff,
+            "matvec_fun_complex_prepared_ms": round(tm * 1e3, 3),
             "note": "opt-in plan form for column-invariant geometries (include/wxhip.h: wx_euler3d_plan_set_column_metric); "
                     "region ALL launches only; the JVP / stage kernels and split launches read the full arrays"}
 

@@ -69,3 +69,34 @@ def test_column_metric_is_refused_over_a_mountain(built_lib):
     with pytest.raises(ValueError, match="not the same on all levels"):
         Euler3DPlan(g.n, g.H, g.V, g.case, p, g.ops, m, column_metric=True)
     assert not Euler3DPlan(g.n, g.H, g.V, g.case, p, g.ops, m, column_metric="auto").column_metric
+
+
+@pytest.mark.parametrize("name", ["euler3d_c31p_n8_h2_v2", "euler3d_c31p_n3_h4_v2"])
+def test_column_metric_jvp_matches_general_kernel_and_reference(built_lib, name):
+    """The complex-step JVP kernels (wx_euler3d_jvp, and the prepared form) on a dual plan with the column slabs: against the
+    same kernels on the full arrays and against Im R(Q + i eps V) of the reference."""
+    from tests.gpu_util import device_metric, to_dev
+    from wxfactory_amd import _lib
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan
+
+    g = golden(name)
+    for p in g.metric_panels():
+        m = device_metric(g, p, DEV)
+        q, v = to_dev(g[f"p{p}/Q"]), to_dev(g[f"p{p}/V"])
+        halo = [to_dev(h) for h in g.halo(p, True)]
+        res = []
+        for col in (False, True):
+            plan = Euler3DPlan(g.n, g.H, g.V, g.case, p, g.ops, m, dtype=torch.complex128, dual=True, column_metric=col)
+            assert plan.column_metric == col
+            send = torch.zeros((4, plan.edge_count), dtype=torch.complex128, device=DEV)
+            plan.jvp_extrap_pack(q, v, g.eps, list(send))
+            out = torch.full_like(q, float("nan"))
+            plan.jvp(q, v, g.eps, halo, out, 1.0, _lib.WX_REGION_ALL)
+            torch.cuda.synchronize()
+            res.append(out.cpu().numpy())
+        ref = g.r(p, True).imag
+        scale = var_max(ref)
+        d = np.abs(res[1] - res[0]).max(axis=(1, 2, 3, 4))
+        assert (d <= 1e-11 * scale).all(), (p, d / scale)
+        err = np.abs(res[1] - ref).max(axis=(1, 2, 3, 4))
+        assert (err <= 1e-9 * scale).all(), (p, err / scale)

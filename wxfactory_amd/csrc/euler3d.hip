@@ -1141,17 +1141,18 @@ __global__ __launch_bounds__(Cfg<N>::BS, (k2_waves<N, T>())) void euler_rhs_batc
 // ------------------------------------------------------------------------------------------------
 // tangent of the forcing of the three momentum rows, times sqrtG (.f1, .f2, .fw), and gcoef = inv_dzdeta * g
 struct JvpForcing { double f1, f2, fw, gcoef; };
+template <bool CACHED>
 __device__ __forceinline__ JvpForcing jvp_forcing(const EulerParams<dual>& P, size_t o, size_t fs, double sg, double h00,
                                                   double h01, double h02, double h11, double h12, double h22, dual q0,
-                                                  dual u1, dual u2, dual u3, dual p) {
+                                                  dual u1, dual u2, dual u3, dual p, size_t om, size_t fsm) {
     JvpForcing r{0.0, 0.0, 0.0, 0.0};
 #pragma unroll 1
     for (int i = 0; i < 3; ++i) {
-        const double* c = P.chr + (size_t)(i * 9) * fs + o;
+        const double* c = P.chr + (size_t)(i * 9) * fsm + om;
         double c01 = 0.0, c02 = 0.0, c03 = 0.0;
-        if (!P.rot_zero) { c01 = ldm(c); c02 = ldm(c + fs); c03 = ldm(c + 2 * fs); }
-        const double c11 = ldm(c + 3 * fs), c12 = ldm(c + 4 * fs), c13 = ldm(c + 5 * fs),
-                     c22 = ldm(c + 6 * fs), c23 = ldm(c + 7 * fs), c33 = ldm(c + 8 * fs);
+        if (!P.rot_zero) { c01 = ldm_if<CACHED>(c); c02 = ldm_if<CACHED>(c + fsm); c03 = ldm_if<CACHED>(c + 2 * fsm); }
+        const double c11 = ldm_if<CACHED>(c + 3 * fsm), c12 = ldm_if<CACHED>(c + 4 * fsm), c13 = ldm_if<CACHED>(c + 5 * fsm),
+                     c22 = ldm_if<CACHED>(c + 6 * fsm), c23 = ldm_if<CACHED>(c + 7 * fsm), c33 = ldm_if<CACHED>(c + 8 * fsm);
         dual f = 2.0 * q0 * (c01 * u1 + c02 * u2 + c03 * u3) + c11 * (q0 * u1 * u1 + h00 * p) +
                  2.0 * c12 * (q0 * u1 * u2 + h01 * p) + 2.0 * c13 * (q0 * u1 * u3 + h02 * p) +
                  c22 * (q0 * u2 * u2 + h11 * p) + 2.0 * c23 * (q0 * u2 * u3 + h12 * p) +
@@ -1161,14 +1162,15 @@ __device__ __forceinline__ JvpForcing jvp_forcing(const EulerParams<dual>& P, si
         else if (i == 1) r.f2 = sg * f.im;
         else r.fw = sg * f.im;
     }
-    r.gcoef = ldm(P.idz + o) * kGravity;
+    r.gcoef = ldm_if<CACHED>(P.idz + om) * kGravity;
     return r;
 }
 
-template <int N>
+template <int N, bool COLM = false>
 __device__ __forceinline__ void euler_jvp_body(const EulerParams<dual>& P) {
     using C = Cfg<N>;
     using T = dual;
+    const int bx = COLM ? xcd_slab_block(blockIdx.x, gridDim.x >> 3) : (int)blockIdx.x;
     constexpr int N2 = C::N2, N3 = C::N3, EPB = C::EPB, BS = C::BS;
     __shared__ double ft[6][EPB * C::LE];     // tangents: F rows rho, rho u1, rho u2, rho theta; A; sqrtG*rho
     __shared__ double fx[3][EPB * C::LE];     // B = sqrtG h^{d3} (metric only); log p, value and tangent planes
@@ -1189,7 +1191,7 @@ __device__ __forceinline__ void euler_jvp_body(const EulerParams<dual>& P) {
     }
 
     const int le = tid / N3, pt = tid % N3;
-    const Elem el = decode_elem(blockIdx.x * EPB + le, P.count, P.region, H, V);
+    const Elem el = COLM ? decode_elem_col(bx * EPB + le, P.count, H, V) : decode_elem(bx * EPB + le, P.count, P.region, H, V);
     const bool active = (le < EPB) && el.valid;
     const int kl = pt / N2, jl = (pt / N) % N, il = pt % N;
     const int lb = (le < EPB ? le : 0) * C::LE;
@@ -1201,10 +1203,10 @@ __device__ __forceinline__ void euler_jvp_body(const EulerParams<dual>& P) {
         const int fle = fi / (6 * N2);
         const int r = fi % (6 * N2);
         const int f = r / N2, fp = r % N2;
-        const Elem fel = decode_elem(blockIdx.x * EPB + fle, P.count, P.region, H, V);
+        const Elem fel = COLM ? decode_elem_col(bx * EPB + fle, P.count, H, V) : decode_elem(bx * EPB + fle, P.count, P.region, H, V);
         if (!fel.valid) continue;
         T out[7];
-        face_problem<N, T, true>(P, fel, f, fp, out);
+        face_problem<N, T, true, COLM>(P, fel, f, fp, out);
 #pragma unroll
         for (int c = 0; c < 5; ++c) frt[fle][f][c][fp] = out[c].im;
         frf[fle][f][0][fp] = out[5];
@@ -1212,7 +1214,9 @@ __device__ __forceinline__ void euler_jvp_body(const EulerParams<dual>& P) {
     }
 
     PointIn<T> S;
-    k2_point_loads<T>(P, active, o, fs, S);
+    const size_t om = COLM ? ((size_t)el.ej * H + el.ei) * N2 + pt % N2 : o;
+    const size_t fsm = COLM ? (size_t)H * H * N2 : fs;
+    k2_point_loads<T, COLM>(P, active, o, fs, S, om, fsm);
     const T q0 = S.q0, q1 = S.q1, q2 = S.q2, q3 = S.q3, q4 = S.q4;
     const double sg = S.sg;
     // ---- pointwise quantities
@@ -1230,7 +1234,7 @@ __device__ __forceinline__ void euler_jvp_body(const EulerParams<dual>& P) {
     // ---- forcing (tangent)
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc4 = 0.0, accw = 0.0, hf = 0.0, gcoef = 0.0;
     if (active) {
-        const JvpForcing F = jvp_forcing(P, o, fs, sg, S.h00, S.h01, S.h02, S.h11, S.h12, S.h22, q0, u1, u2, u3, p);
+        const JvpForcing F = jvp_forcing<COLM>(P, o, fs, sg, S.h00, S.h01, S.h02, S.h11, S.h12, S.h22, q0, u1, u2, u3, p, om, fsm);
         acc1 = F.f1; acc2 = F.f2; accw = F.fw; gcoef = F.gcoef;
     }
 
@@ -1320,8 +1324,10 @@ __device__ __forceinline__ void euler_jvp_body(const EulerParams<dual>& P) {
 // high-filter; the tangent of B* has no nodal part and keeps its two-term correction on the vector pipe.
 constexpr int kJvFS = 9 * 64 + 16;   // doubles per face of the JVP kernel's face image (9 quantities)
 
+template <bool COLM = false>
 __device__ __forceinline__ void euler_jvp_body_mf(const EulerParams<dual>& P) {
     using T = dual;
+    const int bx = COLM ? xcd_slab_block(blockIdx.x, gridDim.x >> 3) : (int)blockIdx.x;
     constexpr int N = 8, N2 = 64, N3 = 512;
     __shared__ double pl[9 * kMfLE];   // 0-4 flux tangents (rho, rho u1, rho u2, rho theta, A); 5 B; 6, 7 log p (value, tangent); 8 (sqrtG rho)'
     __shared__ double fq[6 * kJvFS];   // per face: 0-4 tangents of F*; 5 B*.re; 6, 7 log p_own (value, tangent); 8 B*.im
@@ -1334,7 +1340,7 @@ __device__ __forceinline__ void euler_jvp_body_mf(const EulerParams<dual>& P) {
         sCp[tid] = P.K->cp[tid];
     }
     const MfOps4 mops = mf4_load_ops(P.K->D, P.K->cm, P.K->cp, P.K->HF, tid & 63);
-    const Elem el = decode_elem(blockIdx.x, P.count, P.region, H, V);
+    const Elem el = COLM ? decode_elem_col(bx, P.count, H, V) : decode_elem(bx, P.count, P.region, H, V);
     const bool active = el.valid;
     const int kl = tid / N2, jl = (tid / N) % N, il = tid % N;
     const int lptm = mf_idx(kl, jl, il);
@@ -1345,7 +1351,7 @@ __device__ __forceinline__ void euler_jvp_body_mf(const EulerParams<dual>& P) {
         const int f = fi / N2, fp = fi % N2;
         if (!el.valid) continue;
         T out[7];
-        face_problem<N, T, true>(P, el, f, fp, out);
+        face_problem<N, T, true, COLM>(P, el, f, fp, out);
         double* q = fq + f * kJvFS + fp;
 #pragma unroll
         for (int c = 0; c < 5; ++c) q[c * N2] = out[c].im;
@@ -1354,7 +1360,9 @@ __device__ __forceinline__ void euler_jvp_body_mf(const EulerParams<dual>& P) {
     }
 
     PointIn<T> S;
-    k2_point_loads<T>(P, active, o, fs, S);
+    const size_t om = COLM ? ((size_t)el.ej * H + el.ei) * N2 + tid % N2 : o;
+    const size_t fsm = COLM ? (size_t)H * H * N2 : fs;
+    k2_point_loads<T, COLM>(P, active, o, fs, S, om, fsm);
     const T q0 = S.q0, q1 = S.q1, q2 = S.q2, q3 = S.q3, q4 = S.q4;
     const double sg = S.sg;
     const T rinv = 1.0 / q0;
@@ -1366,7 +1374,7 @@ __device__ __forceinline__ void euler_jvp_body_mf(const EulerParams<dual>& P) {
     // ---- forcing (tangent)
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc4 = 0.0, accw = 0.0, hf = 0.0, gcoef = 0.0;
     if (active) {
-        const JvpForcing F = jvp_forcing(P, o, fs, sg, S.h00, S.h01, S.h02, S.h11, S.h12, S.h22, q0, u1, u2, u3, p);
+        const JvpForcing F = jvp_forcing<COLM>(P, o, fs, sg, S.h00, S.h01, S.h02, S.h11, S.h12, S.h22, q0, u1, u2, u3, p, om, fsm);
         acc1 = F.f1; acc2 = F.f2; accw = F.fw; gcoef = F.gcoef;
     }
 
@@ -1427,8 +1435,8 @@ __device__ __forceinline__ void euler_jvp_body_mf(const EulerParams<dual>& P) {
 
 template <int N>
 __global__ __launch_bounds__(Cfg<N>::BS, kJvpWaves) void euler_jvp_kernel(const EulerParams<dual> P) {
-    if constexpr (N == 8 && WX_MFMA) euler_jvp_body_mf(P);
-    else euler_jvp_body<N>(P);
+    if constexpr (N == 8 && WX_MFMA) euler_jvp_body_mf<false>(P);
+    else euler_jvp_body<N, false>(P);
 }
 
 template <int N>
@@ -1439,8 +1447,8 @@ __global__ __launch_bounds__(Cfg<N>::BS, kJvpWaves) void euler_jvp_batch_kernel(
         batch_state<dual>(Q, dyn);
         Q.region = dyn.region; Q.count = dyn.count;
     });
-    if constexpr (N == 8 && WX_MFMA) euler_jvp_body_mf(P);
-    else euler_jvp_body<N>(P);
+    if constexpr (N == 8 && WX_MFMA) euler_jvp_body_mf<false>(P);
+    else euler_jvp_body<N, false>(P);
 }
 
 // plan-time scan of a static field: raises *flag when any value differs from (+/-) zero
@@ -1540,6 +1548,35 @@ static wx_status launch_jvp(const EulerParams<dual>& P, hipStream_t st) {
     hipLaunchKernelGGL((euler_jvp_kernel<N>), dim3(grid), dim3(C::BS), 0, st, P);
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
+}
+
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::BS, kJvpWaves) void euler_jvp_column_kernel(const EulerParams<dual> P) {
+    if constexpr (N == 8 && WX_MFMA) euler_jvp_body_mf<true>(P);
+    else euler_jvp_body<N, true>(P);
+}
+
+template <int N>
+static wx_status launch_jvp_column(const EulerParams<dual>& P, hipStream_t st) {
+    using C = Cfg<N>;
+    if (P.count == 0) return WX_OK;
+    const int grid = (P.count + C::EPB - 1) / C::EPB;
+    hipLaunchKernelGGL((euler_jvp_column_kernel<N>), dim3(8 * ((grid + 7) / 8)), dim3(C::BS), 0, st, P);
+    WX_HIP_TRY(hipGetLastError());
+    return WX_OK;
+}
+
+static wx_status dispatch_jvp_column(int n, const EulerParams<dual>& P, hipStream_t st) {
+    switch (n) {
+        case 2: return launch_jvp_column<2>(P, st);
+        case 3: return launch_jvp_column<3>(P, st);
+        case 4: return launch_jvp_column<4>(P, st);
+        case 5: return launch_jvp_column<5>(P, st);
+        case 6: return launch_jvp_column<6>(P, st);
+        case 7: return launch_jvp_column<7>(P, st);
+        case 8: return launch_jvp_column<8>(P, st);
+    }
+    return fail(WX_ERR_UNSUPPORTED, "num_solpts %d not in 2..8", n);
 }
 
 }  // namespace wx
@@ -1796,7 +1833,8 @@ wx_status wx_euler3d_debug_set_stamps(wx_euler3d_plan* pl, void* dev_buffer) {
 wx_status wx_euler3d_plan_set_column_metric(wx_euler3d_plan* pl, const wx_euler3d_metric* cm) {
     if (!pl) return fail(WX_ERR_INVALID, "wx_euler3d_plan_set_column_metric: null plan");
     if (!cm) { pl->column = false; return WX_OK; }
-    if (pl->dtype != WX_F64) return fail(WX_ERR_INVALID, "wx_euler3d_plan_set_column_metric: the plan must be WX_F64");
+    if (pl->dtype != WX_F64 && pl->dtype != WX_DUAL128)
+        return fail(WX_ERR_INVALID, "wx_euler3d_plan_set_column_metric: the plan must be WX_F64 or WX_DUAL128");
     if (!cm->sqrtG || !cm->h_contra || !cm->christoffel || !cm->inv_dzdeta || !cm->sqrtG_itf_i || !cm->sqrtG_itf_j ||
         !cm->sqrtG_itf_k || !cm->h_contra_itf_i || !cm->h_contra_itf_j || !cm->h_contra_itf_k)
         return fail(WX_ERR_INVALID, "wx_euler3d_plan_set_column_metric: the column metric has a null member");
@@ -1916,6 +1954,11 @@ wx_status wx_euler3d_jvp(wx_euler3d_plan* pl, const double* q, const double* v, 
     }
     WX_STREAM(st, stream);
     if (!jvp_lean()) return dispatch_rhs<dual>(pl->n, P, st);
+    if (pl->column && region == WX_REGION_ALL) {   // column form of the metric: whole-tile launches read the slabs
+        P.sg = pl->c_sg; P.h = pl->c_h; P.chr = pl->c_chr; P.idz = pl->c_idz;
+        P.sgi = pl->c_sgi; P.sgj = pl->c_sgj; P.sgk = pl->c_sgk; P.hi = pl->c_hi; P.hj = pl->c_hj; P.hk = pl->c_hk;
+        return dispatch_jvp_column(pl->n, P, st);
+    }
     switch (pl->n) {
         case 2: return launch_jvp<2>(P, st);
         case 3: return launch_jvp<3>(P, st);
@@ -2009,6 +2052,11 @@ wx_status wx_euler3d_jvp_prepared(wx_euler3d_plan* pl, const double* q, const do
         P.hv_w = static_cast<const double*>(halo_val[2]); P.hv_e = static_cast<const double*>(halo_val[3]);
     }
     WX_STREAM(st, stream);
+    if (pl->column && region == WX_REGION_ALL) {   // column form of the metric: whole-tile launches read the slabs
+        P.sg = pl->c_sg; P.h = pl->c_h; P.chr = pl->c_chr; P.idz = pl->c_idz;
+        P.sgi = pl->c_sgi; P.sgj = pl->c_sgj; P.sgk = pl->c_sgk; P.hi = pl->c_hi; P.hj = pl->c_hj; P.hk = pl->c_hk;
+        return dispatch_jvp_column(pl->n, P, st);
+    }
     switch (pl->n) {
         case 2: return launch_jvp<2>(P, st);
         case 3: return launch_jvp<3>(P, st);

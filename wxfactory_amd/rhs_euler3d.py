@@ -79,7 +79,7 @@ class Euler3DPlan:
     def __init__(self, n: int, H: int, V: int, case_number: int, panel: int, ops: Dict[str, numpy.ndarray],
                  metric: Dict[str, torch.Tensor], dtype: torch.dtype = torch.float64, dual: bool = False,
                  on_panel_edge=(True, True, True, True), column_metric=False):
-        """`column_metric` (float64 plans): False; True - the metric is column-invariant (a shallow atmosphere without
+        """`column_metric` (float64 and dual plans): False; True - the metric is column-invariant (a shallow atmosphere without
         topography: every metric array takes the same values on all levels, which is what the reference's arrays hold
         to rounding for config/dcmip31.ini and its own RHS benchmark), checked here, ValueError otherwise; or "auto" -
         taken when the check passes.  Whole-tile launches then read the metric as one (n x n) slab per column and field
@@ -131,7 +131,7 @@ class Euler3DPlan:
                                                        ctypes.byref(o), ctypes.byref(m)), "wx_euler3d_plan_create_tile")
         self.edge_count = int(self.lib.wx_euler3d_edge_count(self._h))
         self.column_metric = False
-        if column_metric and dtype == torch.float64:
+        if column_metric and (dtype == torch.float64 or self.dual):
             slabs = column_metric_slabs(metric, n, H, V)
             if slabs is None and column_metric is True:
                 raise ValueError("column_metric=True, but the metric arrays are not the same on all levels")
@@ -150,7 +150,7 @@ class Euler3DPlan:
         """Plan of another dtype over the same (borrowed) metric tensors."""
         return Euler3DPlan(self.n, self.H, self.V, self.case_number, self.panel, self._ops, self._metric, dtype=dtype,
                            dual=dual, on_panel_edge=self.on_panel_edge,
-                           column_metric="auto" if (self.column_metric and dtype == torch.float64) else False)
+                           column_metric="auto" if (self.column_metric and (dtype == torch.float64 or dual)) else False)
 
     def _check_q(self, q):
         if q.dtype != self.dtype or q.numel() != 5 * self.V * self.H * self.H * self.n**3 or not q.is_contiguous() \
