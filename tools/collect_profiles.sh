@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the evidence bench.py and DESIGN.md quote, on the GPU box (development tool):
-#   WX_COMMIT=<short hash> tools/collect_profiles.sh <tag>        -> gpurun_out/<tag>/...
+#   WX_COMMIT=<short hash> tools/collect_profiles.sh <tag> [--pmc-only | --no-pmc | --stats-only]   -> gpurun_out/<tag>/...
 # 1. separate --pmc FETCH_SIZE / WRITE_SIZE passes over one E7 panel, K1 + K2 (27-field and rot-zero metric) and the JVP
 #    kernels, + tools/pmc_summary.py (bench.py quotes roofline.traffic from the K2 summaries once they are copied to
 #    profiles/ - so run this BEFORE the bench whose line is to carry the figure);
@@ -22,7 +22,7 @@ pmc() {  # pmc <name> <program> [args]: FETCH_SIZE and WRITE_SIZE passes + summa
   done
   python3 tools/pmc_summary.py "$OUT/pmc_${name}_FETCH_SIZE" "$OUT/pmc_${name}_WRITE_SIZE" "$OUT/pmc_${name}_summary.json" > "$OUT/pmc_${name}_summary.txt" || true
 }
-if [ "$2" != "--stats-only" ]; then
+if [ "$2" != "--stats-only" ] && [ "$2" != "--no-pmc" ]; then
 pmc rotzero "$ROOT/tools/kbench.py" --child --reps 5 --rot-zero
 pmc full "$ROOT/tools/kbench.py" --child --reps 5
 pmc jvp "$ROOT/tools/jvpkbench.py" --reps 5
