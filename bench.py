@@ -294,7 +294,7 @@ def extras(dev, seed):
                                    "algorithmic_bytes_per_point": 156.0, "achieved": round(156.0 * 6 * H * H * n * n / te / 1e9, 1),
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(156.0 * 6 * H * H * n * n / te / 1e9 / HBM_PEAK_GBS, 4),
-                                   "profile": "profiles/r03_v10_swbench_kernel_stats.csv, profiles/r03_sw_pmc_summary.json"},
+                                   "profile": "profiles/r03_v14_swbench_kernel_stats.csv, profiles/r03_sw_pmc_summary.json"},
                       "note": "all six panels in one launch per phase (wx_sw_batch_*): 2 launches per R(Q); launch-latency "
                               "bound (5.5 MB of state per panel)"}}
 
@@ -386,7 +386,8 @@ def column_metric_extras(plans, mine, state, out_general, edge_doubles, dev, k, 
             "speedup_over_headline": round(general_s / t, 3), "max_rel_difference_from_headline_result": diff,
             "matvec_fun_complex_prepared_ms": round(tm * 1e3, 3),
             "note": "opt-in plan form for column-invariant geometries (include/wxhip.h: wx_euler3d_plan_set_column_metric); "
-                    "region ALL launches only; the JVP / stage kernels and split launches read the full arrays"}
+                    "whole-tile (region ALL) launches of the RHS and of the complex-step JVP kernels; the stage kernels and "
+                    "split launches read the full arrays"}
 
 
 def epi2_kiops_e7_extras(dev, seed, n=8, H=60, V=2, dt=0.5, steps=3):
