@@ -1360,7 +1360,9 @@ __device__ __forceinline__ void euler_jvp_body_mf(const EulerParams<dual>& P) {
     }
 
     PointIn<T> S;
-    const size_t om = COLM ? ((size_t)el.ej * H + el.ei) * N2 + tid % N2 : o;
+    // (column form: a 32-bit offset into the slabs, which are small - one register instead of two beside `o`)
+    const unsigned om32 = (unsigned)((el.ej * H + el.ei) * N2 + tid % N2);
+    const size_t om = COLM ? (size_t)om32 : o;
     const size_t fsm = COLM ? (size_t)H * H * N2 : fs;
     k2_point_loads<T, COLM>(P, active, o, fs, S, om, fsm);
     const T q0 = S.q0, q1 = S.q1, q2 = S.q2, q3 = S.q3, q4 = S.q4;
