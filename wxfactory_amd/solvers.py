@@ -601,6 +601,9 @@ class _PmexControl(_SubstepControl):
         return self.m if keep_tau < self.tau else best_m
 
 
+_BASIS_CHECK_BYTES = 1 << 30   # Krylov bases below this size are allocated without asking how much memory is free
+
+
 def _affordable_mmax(n: int, p: int, mmax: int, mmin: int, dev, dtype, group=None, what: str = "kiops") -> int:
     """The largest Krylov basis (<= mmax) whose rows fit in the device memory that is free now.  The reference passes
     mmax = 64 (integrators/epi.py:315, 334) whatever the problem size; a basis of 65 vectors of the whole E7 sphere is
@@ -609,6 +612,9 @@ def _affordable_mmax(n: int, p: int, mmax: int, mmin: int, dev, dtype, group=Non
     vectors than fit.  All ranks take the same limit (all-reduce MIN).  Raises MemoryError when not even mmin fits."""
     dev = torch.device(dev)
     limit = mmax
+    row_bytes = (n + p) * 8
+    if (mmax + 9) * row_bytes < _BASIS_CHECK_BYTES:
+        return mmax   # (a small basis: not worth the allocator statistics, which cost a millisecond)
     if dev.type == "cuda":
         free, _ = torch.cuda.mem_get_info(dev)
         free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)   # (blocks the caching allocator can reuse)
