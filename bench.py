@@ -386,8 +386,8 @@ def column_metric_extras(plans, mine, state, out_general, edge_doubles, dev, k, 
             "speedup_over_headline": round(general_s / t, 3), "max_rel_difference_from_headline_result": diff,
             "matvec_fun_complex_prepared_ms": round(tm * 1e3, 3),
             "note": "opt-in plan form for column-invariant geometries (include/wxhip.h: wx_euler3d_plan_set_column_metric); "
-                    "whole-tile (region ALL) launches of the RHS and of the complex-step JVP kernels; the stage kernels and "
-                    "split launches read the full arrays"}
+                    "the RHS and the complex-step JVP kernels, whole-tile and split launches; the stage kernels read the "
+                    "full arrays"}
 
 
 def epi2_kiops_e7_extras(dev, seed, n=8, H=60, V=2, dt=0.5, steps=3):

@@ -50,13 +50,13 @@ def test_column_metric_rhs_matches_reference_and_general_kernel(built_lib, name)
         assert (d <= 1e-12 * np.maximum(scale, cancel)).all(), (p, d / np.maximum(scale, cancel))
         err = np.abs(outs[1] - ref).max(axis=(1, 2, 3, 4))
         assert (err <= 1e-10 * np.maximum(scale, cancel)).all(), (p, err / np.maximum(scale, cancel))
-        # the other regions of the same plan take the general kernel (full arrays): INTERIOR + BOUNDARY == ALL of the general plan
+        # the split launches of the multi-GPU path on the same plan: INTERIOR + BOUNDARY == ALL, bit for bit
         if g.H > 2:
             out2 = torch.full_like(q, float("nan"))
             column.rhs(q, None, out2, _lib.WX_REGION_INTERIOR)
             column.rhs(q, halo, out2, _lib.WX_REGION_BOUNDARY)
             torch.cuda.synchronize()
-            assert np.array_equal(out2.cpu().numpy(), outs[0])
+            assert np.array_equal(out2.cpu().numpy(), outs[1])
 
 
 def test_column_metric_is_refused_over_a_mountain(built_lib):
@@ -94,6 +94,12 @@ def test_column_metric_jvp_matches_general_kernel_and_reference(built_lib, name)
             plan.jvp(q, v, g.eps, halo, out, 1.0, _lib.WX_REGION_ALL)
             torch.cuda.synchronize()
             res.append(out.cpu().numpy())
+        if g.H > 2:   # (plan: the column one of the loop's last pass) split launches == whole-tile launch
+            out2 = torch.full_like(q, float("nan"))
+            plan.jvp(q, v, g.eps, None, out2, 1.0, _lib.WX_REGION_INTERIOR)
+            plan.jvp(q, v, g.eps, halo, out2, 1.0, _lib.WX_REGION_BOUNDARY)
+            torch.cuda.synchronize()
+            assert np.array_equal(out2.cpu().numpy(), res[1])
         ref = g.r(p, True).imag
         scale = var_max(ref)
         d = np.abs(res[1] - res[0]).max(axis=(1, 2, 3, 4))

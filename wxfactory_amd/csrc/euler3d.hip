@@ -170,17 +170,37 @@ __device__ __forceinline__ Elem decode_elem(int slot, int count, int region, int
     return r;
 }
 
-// COLUMN form (float64 plans with a column-invariant metric, region ALL): the V elements of a column follow each other,
+// COLUMN form (plans with a column-invariant metric): the V elements of a column follow each other,
 // so that the column's metric - one (n x n) slab per field instead of V n of them - is fetched once and found in cache
 // by the rest of the column
-__device__ __forceinline__ Elem decode_elem_col(int slot, int count, int H, int V) {
+__device__ __forceinline__ Elem decode_elem_col(int slot, int count, int region, int H, int V) {
     Elem r;
     r.valid = slot < count;
     if (!r.valid) slot = 0;
-    const int c = slot / V;
+    const int c = slot / V;   // the column within the region, in the order decode_elem walks one level of it
     r.ek = slot % V;
-    r.ei = c % H;
-    r.ej = c / H;
+    if (region == WX_REGION_ALL) {
+        r.ei = c % H;
+        r.ej = c / H;
+    } else if (region == WX_REGION_INTERIOR) {
+        const int w = H - 2;
+        r.ei = 1 + c % w;
+        r.ej = 1 + c / w;
+    } else {
+        const int w = H > 2 ? H - 2 : 0;
+        int s = c;
+        if (s < H) {
+            r.ej = 0;
+            r.ei = s;
+        } else if (s < 2 * H) {
+            r.ej = H - 1;
+            r.ei = s - H;
+        } else {
+            s -= 2 * H;
+            r.ej = 1 + s % w;
+            r.ei = (s / w) ? H - 1 : 0;
+        }
+    }
     r.e = (r.ek * H + r.ej) * H + r.ei;
     return r;
 }
@@ -837,7 +857,7 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
     }
 
     const int le = tid / N3, pt = tid % N3;
-    const Elem el = COLM ? decode_elem_col(bx * EPB + le, P.count, H, V) : decode_elem(bx * EPB + le, P.count, P.region, H, V);
+    const Elem el = COLM ? decode_elem_col(bx * EPB + le, P.count, P.region, H, V) : decode_elem(bx * EPB + le, P.count, P.region, H, V);
     const bool active = (le < EPB) && el.valid;
     const int kl = pt / N2, jl = (pt / N) % N, il = pt % N;
     const int lb = (le < EPB ? le : 0) * C::LE;  // LDS base of this thread's element
@@ -879,7 +899,7 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
         int f = r / N2;
         const int fp = r % N2;
         if (N2 % 64 == 0 && BS % 64 == 0) f = __builtin_amdgcn_readfirstlane(f);
-        const Elem fel = COLM ? decode_elem_col(bx * EPB + fle, P.count, H, V) : decode_elem(bx * EPB + fle, P.count, P.region, H, V);
+        const Elem fel = COLM ? decode_elem_col(bx * EPB + fle, P.count, P.region, H, V) : decode_elem(bx * EPB + fle, P.count, P.region, H, V);
         if (!fel.valid) continue;
         T out[NC];
         face_problem<N, T, false, COLM>(P, fel, f, fp, out);
@@ -1191,7 +1211,7 @@ __device__ __forceinline__ void euler_jvp_body(const EulerParams<dual>& P) {
     }
 
     const int le = tid / N3, pt = tid % N3;
-    const Elem el = COLM ? decode_elem_col(bx * EPB + le, P.count, H, V) : decode_elem(bx * EPB + le, P.count, P.region, H, V);
+    const Elem el = COLM ? decode_elem_col(bx * EPB + le, P.count, P.region, H, V) : decode_elem(bx * EPB + le, P.count, P.region, H, V);
     const bool active = (le < EPB) && el.valid;
     const int kl = pt / N2, jl = (pt / N) % N, il = pt % N;
     const int lb = (le < EPB ? le : 0) * C::LE;
@@ -1203,7 +1223,7 @@ __device__ __forceinline__ void euler_jvp_body(const EulerParams<dual>& P) {
         const int fle = fi / (6 * N2);
         const int r = fi % (6 * N2);
         const int f = r / N2, fp = r % N2;
-        const Elem fel = COLM ? decode_elem_col(bx * EPB + fle, P.count, H, V) : decode_elem(bx * EPB + fle, P.count, P.region, H, V);
+        const Elem fel = COLM ? decode_elem_col(bx * EPB + fle, P.count, P.region, H, V) : decode_elem(bx * EPB + fle, P.count, P.region, H, V);
         if (!fel.valid) continue;
         T out[7];
         face_problem<N, T, true, COLM>(P, fel, f, fp, out);
@@ -1340,7 +1360,7 @@ __device__ __forceinline__ void euler_jvp_body_mf(const EulerParams<dual>& P) {
         sCp[tid] = P.K->cp[tid];
     }
     const MfOps4 mops = mf4_load_ops(P.K->D, P.K->cm, P.K->cp, P.K->HF, tid & 63);
-    const Elem el = COLM ? decode_elem_col(bx, P.count, H, V) : decode_elem(bx, P.count, P.region, H, V);
+    const Elem el = COLM ? decode_elem_col(bx, P.count, P.region, H, V) : decode_elem(bx, P.count, P.region, H, V);
     const bool active = el.valid;
     const int kl = tid / N2, jl = (tid / N) % N, il = tid % N;
     const int lptm = mf_idx(kl, jl, il);
@@ -1697,8 +1717,8 @@ wx_status run_rhs(wx_euler3d_plan* pl, const void* q, const void* const halo[4],
         P.halo_w = static_cast<const T*>(halo[2]); P.halo_e = static_cast<const T*>(halo[3]);
     }
     if constexpr (std::is_same<T, double>::value) {
-        // column form: whole-tile launches of the plain kernel on a plan that holds the column slabs
-        if (pl->column && region == WX_REGION_ALL && !epilogue && itf_in == 0 && P.q_tan == nullptr) {
+        // column form: launches of the plain kernel on a plan that holds the column slabs
+        if (pl->column && !epilogue && itf_in == 0 && P.q_tan == nullptr) {
             P.sg = pl->c_sg; P.h = pl->c_h; P.chr = pl->c_chr; P.idz = pl->c_idz;
             P.sgi = pl->c_sgi; P.sgj = pl->c_sgj; P.sgk = pl->c_sgk; P.hi = pl->c_hi; P.hj = pl->c_hj; P.hk = pl->c_hk;
             return dispatch_rhs_column(pl->n, P, st);
@@ -1956,7 +1976,7 @@ wx_status wx_euler3d_jvp(wx_euler3d_plan* pl, const double* q, const double* v, 
     }
     WX_STREAM(st, stream);
     if (!jvp_lean()) return dispatch_rhs<dual>(pl->n, P, st);
-    if (pl->column && region == WX_REGION_ALL) {   // column form of the metric: whole-tile launches read the slabs
+    if (pl->column) {   // column form of the metric: the launch reads the slabs
         P.sg = pl->c_sg; P.h = pl->c_h; P.chr = pl->c_chr; P.idz = pl->c_idz;
         P.sgi = pl->c_sgi; P.sgj = pl->c_sgj; P.sgk = pl->c_sgk; P.hi = pl->c_hi; P.hj = pl->c_hj; P.hk = pl->c_hk;
         return dispatch_jvp_column(pl->n, P, st);
@@ -2054,7 +2074,7 @@ wx_status wx_euler3d_jvp_prepared(wx_euler3d_plan* pl, const double* q, const do
         P.hv_w = static_cast<const double*>(halo_val[2]); P.hv_e = static_cast<const double*>(halo_val[3]);
     }
     WX_STREAM(st, stream);
-    if (pl->column && region == WX_REGION_ALL) {   // column form of the metric: whole-tile launches read the slabs
+    if (pl->column) {   // column form of the metric: the launch reads the slabs
         P.sg = pl->c_sg; P.h = pl->c_h; P.chr = pl->c_chr; P.idz = pl->c_idz;
         P.sgi = pl->c_sgi; P.sgj = pl->c_sgj; P.sgk = pl->c_sgk; P.hi = pl->c_hi; P.hj = pl->c_hj; P.hk = pl->c_hk;
         return dispatch_jvp_column(pl->n, P, st);
