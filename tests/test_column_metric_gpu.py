@@ -106,3 +106,36 @@ def test_column_metric_jvp_matches_general_kernel_and_reference(built_lib, name)
         assert (d <= 1e-11 * scale).all(), (p, d / scale)
         err = np.abs(res[1] - ref).max(axis=(1, 2, 3, 4))
         assert (err <= 1e-9 * scale).all(), (p, err / scale)
+
+
+def test_column_plans_under_the_rhs_object_and_the_matvec(built_lib):
+    """Six column plans under RhsEuler3D (per-tile launches, as whole E7 panels take them): R(Q) and the prepared
+    complex-step matvec - whose dual twin plans inherit the slabs - against the reference's values of the callers fixture;
+    the batched launches of small tiles keep the general kernels and agree."""
+    from tests.gpu_util import device_metric
+    from tests.util import Golden
+    from wxfactory_amd.matvec import ComplexStepOperator
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D
+
+    g = Golden("callers_euler3d_n8_h2_v2")
+    plans = {p: Euler3DPlan(g.n, g.H, g.V, g.case, p, g.ops, device_metric(g, p, DEV), column_metric="auto") for p in range(6)}
+    assert all(pl.column_metric for pl in plans.values())
+    stack = lambda key: torch.from_numpy(np.stack([g[f"p{p}/{key}"] for p in range(6)])).to(DEV)  # noqa: E731
+    Q, V, R = stack("Q"), stack("V"), stack("R")
+    ax = (0, 2, 3, 4, 5)
+    rhs = RhsEuler3D(plans)
+    outs = {}
+    for batched in (False, True):
+        rhs.batched = batched
+        r = rhs(Q)
+        err = (r - R).abs().amax(dim=ax) / R.abs().amax(dim=ax)
+        assert (err < 1e-11).all(), (batched, err)
+        op = ComplexStepOperator(float(g["meta/dt_jvp"]), Q, R, rhs)
+        jv = op(V.flatten()).reshape(Q.shape)
+        rhs.jvp_release()
+        ref = stack("jvp_complex")
+        errj = (jv - ref).abs().amax(dim=ax) / ref.abs().amax(dim=ax)
+        assert (errj < 1e-9).all(), (batched, errj)
+        outs[batched] = (r, jv)
+    assert all(pl.column_metric for pl in rhs._jvp_plans().values())   # the dual twins took the slabs
+    assert float((outs[True][0] - outs[False][0]).abs().max()) <= 1e-12 * float(R.abs().max())
