@@ -304,7 +304,7 @@ def _state_worker(rank, world, port, q, k):
         raise
 
 
-@pytest.mark.parametrize("world,k", [(2, 1), (8, 1), (4, 2), (8, 2)])
+@pytest.mark.parametrize("world,k", [(2, 1), (8, 1), (4, 2), (8, 2), (6, 3)])
 def test_checkpoint_layout_is_rank_count_independent(world, k):
     """gather_cube / distribute_cube (process_topology.py:444-539) for whole panels and for the 24-tile layout the
     benchmark uses on 4 and 8 GPUs; only rank 0 holds the global array (tensor gather / scatter)."""
