@@ -86,7 +86,7 @@ if __name__ == "__main__":
             env = dict(os.environ, WXHIP_LIB=lib if os.path.isabs(lib) else os.path.join(libdir, lib))
             cmd = [sys.executable, os.path.abspath(__file__), "--child", "--n", str(a.n), "--H", str(a.H), "--V", str(a.V),
                    "--reps", str(a.reps)] + (["--cplx"] if a.cplx else []) + (["--dual"] if a.dual else []) + (
-                       ["--rot-zero"] if a.rot_zero else [])
+                       ["--rot-zero"] if a.rot_zero else []) + (["--column"] if a.column else [])
             r = subprocess.run(cmd, env=env)
             if r.returncode != 0:
                 print(f"{lib}: FAILED rc={r.returncode}", flush=True)
