@@ -383,6 +383,8 @@ def column_metric_extras(plans, mine, state, out_general, edge_doubles, dev, k, 
     tm = (time.perf_counter() - t0) / 10
     rhs.jvp_release()
     return {"applies": True, "ms_per_eval": round(t * 1e3, 4), "dof_updates_per_s": state.numel() / t,
+            # the north star's target accounting (384 B/point whatever is read; >= 0.50 asked for)
+            "frac_at_survey_bytes_per_point": round(state.numel() / 5 / t * ALGO_BYTES_PER_POINT / 1e9 / HBM_PEAK_GBS, 4),
             "speedup_over_headline": round(general_s / t, 3), "max_rel_difference_from_headline_result": diff,
             "matvec_fun_complex_prepared_ms": round(tm * 1e3, 3),
             "note": "opt-in plan form for column-invariant geometries (include/wxhip.h: wx_euler3d_plan_set_column_metric); "
