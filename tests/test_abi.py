@@ -59,3 +59,24 @@ def test_no_cpu_fallback_in_product():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "oracle/" not in src, f
+
+
+def test_header_is_plain_c_and_the_c_example_links(built_lib, tmp_path):
+    """include/wxhip.h compiles as C99 (no C++, no torch types) and examples/c_abi_rhs.c links against the library:
+    the boundary is usable from C as it stands (the program itself runs under -m gpu)."""
+    import shutil
+    import subprocess
+
+    gcc, rocm = shutil.which("gcc"), os.environ.get("ROCM_PATH", "/opt/rocm")
+    if gcc is None or not os.path.exists(os.path.join(rocm, "include", "hip", "hip_runtime_api.h")):
+        pytest.skip("no C toolchain / HIP headers here")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "only_header.c"
+    src.write_text('#include "wxhip.h"\nint main(void) { return wx_version() == 0; }\n')
+    libdir = os.path.dirname(built_lib)
+    # (-pedantic for the header alone: the HIP runtime's own headers, which the example includes, are not pedantic C)
+    for source, out, extra in ((str(src), "only_header", ["-pedantic"]),
+                               (os.path.join(root, "examples", "c_abi_rhs.c"), "c_abi_rhs", [])):
+        subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", *extra, "-D__HIP_PLATFORM_AMD__", f"-I{rocm}/include",
+                        f"-I{root}/include", source, f"-L{libdir}", "-lwxhip", f"-L{rocm}/lib", "-lamdhip64", "-lm", "-o",
+                        str(tmp_path / out)], check=True, capture_output=True, text=True)
