@@ -612,6 +612,10 @@ def main():
     ap.add_argument("--loopback", action="store_true",
                     help="rehearsal on one GPU: route every edge message through the RCCL collective (1-rank group) and split "
                          "the evaluation into INTERIOR / BOUNDARY launches, as a multi-GPU run does")
+    ap.add_argument("--exchange", choices=("rccl", "torch"), default="rccl",
+                    help="halo exchange of the several-GPU path: 'rccl' = the library's own behind the C ABI (wx_exchange_*: "
+                         "grouped ncclSend / ncclRecv on a communication stream, event fork / join; the whole evaluation of a "
+                         "rank is one wx_euler3d_rhs_overlapped call), 'torch' = torch.distributed.all_to_all_single")
     ap.add_argument("--metric", choices=("true", "synthetic"), default="true",
                     help="static metric fields: the cubed-sphere metric of the DCMIP 3-1 planet from wxfactory_amd.geometry3d "
                          "(default, SURVEY 8d) or SURVEY's seeded synthetic fields; values do not affect speed")
@@ -635,6 +639,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1 or args.loopback:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world > 1 or (args.loopback and args.exchange == "torch"):
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if "MASTER_PORT" not in os.environ:   # a free port, as the tests pick theirs
@@ -675,7 +680,13 @@ def main():
         qs[t] = synthetic.euler3d_state(n, Ht, V, t, dev, args.seed)
     t_setup = time.perf_counter() - t_setup
     edge_doubles = 5 * V * Ht * n * n  # WX_EULER3D_EDGE_FIELDS
-    ex = PanelExchange(edge_doubles, dev, rank=rank, world_size=world, tiles_per_side=k, loopback=args.loopback)
+    comm = None
+    if args.exchange == "rccl" and (world > 1 or args.loopback):
+        from wxfactory_amd.exchange import RcclComm
+
+        comm = RcclComm(rank, world, device=dev)   # (the unique id travels through the process group; one rank needs none)
+    ex = PanelExchange(edge_doubles, dev, rank=rank, world_size=world, tiles_per_side=k, loopback=args.loopback,
+                       backend=args.exchange if comm is not None else "torch", comm=comm)
     rhs = RhsEuler3D(plans, ex, overlap=not args.no_overlap)
 
     # live timing of the dominant kernel: HIP events on the launch stream around every K2 launch
@@ -739,6 +750,20 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # the exchange behind the C ABI: a rank's whole evaluation is ONE wx_euler3d_rhs_overlapped call (whole panels; the
+    # tiles of the 24-tile layout share launches through the batch instead), which the Python-side event pairs above never
+    # see - the call stamps the reference's nine-slot timing row itself (wx_exchange_set_timer), one timer per timed step
+    import ctypes
+
+    native_timers = []
+    one_call = (getattr(ex, "_native", None) is not None and bool(mine) and not rhs._small_tiles() and not args.no_overlap)
+    if one_call:
+        lib = _lib.load()
+        for _ in range(args.steps):
+            h = ctypes.c_void_p()
+            _lib.check(lib.wx_phase_timer_create(ctypes.byref(h)), "wx_phase_timer_create")
+            native_timers.append(h)
+
     out = None
     for _ in range(args.warmup):
         out = rhs(state)
@@ -751,11 +776,22 @@ def main():
         # is two marker packets between kernels that would otherwise follow each other directly and overlap their tails:
         # 24 pairs per evaluation cost it 0.3-0.4 % (measured, profiles/r03_v12_event_sampling.txt)
         recording[0] = i % args.event_every == 0
+        if one_call:
+            lib.wx_exchange_set_timer(ex._native, native_timers[i] if recording[0] else None)
         out = rhs(state)
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
     recording[0] = False
+    native_rows = []
+    if one_call:
+        lib.wx_exchange_set_timer(ex._native, None)
+        for i, h in enumerate(native_timers):
+            if i % args.event_every == 0:
+                row = (ctypes.c_double * 9)()
+                _lib.check(lib.wx_phase_timer_elapsed(h, row), "wx_phase_timer_elapsed")
+                native_rows.append(list(row))
+            lib.wx_phase_timer_destroy(h)
     if mine:
         chk = float(out.abs().amax(dim=(1, 2, 3, 4, 5)).sum())
         if not (chk == chk and chk < float("inf")):
@@ -794,11 +830,15 @@ def main():
 
     # dominant-kernel roofline (rank 0's launches)
     roof = None
-    if ev:
+    if ev or native_rows:
         by_region, tiles_in_launch = {}, {}
         for a, b, region, ntl in ev:
             by_region.setdefault(region, []).append(a.elapsed_time(b) * 1e-3)
             tiles_in_launch[region] = ntl
+        for row in native_rows:   # seconds between the stamps 0 1 2 3 5 8: pack, start, INTERIOR, -, join, -, -, BOUNDARY
+            by_region.setdefault(_lib.WX_REGION_INTERIOR, []).append(row[2] / len(mine))
+            by_region.setdefault(_lib.WX_REGION_BOUNDARY, []).append(row[7] / len(mine))
+            tiles_in_launch[_lib.WX_REGION_INTERIOR] = tiles_in_launch[_lib.WX_REGION_BOUNDARY] = 1
         w = Ht - 2 if Ht > 2 else 0
         frac_of_panel = {_lib.WX_REGION_ALL: 1.0, _lib.WX_REGION_INTERIOR: (w * w) / (Ht * Ht),
                          _lib.WX_REGION_BOUNDARY: 1.0 - (w * w) / (Ht * Ht)}
@@ -819,6 +859,10 @@ def main():
                 "region": {0: "all", 1: "interior", 2: "boundary"}[region], "tiles_per_launch": tiles_in_launch[region]}
         if ev1:
             roof["extrap_kernel_launch_ms"] = round(sum(a.elapsed_time(b) for a, b in ev1) / len(ev1), 4)
+        if native_rows:
+            roof["extrap_kernel_launch_ms"] = round(sum(r[0] for r in native_rows) / len(native_rows) / len(mine) * 1e3, 4)
+            roof["timing_source"] = ("wx_phase_timer stamps inside wx_euler3d_rhs_overlapped (one host call per evaluation): "
+                                     "the launches of a phase follow each other on the compute stream, launch time = phase / tiles")
         # the whole sweep (extrapolation kernel + exchange + fused kernel, every local tile): compulsory bytes of one
         # R(Q) of this rank's tiles (each static field and Q read once, R written once) over the step time
         sweep_bytes = bpp * (pts_panel / (k * k)) * len(mine)
@@ -848,6 +892,8 @@ def main():
                        "n": n, "H": H, "V": V, "tiles": topo.ntiles, "tile_H": Ht, "tiles_per_gpu": len(mine),
                        "parallelism": f"tile-dd{min(world, topo.ntiles)}",
                        "overlap": not args.no_overlap,
+                       "exchange": ("rccl p2p behind the C ABI (wx_exchange_*), RCCL %d" % comm.version) if comm is not None
+                                   else ("torch.distributed.all_to_all_single" if (world > 1 or args.loopback) else "aliasing (one rank)"),
                        "metric": "geometry3d: equiangular cubed sphere, DCMIP 3-1 planet (R/125), ztop 10 km"
                                  if args.metric == "true" else "seeded synthetic fields (SURVEY 8d)",
                        "metric_setup_s": round(t_setup, 1)},
@@ -868,7 +914,7 @@ def main():
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, V, args.seed, H)
         print(json.dumps(line), flush=True)
-    if world > 1 or args.loopback:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

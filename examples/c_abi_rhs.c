@@ -139,6 +139,55 @@ int main(int argc, char** argv) {
         printf("variable %d: max |R - R_expected| = %.3e, max |R_expected| = %.3e\n", v, err, scale);
         if (!(err <= 1e-10 * scale)) ok = 0;
     }
+    /* The same evaluation with the halos TRAVELLING: a one-rank RCCL communicator, the library's exchange in loopback mode
+     * (every edge message through ncclSend / ncclRecv on a communication stream forked from the compute stream by an
+     * event), INTERIOR launch while it is in flight, join, BOUNDARY launch - the several-GPU path of
+     * process_topology.py:269-386, 564-606 + rhs/rhs.py:88-118 from C, on one GPU.  This program holds one tile: the
+     * messages its neighbours would have packed are the halo files, put where the neighbours' pack kernels would have
+     * written them. */
+    {
+        unsigned char id[WX_COMM_ID_BYTES];
+        wx_comm* comm = NULL;
+        wx_exchange* ex = NULL;
+        hipStream_t comm_stream;
+        int e, tile = panel, same = 1;   /* one tile per panel: tile id = panel */
+        size_t i;
+        double* r2 = NULL;
+        double* r2_host = (double*)malloc(5 * pts * sizeof(double));
+        void* send2[4];
+        const void* halo2[4];
+        CHECK_WX(wx_comm_unique_id(id));
+        CHECK_WX(wx_comm_init_rank(&comm, 1, id, 0));
+        CHECK_WX(wx_exchange_create(&ex, comm, 0, 1, 1, edge, 1));
+        CHECK_WX(wx_exchange_bind(ex, NULL, NULL));
+        CHECK_HIP(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
+        CHECK_HIP(hipMalloc((void**)&r2, 5 * pts * sizeof(double)));
+        CHECK_HIP(hipMemset(r2, 0, 5 * pts * sizeof(double)));
+        for (e = 0; e < 4; ++e) {
+            int q_tile, q_edge, q_rank;
+            CHECK_WX(wx_exchange_neighbor(ex, tile, e, &q_tile, &q_edge, &q_rank));
+            CHECK_HIP(hipMemcpy(wx_exchange_send_ptr(ex, q_tile, q_edge), halo[e], edge * sizeof(double), hipMemcpyDeviceToDevice));
+            send2[e] = wx_exchange_send_ptr(ex, tile, e);
+            halo2[e] = wx_exchange_halo_ptr(ex, tile, e);
+        }
+        CHECK_WX(wx_euler3d_extrap_pack(plan, q, send2, stream));
+        CHECK_WX(wx_exchange_start(ex, stream, comm_stream));
+        CHECK_WX(wx_euler3d_rhs(plan, q, NULL, r2, WX_REGION_INTERIOR, stream));
+        CHECK_WX(wx_exchange_wait(ex, stream));
+        CHECK_WX(wx_euler3d_rhs(plan, q, halo2, r2, WX_REGION_BOUNDARY, stream));
+        CHECK_HIP(hipStreamSynchronize(stream));
+        CHECK_HIP(hipMemcpy(r2_host, r2, 5 * pts * sizeof(double), hipMemcpyDeviceToHost));
+        for (i = 0; i < 5 * pts; ++i)
+            if (r2_host[i] != r_host[i]) same = 0;
+        printf("RCCL %d, loopback exchange + INTERIOR / BOUNDARY launches: %s\n", wx_comm_rccl_version(),
+               same ? "bit-identical to the single launch" : "DIFFERENT");
+        if (!same) ok = 0;
+        CHECK_WX(wx_exchange_destroy(ex));
+        CHECK_WX(wx_comm_destroy(comm));
+        CHECK_HIP(hipStreamDestroy(comm_stream));
+        free(r2_host);
+    }
+
     /* an invalid call reports through the status and wx_last_error, as the header says */
     if (wx_euler3d_rhs(plan, q, NULL, r, WX_REGION_ALL, stream) == WX_OK) ok = 0;
     else printf("expected refusal: %s\n", wx_last_error());

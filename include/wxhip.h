@@ -48,7 +48,8 @@ typedef enum {
     WX_ERR_INVALID = 1,     /* bad argument (null pointer, unsupported n, shape mismatch) */
     WX_ERR_UNSUPPORTED = 2, /* valid request this build cannot serve (dtype, case) */
     WX_ERR_HIP = 3,         /* a HIP runtime call failed; message has hipGetErrorString */
-    WX_ERR_NOMEM = 4
+    WX_ERR_NOMEM = 4,
+    WX_ERR_COMM = 5         /* an RCCL call failed; message has ncclGetErrorString */
 } wx_status;
 
 typedef enum {
@@ -86,9 +87,10 @@ int wx_device_count(void);
  *       kernels itself - INTEGRATION.md section 4, the MPI route - stamps: 0 start, 1 after wx_euler3d_extrap_pack,
  *       2 exchange posted, 3 = 4 after the INTERIOR launch, 5 exchange complete, 6 = 7 = 8 after the BOUNDARY / ALL
  *       launch: pointwise fluxes + divergence, and Riemann + correction + forcing, are one kernel each here)
- *   wx_phase_timer_elapsed(t, out[9])       synchronises on the last stamp and writes the eight intervals between
- *       consecutive stamps and their total, in SECONDS like device.elapsed; slots never stamped repeat their predecessor
- *       (interval 0).  Returns WX_ERR_INVALID when slot 0 or 8 was not stamped.
+ *   wx_phase_timer_elapsed(t, out[9])       waits for every stamped event (they may sit on different streams) and writes
+ *       the eight intervals between consecutive stamps and their total, in SECONDS like device.elapsed; slots never
+ *       stamped repeat their predecessor (interval 0), and so does a stamp that another stream reached before its
+ *       predecessor.  Returns WX_ERR_INVALID when slot 0 or 8 was not stamped.
  * ------------------------------------------------------------------------------------------ */
 typedef struct wx_phase_timer wx_phase_timer;
 wx_status wx_phase_timer_create(wx_phase_timer** timer);
@@ -150,6 +152,8 @@ wx_status wx_euler3d_plan_create_tile(wx_euler3d_plan** plan, int n, int H, int 
                                       int panel, const int on_panel_edge[4], const wx_dfr_ops* ops,
                                       const wx_euler3d_metric* metric);
 wx_status wx_euler3d_plan_destroy(wx_euler3d_plan* plan);
+/* the dtype the plan was created with (WX_F64 when plan is NULL) */
+wx_dtype wx_euler3d_plan_dtype(const wx_euler3d_plan* plan);
 
 /* Values per face point in an edge message: the 5 prognostic variables the reference exchanges
  * (rho, rho u1, rho u2, rho w, rho theta). */
@@ -373,6 +377,99 @@ wx_status wx_sw_batch_rhs(wx_sw_batch* batch, const void* q, void* rhs, size_t p
 /* y (nullable) and out are stacked like q */
 wx_status wx_sw_batch_rhs_axpy(wx_sw_batch* batch, const void* q, const void* y, void* out, size_t panel_stride, double a,
                                double b, double c, wx_region region, wx_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Panel-edge halo exchange over RCCL point-to-point (xGMI inside a node).
+ * Replaces  process_topology.py:259-261 (Create_dist_graph_adjacent), :269-386 (start_exchange_scalars / _vectors:
+ *           rotate, flip, pack, device.synchronize(), Ineighbor_alltoall) and :564-606 (ExchangeRequest.wait).
+ * Rotation, flip and packing are done by the extrapolation kernels (wx_*_extrap_pack write exactly what the neighbour's
+ * q_itf_{s,n,w,e} holds after wait()); what remains is movement: ONE message per tile edge (the reference sends three),
+ * every message of a rank in one ncclGroupStart .. ncclSend / ncclRecv .. ncclGroupEnd on a communication stream forked
+ * from the compute stream by an event - no device synchronisation - and joined again by wx_exchange_wait, the elements
+ * that need no halo being evaluated in between (rhs/rhs.py:88-118).  A message between two tiles of one rank never moves:
+ * the receiver's halo pointer is the sender's slot.  The fork / join records into a HIP-graph capture of the compute
+ * stream like any other launch, so an evaluation WITH the exchange in flight beside the interior launch replays from one
+ * graph (BASELINE config 5).
+ *
+ * wx_comm: an RCCL communicator.  Either the caller's own ncclComm_t (wx_comm_adopt: borrowed, never destroyed here), or
+ *   one this library makes: rank 0 calls wx_comm_unique_id, hands the 128 bytes to every rank by whatever means it has
+ *   (MPI_Bcast of the reference's communicator, torch.distributed, a file), and every rank calls wx_comm_init_rank with
+ *   ITS GPU current (collective, blocking; setup time).
+ * wx_exchange: the tile graph of the 6 k^2-tile decomposition (process_topology.py:69-125: neighbour table, the tile
+ *   across each panel edge, the edge a message lands on), tile ownership (contiguous equal runs of tiles per rank where
+ *   that divides, round-robin otherwise; ranks beyond the tile count own nothing but take part), and the two edge
+ *   buffers of this rank: messages are laid out by destination rank, inside a rank pair by (destination tile,
+ *   destination edge).  edge_doubles: float64 words per edge message (wx_euler3d_edge_count / wx_sw_edge_count, doubled
+ *   for 16-byte dtypes).  loopback != 0: same-rank messages go through the communicator too (a one-GPU rehearsal of the
+ *   several-GPU path).  comm may be NULL when nothing travels (world == 1, no loopback) - or for layout queries only:
+ *   wx_exchange_start then refuses.  Creation is host-only.
+ *     wx_exchange_bind        gives the exchange its buffers: the caller's (wx_exchange_send_doubles / _recv_doubles
+ *                             doubles each, device memory, alive as long as the exchange) or - both NULL - the library's
+ *                             own (hipMalloc, zeroed: the only allocation, at setup time)
+ *     wx_exchange_send_ptr    where wx_*_extrap_pack must write edge e (S, N, W, E) of tile t: pass as send[e]
+ *     wx_exchange_halo_ptr    where the message for edge e of tile t is found after wx_exchange_wait: pass as halo[e]
+ *     wx_exchange_start       enqueue the exchange of everything packed on `compute` so far.  comm_stream != compute:
+ *                             event fork, the group on comm_stream, event record for the join (returns at once: the
+ *                             caller launches the WX_REGION_INTERIOR work on `compute` now).  comm_stream NULL or ==
+ *                             compute: the group in stream order on `compute`, nothing to wait for.
+ *     wx_exchange_wait        make `compute` wait for the halos (a stream wait, not a host wait)
+ *     wx_exchange_fork / _join  the mirror arrangement: `side` is forked off `compute` by an event (fork), takes the
+ *                             WX_REGION_INTERIOR launches, and is joined into `compute` again (join), while the exchange
+ *                             (wx_exchange_start(ex, compute, compute)) and the BOUNDARY launches stay on `compute`.
+ *   Nothing travels (wx_exchange_needs_comm == 0): start and wait are no-ops.  One exchange in flight per object.
+ *   STREAM CAPTURE.  Both arrangements record into a HIP-graph capture of `compute` on ROCm 7.2 (HIP 7.2, RCCL 2.27:
+ *   tools/rccl_capture_probe.c).  The HIP 7.0.2 runtime that ships inside torch 2.10 wheels survives an RCCL launch in a
+ *   capture only on the capture's ORIGIN stream: hipStreamWaitEvent there lets every non-origin stream that waits on a
+ *   captured event join again (parent + parallel-stream list), RCCL forks and joins its own internal stream around each
+ *   launch, so a user stream that is itself forked and RCCL's stream end up in each other's lists and
+ *   hip::Stream::EndCapture - which walks those lists before it clears them - recurses until the stack is gone
+ *   (profiles/r04_capture_crash.md).  There, capture the fork / join arrangement with `compute` = the origin stream
+ *   (wx_*_rhs_overlapped does exactly that), or the stream-ordered form.
+ * wx_euler3d_rhs_overlapped / wx_sw_rhs_overlapped: the whole evaluation of a rank from one call - pack every local tile on
+ *   `compute`, fork `side` for the INTERIOR launches, the exchange and then the BOUNDARY launches on `compute`, join (one
+ *   WX_REGION_ALL launch per tile when nothing travels; side NULL or == compute: everything in stream order);
+ *   plans[i], q[i], rhs[i] belong to the i-th tile of wx_exchange_local_tiles.
+ * ------------------------------------------------------------------------------------------ */
+#define WX_COMM_ID_BYTES 128
+typedef struct wx_comm wx_comm;
+typedef struct wx_exchange wx_exchange;
+/* ncclGetVersion (e.g. 22606), < 0 on error */
+int wx_comm_rccl_version(void);
+wx_status wx_comm_unique_id(unsigned char id[WX_COMM_ID_BYTES]);
+wx_status wx_comm_init_rank(wx_comm** comm, int nranks, const unsigned char id[WX_COMM_ID_BYTES], int rank);
+wx_status wx_comm_adopt(wx_comm** comm, void* nccl_comm /* ncclComm_t */, int nranks, int rank);
+wx_status wx_comm_destroy(wx_comm* comm);
+
+wx_status wx_exchange_create(wx_exchange** exchange, wx_comm* comm, int rank, int world, int tiles_per_side,
+                             size_t edge_doubles, int loopback);
+wx_status wx_exchange_destroy(wx_exchange* exchange);
+/* number of tiles this rank owns; the first `capacity` ids (ascending) into tiles (nullable) */
+int wx_exchange_local_tiles(const wx_exchange* exchange, int* tiles, int capacity);
+/* the tile across edge `edge` (S, N, W, E = 0..3) of `tile`, the edge of that tile the message lands on, and the rank
+ * that owns it (process_topology.py:105-125, 259-261); outputs nullable */
+wx_status wx_exchange_neighbor(const wx_exchange* exchange, int tile, int edge, int* neighbor_tile, int* landing_edge,
+                               int* neighbor_rank);
+int wx_exchange_needs_comm(const wx_exchange* exchange);
+size_t wx_exchange_send_doubles(const wx_exchange* exchange);
+size_t wx_exchange_recv_doubles(const wx_exchange* exchange);
+/* doubles sent to / received from every rank per exchange [host arrays of `world` entries, nullable] */
+wx_status wx_exchange_peer_counts(const wx_exchange* exchange, size_t* send_doubles, size_t* recv_doubles);
+wx_status wx_exchange_bind(wx_exchange* exchange, double* send_buf, double* recv_buf);
+void* wx_exchange_send_ptr(const wx_exchange* exchange, int tile, int edge);
+const void* wx_exchange_halo_ptr(const wx_exchange* exchange, int tile, int edge);
+/* timer != NULL: the *_rhs_overlapped calls on this exchange stamp the reference's nine-slot timing row on the compute
+ * stream (rhs/rhs.py:88-118): 0 start, 1 packed, 2 / 3 around the INTERIOR launches (on the stream that carries them),
+ * 5 halos received, 8 BOUNDARY / ALL launches done and the streams joined; read it with wx_phase_timer_elapsed.
+ * NULL: no stamps (default).  The timer is borrowed. */
+wx_status wx_exchange_set_timer(wx_exchange* exchange, wx_phase_timer* timer);
+wx_status wx_exchange_start(wx_exchange* exchange, wx_stream compute, wx_stream comm_stream);
+wx_status wx_exchange_wait(wx_exchange* exchange, wx_stream compute);
+wx_status wx_exchange_fork(wx_exchange* exchange, wx_stream compute, wx_stream side);
+wx_status wx_exchange_join(wx_exchange* exchange, wx_stream compute, wx_stream side);
+wx_status wx_euler3d_rhs_overlapped(wx_euler3d_plan* const plans[], int count, wx_exchange* exchange, const void* const q[],
+                                    void* const rhs[], wx_stream compute, wx_stream side);
+wx_status wx_sw_rhs_overlapped(wx_sw_plan* const plans[], int count, wx_exchange* exchange, const void* const q[],
+                               void* const rhs[], wx_stream compute, wx_stream side);
 
 /* ------------------------------------------------------------------------------------------
  * The reference's compiled `pde` module, function for function (pde/interface.cpp:282-302,

@@ -1191,6 +1191,15 @@ CASES = {
     "euler3d_c21_n4_h3_v4": lambda nm: euler_case(
         nm, "dcmip21.ini", dict(num_solpts=4, num_elements_horizontal=3, num_elements_vertical=4),
         metric_panels=(0, 3, 5), phase_panels=()),
+    # the same with an O(1) perturbation (round 4): topography + sponge are neither balanced nor symmetric, so the TANGENT
+    # Im R(Q + i eps v) / eps - sponge tangent rho / tau (u - u_ref) included - is pinned tightly (1e-10), as on c31p;
+    # n = 4 (vector pipe) and the benchmark order n = 8 (matrix cores), panels that carry the Schaer mountain (0, 1)
+    "euler3d_c21p_n4_h3_v4": lambda nm: euler_case(
+        nm, "dcmip21.ini", dict(num_solpts=4, num_elements_horizontal=3, num_elements_vertical=4),
+        metric_panels=(0, 3, 5), phase_panels=(), perturb=0.01, seed=2121),
+    "euler3d_c21p_n8_h2_v2": lambda nm: euler_case(
+        nm, "dcmip21.ini", dict(num_solpts=8, num_elements_horizontal=2, num_elements_vertical=2),
+        metric_panels=(0, 1, 4), phase_panels=(), perturb=0.01, seed=2128),
     # shallow water: Rossby-Haurwitz wave (case 6), p=4 as BASELINE config 2; mountain (case 5,
     # topography); steady zonal flow (case 2) at the benchmark order p=7
     "sw_c6_n5_h4": lambda nm: sw_case(nm, "case6.ini", dict(num_solpts=5, num_elements_horizontal=4)),

@@ -80,3 +80,51 @@ def test_header_is_plain_c_and_the_c_example_links(built_lib, tmp_path):
         subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", *extra, "-D__HIP_PLATFORM_AMD__", f"-I{rocm}/include",
                         f"-I{root}/include", source, f"-L{libdir}", "-lwxhip", f"-L{rocm}/lib", "-lamdhip64", "-lm", "-o",
                         str(tmp_path / out)], check=True, capture_output=True, text=True)
+
+
+@pytest.mark.parametrize("world,k,loopback", [(1, 1, False), (1, 1, True), (2, 1, False), (3, 1, False), (6, 1, False),
+                                              (4, 2, False), (8, 2, False), (8, 1, False), (1, 2, True), (5, 1, False),
+                                              (24, 2, False), (54, 3, False)])
+def test_native_exchange_layout_equals_the_host_mirror(built_lib, world, k, loopback):
+    """The C-ABI exchange (csrc/exchange.hip: tile graph, ownership and slot order from csrc/wx_panels.h) and the Python
+    mirror (exchange.PanelExchange, pinned against the halos the reference delivered on 6 and 24 ranks by
+    tests/test_exchange_gloo.py) name the same tiles, buffer sizes, per-rank message sizes and slot of every tile edge.
+    Host-only calls: no GPU, no communicator."""
+    import torch
+
+    from wxfactory_amd import _lib
+    from wxfactory_amd.exchange import PanelExchange
+
+    lib = _lib.load()
+    ec = 40
+    for rank in range(world):
+        py = PanelExchange(ec, "cpu", rank=rank, world_size=world, loopback=loopback, tiles_per_side=k)
+        h = ctypes.c_void_p()
+        _lib.check(lib.wx_exchange_create(ctypes.byref(h), None, rank, world, k, ec, int(loopback)), "wx_exchange_create")
+        try:
+            n = lib.wx_exchange_local_tiles(h, None, 0)
+            tiles = (ctypes.c_int * max(n, 1))()
+            assert lib.wx_exchange_local_tiles(h, tiles, n) == n and list(tiles[:n]) == py.local
+            assert lib.wx_exchange_needs_comm(h) == int(py.needs_comm)
+            assert lib.wx_exchange_send_doubles(h) == py.send_buf.numel()
+            assert lib.wx_exchange_recv_doubles(h) == py.recv_buf.numel()
+            sc, rc = (ctypes.c_size_t * world)(), (ctypes.c_size_t * world)()
+            _lib.check(lib.wx_exchange_peer_counts(h, sc, rc), "wx_exchange_peer_counts")
+            assert list(sc) == py.send_splits and list(rc) == py.recv_splits
+            # fake base addresses (never dereferenced on the host): the slots are offsets from them
+            sbase, rbase = 1 << 40, 1 << 41
+            _lib.check(lib.wx_exchange_bind(h, sbase, rbase), "wx_exchange_bind")
+            for p in py.local:
+                for e in range(4):
+                    want_s = sbase + 8 * py._send_slot[(p, e)] * ec
+                    kind, slot = py._halo_src[(p, e)]
+                    want_h = (sbase if kind == "send" else rbase) + 8 * slot * ec
+                    assert lib.wx_exchange_send_ptr(h, p, e) == want_s and lib.wx_exchange_halo_ptr(h, p, e) == want_h
+            assert lib.wx_exchange_send_ptr(h, 6 * k * k, 0) is None       # not a tile of this rank / not a tile at all
+            if py.needs_comm:   # no communicator: the exchange refuses to start, with a message
+                assert lib.wx_exchange_start(h, None, None) == 1 and b"communicator" in lib.wx_last_error()
+            else:
+                assert lib.wx_exchange_start(h, None, None) == 0 and lib.wx_exchange_wait(h, None) == 0
+        finally:
+            lib.wx_exchange_destroy(h)
+    del torch

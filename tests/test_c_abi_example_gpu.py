@@ -43,3 +43,4 @@ def test_plain_c_caller(built_lib, name, tmp_path):
     r = subprocess.run([str(exe), str(d)], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "PASS" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
     assert "timing row" in r.stdout and "expected refusal" in r.stdout
+    assert "bit-identical to the single launch" in r.stdout   # the RCCL loopback leg (csrc/exchange.hip) from plain C

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import EDGE_FIELDS, EULER_FIXTURES, MONOLITH_FIXTURES, golden, halo7, make_oracle, var_err, var_max
+from tests.util import tight_tangent, EDGE_FIELDS, EULER_FIXTURES, MONOLITH_FIXTURES, golden, halo7, make_oracle, var_err, var_max
 
 pytestmark = pytest.mark.gpu
 
@@ -82,7 +82,7 @@ def test_rhs_matches_reference(name, cplx):
         assert np.isfinite(R.view(np.float64)).all()
         assert (err <= TOL * scale).all(), (name, p, cplx, err / scale)
         if cplx:
-            tight = "31p" in name  # see tests/test_oracle_euler3d.py on max() tie-breaks
+            tight = tight_tangent(name)  # see tests/test_oracle_euler3d.py on max() tie-breaks
             ierr = var_err(R.imag, ref.imag) / np.maximum(var_max(ref.imag), g.eps * s * 1e-3)
             assert (ierr <= (1e-10 if tight else 1e-3)).all(), (name, p, ierr)
         plan.close()
@@ -260,7 +260,8 @@ def test_rccl_exchange_path_on_one_gpu():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["euler3d_c31p_n3_h4_v2", "euler3d_c31p_n8_h2_v2", "euler3d_c21_n4_h3_v4"])
+@pytest.mark.parametrize("name", ["euler3d_c31p_n3_h4_v2", "euler3d_c31p_n8_h2_v2", "euler3d_c21_n4_h3_v4", "euler3d_c21p_n4_h3_v4",
+                                  "euler3d_c21p_n8_h2_v2"])
 def test_dual_number_arithmetic_equals_complex_step(name):
     """WX_DUAL128 (first-order arithmetic in complex128 storage) returns the reference's complex-step
     result: same real part, same tangent Im R / eps, to the 1e-10 bound."""
@@ -279,7 +280,7 @@ def test_dual_number_arithmetic_equals_complex_step(name):
         R, ref = out.cpu().numpy(), g.r(p, True)
         s = _scale(g, p, True)
         assert (var_err(R.real, ref.real) <= TOL * np.maximum(var_max(ref.real), s)).all()
-        tight = "31p" in name
+        tight = tight_tangent(name)
         ierr = var_err(R.imag, ref.imag) / np.maximum(var_max(ref.imag), g.eps * s * 1e-3)
         assert (ierr <= (1e-10 if tight else 1e-3)).all(), (name, p, ierr)
         plan.close()

@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import GOLDEN, Golden, golden, halo7, make_oracle, var_err, var_max
+from tests.util import tight_tangent, GOLDEN, Golden, golden, halo7, make_oracle, var_err, var_max
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -46,7 +46,7 @@ def test_matrix_core_instantiations_are_selected(built_lib):
 # ---------------------------------------------------------------------------------------------------------
 # the JVP kernel itself, one panel at a time, against Im R(Q + i eps V) of the reference
 # ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["euler3d_c31p_n8_h2_v2", "euler3d_c31_n8_h2_v2"])
+@pytest.mark.parametrize("name", ["euler3d_c31p_n8_h2_v2", "euler3d_c31_n8_h2_v2", "euler3d_c21p_n8_h2_v2"])
 def test_jvp_kernel_n8_matches_reference_complex_step(built_lib, name):
     from tests.gpu_util import device_metric, to_dev
     from wxfactory_amd import _lib
@@ -54,7 +54,7 @@ def test_jvp_kernel_n8_matches_reference_complex_step(built_lib, name):
     from wxfactory_amd.rhs_euler3d import Euler3DPlan
 
     g = golden(name)
-    tight = "31p" in name   # balanced states: numpy.maximum's tie-break decides the tangent (tests/test_oracle_euler3d.py)
+    tight = tight_tangent(name)   # balanced states: numpy.maximum's tie-break decides the tangent (tests/test_oracle_euler3d.py)
     for p in g.metric_panels():
         plan = Euler3DPlan(g.n, g.H, g.V, g.case, p, g.ops, device_metric(g, p, DEV), dtype=torch.complex128, dual=True)
         assert _mc(plan, _lib.WX_KERNEL_JVP) == 1 or os.environ.get("WXHIP_JVP_LEAN") == "0"

@@ -5,7 +5,7 @@ import pytest
 
 from oracle import cubed_sphere as cs
 from oracle.c_port import Euler3DPortC
-from tests.util import EULER_FIXTURES, MONOLITH_FIXTURES, golden, make_oracle, var_err, var_max
+from tests.util import tight_tangent, EULER_FIXTURES, MONOLITH_FIXTURES, golden, make_oracle, var_err, var_max
 
 TOL = 1e-10
 
@@ -43,7 +43,8 @@ def test_port_rhs_matches_reference(name):
         assert (err <= TOL * scale).all(), (name, p, err / scale)
 
 
-@pytest.mark.parametrize("name", ["euler3d_c31p_n3_h4_v2", "euler3d_c31p_n8_h2_v2", "euler3d_c21_n4_h3_v4", "euler3d_c31p_n5_h2_v1"])
+@pytest.mark.parametrize("name", ["euler3d_c31p_n3_h4_v2", "euler3d_c31p_n8_h2_v2", "euler3d_c21_n4_h3_v4", "euler3d_c31p_n5_h2_v1",
+                                  "euler3d_c21p_n4_h3_v4", "euler3d_c21p_n8_h2_v2"])
 def test_port_complex_step_matches_reference(name):
     """The complex128 instantiation against R(Q + i eps V) of the reference (solvers/matvec.py:56-61 on rhs_dfr.py):
     faces and routed halos, real part at the 1e-10 bound, tangent Im R at 1e-10 of its own size."""
@@ -55,7 +56,7 @@ def test_port_complex_step_matches_reference(name):
             ref = g.halo(cs.NEIGHBOR[p][e], True)[cs.landing_edge(p, e)]
             assert np.abs(got.real - ref.real).max() <= 1e-13 * np.abs(ref.real).max(), (p, e)
             assert np.abs(got.imag - ref.imag).max() <= 1e-12 * np.abs(ref.imag).max(), (p, e)
-    tight = "31p" in name   # see tests/test_oracle_euler3d.py on numpy.maximum's tie-break on symmetric states
+    tight = tight_tangent(name)   # see tests/test_oracle_euler3d.py on numpy.maximum's tie-break on symmetric states
     for p in g.metric_panels():
         o, ref_o = make_port(g, p), make_oracle(g, p)
         want = {}

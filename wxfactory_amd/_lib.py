@@ -11,6 +11,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WXHIP_LIB") or os.path.join(PKG, "lib", "libwxhip.so")  # WXHIP_LIB: A/B variants
 
 WX_OK = 0
+WX_ERR_COMM = 5
+WX_COMM_ID_BYTES = 128
 WX_F64, WX_C128, WX_DUAL128 = 0, 1, 2
 WX_REGION_ALL, WX_REGION_INTERIOR, WX_REGION_BOUNDARY = 0, 1, 2
 WX_KERNEL_RHS, WX_KERNEL_STAGE, WX_KERNEL_JVP, WX_KERNEL_BATCH_RHS, WX_KERNEL_BATCH_JVP = 0, 1, 2, 3, 4
@@ -150,6 +152,32 @@ SIGNATURES = {
     "wx_cart2d_plan_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_double, c_double, c_int, POINTER(DfrOps)]),
     "wx_cart2d_plan_destroy": (c_int, [c_void_p]),
     "wx_cart2d_rhs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wx_euler3d_plan_dtype": (c_int, [c_void_p]),
+    "wx_comm_rccl_version": (c_int, []),
+    "wx_comm_unique_id": (c_int, [c_void_p]),
+    "wx_comm_init_rank": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_int]),
+    "wx_comm_adopt": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_int]),
+    "wx_comm_destroy": (c_int, [c_void_p]),
+    "wx_exchange_create": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_int, c_int, c_size_t, c_int]),
+    "wx_exchange_destroy": (c_int, [c_void_p]),
+    "wx_exchange_local_tiles": (c_int, [c_void_p, POINTER(c_int), c_int]),
+    "wx_exchange_neighbor": (c_int, [c_void_p, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "wx_exchange_needs_comm": (c_int, [c_void_p]),
+    "wx_exchange_send_doubles": (c_size_t, [c_void_p]),
+    "wx_exchange_recv_doubles": (c_size_t, [c_void_p]),
+    "wx_exchange_peer_counts": (c_int, [c_void_p, POINTER(c_size_t), POINTER(c_size_t)]),
+    "wx_exchange_bind": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "wx_exchange_send_ptr": (c_void_p, [c_void_p, c_int, c_int]),
+    "wx_exchange_halo_ptr": (c_void_p, [c_void_p, c_int, c_int]),
+    "wx_exchange_set_timer": (c_int, [c_void_p, c_void_p]),
+    "wx_exchange_start": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "wx_exchange_wait": (c_int, [c_void_p, c_void_p]),
+    "wx_exchange_fork": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "wx_exchange_join": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "wx_euler3d_rhs_overlapped": (c_int, [POINTER(c_void_p), c_int, c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_void_p,
+                                          c_void_p]),
+    "wx_sw_rhs_overlapped": (c_int, [POINTER(c_void_p), c_int, c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_void_p,
+                                     c_void_p]),
 }
 
 _lib = None

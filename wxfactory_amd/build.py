@@ -13,7 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libwxhip.so")
-SOURCES = ["wx_api.hip", "euler3d.hip", "sw2d.hip", "cart2d.hip", "filters.hip", "krylov.hip"]
+SOURCES = ["wx_api.hip", "euler3d.hip", "sw2d.hip", "cart2d.hip", "filters.hip", "krylov.hip", "exchange.hip"]
 ARCH = "gfx950"
 
 
@@ -48,7 +48,8 @@ def build(force: bool = False, verbose: bool = False, defines=(), out: str = LIB
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs
+    # RCCL (the halo exchange, csrc/exchange.hip): librccl.so.1 - inside a torch process the copy torch has loaded already
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs + ["-L/opt/rocm/lib", "-lrccl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -1845,6 +1845,8 @@ wx_status wx_euler3d_plan_destroy(wx_euler3d_plan* pl) {
     return WX_OK;
 }
 
+wx_dtype wx_euler3d_plan_dtype(const wx_euler3d_plan* pl) { return pl ? pl->dtype : WX_F64; }
+
 // Diagnostic (not in wxhip.h): give the plan a device buffer of 8 uint64 per workgroup for phase stamps.
 wx_status wx_euler3d_debug_set_stamps(wx_euler3d_plan* pl, void* dev_buffer) {
     if (!pl) return fail(WX_ERR_INVALID, "null plan");

@@ -81,14 +81,16 @@ wx_status wx_phase_timer_stamp(wx_phase_timer* t, int slot, wx_stream stream) {
 wx_status wx_phase_timer_elapsed(wx_phase_timer* t, double seconds[9]) {
     if (!t || !seconds) return wx::fail(WX_ERR_INVALID, "wx_phase_timer_elapsed: null argument");
     if (!t->set[0] || !t->set[8]) return wx::fail(WX_ERR_INVALID, "wx_phase_timer_elapsed: slots 0 and 8 must be stamped");
-    WX_HIP_TRY(hipEventSynchronize(t->ev[8]));
+    // every stamped event is waited for, not only the last: the slots may have been stamped on different streams
+    for (int i = 0; i <= 8; ++i)
+        if (t->set[i]) WX_HIP_TRY(hipEventSynchronize(t->ev[i]));
     int prev = 0;
     for (int i = 1; i <= 8; ++i) {
         seconds[i - 1] = 0.0;
         if (!t->set[i]) continue;   // this phase shares its kernel with the next stamped one
         float ms = 0.0f;
         WX_HIP_TRY(hipEventElapsedTime(&ms, t->ev[prev], t->ev[i]));
-        seconds[i - 1] = 1e-3 * ms;
+        seconds[i - 1] = ms > 0.0f ? 1e-3 * ms : 0.0;   // (stamps of two streams: a phase that ended before its predecessor waited 0)
         prev = i;
     }
     float total = 0.0f;

@@ -20,6 +20,57 @@ static const double kRot[6][4][8] = {
 };
 
 
+// ---- host side: the tile graph of the 6 k^2-tile decomposition (process_topology.py:69-125, 219-228, 259-261).
+// tile id = panel k^2 + row k + col (row along x2, col along x1); edges S, N, W, E = 0..3.
+static const int kNeighbor[6][4] = {{5, 4, 3, 1}, {5, 4, 0, 2}, {5, 4, 1, 3}, {5, 4, 2, 0}, {0, 2, 3, 1}, {2, 0, 3, 1}};
+
+struct CubeTiles {
+    int k;
+    int ntiles() const { return 6 * k * k; }
+    void locate(int t, int& p, int& r, int& c) const { p = t / (k * k); r = (t % (k * k)) / k; c = t % k; }
+    int tile(int p, int r, int c) const { return p * k * k + (((r % k) + k) % k) * k + (((c % k) + k) % k); }
+    bool on_panel_edge(int t, int e) const {
+        int p, r, c;
+        locate(t, p, r, c);
+        return e == E_S ? r == 0 : (e == E_N ? r == k - 1 : (e == E_W ? c == 0 : c == k - 1));
+    }
+    // the tile across edge e of tile t: the neighbour inside the panel, or - across a panel edge - the tile of the
+    // neighbouring panel that process_topology.py:118-125 (edge_coords) names; negative indices count from the far side
+    int neighbor(int t, int e) const {
+        int p, r, c;
+        locate(t, p, r, c);
+        if (!on_panel_edge(t, e)) {
+            static const int dr[4] = {-1, 1, 0, 0}, dc[4] = {0, 0, -1, 1};
+            return tile(p, r + dr[e], c + dc[e]);
+        }
+        const int table[6][4][2] = {
+            {{-1, c}, {0, c}, {r, -1}, {r, 0}},
+            {{-c - 1, -1}, {c, -1}, {r, -1}, {r, 0}},
+            {{0, -c - 1}, {-1, -c - 1}, {r, -1}, {r, 0}},
+            {{c, 0}, {-c - 1, 0}, {r, -1}, {r, 0}},
+            {{-1, c}, {-1, -c - 1}, {-1, -r - 1}, {-1, r}},
+            {{0, -c - 1}, {0, c}, {0, r}, {0, -r - 1}},
+        };
+        return tile(kNeighbor[p][e], table[p][e][0], table[p][e][1]);
+    }
+    // the edge of neighbor(t, e) through which it sees t (the delivery rule of MPI_Neighbor_alltoall on the
+    // dist-graph communicator); -1 cannot happen for k >= 1
+    int landing(int t, int e) const {
+        const int q = neighbor(t, e);
+        for (int e2 = 0; e2 < 4; ++e2)
+            if (neighbor(q, e2) == t) return e2;
+        return -1;
+    }
+};
+
+// rank that owns each tile: contiguous equal runs over the first min(world, ntiles) ranks when that divides evenly,
+// round-robin otherwise; ranks beyond the tile count own nothing (the host mirror: wxfactory_amd/panels.py)
+inline int tile_owner(int t, int world, int ntiles) {
+    const int active = world < ntiles ? world : ntiles;
+    if (ntiles % active == 0) return t / (ntiles / active);
+    return t % active;
+}
+
 // Rotation of the horizontal contravariant pair into the neighbour panel's basis, c = 2X/(1+X^2)
 template <typename T>
 __device__ __forceinline__ void rotate_contra(const double* m, double X, T& a1, T& a2) {

@@ -17,6 +17,7 @@ all five variables, already rotated and flipped by the pack kernel (wx_euler3d_e
   (the fork / join the overlap needs) crashes hipStreamEndCapture; the stream-ordered form captures and
   replays bit-identically (tools/graphcoll_probe.py).
 """
+import ctypes
 from typing import Dict, List, Tuple
 
 import torch
@@ -25,13 +26,60 @@ import torch.distributed as dist
 from .panels import CubeTopology, owner_of_tiles
 
 
+class RcclComm:
+    """An RCCL communicator of this library's own (wx_comm_unique_id / wx_comm_init_rank, include/wxhip.h): the halo
+    exchange of backend "rccl" runs on it through the C ABI, with no torch.distributed call on the data path.  The 128-byte
+    unique id travels from rank 0 to the others through `group` (any torch.distributed backend; not needed on one rank).
+    Collective; the calling process must have its GPU current (torch.cuda.set_device)."""
+
+    def __init__(self, rank: int = 0, world_size: int = 1, group=None, device=None):
+        from . import _lib
+
+        self.lib = _lib.load()
+        self.rank, self.world = rank, world_size
+        ident = (ctypes.c_ubyte * _lib.WX_COMM_ID_BYTES)()
+        if rank == 0:
+            _lib.check(self.lib.wx_comm_unique_id(ident), "wx_comm_unique_id")
+        if world_size > 1:
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            ident = (ctypes.c_ubyte * _lib.WX_COMM_ID_BYTES)(*box[0])
+        self._h = ctypes.c_void_p()
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.wx_comm_init_rank(ctypes.byref(self._h), world_size, ident, rank), "wx_comm_init_rank")
+        self.device = dev
+
+    @property
+    def version(self) -> int:
+        return int(self.lib.wx_comm_rccl_version())
+
+    def close(self):
+        if self._h:
+            self.lib.wx_comm_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class PanelExchange:
     def __init__(self, edge_doubles: int, device, rank: int = 0, world_size: int = 1, group=None,
-                 loopback: bool = False, tiles_per_side: int = 1, mode: dict = None):
+                 loopback: bool = False, tiles_per_side: int = 1, mode: dict = None, backend: str = "torch",
+                 comm: "RcclComm" = None):
         """edge_doubles: float64 words per edge message (5*V*H*n^2, doubled for complex128);
         buffers are float64 (complex payloads travel as interleaved re/im, which RCCL accepts).
-        mode: a dict shared by all exchanges of one RHS object; mode["inline"] switches them together."""
+        mode: a dict shared by all exchanges of one RHS object; mode["inline"] switches them together.
+        backend: "torch" - torch.distributed.all_to_all_single on `group` (RCCL on GPUs, gloo on CPU) - or "rccl" - the
+        library's own exchange behind the C ABI (wx_exchange_*: grouped ncclSend / ncclRecv on a communication stream
+        forked from the compute stream by an event; `comm` = an RcclComm, not needed when nothing travels)."""
         dtype = torch.float64
+        if backend not in ("torch", "rccl"):
+            raise ValueError("backend must be 'torch' or 'rccl'")
+        self.backend = backend
         self.inline = False          # stream-ordered collective, no work handle (graph capture)
         self.mode = mode
         self.edge_count = int(edge_doubles)
@@ -90,6 +138,47 @@ class PanelExchange:
                 rslot += 1
         self.n_remote_in = rslot
         self._work = None
+        self._native = None
+        if backend == "rccl":
+            self._bind_native(comm, device, tiles_per_side)
+
+    def _bind_native(self, comm, device, k):
+        """The C-ABI exchange over the SAME two buffers: the library derives the tile graph, the ownership and the slot
+        order itself (csrc/wx_panels.h) - every send / halo address it names must be the one this class computed."""
+        from . import _lib
+
+        self.lib = _lib.load()
+        self.comm = comm
+        if self.needs_comm and comm is None:
+            raise ValueError("backend='rccl': messages travel, an RcclComm is needed")
+        if torch.device(device).type != "cuda":
+            raise ValueError("backend='rccl' moves device buffers: the exchange must live on a GPU")
+        h = ctypes.c_void_p()
+        _lib.check(self.lib.wx_exchange_create(ctypes.byref(h), comm._h if comm is not None else None, self.rank, self.world,
+                                               k, self.edge_count, int(self.loopback)), "wx_exchange_create")
+        self._native = h
+        if self.send_buf.numel() != self.lib.wx_exchange_send_doubles(h) or self.recv_buf.numel() != self.lib.wx_exchange_recv_doubles(h):
+            raise RuntimeError("the library's edge-buffer sizes differ from the host mirror's")
+        _lib.check(self.lib.wx_exchange_bind(h, self.send_buf.data_ptr() if self.send_buf.numel() else None,
+                                             self.recv_buf.data_ptr()), "wx_exchange_bind")
+        for p in self.local:
+            for e in range(4):
+                if (self.lib.wx_exchange_send_ptr(h, p, e) != self.send_view(p, e).data_ptr()
+                        or self.lib.wx_exchange_halo_ptr(h, p, e) != self.halo_view(p, e).data_ptr()):
+                    raise RuntimeError(f"the library's slot of tile {p}, edge {e} differs from the host mirror's")
+        # the communication stream the exchange is forked to (one per exchange object; the join is an event wait)
+        self.comm_stream = torch.cuda.Stream(device=device) if self.needs_comm else None
+
+    def close(self):
+        if self._native:
+            self.lib.wx_exchange_destroy(self._native)
+            self._native = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # -- views (tests / host logic) and raw pointers (kernels)
     def send_view(self, panel: int, edge: int) -> torch.Tensor:
@@ -121,10 +210,38 @@ class PanelExchange:
     def is_inline(self) -> bool:
         return self.inline or bool(self.mode and self.mode.get("inline"))
 
-    def start(self):
+    @property
+    def native(self) -> bool:
+        """The library's own exchange behind the C ABI (backend "rccl") carries the messages."""
+        return self._native is not None
+
+    def fork(self):
+        """backend "rccl": fork the exchange's second stream off the current one (it will carry the INTERIOR launches)."""
+        from . import _lib
+
+        cs = torch.cuda.current_stream(self.send_buf.device).cuda_stream
+        _lib.check(self.lib.wx_exchange_fork(self._native, cs, self.comm_stream.cuda_stream), "wx_exchange_fork")
+
+    def join(self):
+        """... and make the current stream wait for what was enqueued on the second stream since."""
+        from . import _lib
+
+        cs = torch.cuda.current_stream(self.send_buf.device).cuda_stream
+        _lib.check(self.lib.wx_exchange_join(self._native, cs, self.comm_stream.cuda_stream), "wx_exchange_join")
+
+    def start(self, on_compute: bool = False):
         """Post the exchange of everything the pack kernels wrote (stream-ordered after them).  Inline mode: the
         collective is complete, in stream order, when this returns - nothing to wait for, nothing kept."""
         if not self.needs_comm:
+            return
+        if self._native is not None:
+            # on the current stream (inline, or the arrangement whose INTERIOR launches were forked instead), or forked
+            # to the communication stream by an event (csrc/exchange.hip)
+            from . import _lib
+
+            cs = torch.cuda.current_stream(self.send_buf.device).cuda_stream
+            ms = cs if (self.is_inline or on_compute) else self.comm_stream.cuda_stream
+            _lib.check(self.lib.wx_exchange_start(self._native, cs, ms), "wx_exchange_start")
             return
         ec = self.edge_count
         send = self.send_buf[: self.n_remote_out * ec]
@@ -138,6 +255,12 @@ class PanelExchange:
 
     def wait(self):
         """Make the current stream (GPU) / the caller (CPU) wait for the halos."""
+        if self._native is not None:
+            from . import _lib
+
+            _lib.check(self.lib.wx_exchange_wait(self._native, torch.cuda.current_stream(self.send_buf.device).cuda_stream),
+                       "wx_exchange_wait")
+            return
         if self._work is not None:
             self._work.wait()
             self._work = None

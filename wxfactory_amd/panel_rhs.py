@@ -54,13 +54,21 @@ class PanelRhs:
             self._plans[dtype] = {p: pl.twin(dtype, dual=self.complex_arith == "dual") for p, pl in base.items()}
         return self._plans[dtype]
 
+    def new_exchange(self, words: int) -> PanelExchange:
+        """Another exchange like the one this object was given (same ranks, tiling, backend, communicator, loopback
+        rehearsal): the complex twin, the second buffer set of the stage pipeline, the value / tangent sets of the
+        prepared JVP."""
+        dev = self.device if self.device is not None else "cpu"
+        first = next(iter(self._ex.values()), None)
+        return PanelExchange(words, dev, rank=self.rank, world_size=self.world, group=self.group,
+                             tiles_per_side=self.tiles_per_side, mode=self.comm_mode,
+                             loopback=first.loopback if first is not None else False,
+                             backend=first.backend if first is not None else "torch",
+                             comm=getattr(first, "comm", None))
+
     def exchange_for(self, dtype):
         if dtype not in self._ex:
-            words = self.edge_count * (2 if dtype.is_complex else 1)
-            dev = self.device if self.device is not None else "cpu"
-            loop = any(e.loopback for e in self._ex.values())   # (a rehearsal's loopback applies to every dtype)
-            self._ex[dtype] = PanelExchange(words, dev, rank=self.rank, world_size=self.world, group=self.group,
-                                            tiles_per_side=self.tiles_per_side, mode=self.comm_mode, loopback=loop)
+            self._ex[dtype] = self.new_exchange(self.edge_count * (2 if dtype.is_complex else 1))
         return self._ex[dtype]
 
     def set_inline_exchange(self, inline: bool = True):
@@ -146,30 +154,65 @@ class PanelRhs:
             for i in slots:
                 self.timestamps[i] = ev
 
-    def _exchange_and_launch(self, ex: PanelExchange, launch):
+    def _phases(self, ex: PanelExchange, run):
         """The phase order of rhs/rhs.py:88-118 once the edge messages are packed: start the exchange, evaluate
         the elements that need no halo (INTERIOR) while it is in flight, then the ring (BOUNDARY); when nothing
         travels (all neighbours on this rank: the halos alias the packed buffers) one launch covers ALL.
-        `launch(i, tile, halo_or_None, region)` enqueues one tile's kernel."""
+        `run(region)` enqueues the kernels of that region on the current stream.
+        The library's own exchange (backend "rccl") keeps the grouped sends / receives on the compute stream and forks
+        the INTERIOR launches to the exchange's second stream instead (include/wxhip.h, STREAM CAPTURE: the arrangement
+        that also records into a HIP graph on the runtime torch ships)."""
         self._stamp(1)
         if ex.needs_comm and self.overlap and not ex.is_inline:
+            if ex.native and not self.timed:
+                ex.fork()
+                with torch.cuda.stream(ex.comm_stream):
+                    run(_lib.WX_REGION_INTERIOR)
+                ex.start(on_compute=True)
+                run(_lib.WX_REGION_BOUNDARY)
+                ex.join()
+                return
             ex.start()
             self._stamp(2)
-            for i, p in enumerate(self.panels):
-                launch(i, p, None, _lib.WX_REGION_INTERIOR)
+            run(_lib.WX_REGION_INTERIOR)
             self._stamp(3, 4)
             ex.wait()
             self._stamp(5)
-            for i, p in enumerate(self.panels):
-                launch(i, p, ex.halo_views(p), _lib.WX_REGION_BOUNDARY)
+            run(_lib.WX_REGION_BOUNDARY)
         else:
-            ex.start()
+            ex.start(on_compute=True)   # nothing to overlap with: in stream order
             self._stamp(2, 3, 4)
             ex.wait()
             self._stamp(5)
-            for i, p in enumerate(self.panels):
-                launch(i, p, ex.halo_views(p), _lib.WX_REGION_ALL)
+            run(_lib.WX_REGION_ALL)
         self._stamp(6, 7, 8)
+
+    def _exchange_and_launch(self, ex: PanelExchange, launch):
+        """`launch(i, tile, halo_or_None, region)` enqueues one tile's kernel; see _phases."""
+        def run(region):
+            for i, p in enumerate(self.panels):
+                launch(i, p, None if region == _lib.WX_REGION_INTERIOR else ex.halo_views(p), region)
+
+        self._phases(ex, run)
+
+    overlapped_entry = None   # name of the library's "pack, start, INTERIOR, wait, BOUNDARY" entry point for these plans
+
+    def _run_native(self, plans, ex, flat, outs):
+        """wx_euler3d_rhs_overlapped / wx_sw_rhs_overlapped (include/wxhip.h): the exchange behind the C ABI on its own
+        communication stream, the launches of every local tile, one host call - the Python of rhs/rhs.py:88-118 gone."""
+        import ctypes
+
+        n = len(self.panels)
+        for p in self.panels:
+            plans[p]._check_q(flat[p])
+            plans[p].faces_epoch = getattr(plans[p], "faces_epoch", 0) + 1
+        handles = (ctypes.c_void_p * n)(*[plans[p]._h for p in self.panels])
+        qp = (ctypes.c_void_p * n)(*[flat[p].data_ptr() for p in self.panels])
+        rp = (ctypes.c_void_p * n)(*[outs[p].data_ptr() for p in self.panels])
+        cs = torch.cuda.current_stream(self.device).cuda_stream
+        ms = ex.comm_stream.cuda_stream if ex.comm_stream is not None else None   # the second stream: INTERIOR launches
+        lib = _lib.load()
+        _lib.check(getattr(lib, self.overlapped_entry)(handles, n, ex._native, qp, rp, cs, ms), self.overlapped_entry)
 
     def _run(self, qs, ys, coef, dtype, zs=None):
         np_ = len(self.panels)
@@ -182,7 +225,7 @@ class PanelRhs:
             # a rank that owns no panel (ranks 6, 7 of an 8-GPU node) still takes part in the collective
             ex = self.exchange_for(dtype or torch.float64)
             if ex.needs_comm:
-                ex.start()
+                ex.start(on_compute=True)
                 ex.wait()
             return qs
         dtype = next(iter(qs.values())).dtype
@@ -208,9 +251,13 @@ class PanelRhs:
             outs = {p: out_all[i] for i, p in enumerate(self.panels)}
         else:
             outs = {p: torch.empty_like(flat[p]) for p in self.panels}
-        for p in self.panels:
-            plans[p].extrap_pack(flat[p], ex.send_views(p))
-        self._exchange_and_launch(ex, lambda i, p, halo, region: launch(p, halo, region))
+        if (coef is None and getattr(ex, "_native", None) is not None and self.overlapped_entry and not self.timed
+                and (self.overlap or not ex.needs_comm) and not ex.is_inline):
+            self._run_native(plans, ex, flat, outs)   # the whole evaluation of this rank from one call of the C ABI
+        else:
+            for p in self.panels:
+                plans[p].extrap_pack(flat[p], ex.send_views(p))
+            self._exchange_and_launch(ex, lambda i, p, halo, region: launch(p, halo, region))
         if kind == "stacked":
             return out_all.reshape(shape)
         if kind == "single":

@@ -382,6 +382,7 @@ class RhsEuler3D(PanelRhs):
 
     supports_jvp = True
     supports_pipeline = True
+    overlapped_entry = "wx_euler3d_rhs_overlapped"
     batched = True  # stacked states of several SMALL tiles: one launch per phase for all of them (Euler3DBatch)
     batch_max_points = 4_000_000  # per tile.  Whole E7 panels (14.7 M points) are faster launched one by one (7.07 vs 7.16 ms
     #                               per sphere, 7.01 vs 7.31 ms with the INTERIOR / BOUNDARY split); the 3.7 M-point tiles of the
@@ -410,15 +411,7 @@ class RhsEuler3D(PanelRhs):
 
     def _batched_phases(self, ex, launch):
         """launch(region) enqueues one kernel for all tiles."""
-        if ex.needs_comm and self.overlap and not ex.is_inline:
-            ex.start()
-            launch(_lib.WX_REGION_INTERIOR)
-            ex.wait()
-            launch(_lib.WX_REGION_BOUNDARY)
-        else:
-            ex.start()
-            ex.wait()
-            launch(_lib.WX_REGION_ALL)
+        self._phases(ex, launch)
 
     def _run_batched(self, q, y, z, coef):
         dt = q.dtype
@@ -461,15 +454,12 @@ class RhsEuler3D(PanelRhs):
             self._pipe = {}
         st = self._pipe.setdefault(dtype, {"slot": 0, "ready": None, "ex": [self.exchange_for(dtype), None]})
         if st["ex"][1] is None:
-            words = self.edge_count * (2 if dtype.is_complex else 1)
-            st["ex"][1] = PanelExchange(words, self.device, rank=self.rank, world_size=self.world, group=self.group,
-                                        loopback=st["ex"][0].loopback, tiles_per_side=self.tiles_per_side,
-                                        mode=self.comm_mode)
+            st["ex"][1] = self.new_exchange(self.edge_count * (2 if dtype.is_complex else 1))
         cur = st["slot"]
         ex, exn = st["ex"][cur], st["ex"][1 - cur]
         if not self.panels:   # a rank that owns no tile: the exchange of this stage, and the same slot flip as the others
             if ex.needs_comm:
-                ex.start()
+                ex.start(on_compute=True)
                 ex.wait()
             st["slot"] = 1 - cur
             return torch.empty_like(Q)
@@ -519,7 +509,7 @@ class RhsEuler3D(PanelRhs):
         if not self.panels:   # a rank that owns no tile only takes part in the exchange
             ex = self.exchange_for(torch.float64)
             if ex.needs_comm:
-                ex.start()
+                ex.start(on_compute=True)
                 ex.wait()
             return torch.empty_like(Q)
         shp = (np_,) + tuple(self.panel_shape)
@@ -597,17 +587,14 @@ class RhsEuler3D(PanelRhs):
             self._jvp_lin = None
             return False
         if getattr(self, "_ex_val", None) is None:
-            loop = any(e.loopback for e in self._ex.values())
-            mk = lambda: PanelExchange(self.edge_count, self.device, rank=self.rank, world_size=self.world, group=self.group,  # noqa: E731
-                                       tiles_per_side=self.tiles_per_side, mode=self.comm_mode, loopback=loop)
-            self._ex_val, self._ex_tan = mk(), mk()
+            self._ex_val, self._ex_tan = self.new_exchange(self.edge_count), self.new_exchange(self.edge_count)
         ex = self._ex_val
         if self.panels:
             Qs = Q.reshape((len(self.panels),) + tuple(self.panel_shape))
             plans = self._jvp_plans()
             for i, p in enumerate(self.panels):
                 plans[p].jvp_prepare(Qs[i], ex.send_views(p))
-        ex.start()
+        ex.start(on_compute=True)
         ex.wait()
         self._jvp_lin = (weakref.ref(Q), Q.data_ptr(), Q._version) if self.panels else ("idle",)
         return True
@@ -642,7 +629,7 @@ class RhsEuler3D(PanelRhs):
         if not self.panels:   # a rank that owns no tile only takes part in the exchange of the product
             ex = self._ex_tan if prepared else self.exchange_for(torch.complex128)
             if ex.needs_comm:
-                ex.start()
+                ex.start(on_compute=True)
                 ex.wait()
             return torch.empty_like(Q)
         Qs = Q.reshape((np_,) + tuple(self.panel_shape))

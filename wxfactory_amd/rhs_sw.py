@@ -169,6 +169,7 @@ class RhsShallowWater(PanelRhs):
     with ONE launch per phase for all of them (SwBatch)."""
 
     batched = True
+    overlapped_entry = "wx_sw_rhs_overlapped"
 
     def _run(self, qs, ys, coef, dtype, zs=None):
         if (self.batched and zs is None and isinstance(qs, torch.Tensor) and len(self.panels) > 1
@@ -187,13 +188,5 @@ class RhsShallowWater(PanelRhs):
         b = self._batches[dt]
         out = torch.empty_like(q)
         b.extrap_pack(q)
-        if ex.needs_comm and self.overlap:
-            ex.start()
-            b.rhs(q, out, _lib.WX_REGION_INTERIOR, y, coef)
-            ex.wait()
-            b.rhs(q, out, _lib.WX_REGION_BOUNDARY, y, coef)
-        else:
-            ex.start()
-            ex.wait()
-            b.rhs(q, out, _lib.WX_REGION_ALL, y, coef)
+        self._phases(ex, lambda region: b.rhs(q, out, region, y, coef))
         return out
