@@ -169,3 +169,27 @@ def test_shallow_water_over_the_native_exchange(comm):
         got = rhs(Q)
         torch.cuda.synchronize()
         assert torch.equal(got, want), batched
+
+
+@pytest.mark.parametrize("form", ["forkjoin", "inline"])
+def test_plain_c_capture_probe(built_lib, tmp_path, form):
+    """tools/rccl_capture_probe.c - plain C on the image's ROCm (HIP 7.2, RCCL 2.27), no torch in the process: the
+    library's wx_exchange_start / _wait with the exchange on its own communication stream, captured into a HIP graph and
+    replayed with fresh data three times, every halo checked.  (The same program on the HIP 7.0.2 runtime bundled with
+    torch dies in hipStreamEndCapture: profiles/r04_capture_crash.md.)"""
+    import os
+    import shutil
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc, rocm = shutil.which("gcc"), os.environ.get("ROCM_PATH", "/opt/rocm")
+    if gcc is None or not os.path.exists(os.path.join(rocm, "include", "hip", "hip_runtime_api.h")):
+        pytest.skip("no C toolchain / HIP headers on this box")
+    exe, libdir = tmp_path / "probe", os.path.dirname(built_lib)
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", f"-I{rocm}/include", f"-I{root}/include",
+                    os.path.join(root, "tools", "rccl_capture_probe.c"), f"-L{libdir}", "-lwxhip", f"-L{rocm}/lib", "-lamdhip64",
+                    "-o", str(exe)], check=True, capture_output=True, text=True)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.pathsep.join([libdir, f"{rocm}/lib"]))
+    r = subprocess.run([str(exe)] + (["inline"] if form == "inline" else []) + ["multi"], env=env, capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode == 0 and "PASS" in r.stdout and r.stdout.count("halos correct") == 4, (r.stdout[-1500:], r.stderr[-500:])

@@ -12,10 +12,17 @@ all five variables, already rotated and flipped by the pack kernel (wx_euler3d_e
   are computed while it is in flight;
 * `inline` mode (HIP-graph capture, BASELINE config 5): the same collective enqueued in stream order with no
   work handle kept - between the pack and the evaluation launches - on buffers that never move, so that a
-  whole Krylov matvec (tangent extrapolation -> exchange -> JVP kernels) records into ONE graph.  Measured
-  on MI355X / RCCL 2.26: a collective whose wait is deferred behind other launches of the capturing stream
-  (the fork / join the overlap needs) crashes hipStreamEndCapture; the stream-ordered form captures and
-  replays bit-identically (tools/graphcoll_probe.py).
+  whole Krylov matvec (tangent extrapolation -> exchange -> JVP kernels) records into ONE graph.
+* backend "rccl": the library's own exchange behind the C ABI (csrc/exchange.hip, wx_exchange_* of include/wxhip.h:
+  grouped ncclSend / ncclRecv on a communicator made by wx_comm_init_rank) over the same two buffers, with no
+  torch.distributed call on the data path.  Overlap there = the exchange on the compute stream and the INTERIOR
+  launches forked to a second stream (PanelRhs._phases), which also records into a HIP graph.
+
+Why torch's async collective cannot be captured on this stack (profiles/r04_capture_crash.md): the HIP 7.0.2 runtime
+inside the torch wheel lets a non-origin stream that waits on a captured event join the capture AGAIN, RCCL forks /
+joins an internal stream around every launch, and ProcessGroupNCCL launches async work on an internal (non-origin)
+stream - the two streams end up in each other's parallel-capture lists and hip::Stream::EndCapture recurses until the
+stack is gone.  RCCL launched on the capture's origin stream (the inline form, and backend "rccl") records.
 """
 import ctypes
 from typing import Dict, List, Tuple
