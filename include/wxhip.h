@@ -20,10 +20,10 @@
  *     DEVICE first (so that static fields still being produced on a non-blocking stream are complete,
  *     and no kernel is still reading constants about to be replaced).  Do not call them while a
  *     stream is being captured into a graph.
- *   - two evaluation-time entry points allocate ONCE per plan, on their first use: wx_euler3d_jvp_prepare (the cache of
- *     face values) and the stage pipeline (wx_euler3d_stage / wx_euler3d_extrap_pack_slot: the second interface slot).
- *     Make that first call outside a stream capture (graph.py warms every captured function up for this reason); later
- *     calls allocate nothing.
+ *   - what only some callers need is allocated by wx_euler3d_plan_reserve at setup time: the second interface slot of the
+ *     stage pipeline (wx_euler3d_stage / wx_euler3d_extrap_pack_slot) and the face-value cache of the prepared JVP
+ *     (wx_euler3d_jvp_prepare).  Without it those entry points return WX_ERR_INVALID; with it their FIRST call may sit inside
+ *     a stream capture like any later one.
  *   - device flags (nan_flag arguments) are only ever raised to 1 by plain stores from many threads - one
  *     value, so no atomic is needed - and never cleared by the library.
  *   - arrays are C-contiguous float64 (WX_F64) or complex128 (WX_C128, interleaved
@@ -152,6 +152,14 @@ wx_status wx_euler3d_plan_create_tile(wx_euler3d_plan** plan, int n, int H, int 
                                       int panel, const int on_panel_edge[4], const wx_dfr_ops* ops,
                                       const wx_euler3d_metric* metric);
 wx_status wx_euler3d_plan_destroy(wx_euler3d_plan* plan);
+/* Setup-time allocation of the buffers only some callers need (a bit mask); idempotent.  wx_euler3d_plan_reserved: what the
+ * plan holds. */
+typedef enum {
+    WX_RESERVE_STAGE = 1, /* second interface slot: wx_euler3d_stage with prepare_next / itf_in = 1, wx_euler3d_extrap_pack_slot(.., 1) */
+    WX_RESERVE_JVP = 2    /* face-value cache of the prepared complex-step JVP (WX_DUAL128 plans): wx_euler3d_jvp_prepare */
+} wx_reserve;
+wx_status wx_euler3d_plan_reserve(wx_euler3d_plan* plan, int what);
+int wx_euler3d_plan_reserved(const wx_euler3d_plan* plan);
 /* the dtype the plan was created with (WX_F64 when plan is NULL) */
 wx_dtype wx_euler3d_plan_dtype(const wx_euler3d_plan* plan);
 

@@ -495,9 +495,7 @@ def test_kiops_long_vector_build(built_lib, p, taus, monkeypatch):
     # the several-rank form of the same stages (products of the n-long parts all-reduced, the replicated augmented
     # components added once afterwards), taken here on one rank
     monkeypatch.delenv("WXHIP_KIOPS_LONG")
-    monkeypatch.setenv("WXHIP_KIOPS_SPLIT_TEST", "1")
-    w_split, st_split = kiops(taus, A, u, **args)
-    monkeypatch.delenv("WXHIP_KIOPS_SPLIT_TEST")
+    w_split, st_split = kiops(taus, A, u, _force_split=True, **args)
     assert st_split[:4] == st_long[:4] and float((w_split - w_long).abs().max()) <= 1e-12 * scale
     # exact: w(tau) = sum_k tau^k phi_k(tau lam) u_k
     import math

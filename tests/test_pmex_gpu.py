@@ -126,9 +126,7 @@ def test_pmex_device_kernels_split_form_and_exact_result(built_lib, p, taus, mon
     assert st_dev[:4] == st_cpu[:4] and st_dev[5:] == st_cpu[5:], (st_dev, st_cpu)
     scale = float(w_cpu.abs().max())
     assert float((w_dev.cpu() - w_cpu).abs().max()) <= 1e-11 * scale
-    monkeypatch.setenv("WXHIP_KIOPS_SPLIT_TEST", "1")
-    w_split, st_split = pmex(taus, A, u, **args)
-    monkeypatch.delenv("WXHIP_KIOPS_SPLIT_TEST")
+    w_split, st_split = pmex(taus, A, u, _force_split=True, **args)
     assert st_split[:4] == st_dev[:4] and float((w_split - w_dev).abs().max()) <= 1e-12 * scale
     # ... and the one-rank form with a host round trip per vector (the projector on the host, as the reference has it)
     # against the default, whose vectors are built by wx_pmex_vector with none

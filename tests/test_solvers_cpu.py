@@ -289,6 +289,18 @@ def _idle_rank_worker(rank, world, port, q):
         if hi > lo:
             refw = _phi_exact(A, u, 1.0)
             assert np.abs(w[0].numpy() - refw[lo:hi]).max() < 1e-8 * np.abs(refw).max()
+        # the basis-size query (_affordable_mmax) is collective: with the "small basis" shortcut at a size that the
+        # working ranks exceed and the idle ranks (n = 0) do not, every rank must still reach its all-reduce - decided
+        # from rank-local n they would part ways there and pair the MIN with the next SUM (or hang)
+        import wxfactory_amd.solvers as solvers_mod
+
+        solvers_mod._BASIS_CHECK_BYTES = 2000
+        for solver in (kiops, solvers_mod.pmex):
+            w2, stats2 = solver([1.0], lambda v: Arows @ gather(v), torch.from_numpy(u[:, lo:hi].copy()), tol=1e-10, m_init=8,
+                                mmin=8, mmax=48)
+            if hi > lo:
+                assert np.abs(w2[0].numpy() - refw[lo:hi]).max() < 1e-8 * np.abs(refw).max()
+        assert solvers_mod._affordable_mmax(hi - lo, 1, 48, 8, "cpu", torch.float64) == 48
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok", stats))
@@ -398,3 +410,54 @@ def test_restart_powers(solver):
         assert (err < 1e-9) if exact else (err > 1e-3), (p, powers, err)
     with pytest.raises(ValueError, match="restart_powers"):
         fn(taus, lambda v: torch.from_numpy(A) @ v, torch.from_numpy(u), restart_powers="other")
+
+
+def test_pmex_breakdown_option():
+    """A happy breakdown that is seen at once (u in a four-dimensional invariant subspace of a block-diagonal operator).
+    The reference stores the Hessenberg column of the vector that breaks down only after its test (pmex.py:225-233), so its
+    result misses the projections of the last product: breakdown="reference" (the default: drop-in behaviour) is off by
+    their weight, breakdown="exact" keeps the column and is exact.  Same statistics either way."""
+    from wxfactory_amd.solvers import pmex
+
+    rng = np.random.default_rng(3)
+    n = 40
+    A = np.zeros((n, n))
+    A[:4, :4] = 0.8 * rng.standard_normal((4, 4))
+    A[4:, 4:] = np.diag(rng.uniform(-2, -0.1, n - 4))
+    u = np.zeros((2, n))
+    u[0, :4], u[1, :4] = rng.standard_normal(4), rng.standard_normal(4)
+    ref = _phi_exact(A, u, 1.0)
+    out = {}
+    for mode in ("reference", "exact"):
+        w, st = pmex([1.0], lambda v: torch.from_numpy(A) @ v, torch.from_numpy(u), tol=1e-10, m_init=10, mmin=10, mmax=30,
+                     breakdown=mode)
+        out[mode] = (np.abs(w[0].numpy() - ref).max() / np.abs(ref).max(), st)
+    assert out["exact"][0] < 1e-13 and 1e-4 < out["reference"][0] < 1e-1, out
+    assert out["exact"][1] == out["reference"][1] and out["exact"][1][2] == 4       # four vectors, then the breakdown
+    with pytest.raises(ValueError, match="breakdown"):
+        pmex([1.0], lambda v: torch.from_numpy(A) @ v, torch.from_numpy(u), breakdown="other")
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_low_sync_gram_schmidt_breakdown_is_resolved(seed):
+    """The lagged norm of the one-synchronisation Gram-Schmidt is the root of <a, a> - s.s, a difference of two numbers of
+    size |a|^2: at a breakdown it is rounding of either sign and says nothing below sqrt(eps) |a| (taken at face value, half
+    of these seeds return a "norm" of 1e-8 and the row of noise is normalised).  A row that lies entirely in the span of
+    its finished predecessors - an invariant subspace of dimension three - must come back as vanished: 0.0."""
+    import wxfactory_amd.solvers as S
+
+    rng = np.random.default_rng(seed)
+    n, j = 200, 5
+    V = torch.zeros((8, n), dtype=torch.float64)
+    Qm, _ = np.linalg.qr(rng.standard_normal((n, 6)))
+    for k in range(j - 2):
+        V[k] = torch.from_numpy(Qm[:, k])                                   # finished rows 0 .. j-3
+    V[j - 2] = torch.from_numpy(Qm[:, : j - 2] @ rng.standard_normal(j - 2))   # row j-2: inside their span
+    V[j - 1] = torch.from_numpy(rng.standard_normal(n))
+    gs = S._LowSyncGramSchmidt(S._Basis(V), 8)
+    assert gs.step(j) == 0.0
+    assert np.isfinite(gs.R).all() and gs.R[j - 2, j - 2] == 0.0
+    # ... while a row with a genuine orthogonal part of 1e-7 of its length keeps it (to the accuracy the explicit norm has)
+    V[j - 2] = torch.from_numpy(Qm[:, : j - 2] @ rng.standard_normal(j - 2) + 1e-7 * Qm[:, j - 2])
+    gs = S._LowSyncGramSchmidt(S._Basis(V.clone()), 8)
+    assert abs(gs.step(j) - 1e-7) < 1e-12

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("WXHIP_LIB") or os.path.join(PKG, "lib", "libwxhip.so"
 WX_OK = 0
 WX_ERR_COMM = 5
 WX_COMM_ID_BYTES = 128
+WX_RESERVE_STAGE, WX_RESERVE_JVP = 1, 2
 WX_F64, WX_C128, WX_DUAL128 = 0, 1, 2
 WX_REGION_ALL, WX_REGION_INTERIOR, WX_REGION_BOUNDARY = 0, 1, 2
 WX_KERNEL_RHS, WX_KERNEL_STAGE, WX_KERNEL_JVP, WX_KERNEL_BATCH_RHS, WX_KERNEL_BATCH_JVP = 0, 1, 2, 3, 4
@@ -153,6 +154,8 @@ SIGNATURES = {
     "wx_cart2d_plan_destroy": (c_int, [c_void_p]),
     "wx_cart2d_rhs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "wx_euler3d_plan_dtype": (c_int, [c_void_p]),
+    "wx_euler3d_plan_reserve": (c_int, [c_void_p, c_int]),
+    "wx_euler3d_plan_reserved": (c_int, [c_void_p]),
     "wx_comm_rccl_version": (c_int, []),
     "wx_comm_unique_id": (c_int, [c_void_p]),
     "wx_comm_init_rank": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_int]),

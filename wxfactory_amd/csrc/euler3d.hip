@@ -2003,11 +2003,9 @@ wx_status wx_euler3d_jvp_prepare(wx_euler3d_plan* pl, const double* q, void* con
     if (!pl || !q) return fail(WX_ERR_INVALID, "wx_euler3d_jvp_prepare: null argument");
     if (pl->dtype != WX_DUAL128) return fail(WX_ERR_INVALID, "wx_euler3d_jvp_*: the plan must be WX_DUAL128");
     static_assert(NQ == 5, "the value cache holds the five prognostic face values");
-    if (!pl->face_val) {
-        hipError_t e = hipMalloc((void**)&pl->face_val, pl->itf_bytes / 2);
-        if (e != hipSuccess) return fail(WX_ERR_NOMEM, "hipMalloc(%zu bytes) for the face-value cache failed: %s",
-                                         pl->itf_bytes / 2, hipGetErrorString(e));
-    }
+    if (!pl->face_val)
+        return fail(WX_ERR_INVALID, "wx_euler3d_jvp_prepare: no face-value cache - call wx_euler3d_plan_reserve(plan, "
+                                    "WX_RESERVE_JVP) at setup time (evaluation entry points do not allocate)");
     EulerParams<double> P = make_params<double>(pl);
     P.itf = pl->face_val;
     P.q = q;
@@ -2141,10 +2139,32 @@ wx_status wx_euler3d_shifted_rhs_axpy2(wx_euler3d_plan* pl, const double* q, con
 
 static wx_status ensure_slot1(wx_euler3d_plan* pl) {
     if (pl->itf2) return WX_OK;
-    hipError_t e = hipMalloc(&pl->itf2, pl->itf_bytes);
-    if (e != hipSuccess) return fail(WX_ERR_NOMEM, "hipMalloc(%zu bytes) for the second interface buffer failed: %s",
-                                     pl->itf_bytes, hipGetErrorString(e));
+    return fail(WX_ERR_INVALID, "the stage pipeline needs the second interface buffer - call wx_euler3d_plan_reserve(plan, "
+                                "WX_RESERVE_STAGE) at setup time (evaluation entry points do not allocate)");
+}
+
+// Setup-time allocation of what only some callers need: the second interface slot of the stage pipeline, the face-value
+// cache of the prepared JVP.  Evaluation entry points never allocate; they refuse when their buffer is absent.
+wx_status wx_euler3d_plan_reserve(wx_euler3d_plan* pl, int what) {
+    if (!pl) return fail(WX_ERR_INVALID, "wx_euler3d_plan_reserve: null plan");
+    if (what & ~(WX_RESERVE_STAGE | WX_RESERVE_JVP)) return fail(WX_ERR_INVALID, "wx_euler3d_plan_reserve: unknown flags %d", what);
+    if ((what & WX_RESERVE_JVP) && pl->dtype != WX_DUAL128)
+        return fail(WX_ERR_INVALID, "wx_euler3d_plan_reserve: WX_RESERVE_JVP is for WX_DUAL128 plans");
+    if ((what & WX_RESERVE_STAGE) && !pl->itf2) {
+        hipError_t e = hipMalloc(&pl->itf2, pl->itf_bytes);
+        if (e != hipSuccess) return fail(WX_ERR_NOMEM, "hipMalloc(%zu bytes) for the second interface buffer failed: %s",
+                                         pl->itf_bytes, hipGetErrorString(e));
+    }
+    if ((what & WX_RESERVE_JVP) && !pl->face_val) {
+        hipError_t e = hipMalloc((void**)&pl->face_val, pl->itf_bytes / 2);
+        if (e != hipSuccess) return fail(WX_ERR_NOMEM, "hipMalloc(%zu bytes) for the face-value cache failed: %s",
+                                         pl->itf_bytes / 2, hipGetErrorString(e));
+    }
     return WX_OK;
+}
+
+int wx_euler3d_plan_reserved(const wx_euler3d_plan* pl) {
+    return pl ? ((pl->itf2 ? WX_RESERVE_STAGE : 0) | (pl->face_val ? WX_RESERVE_JVP : 0)) : 0;
 }
 
 wx_status wx_euler3d_extrap_pack_slot(wx_euler3d_plan* pl, const void* q, void* const send[4], int slot,

@@ -210,8 +210,22 @@ class Euler3DPlan:
                                                     z.data_ptr() if z is not None else None, out.data_ptr(), a, b, c, d,
                                                     region, st), "wx_euler3d_shifted_rhs_axpy2")
 
+    def reserve(self, what: int):
+        """Setup-time allocation of the second interface slot (_lib.WX_RESERVE_STAGE) / the face-value cache of the prepared
+        JVP (_lib.WX_RESERVE_JVP): wx_euler3d_plan_reserve.  The evaluation entry points never allocate; the host wrappers
+        below reserve on first use, which must therefore not sit inside a stream capture - or call this before."""
+        if (self.lib.wx_euler3d_plan_reserved(self._h) & what) == what:
+            return
+        if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("Euler3DPlan.reserve: this plan's buffers for the stage pipeline / prepared JVP do not exist "
+                               "yet and a stream capture is in progress - call reserve() (or RhsEuler3D.reserve()) before it")
+        with torch.cuda.device(self.device):
+            check(self.lib.wx_euler3d_plan_reserve(self._h, what), "wx_euler3d_plan_reserve")
+
     def extrap_pack_slot(self, q, send, slot: int):
         self._check_q(q)
+        if slot == 1:
+            self.reserve(_lib.WX_RESERVE_STAGE)
         self.faces_epoch += 1
         st = torch.cuda.current_stream(self.device).cuda_stream
         check(self.lib.wx_euler3d_extrap_pack_slot(self._h, q.data_ptr(), _ptr_array(send), slot, st),
@@ -235,6 +249,8 @@ class Euler3DPlan:
             if t is not None:
                 self._check_q(t)
         self.faces_epoch += int(bool(prepare_next))
+        if prepare_next or itf_in == 1:
+            self.reserve(_lib.WX_RESERVE_STAGE)
         st = torch.cuda.current_stream(self.device).cuda_stream
         check(self.lib.wx_euler3d_stage(self._h, q.data_ptr(), _ptr_array(halo), y.data_ptr() if y is not None else None,
                                         z.data_ptr() if z is not None else None, out.data_ptr(), a, b, c, d, region,
@@ -266,6 +282,7 @@ class Euler3DPlan:
     def jvp_prepare(self, q, send_val):
         """dual plans: cache the face values of the linearisation state q (and pack its value edge messages)."""
         self._check_real(q)
+        self.reserve(_lib.WX_RESERVE_JVP)
         st = torch.cuda.current_stream(self.device).cuda_stream
         check(self.lib.wx_euler3d_jvp_prepare(self._h, q.data_ptr(), _ptr_array(send_val), st), "wx_euler3d_jvp_prepare")
 
@@ -421,6 +438,22 @@ class RhsEuler3D(PanelRhs):
         b.extrap_pack(q)
         self._batched_phases(ex, lambda region: b.rhs(q, out, region, y, z, coef))
         return out
+
+    def reserve(self, stage: bool = False, jvp: bool = False, dtype=torch.float64):
+        """Allocate now what the stage pipeline (`stage`: second interface slot and edge-buffer set of `dtype`) and the
+        prepared complex-step JVP (`jvp`: face-value cache, value / tangent exchanges) need, so that their FIRST call can
+        already sit inside a HIP-graph capture (the evaluation entry points of the C ABI never allocate)."""
+        if stage:
+            for pl in self.plans_for(dtype).values():
+                pl.reserve(_lib.WX_RESERVE_STAGE)
+            st = self.__dict__.setdefault("_pipe", {}).setdefault(dtype, {"slot": 0, "ready": None, "ex": [self.exchange_for(dtype), None]})
+            if st["ex"][1] is None:
+                st["ex"][1] = self.new_exchange(self.edge_count * (2 if dtype.is_complex else 1))
+        if jvp:
+            for pl in self._jvp_plans().values():
+                pl.reserve(_lib.WX_RESERVE_JVP)
+            if getattr(self, "_ex_val", None) is None:
+                self._ex_val, self._ex_tan = self.new_exchange(self.edge_count), self.new_exchange(self.edge_count)
 
     def set_exp_filter(self, filter_matrix):
         """Give every plan (of every dtype in use) the nodal 1-D exponential filter for filtered stages."""

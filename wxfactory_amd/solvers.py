@@ -166,9 +166,17 @@ class _LowSyncGramSchmidt:
         s = ga[: j - 2]                       # <V[k], a>, k < j-2: what the first pass left in a
         R[: j - 1, j - 1] = gb[: j - 1]
         d = ga[j - 2] - s @ s
+        # d is a difference of two numbers of size |a|^2: it resolves the orthogonal part of row j-2 down to about
+        # sqrt(eps) of the row's length and no further - below that it is rounding, of either sign.  When it falls under
+        # _SUSPECT of |a|^2 the squared norm of the corrected row is formed explicitly (one extra pass over j-1 rows and
+        # one more reduction; rare: only near a breakdown), every rank taking the same branch from all-reduced numbers.
+        if d == d and d <= _SUSPECT * ga[j - 2]:
+            r = a - (torch.as_tensor(s, dtype=a.dtype, device=a.device) @ V[: j - 2] if j > 2 else 0.0)
+            d = float(_allreduce(torch.dot(r, r).reshape(1), self.group)[0])
         # (happy) breakdown: nothing but rounding is left of row j-2 once it is orthogonal to its predecessors - the
-        # Krylov space is exhausted (A = c I after one vector).  The lagged norm is then taken as exactly zero, the
-        # Hessenberg column is completed without dividing by it, and the caller ends the cycle with the rows it has.
+        # Krylov space is exhausted (A = c I after one vector; an invariant subspace).  The lagged norm is then taken as
+        # exactly zero, the Hessenberg column is completed without dividing by it, and the caller ends the cycle with
+        # the rows it has.
         if d == d and d <= _BREAKDOWN * _BREAKDOWN * ga[j - 2]:
             R[j - 2, j - 2] = 0.0
             if j > 2:
@@ -192,6 +200,7 @@ class _LowSyncGramSchmidt:
 
 
 _BREAKDOWN = 1e-14  # low-sync Gram-Schmidt: a row whose orthogonal part is below this fraction of its length has vanished
+_SUSPECT = 1e-12    # ... and below this fraction of |a|^2 the difference <a,a> - s.s no longer says how large that part is
 _REORTH = 0.1  # fgmres: re-orthogonalise when |w - V V^T w| < _REORTH |w| (orthogonality kept to ~1e-15 / _REORTH)
 
 
@@ -613,16 +622,21 @@ def _affordable_mmax(n: int, p: int, mmax: int, mmin: int, dev, dtype, group=Non
     dev = torch.device(dev)
     limit = mmax
     row_bytes = (n + p) * 8
-    if (mmax + 9) * row_bytes < _BASIS_CHECK_BYTES:
+    several = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    # n is the RANK-LOCAL length: ranks own different numbers of tiles (an idle rank has n = 0), so "is my basis small" is
+    # not a decision every rank takes alike - and the all-reduce below is collective.  Over several ranks every rank
+    # enters it, a rank with a small basis contributing mmax; one rank alone skips the query for small bases.
+    small = (mmax + 9) * row_bytes < _BASIS_CHECK_BYTES
+    if small and not several:
         return mmax   # (a small basis: not worth the allocator statistics, which cost a millisecond)
-    if dev.type == "cuda":
+    if dev.type == "cuda" and not small:
         free, _ = torch.cuda.mem_get_info(dev)
         free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)   # (blocks the caching allocator can reuse)
         row = (n + p) * torch.empty((), dtype=dtype).element_size()
         # beside the basis: the operator's own temporaries, the result rows, the finish workspace - eight vectors' worth
         rows = (free - 8 * row) // row
         limit = int(min(mmax, rows - 1))
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if several:
         t = torch.tensor([limit], dtype=torch.int64, device=dev if dev.type == "cuda" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
         limit = int(t.item())
@@ -737,7 +751,7 @@ def _combine_rows(basis: "_Basis", Vd: torch.Tensor, j: int, n: int, coef) -> to
 
 def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int = 10, mmin: int = 10, mmax: int = 128,
           iop: int = 2, task1: bool = False, group=None, workspace: Optional[KiopsWorkspace] = None, graph_token=None,
-          restart_powers: str = "reference"):
+          restart_powers: str = "reference", _force_split: bool = False):
     """w(i) = sum_k phi_k(tau_i A) u[k]  by the adaptive Krylov method with incomplete orthogonalisation.
 
     Same signature, adaptivity rules and `stats` tuple as reference wx_factory/solvers/kiops.py:10-347
@@ -775,7 +789,7 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
     Vd, basis, Ht, nrm2 = ws.Vd, ws.basis, ws.Ht, ws.nrm2
     H = np.zeros((mmax + 1, mmax + 1))
     split = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-    if os.environ.get("WXHIP_KIOPS_SPLIT_TEST") == "1":
+    if _force_split:
         split = True   # (tests: take the several-rank code paths - reductions completed after an all-reduce - on one rank)
     # HIP graphs of whole passes: single rank (no collective inside), launch-bound sizes, an operator the caller vouches for
     use_graphs = (workspace is not None and graph_token is not None and not split and Vd.is_cuda
@@ -971,7 +985,8 @@ def _norm_after_projection(gram_col, j: int):
 
 
 def pmex(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, delta: float = 1.2, m_init: int = 10, mmin: int = 10,
-         mmax: int = 128, reuse_info: bool = True, task1: bool = False, group=None, restart_powers: str = "reference"):
+         mmax: int = 128, reuse_info: bool = True, task1: bool = False, group=None, restart_powers: str = "reference",
+         breakdown: str = "reference", _force_split: bool = False):
     """w(i) = sum_k phi_k(tau_i A) u[k]  by the adaptive Krylov method with FULL orthogonalisation at one
     synchronisation per vector: the schema's default `exponential_solver` (config-format.json; case6.ini,
     density_current.ini), reference wx_factory/solvers/pmex.py:8-374 - same signature, decisions and `stats`
@@ -982,9 +997,14 @@ def pmex(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, delta: float 
     all-reduce of that (j+1) x 2 block when the vectors are split over ranks (the replicated augmented components
     enter once, afterwards), one fused update (wx_multi_axpy) and the scaling.  The host holds what the reference
     holds there too: the projector's triangular factors, the Hessenberg matrix and its exponential.
-    `restart_powers`: see _restart_tail ("reference" by default)."""
+    `restart_powers`: see _restart_tail ("reference" by default).
+    `breakdown`: what the Hessenberg matrix holds at a happy breakdown - "reference" (default): the column of the vector that
+    broke down is left out, as pmex.py:225-233 stores it only after the test (the result then misses the projections of the
+    last product: 1e-4 on the invariant-subspace problem of tests/golden/solvers_dense.npz); "exact": the column is kept."""
     import numpy as np
 
+    if breakdown not in ("reference", "exact"):
+        raise ValueError("breakdown must be 'reference' or 'exact'")
     dev, dtype = u.device, u.dtype
     tau_out = [float(t) for t in tau_out]
     ppo, n = u.shape
@@ -993,7 +1013,7 @@ def pmex(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, delta: float 
         p = 1
         u = torch.cat((u, torch.zeros((1, n), dtype=dtype, device=dev)))
     split = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-    if os.environ.get("WXHIP_KIOPS_SPLIT_TEST") == "1":
+    if _force_split:
         split = True   # (tests: the several-rank code paths - reductions completed after an all-reduce - on one rank)
     mmax = _affordable_mmax(n, p, mmax, mmin, dev, dtype, group, "pmex")
     m = max(mmin, min(m_init, mmax))
@@ -1078,6 +1098,8 @@ def pmex(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, delta: float 
                 if Hh[c - j0, c + 1] < tol:   # happy breakdown at vector c + 1: the rest of the pass is void
                     happy = True
                     j = c + 1
+                    if breakdown == "reference":
+                        H[: c + 1, c] = 0.0   # pmex.py:225-233 stores the column only after its breakdown test
                     break
                 H[c + 1, c] = Hh[c - j0, c + 1]
                 krystep += 1
@@ -1096,11 +1118,13 @@ def pmex(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, delta: float 
             # (The reference stores this column only after its breakdown test, pmex.py:225-233: at a breakdown the
             # projections of A v_{j-1} on the basis are then missing from H, and the result is wrong by their weight -
             # 1e-4 on the invariant-subspace problem of tests/golden/solvers_dense.npz when the breakdown is seen at
-            # once.  Stored first here; nothing else differs.)
-            H[:j, j - 1] = sol
+            # once.  breakdown = "reference" (default) does the same; "exact" keeps the column.)
             if nrm_j < tol:   # happy breakdown: the Krylov space is invariant
+                if breakdown == "exact":
+                    H[:j, j - 1] = sol
                 happy = True
                 break
+            H[:j, j - 1] = sol
             if not scaled:
                 Vd[j] /= nrm_j
             H[j, j - 1] = nrm_j
