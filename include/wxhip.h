@@ -78,6 +78,10 @@ const char* wx_version(void);
 const char* wx_build_info(void);
 /* number of HIP devices visible; <0 on error.  Does not create a context. */
 int wx_device_count(void);
+/* dst = src, `bytes` of them (a multiple of 16, 16-byte aligned device buffers), as one streaming kernel - 16 bytes per lane,
+ * every wave slot of the chip: the measured read-once / write-once rate a kernel's roofline fraction is put beside
+ * (bench.py: roofline.ceiling).  Moves 2 x bytes through HBM. */
+wx_status wx_stream_copy(const void* src, void* dst, size_t bytes, wx_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * The reference's per-evaluation timing row without torch: RHS.timestamps / retrieve_last_times (rhs/rhs.py:39-41, 68-118;

@@ -23,7 +23,7 @@ def build(force: bool = False) -> str:
     src = os.path.join(HERE, "c", "euler3d_port.cpp")
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
         tmp = f"{LIB}.{os.getpid()}.tmp"
-        subprocess.check_call(["g++", "-O3", "-march=native", "-fopenmp", "-shared", "-std=c++17", "-fPIC", src, "-o", tmp])
+        subprocess.check_call(["g++", "-O3", "-march=native", "-fno-math-errno", "-fopenmp", "-shared", "-std=c++17", "-fPIC", src, "-o", tmp, "-lmvec", "-lm"])
         os.replace(tmp, LIB)
     return LIB
 
@@ -59,7 +59,8 @@ def load():
                 f.write(want)
             os.replace(f"{stamp}.{os.getpid()}.tmp", stamp)
         _lib = ctypes.CDLL(LIB)
-        for fn in ("wxo_euler3d_extrapolate", "wxo_euler3d_rhs", "wxo_euler3d_extrapolate_c", "wxo_euler3d_rhs_c"):
+        for fn in ("wxo_euler3d_extrapolate", "wxo_euler3d_rhs", "wxo_euler3d_extrapolate_c", "wxo_euler3d_rhs_c",
+                   "wxo_euler3d_extrapolate_generic", "wxo_euler3d_rhs_generic"):
             getattr(_lib, fn).restype = ctypes.c_int
     return _lib
 
@@ -77,9 +78,12 @@ class Euler3DPortC(Euler3DOracle):
     float64 or complex128 states (the complex instantiation follows NumPy's abs / maximum rules, so that
     Im R(Q + i eps v) / eps is the reference's complex-step JVP)."""
 
-    def __init__(self, *args, threads: int = 0, **kw):
+    def __init__(self, *args, threads: int = 0, generic: bool = False, **kw):
+        """generic: float64 calls take the scalar, type-generic instantiation (what complex128 states always run) instead
+        of the vectorised float64 path - the cross-check of the two (tests/test_oracle_c.py)."""
         super().__init__(*args, **kw)
         self.threads = int(threads)
+        self.generic = bool(generic)
         self.lib = load()
         self._mc = None   # contiguous copies of the metric, made on the first rhs() (extrapolation needs none)
         self._ops = [_c(x) for x in (self.em, self.ep, self.D, self.C, self.HF)]
@@ -89,7 +93,8 @@ class Euler3DPortC(Euler3DOracle):
         dt = numpy.complex128 if numpy.iscomplexobj(q) else numpy.float64
         q = _c(q, dt)
         itf = [numpy.empty((5, V, H, H, 2 * n * n), dtype=dt) for _ in range(3)]
-        fn = self.lib.wxo_euler3d_extrapolate_c if dt is numpy.complex128 else self.lib.wxo_euler3d_extrapolate
+        fn = self.lib.wxo_euler3d_extrapolate_c if dt is numpy.complex128 else (
+            self.lib.wxo_euler3d_extrapolate_generic if self.generic else self.lib.wxo_euler3d_extrapolate)
         rc = fn(n, H, V, _p(self._ops[0]), _p(self._ops[1]), _p(q), _p(itf[0]), _p(itf[1]), _p(itf[2]), self.threads)
         assert rc == 0
         return itf
@@ -110,7 +115,8 @@ class Euler3DPortC(Euler3DOracle):
             self._damp = (_c(m["damp_coef"]), _c(m["damp_uref"])) if self.case_number in (21, 22) else (None, None)
         mc = self._mc
         out = numpy.empty_like(q)
-        fn = self.lib.wxo_euler3d_rhs_c if dt is numpy.complex128 else self.lib.wxo_euler3d_rhs
+        fn = self.lib.wxo_euler3d_rhs_c if dt is numpy.complex128 else (
+            self.lib.wxo_euler3d_rhs_generic if self.generic else self.lib.wxo_euler3d_rhs)
         rc = fn(
             n, H, V, self.case_number, _p(self._ops[2]), _p(self._ops[3]), _p(self._ops[4]), _p(q), _p(itf[0]), _p(itf[1]),
             _p(itf[2]), _p(halo[0]), _p(halo[1]), _p(halo[2]), _p(halo[3]), _p(mc["sqrtG_new"]), _p(mc["h_contra_new"]),

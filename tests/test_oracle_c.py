@@ -75,3 +75,23 @@ def test_thread_count_does_not_change_the_result():
     a = make_port(g, p, threads=1).rhs(g.q(p), g.halo(p))
     b = make_port(g, p, threads=4).rhs(g.q(p), g.halo(p))
     assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["euler3d_c31p_n8_h2_v2", "euler3d_c21p_n4_h3_v4", "euler3d_c31p_n5_h2_v1", "euler3d_c31p_n2_h4_v3"])
+def test_vectorised_float64_path_equals_the_generic_one(name):
+    """The float64 entry points run a path written for the vector units (structure-of-arrays scratch, `omp simd` loops,
+    exp / log through libmvec: <= 4 ulp) - what bench.py times as the CPU baseline.  Same arithmetic as the scalar,
+    type-generic instantiation that the complex entry points use: faces and R agree to rounding (and both are held to the
+    reference's values above)."""
+    g = golden(name)
+    for p in g.metric_panels():
+        fast, slow = make_port(g, p), make_port(g, p)
+        slow.generic = True
+        fa, fb = fast.extrapolate(g.q(p)), slow.extrapolate(g.q(p))
+        for a, b in zip(fa, fb):
+            assert np.abs(a - b).max() <= 1e-14 * np.abs(b).max()
+        Ra, Rb = fast.rhs(g.q(p), g.halo(p), itf=fa), slow.rhs(g.q(p), g.halo(p), itf=fb)
+        want = {}
+        make_oracle(g, p).rhs(g.q(p), g.halo(p), want=want)
+        scale = np.maximum(var_max(Rb), make_oracle(g, p).cancel_scale(want))
+        assert (var_err(Ra, Rb) <= 1e-13 * scale).all(), (name, p, var_err(Ra, Rb) / scale)

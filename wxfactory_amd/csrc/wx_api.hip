@@ -35,6 +35,28 @@ int wx_device_count(void) {
 
 }  // extern "C"
 
+// ---- the streaming copy a roofline fraction is put beside: what this part sustains on a pure read-once / write-once
+// pattern (16 bytes per lane, grid-stride, one pass) - the achievable side of "achieved vs 8 TB/s"
+__global__ __launch_bounds__(256) void wx_stream_copy_kernel(const double2* __restrict__ src, double2* __restrict__ dst, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+
+extern "C" wx_status wx_stream_copy(const void* src, void* dst, size_t bytes, wx_stream stream) {
+    if (!src || !dst) return wx::fail(WX_ERR_INVALID, "wx_stream_copy: null argument");
+    if (bytes % 16 != 0 || ((uintptr_t)src | (uintptr_t)dst) % 16 != 0)
+        return wx::fail(WX_ERR_INVALID, "wx_stream_copy: buffers and size must be multiples of 16 bytes");
+    if (bytes == 0) return WX_OK;
+    WX_STREAM(st, stream);
+    const size_t n16 = bytes / 16;
+    size_t blocks = (n16 + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;   // 32 workgroups of 4 waves per CU: every wave slot of the chip, several lines each
+    hipLaunchKernelGGL(wx_stream_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const double2*>(src),
+                       static_cast<double2*>(dst), n16);
+    WX_HIP_TRY(hipGetLastError());
+    return WX_OK;
+}
+
 // ---- the nine-stamp timing row of the reference's RHS (rhs/rhs.py:39-41, 68-118) for callers without torch
 struct wx_phase_timer {
     hipEvent_t ev[9];

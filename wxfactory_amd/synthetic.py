@@ -85,8 +85,14 @@ def euler3d_metric(n: int, H: int, V: int, panel: int, device, seed: int = 20250
     return m
 
 
-def euler3d_state(n: int, H: int, V: int, panel: int, device, seed: int = 20250824, ztop: float = 10000.0
-                  ) -> torch.Tensor:
+def euler3d_state(n: int, H: int, V: int, panel: int, device, seed: int = 20250824, ztop: float = 10000.0,
+                  row: int = 0, col: int = 0, k: int = 1) -> torch.Tensor:
+    """State of one tile: H x H x V elements.  With k > 1 the tile is the (row, col) one of the k x k tiles of `panel`
+    (row along x2, col along x1) and holds the corresponding cut of the PANEL's state - the same sphere whatever the
+    decomposition, so that results of different decompositions can be compared (bench.py: checksum)."""
+    if k > 1:
+        full = euler3d_state(n, H * k, V, panel, device, seed, ztop)
+        return full[:, :, row * H:(row + 1) * H, col * H:(col + 1) * H, :].contiguous()
     gen = torch.Generator(device=device)
     gen.manual_seed(seed + 1000 * panel + 2)
     n3 = n**3
