@@ -390,6 +390,26 @@ wx_status wx_sw_batch_rhs(wx_sw_batch* batch, const void* q, void* rhs, size_t p
 wx_status wx_sw_batch_rhs_axpy(wx_sw_batch* batch, const void* q, const void* y, void* out, size_t panel_stride, double a,
                                double b, double c, wx_region region, wx_stream stream);
 
+/* Stage pipeline for explicit Runge-Kutta loops (integrators/tvdrk3.py:12-19 over rhs/rhs_sw.py:38-240), the twin of
+ * wx_euler3d_stage: the plan owns two interface buffers (slot 1 after wx_sw_plan_reserve(plan, WX_RESERVE_STAGE): setup
+ * time).  wx_sw_stage evaluates  out = a*y + b*q + c*R(q)  reading q's faces from slot itf_in and - prepare_next != 0 -
+ * extrapolates `out` (the next stage's state, still in registers) to the element faces of the OTHER slot and packs its
+ * tile-edge lines into next_send[e]: the next stage needs no wx_sw_extrap_pack (at the benchmark's S7 size the
+ * extrapolation launch is a fifth of an evaluation).  next_send must not be the buffers the current halos alias.
+ * wx_sw_extrap_pack_slot: wx_sw_extrap_pack into a chosen slot (pipeline start-up).
+ * Batches: wx_sw_batch_create_pipelined fixes both edge-buffer sets of every tile (send / halo: slot 0, send2 / halo2:
+ * slot 1; the plans must have been reserved); wx_sw_batch_stage reads slot itf_in and prepares the other one. */
+wx_status wx_sw_plan_reserve(wx_sw_plan* plan, int what);
+wx_status wx_sw_extrap_pack_slot(wx_sw_plan* plan, const void* q, void* const send[4], int slot, wx_stream stream);
+wx_status wx_sw_stage(wx_sw_plan* plan, const void* q, const void* const halo[4], const void* y, void* out, double a,
+                      double b, double c, wx_region region, int itf_in, void* const next_send[4], int prepare_next,
+                      wx_stream stream);
+wx_status wx_sw_batch_create_pipelined(wx_sw_batch** batch, wx_sw_plan* const plans[], int count, void* const send[][4],
+                                       const void* const halo[][4], void* const send2[][4], const void* const halo2[][4]);
+wx_status wx_sw_batch_extrap_pack_slot(wx_sw_batch* batch, const void* q, size_t panel_stride, int slot, wx_stream stream);
+wx_status wx_sw_batch_stage(wx_sw_batch* batch, const void* q, const void* y, void* out, size_t panel_stride, double a,
+                            double b, double c, wx_region region, int itf_in, int prepare_next, wx_stream stream);
+
 /* ------------------------------------------------------------------------------------------
  * Panel-edge halo exchange over RCCL point-to-point (xGMI inside a node).
  * Replaces  process_topology.py:259-261 (Create_dist_graph_adjacent), :269-386 (start_exchange_scalars / _vectors:

@@ -207,6 +207,49 @@ def test_tiles_of_a_24_rank_decomposition(built_lib):
         assert (var_err(R[t], ref) <= TOL * scale).all(), t
 
 
+@pytest.mark.parametrize("topo", [False, True])
+def test_stage_pipeline_equals_the_fused_stages(built_lib, topo):
+    """wx_sw_stage / wx_sw_batch_stage: the stage's kernel extrapolates its own output (the next stage's state) to the faces
+    and packs its edge lines, so the next stage has no extrapolation launch.  Three SSP-RK3 stages that way equal the
+    fused stages with a separate extrapolation (RhsShallowWater.axpy) to rounding - per tile and batched, flat and with
+    topography, aliasing halos and halos that travel (loopback exchange behind the C ABI: INTERIOR / BOUNDARY launches each
+    write the faces of their own elements) - and a state that was modified in between is extrapolated afresh."""
+    from wxfactory_amd.exchange import PanelExchange, RcclComm
+    from wxfactory_amd.integrators import Tvdrk3
+    from wxfactory_amd.rhs_sw import RhsShallowWater
+
+    g = golden_sw("sw_c5_n4_h3" if topo else "sw_c2p_n8_h3")
+    plans = {p: _plan(g, p) for p in range(6)}
+    Q = torch.stack([_dev(g.q(p)) for p in range(6)])
+    dt = 50.0
+    plain = RhsShallowWater(plans)
+    P1 = plain.axpy(Q, None, 0.0, 1.0, dt)
+    P2 = plain.axpy(P1, Q, 0.75, 0.25, 0.25 * dt)
+    P3 = plain.axpy(P2, Q, 1.0 / 3.0, 2.0 / 3.0, (2.0 / 3.0) * dt)
+    scale = P3.abs().amax(dim=(0, 2, 3), keepdim=True)
+    comm = RcclComm(0, 1, device=DEV)
+    for batched in (True, False):
+        for loop in (False, True):
+            ex = PanelExchange(plans[0].edge_count, DEV, rank=0, world_size=1, loopback=loop, backend="rccl" if loop else "torch",
+                               comm=comm if loop else None)
+            piped = RhsShallowWater(plans, ex)
+            piped.batched = batched
+            Q1 = piped.stage(Q, None, 0.0, 1.0, dt)
+            Q2 = piped.stage(Q1, Q, 0.75, 0.25, 0.25 * dt)
+            Q3 = piped.stage(Q2, Q, 1.0 / 3.0, 2.0 / 3.0, (2.0 / 3.0) * dt)
+            torch.cuda.synchronize()
+            assert ((Q3 - P3).abs() <= 1e-14 * scale).all(), (batched, loop)
+            # the prepared faces belong to Q3 as returned: an in-place change is seen (version counter) and extrapolated afresh
+            Q3.mul_(1.0 + 1e-3)
+            Q4 = piped.stage(Q3, None, 0.0, 1.0, dt)
+            want = plain.axpy(Q3, None, 0.0, 1.0, dt)
+            torch.cuda.synchronize()
+            assert ((Q4 - want).abs() <= 1e-14 * scale).all(), (batched, loop)
+            assert Tvdrk3(piped).pipeline
+    torch.cuda.synchronize()
+    comm.close()
+
+
 @pytest.mark.parametrize("name", ["sw_rk3_c6_n5_h4", "sw_rk3_c6_n8_h3"])
 @pytest.mark.parametrize("fused,batched", [(True, True), (True, False), (False, True)])
 def test_rk3_time_loop_matches_reference(name, fused, batched, built_lib):
@@ -219,7 +262,8 @@ def test_rk3_time_loop_matches_reference(name, fused, batched, built_lib):
     g = golden_sw(name)
     rhs = RhsShallowWater({p: _plan(g, p) for p in range(6)})
     rhs.batched = batched
-    stepper = Tvdrk3(rhs, fused=fused)
+    stepper = Tvdrk3(rhs, fused=fused)   # (fused: the stage pipeline - wx_sw_stage / wx_sw_batch_stage)
+    assert stepper.pipeline == fused
     Q0 = torch.stack([_dev(g.q(p)) for p in range(6)])
     dt, nsteps = float(g["meta/rk3_dt"]), int(g["meta/rk3_steps"])
     stack = lambda key: np.stack([g[f"p{p}/{key}"] for p in range(6)])  # noqa: E731

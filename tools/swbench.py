@@ -58,3 +58,29 @@ for _ in range(reps):
 ev[1].record()
 torch.cuda.synchronize()
 print(f"S7 GPU time per evaluation (events around {reps} back-to-back evaluations): {ev[0].elapsed_time(ev[1])/reps*1e3:.1f} us")
+
+# SSP-RK3 step (integrators/tvdrk3.py:12-19): fused stages with a separate extrapolation launch per stage, against the stage
+# pipeline (wx_sw_batch_stage: the stage's kernel extrapolates its own output; 3 launches per step instead of 6)
+from wxfactory_amd.integrators import Tvdrk3  # noqa: E402
+
+
+def step_us(stepper, reps=100):
+    q = Q
+    for _ in range(5):
+        q = stepper.step(q, 1.0)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        q = stepper.step(q, 1.0)
+    b.record()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(q).all())
+    return a.elapsed_time(b) / reps * 1e3
+
+
+fused, piped = Tvdrk3(RhsShallowWater(plans), pipeline=False), Tvdrk3(RhsShallowWater(plans))
+assert piped.pipeline and not fused.pipeline
+tf, tp = step_us(fused), step_us(piped)
+print(f"S7 SSP-RK3 step: fused stages {tf:.1f} us, stage pipeline {tp:.1f} us ({tf / tp:.2f} x)  -> per stage {tp / 3:.1f} us = "
+      f"{156.0 * 6 * H * H * n * n / (tp / 3 * 1e-6) / 1e9:.1f} GB/s on 156 B/point")

@@ -46,6 +46,10 @@ struct SwDyn {
     int axpy;
     const T* y;
     double ca, cb, cc;
+    // stage pipeline: `slot` = the interface buffer / edge-buffer set that holds the faces of q (extrapolation: that it
+    // writes); prepare != 0: the RHS kernel also extrapolates ITS OUTPUT - the next stage's state - to the faces of the
+    // OTHER slot and packs its tile-edge lines into the other send set (no separate extrapolation pass for the next stage)
+    int slot, prepare;
 };
 
 template <typename T>
@@ -54,6 +58,10 @@ struct SwParams {
     T* itf;  // [elem][4 faces W,E,S,N][3 vars][N]
     const T *halo_s, *halo_n, *halo_w, *halo_e;
     T *send_s, *send_n, *send_w, *send_e;
+    // slot 1 of the stage pipeline (wx_sw_plan_reserve; null until then)
+    T* itf2;
+    const T *halo2_s, *halo2_n, *halo2_w, *halo2_e;
+    T *send2_s, *send2_n, *send2_w, *send2_e;
     const double *sg, *h11, *h12, *h21, *h22;
     const double *c101, *c102, *c111, *c112, *c201, *c202, *c212, *c222;
     const double *sgi, *sgj, *h11i, *h21i, *h12j, *h22j;
@@ -97,11 +105,78 @@ __device__ __forceinline__ Elem2 decode_elem2(int slot, int count, int region, i
     return r;
 }
 
+// the interface buffer and the edge buffers of one slot
+template <typename T>
+struct SwSlot {
+    T* itf;
+    const T *halo_s, *halo_n, *halo_w, *halo_e;
+    T *send_s, *send_n, *send_w, *send_e;
+};
+template <typename T>
+__device__ __forceinline__ SwSlot<T> sw_slot(const SwParams<T>& P, int slot) {
+    if (slot == 1) return {P.itf2, P.halo2_s, P.halo2_n, P.halo2_w, P.halo2_e, P.send2_s, P.send2_n, P.send2_w, P.send2_e};
+    return {P.itf, P.halo_s, P.halo_n, P.halo_w, P.halo_e, P.send_s, P.send_n, P.send_w, P.send_e};
+}
+
 // ------------------------------------------------------------------------------------------------
+// rhs_sw.py:76-117 on nodal values staged in LDS (h + hsurf, hu1, hu2): one thread per face point extrapolates, writes
+// the interface buffer and - on outward tile-edge faces - the rotated / flipped edge line.  Shared by the extrapolation
+// kernel and by the RHS kernel's stage-pipeline epilogue.
+template <int N, typename T>
+__device__ __forceinline__ void sw_extrap_faces(const SwParams<T>& P, T (*fld)[Cfg2<N>::EPB * Cfg2<N>::LE], int slot0, int count,
+                                                int region, const SwSlot<T>& S) {
+    using C = Cfg2<N>;
+    constexpr int EPB = C::EPB, BS = C::BS;
+    const int tid = threadIdx.x;
+    const int H = P.H;
+    for (int fi = tid; fi < EPB * 4 * N; fi += BS) {
+        const int le = fi / (4 * N);
+        const int r = fi % (4 * N);
+        const int f = r / N, k = r % N;
+        const Elem2 el = decode_elem2(slot0 + le, count, region, H);
+        if (!el.valid) continue;
+        const int d = f >> 1, plus = f & 1;
+        const int base = d == 0 ? C::lidx(k, 0) : C::lidx(0, k);
+        const int stride = d == 0 ? 1 : C::NP;
+        const double* w = plus ? P.K->ep : P.K->em;
+        T s[3] = {T(0.0), T(0.0), T(0.0)};
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+            const double wm = w[m];
+#pragma unroll
+            for (int v = 0; v < 3; ++v) s[v] += wm * fld[v][le * C::LE + base + m * stride];
+        }
+        T* dst = S.itf + ((size_t)el.e * 4 + f) * 3 * N + k;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) dst[v * N] = s[v];
+
+        int edge = -1, along = 0;
+        double X = 0.0;
+        if (d == 0 && ((plus && el.ei == H - 1) || (!plus && el.ei == 0))) {
+            edge = plus ? E_E : E_W;
+            along = el.ej;
+            X = P.bwe[el.ej * N + k];
+        } else if (d == 1 && ((plus && el.ej == H - 1) || (!plus && el.ej == 0))) {
+            edge = plus ? E_N : E_S;
+            along = el.ei;
+            X = P.bsn[el.ei * N + k];
+        }
+        T* sendp = edge == E_S ? S.send_s : (edge == E_N ? S.send_n : (edge == E_W ? S.send_w : S.send_e));
+        if (edge >= 0 && sendp != nullptr) {
+            rotate_contra<T>(P.K->rot[edge], X, s[1], s[2]);
+            int pos = along * N + k;
+            if (P.K->flip[edge]) pos = H * N - 1 - pos;
+            const size_t vs = (size_t)H * N;
+#pragma unroll
+            for (int v = 0; v < 3; ++v) sendp[v * vs + pos] = s[v];
+        }
+    }
+}
+
 template <int N, typename T>
 __device__ __forceinline__ void sw_extrap_body(const SwParams<T> P, const SwDyn<T> D) {
     using C = Cfg2<N>;
-    constexpr int N2 = C::N2, EPB = C::EPB, BS = C::BS;
+    constexpr int N2 = C::N2, EPB = C::EPB;
     __shared__ T fld[3][EPB * C::LE];
     const int tid = threadIdx.x;
     const int H = P.H;
@@ -120,55 +195,15 @@ __device__ __forceinline__ void sw_extrap_body(const SwParams<T> P, const SwDyn<
         }
     }
     __syncthreads();
-    for (int fi = tid; fi < EPB * 4 * N; fi += BS) {
-        const int le = fi / (4 * N);
-        const int r = fi % (4 * N);
-        const int f = r / N, k = r % N;
-        const Elem2 el = decode_elem2(blockIdx.x * EPB + le, P.nelem, WX_REGION_ALL, H);
-        if (!el.valid) continue;
-        const int d = f >> 1, plus = f & 1;
-        const int base = d == 0 ? C::lidx(k, 0) : C::lidx(0, k);
-        const int stride = d == 0 ? 1 : C::NP;
-        const double* w = plus ? P.K->ep : P.K->em;
-        T s[3] = {T(0.0), T(0.0), T(0.0)};
-#pragma unroll
-        for (int m = 0; m < N; ++m) {
-            const double wm = w[m];
-#pragma unroll
-            for (int v = 0; v < 3; ++v) s[v] += wm * fld[v][le * C::LE + base + m * stride];
-        }
-        T* dst = P.itf + ((size_t)el.e * 4 + f) * 3 * N + k;
-#pragma unroll
-        for (int v = 0; v < 3; ++v) dst[v * N] = s[v];
-
-        int edge = -1, along = 0;
-        double X = 0.0;
-        if (d == 0 && ((plus && el.ei == H - 1) || (!plus && el.ei == 0))) {
-            edge = plus ? E_E : E_W;
-            along = el.ej;
-            X = P.bwe[el.ej * N + k];
-        } else if (d == 1 && ((plus && el.ej == H - 1) || (!plus && el.ej == 0))) {
-            edge = plus ? E_N : E_S;
-            along = el.ei;
-            X = P.bsn[el.ei * N + k];
-        }
-        T* sendp = edge == E_S ? P.send_s : (edge == E_N ? P.send_n : (edge == E_W ? P.send_w : P.send_e));
-        if (edge >= 0 && sendp != nullptr) {
-            rotate_contra<T>(P.K->rot[edge], X, s[1], s[2]);
-            int pos = along * N + k;
-            if (P.K->flip[edge]) pos = H * N - 1 - pos;
-            const size_t vs = (size_t)H * N;
-#pragma unroll
-            for (int v = 0; v < 3; ++v) sendp[v * vs + pos] = s[v];
-        }
-    }
+    sw_extrap_faces<N, T>(P, fld, blockIdx.x * EPB, P.nelem, WX_REGION_ALL, sw_slot<T>(P, D.slot));
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int N, typename T>
+template <int N, typename T, bool PIPE = false>
 __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> D) {
     using C = Cfg2<N>;
     constexpr int N2 = C::N2, EPB = C::EPB, BS = C::BS;
+    const SwSlot<T> S = sw_slot<T>(P, PIPE ? D.slot : 0);   // (the plain kernel reads slot 0: its schedule is untouched)
     __shared__ T fld[3][EPB * C::LE];
     __shared__ T fr[EPB][4][3][N];
     __shared__ double sD[N * N], sCm[N], sCp[N];
@@ -189,23 +224,23 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
         const Elem2 el = decode_elem2(blockIdx.x * EPB + le, D.count, D.region, H);
         if (!el.valid) continue;
         const int d = f >> 1, plus = f & 1;
-        const T* own = P.itf + ((size_t)el.e * 4 + f) * 3 * N + k;
+        const T* own = S.itf + ((size_t)el.e * 4 + f) * 3 * N + k;
         const T* nbr;
         size_t nstride = N;
         size_t o_own, o_nbr;  // slots in the halo-padded interface arrays (own side, neighbour side)
         const double *sgp, *hddp, *hodp, *hsp;
         if (d == 0) {
             const int ne = el.ei + (plus ? 1 : -1);
-            if (ne >= 0 && ne < H) nbr = P.itf + ((size_t)(el.e + (plus ? 1 : -1)) * 4 + (f ^ 1)) * 3 * N + k;
-            else { nbr = (plus ? P.halo_e : P.halo_w) + (size_t)el.ej * N + k; nstride = (size_t)H * N; }
+            if (ne >= 0 && ne < H) nbr = S.itf + ((size_t)(el.e + (plus ? 1 : -1)) * 4 + (f ^ 1)) * 3 * N + k;
+            else { nbr = (plus ? S.halo_e : S.halo_w) + (size_t)el.ej * N + k; nstride = (size_t)H * N; }
             const size_t row = (size_t)el.ej * (H + 2);
             o_own = (row + el.ei + 1) * 2 * N + plus * N + k;
             o_nbr = (row + el.ei + 1 + (plus ? 1 : -1)) * 2 * N + (1 - plus) * N + k;
             sgp = P.sgi; hddp = P.h11i; hodp = P.h21i; hsp = P.hsi;
         } else {
             const int ne = el.ej + (plus ? 1 : -1);
-            if (ne >= 0 && ne < H) nbr = P.itf + ((size_t)(el.e + (plus ? H : -H)) * 4 + (f ^ 1)) * 3 * N + k;
-            else { nbr = (plus ? P.halo_n : P.halo_s) + (size_t)el.ei * N + k; nstride = (size_t)H * N; }
+            if (ne >= 0 && ne < H) nbr = S.itf + ((size_t)(el.e + (plus ? H : -H)) * 4 + (f ^ 1)) * 3 * N + k;
+            else { nbr = (plus ? S.halo_n : S.halo_s) + (size_t)el.ei * N + k; nstride = (size_t)H * N; }
             o_own = ((size_t)(el.ej + 1) * H + el.ei) * 2 * N + plus * N + k;
             o_nbr = ((size_t)(el.ej + 1 + (plus ? 1 : -1)) * H + el.ei) * 2 * N + (1 - plus) * N + k;
             sgp = P.sgj; hddp = P.h22j; hodp = P.h12j; hsp = P.hsj;
@@ -307,16 +342,32 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
         acc1 += dv[1];
         acc2 += dv[2];
     }
-    if (!active) return;
+    if (!PIPE && !active) return;
     const double inv_sg = 1.0 / sg;
     T r0 = inv_sg * (-acc0), r1 = inv_sg * (-acc1) - forc1, r2 = inv_sg * (-acc2) - forc2;
-    if (D.axpy) {  // integrators/tvdrk3.py:12-19 stage formed in the store
-        r0 = D.cb * q0 + D.cc * r0; r1 = D.cb * q1 + D.cc * r1; r2 = D.cb * q2 + D.cc * r2;
-        if (D.y != nullptr) { r0 += D.ca * D.y[o]; r1 += D.ca * D.y[fs + o]; r2 += D.ca * D.y[2 * fs + o]; }
+    if (active) {
+        if (D.axpy) {  // integrators/tvdrk3.py:12-19 stage formed in the store
+            r0 = D.cb * q0 + D.cc * r0; r1 = D.cb * q1 + D.cc * r1; r2 = D.cb * q2 + D.cc * r2;
+            if (D.y != nullptr) { r0 += D.ca * D.y[o]; r1 += D.ca * D.y[fs + o]; r2 += D.ca * D.y[2 * fs + o]; }
+        }
+        D.rhs[o] = r0;
+        D.rhs[fs + o] = r1;
+        D.rhs[2 * fs + o] = r2;
     }
-    D.rhs[o] = r0;
-    D.rhs[fs + o] = r1;
-    D.rhs[2 * fs + o] = r2;
+    // ---- stage pipeline: the output is the next stage's state - extrapolate it to the faces while it is in registers
+    // (the next evaluation then needs no extrapolation launch: a second instantiation, the plain kernel is as it was)
+    if (PIPE && D.prepare) {
+        __syncthreads();   // the last directional pass has finished reading fld
+        if (le < EPB) {
+            T h = r0;
+            if (active && P.has_topo) h = h + P.hsurf[o];
+            fld[0][lpt] = active ? h : T(0.0);
+            fld[1][lpt] = active ? r1 : T(0.0);
+            fld[2][lpt] = active ? r2 : T(0.0);
+        }
+        __syncthreads();
+        sw_extrap_faces<N, T>(P, fld, blockIdx.x * EPB, D.count, D.region, sw_slot<T>(P, 1 - D.slot));
+    }
 }
 
 // one tile per launch: parameters by value
@@ -324,25 +375,26 @@ template <int N, typename T>
 __global__ __launch_bounds__(Cfg2<N>::BS) void sw_extrap_kernel(const SwParams<T> P, const SwDyn<T> D) {
     sw_extrap_body<N, T>(P, D);
 }
-template <int N, typename T>
+template <int N, typename T, bool PIPE>
 __global__ __launch_bounds__(Cfg2<N>::BS) void sw_rhs_kernel(const SwParams<T> P, const SwDyn<T> D) {
-    sw_rhs_body<N, T>(P, D);
+    sw_rhs_body<N, T, PIPE>(P, D);
 }
 // several tiles (the panels one rank owns) per launch: blockIdx.y selects the tile's static parameters
 // from a device-resident table; states/results are slices of one stacked array
 template <int N, typename T>
 __global__ __launch_bounds__(Cfg2<N>::BS) void sw_extrap_batch_kernel(const SwParams<T>* __restrict__ PB, const T* q,
-                                                                     size_t stride) {
-    SwDyn<T> D{q + (size_t)blockIdx.y * stride, nullptr, 0, 0, 0, nullptr, 0.0, 0.0, 1.0};
+                                                                     size_t stride, int slot) {
+    SwDyn<T> D{q + (size_t)blockIdx.y * stride, nullptr, 0, 0, 0, nullptr, 0.0, 0.0, 1.0, slot, 0};
     sw_extrap_body<N, T>(PB[blockIdx.y], D);
 }
-template <int N, typename T>
+template <int N, typename T, bool PIPE>
 __global__ __launch_bounds__(Cfg2<N>::BS) void sw_rhs_batch_kernel(const SwParams<T>* __restrict__ PB, const T* q, T* rhs,
                                                                   size_t stride, int count, int region, int axpy,
-                                                                  const T* y, double ca, double cb, double cc) {
+                                                                  const T* y, double ca, double cb, double cc, int slot,
+                                                                  int prepare) {
     SwDyn<T> D{q + (size_t)blockIdx.y * stride, rhs + (size_t)blockIdx.y * stride, count, region, axpy,
-               y ? y + (size_t)blockIdx.y * stride : nullptr, ca, cb, cc};
-    sw_rhs_body<N, T>(PB[blockIdx.y], D);
+               y ? y + (size_t)blockIdx.y * stride : nullptr, ca, cb, cc, slot, prepare};
+    sw_rhs_body<N, T, PIPE>(PB[blockIdx.y], D);
 }
 
 }  // namespace wx
@@ -354,6 +406,7 @@ struct wx_sw_plan {
     int n, H, panel;
     wx_dtype dtype;
     void* itf = nullptr;
+    void* itf2 = nullptr;   // interface slot 1 (wx_sw_plan_reserve: the stage pipeline)
     SwConsts* consts = nullptr;
     SwParams<double> base;
 };
@@ -363,6 +416,7 @@ struct wx_sw_batch {
     int n, H, count;
     wx_dtype dtype;
     void* table = nullptr;  // device: SwParams<T>[count]
+    bool pipelined = false; // the table holds both slots (wx_sw_batch_create_pipelined)
 };
 
 namespace {
@@ -375,6 +429,9 @@ SwParams<T> make_sw_params(const wx_sw_plan* pl) {
     P.itf = static_cast<T*>(pl->itf);
     P.halo_s = P.halo_n = P.halo_w = P.halo_e = nullptr;
     P.send_s = P.send_n = P.send_w = P.send_e = nullptr;
+    P.itf2 = static_cast<T*>(pl->itf2);
+    P.halo2_s = P.halo2_n = P.halo2_w = P.halo2_e = nullptr;
+    P.send2_s = P.send2_n = P.send2_w = P.send2_e = nullptr;
     P.sg = b.sg; P.h11 = b.h11; P.h12 = b.h12; P.h21 = b.h21; P.h22 = b.h22;
     P.c101 = b.c101; P.c102 = b.c102; P.c111 = b.c111; P.c112 = b.c112;
     P.c201 = b.c201; P.c202 = b.c202; P.c212 = b.c212; P.c222 = b.c222;
@@ -385,14 +442,22 @@ SwParams<T> make_sw_params(const wx_sw_plan* pl) {
 }
 
 template <typename T>
-void set_edges(SwParams<T>& P, void* const send[4], const void* const halo[4]) {
-    if (send) {
+void set_edges(SwParams<T>& P, void* const send[4], const void* const halo[4], int slot = 0) {
+    if (send && slot == 0) {
         P.send_s = static_cast<T*>(send[0]); P.send_n = static_cast<T*>(send[1]);
         P.send_w = static_cast<T*>(send[2]); P.send_e = static_cast<T*>(send[3]);
     }
-    if (halo) {
+    if (halo && slot == 0) {
         P.halo_s = static_cast<const T*>(halo[0]); P.halo_n = static_cast<const T*>(halo[1]);
         P.halo_w = static_cast<const T*>(halo[2]); P.halo_e = static_cast<const T*>(halo[3]);
+    }
+    if (send && slot == 1) {
+        P.send2_s = static_cast<T*>(send[0]); P.send2_n = static_cast<T*>(send[1]);
+        P.send2_w = static_cast<T*>(send[2]); P.send2_e = static_cast<T*>(send[3]);
+    }
+    if (halo && slot == 1) {
+        P.halo2_s = static_cast<const T*>(halo[0]); P.halo2_n = static_cast<const T*>(halo[1]);
+        P.halo2_w = static_cast<const T*>(halo[2]); P.halo2_e = static_cast<const T*>(halo[3]);
     }
 }
 
@@ -409,12 +474,19 @@ wx_status sw_launch(int what, const SwParams<T>* P, const SwDyn<T>& D, const SwP
     const int cnt = (what == 0 || what == 2) ? (P ? P->nelem : D.count) : D.count;
     if (cnt == 0) return WX_OK;
     const int grid = (cnt + C::EPB - 1) / C::EPB;
+    const bool pipe = D.prepare != 0 || D.slot != 0;   // the stage pipeline's instantiation
     switch (what) {
         case 0: hipLaunchKernelGGL((sw_extrap_kernel<N, T>), dim3(grid), dim3(C::BS), 0, st, *P, D); break;
-        case 1: hipLaunchKernelGGL((sw_rhs_kernel<N, T>), dim3(grid), dim3(C::BS), 0, st, *P, D); break;
-        case 2: hipLaunchKernelGGL((sw_extrap_batch_kernel<N, T>), dim3(grid, nb), dim3(C::BS), 0, st, table, D.q, stride); break;
-        default: hipLaunchKernelGGL((sw_rhs_batch_kernel<N, T>), dim3(grid, nb), dim3(C::BS), 0, st, table, D.q, D.rhs,
-                                    stride, D.count, D.region, D.axpy, D.y, D.ca, D.cb, D.cc);
+        case 1:
+            if (pipe) hipLaunchKernelGGL((sw_rhs_kernel<N, T, true>), dim3(grid), dim3(C::BS), 0, st, *P, D);
+            else hipLaunchKernelGGL((sw_rhs_kernel<N, T, false>), dim3(grid), dim3(C::BS), 0, st, *P, D);
+            break;
+        case 2: hipLaunchKernelGGL((sw_extrap_batch_kernel<N, T>), dim3(grid, nb), dim3(C::BS), 0, st, table, D.q, stride, D.slot); break;
+        default:
+            if (pipe) hipLaunchKernelGGL((sw_rhs_batch_kernel<N, T, true>), dim3(grid, nb), dim3(C::BS), 0, st, table, D.q, D.rhs,
+                                         stride, D.count, D.region, D.axpy, D.y, D.ca, D.cb, D.cc, D.slot, D.prepare);
+            else hipLaunchKernelGGL((sw_rhs_batch_kernel<N, T, false>), dim3(grid, nb), dim3(C::BS), 0, st, table, D.q, D.rhs,
+                                    stride, D.count, D.region, D.axpy, D.y, D.ca, D.cb, D.cc, 0, 0);
     }
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
@@ -435,24 +507,28 @@ wx_status sw_dispatch(int n, int what, const SwParams<T>* P, const SwDyn<T>& D, 
     return fail(WX_ERR_UNSUPPORTED, "num_solpts %d not in 2..8", n);
 }
 
+// slot: the interface / edge set that holds (extrapolation: receives) the faces of q; next_send + prepare: the stage pipeline
 template <typename T>
 wx_status sw_run(wx_sw_plan* pl, bool extrap, const void* q, void* const send[4], const void* const halo[4], void* rhs,
                  int region, int count, hipStream_t st, int axpy = 0, const void* y = nullptr, double ca = 0.0,
-                 double cb = 0.0, double cc = 1.0) {
+                 double cb = 0.0, double cc = 1.0, int slot = 0, void* const next_send[4] = nullptr, int prepare = 0) {
     SwParams<T> P = make_sw_params<T>(pl);
-    set_edges<T>(P, send, halo);
-    SwDyn<T> D{static_cast<const T*>(q), static_cast<T*>(rhs), count, region, axpy, static_cast<const T*>(y), ca, cb, cc};
+    set_edges<T>(P, send, halo, slot);
+    if (prepare) set_edges<T>(P, next_send, nullptr, 1 - slot);
+    SwDyn<T> D{static_cast<const T*>(q), static_cast<T*>(rhs), count, region, axpy, static_cast<const T*>(y), ca, cb, cc,
+               slot, prepare};
     return sw_dispatch<T>(pl->n, extrap ? 0 : 1, &P, D, nullptr, 0, 0, st);
 }
 
 template <typename T>
 wx_status sw_batch_build(wx_sw_batch* b, wx_sw_plan* const plans[], int count, void* const send[][4],
-                         const void* const halo[][4]) {
+                         const void* const halo[][4], void* const send2[][4] = nullptr, const void* const halo2[][4] = nullptr) {
     SwParams<T>* host = new (std::nothrow) SwParams<T>[count];
     if (!host) return fail(WX_ERR_NOMEM, "out of host memory");
     for (int i = 0; i < count; ++i) {
         host[i] = make_sw_params<T>(plans[i]);
         set_edges<T>(host[i], send[i], halo[i]);
+        if (send2 && halo2) set_edges<T>(host[i], send2[i], halo2[i], 1);
     }
     hipError_t e = hipMalloc(&b->table, sizeof(SwParams<T>) * count);
     if (e == hipSuccess) e = hipMemcpy(b->table, host, sizeof(SwParams<T>) * count, hipMemcpyHostToDevice);
@@ -463,9 +539,10 @@ wx_status sw_batch_build(wx_sw_batch* b, wx_sw_plan* const plans[], int count, v
 
 template <typename T>
 wx_status sw_batch_run(wx_sw_batch* b, bool extrap, const void* q, void* rhs, size_t stride, int region, hipStream_t st,
-                       int axpy = 0, const void* y = nullptr, double ca = 0.0, double cb = 0.0, double cc = 1.0) {
+                       int axpy = 0, const void* y = nullptr, double ca = 0.0, double cb = 0.0, double cc = 1.0, int slot = 0,
+                       int prepare = 0) {
     SwDyn<T> D{static_cast<const T*>(q), static_cast<T*>(rhs), extrap ? b->H * b->H : sw_region_count(region, b->H), region,
-               axpy, static_cast<const T*>(y), ca, cb, cc};
+               axpy, static_cast<const T*>(y), ca, cb, cc, slot, prepare};
     return sw_dispatch<T>(b->n, extrap ? 2 : 3, nullptr, D, static_cast<const SwParams<T>*>(b->table), b->count, stride, st);
 }
 
@@ -543,6 +620,7 @@ wx_status wx_sw_plan_create_tile(wx_sw_plan** out, int n, int H, wx_dtype dtype,
 wx_status wx_sw_plan_destroy(wx_sw_plan* pl) {
     if (!pl) return WX_OK;
     hipError_t e = hipFree(pl->itf);
+    if (pl->itf2) (void)hipFree(pl->itf2);
     hipError_t e2 = hipFree(pl->consts);
     if (e == hipSuccess) e = e2;
     delete pl;
@@ -680,6 +758,109 @@ wx_status wx_sw_batch_rhs(wx_sw_batch* b, const void* q, void* rhs, size_t panel
         case WX_F64: return sw_batch_run<double>(b, false, q, rhs, panel_stride, region, st);
         case WX_C128: return sw_batch_run<cplx>(b, false, q, rhs, panel_stride, region, st);
         default: return sw_batch_run<dual>(b, false, q, rhs, panel_stride, region, st);
+    }
+}
+
+// ---- stage pipeline (the shallow-water twin of wx_euler3d_stage)
+wx_status wx_sw_plan_reserve(wx_sw_plan* pl, int what) {
+    if (!pl) return fail(WX_ERR_INVALID, "wx_sw_plan_reserve: null plan");
+    if (what & ~WX_RESERVE_STAGE) return fail(WX_ERR_INVALID, "wx_sw_plan_reserve: unknown flags %d", what);
+    if ((what & WX_RESERVE_STAGE) && !pl->itf2) {
+        const size_t bytes = (size_t)pl->H * pl->H * 4 * 3 * pl->n * (pl->dtype == WX_F64 ? 8 : 16);
+        hipError_t e = hipMalloc(&pl->itf2, bytes);
+        if (e != hipSuccess) return fail(WX_ERR_NOMEM, "hipMalloc(%zu bytes) for the second interface buffer failed: %s", bytes,
+                                         hipGetErrorString(e));
+    }
+    return WX_OK;
+}
+
+wx_status wx_sw_extrap_pack_slot(wx_sw_plan* pl, const void* q, void* const send[4], int slot, wx_stream stream) {
+    if (!pl || !q) return fail(WX_ERR_INVALID, "wx_sw_extrap_pack_slot: null argument");
+    if (slot != 0 && slot != 1) return fail(WX_ERR_INVALID, "interface slot %d not in {0,1}", slot);
+    if (slot == 1 && !pl->itf2) return fail(WX_ERR_INVALID, "wx_sw_extrap_pack_slot: call wx_sw_plan_reserve(plan, WX_RESERVE_STAGE) first");
+    WX_STREAM(st, stream);
+    switch (pl->dtype) {
+        case WX_F64: return sw_run<double>(pl, true, q, send, nullptr, nullptr, 0, 0, st, 0, nullptr, 0.0, 0.0, 1.0, slot);
+        case WX_C128: return sw_run<cplx>(pl, true, q, send, nullptr, nullptr, 0, 0, st, 0, nullptr, 0.0, 0.0, 1.0, slot);
+        default: return sw_run<dual>(pl, true, q, send, nullptr, nullptr, 0, 0, st, 0, nullptr, 0.0, 0.0, 1.0, slot);
+    }
+}
+
+wx_status wx_sw_stage(wx_sw_plan* pl, const void* q, const void* const halo[4], const void* y, void* out, double a, double b,
+                      double c, wx_region region, int itf_in, void* const next_send[4], int prepare_next, wx_stream stream) {
+    wx_status ok = sw_check_rhs_args(pl, q, out, halo, region);
+    if (ok != WX_OK) return ok;
+    if (itf_in != 0 && itf_in != 1) return fail(WX_ERR_INVALID, "interface slot %d not in {0,1}", itf_in);
+    if ((prepare_next || itf_in == 1) && !pl->itf2)
+        return fail(WX_ERR_INVALID, "wx_sw_stage: call wx_sw_plan_reserve(plan, WX_RESERVE_STAGE) first");
+    const int count = sw_region_count(region, pl->H);
+    const int prep = prepare_next ? 1 : 0;
+    WX_STREAM(st, stream);
+    switch (pl->dtype) {
+        case WX_F64: return sw_run<double>(pl, false, q, nullptr, halo, out, region, count, st, 1, y, a, b, c, itf_in, next_send, prep);
+        case WX_C128: return sw_run<cplx>(pl, false, q, nullptr, halo, out, region, count, st, 1, y, a, b, c, itf_in, next_send, prep);
+        default: return sw_run<dual>(pl, false, q, nullptr, halo, out, region, count, st, 1, y, a, b, c, itf_in, next_send, prep);
+    }
+}
+
+wx_status wx_sw_batch_create_pipelined(wx_sw_batch** out, wx_sw_plan* const plans[], int count, void* const send[][4],
+                                       const void* const halo[][4], void* const send2[][4], const void* const halo2[][4]) {
+    if (!out || !plans || !send || !halo || !send2 || !halo2 || count < 1)
+        return fail(WX_ERR_INVALID, "wx_sw_batch_create_pipelined: bad argument");
+    *out = nullptr;
+    for (int i = 0; i < count; ++i) {
+        if (!plans[i]) return fail(WX_ERR_INVALID, "wx_sw_batch_create_pipelined: plans[%d] is null", i);
+        if (plans[i]->n != plans[0]->n || plans[i]->H != plans[0]->H || plans[i]->dtype != plans[0]->dtype)
+            return fail(WX_ERR_INVALID, "wx_sw_batch_create_pipelined: plans differ in n, H or dtype");
+        if (!plans[i]->itf2) return fail(WX_ERR_INVALID, "wx_sw_batch_create_pipelined: call wx_sw_plan_reserve on every plan first");
+        for (int e = 0; e < 4; ++e)
+            if (!send[i][e] || !halo[i][e] || !send2[i][e] || !halo2[i][e])
+                return fail(WX_ERR_INVALID, "wx_sw_batch_create_pipelined: null edge buffer");
+    }
+    wx_sw_batch* b = new (std::nothrow) wx_sw_batch();
+    if (!b) return fail(WX_ERR_NOMEM, "out of host memory");
+    b->n = plans[0]->n; b->H = plans[0]->H; b->count = count; b->dtype = plans[0]->dtype; b->pipelined = true;
+    wx_status st;
+    switch (b->dtype) {
+        case WX_F64: st = sw_batch_build<double>(b, plans, count, send, halo, send2, halo2); break;
+        case WX_C128: st = sw_batch_build<cplx>(b, plans, count, send, halo, send2, halo2); break;
+        default: st = sw_batch_build<dual>(b, plans, count, send, halo, send2, halo2);
+    }
+    if (st != WX_OK) {
+        if (b->table) (void)hipFree(b->table);
+        delete b;
+        return st;
+    }
+    *out = b;
+    return WX_OK;
+}
+
+wx_status wx_sw_batch_extrap_pack_slot(wx_sw_batch* b, const void* q, size_t panel_stride, int slot, wx_stream stream) {
+    if (!b || !q) return fail(WX_ERR_INVALID, "wx_sw_batch_extrap_pack_slot: null argument");
+    if (slot != 0 && slot != 1) return fail(WX_ERR_INVALID, "interface slot %d not in {0,1}", slot);
+    if (slot == 1 && !b->pipelined) return fail(WX_ERR_INVALID, "wx_sw_batch_extrap_pack_slot: the batch has one slot (wx_sw_batch_create_pipelined)");
+    WX_STREAM(st, stream);
+    switch (b->dtype) {
+        case WX_F64: return sw_batch_run<double>(b, true, q, nullptr, panel_stride, 0, st, 0, nullptr, 0.0, 0.0, 1.0, slot);
+        case WX_C128: return sw_batch_run<cplx>(b, true, q, nullptr, panel_stride, 0, st, 0, nullptr, 0.0, 0.0, 1.0, slot);
+        default: return sw_batch_run<dual>(b, true, q, nullptr, panel_stride, 0, st, 0, nullptr, 0.0, 0.0, 1.0, slot);
+    }
+}
+
+wx_status wx_sw_batch_stage(wx_sw_batch* bt, const void* q, const void* y, void* out, size_t panel_stride, double a, double b,
+                            double c, wx_region region, int itf_in, int prepare_next, wx_stream stream) {
+    if (!bt || !q || !out) return fail(WX_ERR_INVALID, "wx_sw_batch_stage: null argument");
+    if (out == q) return fail(WX_ERR_INVALID, "wx_sw_batch_stage: output must not alias the state");
+    if (region != WX_REGION_ALL && region != WX_REGION_INTERIOR && region != WX_REGION_BOUNDARY)
+        return fail(WX_ERR_INVALID, "unknown region %d", (int)region);
+    if (itf_in != 0 && itf_in != 1) return fail(WX_ERR_INVALID, "interface slot %d not in {0,1}", itf_in);
+    if (!bt->pipelined) return fail(WX_ERR_INVALID, "wx_sw_batch_stage: the batch has one slot (wx_sw_batch_create_pipelined)");
+    const int prep = prepare_next ? 1 : 0;
+    WX_STREAM(st, stream);
+    switch (bt->dtype) {
+        case WX_F64: return sw_batch_run<double>(bt, false, q, out, panel_stride, region, st, 1, y, a, b, c, itf_in, prep);
+        case WX_C128: return sw_batch_run<cplx>(bt, false, q, out, panel_stride, region, st, 1, y, a, b, c, itf_in, prep);
+        default: return sw_batch_run<dual>(bt, false, q, out, panel_stride, region, st, 1, y, a, b, c, itf_in, prep);
     }
 }
 

@@ -37,24 +37,67 @@ int wx_device_count(void) {
 
 // ---- the streaming copy a roofline fraction is put beside: what this part sustains on a pure read-once / write-once
 // pattern (16 bytes per lane, grid-stride, one pass) - the achievable side of "achieved vs 8 TB/s"
+// U loads of 16 bytes in flight per lane before the first store; NT: non-temporal loads and stores (the data is used once)
+template <int U, bool NT>
 __global__ __launch_bounds__(256) void wx_stream_copy_kernel(const double2* __restrict__ src, double2* __restrict__ dst, size_t n16) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (U - 1) * stride < n16; i += U * stride) {
+        double2 v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const double2* p = src + i + k * stride;
+            if (NT) { v[k].x = __builtin_nontemporal_load(&p->x); v[k].y = __builtin_nontemporal_load(&p->y); }
+            else v[k] = *p;
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            double2* p = dst + i + k * stride;
+            if (NT) { __builtin_nontemporal_store(v[k].x, &p->x); __builtin_nontemporal_store(v[k].y, &p->y); }
+            else *p = v[k];
+        }
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
 }
 
-extern "C" wx_status wx_stream_copy(const void* src, void* dst, size_t bytes, wx_stream stream) {
+template <int U, bool NT>
+static void launch_copy(const void* src, void* dst, size_t n16, int wg_per_cu, hipStream_t st) {
+    size_t blocks = (n16 / U + 255) / 256;
+    if (blocks > (size_t)256 * wg_per_cu) blocks = (size_t)256 * wg_per_cu;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL((wx_stream_copy_kernel<U, NT>), dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const double2*>(src),
+                       static_cast<double2*>(dst), n16);
+}
+
+// development entry point (not in wxhip.h; tools/copybench.py): the copy with its launch shape as arguments
+extern "C" wx_status wx_stream_copy_variant(const void* src, void* dst, size_t bytes, int unroll, int nt, int wg_per_cu,
+                                            wx_stream stream) {
     if (!src || !dst) return wx::fail(WX_ERR_INVALID, "wx_stream_copy: null argument");
     if (bytes % 16 != 0 || ((uintptr_t)src | (uintptr_t)dst) % 16 != 0)
         return wx::fail(WX_ERR_INVALID, "wx_stream_copy: buffers and size must be multiples of 16 bytes");
     if (bytes == 0) return WX_OK;
+    if (wg_per_cu < 1 || wg_per_cu > 64) return wx::fail(WX_ERR_INVALID, "wx_stream_copy: %d workgroups per CU", wg_per_cu);
     WX_STREAM(st, stream);
     const size_t n16 = bytes / 16;
-    size_t blocks = (n16 + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;   // 32 workgroups of 4 waves per CU: every wave slot of the chip, several lines each
-    hipLaunchKernelGGL(wx_stream_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const double2*>(src),
-                       static_cast<double2*>(dst), n16);
+    switch (unroll * 2 + (nt ? 1 : 0)) {
+        case 2: launch_copy<1, false>(src, dst, n16, wg_per_cu, st); break;
+        case 3: launch_copy<1, true>(src, dst, n16, wg_per_cu, st); break;
+        case 4: launch_copy<2, false>(src, dst, n16, wg_per_cu, st); break;
+        case 5: launch_copy<2, true>(src, dst, n16, wg_per_cu, st); break;
+        case 8: launch_copy<4, false>(src, dst, n16, wg_per_cu, st); break;
+        case 9: launch_copy<4, true>(src, dst, n16, wg_per_cu, st); break;
+        case 16: launch_copy<8, false>(src, dst, n16, wg_per_cu, st); break;
+        case 17: launch_copy<8, true>(src, dst, n16, wg_per_cu, st); break;
+        default: return wx::fail(WX_ERR_INVALID, "wx_stream_copy: unroll %d not in {1, 2, 4, 8}", unroll);
+    }
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
+}
+
+// the shape that measured fastest on MI355X (tools/copybench.py, profiles/r04_copybench.log)
+constexpr int kCopyUnroll = 4, kCopyNT = 0, kCopyWgPerCu = 8;
+extern "C" wx_status wx_stream_copy(const void* src, void* dst, size_t bytes, wx_stream stream) {
+    return wx_stream_copy_variant(src, dst, bytes, kCopyUnroll, kCopyNT, kCopyWgPerCu, stream);
 }
 
 // ---- the nine-stamp timing row of the reference's RHS (rhs/rhs.py:39-41, 68-118) for callers without torch

@@ -103,6 +103,38 @@ class SwPlan:
         check(self.lib.wx_sw_rhs_axpy(self._h, q.data_ptr(), _ptr_array(halo_ptrs), y.data_ptr() if y is not None else None,
                                       out.data_ptr(), a, b, c, region, st), "wx_sw_rhs_axpy")
 
+    def reserve(self):
+        """Setup-time allocation of the second interface slot (stage pipeline): wx_sw_plan_reserve."""
+        if getattr(self, "_reserved", False):
+            return
+        if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("SwPlan.reserve: the stage pipeline's buffers do not exist yet and a stream capture is in "
+                               "progress - call reserve() (or RhsShallowWater.reserve()) before it")
+        with torch.cuda.device(self.device):
+            check(self.lib.wx_sw_plan_reserve(self._h, _lib.WX_RESERVE_STAGE), "wx_sw_plan_reserve")
+        self._reserved = True
+
+    def extrap_pack_slot(self, q, send_ptrs, slot: int):
+        self._check_q(q)
+        if slot == 1:
+            self.reserve()
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.wx_sw_extrap_pack_slot(self._h, q.data_ptr(), _ptr_array(send_ptrs), slot, st), "wx_sw_extrap_pack_slot")
+
+    def stage(self, q, halo_ptrs, y, out, a, b, c, region, itf_in: int, next_send, prepare_next: bool):
+        """out = a*y + b*q + c*R(q) reading faces from slot itf_in; with prepare_next also the faces of `out` into the
+        other slot / next_send (wx_sw_stage)."""
+        self._check_q(q)
+        self._check_q(out)
+        if y is not None:
+            self._check_q(y)
+        if prepare_next or itf_in == 1:
+            self.reserve()
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.wx_sw_stage(self._h, q.data_ptr(), _ptr_array(halo_ptrs), y.data_ptr() if y is not None else None,
+                                   out.data_ptr(), a, b, c, region, itf_in, _ptr_array(next_send), int(bool(prepare_next)), st),
+              "wx_sw_stage")
+
     def close(self):
         if self._h:
             self.lib.wx_sw_plan_destroy(self._h)
@@ -119,7 +151,9 @@ class SwBatch:
     """All panels of a rank in one launch per phase (wx_sw_batch_*): the edge buffers are the
     exchange's persistent send/halo slots, the states are slices of one stacked tensor."""
 
-    def __init__(self, plans: Dict[int, SwPlan], exchange: PanelExchange):
+    def __init__(self, plans: Dict[int, SwPlan], exchange: PanelExchange, exchange2: PanelExchange = None):
+        """exchange2: the second edge-buffer set of the stage pipeline (wx_sw_batch_create_pipelined; the plans are
+        reserved here)."""
         self.lib = _lib.load()
         self.panels = sorted(plans)
         n = len(self.panels)
@@ -127,16 +161,38 @@ class SwBatch:
         self.device, self.dtype = first.device, first.dtype
         self.stride = 3 * first.H * first.H * first.n**2
         handles = (ctypes.c_void_p * n)(*[plans[p]._h for p in self.panels])
-        send = ((ctypes.c_void_p * 4) * n)()
-        halo = ((ctypes.c_void_p * 4) * n)()
-        for i, p in enumerate(self.panels):
-            for e in range(4):
-                send[i][e] = exchange.send_view(p, e).data_ptr()
-                halo[i][e] = exchange.halo_view(p, e).data_ptr()
-        self._keep = (plans, exchange)
+
+        def edges(ex):
+            send = ((ctypes.c_void_p * 4) * n)()
+            halo = ((ctypes.c_void_p * 4) * n)()
+            for i, p in enumerate(self.panels):
+                for e in range(4):
+                    send[i][e] = ex.send_view(p, e).data_ptr()
+                    halo[i][e] = ex.halo_view(p, e).data_ptr()
+            return send, halo
+
+        send, halo = edges(exchange)
+        self._keep = (plans, exchange, exchange2)
         self._h = ctypes.c_void_p()
+        self.pipelined = exchange2 is not None
         with torch.cuda.device(self.device):
-            check(self.lib.wx_sw_batch_create(ctypes.byref(self._h), handles, n, send, halo), "wx_sw_batch_create")
+            if self.pipelined:
+                for pl in plans.values():
+                    pl.reserve()
+                send2, halo2 = edges(exchange2)
+                check(self.lib.wx_sw_batch_create_pipelined(ctypes.byref(self._h), handles, n, send, halo, send2, halo2),
+                      "wx_sw_batch_create_pipelined")
+            else:
+                check(self.lib.wx_sw_batch_create(ctypes.byref(self._h), handles, n, send, halo), "wx_sw_batch_create")
+
+    def extrap_pack_slot(self, q, slot: int):
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.wx_sw_batch_extrap_pack_slot(self._h, q.data_ptr(), self.stride, slot, st), "wx_sw_batch_extrap_pack_slot")
+
+    def stage(self, q, y, out, a, b, c, region, itf_in: int, prepare_next: bool):
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.wx_sw_batch_stage(self._h, q.data_ptr(), y.data_ptr() if y is not None else None, out.data_ptr(),
+                                         self.stride, a, b, c, region, itf_in, int(bool(prepare_next)), st), "wx_sw_batch_stage")
 
     def extrap_pack(self, q):
         st = torch.cuda.current_stream(self.device).cuda_stream
@@ -170,6 +226,79 @@ class RhsShallowWater(PanelRhs):
 
     batched = True
     overlapped_entry = "wx_sw_rhs_overlapped"
+    supports_pipeline = True
+
+    def _pipe_state(self, dtype):
+        """The stage pipeline's ping-pong state of one dtype: slot in use, the tensor whose faces are prepared, the two
+        edge-buffer sets (the second created here: setup time)."""
+        if not hasattr(self, "_pipe"):
+            self._pipe = {}
+        st = self._pipe.get(dtype)
+        if st is None:
+            st = self._pipe[dtype] = {"slot": 0, "ready": None, "ex": [self.exchange_for(dtype), None], "batch": None}
+            st["ex"][1] = self.new_exchange(self.edge_count * (2 if dtype.is_complex else 1))
+        return st
+
+    def reserve(self, stage: bool = True, dtype=torch.float64):
+        """Allocate now what the stage pipeline needs (second interface slots, second edge-buffer set, the pipelined
+        batch), so that its first call can sit inside a HIP-graph capture."""
+        if not stage:
+            return
+        st = self._pipe_state(dtype)
+        plans = self.plans_for(dtype)
+        for pl in plans.values():
+            pl.reserve()
+        if self.batched and len(self.panels) > 1 and st["batch"] is None:
+            st["batch"] = SwBatch(plans, st["ex"][0], st["ex"][1])
+
+    def invalidate_faces(self):
+        """Forget the faces the last stage prepared (call after modifying a state that stage() returned)."""
+        for st in getattr(self, "_pipe", {}).values():
+            st["ready"] = None
+
+    def stage(self, Q: torch.Tensor, Y, a: float, b: float, c: float) -> torch.Tensor:
+        """One explicit Runge-Kutta stage  a*Y + b*Q + c*R(Q)  on stacked states with the stage pipeline (wx_sw_stage /
+        wx_sw_batch_stage): the kernel that produces the result also extrapolates it to the element faces and packs its
+        edge lines, so that the NEXT call whose Q is that very tensor starts at the exchange - at the benchmark's S7 size
+        the extrapolation launch is a fifth of an evaluation.  Same contract as RhsEuler3D.stage: the prepared faces are
+        used only for the tensor the previous stage returned, unmodified (torch's version counter; invalidate_faces())."""
+        import weakref
+
+        np_ = len(self.panels)
+        dtype = Q.dtype
+        plans = self.plans_for(dtype)
+        st = self._pipe_state(dtype)
+        cur = st["slot"]
+        ex, exn = st["ex"][cur], st["ex"][1 - cur]
+        if not self.panels:   # a rank that owns no tile: the exchange of this stage, and the same slot flip as the others
+            if ex.needs_comm:
+                ex.start(on_compute=True)
+                ex.wait()
+            st["slot"] = 1 - cur
+            return torch.empty_like(Q)
+        Qs = Q.reshape((np_,) + tuple(self.panel_shape))
+        Ys = Y.reshape((np_,) + tuple(self.panel_shape)) if Y is not None else None
+        out = torch.empty_like(Qs)
+        last = st["ready"][0]() if st["ready"] is not None else None
+        reuse = last is Q and st["ready"][1:] == (Q.data_ptr(), Q._version, Q.numel())
+        use_batch = self.batched and np_ > 1 and Q.is_contiguous() and (Y is None or Y.is_contiguous())
+        if use_batch:
+            if st["batch"] is None:
+                st["batch"] = SwBatch(plans, st["ex"][0], st["ex"][1])
+            bt = st["batch"]
+            if not reuse:
+                bt.extrap_pack_slot(Qs, cur)
+            self._phases(ex, lambda region: bt.stage(Qs, Ys, out, a, b, c, region, cur, True))
+        else:
+            if not reuse:
+                for i, p in enumerate(self.panels):
+                    plans[p].extrap_pack_slot(Qs[i], ex.send_views(p), cur)
+            self._exchange_and_launch(ex, lambda i, p, halo, region: plans[p].stage(
+                Qs[i], halo, Ys[i] if Ys is not None else None, out[i], a, b, c, region, cur, exn.send_views(p), True))
+        res = out.reshape(Q.shape)
+        st["slot"] = 1 - cur
+        st["ready"] = (weakref.ref(res), res.data_ptr(), res._version, res.numel())
+        return res
 
     def _run(self, qs, ys, coef, dtype, zs=None):
         if (self.batched and zs is None and isinstance(qs, torch.Tensor) and len(self.panels) > 1
