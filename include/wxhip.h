@@ -181,8 +181,8 @@ double wx_euler3d_bytes_per_point(const wx_euler3d_plan* plan);
  * the plan ONE slab per column and field - point fields [..][H][H][n^2] (the lowest level of the lowest element),
  * sqrtG_itf_i / h_contra_itf_i [..][H][H+2][2][n], sqrtG_itf_j / h_contra_itf_j [..][H+2][H][2][n] (the n values along
  * the face's horizontal direction), sqrtG_itf_k / h_contra_itf_k [..][H][H][n^2]; damp_*, boundary_* are not read - and
- * wx_euler3d_rhs / _rhs_axpy (WX_F64) and wx_euler3d_jvp / _jvp_prepared (WX_DUAL128), every region, read those instead of
- * the full arrays, the elements of a column following
+ * wx_euler3d_rhs / _rhs_axpy* / wx_euler3d_stage (WX_F64; the stage pipeline incl. its fused filter) and wx_euler3d_jvp /
+ * _jvp_prepared (WX_DUAL128), every region, read those instead of the full arrays, the elements of a column following
  * each other so that its slabs are fetched once.  The CALLER vouches for the invariance (the Python host checks it:
  * rhs_euler3d.column_metric_slabs); the full arrays stay in use for every other entry point.  NULL: back to the full
  * arrays.  The slabs are borrowed like the plan's metric. */

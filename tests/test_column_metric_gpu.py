@@ -139,3 +139,64 @@ def test_column_plans_under_the_rhs_object_and_the_matvec(built_lib):
         outs[batched] = (r, jv)
     assert all(pl.column_metric for pl in rhs._jvp_plans().values())   # the dual twins took the slabs
     assert float((outs[True][0] - outs[False][0]).abs().max()) <= 1e-12 * float(R.abs().max())
+
+
+@pytest.mark.parametrize("name", ["euler3d_c31p_n8_h2_v2", "euler3d_c31p_n3_h4_v2"])
+def test_column_metric_stage_pipeline(built_lib, name):
+    """The stage kernels on column plans (wx_euler3d_stage with the slabs: the RK stage, its extrapolation epilogue and the
+    fused per-step filter): three pipelined SSP-RK3 stages and a filtered last stage against the same stages on the full
+    arrays - and RhsEuler3D(column_metric="auto") switches the plans it is given."""
+    from tests.gpu_util import device_metric, to_dev
+    from wxfactory_amd.filters import NanFlag, make_filter
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D
+
+    g = golden(name)
+    panels = g.metric_panels()
+    if len(panels) < 6:   # the n = 8 fixture stores two panels: a two-tile "sphere" cannot exchange - one tile, fixture halos
+        pytest.skip("needs all six panels") if name != "euler3d_c31p_n8_h2_v2" else None
+    if len(panels) == 6:
+        mk = lambda: {p: Euler3DPlan(g.n, g.H, g.V, g.case, p, g.ops, device_metric(g, p, DEV)) for p in range(6)}  # noqa: E731
+        full, col = RhsEuler3D(mk()), RhsEuler3D(mk(), column_metric="auto")
+        assert all(pl.column_metric for pl in col.plans.values()) and not any(pl.column_metric for pl in full.plans.values())
+        Q = torch.stack([to_dev(g.q(p)) for p in range(6)])
+        F = make_filter(g.n, 0.5, 8, 0.0) if hasattr(make_filter, "__call__") else None
+        outs = []
+        for rhs in (full, col):
+            rhs.batched = False
+            dt = 1e-3
+            Q1 = rhs.stage(Q, None, 0.0, 1.0, dt)
+            Q2 = rhs.stage(Q1, Q, 0.75, 0.25, 0.25 * dt)
+            Q3 = rhs.stage(Q2, Q, 1.0 / 3.0, 2.0 / 3.0, (2.0 / 3.0) * dt)
+            torch.cuda.synchronize()
+            outs.append(Q3)
+        scale = outs[0].abs().amax(dim=(0, 2, 3, 4, 5), keepdim=True)
+        assert ((outs[1] - outs[0]).abs() <= 1e-13 * scale).all()
+        return
+    # n = 8 (matrix cores): one tile driven through the plan, halos from the fixture; stage + epilogue on slabs vs full arrays
+    from wxfactory_amd import _lib
+
+    p = panels[0]
+    m = device_metric(g, p, DEV)
+    q = to_dev(g[f"p{p}/Q"])
+    halo = [to_dev(h) for h in g.halo(p, False)]
+    res = []
+    for colm in (False, True):
+        plan = Euler3DPlan(g.n, g.H, g.V, g.case, p, g.ops, m, column_metric=colm)
+        plan.reserve(_lib.WX_RESERVE_STAGE)
+        send = torch.zeros((4, plan.edge_count), dtype=torch.float64, device=DEV)
+        nsend = torch.zeros((4, plan.edge_count), dtype=torch.float64, device=DEV)
+        plan.extrap_pack_slot(q, list(send), 0)
+        out = torch.full_like(q, float("nan"))
+        plan.stage(q, halo, None, None, out, 0.0, 1.0, 1e-3, 0.0, _lib.WX_REGION_ALL, 0, list(nsend), 1)
+        # the faces the epilogue prepared in slot 1 are those of `out`: a second stage from slot 1 equals one that extrapolates
+        out2 = torch.full_like(q, float("nan"))
+        plan.stage(out, halo, q, None, out2, 0.75, 0.25, 0.25e-3, 0.0, _lib.WX_REGION_ALL, 1, list(send), 1)
+        chk = torch.zeros((4, plan.edge_count), dtype=torch.float64, device=DEV)
+        plan.extrap_pack_slot(out, list(chk), 0)
+        torch.cuda.synchronize()
+        assert torch.equal(chk, nsend)   # edge lines of the epilogue == those of the extrapolation kernel, bit for bit
+        res.append((out.cpu().numpy(), out2.cpu().numpy(), nsend.cpu().numpy()))
+        assert _lib.load().wx_euler3d_uses_matrix_cores(plan._h, _lib.WX_KERNEL_STAGE) == 1
+    for a, b in zip(res[0], res[1]):
+        sc = np.abs(a).max(axis=tuple(range(1, a.ndim)), keepdims=True)
+        assert (np.abs(a - b) <= 1e-13 * sc).all()

@@ -84,3 +84,26 @@ assert piped.pipeline and not fused.pipeline
 tf, tp = step_us(fused), step_us(piped)
 print(f"S7 SSP-RK3 step: fused stages {tf:.1f} us, stage pipeline {tp:.1f} us ({tf / tp:.2f} x)  -> per stage {tp / 3:.1f} us = "
       f"{156.0 * 6 * H * H * n * n / (tp / 3 * 1e-6) / 1e9:.1f} GB/s on 156 B/point")
+
+# ... and the same two steps replayed from HIP graphs (the host out of the way: what the kernels themselves take)
+for name, stepper in (("fused stages", fused), ("stage pipeline", piped)):
+    if name == "stage pipeline":
+        stepper.rhs.reserve(stage=True)
+
+    def one_step(q, stepper=stepper):
+        if hasattr(stepper.rhs, "invalidate_faces"):
+            stepper.rhs.invalidate_faces()       # a replay starts from a copied-in state: its faces are not prepared
+        return stepper.step(q, 1.0)
+
+    gs = GraphedFunction(one_step, Q)
+    q = Q
+    for _ in range(5):
+        q = gs(q)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(100):
+        q = gs(Q)
+    b.record()
+    torch.cuda.synchronize()
+    print(f"S7 SSP-RK3 step from a HIP graph, {name}: {a.elapsed_time(b) / 100 * 1e3:.1f} us")

@@ -19,7 +19,8 @@
 //               the A/B build of profiles/r02_k2_valu_*
 //   WX_K2_DIAG  0: the product (default).  Diagnostic builds of the fused kernel, wrong results / extra stores:
 //               1 per-workgroup phase stamps (tools/kstamps.py); 2 skeleton: every load, LDS write and store but no
-//               arithmetic; 3 without the Riemann arithmetic only; 4 without the three directional passes only
+//               arithmetic; 3 without the Riemann arithmetic only; 4 without the three directional passes only; 5 the
+//               vertical face states neither stored nor loaded (the ceiling of column-walking designs)
 // Everything else that was A/B-tested in rounds 1-2 (LDS swizzles, element orders, load orders, own/neighbour flux
 // forms, non-temporal stores, extra face fields, the 16x16x4 MFMA shape ...) is decided and gone: DESIGN.md 4.1
 // keeps the measurements.
@@ -53,6 +54,10 @@ constexpr int kMfFieldBatch = 8;      // matrix-core passes of the fused kernel:
 constexpr int kJvpMfFieldBatch = 4;   // ... of the JVP kernel
 constexpr bool kSkelFace = WX_K2_DIAG == 2 || WX_K2_DIAG == 3;
 constexpr bool kSkelDirs = WX_K2_DIAG == 2 || WX_K2_DIAG == 4;
+// 5: the ceiling of every design that keeps the VERTICAL face states on chip (a workgroup walking a column, the top face handed
+// to the next element through LDS): the extrapolation kernel neither computes nor stores them, the fused kernel never loads
+// them (wrong results) - what such a design could gain before it pays for its own work (profiles/r04_vertical_faces_ceiling.txt)
+constexpr bool kNoVertFaces = WX_K2_DIAG == 5;
 
 // the streamed-once static fields go through non-temporal loads
 __device__ __forceinline__ double ldm(const double* p) { return __builtin_nontemporal_load(p); }
@@ -269,7 +274,7 @@ __device__ __forceinline__ void store_r<dual>(const EulerParams<dual>& P, size_t
 // Phase 1-2 on nodal values already staged in LDS (log rho, rho u1, rho u2, rho w, log rho*theta):
 // one thread per face point extrapolates, exponentiates, writes the interface buffer and, on outward
 // tile-edge faces, the rotated / flipped edge message.  Shared by K1 and by K2's stage-pipeline epilogue.
-template <int N, typename T>
+template <int N, typename T, bool COLM = false>
 __device__ __forceinline__ void extrap_faces(const EulerParams<T>& P, T (*fld)[Cfg<N>::EPB * Cfg<N>::LE], int slot0,
                                              int count, int region, T* itf_dst, T* ss, T* sn, T* sw, T* se) {
     using C = Cfg<N>;
@@ -284,8 +289,9 @@ __device__ __forceinline__ void extrap_faces(const EulerParams<T>& P, T (*fld)[C
         // a face is a whole number of waves when n^2 is a multiple of 64 (n = 8): tell the compiler, so that the
         // face's direction, strides and weights live in scalar registers
         if (N2 % 64 == 0 && BS % 64 == 0) f = __builtin_amdgcn_readfirstlane(f);
-        const Elem el = decode_elem(slot0 + le, count, region, H, V);
+        const Elem el = COLM ? decode_elem_col(slot0 + le, count, region, H, V) : decode_elem(slot0 + le, count, region, H, V);
         if (!el.valid) continue;
+        if (kNoVertFaces && f >= 4) continue;
         const int d = f >> 1, plus = f & 1;
         const int a = fp / N, b = fp % N;
         // point index of m-th node on the line normal to the face, and its stride
@@ -661,10 +667,15 @@ __device__ __forceinline__ void face_load(const EulerParams<T>& P, const Elem& e
         }
     }
     if (!split) {
+        if (kNoVertFaces && d == 2) {   // diagnostic: a plausible state without a load
 #pragma unroll
-        for (int v = 0; v < 5; ++v) {
-            in.qo[v] = own[v * N2];
-            in.qn[v] = nbr[v * nstride];
+            for (int v = 0; v < 5; ++v) { in.qo[v] = T(v == 0 ? 1.0 : (v == 4 ? 300.0 : 1e-5)); in.qn[v] = in.qo[v]; }
+        } else {
+#pragma unroll
+            for (int v = 0; v < 5; ++v) {
+                in.qo[v] = own[v * N2];
+                in.qn[v] = nbr[v * nstride];
+            }
         }
     }
     in.sg = *sgp; in.h0 = hp[0]; in.h1 = hp[hfs]; in.h2 = hp[2 * hfs];
@@ -809,7 +820,7 @@ __device__ __forceinline__ void k2_forcing(const EulerParams<T>& P, bool active,
 template <int N, typename T, bool PIPE, bool COLM = false>
 __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
     using C = Cfg<N>;
-    static_assert(!COLM || (std::is_same<T, double>::value && !PIPE), "the column form: float64, plain kernel");
+    static_assert(!COLM || std::is_same<T, double>::value, "the column form: float64");
     const int bx = COLM ? xcd_slab_block(blockIdx.x, gridDim.x >> 3) : (int)blockIdx.x;
     constexpr int N2 = C::N2, N3 = C::N3, EPB = C::EPB, BS = C::BS;
     constexpr int NF = 8;   // staged fields: 4 F rows, A, B (per direction) + log p + sqrtG*rho
@@ -1111,7 +1122,7 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
             fld[4][lpt] = active ? w_log(r4) : T(0.0);
         }
         __syncthreads();
-        extrap_faces<N, T>(P, fld, blockIdx.x * EPB, P.count, P.region, P.itf_out, P.nsend_s, P.nsend_n, P.nsend_w, P.nsend_e);
+        extrap_faces<N, T, COLM>(P, fld, bx * EPB, P.count, P.region, P.itf_out, P.nsend_s, P.nsend_n, P.nsend_w, P.nsend_e);
     }
 #undef WX_STAMP
 #undef WX_FR
@@ -1493,9 +1504,9 @@ static wx_status launch_extrap(const EulerParams<T>& P, hipStream_t st) {
     return WX_OK;
 }
 
-template <int N>
+template <int N, bool PIPE>
 __global__ __launch_bounds__(Cfg<N>::BS, kK2Waves) void euler_rhs_column_kernel(const EulerParams<double> P) {
-    euler_rhs_body<N, double, false, true>(P);
+    euler_rhs_body<N, double, PIPE, true>(P);
 }
 
 template <int N>
@@ -1503,7 +1514,8 @@ static wx_status launch_rhs_column(const EulerParams<double>& P, hipStream_t st)
     using C = Cfg<N>;
     if (P.count == 0) return WX_OK;
     const int grid = (P.count + C::EPB - 1) / C::EPB;
-    hipLaunchKernelGGL((euler_rhs_column_kernel<N>), dim3(8 * ((grid + 7) / 8)), dim3(C::BS), 0, st, P);
+    if (P.itf_out != nullptr) hipLaunchKernelGGL((euler_rhs_column_kernel<N, true>), dim3(8 * ((grid + 7) / 8)), dim3(C::BS), 0, st, P);
+    else hipLaunchKernelGGL((euler_rhs_column_kernel<N, false>), dim3(8 * ((grid + 7) / 8)), dim3(C::BS), 0, st, P);
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
 }
@@ -1717,8 +1729,8 @@ wx_status run_rhs(wx_euler3d_plan* pl, const void* q, const void* const halo[4],
         P.halo_w = static_cast<const T*>(halo[2]); P.halo_e = static_cast<const T*>(halo[3]);
     }
     if constexpr (std::is_same<T, double>::value) {
-        // column form: launches of the plain kernel on a plan that holds the column slabs
-        if (pl->column && !epilogue && itf_in == 0 && P.q_tan == nullptr) {
+        // column form: launches on a plan that holds the column slabs (the plain kernel and the stage pipeline's)
+        if (pl->column && P.q_tan == nullptr) {
             P.sg = pl->c_sg; P.h = pl->c_h; P.chr = pl->c_chr; P.idz = pl->c_idz;
             P.sgi = pl->c_sgi; P.sgj = pl->c_sgj; P.sgk = pl->c_sgk; P.hi = pl->c_hi; P.hj = pl->c_hj; P.hk = pl->c_hk;
             return dispatch_rhs_column(pl->n, P, st);

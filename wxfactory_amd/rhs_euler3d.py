@@ -131,26 +131,39 @@ class Euler3DPlan:
                                                        ctypes.byref(o), ctypes.byref(m)), "wx_euler3d_plan_create_tile")
         self.edge_count = int(self.lib.wx_euler3d_edge_count(self._h))
         self.column_metric = False
-        if column_metric and (dtype == torch.float64 or self.dual):
-            slabs = column_metric_slabs(metric, n, H, V)
-            if slabs is None and column_metric is True:
+        if column_metric:
+            self.enable_column_metric(column_metric)
+
+    def enable_column_metric(self, mode="auto", slabs=None) -> bool:
+        """Give the plan the column form of its metric (see __init__): mode True - required, ValueError when the arrays differ
+        between levels; "auto" - taken when the check passes.  `slabs`: the result of column_metric_slabs when the caller has
+        it already (the twins of a plan share one set).  Returns whether the plan now runs the column kernels."""
+        if self.column_metric or not (self.dtype == torch.float64 or self.dual):
+            return self.column_metric
+        if slabs is None:
+            slabs = column_metric_slabs(self._metric, self.n, self.H, self.V)
+        if slabs is None:
+            if mode is True:
                 raise ValueError("column_metric=True, but the metric arrays are not the same on all levels")
-            if slabs is not None:
-                cm = Euler3DMetric()
-                for k in _lib.EULER3D_METRIC_FIELDS:
-                    setattr(cm, k, slabs[k].data_ptr() if k in slabs else None)
-                self._keep.append(slabs)
-                check(self.lib.wx_euler3d_plan_set_column_metric(self._h, ctypes.byref(cm)),
-                      "wx_euler3d_plan_set_column_metric")
-                self.column_metric = True
+            return False
+        cm = Euler3DMetric()
+        for k in _lib.EULER3D_METRIC_FIELDS:
+            setattr(cm, k, slabs[k].data_ptr() if k in slabs else None)
+        self._keep.append(slabs)
+        self._column_slabs = slabs
+        check(self.lib.wx_euler3d_plan_set_column_metric(self._h, ctypes.byref(cm)), "wx_euler3d_plan_set_column_metric")
+        self.column_metric = True
+        return True
 
     axpy_two = True  # rhs_axpy takes a second array (z, d)
 
     def twin(self, dtype, dual: bool = False):
         """Plan of another dtype over the same (borrowed) metric tensors."""
-        return Euler3DPlan(self.n, self.H, self.V, self.case_number, self.panel, self._ops, self._metric, dtype=dtype,
-                           dual=dual, on_panel_edge=self.on_panel_edge,
-                           column_metric="auto" if (self.column_metric and (dtype == torch.float64 or dual)) else False)
+        t = Euler3DPlan(self.n, self.H, self.V, self.case_number, self.panel, self._ops, self._metric, dtype=dtype,
+                        dual=dual, on_panel_edge=self.on_panel_edge)
+        if self.column_metric:
+            t.enable_column_metric("auto", slabs=self._column_slabs)   # (the same slabs: no second check, no second copy)
+        return t
 
     def _check_q(self, q):
         if q.dtype != self.dtype or q.numel() != 5 * self.V * self.H * self.H * self.n**3 or not q.is_contiguous() \
@@ -400,6 +413,16 @@ class RhsEuler3D(PanelRhs):
     supports_jvp = True
     supports_pipeline = True
     overlapped_entry = "wx_euler3d_rhs_overlapped"
+
+    def __init__(self, plans, *args, column_metric=False, **kw):
+        """column_metric: False (default: every kernel reads the metric arrays as they were handed over); "auto" - plans whose
+        metric is the same on all levels to rounding (a shallow atmosphere without topography: config/dcmip31.ini, the
+        reference's RHS benchmark) switch to the column form (Euler3DPlan.enable_column_metric), the others stay as they
+        are; True - required of every plan."""
+        super().__init__(plans, *args, **kw)
+        if column_metric:
+            for pl in plans.values():
+                pl.enable_column_metric(column_metric)
     batched = True  # stacked states of several SMALL tiles: one launch per phase for all of them (Euler3DBatch)
     batch_max_points = 4_000_000  # per tile.  Whole E7 panels (14.7 M points) are faster launched one by one (7.07 vs 7.16 ms
     #                               per sphere, 7.01 vs 7.31 ms with the INTERIOR / BOUNDARY split); the 3.7 M-point tiles of the
