@@ -147,7 +147,6 @@ def test_column_metric_stage_pipeline(built_lib, name):
     fused per-step filter): three pipelined SSP-RK3 stages and a filtered last stage against the same stages on the full
     arrays - and RhsEuler3D(column_metric="auto") switches the plans it is given."""
     from tests.gpu_util import device_metric, to_dev
-    from wxfactory_amd.filters import NanFlag, make_filter
     from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D
 
     g = golden(name)
@@ -159,7 +158,6 @@ def test_column_metric_stage_pipeline(built_lib, name):
         full, col = RhsEuler3D(mk()), RhsEuler3D(mk(), column_metric="auto")
         assert all(pl.column_metric for pl in col.plans.values()) and not any(pl.column_metric for pl in full.plans.values())
         Q = torch.stack([to_dev(g.q(p)) for p in range(6)])
-        F = make_filter(g.n, 0.5, 8, 0.0) if hasattr(make_filter, "__call__") else None
         outs = []
         for rhs in (full, col):
             rhs.batched = False

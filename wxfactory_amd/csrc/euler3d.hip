@@ -65,7 +65,6 @@ __device__ __forceinline__ double ldm(const double* p) { return __builtin_nontem
 // same CU) and by the V elements of the column (the same XCD): cached loads
 template <bool CACHED>
 __device__ __forceinline__ double ldm_if(const double* p) { return CACHED ? *p : __builtin_nontemporal_load(p); }
-
 template <int N>
 struct Cfg {
     static constexpr int N2 = N * N;
