@@ -399,6 +399,17 @@ wx_status wx_sw_batch_rhs_axpy(wx_sw_batch* batch, const void* q, const void* y,
  * wx_sw_extrap_pack_slot: wx_sw_extrap_pack into a chosen slot (pipeline start-up).
  * Batches: wx_sw_batch_create_pipelined fixes both edge-buffer sets of every tile (send / halo: slot 0, send2 / halo2:
  * slot 1; the plans must have been reserved); wx_sw_batch_stage reads slot itf_in and prepares the other one. */
+/* The direct form of the evaluation (no interface buffer): the RHS kernel extrapolates the own face states from the element's
+ * nodal values and the neighbour's from the NEIGHBOUR ELEMENT's nodal values in memory; only the tile-edge lines are packed
+ * beforehand - wx_sw_extrap_pack_ring: the ring of elements on the four tile edges - and exchanged.  One launch instead of
+ * the extrapolation + RHS pair, no 36 B/point round trip of face values; same results term by term.
+ * wx_sw_rhs_direct: axpy = 0: out = R(q); axpy != 0: out = a*y + b*q + c*R(q) (y nullable).  Batches alike. */
+wx_status wx_sw_extrap_pack_ring(wx_sw_plan* plan, const void* q, void* const send[4], wx_stream stream);
+wx_status wx_sw_rhs_direct(wx_sw_plan* plan, const void* q, const void* const halo[4], const void* y, void* out, double a,
+                           double b, double c, int axpy, wx_region region, wx_stream stream);
+wx_status wx_sw_batch_extrap_pack_ring(wx_sw_batch* batch, const void* q, size_t panel_stride, wx_stream stream);
+wx_status wx_sw_batch_rhs_direct(wx_sw_batch* batch, const void* q, const void* y, void* out, size_t panel_stride, double a,
+                                 double b, double c, int axpy, wx_region region, wx_stream stream);
 wx_status wx_sw_plan_reserve(wx_sw_plan* plan, int what);
 wx_status wx_sw_extrap_pack_slot(wx_sw_plan* plan, const void* q, void* const send[4], int slot, wx_stream stream);
 wx_status wx_sw_stage(wx_sw_plan* plan, const void* q, const void* const halo[4], const void* y, void* out, double a,

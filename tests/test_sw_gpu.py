@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import SW_FIXTURES, golden_sw, make_sw_oracle, var_err, var_max
+from tests.util import SW_FIXTURES, golden_sw, make_sw_oracle, var_err, var_max  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
@@ -205,6 +205,60 @@ def test_tiles_of_a_24_rank_decomposition(built_lib):
         ref = g.r(t)
         scale = np.maximum(var_max(ref), _scale(g, t, False))
         assert (var_err(R[t], ref) <= TOL * scale).all(), t
+
+
+@pytest.mark.parametrize("name", SW_FIXTURES)
+def test_direct_form_equals_the_two_kernel_form(built_lib, name):
+    """wx_sw_rhs_direct / wx_sw_batch_rhs_direct: no interface buffer - the RHS kernel extrapolates its own face states from
+    LDS and the neighbours' from the neighbour elements' nodal values; only the ring of tile-edge lines is packed before
+    the exchange.  Same arithmetic term by term: the result equals the two-kernel form to the last bits (and with it the
+    reference's R), per tile and batched, with topography, R(Q) and the fused stage update, whole tiles and the
+    INTERIOR / BOUNDARY launches of a travelling exchange."""
+    from wxfactory_amd import _lib
+    from wxfactory_amd.exchange import PanelExchange, RcclComm
+    from wxfactory_amd.rhs_sw import RhsShallowWater
+
+    g = golden_sw(name)
+    plans = {p: _plan(g, p) for p in range(6)}
+    Q = torch.stack([_dev(g.q(p)) for p in range(6)])
+    two = RhsShallowWater(plans)
+    want, want_axpy = two(Q), two.axpy(Q, Q, 0.75, 0.25, 12.5)
+    scale = want.abs().amax(dim=(0, 2, 3), keepdim=True)
+    comm = RcclComm(0, 1, device=DEV)
+    for loop in (False, True):
+        ex = PanelExchange(plans[0].edge_count, DEV, rank=0, world_size=1, loopback=loop, backend="rccl" if loop else "torch",
+                           comm=comm if loop else None)
+        one = RhsShallowWater(plans, ex)
+        one.direct = True
+        got, got_axpy = one(Q), one.axpy(Q, Q, 0.75, 0.25, 12.5)
+        torch.cuda.synchronize()
+        assert ((got - want).abs() <= 1e-15 * scale).all(), (name, loop, float(((got - want).abs() / scale).max()))
+        assert ((got_axpy - want_axpy).abs() <= 1e-15 * want_axpy.abs().amax(dim=(0, 2, 3), keepdim=True)).all(), (name, loop)
+        # the ring-only pack wrote the same edge lines as the full extrapolation
+        twoex = RhsShallowWater(plans, PanelExchange(plans[0].edge_count, DEV, rank=0, world_size=1))
+        twoex(Q)
+        if not loop:
+            torch.cuda.synchronize()
+            assert torch.equal(one.ex.send_buf, twoex.ex.send_buf)
+    # one tile through the plan: the per-tile entry points, halos from the fixture
+    p = 3
+    q = _dev(g.q(p))
+    halo = [_dev(h) for h in g.halo(p, False)]
+    send = torch.zeros((4, plans[p].edge_count), dtype=torch.float64, device=DEV)
+    plans[p].extrap_pack_ring(q, [send[e].data_ptr() for e in range(4)])
+    out = torch.full_like(q, float("nan"))
+    plans[p].rhs_direct(q, [h.data_ptr() for h in halo], out, _lib.WX_REGION_ALL)
+    out2 = torch.full_like(q, float("nan"))
+    if g.H > 2:
+        plans[p].rhs_direct(q, None, out2, _lib.WX_REGION_INTERIOR)
+        plans[p].rhs_direct(q, [h.data_ptr() for h in halo], out2, _lib.WX_REGION_BOUNDARY)
+    torch.cuda.synchronize()
+    ref = g.r(p, False)
+    sc = np.maximum(var_max(ref), _scale(g, p, False))
+    assert (var_err(out.cpu().numpy(), ref) <= TOL * sc).all()
+    if g.H > 2:
+        assert torch.equal(out, out2)
+    comm.close()
 
 
 @pytest.mark.parametrize("topo", [False, True])

@@ -107,3 +107,21 @@ for name, stepper in (("fused stages", fused), ("stage pipeline", piped)):
     b.record()
     torch.cuda.synchronize()
     print(f"S7 SSP-RK3 step from a HIP graph, {name}: {a.elapsed_time(b) / 100 * 1e3:.1f} us")
+
+
+# the direct form (no interface buffer: ring-only pack + ONE launch) against the two-kernel form, eager, GPU time from events
+direct = RhsShallowWater(plans)
+direct.direct = True
+for name, r in (("two kernels", rhs), ("direct form", direct)):
+    for _ in range(5):
+        Rd = r(Q)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        Rd = r(Q)
+    b.record()
+    torch.cuda.synchronize()
+    t = a.elapsed_time(b) / reps * 1e-3
+    print(f"S7 R(Q), {name}: {t*1e6:6.1f} us -> {156.0*6*H*H*n*n/t/1e9:7.1f} GB/s on 156 B/point = {156.0*6*H*H*n*n/t/1e9/80:.1f} % of 8 TB/s"
+          f"  (max |diff| vs two kernels {float((Rd - R).abs().max()):.2e})")

@@ -142,6 +142,12 @@ SIGNATURES = {
                                c_int, c_void_p]),
     "wx_sw_batch_rhs_axpy": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_double, c_double, c_double,
                                      c_int, c_void_p]),
+    "wx_sw_extrap_pack_ring": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p]),
+    "wx_sw_rhs_direct": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_double, c_double, c_double, c_int,
+                                 c_int, c_void_p]),
+    "wx_sw_batch_extrap_pack_ring": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wx_sw_batch_rhs_direct": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_double, c_double, c_double, c_int,
+                                       c_int, c_void_p]),
     "wx_sw_plan_reserve": (c_int, [c_void_p, c_int]),
     "wx_sw_extrap_pack_slot": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_int, c_void_p]),
     "wx_sw_stage": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_double, c_double, c_double, c_int,

@@ -199,10 +199,18 @@ __device__ __forceinline__ void sw_extrap_body(const SwParams<T> P, const SwDyn<
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int N, typename T, bool PIPE = false>
+// DIRECT: no interface buffer - the face stage extrapolates the own face states from the element's nodal values (staged in
+// LDS) and the neighbour's from the NEIGHBOUR ELEMENT's nodal values in memory (an element of the same tile: its lines are
+// one or two cache lines, read by the neighbour's own workgroup too - the launch deals its workgroups to the XCDs in
+// contiguous slabs so that the two meet in one L2), tile-edge faces from the received halo lines as ever.  One launch does
+// what the extrapolation kernel + the RHS kernel do (the tile-edge lines alone are packed by a ring-only extrapolation
+// launch in front of the exchange): no 12 + 24 B/point round trip of the face values, one launch boundary less in a
+// 60 us evaluation.  Same arithmetic term by term (the face sums run in the extrapolation kernel's order).
+template <int N, typename T, bool PIPE = false, bool DIRECT = false>
 __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> D) {
     using C = Cfg2<N>;
     constexpr int N2 = C::N2, EPB = C::EPB, BS = C::BS;
+    static_assert(!(PIPE && DIRECT), "the stage pipeline prepares an interface buffer: not for the direct form");
     const SwSlot<T> S = sw_slot<T>(P, PIPE ? D.slot : 0);   // (the plain kernel reads slot 0: its schedule is untouched)
     __shared__ T fld[3][EPB * C::LE];
     __shared__ T fr[EPB][4][3][N];
@@ -210,10 +218,25 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
     const int tid = threadIdx.x;
     const int H = P.H;
     const size_t fs = (size_t)P.nelem * N2;
+    const int bx = DIRECT ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;   // XCD slabs
     for (int i = tid; i < N * N; i += BS) sD[i] = P.K->D[i];
     if (tid < N) {
         sCm[tid] = P.K->cm[tid];
         sCp[tid] = P.K->cp[tid];
+    }
+    T dq0 = T(1.0), dq1 = T(0.0), dq2 = T(0.0);   // DIRECT: the thread's own nodal state, loaded before the face stage
+    if constexpr (DIRECT) {
+        const int le0 = tid / N2, pt0 = tid % N2;
+        const Elem2 el0 = decode_elem2(bx * EPB + le0, D.count, D.region, H);
+        if (le0 < EPB && el0.valid) {
+            const size_t o0 = (size_t)el0.e * N2 + pt0;
+            const int lp = le0 * C::LE + C::lidx(pt0 / N, pt0 % N);
+            dq0 = D.q[o0]; dq1 = D.q[fs + o0]; dq2 = D.q[2 * fs + o0];
+            T h = dq0;
+            if (P.has_topo) h = h + P.hsurf[o0];
+            fld[0][lp] = h; fld[1][lp] = dq1; fld[2][lp] = dq2;
+        }
+        __syncthreads();
     }
 
     // ---- face stage: AUSM common flux of the 4 faces (rhs_sw.py:157-207)
@@ -221,17 +244,18 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
         const int le = fi / (4 * N);
         const int r = fi % (4 * N);
         const int f = r / N, k = r % N;
-        const Elem2 el = decode_elem2(blockIdx.x * EPB + le, D.count, D.region, H);
+        const Elem2 el = decode_elem2(bx * EPB + le, D.count, D.region, H);
         if (!el.valid) continue;
         const int d = f >> 1, plus = f & 1;
         const T* own = S.itf + ((size_t)el.e * 4 + f) * 3 * N + k;
         const T* nbr;
         size_t nstride = N;
+        long nelem_nbr = -1;   // DIRECT: the neighbour element inside the tile (-1: the face lies on the tile edge)
         size_t o_own, o_nbr;  // slots in the halo-padded interface arrays (own side, neighbour side)
         const double *sgp, *hddp, *hodp, *hsp;
         if (d == 0) {
             const int ne = el.ei + (plus ? 1 : -1);
-            if (ne >= 0 && ne < H) nbr = S.itf + ((size_t)(el.e + (plus ? 1 : -1)) * 4 + (f ^ 1)) * 3 * N + k;
+            if (ne >= 0 && ne < H) { nbr = S.itf + ((size_t)(el.e + (plus ? 1 : -1)) * 4 + (f ^ 1)) * 3 * N + k; nelem_nbr = el.e + (plus ? 1 : -1); }
             else { nbr = (plus ? S.halo_e : S.halo_w) + (size_t)el.ej * N + k; nstride = (size_t)H * N; }
             const size_t row = (size_t)el.ej * (H + 2);
             o_own = (row + el.ei + 1) * 2 * N + plus * N + k;
@@ -239,17 +263,48 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
             sgp = P.sgi; hddp = P.h11i; hodp = P.h21i; hsp = P.hsi;
         } else {
             const int ne = el.ej + (plus ? 1 : -1);
-            if (ne >= 0 && ne < H) nbr = S.itf + ((size_t)(el.e + (plus ? H : -H)) * 4 + (f ^ 1)) * 3 * N + k;
+            if (ne >= 0 && ne < H) { nbr = S.itf + ((size_t)(el.e + (plus ? H : -H)) * 4 + (f ^ 1)) * 3 * N + k; nelem_nbr = el.e + (plus ? H : -H); }
             else { nbr = (plus ? S.halo_n : S.halo_s) + (size_t)el.ei * N + k; nstride = (size_t)H * N; }
             o_own = ((size_t)(el.ej + 1) * H + el.ei) * 2 * N + plus * N + k;
             o_nbr = ((size_t)(el.ej + 1 + (plus ? 1 : -1)) * H + el.ei) * 2 * N + (1 - plus) * N + k;
             sgp = P.sgj; hddp = P.h22j; hodp = P.h12j; hsp = P.hsj;
         }
         T qo[3], qn[3];
+        if constexpr (DIRECT) {
+            const int base = d == 0 ? C::lidx(k, 0) : C::lidx(0, k);
+            const int stride = d == 0 ? 1 : C::NP;
+            const double* wo = plus ? P.K->ep : P.K->em;   // the own face ...
+            const double* wn = plus ? P.K->em : P.K->ep;   // ... is the neighbour's opposite one
 #pragma unroll
-        for (int v = 0; v < 3; ++v) {
-            qo[v] = own[v * N];
-            qn[v] = nbr[v * nstride];
+            for (int v = 0; v < 3; ++v) { qo[v] = T(0.0); qn[v] = T(0.0); }
+#pragma unroll
+            for (int m = 0; m < N; ++m) {
+                const double wm = wo[m];
+#pragma unroll
+                for (int v = 0; v < 3; ++v) qo[v] += wm * fld[v][le * C::LE + base + m * stride];
+            }
+            if (nelem_nbr >= 0) {
+                const size_t nb = (size_t)nelem_nbr * N2 + (d == 0 ? k * N : k);
+                const int ns = d == 0 ? 1 : N;
+#pragma unroll
+                for (int m = 0; m < N; ++m) {
+                    const double wm = wn[m];
+                    T h = D.q[nb + m * ns];
+                    if (P.has_topo) h = h + P.hsurf[nb + m * ns];
+                    qn[0] += wm * h;
+                    qn[1] += wm * D.q[fs + nb + m * ns];
+                    qn[2] += wm * D.q[2 * fs + nb + m * ns];
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < 3; ++v) qn[v] = nbr[v * nstride];
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                qo[v] = own[v * N];
+                qn[v] = nbr[v * nstride];
+            }
         }
         if (P.has_topo) {  // "substract topo after extrapolation" (rhs_sw.py:153-155), slot by slot
             qo[0] = qo[0] - hsp[o_own];
@@ -286,7 +341,7 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
 
     // ---- point stage
     const int le = tid / N2, pt = tid % N2;
-    const Elem2 el = decode_elem2(blockIdx.x * EPB + le, D.count, D.region, H);
+    const Elem2 el = decode_elem2(bx * EPB + le, D.count, D.region, H);
     const bool active = (le < EPB) && el.valid;
     const int jl = pt / N, il = pt % N;
     const int lf = le < EPB ? le : 0;
@@ -297,7 +352,8 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
     T q0 = T(1.0), q1 = T(0.0), q2 = T(0.0);
     double sg = 1.0, h11 = 0, h12 = 0, h21 = 0, h22 = 0;
     if (active) {
-        q0 = D.q[o]; q1 = D.q[fs + o]; q2 = D.q[2 * fs + o];
+        if constexpr (DIRECT) { q0 = dq0; q1 = dq1; q2 = dq2; }
+        else { q0 = D.q[o]; q1 = D.q[fs + o]; q2 = D.q[2 * fs + o]; }
         sg = P.sg[o];
         h11 = P.h11[o]; h12 = P.h12[o]; h21 = P.h21[o]; h22 = P.h22[o];
     }
@@ -317,7 +373,7 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
     for (int d = 0; d < 2; ++d) {
         const T ud = w_sel(d == 0, u1, u2);
         const double ha = d == 0 ? h11 : h12, hb = d == 0 ? h21 : h22;
-        if (d > 0) __syncthreads();
+        if (d > 0 || DIRECT) __syncthreads();   // (DIRECT: the face stage has read the nodal values out of fld)
         if (le < EPB) {
             fld[0][lpt] = sg * w_sel(d == 0, q1, q2);
             fld[1][lpt] = sg * (q1 * ud + (0.5 * kGravity * ha) * hsq);
@@ -366,7 +422,7 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
             fld[2][lpt] = active ? r2 : T(0.0);
         }
         __syncthreads();
-        sw_extrap_faces<N, T>(P, fld, blockIdx.x * EPB, D.count, D.region, sw_slot<T>(P, 1 - D.slot));
+        sw_extrap_faces<N, T>(P, fld, bx * EPB, D.count, D.region, sw_slot<T>(P, 1 - D.slot));
     }
 }
 
@@ -378,6 +434,54 @@ __global__ __launch_bounds__(Cfg2<N>::BS) void sw_extrap_kernel(const SwParams<T
 template <int N, typename T, bool PIPE>
 __global__ __launch_bounds__(Cfg2<N>::BS) void sw_rhs_kernel(const SwParams<T> P, const SwDyn<T> D) {
     sw_rhs_body<N, T, PIPE>(P, D);
+}
+template <int N, typename T>
+__global__ __launch_bounds__(Cfg2<N>::BS) void sw_rhs_direct_kernel(const SwParams<T> P, const SwDyn<T> D) {
+    sw_rhs_body<N, T, false, true>(P, D);
+}
+// the tile-edge lines alone (the ring of elements on the four tile edges): what the direct form still has to exchange
+template <int N, typename T>
+__device__ __forceinline__ void sw_extrap_ring_body(const SwParams<T> P, const SwDyn<T> D) {
+    using C = Cfg2<N>;
+    constexpr int N2 = C::N2, EPB = C::EPB;
+    __shared__ T fld[3][EPB * C::LE];
+    const int tid = threadIdx.x;
+    const int H = P.H;
+    const size_t fs = (size_t)P.nelem * N2;
+    const int w = H > 2 ? H - 2 : 0, ring = H * H - w * w;
+    {
+        const int le = tid / N2, pt = tid % N2;
+        const Elem2 el = decode_elem2(blockIdx.x * EPB + le, ring, WX_REGION_BOUNDARY, H);
+        if (le < EPB && el.valid) {
+            const size_t o = (size_t)el.e * N2 + pt;
+            const int lp = le * C::LE + C::lidx(pt / N, pt % N);
+            T h = D.q[o];
+            if (P.has_topo) h = h + P.hsurf[o];
+            fld[0][lp] = h;
+            fld[1][lp] = D.q[fs + o];
+            fld[2][lp] = D.q[2 * fs + o];
+        }
+    }
+    __syncthreads();
+    sw_extrap_faces<N, T>(P, fld, blockIdx.x * EPB, ring, WX_REGION_BOUNDARY, sw_slot<T>(P, D.slot));
+}
+template <int N, typename T>
+__global__ __launch_bounds__(Cfg2<N>::BS) void sw_extrap_ring_kernel(const SwParams<T> P, const SwDyn<T> D) {
+    sw_extrap_ring_body<N, T>(P, D);
+}
+template <int N, typename T>
+__global__ __launch_bounds__(Cfg2<N>::BS) void sw_extrap_ring_batch_kernel(const SwParams<T>* __restrict__ PB, const T* q,
+                                                                          size_t stride) {
+    SwDyn<T> D{q + (size_t)blockIdx.y * stride, nullptr, 0, 0, 0, nullptr, 0.0, 0.0, 1.0, 0, 0};
+    sw_extrap_ring_body<N, T>(PB[blockIdx.y], D);
+}
+template <int N, typename T>
+__global__ __launch_bounds__(Cfg2<N>::BS) void sw_rhs_direct_batch_kernel(const SwParams<T>* __restrict__ PB, const T* q, T* rhs,
+                                                                         size_t stride, int count, int region, int axpy,
+                                                                         const T* y, double ca, double cb, double cc) {
+    SwDyn<T> D{q + (size_t)blockIdx.y * stride, rhs + (size_t)blockIdx.y * stride, count, region, axpy,
+               y ? y + (size_t)blockIdx.y * stride : nullptr, ca, cb, cc, 0, 0};
+    sw_rhs_body<N, T, false, true>(PB[blockIdx.y], D);
 }
 // several tiles (the panels one rank owns) per launch: blockIdx.y selects the tile's static parameters
 // from a device-resident table; states/results are slices of one stacked array
@@ -475,6 +579,23 @@ wx_status sw_launch(int what, const SwParams<T>* P, const SwDyn<T>& D, const SwP
     if (cnt == 0) return WX_OK;
     const int grid = (cnt + C::EPB - 1) / C::EPB;
     const bool pipe = D.prepare != 0 || D.slot != 0;   // the stage pipeline's instantiation
+    if (what >= 4) {   // the direct form: ring-only extrapolation (4, 6), one-launch RHS with its workgroups in XCD slabs (5, 7)
+        if (what == 4 || what == 6) {
+            const int H = (int)D.count;   // (the ring launches carry H in D.count)
+            const int ww = H > 2 ? H - 2 : 0, ring = H * H - ww * ww;
+            const int g = (ring + C::EPB - 1) / C::EPB;
+            if (g == 0) return WX_OK;
+            if (what == 4) hipLaunchKernelGGL((sw_extrap_ring_kernel<N, T>), dim3(g), dim3(C::BS), 0, st, *P, D);
+            else hipLaunchKernelGGL((sw_extrap_ring_batch_kernel<N, T>), dim3(g, nb), dim3(C::BS), 0, st, table, D.q, stride);
+        } else {
+            const int g8 = 8 * ((grid + 7) / 8);   // a multiple of eight workgroups: the surplus finds no element
+            if (what == 5) hipLaunchKernelGGL((sw_rhs_direct_kernel<N, T>), dim3(g8), dim3(C::BS), 0, st, *P, D);
+            else hipLaunchKernelGGL((sw_rhs_direct_batch_kernel<N, T>), dim3(g8, nb), dim3(C::BS), 0, st, table, D.q, D.rhs, stride,
+                                    D.count, D.region, D.axpy, D.y, D.ca, D.cb, D.cc);
+        }
+        WX_HIP_TRY(hipGetLastError());
+        return WX_OK;
+    }
     switch (what) {
         case 0: hipLaunchKernelGGL((sw_extrap_kernel<N, T>), dim3(grid), dim3(C::BS), 0, st, *P, D); break;
         case 1:
@@ -547,6 +668,24 @@ wx_status sw_batch_run(wx_sw_batch* b, bool extrap, const void* q, void* rhs, si
 }
 
 }  // namespace
+
+template <typename T>
+static wx_status sw_run_direct(wx_sw_plan* pl, const void* q, const void* const halo[4], void* out, int region, int axpy,
+                               const void* y, double a, double b, double c, hipStream_t st) {
+    SwParams<T> P = make_sw_params<T>(pl);
+    set_edges<T>(P, nullptr, halo);
+    SwDyn<T> D{static_cast<const T*>(q), static_cast<T*>(out), sw_region_count(region, pl->H), region, axpy,
+               static_cast<const T*>(y), a, b, c, 0, 0};
+    return sw_dispatch<T>(pl->n, 5, &P, D, nullptr, 0, 0, st);
+}
+
+template <typename T>
+static wx_status sw_batch_direct(wx_sw_batch* b, int what, const void* q, void* out, size_t stride, int region, int axpy,
+                                 const void* y, double ca, double cb, double cc, hipStream_t st) {
+    SwDyn<T> D{static_cast<const T*>(q), static_cast<T*>(out), what == 6 ? b->H : sw_region_count(region, b->H), region, axpy,
+               static_cast<const T*>(y), ca, cb, cc, 0, 0};
+    return sw_dispatch<T>(b->n, what, nullptr, D, static_cast<const SwParams<T>*>(b->table), b->count, stride, st);
+}
 
 extern "C" {
 
@@ -758,6 +897,59 @@ wx_status wx_sw_batch_rhs(wx_sw_batch* b, const void* q, void* rhs, size_t panel
         case WX_F64: return sw_batch_run<double>(b, false, q, rhs, panel_stride, region, st);
         case WX_C128: return sw_batch_run<cplx>(b, false, q, rhs, panel_stride, region, st);
         default: return sw_batch_run<dual>(b, false, q, rhs, panel_stride, region, st);
+    }
+}
+
+// ---- the direct form: no interface buffer (one launch after the exchange of the tile-edge lines)
+wx_status wx_sw_extrap_pack_ring(wx_sw_plan* pl, const void* q, void* const send[4], wx_stream stream) {
+    if (!pl || !q) return fail(WX_ERR_INVALID, "wx_sw_extrap_pack_ring: null argument");
+    WX_STREAM(st, stream);
+    switch (pl->dtype) {
+        case WX_F64: { SwParams<double> P = make_sw_params<double>(pl); set_edges<double>(P, send, nullptr);
+                       SwDyn<double> D{static_cast<const double*>(q), nullptr, pl->H, 0, 0, nullptr, 0.0, 0.0, 1.0, 0, 0};
+                       return sw_dispatch<double>(pl->n, 4, &P, D, nullptr, 0, 0, st); }
+        case WX_C128: { SwParams<cplx> P = make_sw_params<cplx>(pl); set_edges<cplx>(P, send, nullptr);
+                        SwDyn<cplx> D{static_cast<const cplx*>(q), nullptr, pl->H, 0, 0, nullptr, 0.0, 0.0, 1.0, 0, 0};
+                        return sw_dispatch<cplx>(pl->n, 4, &P, D, nullptr, 0, 0, st); }
+        default: { SwParams<dual> P = make_sw_params<dual>(pl); set_edges<dual>(P, send, nullptr);
+                   SwDyn<dual> D{static_cast<const dual*>(q), nullptr, pl->H, 0, 0, nullptr, 0.0, 0.0, 1.0, 0, 0};
+                   return sw_dispatch<dual>(pl->n, 4, &P, D, nullptr, 0, 0, st); }
+    }
+}
+
+wx_status wx_sw_rhs_direct(wx_sw_plan* pl, const void* q, const void* const halo[4], const void* y, void* out, double a,
+                           double b, double c, int axpy, wx_region region, wx_stream stream) {
+    wx_status ok = sw_check_rhs_args(pl, q, out, halo, region);
+    if (ok != WX_OK) return ok;
+    WX_STREAM(st, stream);
+    switch (pl->dtype) {
+        case WX_F64: return sw_run_direct<double>(pl, q, halo, out, region, axpy, y, a, b, c, st);
+        case WX_C128: return sw_run_direct<cplx>(pl, q, halo, out, region, axpy, y, a, b, c, st);
+        default: return sw_run_direct<dual>(pl, q, halo, out, region, axpy, y, a, b, c, st);
+    }
+}
+
+wx_status wx_sw_batch_extrap_pack_ring(wx_sw_batch* b, const void* q, size_t panel_stride, wx_stream stream) {
+    if (!b || !q) return fail(WX_ERR_INVALID, "wx_sw_batch_extrap_pack_ring: null argument");
+    WX_STREAM(st, stream);
+    switch (b->dtype) {
+        case WX_F64: return sw_batch_direct<double>(b, 6, q, nullptr, panel_stride, 0, 0, nullptr, 0.0, 0.0, 1.0, st);
+        case WX_C128: return sw_batch_direct<cplx>(b, 6, q, nullptr, panel_stride, 0, 0, nullptr, 0.0, 0.0, 1.0, st);
+        default: return sw_batch_direct<dual>(b, 6, q, nullptr, panel_stride, 0, 0, nullptr, 0.0, 0.0, 1.0, st);
+    }
+}
+
+wx_status wx_sw_batch_rhs_direct(wx_sw_batch* bt, const void* q, const void* y, void* out, size_t panel_stride, double a,
+                                 double b, double c, int axpy, wx_region region, wx_stream stream) {
+    if (!bt || !q || !out) return fail(WX_ERR_INVALID, "wx_sw_batch_rhs_direct: null argument");
+    if (out == q) return fail(WX_ERR_INVALID, "wx_sw_batch_rhs_direct: output must not alias the state");
+    if (region != WX_REGION_ALL && region != WX_REGION_INTERIOR && region != WX_REGION_BOUNDARY)
+        return fail(WX_ERR_INVALID, "unknown region %d", (int)region);
+    WX_STREAM(st, stream);
+    switch (bt->dtype) {
+        case WX_F64: return sw_batch_direct<double>(bt, 7, q, out, panel_stride, region, axpy, y, a, b, c, st);
+        case WX_C128: return sw_batch_direct<cplx>(bt, 7, q, out, panel_stride, region, axpy, y, a, b, c, st);
+        default: return sw_batch_direct<dual>(bt, 7, q, out, panel_stride, region, axpy, y, a, b, c, st);
     }
 }
 

@@ -103,6 +103,21 @@ class SwPlan:
         check(self.lib.wx_sw_rhs_axpy(self._h, q.data_ptr(), _ptr_array(halo_ptrs), y.data_ptr() if y is not None else None,
                                       out.data_ptr(), a, b, c, region, st), "wx_sw_rhs_axpy")
 
+    def extrap_pack_ring(self, q, send_ptrs):
+        """The tile-edge lines alone (direct form): wx_sw_extrap_pack_ring."""
+        self._check_q(q)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.wx_sw_extrap_pack_ring(self._h, q.data_ptr(), _ptr_array(send_ptrs), st), "wx_sw_extrap_pack_ring")
+
+    def rhs_direct(self, q, halo_ptrs, out, region=_lib.WX_REGION_ALL, y=None, coef=None):
+        """R(q) - or coef = (a, b, c): a*y + b*q + c*R(q) - with no interface buffer (wx_sw_rhs_direct)."""
+        self._check_q(q)
+        self._check_q(out)
+        a, b, c = coef[:3] if coef is not None else (0.0, 0.0, 1.0)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.wx_sw_rhs_direct(self._h, q.data_ptr(), _ptr_array(halo_ptrs), y.data_ptr() if y is not None else None,
+                                        out.data_ptr(), a, b, c, 0 if coef is None else 1, region, st), "wx_sw_rhs_direct")
+
     def reserve(self):
         """Setup-time allocation of the second interface slot (stage pipeline): wx_sw_plan_reserve."""
         if getattr(self, "_reserved", False):
@@ -185,6 +200,16 @@ class SwBatch:
             else:
                 check(self.lib.wx_sw_batch_create(ctypes.byref(self._h), handles, n, send, halo), "wx_sw_batch_create")
 
+    def extrap_pack_ring(self, q):
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.wx_sw_batch_extrap_pack_ring(self._h, q.data_ptr(), self.stride, st), "wx_sw_batch_extrap_pack_ring")
+
+    def rhs_direct(self, q, out, region, y=None, coef=None):
+        a, b, c = coef[:3] if coef is not None else (0.0, 0.0, 1.0)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.wx_sw_batch_rhs_direct(self._h, q.data_ptr(), y.data_ptr() if y is not None else None, out.data_ptr(),
+                                              self.stride, a, b, c, 0 if coef is None else 1, region, st), "wx_sw_batch_rhs_direct")
+
     def extrap_pack_slot(self, q, slot: int):
         st = torch.cuda.current_stream(self.device).cuda_stream
         check(self.lib.wx_sw_batch_extrap_pack_slot(self._h, q.data_ptr(), self.stride, slot, st), "wx_sw_batch_extrap_pack_slot")
@@ -227,6 +252,7 @@ class RhsShallowWater(PanelRhs):
     batched = True
     overlapped_entry = "wx_sw_rhs_overlapped"
     supports_pipeline = True
+    direct = False   # True: the direct form (no interface buffer: ring-only pack, then ONE launch; wx_sw_rhs_direct)
 
     def _pipe_state(self, dtype):
         """The stage pipeline's ping-pong state of one dtype: slot in use, the tensor whose faces are prepared, the two
@@ -316,6 +342,10 @@ class RhsShallowWater(PanelRhs):
             self._batches[dt] = SwBatch(plans, ex)
         b = self._batches[dt]
         out = torch.empty_like(q)
+        if self.direct:
+            b.extrap_pack_ring(q)
+            self._phases(ex, lambda region: b.rhs_direct(q, out, region, y, coef))
+            return out
         b.extrap_pack(q)
         self._phases(ex, lambda region: b.rhs(q, out, region, y, coef))
         return out
