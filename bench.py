@@ -152,7 +152,7 @@ def kernel_source_hash():
     return h.hexdigest()
 
 
-PMC_SUMMARIES = {384.0: "r03_pmc_full_summary.json", 312.0: "r03_pmc_rotzero_summary.json"}
+PMC_SUMMARIES = {384.0: "r04_pmc_full_summary.json", 312.0: "r04_pmc_rotzero_summary.json"}
 
 
 def pmc_traffic(region, n, H, V, bpp=ALGO_BYTES_PER_POINT):

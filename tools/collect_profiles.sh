@@ -32,6 +32,9 @@ pmc sw "$ROOT/tools/swbench.py"
 pmc n4 "$ROOT/tools/matrixbench.py" --orders 4 --reps 5     # the program the n = 4 / 6 times come from
 pmc n6 "$ROOT/tools/matrixbench.py" --orders 6 --reps 5
 echo "== pmc done"; cat "$OUT"/pmc_rotzero_summary.txt "$OUT"/pmc_jvp_summary.txt
+# the bench below quotes roofline.traffic from profiles/<round>_pmc_*_summary.json of THIS tree (hash-checked): put them there
+R=${TAG%%_*}
+for k in rotzero full; do cp "$OUT/pmc_${k}_summary.json" "$ROOT/profiles/${R}_pmc_${k}_summary.json" 2>/dev/null || true; done
 fi
 if [ "$2" = "--stats-only" ]; then
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-extras > "$OUT/bench_profiled.json.log" 2> "$OUT/stats.err") || echo "bench stats failed"
