@@ -95,7 +95,7 @@ extern "C" wx_status wx_stream_copy_variant(const void* src, void* dst, size_t b
 }
 
 // the shape that measured fastest on MI355X (tools/copybench.py, profiles/r04_copybench.log)
-constexpr int kCopyUnroll = 4, kCopyNT = 0, kCopyWgPerCu = 8;
+constexpr int kCopyUnroll = 2, kCopyNT = 1, kCopyWgPerCu = 2;   // the best of tools/copybench.py (profiles/r04_copybench.log)
 extern "C" wx_status wx_stream_copy(const void* src, void* dst, size_t bytes, wx_stream stream) {
     return wx_stream_copy_variant(src, dst, bytes, kCopyUnroll, kCopyNT, kCopyWgPerCu, stream);
 }
