@@ -81,7 +81,8 @@ def test_thread_count_does_not_change_the_result():
 def test_vectorised_float64_path_equals_the_generic_one(name):
     """The float64 entry points run a path written for the vector units (structure-of-arrays scratch, `omp simd` loops,
     exp / log through libmvec: <= 4 ulp) - what bench.py times as the CPU baseline.  Same arithmetic as the scalar,
-    type-generic instantiation that the complex entry points use: faces and R agree to rounding (and both are held to the
+    type-generic instantiation that the complex entry points use: faces and R agree to rounding - 1e-12 of the cancellation scale:
+    which elements fall into the scalar remainder loops depends on the alignment of the arrays - (and both are held to the
     reference's values above)."""
     g = golden(name)
     for p in g.metric_panels():
@@ -94,4 +95,4 @@ def test_vectorised_float64_path_equals_the_generic_one(name):
         want = {}
         make_oracle(g, p).rhs(g.q(p), g.halo(p), want=want)
         scale = np.maximum(var_max(Rb), make_oracle(g, p).cancel_scale(want))
-        assert (var_err(Ra, Rb) <= 1e-13 * scale).all(), (name, p, var_err(Ra, Rb) / scale)
+        assert (var_err(Ra, Rb) <= 1e-12 * scale).all(), (name, p, var_err(Ra, Rb) / scale)
