@@ -703,7 +703,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1 or args.loopback:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if world > 1 or (args.loopback and args.exchange == "torch"):
+    if world > 1 or args.loopback:   # (loopback: a one-rank group, so that the exchange self-check below is rehearsed too)
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if "MASTER_PORT" not in os.environ:   # a free port, as the tests pick theirs
@@ -746,13 +746,76 @@ def main():
     t_setup = time.perf_counter() - t_setup
     edge_doubles = 5 * V * Ht * n * n  # WX_EULER3D_EDGE_FIELDS
     comm = None
+    exchange_report = {"backend": "none needed: one rank owns every tile, the halos alias the packed edge buffers"}
+
+    def all_ranks(flag: bool) -> bool:
+        """True when `flag` holds on every rank (one all-reduce of the process group; the decision is the same everywhere)."""
+        if world == 1 or not dist.is_initialized():
+            return flag
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    def torch_exchange():
+        return PanelExchange(edge_doubles, dev, rank=rank, world_size=world, tiles_per_side=k, loopback=args.loopback,
+                             backend="torch")
+
+    ex = None
     if args.exchange == "rccl" and (world > 1 or args.loopback):
+        # the library's own exchange (wx_comm_*, wx_exchange_*).  Its first run on several GPUs is the driver's: if the
+        # communicator or the buffers cannot be set up on some rank, every rank falls back to all_to_all_single and the
+        # line says so, instead of the whole scaling run being lost
         from wxfactory_amd.exchange import RcclComm
 
-        comm = RcclComm(rank, world, device=dev)   # (the unique id travels through the process group; one rank needs none)
-    ex = PanelExchange(edge_doubles, dev, rank=rank, world_size=world, tiles_per_side=k, loopback=args.loopback,
-                       backend=args.exchange if comm is not None else "torch", comm=comm)
+        why = None
+        try:
+            comm = RcclComm(rank, world, device=dev)   # (the unique id travels through the process group; one rank needs none)
+            ex = PanelExchange(edge_doubles, dev, rank=rank, world_size=world, tiles_per_side=k, loopback=args.loopback,
+                               backend="rccl", comm=comm)
+        except Exception as e:   # noqa: BLE001 - reported in the line
+            why = f"{type(e).__name__}: {e}"
+        if all_ranks(why is None):
+            exchange_report = {"backend": "rccl behind the C ABI (wx_exchange_*: grouped ncclSend / ncclRecv, event fork / join)"}
+        else:
+            ex, comm = None, None
+            exchange_report = {"backend": "torch.distributed.all_to_all_single", "fell_back_from": "rccl behind the C ABI",
+                               "reason": why or "set-up failed on another rank"}
+    elif world > 1 or args.loopback:
+        exchange_report = {"backend": "torch.distributed.all_to_all_single"}
+    if ex is None:
+        ex = torch_exchange()
     rhs = RhsEuler3D(plans, ex, overlap=not args.no_overlap)
+
+    if getattr(ex, "_native", None) is not None and dist.is_initialized():
+        # self-check before anything is timed: the same state through the library's exchange and through
+        # all_to_all_single must give the same R bit for bit on every rank (the second path is the one the gloo tests pin
+        # against the reference's halos); a watchdog turns a communication hang into a message instead of a silent timeout
+        import threading
+
+        def hung():
+            sys.stderr.write(f"bench.py rank {rank}: the first evaluation through the RCCL exchange did not finish in 240 s "
+                             "(grouped ncclSend / ncclRecv between the ranks); rerun with --exchange torch\n")
+            sys.stderr.flush()
+            os._exit(4)
+
+        dog = threading.Timer(240.0, hung)
+        dog.daemon = True
+        dog.start()
+        probe = torch.stack([qs[t] for t in mine]) if mine else qs
+        got = rhs(probe)
+        torch.cuda.synchronize()
+        dog.cancel()
+        rhs_t = RhsEuler3D(plans, torch_exchange(), overlap=not args.no_overlap)
+        want = rhs_t(probe)
+        torch.cuda.synchronize()
+        same = all_ranks(bool(torch.equal(got, want)) if mine else True)
+        exchange_report["selfcheck"] = ("R(Q) bit-identical to the all_to_all_single exchange on every rank" if same else
+                                        "MISMATCH against the all_to_all_single exchange: timed on all_to_all_single instead")
+        if not same:
+            exchange_report["backend"] = "torch.distributed.all_to_all_single"
+            exchange_report["fell_back_from"] = "rccl behind the C ABI"
+            rhs, ex = rhs_t, rhs_t.ex
+        del got, want, probe
 
     # live timing of the dominant kernel: HIP events on the launch stream around every K2 launch
     ev = []
@@ -982,8 +1045,7 @@ def main():
                        "n": n, "H": H, "V": V, "tiles": topo.ntiles, "tile_H": Ht, "tiles_per_gpu": len(mine),
                        "parallelism": f"tile-dd{min(world, topo.ntiles)}",
                        "overlap": not args.no_overlap,
-                       "exchange": ("rccl p2p behind the C ABI (wx_exchange_*), RCCL %d" % comm.version) if comm is not None
-                                   else ("torch.distributed.all_to_all_single" if (world > 1 or args.loopback) else "aliasing (one rank)"),
+                       "exchange": exchange_report,
                        "metric": "geometry3d: equiangular cubed sphere, DCMIP 3-1 planet (R/125), ztop 10 km"
                                  if args.metric == "true" else "seeded synthetic fields (SURVEY 8d)",
                        "metric_setup_s": round(t_setup, 1)},

@@ -67,14 +67,44 @@ def evaluation(k1_streams, k2_streams):
     striped(k2_streams, lambda p: plans[p].rhs(qs[p], halo[p], outs[p], _lib.WX_REGION_ALL))
 
 
+def split_evaluation(pipelined):
+    """INTERIOR launches on a second stream, BOUNDARY launches (ring elements: 6.5 % of a panel) on the main one, beside
+    them; pipelined: the INTERIOR launch of a panel follows that panel's K1 at once (it needs no other panel's faces)."""
+    side = sides[0]
+    if not pipelined:
+        for p in range(6):
+            plans[p].extrap_pack(qs[p], send[p])
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            for p in range(6):
+                plans[p].rhs(qs[p], None, outs[p], _lib.WX_REGION_INTERIOR)
+    else:
+        for p in range(6):
+            plans[p].extrap_pack(qs[p], send[p])
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                plans[p].rhs(qs[p], None, outs[p], _lib.WX_REGION_INTERIOR)
+    for p in range(6):
+        plans[p].rhs(qs[p], halo[p], outs[p], _lib.WX_REGION_BOUNDARY)
+    main.wait_stream(side)
+
+
 def clock(k1s, k2s):
+    if k1s == "split":
+        fn = lambda: split_evaluation(k2s)  # noqa: E731
+    else:
+        fn = lambda: evaluation(k1s, k2s)  # noqa: E731
+    return clock_fn(fn)
+
+
+def clock_fn(evaluation):
     for _ in range(3):
-        evaluation(k1s, k2s)
+        evaluation()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(a.reps):
-        evaluation(k1s, k2s)
+        evaluation()
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / a.reps
@@ -83,11 +113,33 @@ def clock(k1s, k2s):
 evaluation(1, 1)
 torch.cuda.synchronize()
 ref = [o.clone() for o in outs]
+
+# the product's host classes on the same plans: RhsEuler3D over the aliasing exchange (Python launches, one stream, ALL) and
+# over the library's own exchange in loopback mode (one call of wx_euler3d_rhs_overlapped: INTERIOR on the second stream,
+# grouped sends / receives and BOUNDARY on the first)
+from wxfactory_amd.exchange import RcclComm  # noqa: E402
+from wxfactory_amd.rhs_euler3d import RhsEuler3D  # noqa: E402
+
+state = torch.stack(qs)
+pd = {p: plans[p] for p in range(6)}
+rhs_alias = RhsEuler3D(pd, PanelExchange(plans[0].edge_count, dev, rank=0, world_size=1))
+comm = RcclComm(0, 1, device=dev)
+rhs_loop = RhsEuler3D(pd, PanelExchange(plans[0].edge_count, dev, rank=0, world_size=1, loopback=True, backend="rccl", comm=comm))
+for name, r in (("RhsEuler3D, aliasing exchange", rhs_alias), ("RhsEuler3D, library exchange in loopback (one C call)", rhs_loop)):
+    got = r(state)
+    torch.cuda.synchronize()
+    same = all(torch.equal(got[p], ref[p]) for p in range(6))
+    for rnd in range(2):
+        ms = clock_fn(lambda: r(state))
+        print(f"{name}: {ms:7.4f} ms per evaluation; bit-identical to one stream: {same}", flush=True)
 pts = 6 * V * H * H * n**3
 bpp = plans[0].bytes_per_point
 for rnd in range(2):
-    for k1s, k2s in ((1, 1), (1, 2), (1, 3), (2, 2), (3, 3), (1, 1)):
+    for k1s, k2s in ((1, 1), (1, 2), (2, 2), ("split", False), ("split", True), (1, 1)):
         ms = clock(k1s, k2s)
         same = all(torch.equal(o, r) for o, r in zip(outs, ref))
-        print(f"K1 on {k1s} stream(s), K2 on {k2s}: {ms:7.4f} ms per evaluation = {bpp * pts / ms / 1e6 / 80:5.2f} % of 8 TB/s "
+        label = (f"K1 on {k1s} stream(s), K2 on {k2s}" if k1s != "split" else
+                 "INTERIOR on a second stream beside K1 (pipelined per panel) and BOUNDARY" if k2s else
+                 "INTERIOR on a second stream beside BOUNDARY")
+        print(f"{label}: {ms:7.4f} ms per evaluation = {bpp * pts / ms / 1e6 / 80:5.2f} % of 8 TB/s "
               f"on {bpp:.0f} B/point; bit-identical to one stream: {same}", flush=True)
