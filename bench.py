@@ -137,8 +137,10 @@ def cpu_baseline(n, V, seed, H=60):
                                      "(measured in the survey container, not on this host)"}
 
 
-KERNEL_SOURCES = ("wxfactory_amd/csrc/euler3d.hip", "wxfactory_amd/csrc/wx_math.h", "wxfactory_amd/csrc/wx_mfma.h",
-                  "wxfactory_amd/csrc/wx_common.h", "wxfactory_amd/csrc/wx_panels.h")
+KERNEL_SOURCES = ("wxfactory_amd/csrc/euler3d.hip", "wxfactory_amd/csrc/euler3d_common.h", "wxfactory_amd/csrc/euler3d_extrap.h",
+                  "wxfactory_amd/csrc/euler3d_rhs.h", "wxfactory_amd/csrc/euler3d_jvp.h", "wxfactory_amd/csrc/euler3d_launch.h",
+                  "wxfactory_amd/csrc/wx_math.h", "wxfactory_amd/csrc/wx_mfma.h", "wxfactory_amd/csrc/wx_common.h",
+                  "wxfactory_amd/csrc/wx_panels.h")
 
 
 def kernel_source_hash():

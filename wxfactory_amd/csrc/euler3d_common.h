@@ -1,0 +1,237 @@
+// Shared by every 3-D Euler kernel: launch shape (Cfg), the parameter block (EulerParams), constants, the element
+// descriptor and the value-type helpers (double, complex128, dual).  Included by euler3d.hip only, in this order:
+// euler3d_common.h, euler3d_extrap.h, euler3d_rhs.h, euler3d_jvp.h, euler3d_launch.h.
+#pragma once
+
+namespace wx {
+
+constexpr int kMaxN = 8;
+constexpr int NQ = 5;   // values per face point in the interface buffer and in the edge messages: the prognostic variables
+
+// measured optima (A/B on MI355X): compile-time constants, not build knobs
+constexpr int kK1Waves = 1;           // min waves per SIMD requested for the extrapolation kernel
+constexpr int kK2Waves = 4;           // ... for the fused kernel, 8-byte dtypes (n = 8: two workgroups of 8 waves per CU)
+constexpr int kJvpWaves = 4;          // ... for the JVP kernel
+constexpr int kFieldBatch = 3;        // vector-pipe passes: fields contracted per rolled batch (all 7 at once: 241 VGPRs)
+constexpr int kFieldBatchWide = 4;    // ... 16-byte dtypes (one workgroup per CU: a little more ILP pays)
+constexpr int kMfFieldBatch = 8;      // matrix-core passes of the fused kernel: fields whose operands are in flight together
+constexpr int kJvpMfFieldBatch = 4;   // ... of the JVP kernel
+constexpr bool kSkelFace = WX_K2_DIAG == 2 || WX_K2_DIAG == 3;
+constexpr bool kSkelDirs = WX_K2_DIAG == 2 || WX_K2_DIAG == 4;
+// 5: the ceiling of every design that keeps the VERTICAL face states on chip (a workgroup walking a column, the top face handed
+// to the next element through LDS): the extrapolation kernel neither computes nor stores them, the fused kernel never loads
+// them (wrong results) - what such a design could gain before it pays for its own work (profiles/r04_vertical_faces_ceiling.txt)
+constexpr bool kNoVertFaces = WX_K2_DIAG == 5;
+
+// the streamed-once static fields go through non-temporal loads
+__device__ __forceinline__ double ldm(const double* p) { return __builtin_nontemporal_load(p); }
+// ... unless they are REUSED: the column slabs of a column-invariant metric are read by all n levels of an element (the
+// same CU) and by the V elements of the column (the same XCD): cached loads
+template <bool CACHED>
+__device__ __forceinline__ double ldm_if(const double* p) { return CACHED ? *p : __builtin_nontemporal_load(p); }
+template <int N>
+struct Cfg {
+    static constexpr int N2 = N * N;
+    static constexpr int N3 = N * N * N;
+    // elements per workgroup: whole elements, <= 256 points unless one element is larger
+    static constexpr int EPB = (N3 >= 216) ? 1 : (256 / N3);   // (n = 3 with 8 instead of 9 elements: fused kernel -5 %, extrapolation +9 %)
+    static constexpr int BS = ((EPB * N3 + 63) / 64) * 64;
+    // LDS image of one element's nodal field: rows of N nodes padded to an odd length so that
+    // line reads along i (lane stride = one row) do not pile onto a few banks (N=8: 8-way -> none).
+    // Not for n = 2, 4: there the padding's LDS costs a workgroup per CU (n = 4: 42.3 KB -> 38.2 KB, 3 -> 4 workgroups,
+    // fused kernel 113 -> 99 us on the reference's benchmark size; n = 2 JVP kernel 1 -> 2 workgroups, matvec 0.48 -> 0.33 ms)
+    // and the conflicts it would avoid are at most two-way
+    static constexpr int NP = (N % 2 == 0 && N >= 6) ? N + 1 : N;
+    static constexpr int LE = N2 * NP;  // doubles per element image
+    __host__ __device__ static constexpr int lidx(int kl, int jl, int il) { return (kl * N + jl) * NP + il; }
+};
+
+enum { F_W = 0, F_E = 1, F_S = 2, F_N = 3, F_B = 4, F_T = 5 };
+
+// 1-D operator pieces and the tile's edge tables, in device memory (one copy per plan): dynamic
+// indexing into a by-value kernel argument would force the whole struct into scratch.
+struct EulerConsts {
+    double em[kMaxN], ep[kMaxN], cm[kMaxN], cp[kMaxN];
+    double D[kMaxN * kMaxN], HF[kMaxN * kMaxN];
+    double EF[kMaxN * kMaxN];  // nodal exponential filter (wx_euler3d_set_exp_filter), identity until set
+    double rot[4][8];
+    int flip[4];
+};
+
+template <typename T>
+struct EulerParams {
+    int H, V, nelem, count, region;
+    int advection_only, has_damp;
+    int rot_zero;          // plan-time finding: christoffel[:, 0:3] (the rotation symbols) is identically zero
+    int axpy;              // 1: out = ca*y + cb*q + cc*R(q) + cd*z (RK stage / FD Jacobian operator), 0: out = R(q)
+    double ca, cb, cc, cd;
+    const T* y;            // nullable (then ca is ignored)
+    const T* z;            // nullable (then cd is ignored)
+    // stage pipeline: when itf_out != null the kernel also extrapolates ITS OUTPUT (the next stage's state)
+    // to the element faces (phase 1-2 of the NEXT evaluation) into itf_out / nsend_*: no separate K1 pass
+    T* itf_out;
+    T *nsend_s, *nsend_n, *nsend_w, *nsend_e;
+    int efilter;           // stage pipeline only: apply the exponential filter to the stage's output before storing it
+    int* nan_flag;         // ... and raise this device flag when the stored values hold a NaN (nullable)
+    // JVP mode (T = dual only): the state is formed on load as (q_re, jvp_eps * q_tan) from two REAL arrays
+    // and only jvp_scale * tangent(R) is stored, as a real array - no complex temporaries in HBM
+    int jvp;
+    const double *q_re, *q_tan;
+    double* out_tan;
+    double jvp_eps, jvp_scale;
+    // prepared JVP (wx_euler3d_jvp_prepare): the face VALUES of the linearisation state stay in fv (real,
+    // [elem][6][5][n^2]) and in the value halos hv_* for a whole Krylov solve; per product only the face TANGENTS are
+    // extrapolated (ft, real, same layout; tangent edge messages through send_* / halo_* as REAL arrays)
+    int split;   // 0: off; 1: the JVP kernel reads (fv, ft), written by euler_tan_extrap_kernel (split = 2 there: unused flag)
+    double* ft;
+    const double* fv;
+    const double *hv_s, *hv_n, *hv_w, *hv_e;
+    const T* q;
+    T* rhs;
+    T* itf;  // [elem][6 faces][NQ vars][N2]
+    const T *halo_s, *halo_n, *halo_w, *halo_e;
+    T *send_s, *send_n, *send_w, *send_e;
+    const double *sg, *h, *chr, *idz;
+    const double *sgi, *sgj, *sgk, *hi, *hj, *hk;
+    const double *dcoef, *duref, *bsn, *bwe;
+    const EulerConsts* K;  // device memory
+    unsigned long long* stamps;  // WX_K2_DIAG == 1 only, else null
+};
+
+struct Elem {
+    int ek, ej, ei, e;
+    bool valid;
+};
+
+// slot (position in this launch's processing order = memory order of the region's elements) -> element of the tile
+__device__ __forceinline__ Elem decode_elem(int slot, int count, int region, int H, int V) {
+    Elem r;
+    r.valid = slot < count;
+    if (!r.valid) slot = 0;
+    if (region == WX_REGION_ALL) {
+        r.ei = slot % H;
+        r.ej = (slot / H) % H;
+        r.ek = slot / (H * H);
+    } else if (region == WX_REGION_INTERIOR) {
+        const int w = H - 2;
+        r.ei = 1 + slot % w;
+        r.ej = 1 + (slot / w) % w;
+        r.ek = slot / (w * w);
+    } else {
+        const int w = H > 2 ? H - 2 : 0;
+        const int ring = H * H - w * w;
+        r.ek = slot / ring;
+        int s = slot % ring;
+        if (s < H) {
+            r.ej = 0;
+            r.ei = s;
+        } else if (s < 2 * H) {
+            r.ej = H - 1;
+            r.ei = s - H;
+        } else {
+            s -= 2 * H;
+            r.ej = 1 + s % w;
+            r.ei = (s / w) ? H - 1 : 0;
+        }
+    }
+    r.e = (r.ek * H + r.ej) * H + r.ei;
+    return r;
+}
+
+// COLUMN form (plans with a column-invariant metric): the V elements of a column follow each other,
+// so that the column's metric - one (n x n) slab per field instead of V n of them - is fetched once and found in cache
+// by the rest of the column
+__device__ __forceinline__ Elem decode_elem_col(int slot, int count, int region, int H, int V) {
+    Elem r;
+    r.valid = slot < count;
+    if (!r.valid) slot = 0;
+    const int c = slot / V;   // the column within the region, in the order decode_elem walks one level of it
+    r.ek = slot % V;
+    if (region == WX_REGION_ALL) {
+        r.ei = c % H;
+        r.ej = c / H;
+    } else if (region == WX_REGION_INTERIOR) {
+        const int w = H - 2;
+        r.ei = 1 + c % w;
+        r.ej = 1 + c / w;
+    } else {
+        const int w = H > 2 ? H - 2 : 0;
+        int s = c;
+        if (s < H) {
+            r.ej = 0;
+            r.ei = s;
+        } else if (s < 2 * H) {
+            r.ej = H - 1;
+            r.ei = s - H;
+        } else {
+            s -= 2 * H;
+            r.ej = 1 + s % w;
+            r.ei = (s / w) ? H - 1 : 0;
+        }
+    }
+    r.e = (r.ek * H + r.ej) * H + r.ei;
+    return r;
+}
+// (workgroups go to the eight XCDs round-robin: give each XCD a contiguous eighth of the launch, so that a column stays in
+// one L2; the launch has a multiple of eight workgroups, the surplus finds no element)
+__device__ __forceinline__ int xcd_slab_block(int b, int nblocks8) { return (b & 7) * nblocks8 + (b >> 3); }
+
+template <typename T>
+__device__ __forceinline__ T load_q(const EulerParams<T>& P, size_t i) {
+    return P.q[i];
+}
+// float64 plans: the state may be a shifted one, q + eps * v formed on load (finite-difference Jacobian
+// products: no pass that materialises Q + eps v)
+template <>
+__device__ __forceinline__ double load_q<double>(const EulerParams<double>& P, size_t i) {
+    if (P.q_tan != nullptr) return P.q[i] + P.jvp_eps * P.q_tan[i];  // (same expression as load_state<double>)
+    return P.q[i];
+}
+template <>
+__device__ __forceinline__ dual load_q<dual>(const EulerParams<dual>& P, size_t i) {
+    if (P.jvp) return dual(P.q_re[i], P.jvp_eps * P.q_tan[i]);
+    return P.q[i];
+}
+// the five prognostic values of one point, the mode decided ONCE (a branch per load costs the extrapolation
+// kernel 12 %: the compiler no longer issues the five loads back to back)
+template <typename T>
+__device__ __forceinline__ void load_state(const EulerParams<T>& P, size_t o, size_t fs, T& a0, T& a1, T& a2, T& a3, T& a4) {
+    a0 = load_q<T>(P, o); a1 = load_q<T>(P, fs + o); a2 = load_q<T>(P, 2 * fs + o);
+    a3 = load_q<T>(P, 3 * fs + o); a4 = load_q<T>(P, 4 * fs + o);
+}
+template <>
+__device__ __forceinline__ void load_state<double>(const EulerParams<double>& P, size_t o, size_t fs, double& a0, double& a1,
+                                                   double& a2, double& a3, double& a4) {
+    const double* q = P.q;
+    a0 = q[o]; a1 = q[fs + o]; a2 = q[2 * fs + o]; a3 = q[3 * fs + o]; a4 = q[4 * fs + o];
+    if (P.q_tan != nullptr) {
+        const double* v = P.q_tan;
+        const double e = P.jvp_eps;
+        a0 += e * v[o]; a1 += e * v[fs + o]; a2 += e * v[2 * fs + o]; a3 += e * v[3 * fs + o]; a4 += e * v[4 * fs + o];
+    }
+}
+template <>
+__device__ __forceinline__ void load_state<dual>(const EulerParams<dual>& P, size_t o, size_t fs, dual& a0, dual& a1, dual& a2,
+                                                 dual& a3, dual& a4) {
+    if (P.jvp) {
+        const double *r = P.q_re, *t = P.q_tan;
+        const double e = P.jvp_eps;
+        a0 = dual(r[o], e * t[o]); a1 = dual(r[fs + o], e * t[fs + o]); a2 = dual(r[2 * fs + o], e * t[2 * fs + o]);
+        a3 = dual(r[3 * fs + o], e * t[3 * fs + o]); a4 = dual(r[4 * fs + o], e * t[4 * fs + o]);
+    } else {
+        const dual* q = P.q;
+        a0 = q[o]; a1 = q[fs + o]; a2 = q[2 * fs + o]; a3 = q[3 * fs + o]; a4 = q[4 * fs + o];
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void store_r(const EulerParams<T>& P, size_t i, T r) {
+    P.rhs[i] = r;
+}
+template <>
+__device__ __forceinline__ void store_r<dual>(const EulerParams<dual>& P, size_t i, dual r) {
+    if (P.jvp) P.out_tan[i] = P.jvp_scale * r.im;
+    else P.rhs[i] = r;
+}
+
+}  // namespace wx
