@@ -305,10 +305,14 @@ def extras(dev, seed):
 
     n, H = 8, 60
     ops = synthetic.dfr_ops(n)
-    # the true equiangular-gnomonic metric (wxfactory_amd/geometry.py, pinned against the reference's), synthetic state
-    plans = {p: SwPlan(n, H, p, ops, metric2d_torch(CubedSphereTile2D(n, H, p, phi0=0.7853981633974483), dev))
-             for p in range(6)}
-    Q = torch.stack([synthetic.sw_state(n, H, p, dev, seed) for p in range(6)])
+    # the true equiangular-gnomonic metric (wxfactory_amd/geometry.py, pinned against the reference's) and the Galewsky
+    # jet + bump of BASELINE.json's galewsky line (own implementation, wxfactory_amd/initial_sw.py: the reference's cannot run)
+    from wxfactory_amd.initial_sw import galewsky, galewsky_h0
+
+    tiles = [CubedSphereTile2D(n, H, p) for p in range(6)]
+    plans = {p: SwPlan(n, H, p, ops, metric2d_torch(tiles[p], dev)) for p in range(6)}
+    h0 = galewsky_h0(tiles[0].earth_radius, tiles[0].rotation_speed)
+    Q = torch.stack([torch.from_numpy(galewsky(t, True, h0)).to(dev) for t in tiles])
     rhs = RhsShallowWater(plans)
     for _ in range(5):
         rhs(Q)
@@ -320,7 +324,7 @@ def extras(dev, seed):
     torch.cuda.synchronize()
     te = (time.perf_counter() - t0) / reps
     dof = 3 * 6 * H * H * n * n
-    return {"euler_k2_all_27_christoffel": k2_full_metric(dev, seed), "sw_s7": {"workload": "shallow water, n=8, H=60, 6 panels on 1 GPU (1244160 DOF), whole-sphere R(Q)",
+    return {"euler_k2_all_27_christoffel": k2_full_metric(dev, seed), "sw_s7": {"workload": "shallow water, n=8, H=60, 6 panels on 1 GPU (1244160 DOF), whole-sphere R(Q) of the Galewsky jet + bump",
                       "us_per_eval": te * 1e6, "dof_updates_per_s": dof / te,
                       "algorithmic_GBps": 156.0 * 6 * H * H * n * n / te / 1e9,
                       "roofline": {"bound": "hbm", "kernels": "sw_extrap_batch_kernel + sw_rhs_batch_kernel (one R(Q) = both)",

@@ -358,3 +358,54 @@ def test_case6_ini_integrator_epi3_with_pmex(built_lib):
         # both sides solve each step to the tolerance 1e-7 (relative to the update)
         assert (moved > 0).all() and (err <= 1e-6 * moved).all(), (i, err, moved)
         prev = ref
+
+
+@pytest.mark.parametrize("case", ["galewsky", 5])
+def test_own_geometry_and_initial_states_against_the_oracle(built_lib, case):
+    """The whole chain a run without fixtures takes - own geometry + metric (geometry.py), own initial state
+    (initial_sw.py: the Galewsky jet with its bump; Williamson 5 with its mountain and the topography arrays), all six
+    panels through RhsShallowWater - against the NumPy oracle on the same inputs at 1e-10, and the balance property at
+    a size the oracle no longer covers: on the S7 sphere the jet without its bump is steady to truncation error."""
+    from oracle.sw2d import SW2DOracle
+    from wxfactory_amd import initial_sw, synthetic
+    from wxfactory_amd.geometry import CubedSphereTile2D, metric2d
+    from wxfactory_amd.rhs_sw import RhsShallowWater, SwPlan
+
+    n, H = 8, 6
+    ops = synthetic.dfr_ops(n)
+    tiles = [CubedSphereTile2D(n, H, p) for p in range(6)]
+    metrics = [metric2d(t) for t in tiles]
+    if case == "galewsky":
+        h0 = initial_sw.galewsky_h0(tiles[0].earth_radius, tiles[0].rotation_speed)
+        states = [(initial_sw.galewsky(t, True, h0), None) for t in tiles]
+    else:
+        states = [initial_sw.williamson5(t, ops["diff_solpt"], ops["correction"]) for t in tiles]
+    oracles = [SW2DOracle(n, H, ops, m, tp, t.boundary_sn, t.boundary_we, panel=p)
+               for p, (t, m, (_, tp)) in enumerate(zip(tiles, metrics, states))]
+    from oracle import cubed_sphere as cs
+
+    itfs = [o.extrapolate(q) for o, (q, _) in zip(oracles, states)]
+    recvs = cs.route([o.pack_edges(itf) for o, itf in zip(oracles, itfs)])
+    terms = [{} for _ in range(6)]
+    want = [o.rhs(states[p][0], recvs[p], itf=itfs[p], want=terms[p]) for p, o in enumerate(oracles)]
+    plans = {p: SwPlan(n, H, p, ops, {k: _dev(v) for k, v in {**metrics[p], **(states[p][1] or {})}.items()}) for p in range(6)}
+    rhs = RhsShallowWater(plans)
+    got = rhs(torch.stack([_dev(q) for q, _ in states]))
+    torch.cuda.synchronize()
+    for p in range(6):
+        R, ref = got[p].cpu().numpy(), want[p]
+        scale = np.maximum(var_max(ref), SW2DOracle.cancel_scale(terms[p]))
+        assert (var_err(R, ref) <= TOL * scale).all(), (case, p, var_err(R, ref) / scale)
+    if case != "galewsky":
+        return
+    n, H = 8, 60   # S7
+    tiles = [CubedSphereTile2D(n, H, p) for p in range(6)]
+    plans = {p: SwPlan(n, H, p, ops, {k: _dev(v) for k, v in metric2d(t).items()}) for p, t in enumerate(tiles)}
+    rhs = RhsShallowWater(plans)
+    jet = torch.stack([_dev(initial_sw.galewsky(t, False, h0)) for t in tiles])
+    full = torch.stack([_dev(initial_sw.galewsky(t, True, h0)) for t in tiles])
+    Rj, Rf = rhs(jet), rhs(full)
+    torch.cuda.synchronize()
+    assert float(Rj[:, 0].abs().max()) < 1e-7                   # m/s of depth (1.3e-3 at 8 x 8 elements per panel)
+    assert 1e-3 < float(Rf[:, 0].abs().max()) < 1e-1            # the bump's gravity waves set off
+    assert float((Rj[:, 1:].abs().amax(dim=(0, 2, 3, 4)) / jet[:, 1:].abs().amax(dim=(0, 2, 3, 4))).max()) < 1e-9   # 1/s
