@@ -27,17 +27,7 @@ def child(args):
     if args.rot_zero:  # a non-rotating planet: the plan finds the nine rotation symbols zero and skips them
         m["christoffel"].view(3, 9, -1)[:, :3] = 0.0
     if args.column:   # make the synthetic metric the same on all levels and take the column form of the plan
-        n2 = n * n
-        for k in ("sqrtG", "h_contra", "christoffel", "inv_dzdeta"):
-            v = m[k].view(*m[k].shape[:-4], V, H, H, n, n2)
-            v.copy_(v[..., 0:1, :, :, 0:1, :].clone().expand_as(v))
-        for k, hh in (("sqrtG_itf_i", (H, H + 2)), ("h_contra_itf_i", (H, H + 2)), ("sqrtG_itf_j", (H + 2, H)),
-                      ("h_contra_itf_j", (H + 2, H))):
-            v = m[k].view(*m[k].shape[:-4], V, hh[0], hh[1], 2, n, n)
-            v.copy_(v[..., 0:1, :, :, :, 0:1, :].clone().expand_as(v))
-        for k in ("sqrtG_itf_k", "h_contra_itf_k"):
-            v = m[k].view(*m[k].shape[:-4], V + 2, H, H, 2, n2)
-            v.copy_(v[..., 1:2, :, :, 0:1, :].clone().expand_as(v))
+        synthetic.make_level_invariant(m, n, H, V)
     plan = Euler3DPlan(n, H, V, 31, 0, synthetic.dfr_ops(n), m, dtype=dtype, dual=args.dual, column_metric=bool(args.column))
     q = synthetic.euler3d_state(n, H, V, 0, dev)
     if args.cplx:

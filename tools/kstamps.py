@@ -17,7 +17,12 @@ dev = torch.device("cuda", 0)
 n, H, V = 8, 60, 8
 DUAL = "--dual" in sys.argv  # phase timeline of the dual-number instantiation (JVP kernels)
 dt = torch.complex128 if DUAL else torch.float64
-plan = Euler3DPlan(n, H, V, 31, 0, synthetic.dfr_ops(n), synthetic.euler3d_metric(n, H, V, 0, dev), dtype=dt, dual=DUAL)
+COLUMN = "--column" in sys.argv  # the column form of the plan on a level-invariant metric
+m = synthetic.euler3d_metric(n, H, V, 0, dev)
+m["christoffel"].view(3, 9, -1)[:, :3] = 0.0   # non-rotating planet, as the benchmark
+if COLUMN:
+    synthetic.make_level_invariant(m, n, H, V)
+plan = Euler3DPlan(n, H, V, 31, 0, synthetic.dfr_ops(n), m, dtype=dt, dual=DUAL, column_metric=COLUMN)
 q = synthetic.euler3d_state(n, H, V, 0, dev)
 if DUAL:
     q = q + 1e-8j * q

@@ -111,6 +111,24 @@ def euler3d_state(n: int, H: int, V: int, panel: int, device, seed: int = 202508
     return q
 
 
+def make_level_invariant(m, n: int, H: int, V: int):
+    """Overwrite the synthetic 3-D metric `m` (euler3d_metric) in place with its first level / first vertical node, so that
+    it is the same on all levels as a shallow atmosphere's without topography is: the case the column form of the plan
+    (Euler3DPlan(column_metric=...)) is for.  Development benchmarks only."""
+    n2 = n * n
+    for k in ("sqrtG", "h_contra", "christoffel", "inv_dzdeta"):
+        v = m[k].view(*m[k].shape[:-4], V, H, H, n, n2)
+        v.copy_(v[..., 0:1, :, :, 0:1, :].clone().expand_as(v))
+    for k, hh in (("sqrtG_itf_i", (H, H + 2)), ("h_contra_itf_i", (H, H + 2)), ("sqrtG_itf_j", (H + 2, H)),
+                  ("h_contra_itf_j", (H + 2, H))):
+        v = m[k].view(*m[k].shape[:-4], V, hh[0], hh[1], 2, n, n)
+        v.copy_(v[..., 0:1, :, :, :, 0:1, :].clone().expand_as(v))
+    for k in ("sqrtG_itf_k", "h_contra_itf_k"):
+        v = m[k].view(*m[k].shape[:-4], V + 2, H, H, 2, n2)
+        v.copy_(v[..., 1:2, :, :, 0:1, :].clone().expand_as(v))
+    return m
+
+
 def _pad_itf2(face: torch.Tensor, axis: int, n: int) -> torch.Tensor:
     """2-D twin of _pad_itf; the shallow-water interface metric keeps its values in the outermost
     slots too (geometry/metric2d.py), harmless either way."""
