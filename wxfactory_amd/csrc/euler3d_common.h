@@ -63,6 +63,7 @@ struct EulerParams {
     int H, V, nelem, count, region;
     int advection_only, has_damp;
     int rot_zero;          // plan-time finding: christoffel[:, 0:3] (the rotation symbols) is identically zero
+    int grid3;             // set by the single-tile launchers of one-element workgroups: the element IS the 3-D block index
     int axpy;              // 1: out = ca*y + cb*q + cc*R(q) + cd*z (RK stage / FD Jacobian operator), 0: out = R(q)
     double ca, cb, cc, cd;
     const T* y;            // nullable (then ca is ignored)
@@ -137,6 +138,48 @@ __device__ __forceinline__ Elem decode_elem(int slot, int count, int region, int
     r.e = (r.ek * H + r.ej) * H + r.ei;
     return r;
 }
+
+// One element per workgroup, one tile per launch: the launchers give the grid the region's own shape - (H, H, V) for ALL,
+// (H-2, H-2, V) for INTERIOR, (ring, 1, V) for BOUNDARY - in the same linear order as the slots above, and the element is
+// read off the block index: none of the integer divisions of decode_elem (a reciprocal and ~60 vector instructions) stand
+// between the start of a wave and its first load.
+__device__ __forceinline__ Elem decode_elem_grid(int region, int H) {
+    Elem r;
+    r.valid = true;
+    r.ek = blockIdx.z;
+    if (region == WX_REGION_ALL) {
+        r.ei = blockIdx.x;
+        r.ej = blockIdx.y;
+    } else if (region == WX_REGION_INTERIOR) {
+        r.ei = 1 + blockIdx.x;
+        r.ej = 1 + blockIdx.y;
+    } else {
+        const int w = H > 2 ? H - 2 : 0;
+        int s = blockIdx.x;
+        if (s < H) {
+            r.ej = 0;
+            r.ei = s;
+        } else if (s < 2 * H) {
+            r.ej = H - 1;
+            r.ei = s - H;
+        } else {
+            s -= 2 * H;
+            const int east = s >= w;
+            r.ej = 1 + (east ? s - w : s);
+            r.ei = east ? H - 1 : 0;
+        }
+    }
+    r.e = (r.ek * H + r.ej) * H + r.ei;
+    return r;
+}
+
+// the element of slot `slot` of this launch (general form of the plan)
+template <int EPB, typename T>
+__device__ __forceinline__ Elem decode_blk(const EulerParams<T>& P, int slot, int count, int region) {
+    if (EPB == 1 && P.grid3) return decode_elem_grid(region, P.H);
+    return decode_elem(slot, count, region, P.H, P.V);
+}
+
 
 // COLUMN form (plans with a column-invariant metric): the V elements of a column follow each other,
 // so that the column's metric - one (n x n) slab per field instead of V n of them - is fetched once and found in cache

@@ -22,7 +22,7 @@ __device__ __forceinline__ void extrap_faces(const EulerParams<T>& P, T (*fld)[C
         // a face is a whole number of waves when n^2 is a multiple of 64 (n = 8): tell the compiler, so that the
         // face's direction, strides and weights live in scalar registers
         if (N2 % 64 == 0 && BS % 64 == 0) f = __builtin_amdgcn_readfirstlane(f);
-        const Elem el = COLM ? decode_elem_col(slot0 + le, count, region, H, V) : decode_elem(slot0 + le, count, region, H, V);
+        const Elem el = COLM ? decode_elem_col(slot0 + le, count, region, H, V) : decode_blk<EPB>(P, slot0 + le, count, region);
         if (!el.valid) continue;
         if (kNoVertFaces && f >= 4) continue;
         const int d = f >> 1, plus = f & 1;
@@ -89,7 +89,7 @@ __device__ __forceinline__ void euler_extrap_body(const EulerParams<T>& P) {
 
     {
         const int le = tid / N3, pt = tid % N3;
-        const Elem el = decode_elem(blockIdx.x * EPB + le, P.nelem, WX_REGION_ALL, H, V);
+        const Elem el = decode_blk<EPB>(P, blockIdx.x * EPB + le, P.nelem, WX_REGION_ALL);
         if (le < EPB && el.valid) {
             const size_t o = (size_t)el.e * N3 + pt;
             const int lp = le * C::LE + C::lidx(pt / N2, (pt / N) % N, pt % N);
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(Cfg<N>::BS, kK1Waves) void euler_tan_extrap_kernel(
     const size_t fs = (size_t)P.nelem * N3;
     {
         const int le = tid / N3, pt = tid % N3;
-        const Elem el = decode_elem(blockIdx.x * EPB + le, P.nelem, WX_REGION_ALL, H, V);
+        const Elem el = decode_blk<EPB>(P, blockIdx.x * EPB + le, P.nelem, WX_REGION_ALL);
         if (le < EPB && el.valid) {
             const size_t o = (size_t)el.e * N3 + pt;
             const int lp = le * C::LE + C::lidx(pt / N2, (pt / N) % N, pt % N);
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(Cfg<N>::BS, kK1Waves) void euler_tan_extrap_kernel(
         int f = r / N2;
         const int fp = r % N2;
         if (N2 % 64 == 0 && BS % 64 == 0) f = __builtin_amdgcn_readfirstlane(f);
-        const Elem el = decode_elem(blockIdx.x * EPB + le, P.nelem, WX_REGION_ALL, H, V);
+        const Elem el = decode_blk<EPB>(P, blockIdx.x * EPB + le, P.nelem, WX_REGION_ALL);
         if (!el.valid) continue;
         const int d = f >> 1, plus = f & 1;
         const int a = fp / N, b = fp % N;

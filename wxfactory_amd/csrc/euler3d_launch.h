@@ -6,11 +6,25 @@ namespace wx {
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// grid of a single-tile launch of one-element workgroups: the region's own shape, in slot order (decode_elem_grid)
+static inline dim3 region_grid(int region, int H, int V) {
+    const int w = H > 2 ? H - 2 : 0;
+    if (region == WX_REGION_ALL) return dim3(H, H, V);
+    if (region == WX_REGION_INTERIOR) return dim3(w, w, V);
+    return dim3(H * H - w * w, 1, V);
+}
+
 template <int N, typename T>
 static wx_status launch_extrap(const EulerParams<T>& P, hipStream_t st) {
     using C = Cfg<N>;
-    const int grid = (P.nelem + C::EPB - 1) / C::EPB;
-    hipLaunchKernelGGL((euler_extrap_kernel<N, T>), dim3(grid), dim3(C::BS), 0, st, P);
+    if constexpr (C::EPB == 1) {
+        EulerParams<T> G = P;
+        G.grid3 = 1;
+        hipLaunchKernelGGL((euler_extrap_kernel<N, T>), region_grid(WX_REGION_ALL, P.H, P.V), dim3(C::BS), 0, st, G);
+    } else {
+        const int grid = (P.nelem + C::EPB - 1) / C::EPB;
+        hipLaunchKernelGGL((euler_extrap_kernel<N, T>), dim3(grid), dim3(C::BS), 0, st, P);
+    }
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
 }
@@ -48,9 +62,17 @@ template <int N, typename T>
 static wx_status launch_rhs(const EulerParams<T>& P, hipStream_t st) {
     using C = Cfg<N>;
     if (P.count == 0) return WX_OK;
-    const int grid = (P.count + C::EPB - 1) / C::EPB;
-    if (P.itf_out != nullptr) hipLaunchKernelGGL((euler_rhs_kernel<N, T, true>), dim3(grid), dim3(C::BS), 0, st, P);
-    else hipLaunchKernelGGL((euler_rhs_kernel<N, T, false>), dim3(grid), dim3(C::BS), 0, st, P);
+    if constexpr (C::EPB == 1) {
+        EulerParams<T> G = P;
+        G.grid3 = 1;
+        const dim3 grid = region_grid(P.region, P.H, P.V);
+        if (P.itf_out != nullptr) hipLaunchKernelGGL((euler_rhs_kernel<N, T, true>), grid, dim3(C::BS), 0, st, G);
+        else hipLaunchKernelGGL((euler_rhs_kernel<N, T, false>), grid, dim3(C::BS), 0, st, G);
+    } else {
+        const int grid = (P.count + C::EPB - 1) / C::EPB;
+        if (P.itf_out != nullptr) hipLaunchKernelGGL((euler_rhs_kernel<N, T, true>), dim3(grid), dim3(C::BS), 0, st, P);
+        else hipLaunchKernelGGL((euler_rhs_kernel<N, T, false>), dim3(grid), dim3(C::BS), 0, st, P);
+    }
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
 }
@@ -89,8 +111,14 @@ template <int N>
 static wx_status launch_jvp(const EulerParams<dual>& P, hipStream_t st) {
     using C = Cfg<N>;
     if (P.count == 0) return WX_OK;
-    const int grid = (P.count + C::EPB - 1) / C::EPB;
-    hipLaunchKernelGGL((euler_jvp_kernel<N>), dim3(grid), dim3(C::BS), 0, st, P);
+    if constexpr (C::EPB == 1) {
+        EulerParams<dual> G = P;
+        G.grid3 = 1;
+        hipLaunchKernelGGL((euler_jvp_kernel<N>), region_grid(P.region, P.H, P.V), dim3(C::BS), 0, st, G);
+    } else {
+        const int grid = (P.count + C::EPB - 1) / C::EPB;
+        hipLaunchKernelGGL((euler_jvp_kernel<N>), dim3(grid), dim3(C::BS), 0, st, P);
+    }
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
 }
