@@ -80,7 +80,7 @@ EulerParams<T> make_params(const wx_euler3d_plan* pl) {
     EulerParams<T> P;
     const EulerParams<double>& b = pl->base;
     P.H = b.H; P.V = b.V; P.nelem = b.nelem; P.count = b.count; P.region = b.region;
-    P.advection_only = b.advection_only; P.has_damp = b.has_damp; P.rot_zero = b.rot_zero; P.grid3 = 0;
+    P.advection_only = b.advection_only; P.has_damp = b.has_damp; P.rot_zero = b.rot_zero;
     P.q = nullptr; P.rhs = nullptr; P.itf = static_cast<T*>(pl->itf);
     P.axpy = 0; P.ca = P.cb = P.cd = 0.0; P.cc = 1.0; P.y = nullptr; P.z = nullptr;
     P.itf_out = nullptr; P.nsend_s = P.nsend_n = P.nsend_w = P.nsend_e = nullptr;
@@ -483,9 +483,8 @@ wx_status wx_euler3d_jvp_tangent_extrap_pack(wx_euler3d_plan* pl, const double* 
     const int nelem = (int)pl->nelem;
 #define WX_TAN_CASE(NN)                                                                                                \
     case NN:                                                                                                           \
-        P.grid3 = Cfg<NN>::EPB == 1;                                                                                   \
         hipLaunchKernelGGL((euler_tan_extrap_kernel<NN>),                                                              \
-                           Cfg<NN>::EPB == 1 ? region_grid(WX_REGION_ALL, pl->H, pl->V)                                \
+                           grid3_for<NN>() ? region_grid(WX_REGION_ALL, pl->H, pl->V)                                   \
                                              : dim3((nelem + Cfg<NN>::EPB - 1) / Cfg<NN>::EPB),                        \
                            dim3(Cfg<NN>::BS), 0, st, P);                                                               \
         break;

@@ -63,7 +63,6 @@ struct EulerParams {
     int H, V, nelem, count, region;
     int advection_only, has_damp;
     int rot_zero;          // plan-time finding: christoffel[:, 0:3] (the rotation symbols) is identically zero
-    int grid3;             // set by the single-tile launchers of one-element workgroups: the element IS the 3-D block index
     int axpy;              // 1: out = ca*y + cb*q + cc*R(q) + cd*z (RK stage / FD Jacobian operator), 0: out = R(q)
     double ca, cb, cc, cd;
     const T* y;            // nullable (then ca is ignored)
@@ -144,41 +143,34 @@ __device__ __forceinline__ Elem decode_elem(int slot, int count, int region, int
 // read off the block index: none of the integer divisions of decode_elem (a reciprocal and ~60 vector instructions) stand
 // between the start of a wave and its first load.
 __device__ __forceinline__ Elem decode_elem_grid(int region, int H) {
+    // selects, not branches: the prologue stays one basic block, so that the kernel arguments it needs load in one batch
+    const int bx = blockIdx.x, by = blockIdx.y;
+    const int w = H > 2 ? H - 2 : 0;
+    const int t = bx - 2 * H;             // ring position past the south and north rows: west column, then east column
+    const int east = t >= w;
+    const int ring_ej = bx < H ? 0 : (bx < 2 * H ? H - 1 : 1 + (east ? t - w : t));
+    const int ring_ei = bx < H ? bx : (bx < 2 * H ? bx - H : (east ? H - 1 : 0));
+    const bool ring = region == WX_REGION_BOUNDARY;
+    const int off = region == WX_REGION_INTERIOR ? 1 : 0;
     Elem r;
     r.valid = true;
     r.ek = blockIdx.z;
-    if (region == WX_REGION_ALL) {
-        r.ei = blockIdx.x;
-        r.ej = blockIdx.y;
-    } else if (region == WX_REGION_INTERIOR) {
-        r.ei = 1 + blockIdx.x;
-        r.ej = 1 + blockIdx.y;
-    } else {
-        const int w = H > 2 ? H - 2 : 0;
-        int s = blockIdx.x;
-        if (s < H) {
-            r.ej = 0;
-            r.ei = s;
-        } else if (s < 2 * H) {
-            r.ej = H - 1;
-            r.ei = s - H;
-        } else {
-            s -= 2 * H;
-            const int east = s >= w;
-            r.ej = 1 + (east ? s - w : s);
-            r.ei = east ? H - 1 : 0;
-        }
-    }
+    r.ei = ring ? ring_ei : bx + off;
+    r.ej = ring ? ring_ej : by + off;
     r.e = (r.ek * H + r.ej) * H + r.ei;
     return r;
 }
 
-// the element of slot `slot` of this launch (general form of the plan)
-template <int EPB, typename T>
+// the element of slot `slot` of this launch (general form of the plan).  G3: the kernel is a single-tile one launched on
+// the region's grid (a compile-time property: the prologue stays straight-line and the kernel arguments load in one batch)
+template <int EPB, bool G3, typename T>
 __device__ __forceinline__ Elem decode_blk(const EulerParams<T>& P, int slot, int count, int region) {
-    if (EPB == 1 && P.grid3) return decode_elem_grid(region, P.H);
-    return decode_elem(slot, count, region, P.H, P.V);
+    if constexpr (EPB == 1 && G3) return decode_elem_grid(region, P.H);
+    else return decode_elem(slot, count, region, P.H, P.V);
 }
+// single-tile kernels of one-element workgroups run on the region's grid
+template <int N>
+constexpr bool grid3_for() { return Cfg<N>::EPB == 1; }
 
 
 // COLUMN form (plans with a column-invariant metric): the V elements of a column follow each other,

@@ -7,12 +7,13 @@ namespace wx {
 // Phase 1-2 on nodal values already staged in LDS (log rho, rho u1, rho u2, rho w, log rho*theta):
 // one thread per face point extrapolates, exponentiates, writes the interface buffer and, on outward
 // tile-edge faces, the rotated / flipped edge message.  Shared by K1 and by K2's stage-pipeline epilogue.
-template <int N, typename T, bool COLM = false>
+template <int N, typename T, bool COLM = false, bool G3 = false>
 __device__ __forceinline__ void extrap_faces(const EulerParams<T>& P, T (*fld)[Cfg<N>::EPB * Cfg<N>::LE], int slot0,
                                              int count, int region, T* itf_dst, T* ss, T* sn, T* sw, T* se) {
     using C = Cfg<N>;
     constexpr int N2 = C::N2, EPB = C::EPB, BS = C::BS;
     const int tid = threadIdx.x;
+    __builtin_assume(tid < (int)Cfg<N>::BS);   // (the launch bounds: lets one-element workgroups drop their `le < EPB` guards)
     const int H = P.H, V = P.V;
     for (int fi = tid; fi < EPB * 6 * N2; fi += BS) {
         const int le = fi / (6 * N2);
@@ -22,7 +23,7 @@ __device__ __forceinline__ void extrap_faces(const EulerParams<T>& P, T (*fld)[C
         // a face is a whole number of waves when n^2 is a multiple of 64 (n = 8): tell the compiler, so that the
         // face's direction, strides and weights live in scalar registers
         if (N2 % 64 == 0 && BS % 64 == 0) f = __builtin_amdgcn_readfirstlane(f);
-        const Elem el = COLM ? decode_elem_col(slot0 + le, count, region, H, V) : decode_blk<EPB>(P, slot0 + le, count, region);
+        const Elem el = COLM ? decode_elem_col(slot0 + le, count, region, H, V) : decode_blk<EPB, G3>(P, slot0 + le, count, region);
         if (!el.valid) continue;
         if (kNoVertFaces && f >= 4) continue;
         const int d = f >> 1, plus = f & 1;
@@ -77,19 +78,20 @@ __device__ __forceinline__ void extrap_faces(const EulerParams<T>& P, T (*fld)[C
 // ------------------------------------------------------------------------------------------------
 // K1: extrapolation to element faces + tile-edge pack
 // ------------------------------------------------------------------------------------------------
-template <int N, typename T>
+template <int N, typename T, bool G3 = false>
 __device__ __forceinline__ void euler_extrap_body(const EulerParams<T>& P) {
     using C = Cfg<N>;
     constexpr int N2 = C::N2, N3 = C::N3, EPB = C::EPB;
     __shared__ T fld[5][EPB * C::LE];
 
     const int tid = threadIdx.x;
+    __builtin_assume(tid < (int)Cfg<N>::BS);   // (the launch bounds: lets one-element workgroups drop their `le < EPB` guards)
     const int H = P.H, V = P.V;
     const size_t fs = (size_t)P.nelem * N3;
 
     {
         const int le = tid / N3, pt = tid % N3;
-        const Elem el = decode_blk<EPB>(P, blockIdx.x * EPB + le, P.nelem, WX_REGION_ALL);
+        const Elem el = decode_blk<EPB, G3>(P, blockIdx.x * EPB + le, P.nelem, WX_REGION_ALL);
         if (le < EPB && el.valid) {
             const size_t o = (size_t)el.e * N3 + pt;
             const int lp = le * C::LE + C::lidx(pt / N2, (pt / N) % N, pt % N);
@@ -104,12 +106,12 @@ __device__ __forceinline__ void euler_extrap_body(const EulerParams<T>& P) {
     }
     __syncthreads();
 
-    extrap_faces<N, T>(P, fld, blockIdx.x * EPB, P.nelem, WX_REGION_ALL, P.itf, P.send_s, P.send_n, P.send_w, P.send_e);
+    extrap_faces<N, T, false, G3>(P, fld, blockIdx.x * EPB, P.nelem, WX_REGION_ALL, P.itf, P.send_s, P.send_n, P.send_w, P.send_e);
 }
 
 template <int N, typename T>
 __global__ __launch_bounds__(Cfg<N>::BS, kK1Waves) void euler_extrap_kernel(const EulerParams<T> P) {
-    euler_extrap_body<N, T>(P);
+    euler_extrap_body<N, T, grid3_for<N>()>(P);
 }
 
 // K1 for the prepared complex-step JVP (wx_euler3d_jvp_tangent_extrap_pack): only the TANGENTS of the face states of
@@ -124,11 +126,12 @@ __global__ __launch_bounds__(Cfg<N>::BS, kK1Waves) void euler_tan_extrap_kernel(
     constexpr int N2 = C::N2, N3 = C::N3, EPB = C::EPB, BS = C::BS;
     __shared__ double pl[7][EPB * C::LE];
     const int tid = threadIdx.x;
+    __builtin_assume(tid < (int)Cfg<N>::BS);   // (the launch bounds: lets one-element workgroups drop their `le < EPB` guards)
     const int H = P.H, V = P.V;
     const size_t fs = (size_t)P.nelem * N3;
     {
         const int le = tid / N3, pt = tid % N3;
-        const Elem el = decode_blk<EPB>(P, blockIdx.x * EPB + le, P.nelem, WX_REGION_ALL);
+        const Elem el = decode_blk<EPB, grid3_for<N>()>(P, blockIdx.x * EPB + le, P.nelem, WX_REGION_ALL);
         if (le < EPB && el.valid) {
             const size_t o = (size_t)el.e * N3 + pt;
             const int lp = le * C::LE + C::lidx(pt / N2, (pt / N) % N, pt % N);
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(Cfg<N>::BS, kK1Waves) void euler_tan_extrap_kernel(
         int f = r / N2;
         const int fp = r % N2;
         if (N2 % 64 == 0 && BS % 64 == 0) f = __builtin_amdgcn_readfirstlane(f);
-        const Elem el = decode_blk<EPB>(P, blockIdx.x * EPB + le, P.nelem, WX_REGION_ALL);
+        const Elem el = decode_blk<EPB, grid3_for<N>()>(P, blockIdx.x * EPB + le, P.nelem, WX_REGION_ALL);
         if (!el.valid) continue;
         const int d = f >> 1, plus = f & 1;
         const int a = fp / N, b = fp % N;

@@ -43,7 +43,7 @@ __device__ __forceinline__ JvpForcing jvp_forcing(const EulerParams<dual>& P, si
     return r;
 }
 
-template <int N, bool COLM = false>
+template <int N, bool COLM = false, bool G3 = false>
 __device__ __forceinline__ void euler_jvp_body(const EulerParams<dual>& P) {
     using C = Cfg<N>;
     using T = dual;
@@ -56,6 +56,7 @@ __device__ __forceinline__ void euler_jvp_body(const EulerParams<dual>& P) {
     __shared__ double sD[N * N], sHF[N * N], sCm[N], sCp[N];
 
     const int tid = threadIdx.x;
+    __builtin_assume(tid < (int)Cfg<N>::BS);   // (the launch bounds: lets one-element workgroups drop their `le < EPB` guards)
     const int H = P.H, V = P.V;
     const size_t fs = (size_t)P.nelem * N3;
     for (int i = tid; i < N * N; i += BS) {
@@ -68,7 +69,7 @@ __device__ __forceinline__ void euler_jvp_body(const EulerParams<dual>& P) {
     }
 
     const int le = tid / N3, pt = tid % N3;
-    const Elem el = COLM ? decode_elem_col(bx * EPB + le, P.count, P.region, H, V) : decode_blk<EPB>(P, bx * EPB + le, P.count, P.region);
+    const Elem el = COLM ? decode_elem_col(bx * EPB + le, P.count, P.region, H, V) : decode_blk<EPB, G3>(P, bx * EPB + le, P.count, P.region);
     const bool active = (le < EPB) && el.valid;
     const int kl = pt / N2, jl = (pt / N) % N, il = pt % N;
     const int lb = (le < EPB ? le : 0) * C::LE;
@@ -80,7 +81,7 @@ __device__ __forceinline__ void euler_jvp_body(const EulerParams<dual>& P) {
         const int fle = fi / (6 * N2);
         const int r = fi % (6 * N2);
         const int f = r / N2, fp = r % N2;
-        const Elem fel = COLM ? decode_elem_col(bx * EPB + fle, P.count, P.region, H, V) : decode_blk<EPB>(P, bx * EPB + fle, P.count, P.region);
+        const Elem fel = COLM ? decode_elem_col(bx * EPB + fle, P.count, P.region, H, V) : decode_blk<EPB, G3>(P, bx * EPB + fle, P.count, P.region);
         if (!fel.valid) continue;
         T out[7];
         face_problem<N, T, true, COLM>(P, fel, f, fp, out);
@@ -201,7 +202,7 @@ __device__ __forceinline__ void euler_jvp_body(const EulerParams<dual>& P) {
 // high-filter; the tangent of B* has no nodal part and keeps its two-term correction on the vector pipe.
 constexpr int kJvFS = 9 * 64 + 16;   // doubles per face of the JVP kernel's face image (9 quantities)
 
-template <bool COLM = false>
+template <bool COLM = false, bool G3 = false>
 __device__ __forceinline__ void euler_jvp_body_mf(const EulerParams<dual>& P) {
     using T = dual;
     const int bx = COLM ? xcd_slab_block(blockIdx.x, gridDim.x >> 3) : (int)blockIdx.x;
@@ -210,6 +211,7 @@ __device__ __forceinline__ void euler_jvp_body_mf(const EulerParams<dual>& P) {
     __shared__ double fq[6 * kJvFS];   // per face: 0-4 tangents of F*; 5 B*.re; 6, 7 log p_own (value, tangent); 8 B*.im
     __shared__ double sCm[N], sCp[N];
     const int tid = threadIdx.x;
+    __builtin_assume(tid < (int)Cfg<N>::BS);   // (the launch bounds: lets one-element workgroups drop their `le < EPB` guards)
     const int H = P.H, V = P.V;
     const size_t fs = (size_t)P.nelem * N3;
     if (tid < N) {
@@ -217,7 +219,7 @@ __device__ __forceinline__ void euler_jvp_body_mf(const EulerParams<dual>& P) {
         sCp[tid] = P.K->cp[tid];
     }
     const MfOps4 mops = mf4_load_ops(P.K->D, P.K->cm, P.K->cp, P.K->HF, tid & 63);
-    const Elem el = COLM ? decode_elem_col(bx, P.count, P.region, H, V) : decode_blk<1>(P, bx, P.count, P.region);
+    const Elem el = COLM ? decode_elem_col(bx, P.count, P.region, H, V) : decode_blk<1, G3>(P, bx, P.count, P.region);
     const bool active = el.valid;
     const int kl = tid / N2, jl = (tid / N) % N, il = tid % N;
     const int lptm = mf_idx(kl, jl, il);
@@ -314,8 +316,8 @@ __device__ __forceinline__ void euler_jvp_body_mf(const EulerParams<dual>& P) {
 
 template <int N>
 __global__ __launch_bounds__(Cfg<N>::BS, kJvpWaves) void euler_jvp_kernel(const EulerParams<dual> P) {
-    if constexpr (N == 8 && WX_MFMA) euler_jvp_body_mf<false>(P);
-    else euler_jvp_body<N, false>(P);
+    if constexpr (N == 8 && WX_MFMA) euler_jvp_body_mf<false, true>(P);
+    else euler_jvp_body<N, false, grid3_for<N>()>(P);
 }
 
 template <int N>

@@ -17,10 +17,8 @@ static inline dim3 region_grid(int region, int H, int V) {
 template <int N, typename T>
 static wx_status launch_extrap(const EulerParams<T>& P, hipStream_t st) {
     using C = Cfg<N>;
-    if constexpr (C::EPB == 1) {
-        EulerParams<T> G = P;
-        G.grid3 = 1;
-        hipLaunchKernelGGL((euler_extrap_kernel<N, T>), region_grid(WX_REGION_ALL, P.H, P.V), dim3(C::BS), 0, st, G);
+    if constexpr (grid3_for<N>()) {
+        hipLaunchKernelGGL((euler_extrap_kernel<N, T>), region_grid(WX_REGION_ALL, P.H, P.V), dim3(C::BS), 0, st, P);
     } else {
         const int grid = (P.nelem + C::EPB - 1) / C::EPB;
         hipLaunchKernelGGL((euler_extrap_kernel<N, T>), dim3(grid), dim3(C::BS), 0, st, P);
@@ -62,12 +60,10 @@ template <int N, typename T>
 static wx_status launch_rhs(const EulerParams<T>& P, hipStream_t st) {
     using C = Cfg<N>;
     if (P.count == 0) return WX_OK;
-    if constexpr (C::EPB == 1) {
-        EulerParams<T> G = P;
-        G.grid3 = 1;
+    if constexpr (grid3_for<N>()) {
         const dim3 grid = region_grid(P.region, P.H, P.V);
-        if (P.itf_out != nullptr) hipLaunchKernelGGL((euler_rhs_kernel<N, T, true>), grid, dim3(C::BS), 0, st, G);
-        else hipLaunchKernelGGL((euler_rhs_kernel<N, T, false>), grid, dim3(C::BS), 0, st, G);
+        if (P.itf_out != nullptr) hipLaunchKernelGGL((euler_rhs_kernel<N, T, true>), grid, dim3(C::BS), 0, st, P);
+        else hipLaunchKernelGGL((euler_rhs_kernel<N, T, false>), grid, dim3(C::BS), 0, st, P);
     } else {
         const int grid = (P.count + C::EPB - 1) / C::EPB;
         if (P.itf_out != nullptr) hipLaunchKernelGGL((euler_rhs_kernel<N, T, true>), dim3(grid), dim3(C::BS), 0, st, P);
@@ -111,10 +107,8 @@ template <int N>
 static wx_status launch_jvp(const EulerParams<dual>& P, hipStream_t st) {
     using C = Cfg<N>;
     if (P.count == 0) return WX_OK;
-    if constexpr (C::EPB == 1) {
-        EulerParams<dual> G = P;
-        G.grid3 = 1;
-        hipLaunchKernelGGL((euler_jvp_kernel<N>), region_grid(P.region, P.H, P.V), dim3(C::BS), 0, st, G);
+    if constexpr (grid3_for<N>()) {
+        hipLaunchKernelGGL((euler_jvp_kernel<N>), region_grid(P.region, P.H, P.V), dim3(C::BS), 0, st, P);
     } else {
         const int grid = (P.count + C::EPB - 1) / C::EPB;
         hipLaunchKernelGGL((euler_jvp_kernel<N>), dim3(grid), dim3(C::BS), 0, st, P);

@@ -295,7 +295,7 @@ __device__ __forceinline__ void k2_forcing(const EulerParams<T>& P, bool active,
     k2_forcing<T, false>(P, active, o, fs, S, u1, u2, u3, p, fc0, fc1, fc2, gcoef, o, fs);
 }
 
-template <int N, typename T, bool PIPE, bool COLM = false>
+template <int N, typename T, bool PIPE, bool COLM = false, bool G3 = false>
 __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
     using C = Cfg<N>;
     static_assert(!COLM || std::is_same<T, double>::value, "the column form: float64");
@@ -319,6 +319,7 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
     __shared__ double sEF[(PIPE && !MF) ? N * N : 1];
 
     const int tid = threadIdx.x;
+    __builtin_assume(tid < (int)Cfg<N>::BS);   // (the launch bounds: lets one-element workgroups drop their `le < EPB` guards)
     const int H = P.H, V = P.V;
     const size_t fs = (size_t)P.nelem * N3;
     if (PIPE && !MF && P.efilter)
@@ -347,7 +348,7 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
     }
 
     const int le = tid / N3, pt = tid % N3;
-    const Elem el = COLM ? decode_elem_col(bx * EPB + le, P.count, P.region, H, V) : decode_blk<EPB>(P, bx * EPB + le, P.count, P.region);
+    const Elem el = COLM ? decode_elem_col(bx * EPB + le, P.count, P.region, H, V) : decode_blk<EPB, G3>(P, bx * EPB + le, P.count, P.region);
     const bool active = (le < EPB) && el.valid;
     const int kl = pt / N2, jl = (pt / N) % N, il = pt % N;
     const int lb = (le < EPB ? le : 0) * C::LE;  // LDS base of this thread's element
@@ -389,7 +390,7 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
         int f = r / N2;
         const int fp = r % N2;
         if (N2 % 64 == 0 && BS % 64 == 0) f = __builtin_amdgcn_readfirstlane(f);
-        const Elem fel = COLM ? decode_elem_col(bx * EPB + fle, P.count, P.region, H, V) : decode_blk<EPB>(P, bx * EPB + fle, P.count, P.region);
+        const Elem fel = COLM ? decode_elem_col(bx * EPB + fle, P.count, P.region, H, V) : decode_blk<EPB, G3>(P, bx * EPB + fle, P.count, P.region);
         if (!fel.valid) continue;
         T out[NC];
         face_problem<N, T, false, COLM>(P, fel, f, fp, out);
@@ -601,7 +602,7 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
             fld[4][lpt] = active ? w_log(r4) : T(0.0);
         }
         __syncthreads();
-        extrap_faces<N, T, COLM>(P, fld, bx * EPB, P.count, P.region, P.itf_out, P.nsend_s, P.nsend_n, P.nsend_w, P.nsend_e);
+        extrap_faces<N, T, COLM, G3>(P, fld, bx * EPB, P.count, P.region, P.itf_out, P.nsend_s, P.nsend_n, P.nsend_w, P.nsend_e);
     }
 #undef WX_STAMP
 #undef WX_FR
@@ -612,7 +613,7 @@ constexpr int k2_waves() { return is_complex<T>::value ? 2 : kK2Waves; }
 
 template <int N, typename T, bool PIPE>
 __global__ __launch_bounds__(Cfg<N>::BS, (k2_waves<N, T>())) void euler_rhs_kernel(const EulerParams<T> P) {
-    euler_rhs_body<N, T, PIPE>(P);
+    euler_rhs_body<N, T, PIPE, false, grid3_for<N>()>(P);
 }
 
 template <int N, typename T>
