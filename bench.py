@@ -1072,6 +1072,15 @@ def main():
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, V, args.seed, H)
         print(json.dumps(line), flush=True)
+    # teardown in dependency order: nothing in flight, then the library's exchange and communicator, then the process group
+    torch.cuda.synchronize()
+    barrier()
+    try:
+        ex.close()
+    except Exception:   # noqa: BLE001
+        pass
+    if comm is not None:
+        comm.close()
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -256,7 +256,19 @@ def test_rccl_exchange_path_on_one_gpu():
 
         gc.collect()
         torch.cuda.synchronize()
+    except BaseException as exc:
+        # a failure above leaves graphs with RCCL nodes alive in the failed frames, and destroying the communicator under
+        # them aborts the process (profiles/r04_capture_crash.md): say what failed, then drop those frames' locals
+        import traceback
+
+        traceback.print_exc()
+        traceback.clear_frames(exc.__traceback__)
+        raise
     finally:
+        import gc
+
+        gc.collect()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 

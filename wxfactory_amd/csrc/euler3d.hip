@@ -81,6 +81,7 @@ EulerParams<T> make_params(const wx_euler3d_plan* pl) {
     const EulerParams<double>& b = pl->base;
     P.H = b.H; P.V = b.V; P.nelem = b.nelem; P.count = b.count; P.region = b.region;
     P.advection_only = b.advection_only; P.has_damp = b.has_damp; P.rot_zero = b.rot_zero;
+    P.md_v = b.md_v; P.md_h = b.md_h; P.md_w = b.md_w; P.md_ring = b.md_ring;
     P.q = nullptr; P.rhs = nullptr; P.itf = static_cast<T*>(pl->itf);
     P.axpy = 0; P.ca = P.cb = P.cd = 0.0; P.cc = 1.0; P.y = nullptr; P.z = nullptr;
     P.itf_out = nullptr; P.nsend_s = P.nsend_n = P.nsend_w = P.nsend_e = nullptr;
@@ -225,6 +226,13 @@ wx_status wx_euler3d_plan_create_tile(wx_euler3d_plan** out, int n, int H, int V
     }
     EulerParams<double>& b = pl->base;
     b.H = H; b.V = V; b.nelem = (int)pl->nelem; b.count = 0; b.region = 0;
+    {   // multipliers of fast_div (exact while slot * d < 2^32)
+        auto magic = [&](int d) -> unsigned {
+            return (d >= 2 && (unsigned long long)pl->nelem * (unsigned long long)d < (1ull << 32)) ? (unsigned)((1ull << 32) / (unsigned)d) + 1u : 0u;
+        };
+        b.md_v = magic(V); b.md_h = magic(H); b.md_w = magic(H - 2);
+        b.md_ring = magic(H * H - (H > 2 ? (H - 2) * (H - 2) : 0));
+    }
     b.advection_only = case_number < 13; b.has_damp = damp;
     b.sg = m->sqrtG; b.h = m->h_contra; b.chr = m->christoffel; b.idz = m->inv_dzdeta;
     b.sgi = m->sqrtG_itf_i; b.sgj = m->sqrtG_itf_j; b.sgk = m->sqrtG_itf_k;

@@ -63,6 +63,7 @@ struct EulerParams {
     int H, V, nelem, count, region;
     int advection_only, has_damp;
     int rot_zero;          // plan-time finding: christoffel[:, 0:3] (the rotation symbols) is identically zero
+    unsigned md_v, md_h, md_w, md_ring;   // floor(2^32 / d) + 1 for d = V, H, H - 2, H^2 - (H-2)^2, or 0: the decodes' fast_div
     int axpy;              // 1: out = ca*y + cb*q + cc*R(q) + cd*z (RK stage / FD Jacobian operator), 0: out = R(q)
     double ca, cb, cc, cd;
     const T* y;            // nullable (then ca is ignored)
@@ -103,25 +104,32 @@ struct Elem {
     bool valid;
 };
 
+// n / d with m = floor(2^32 / d) + 1 from the host: one multiply, exact while n d < 2^32 (the host passes m = 0 otherwise, and
+// for d < 2: then the division itself)
+__device__ __forceinline__ int fast_div(int n, int d, unsigned m) { return m ? (int)__umulhi((unsigned)n, m) : n / d; }
+
 // slot (position in this launch's processing order = memory order of the region's elements) -> element of the tile
-__device__ __forceinline__ Elem decode_elem(int slot, int count, int region, int H, int V) {
+__device__ __forceinline__ Elem decode_elem(int slot, int count, int region, int H, int V, unsigned md_h, unsigned md_w,
+                                           unsigned md_ring) {
     Elem r;
     r.valid = slot < count;
     if (!r.valid) slot = 0;
     if (region == WX_REGION_ALL) {
-        r.ei = slot % H;
-        r.ej = (slot / H) % H;
-        r.ek = slot / (H * H);
+        const int row = fast_div(slot, H, md_h);   // = ek * H + ej
+        r.ei = slot - row * H;
+        r.ek = fast_div(row, H, md_h);
+        r.ej = row - r.ek * H;
     } else if (region == WX_REGION_INTERIOR) {
         const int w = H - 2;
-        r.ei = 1 + slot % w;
-        r.ej = 1 + (slot / w) % w;
-        r.ek = slot / (w * w);
+        const int row = fast_div(slot, w, md_w);
+        r.ei = 1 + slot - row * w;
+        r.ek = fast_div(row, w, md_w);
+        r.ej = 1 + row - r.ek * w;
     } else {
         const int w = H > 2 ? H - 2 : 0;
         const int ring = H * H - w * w;
-        r.ek = slot / ring;
-        int s = slot % ring;
+        r.ek = fast_div(slot, ring, md_ring);
+        int s = slot - r.ek * ring;
         if (s < H) {
             r.ej = 0;
             r.ei = s;
@@ -130,8 +138,9 @@ __device__ __forceinline__ Elem decode_elem(int slot, int count, int region, int
             r.ei = s - H;
         } else {
             s -= 2 * H;
-            r.ej = 1 + s % w;
-            r.ei = (s / w) ? H - 1 : 0;
+            const int east = s >= w;
+            r.ej = 1 + (east ? s - w : s);
+            r.ei = east ? H - 1 : 0;
         }
     }
     r.e = (r.ek * H + r.ej) * H + r.ei;
@@ -166,7 +175,7 @@ __device__ __forceinline__ Elem decode_elem_grid(int region, int H) {
 template <int EPB, bool G3, typename T>
 __device__ __forceinline__ Elem decode_blk(const EulerParams<T>& P, int slot, int count, int region) {
     if constexpr (EPB == 1 && G3) return decode_elem_grid(region, P.H);
-    else return decode_elem(slot, count, region, P.H, P.V);
+    else return decode_elem(slot, count, region, P.H, P.V, P.md_h, P.md_w, P.md_ring);
 }
 // single-tile kernels of one-element workgroups run on the region's grid
 template <int N>
@@ -176,19 +185,21 @@ constexpr bool grid3_for() { return Cfg<N>::EPB == 1; }
 // COLUMN form (plans with a column-invariant metric): the V elements of a column follow each other,
 // so that the column's metric - one (n x n) slab per field instead of V n of them - is fetched once and found in cache
 // by the rest of the column
-__device__ __forceinline__ Elem decode_elem_col(int slot, int count, int region, int H, int V) {
+__device__ __forceinline__ Elem decode_elem_col(int slot, int count, int region, int H, int V, unsigned md_v, unsigned md_h,
+                                               unsigned md_w) {
     Elem r;
     r.valid = slot < count;
     if (!r.valid) slot = 0;
-    const int c = slot / V;   // the column within the region, in the order decode_elem walks one level of it
-    r.ek = slot % V;
+    const int c = fast_div(slot, V, md_v);   // the column within the region, in the order decode_elem walks one level of it
+    r.ek = slot - c * V;
     if (region == WX_REGION_ALL) {
-        r.ei = c % H;
-        r.ej = c / H;
+        r.ej = fast_div(c, H, md_h);
+        r.ei = c - r.ej * H;
     } else if (region == WX_REGION_INTERIOR) {
         const int w = H - 2;
-        r.ei = 1 + c % w;
-        r.ej = 1 + c / w;
+        const int row = fast_div(c, w, md_w);
+        r.ei = 1 + c - row * w;
+        r.ej = 1 + row;
     } else {
         const int w = H > 2 ? H - 2 : 0;
         int s = c;
@@ -200,8 +211,9 @@ __device__ __forceinline__ Elem decode_elem_col(int slot, int count, int region,
             r.ei = s - H;
         } else {
             s -= 2 * H;
-            r.ej = 1 + s % w;
-            r.ei = (s / w) ? H - 1 : 0;
+            const int east = s >= w;
+            r.ej = 1 + (east ? s - w : s);
+            r.ei = east ? H - 1 : 0;
         }
     }
     r.e = (r.ek * H + r.ej) * H + r.ei;

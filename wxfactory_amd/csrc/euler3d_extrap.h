@@ -23,7 +23,7 @@ __device__ __forceinline__ void extrap_faces(const EulerParams<T>& P, T (*fld)[C
         // a face is a whole number of waves when n^2 is a multiple of 64 (n = 8): tell the compiler, so that the
         // face's direction, strides and weights live in scalar registers
         if (N2 % 64 == 0 && BS % 64 == 0) f = __builtin_amdgcn_readfirstlane(f);
-        const Elem el = COLM ? decode_elem_col(slot0 + le, count, region, H, V) : decode_blk<EPB, G3>(P, slot0 + le, count, region);
+        const Elem el = COLM ? decode_elem_col(slot0 + le, count, region, H, V, P.md_v, P.md_h, P.md_w) : decode_blk<EPB, G3>(P, slot0 + le, count, region);
         if (!el.valid) continue;
         if (kNoVertFaces && f >= 4) continue;
         const int d = f >> 1, plus = f & 1;

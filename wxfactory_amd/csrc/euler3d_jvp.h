@@ -69,7 +69,7 @@ __device__ __forceinline__ void euler_jvp_body(const EulerParams<dual>& P) {
     }
 
     const int le = tid / N3, pt = tid % N3;
-    const Elem el = COLM ? decode_elem_col(bx * EPB + le, P.count, P.region, H, V) : decode_blk<EPB, G3>(P, bx * EPB + le, P.count, P.region);
+    const Elem el = COLM ? decode_elem_col(bx * EPB + le, P.count, P.region, H, V, P.md_v, P.md_h, P.md_w) : decode_blk<EPB, G3>(P, bx * EPB + le, P.count, P.region);
     const bool active = (le < EPB) && el.valid;
     const int kl = pt / N2, jl = (pt / N) % N, il = pt % N;
     const int lb = (le < EPB ? le : 0) * C::LE;
@@ -81,7 +81,7 @@ __device__ __forceinline__ void euler_jvp_body(const EulerParams<dual>& P) {
         const int fle = fi / (6 * N2);
         const int r = fi % (6 * N2);
         const int f = r / N2, fp = r % N2;
-        const Elem fel = COLM ? decode_elem_col(bx * EPB + fle, P.count, P.region, H, V) : decode_blk<EPB, G3>(P, bx * EPB + fle, P.count, P.region);
+        const Elem fel = COLM ? decode_elem_col(bx * EPB + fle, P.count, P.region, H, V, P.md_v, P.md_h, P.md_w) : decode_blk<EPB, G3>(P, bx * EPB + fle, P.count, P.region);
         if (!fel.valid) continue;
         T out[7];
         face_problem<N, T, true, COLM>(P, fel, f, fp, out);
@@ -219,7 +219,7 @@ __device__ __forceinline__ void euler_jvp_body_mf(const EulerParams<dual>& P) {
         sCp[tid] = P.K->cp[tid];
     }
     const MfOps4 mops = mf4_load_ops(P.K->D, P.K->cm, P.K->cp, P.K->HF, tid & 63);
-    const Elem el = COLM ? decode_elem_col(bx, P.count, P.region, H, V) : decode_blk<1, G3>(P, bx, P.count, P.region);
+    const Elem el = COLM ? decode_elem_col(bx, P.count, P.region, H, V, P.md_v, P.md_h, P.md_w) : decode_blk<1, G3>(P, bx, P.count, P.region);
     const bool active = el.valid;
     const int kl = tid / N2, jl = (tid / N) % N, il = tid % N;
     const int lptm = mf_idx(kl, jl, il);

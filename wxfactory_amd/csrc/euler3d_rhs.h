@@ -348,7 +348,7 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
     }
 
     const int le = tid / N3, pt = tid % N3;
-    const Elem el = COLM ? decode_elem_col(bx * EPB + le, P.count, P.region, H, V) : decode_blk<EPB, G3>(P, bx * EPB + le, P.count, P.region);
+    const Elem el = COLM ? decode_elem_col(bx * EPB + le, P.count, P.region, H, V, P.md_v, P.md_h, P.md_w) : decode_blk<EPB, G3>(P, bx * EPB + le, P.count, P.region);
     const bool active = (le < EPB) && el.valid;
     const int kl = pt / N2, jl = (pt / N) % N, il = pt % N;
     const int lb = (le < EPB ? le : 0) * C::LE;  // LDS base of this thread's element
@@ -390,7 +390,7 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
         int f = r / N2;
         const int fp = r % N2;
         if (N2 % 64 == 0 && BS % 64 == 0) f = __builtin_amdgcn_readfirstlane(f);
-        const Elem fel = COLM ? decode_elem_col(bx * EPB + fle, P.count, P.region, H, V) : decode_blk<EPB, G3>(P, bx * EPB + fle, P.count, P.region);
+        const Elem fel = COLM ? decode_elem_col(bx * EPB + fle, P.count, P.region, H, V, P.md_v, P.md_h, P.md_w) : decode_blk<EPB, G3>(P, bx * EPB + fle, P.count, P.region);
         if (!fel.valid) continue;
         T out[NC];
         face_problem<N, T, false, COLM>(P, fel, f, fp, out);

@@ -55,6 +55,7 @@ struct SwDyn {
 template <typename T>
 struct SwParams {
     int H, nelem, has_topo;
+    unsigned md_h, md_w;   // floor(2^32 / d) + 1 for d = H, H - 2, or 0 (sw_fast_div)
     T* itf;  // [elem][4 faces W,E,S,N][3 vars][N]
     const T *halo_s, *halo_n, *halo_w, *halo_e;
     T *send_s, *send_n, *send_w, *send_e;
@@ -75,17 +76,21 @@ struct Elem2 {
     bool valid;
 };
 
-__device__ __forceinline__ Elem2 decode_elem2(int slot, int count, int region, int H) {
+// n / d with m = floor(2^32 / d) + 1 from the host: one multiply, exact while n d < 2^32 (m = 0: the division itself)
+__device__ __forceinline__ int sw_fast_div(int n, int d, unsigned m) { return m ? (int)__umulhi((unsigned)n, m) : n / d; }
+
+__device__ __forceinline__ Elem2 decode_elem2(int slot, int count, int region, int H, unsigned md_h, unsigned md_w) {
     Elem2 r;
     r.valid = slot < count;
     if (!r.valid) slot = 0;
     if (region == WX_REGION_ALL) {
-        r.ei = slot % H;
-        r.ej = slot / H;
+        r.ej = sw_fast_div(slot, H, md_h);
+        r.ei = slot - r.ej * H;
     } else if (region == WX_REGION_INTERIOR) {
         const int w = H - 2;
-        r.ei = 1 + slot % w;
-        r.ej = 1 + slot / w;
+        const int row = sw_fast_div(slot, w, md_w);
+        r.ei = 1 + slot - row * w;
+        r.ej = 1 + row;
     } else {
         const int w = H > 2 ? H - 2 : 0;
         int s = slot;
@@ -97,8 +102,9 @@ __device__ __forceinline__ Elem2 decode_elem2(int slot, int count, int region, i
             r.ei = s - H;
         } else {
             s -= 2 * H;
-            r.ej = 1 + s % w;
-            r.ei = (s / w) ? H - 1 : 0;
+            const int east = s >= w;
+            r.ej = 1 + (east ? s - w : s);
+            r.ei = east ? H - 1 : 0;
         }
     }
     r.e = r.ej * H + r.ei;
@@ -133,7 +139,7 @@ __device__ __forceinline__ void sw_extrap_faces(const SwParams<T>& P, T (*fld)[C
         const int le = fi / (4 * N);
         const int r = fi % (4 * N);
         const int f = r / N, k = r % N;
-        const Elem2 el = decode_elem2(slot0 + le, count, region, H);
+        const Elem2 el = decode_elem2(slot0 + le, count, region, H, P.md_h, P.md_w);
         if (!el.valid) continue;
         const int d = f >> 1, plus = f & 1;
         const int base = d == 0 ? C::lidx(k, 0) : C::lidx(0, k);
@@ -183,7 +189,7 @@ __device__ __forceinline__ void sw_extrap_body(const SwParams<T> P, const SwDyn<
     const size_t fs = (size_t)P.nelem * N2;
     {
         const int le = tid / N2, pt = tid % N2;
-        const Elem2 el = decode_elem2(blockIdx.x * EPB + le, P.nelem, WX_REGION_ALL, H);
+        const Elem2 el = decode_elem2(blockIdx.x * EPB + le, P.nelem, WX_REGION_ALL, H, P.md_h, P.md_w);
         if (le < EPB && el.valid) {
             const size_t o = (size_t)el.e * N2 + pt;
             const int lp = le * C::LE + C::lidx(pt / N, pt % N);
@@ -227,7 +233,7 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
     T dq0 = T(1.0), dq1 = T(0.0), dq2 = T(0.0);   // DIRECT: the thread's own nodal state, loaded before the face stage
     if constexpr (DIRECT) {
         const int le0 = tid / N2, pt0 = tid % N2;
-        const Elem2 el0 = decode_elem2(bx * EPB + le0, D.count, D.region, H);
+        const Elem2 el0 = decode_elem2(bx * EPB + le0, D.count, D.region, H, P.md_h, P.md_w);
         if (le0 < EPB && el0.valid) {
             const size_t o0 = (size_t)el0.e * N2 + pt0;
             const int lp = le0 * C::LE + C::lidx(pt0 / N, pt0 % N);
@@ -244,7 +250,7 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
         const int le = fi / (4 * N);
         const int r = fi % (4 * N);
         const int f = r / N, k = r % N;
-        const Elem2 el = decode_elem2(bx * EPB + le, D.count, D.region, H);
+        const Elem2 el = decode_elem2(bx * EPB + le, D.count, D.region, H, P.md_h, P.md_w);
         if (!el.valid) continue;
         const int d = f >> 1, plus = f & 1;
         const T* own = S.itf + ((size_t)el.e * 4 + f) * 3 * N + k;
@@ -341,7 +347,7 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
 
     // ---- point stage
     const int le = tid / N2, pt = tid % N2;
-    const Elem2 el = decode_elem2(bx * EPB + le, D.count, D.region, H);
+    const Elem2 el = decode_elem2(bx * EPB + le, D.count, D.region, H, P.md_h, P.md_w);
     const bool active = (le < EPB) && el.valid;
     const int jl = pt / N, il = pt % N;
     const int lf = le < EPB ? le : 0;
@@ -451,7 +457,7 @@ __device__ __forceinline__ void sw_extrap_ring_body(const SwParams<T> P, const S
     const int w = H > 2 ? H - 2 : 0, ring = H * H - w * w;
     {
         const int le = tid / N2, pt = tid % N2;
-        const Elem2 el = decode_elem2(blockIdx.x * EPB + le, ring, WX_REGION_BOUNDARY, H);
+        const Elem2 el = decode_elem2(blockIdx.x * EPB + le, ring, WX_REGION_BOUNDARY, H, P.md_h, P.md_w);
         if (le < EPB && el.valid) {
             const size_t o = (size_t)el.e * N2 + pt;
             const int lp = le * C::LE + C::lidx(pt / N, pt % N);
@@ -529,7 +535,7 @@ template <typename T>
 SwParams<T> make_sw_params(const wx_sw_plan* pl) {
     SwParams<T> P;
     const SwParams<double>& b = pl->base;
-    P.H = b.H; P.nelem = b.nelem; P.has_topo = b.has_topo;
+    P.H = b.H; P.nelem = b.nelem; P.has_topo = b.has_topo; P.md_h = b.md_h; P.md_w = b.md_w;
     P.itf = static_cast<T*>(pl->itf);
     P.halo_s = P.halo_n = P.halo_w = P.halo_e = nullptr;
     P.send_s = P.send_n = P.send_w = P.send_e = nullptr;
@@ -744,6 +750,8 @@ wx_status wx_sw_plan_create_tile(wx_sw_plan** out, int n, int H, wx_dtype dtype,
     }
     SwParams<double>& b = pl->base;
     b.H = H; b.nelem = H * H; b.has_topo = ntopo == 5;
+    b.md_h = (H >= 2 && (unsigned long long)H * H * H < (1ull << 32)) ? (unsigned)((1ull << 32) / (unsigned)H) + 1u : 0u;
+    b.md_w = (H >= 4 && (unsigned long long)H * H * H < (1ull << 32)) ? (unsigned)((1ull << 32) / (unsigned)(H - 2)) + 1u : 0u;
     b.sg = m->sqrtG; b.h11 = m->H_contra_11; b.h12 = m->H_contra_12; b.h21 = m->H_contra_21; b.h22 = m->H_contra_22;
     b.c101 = m->christoffel_1_01; b.c102 = m->christoffel_1_02; b.c111 = m->christoffel_1_11;
     b.c112 = m->christoffel_1_12; b.c201 = m->christoffel_2_01; b.c202 = m->christoffel_2_02;
