@@ -179,7 +179,9 @@ def pmc_traffic(region, n, H, V, bpp=ALGO_BYTES_PER_POINT):
         if doc.get("build_info") != build:   # an A/B or diagnostic variant (-DWX_MFMA=0, -DWX_K2_DIAG=..) is another kernel
             prov["reason"] = f"PMC pass taken on build '{doc.get('build_info')}', this run is '{build}': traffic refused"
             return None, prov
-        return doc["kernels"]["wx::euler_rhs_kernel<8, double, false>"]["hbm_bytes"], prov
+        k2 = doc["kernels"]["wx::euler_rhs_kernel<8, double, false>"]
+        prov["fetch_bytes"], prov["write_bytes"] = k2.get("fetch_bytes"), k2.get("write_bytes")
+        return k2["hbm_bytes"], prov
     except (OSError, KeyError, ValueError) as e:
         return None, {"reason": f"{type(e).__name__}: {e}"}
 
@@ -207,12 +209,29 @@ def copy_ceiling(dev, gib=2, reps=10):
         if it >= 2:
             ts.append(a.elapsed_time(b) * 1e-3)
     ok = bool(torch.equal(src[:1024], dst[:1024]) and torch.equal(src[-1024:], dst[-1024:]))
-    del src, dst
+    # the read side alone (wx_stream_read): a kernel whose traffic is mostly reads is bounded by this rate, not by the copy's
+    sink = torch.zeros(lib.wx_stream_read_sink_doubles(), dtype=torch.float64, device=dev)
+    tr = []
+    for it in range(reps + 2):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        _lib.check(lib.wx_stream_read(src.data_ptr(), nbytes, sink.data_ptr(), st), "wx_stream_read")
+        b.record()
+        torch.cuda.synchronize()
+        if it >= 2:
+            tr.append(a.elapsed_time(b) * 1e-3)
+    total, want = float(sink.sum()), float(src.sum())
+    read_ok = abs(total - want) <= 1e-9 * float(src.abs().sum())
+    del src, dst, sink
     torch.cuda.empty_cache()
     t = sum(ts) / len(ts)
     gbs = 2.0 * nbytes / t / 1e9
+    rd = nbytes / (sum(tr) / len(tr)) / 1e9
     return {"kernel": "wx_stream_copy", "bytes_read_plus_written": 2 * nbytes, "launch_ms": round(t * 1e3, 4),
-            "achieved": round(gbs, 1), "unit": "GB/s", "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4), "copied_correctly": ok}
+            "achieved": round(gbs, 1), "unit": "GB/s", "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4), "copied_correctly": ok,
+            "read_only": {"kernel": "wx_stream_read", "bytes_read": nbytes, "launch_ms": round(sum(tr) / len(tr) * 1e3, 4),
+                          "achieved": round(rd, 1), "unit": "GB/s", "frac_of_peak": round(rd / HBM_PEAK_GBS, 4),
+                          "sum_correct": bool(read_ok)}}
 
 
 def k2_full_metric(dev, seed, n=8, H=60, V=8, reps=20):
@@ -1035,8 +1054,22 @@ def main():
         roof["ceiling"] = copy_ceiling(dev)
         if roof["ceiling"] and traffic:
             on_traffic = traffic / tk / 1e9
-            roof["on_measured_traffic"] = {"GBps": round(on_traffic, 1), "frac_of_ceiling": round(on_traffic / roof["ceiling"]["achieved"], 4),
+            ceil = roof["ceiling"]
+            roof["on_measured_traffic"] = {"GBps": round(on_traffic, 1), "frac_of_copy_rate": round(on_traffic / ceil["achieved"], 4),
                                            "traffic_over_algorithmic": round(traffic / bytes_launch, 4)}
+            fb, wb = traffic_src.get("fetch_bytes"), traffic_src.get("write_bytes")
+            rd = ceil.get("read_only", {}).get("achieved")
+            if fb and wb and rd:
+                # the time this launch's own mix of reads and writes would take at the measured streaming rates: its reads at
+                # the read-only rate, its writes at the rate the copy's writes are left with once its reads are priced so
+                n_copy = ceil["bytes_read_plus_written"] / 2.0
+                t_copy_writes = ceil["launch_ms"] * 1e-3 - n_copy / (rd * 1e9)
+                if t_copy_writes > 0:
+                    wr = n_copy / t_copy_writes / 1e9
+                    floor_s = tiles_in_launch[region] * (fb / (rd * 1e9) + wb / (wr * 1e9))
+                    roof["on_measured_traffic"].update({"read_rate_GBps": rd, "implied_write_rate_GBps": round(wr, 1),
+                                                        "streaming_floor_ms": round(floor_s * 1e3, 4),
+                                                        "frac_of_streaming_floor": round(floor_s / tk, 4)})
 
     if rank == 0:
         line = {

@@ -82,6 +82,11 @@ int wx_device_count(void);
  * every wave slot of the chip: the measured read-once / write-once rate a kernel's roofline fraction is put beside
  * (bench.py: roofline.ceiling).  Moves 2 x bytes through HBM. */
 wx_status wx_stream_copy(const void* src, void* dst, size_t bytes, wx_stream stream);
+/* The read side alone: `bytes` of src (a multiple of 16) streamed once and summed; sink receives
+ * wx_stream_read_sink_doubles() partial sums (their total = the sum of src: the check that everything was read).  A kernel
+ * whose traffic is mostly reads (the fused RHS kernel: 89 %) is put beside THIS rate, a balanced one beside the copy's. */
+int wx_stream_read_sink_doubles(void);
+wx_status wx_stream_read(const void* src, size_t bytes, double* sink, wx_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * The reference's per-evaluation timing row without torch: RHS.timestamps / retrieve_last_times (rhs/rhs.py:39-41, 68-118;

@@ -59,6 +59,8 @@ SIGNATURES = {
     "wx_build_info": (c_char_p, []),
     "wx_device_count": (c_int, []),
     "wx_stream_copy": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wx_stream_read_sink_doubles": (c_int, []),
+    "wx_stream_read": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
     "wx_phase_timer_create": (c_int, [POINTER(c_void_p)]),
     "wx_phase_timer_destroy": (c_int, [c_void_p]),
     "wx_phase_timer_stamp": (c_int, [c_void_p, c_int, c_void_p]),

@@ -100,6 +100,39 @@ extern "C" wx_status wx_stream_copy(const void* src, void* dst, size_t bytes, wx
     return wx_stream_copy_variant(src, dst, bytes, kCopyUnroll, kCopyNT, kCopyWgPerCu, stream);
 }
 
+// the read side alone: every lane sums what it streams (16 bytes per load, 4 loads in flight), one double per workgroup comes out
+__global__ __launch_bounds__(256) void wx_stream_read_kernel(const double2* __restrict__ src, size_t n16, double* __restrict__ sink) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const double2 *p0 = src + i, *p1 = p0 + stride, *p2 = p1 + stride, *p3 = p2 + stride;
+        const double x0 = __builtin_nontemporal_load(&p0->x), y0 = __builtin_nontemporal_load(&p0->y);
+        const double x1 = __builtin_nontemporal_load(&p1->x), y1 = __builtin_nontemporal_load(&p1->y);
+        const double x2 = __builtin_nontemporal_load(&p2->x), y2 = __builtin_nontemporal_load(&p2->y);
+        const double x3 = __builtin_nontemporal_load(&p3->x), y3 = __builtin_nontemporal_load(&p3->y);
+        a0 += x0 + y0; a1 += x1 + y1; a2 += x2 + y2; a3 += x3 + y3;
+    }
+    for (; i < n16; i += stride) a0 += src[i].x + src[i].y;
+    double a = (a0 + a1) + (a2 + a3);
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) sink[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+extern "C" int wx_stream_read_sink_doubles(void) { return 256 * 8; }
+
+extern "C" wx_status wx_stream_read(const void* src, size_t bytes, double* sink, wx_stream stream) {
+    if (!src || !sink) return wx::fail(WX_ERR_INVALID, "wx_stream_read: null argument");
+    if (bytes % 16 != 0 || (uintptr_t)src % 16 != 0) return wx::fail(WX_ERR_INVALID, "wx_stream_read: buffer and size must be multiples of 16 bytes");
+    WX_STREAM(st, stream);
+    hipLaunchKernelGGL(wx_stream_read_kernel, dim3(256 * 8), dim3(256), 0, st, static_cast<const double2*>(src), bytes / 16, sink);
+    WX_HIP_TRY(hipGetLastError());
+    return WX_OK;
+}
+
 // ---- the nine-stamp timing row of the reference's RHS (rhs/rhs.py:39-41, 68-118) for callers without torch
 struct wx_phase_timer {
     hipEvent_t ev[9];
