@@ -355,7 +355,6 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
     const int lpt = lb + C::lidx(kl, jl, il);    // this thread's node in the LDS image
     const int lptm = mf_idx(kl, jl, il);         // ... and in the image of the matrix-core passes
     MfOps4 mops4{0.0, 0.0, 0.0, 0.0, 0.0};
-    if (MF) mops4 = mf4_load_ops(P.K->D, P.K->cm, P.K->cp, P.K->HF, tid & 63);
     const size_t o = (size_t)el.e * N3 + pt;
 
     // ---- loads.  n = 8: one face point per thread (384 of 512) and the face loads go FIRST: vector-memory results return
@@ -398,6 +397,11 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
         for (int c = 0; c < NC; ++c) WX_FR(fle, f, c, fp) = out[c];
     }
     WX_STAMP(1);
+    // the operator fragments of the matrix-core passes (five doubles per lane, from cache): loaded HERE, behind the face stage -
+    // ten registers fewer across the kernel's register peak (at the top of the kernel the stage-pipeline instantiation spilled
+    // one of them behind a full vector-memory wait, in front of its first loads), their latency under the point stage
+    // (the two high-filter fragments, wanted by the third pass only, follow at the top of the second)
+    if (MF) mops4 = mf4_load_ops(P.K->D, P.K->cm, P.K->cp, nullptr, tid & 63);
 
     // ---- pointwise quantities
     const T rinv = 1.0 / q0;
@@ -436,6 +440,10 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
         const T sgu = sg * ud;
         const T Bd = T(sg * hd2);
         if constexpr (MF) {
+            if (d == 1) {
+                const MfOps4 hf = mf4_load_ops(P.K->D, nullptr, nullptr, P.K->HF, tid & 63);
+                mops4.h0 = hf.h0; mops4.h1 = hf.h1;
+            }
             // matrix-core pass (mf4_dir_pass): each thread stages its own node, the 8 waves contract all lines in place -
             // D | cm | cp with the two common face values as a third k-step -, each thread picks its own node up again:
             // no barrier between a thread's read and its next write
