@@ -218,7 +218,6 @@ __device__ __forceinline__ void euler_jvp_body_mf(const EulerParams<dual>& P) {
         sCm[tid] = P.K->cm[tid];
         sCp[tid] = P.K->cp[tid];
     }
-    const MfOps4 mops = mf4_load_ops(P.K->D, P.K->cm, P.K->cp, P.K->HF, tid & 63);
     const Elem el = COLM ? decode_elem_col(bx, P.count, P.region, H, V, P.md_v, P.md_h, P.md_w) : decode_blk<1, G3>(P, bx, P.count, P.region);
     const bool active = el.valid;
     const int kl = tid / N2, jl = (tid / N) % N, il = tid % N;
@@ -237,6 +236,9 @@ __device__ __forceinline__ void euler_jvp_body_mf(const EulerParams<dual>& P) {
         q[5 * N2] = out[5].re; q[8 * N2] = out[5].im;
         q[6 * N2] = out[6].re; q[7 * N2] = out[6].im;
     }
+
+    // the operator fragments of the matrix-core passes: loaded behind the face stage, the kernel's register peak (euler_rhs_body)
+    const MfOps4 mops = mf4_load_ops(P.K->D, P.K->cm, P.K->cp, P.K->HF, tid & 63);
 
     PointIn<T> S;
     // (column form: a 32-bit offset into the slabs, which are small - one register instead of two beside `o`)
