@@ -728,6 +728,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1 or args.loopback:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")   # a communicator that cannot connect says why on stderr
     if world > 1 or args.loopback:   # (loopback: a one-rank group, so that the exchange self-check below is rehearsed too)
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
