@@ -787,7 +787,22 @@ def main():
                              backend="torch")
 
     ex = None
+    dog = None
     if args.exchange == "rccl" and (world > 1 or args.loopback):
+        # a watchdog over the set-up and the first evaluation of the library's exchange: a rank that never reaches the
+        # collective communicator set-up, or a send without its receive, becomes a message on stderr and exit code 4
+        # instead of a silent timeout
+        import threading
+
+        def hung():
+            sys.stderr.write(f"bench.py rank {rank}: the RCCL exchange (communicator set-up / first grouped ncclSend + ncclRecv) "
+                             "did not finish in 300 s; rerun with --exchange torch\n")
+            sys.stderr.flush()
+            os._exit(4)
+
+        dog = threading.Timer(300.0, hung)
+        dog.daemon = True
+        dog.start()
         # the library's own exchange (wx_comm_*, wx_exchange_*).  Its first run on several GPUs is the driver's: if the
         # communicator or the buffers cannot be set up on some rank, every rank falls back to all_to_all_single and the
         # line says so, instead of the whole scaling run being lost
@@ -815,22 +830,10 @@ def main():
     if getattr(ex, "_native", None) is not None and dist.is_initialized():
         # self-check before anything is timed: the same state through the library's exchange and through
         # all_to_all_single must give the same R bit for bit on every rank (the second path is the one the gloo tests pin
-        # against the reference's halos); a watchdog turns a communication hang into a message instead of a silent timeout
-        import threading
-
-        def hung():
-            sys.stderr.write(f"bench.py rank {rank}: the first evaluation through the RCCL exchange did not finish in 240 s "
-                             "(grouped ncclSend / ncclRecv between the ranks); rerun with --exchange torch\n")
-            sys.stderr.flush()
-            os._exit(4)
-
-        dog = threading.Timer(240.0, hung)
-        dog.daemon = True
-        dog.start()
+        # against the reference's halos)
         probe = torch.stack([qs[t] for t in mine]) if mine else qs
         got = rhs(probe)
         torch.cuda.synchronize()
-        dog.cancel()
         rhs_t = RhsEuler3D(plans, torch_exchange(), overlap=not args.no_overlap)
         want = rhs_t(probe)
         torch.cuda.synchronize()
@@ -842,6 +845,8 @@ def main():
             exchange_report["fell_back_from"] = "rccl behind the C ABI"
             rhs, ex = rhs_t, rhs_t.ex
         del got, want, probe
+    if dog is not None:
+        dog.cancel()
 
     # live timing of the dominant kernel: HIP events on the launch stream around every K2 launch
     ev = []
