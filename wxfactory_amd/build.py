@@ -41,6 +41,7 @@ def build(force: bool = False, verbose: bool = False, defines=(), out: str = LIB
         obj = os.path.join(LIBDIR, tag + "_" + src.replace(".hip", ".o"))
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
         cmd += ["-D" + d for d in defines]
+        cmd += os.environ.get("WX_HIPCC_EXTRA", "").split()   # development: extra compiler flags for an experiment variant
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))
