@@ -56,19 +56,19 @@ template <typename T>
 struct SwParams {
     int H, nelem, has_topo;
     unsigned md_h, md_w;   // floor(2^32 / d) + 1 for d = H, H - 2, or 0 (sw_fast_div)
-    T* itf;  // [elem][4 faces W,E,S,N][3 vars][N]
-    const T *halo_s, *halo_n, *halo_w, *halo_e;
-    T *send_s, *send_n, *send_w, *send_e;
+    tp<T, T> itf;  // [elem][4 faces W,E,S,N][3 vars][N]
+    tp<T, const T> halo_s, halo_n, halo_w, halo_e;
+    tp<T, T> send_s, send_n, send_w, send_e;
     // slot 1 of the stage pipeline (wx_sw_plan_reserve; null until then)
-    T* itf2;
-    const T *halo2_s, *halo2_n, *halo2_w, *halo2_e;
-    T *send2_s, *send2_n, *send2_w, *send2_e;
-    const double *sg, *h11, *h12, *h21, *h22;
-    const double *c101, *c102, *c111, *c112, *c201, *c202, *c212, *c222;
-    const double *sgi, *sgj, *h11i, *h21i, *h12j, *h22j;
-    const double *hsurf, *dz1, *dz2, *hsi, *hsj;
-    const double *bsn, *bwe;
-    const SwConsts* K;
+    tp<T, T> itf2;
+    tp<T, const T> halo2_s, halo2_n, halo2_w, halo2_e;
+    tp<T, T> send2_s, send2_n, send2_w, send2_e;
+    gp<const double> sg, h11, h12, h21, h22;
+    gp<const double> c101, c102, c111, c112, c201, c202, c212, c222;
+    gp<const double> sgi, sgj, h11i, h21i, h12j, h22j;
+    gp<const double> hsurf, dz1, dz2, hsi, hsj;
+    gp<const double> bsn, bwe;
+    gp<const SwConsts> K;
 };
 
 struct Elem2 {
@@ -114,9 +114,9 @@ __device__ __forceinline__ Elem2 decode_elem2(int slot, int count, int region, i
 // the interface buffer and the edge buffers of one slot
 template <typename T>
 struct SwSlot {
-    T* itf;
-    const T *halo_s, *halo_n, *halo_w, *halo_e;
-    T *send_s, *send_n, *send_w, *send_e;
+    tp<T, T> itf;
+    tp<T, const T> halo_s, halo_n, halo_w, halo_e;
+    tp<T, T> send_s, send_n, send_w, send_e;
 };
 template <typename T>
 __device__ __forceinline__ SwSlot<T> sw_slot(const SwParams<T>& P, int slot) {
@@ -144,7 +144,7 @@ __device__ __forceinline__ void sw_extrap_faces(const SwParams<T>& P, T (*fld)[C
         const int d = f >> 1, plus = f & 1;
         const int base = d == 0 ? C::lidx(k, 0) : C::lidx(0, k);
         const int stride = d == 0 ? 1 : C::NP;
-        const double* w = plus ? P.K->ep : P.K->em;
+        gp<const double> w = plus ? P.K->ep : P.K->em;
         T s[3] = {T(0.0), T(0.0), T(0.0)};
 #pragma unroll
         for (int m = 0; m < N; ++m) {
@@ -152,7 +152,7 @@ __device__ __forceinline__ void sw_extrap_faces(const SwParams<T>& P, T (*fld)[C
 #pragma unroll
             for (int v = 0; v < 3; ++v) s[v] += wm * fld[v][le * C::LE + base + m * stride];
         }
-        T* dst = S.itf + ((size_t)el.e * 4 + f) * 3 * N + k;
+        tp<T, T> dst = S.itf + ((size_t)el.e * 4 + f) * 3 * N + k;
 #pragma unroll
         for (int v = 0; v < 3; ++v) dst[v * N] = s[v];
 
@@ -167,7 +167,7 @@ __device__ __forceinline__ void sw_extrap_faces(const SwParams<T>& P, T (*fld)[C
             along = el.ei;
             X = P.bsn[el.ei * N + k];
         }
-        T* sendp = edge == E_S ? S.send_s : (edge == E_N ? S.send_n : (edge == E_W ? S.send_w : S.send_e));
+        tp<T, T> sendp = edge == E_S ? S.send_s : (edge == E_N ? S.send_n : (edge == E_W ? S.send_w : S.send_e));
         if (edge >= 0 && sendp != nullptr) {
             rotate_contra<T>(P.K->rot[edge], X, s[1], s[2]);
             int pos = along * N + k;
@@ -245,20 +245,29 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
         __syncthreads();
     }
 
-    // ---- face stage: AUSM common flux of the 4 faces (rhs_sw.py:157-207)
-    for (int fi = tid; fi < EPB * 4 * N; fi += BS) {
+    // ---- face stage: AUSM common flux of the 4 faces (rhs_sw.py:157-207), as a load part and a flux part: when one pass of the
+    // workgroup covers every face point (n >= 3) the point loads are issued between the two, so that they are in flight
+    // under the face arithmetic instead of after it (vector-memory results return in issue order: the faces come first)
+    struct FaceInSw {
+        T qo[3], qn[3];
+        double sg, hdd, hod;
+        int le, f, k, d, plus;
+        bool valid;
+    };
+    auto face_load = [&](int fi, FaceInSw& in) {
+        in.valid = false;
         const int le = fi / (4 * N);
         const int r = fi % (4 * N);
         const int f = r / N, k = r % N;
         const Elem2 el = decode_elem2(bx * EPB + le, D.count, D.region, H, P.md_h, P.md_w);
-        if (!el.valid) continue;
+        if (!el.valid) return;
         const int d = f >> 1, plus = f & 1;
-        const T* own = S.itf + ((size_t)el.e * 4 + f) * 3 * N + k;
-        const T* nbr;
+        tp<T, const T> own = S.itf + ((size_t)el.e * 4 + f) * 3 * N + k;
+        tp<T, const T> nbr;
         size_t nstride = N;
         long nelem_nbr = -1;   // DIRECT: the neighbour element inside the tile (-1: the face lies on the tile edge)
         size_t o_own, o_nbr;  // slots in the halo-padded interface arrays (own side, neighbour side)
-        const double *sgp, *hddp, *hodp, *hsp;
+        gp<const double> sgp, hddp, hodp, hsp;
         if (d == 0) {
             const int ne = el.ei + (plus ? 1 : -1);
             if (ne >= 0 && ne < H) { nbr = S.itf + ((size_t)(el.e + (plus ? 1 : -1)) * 4 + (f ^ 1)) * 3 * N + k; nelem_nbr = el.e + (plus ? 1 : -1); }
@@ -279,8 +288,8 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
         if constexpr (DIRECT) {
             const int base = d == 0 ? C::lidx(k, 0) : C::lidx(0, k);
             const int stride = d == 0 ? 1 : C::NP;
-            const double* wo = plus ? P.K->ep : P.K->em;   // the own face ...
-            const double* wn = plus ? P.K->em : P.K->ep;   // ... is the neighbour's opposite one
+            gp<const double> wo = plus ? P.K->ep : P.K->em;   // the own face ...
+            gp<const double> wn = plus ? P.K->em : P.K->ep;   // ... is the neighbour's opposite one
 #pragma unroll
             for (int v = 0; v < 3; ++v) { qo[v] = T(0.0); qn[v] = T(0.0); }
 #pragma unroll
@@ -316,7 +325,18 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
             qo[0] = qo[0] - hsp[o_own];
             qn[0] = qn[0] - hsp[o_nbr];
         }
-        const double sg = sgp[o_own], hdd = hddp[o_own], hod = hodp[o_own];
+        in.sg = sgp[o_own]; in.hdd = hddp[o_own]; in.hod = hodp[o_own];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) { in.qo[v] = qo[v]; in.qn[v] = qn[v]; }
+        in.le = le; in.f = f; in.k = k; in.d = d; in.plus = plus;
+        in.valid = true;
+    };
+    auto face_flux = [&](const FaceInSw& in) {
+        if (!in.valid) return;
+        const int le = in.le, f = in.f, k = in.k, d = in.d, plus = in.plus;
+        const double sg = in.sg, hdd = in.hdd, hod = in.hod;
+        const T qo[3] = {in.qo[0], in.qo[1], in.qo[2]};
+        const T qn[3] = {in.qn[0], in.qn[1], in.qn[2]};
         T qL[3], qR[3];
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
@@ -343,6 +363,18 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
         out[2] += w_sel(d == 0, po, pn);
 #pragma unroll
         for (int v = 0; v < 3; ++v) fr[le][f][v][k] = out[v];
+        };
+    constexpr bool ONE_PASS = EPB * 4 * N <= BS && !DIRECT;
+    FaceInSw fin;
+    fin.valid = false;
+    if constexpr (ONE_PASS) {
+        if (tid < EPB * 4 * N) face_load(tid, fin);
+    } else {
+        for (int fi = tid; fi < EPB * 4 * N; fi += BS) {
+            FaceInSw in;
+            face_load(fi, in);
+            face_flux(in);
+        }
     }
 
     // ---- point stage
@@ -357,22 +389,23 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
 
     T q0 = T(1.0), q1 = T(0.0), q2 = T(0.0);
     double sg = 1.0, h11 = 0, h12 = 0, h21 = 0, h22 = 0;
-    if (active) {
+    double c101 = 0, c102 = 0, c111 = 0, c112 = 0, c201 = 0, c202 = 0, c212 = 0, c222 = 0, dz1 = 0.0, dz2 = 0.0;
+    if (active) {   // every load of the point stage, issued together
         if constexpr (DIRECT) { q0 = dq0; q1 = dq1; q2 = dq2; }
         else { q0 = D.q[o]; q1 = D.q[fs + o]; q2 = D.q[2 * fs + o]; }
         sg = P.sg[o];
         h11 = P.h11[o]; h12 = P.h12[o]; h21 = P.h21[o]; h22 = P.h22[o];
+        c101 = P.c101[o]; c102 = P.c102[o]; c111 = P.c111[o]; c112 = P.c112[o];
+        c201 = P.c201[o]; c202 = P.c202[o]; c212 = P.c212[o]; c222 = P.c222[o];
+        if (P.has_topo) { dz1 = P.dz1[o]; dz2 = P.dz2[o]; }
     }
+    if constexpr (ONE_PASS) face_flux(fin);   // the face values were issued first and are here first; the point loads fly on
     const T u1 = q1 / q0, u2 = q2 / q0;
     const T hsq = q0 * q0;
     T forc1 = T(0.0), forc2 = T(0.0);
     if (active) {
-        double dz1 = 0.0, dz2 = 0.0;
-        if (P.has_topo) { dz1 = P.dz1[o]; dz2 = P.dz2[o]; }
-        forc1 = 2.0 * (P.c101[o] * q1 + P.c102[o] * q2) + P.c111[o] * q1 * u1 + 2.0 * P.c112[o] * q1 * u2 +
-                kGravity * q0 * (h11 * dz1 + h12 * dz2);
-        forc2 = 2.0 * (P.c201[o] * q1 + P.c202[o] * q2) + 2.0 * P.c212[o] * q1 * u2 + P.c222[o] * q2 * u2 +
-                kGravity * q0 * (h21 * dz1 + h22 * dz2);
+        forc1 = 2.0 * (c101 * q1 + c102 * q2) + c111 * q1 * u1 + 2.0 * c112 * q1 * u2 + kGravity * q0 * (h11 * dz1 + h12 * dz2);
+        forc2 = 2.0 * (c201 * q1 + c202 * q2) + 2.0 * c212 * q1 * u2 + c222 * q2 * u2 + kGravity * q0 * (h21 * dz1 + h22 * dz2);
     }
     T acc0 = T(0.0), acc1 = T(0.0), acc2 = T(0.0);
 #pragma unroll

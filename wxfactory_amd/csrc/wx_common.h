@@ -1,5 +1,6 @@
 // Host-side helpers of libwxhip.so: status/error plumbing shared by every entry point.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -49,5 +50,49 @@ struct StreamDeviceGuard {
 #define WX_STREAM(st, stream)                             \
     hipStream_t st = static_cast<hipStream_t>(stream);    \
     ::wx::StreamDeviceGuard st##_device_guard(st)
+
+// Pointers to device buffers inside parameter blocks.  A pointer that a kernel LOADS from memory (the parameter table of a
+// batched launch) has no known address space, and the compiler addresses through it with FLAT instructions - which count
+// against the LDS counter as well as the vector-memory one, so that every wait for an LDS read also waits for the global
+// loads in flight.  (A by-value kernel argument is known to be global; the cast-and-back and __builtin_assume idioms do not
+// survive to code generation with this compiler; typing the members themselves with the address space breaks every host
+// assignment, because host functions are checked in the device pass too.)  gp<X> is a pointer for the host - same size,
+// same layout, implicit conversions - and on the device every access through it is made in the global address space.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define WX_GLOBAL __attribute__((address_space(1)))
+#else
+#define WX_GLOBAL
+#endif
+template <typename X>
+struct gp {
+    X* p;
+    gp() = default;
+    __host__ __device__ gp(X* q) : p(q) {}
+    __host__ __device__ gp(decltype(nullptr)) : p(nullptr) {}
+    template <typename Y, typename = typename std::enable_if<std::is_convertible<Y*, X*>::value && !std::is_same<Y, X>::value>::type>
+    __host__ __device__ gp(gp<Y> o) : p(o.p) {}
+    __host__ operator X*() const { return p; }   // (host only: device code that would fall back to a generic pointer does not compile)
+    __host__ __device__ X* raw() const { return p; }
+    __host__ __device__ explicit operator bool() const { return p != nullptr; }
+    __host__ __device__ bool operator==(decltype(nullptr)) const { return p == nullptr; }
+    __host__ __device__ bool operator!=(decltype(nullptr)) const { return p != nullptr; }
+    __host__ __device__ gp operator+(long long o) const { return gp(p + o); }
+    __host__ __device__ gp operator+(unsigned long long o) const { return gp(p + o); }
+    __host__ __device__ gp operator+(long o) const { return gp(p + o); }
+    __host__ __device__ gp operator+(unsigned long o) const { return gp(p + o); }
+    __host__ __device__ gp operator+(int o) const { return gp(p + o); }
+    __host__ __device__ gp operator+(unsigned o) const { return gp(p + o); }
+    __host__ __device__ long long operator-(gp o) const { return p - o.p; }
+    __host__ __device__ X WX_GLOBAL* g() const { return (X WX_GLOBAL*)p; }
+    template <typename I>
+    __host__ __device__ X WX_GLOBAL& operator[](I i) const { return g()[i]; }
+    __host__ __device__ X WX_GLOBAL& operator*() const { return *g(); }
+    __host__ __device__ X WX_GLOBAL* operator->() const { return g(); }
+};
+// ... of the state's value type T: global for float64; complex / dual values are class types, which C++ cannot copy out of
+// a qualified address space without per-member loads - those keep plain (generic) pointers, their metric loads are global
+template <typename T, typename X>
+using tp = typename std::conditional<std::is_same<T, double>::value, gp<X>, X*>::type;
+static_assert(sizeof(gp<const double>) == sizeof(const double*), "a gp is a pointer");
 
 }  // namespace wx

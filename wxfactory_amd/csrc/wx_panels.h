@@ -72,8 +72,8 @@ inline int tile_owner(int t, int world, int ntiles) {
 }
 
 // Rotation of the horizontal contravariant pair into the neighbour panel's basis, c = 2X/(1+X^2)
-template <typename T>
-__device__ __forceinline__ void rotate_contra(const double* m, double X, T& a1, T& a2) {
+template <typename T, typename Ptr>
+__device__ __forceinline__ void rotate_contra(Ptr m, double X, T& a1, T& a2) {
     const double c = 2.0 * X / (1.0 + X * X);
     const T b1 = m[0] * a1 + m[1] * a2 + c * (m[2] * a1 + m[3] * a2);
     const T b2 = m[4] * a1 + m[5] * a2 + c * (m[6] * a1 + m[7] * a2);
