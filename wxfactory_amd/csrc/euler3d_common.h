@@ -25,10 +25,13 @@ constexpr bool kNoVertFaces = WX_K2_DIAG == 5;
 
 // the streamed-once static fields go through non-temporal loads
 __device__ __forceinline__ double ldm(const double* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ double ldm(gp<const double> p) { return __builtin_nontemporal_load(p.g()); }
 // ... unless they are REUSED: the column slabs of a column-invariant metric are read by all n levels of an element (the
 // same CU) and by the V elements of the column (the same XCD): cached loads
 template <bool CACHED>
 __device__ __forceinline__ double ldm_if(const double* p) { return CACHED ? *p : __builtin_nontemporal_load(p); }
+template <bool CACHED>
+__device__ __forceinline__ double ldm_if(gp<const double> p) { return CACHED ? *p : __builtin_nontemporal_load(p.g()); }
 template <int N>
 struct Cfg {
     static constexpr int N2 = N * N;
@@ -58,7 +61,10 @@ struct EulerConsts {
     int flip[4];
 };
 
-template <typename T>
+// G: the pointers carry the global address space in device code (wx_common.h: gp) - the batched float64 kernels, whose
+// parameter block is loaded from a device table; every other kernel (by-value arguments, known to be global) and the host
+// use G = false: plain pointers, the same layout
+template <typename T, bool G = false>
 struct EulerParams {
     int H, V, nelem, count, region;
     int advection_only, has_damp;
@@ -66,38 +72,43 @@ struct EulerParams {
     unsigned md_v, md_h, md_w, md_ring;   // floor(2^32 / d) + 1 for d = V, H, H - 2, H^2 - (H-2)^2, or 0: the decodes' fast_div
     int axpy;              // 1: out = ca*y + cb*q + cc*R(q) + cd*z (RK stage / FD Jacobian operator), 0: out = R(q)
     double ca, cb, cc, cd;
-    const T* y;            // nullable (then ca is ignored)
-    const T* z;            // nullable (then cd is ignored)
+    pp<T, const T, G> y;      // nullable (then ca is ignored)
+    pp<T, const T, G> z;      // nullable (then cd is ignored)
     // stage pipeline: when itf_out != null the kernel also extrapolates ITS OUTPUT (the next stage's state)
     // to the element faces (phase 1-2 of the NEXT evaluation) into itf_out / nsend_*: no separate K1 pass
-    T* itf_out;
-    T *nsend_s, *nsend_n, *nsend_w, *nsend_e;
+    pp<T, T, G> itf_out;
+    pp<T, T, G> nsend_s, nsend_n, nsend_w, nsend_e;
     int efilter;           // stage pipeline only: apply the exponential filter to the stage's output before storing it
     int* nan_flag;         // ... and raise this device flag when the stored values hold a NaN (nullable)
     // JVP mode (T = dual only): the state is formed on load as (q_re, jvp_eps * q_tan) from two REAL arrays
     // and only jvp_scale * tangent(R) is stored, as a real array - no complex temporaries in HBM
     int jvp;
-    const double *q_re, *q_tan;
-    double* out_tan;
+    pp<T, const double, G> q_re, q_tan;
+    pp<T, double, G> out_tan;
     double jvp_eps, jvp_scale;
     // prepared JVP (wx_euler3d_jvp_prepare): the face VALUES of the linearisation state stay in fv (real,
     // [elem][6][5][n^2]) and in the value halos hv_* for a whole Krylov solve; per product only the face TANGENTS are
     // extrapolated (ft, real, same layout; tangent edge messages through send_* / halo_* as REAL arrays)
     int split;   // 0: off; 1: the JVP kernel reads (fv, ft), written by euler_tan_extrap_kernel (split = 2 there: unused flag)
-    double* ft;
-    const double* fv;
-    const double *hv_s, *hv_n, *hv_w, *hv_e;
-    const T* q;
-    T* rhs;
-    T* itf;  // [elem][6 faces][NQ vars][N2]
-    const T *halo_s, *halo_n, *halo_w, *halo_e;
-    T *send_s, *send_n, *send_w, *send_e;
-    const double *sg, *h, *chr, *idz;
-    const double *sgi, *sgj, *sgk, *hi, *hj, *hk;
-    const double *dcoef, *duref, *bsn, *bwe;
-    const EulerConsts* K;  // device memory
+    pp<T, double, G> ft;
+    pp<T, const double, G> fv;
+    pp<T, const double, G> hv_s, hv_n, hv_w, hv_e;
+    pp<T, const T, G> q;
+    pp<T, T, G> rhs;
+    pp<T, T, G> itf;  // [elem][6 faces][NQ vars][N2]
+    pp<T, const T, G> halo_s, halo_n, halo_w, halo_e;
+    pp<T, T, G> send_s, send_n, send_w, send_e;
+    // (the float64 kernels see every buffer through global-address-space pointers - wx_common.h: gp -; the complex and dual
+    // instantiations keep plain pointers throughout: their code, and with it the last bit of the Jacobian-vector products that
+    // the reference's KIOPS statistics are matched on, stays what it was)
+    pp<T, const double, G> sg, h, chr, idz;
+    pp<T, const double, G> sgi, sgj, sgk, hi, hj, hk;
+    pp<T, const double, G> dcoef, duref, bsn, bwe;
+    pp<T, const EulerConsts, G> K;  // device memory
     unsigned long long* stamps;  // WX_K2_DIAG == 1 only, else null
 };
+
+static_assert(sizeof(EulerParams<double, true>) == sizeof(EulerParams<double, false>), "one layout, two views");
 
 struct Elem {
     int ek, ej, ei, e;
@@ -172,8 +183,8 @@ __device__ __forceinline__ Elem decode_elem_grid(int region, int H) {
 
 // the element of slot `slot` of this launch (general form of the plan).  G3: the kernel is a single-tile one launched on
 // the region's grid (a compile-time property: the prologue stays straight-line and the kernel arguments load in one batch)
-template <int EPB, bool G3, typename T>
-__device__ __forceinline__ Elem decode_blk(const EulerParams<T>& P, int slot, int count, int region) {
+template <int EPB, bool G3, typename T, bool G>
+__device__ __forceinline__ Elem decode_blk(const EulerParams<T, G>& P, int slot, int count, int region) {
     if constexpr (EPB == 1 && G3) return decode_elem_grid(region, P.H);
     else return decode_elem(slot, count, region, P.H, P.V, P.md_h, P.md_w, P.md_ring);
 }
@@ -223,62 +234,56 @@ __device__ __forceinline__ Elem decode_elem_col(int slot, int count, int region,
 // one L2; the launch has a multiple of eight workgroups, the surplus finds no element)
 __device__ __forceinline__ int xcd_slab_block(int b, int nblocks8) { return (b & 7) * nblocks8 + (b >> 3); }
 
-template <typename T>
-__device__ __forceinline__ T load_q(const EulerParams<T>& P, size_t i) {
-    return P.q[i];
-}
-// float64 plans: the state may be a shifted one, q + eps * v formed on load (finite-difference Jacobian
-// products: no pass that materialises Q + eps v)
-template <>
-__device__ __forceinline__ double load_q<double>(const EulerParams<double>& P, size_t i) {
-    if (P.q_tan != nullptr) return P.q[i] + P.jvp_eps * P.q_tan[i];  // (same expression as load_state<double>)
-    return P.q[i];
-}
-template <>
-__device__ __forceinline__ dual load_q<dual>(const EulerParams<dual>& P, size_t i) {
-    if (P.jvp) return dual(P.q_re[i], P.jvp_eps * P.q_tan[i]);
-    return P.q[i];
+// float64 plans: the state may be a shifted one, q + eps * v formed on load (finite-difference Jacobian products: no pass
+// that materialises Q + eps v); dual plans in JVP mode form (q, eps v) from two real arrays
+template <typename T, bool G>
+__device__ __forceinline__ T load_q(const EulerParams<T, G>& P, size_t i) {
+    if constexpr (std::is_same<T, double>::value) {
+        if (P.q_tan != nullptr) return P.q[i] + P.jvp_eps * P.q_tan[i];  // (same expression as load_state)
+        return P.q[i];
+    } else if constexpr (std::is_same<T, dual>::value) {
+        if (P.jvp) return dual(P.q_re[i], P.jvp_eps * P.q_tan[i]);
+        return P.q[i];
+    } else {
+        return P.q[i];
+    }
 }
 // the five prognostic values of one point, the mode decided ONCE (a branch per load costs the extrapolation
 // kernel 12 %: the compiler no longer issues the five loads back to back)
-template <typename T>
-__device__ __forceinline__ void load_state(const EulerParams<T>& P, size_t o, size_t fs, T& a0, T& a1, T& a2, T& a3, T& a4) {
-    a0 = load_q<T>(P, o); a1 = load_q<T>(P, fs + o); a2 = load_q<T>(P, 2 * fs + o);
-    a3 = load_q<T>(P, 3 * fs + o); a4 = load_q<T>(P, 4 * fs + o);
-}
-template <>
-__device__ __forceinline__ void load_state<double>(const EulerParams<double>& P, size_t o, size_t fs, double& a0, double& a1,
-                                                   double& a2, double& a3, double& a4) {
-    const double* q = P.q;
-    a0 = q[o]; a1 = q[fs + o]; a2 = q[2 * fs + o]; a3 = q[3 * fs + o]; a4 = q[4 * fs + o];
-    if (P.q_tan != nullptr) {
-        const double* v = P.q_tan;
-        const double e = P.jvp_eps;
-        a0 += e * v[o]; a1 += e * v[fs + o]; a2 += e * v[2 * fs + o]; a3 += e * v[3 * fs + o]; a4 += e * v[4 * fs + o];
-    }
-}
-template <>
-__device__ __forceinline__ void load_state<dual>(const EulerParams<dual>& P, size_t o, size_t fs, dual& a0, dual& a1, dual& a2,
-                                                 dual& a3, dual& a4) {
-    if (P.jvp) {
-        const double *r = P.q_re, *t = P.q_tan;
-        const double e = P.jvp_eps;
-        a0 = dual(r[o], e * t[o]); a1 = dual(r[fs + o], e * t[fs + o]); a2 = dual(r[2 * fs + o], e * t[2 * fs + o]);
-        a3 = dual(r[3 * fs + o], e * t[3 * fs + o]); a4 = dual(r[4 * fs + o], e * t[4 * fs + o]);
-    } else {
-        const dual* q = P.q;
+template <typename T, bool G>
+__device__ __forceinline__ void load_state(const EulerParams<T, G>& P, size_t o, size_t fs, T& a0, T& a1, T& a2, T& a3, T& a4) {
+    if constexpr (std::is_same<T, double>::value) {
+        const auto q = P.q;
         a0 = q[o]; a1 = q[fs + o]; a2 = q[2 * fs + o]; a3 = q[3 * fs + o]; a4 = q[4 * fs + o];
+        if (P.q_tan != nullptr) {
+            const auto v = P.q_tan;
+            const double e = P.jvp_eps;
+            a0 += e * v[o]; a1 += e * v[fs + o]; a2 += e * v[2 * fs + o]; a3 += e * v[3 * fs + o]; a4 += e * v[4 * fs + o];
+        }
+    } else if constexpr (std::is_same<T, dual>::value) {
+        if (P.jvp) {
+            const auto r = P.q_re, t = P.q_tan;
+            const double e = P.jvp_eps;
+            a0 = dual(r[o], e * t[o]); a1 = dual(r[fs + o], e * t[fs + o]); a2 = dual(r[2 * fs + o], e * t[2 * fs + o]);
+            a3 = dual(r[3 * fs + o], e * t[3 * fs + o]); a4 = dual(r[4 * fs + o], e * t[4 * fs + o]);
+        } else {
+            const dual* q = P.q;
+            a0 = q[o]; a1 = q[fs + o]; a2 = q[2 * fs + o]; a3 = q[3 * fs + o]; a4 = q[4 * fs + o];
+        }
+    } else {
+        a0 = load_q<T>(P, o); a1 = load_q<T>(P, fs + o); a2 = load_q<T>(P, 2 * fs + o);
+        a3 = load_q<T>(P, 3 * fs + o); a4 = load_q<T>(P, 4 * fs + o);
     }
 }
 
-template <typename T>
-__device__ __forceinline__ void store_r(const EulerParams<T>& P, size_t i, T r) {
-    P.rhs[i] = r;
-}
-template <>
-__device__ __forceinline__ void store_r<dual>(const EulerParams<dual>& P, size_t i, dual r) {
-    if (P.jvp) P.out_tan[i] = P.jvp_scale * r.im;
-    else P.rhs[i] = r;
+template <typename T, bool G>
+__device__ __forceinline__ void store_r(const EulerParams<T, G>& P, size_t i, T r) {
+    if constexpr (std::is_same<T, dual>::value) {
+        if (P.jvp) P.out_tan[i] = P.jvp_scale * r.im;
+        else P.rhs[i] = r;
+    } else {
+        P.rhs[i] = r;
+    }
 }
 
 }  // namespace wx

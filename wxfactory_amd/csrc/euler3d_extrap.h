@@ -7,9 +7,10 @@ namespace wx {
 // Phase 1-2 on nodal values already staged in LDS (log rho, rho u1, rho u2, rho w, log rho*theta):
 // one thread per face point extrapolates, exponentiates, writes the interface buffer and, on outward
 // tile-edge faces, the rotated / flipped edge message.  Shared by K1 and by K2's stage-pipeline epilogue.
-template <int N, typename T, bool COLM = false, bool G3 = false>
-__device__ __forceinline__ void extrap_faces(const EulerParams<T>& P, T (*fld)[Cfg<N>::EPB * Cfg<N>::LE], int slot0,
-                                             int count, int region, T* itf_dst, T* ss, T* sn, T* sw, T* se) {
+template <int N, typename T, bool COLM = false, bool G3 = false, bool G>
+__device__ __forceinline__ void extrap_faces(const EulerParams<T, G>& P, T (*fld)[Cfg<N>::EPB * Cfg<N>::LE], int slot0,
+                                             int count, int region, pp<T, T, G> itf_dst, pp<T, T, G> ss, pp<T, T, G> sn, pp<T, T, G> sw,
+                                             pp<T, T, G> se) {
     using C = Cfg<N>;
     constexpr int N2 = C::N2, EPB = C::EPB, BS = C::BS;
     const int tid = threadIdx.x;
@@ -33,7 +34,7 @@ __device__ __forceinline__ void extrap_faces(const EulerParams<T>& P, T (*fld)[C
         if (d == 0) { base = C::lidx(a, b, 0); stride = 1; }           // (kl=a, jl=b, il=m)
         else if (d == 1) { base = C::lidx(a, 0, b); stride = C::NP; }  // (kl=a, jl=m, il=b)
         else { base = C::lidx(0, a, b); stride = N * C::NP; }          // (kl=m, jl=a, il=b)
-        const double* w = plus ? P.K->ep : P.K->em;
+        const auto w = plus ? P.K->ep : P.K->em;
         T s[5];
 #pragma unroll
         for (int v = 0; v < 5; ++v) s[v] = T(0.0);
@@ -45,7 +46,7 @@ __device__ __forceinline__ void extrap_faces(const EulerParams<T>& P, T (*fld)[C
         }
         s[0] = w_exp(s[0]);
         s[4] = w_exp(s[4]);
-        T* dst = itf_dst + ((size_t)el.e * 6 + f) * NQ * N2 + fp;
+        pp<T, T, G> dst = itf_dst + ((size_t)el.e * 6 + f) * NQ * N2 + fp;
 #pragma unroll
         for (int v = 0; v < 5; ++v) dst[v * N2] = s[v];
 
@@ -61,14 +62,14 @@ __device__ __forceinline__ void extrap_faces(const EulerParams<T>& P, T (*fld)[C
             along = el.ei;
             X = P.bsn[el.ei * N + b];
         }
-        T* sendp = edge == E_S ? ss : (edge == E_N ? sn : (edge == E_W ? sw : se));
+        pp<T, T, G> sendp = edge == E_S ? ss : (edge == E_N ? sn : (edge == E_W ? sw : se));
         if (edge >= 0 && sendp != nullptr) {
             rotate_contra<T>(P.K->rot[edge], X, s[1], s[2]);
             int al = along, bb = b;
             if (P.K->flip[edge]) { al = H - 1 - along; bb = N - 1 - b; }
             const size_t eo = ((size_t)el.ek * H + al) * N2 + a * N + bb;
             const size_t vs = (size_t)V * H * N2;
-            T* out = sendp + eo;
+            pp<T, T, G> out = sendp + eo;
 #pragma unroll
             for (int v = 0; v < 5; ++v) out[v * vs] = s[v];
         }
@@ -78,8 +79,8 @@ __device__ __forceinline__ void extrap_faces(const EulerParams<T>& P, T (*fld)[C
 // ------------------------------------------------------------------------------------------------
 // K1: extrapolation to element faces + tile-edge pack
 // ------------------------------------------------------------------------------------------------
-template <int N, typename T, bool G3 = false>
-__device__ __forceinline__ void euler_extrap_body(const EulerParams<T>& P) {
+template <int N, typename T, bool G3 = false, bool G>
+__device__ __forceinline__ void euler_extrap_body(const EulerParams<T, G>& P) {
     using C = Cfg<N>;
     constexpr int N2 = C::N2, N3 = C::N3, EPB = C::EPB;
     __shared__ T fld[5][EPB * C::LE];
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(Cfg<N>::BS, kK1Waves) void euler_tan_extrap_kernel(
         if (le < EPB && el.valid) {
             const size_t o = (size_t)el.e * N3 + pt;
             const int lp = le * C::LE + C::lidx(pt / N2, (pt / N) % N, pt % N);
-            const double *r = P.q_re, *t = P.q_tan;
+            const auto r = P.q_re, t = P.q_tan;
             const double e = P.jvp_eps;
             const double r0 = r[o], r4 = r[4 * fs + o];
             pl[0][lp] = log(r0);
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(Cfg<N>::BS, kK1Waves) void euler_tan_extrap_kernel(
         if (d == 0) { base = C::lidx(a, b, 0); stride = 1; }
         else if (d == 1) { base = C::lidx(a, 0, b); stride = C::NP; }
         else { base = C::lidx(0, a, b); stride = N * C::NP; }
-        const double* w = plus ? P.K->ep : P.K->em;
+        const auto w = plus ? P.K->ep : P.K->em;
         double s[7];
 #pragma unroll
         for (int v = 0; v < 7; ++v) s[v] = 0.0;
@@ -221,13 +222,13 @@ struct EulerBatchDyn {
     int jvp;
 };
 
-template <typename T>
-__device__ __forceinline__ void batch_state(EulerParams<T>& P, const EulerBatchDyn<T>& dyn) {
+template <typename T, bool G>
+__device__ __forceinline__ void batch_state(EulerParams<T, G>& P, const EulerBatchDyn<T>& dyn) {
     const size_t off = (size_t)blockIdx.y * dyn.stride, offr = (size_t)blockIdx.y * dyn.stride_re;
-    P.q = dyn.q ? dyn.q + off : nullptr;
-    P.q_re = dyn.q_re ? dyn.q_re + offr : nullptr;
-    P.q_tan = dyn.q_tan ? dyn.q_tan + offr : nullptr;
-    P.out_tan = dyn.out_tan ? dyn.out_tan + offr : nullptr;
+    P.q = dyn.q ? dyn.q + off : (const T*)nullptr;
+    P.q_re = dyn.q_re ? dyn.q_re + offr : (const double*)nullptr;
+    P.q_tan = dyn.q_tan ? dyn.q_tan + offr : (const double*)nullptr;
+    P.out_tan = dyn.out_tan ? dyn.out_tan + offr : (double*)nullptr;
     P.jvp = dyn.jvp; P.jvp_eps = dyn.eps; P.jvp_scale = dyn.scale;
 }
 
@@ -253,7 +254,8 @@ template <int N, typename T>
 __global__ __launch_bounds__(Cfg<N>::BS, kK1Waves) void euler_extrap_batch_kernel(const EulerParams<T>* table,
                                                                                   const EulerBatchDyn<T> dyn) {
     if constexpr (std::is_same<T, double>::value) {   // (float64: the register copy fits - 66 VGPRs, nothing spills - and is faster)
-        EulerParams<T> P = table[blockIdx.y];
+        // the block comes out of memory: typed so that every access through its pointers is a global one (wx_common.h: gp)
+        EulerParams<T, true> P = *reinterpret_cast<const EulerParams<T, true>*>(table + blockIdx.y);
         batch_state<T>(P, dyn);
         euler_extrap_body<N, T>(P);
     } else {

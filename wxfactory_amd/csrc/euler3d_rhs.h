@@ -78,18 +78,18 @@ struct FaceIn {
 // The loads of one face point of one element: own slot of the interface buffer; the neighbour element's slot,
 // the received halo on a lateral tile edge, or the own state again (mirrored later) at ground / top; the
 // interface metric.  Separate from the arithmetic so that a kernel can issue them early.
-template <int N, typename T, bool COLM = false>
-__device__ __forceinline__ void face_load(const EulerParams<T>& P, const Elem& el, int f, int fp, FaceIn<T>& in) {
+template <int N, typename T, bool COLM = false, bool G>
+__device__ __forceinline__ void face_load(const EulerParams<T, G>& P, const Elem& el, int f, int fp, FaceIn<T>& in) {
     constexpr int N2 = N * N;
     const int H = P.H, V = P.V;
     const int d = f >> 1, plus = f & 1;
     const size_t vsh = (size_t)V * H * N2;  // var stride in a halo edge message
 
-    const T* own = P.itf + ((size_t)el.e * 6 + f) * NQ * N2 + fp;
-    const T* nbr;
+    pp<T, const T, G> own = P.itf + ((size_t)el.e * 6 + f) * NQ * N2 + fp;
+    pp<T, const T, G> nbr;
     size_t nstride = N2;
     bool mirror = false, from_halo = false;
-    const double *sgp, *hp;
+    pp<T, const double, G> sgp, hp;
     size_t hfs;  // field stride of the h_contra_itf array
     if (d == 0) {
         const int ne = el.ei + (plus ? 1 : -1);
@@ -207,8 +207,8 @@ __device__ __forceinline__ void face_flux(const FaceIn<T>& in, int f, bool advec
 }
 
 // One face point of one element, loads + arithmetic.  Shared by the fused RHS kernel and the JVP kernel.
-template <int N, typename T, bool OWN_FORM = false, bool COLM = false>
-__device__ __forceinline__ void face_problem(const EulerParams<T>& P, const Elem& el, int f, int fp, T* out) {
+template <int N, typename T, bool OWN_FORM = false, bool COLM = false, bool G>
+__device__ __forceinline__ void face_problem(const EulerParams<T, G>& P, const Elem& el, int f, int fp, T* out) {
     FaceIn<T> in;
     face_load<N, T, COLM>(P, el, f, fp, in);
     face_flux<T, OWN_FORM>(in, f, P.advection_only, out);
@@ -228,8 +228,8 @@ struct PointIn {
 };
 
 // (om, fsm: offset and field stride of the point in the metric arrays - those of the state, or of the column slabs)
-template <typename T, bool CACHED = false>
-__device__ __forceinline__ void k2_point_loads(const EulerParams<T>& P, bool active, size_t o, size_t fs, PointIn<T>& S,
+template <typename T, bool CACHED = false, bool G>
+__device__ __forceinline__ void k2_point_loads(const EulerParams<T, G>& P, bool active, size_t o, size_t fs, PointIn<T>& S,
                                                size_t om, size_t fsm) {
     S.q0 = T(1.0); S.q1 = T(0.0); S.q2 = T(0.0); S.q3 = T(0.0); S.q4 = T(1.0);
     S.sg = 1.0; S.h00 = S.h01 = S.h02 = S.h11 = S.h12 = S.h22 = 0.0;
@@ -241,25 +241,25 @@ __device__ __forceinline__ void k2_point_loads(const EulerParams<T>& P, bool act
         S.h12 = ldm_if<CACHED>(P.h + 5 * fsm + om); S.h22 = ldm_if<CACHED>(P.h + 8 * fsm + om);
     }
 }
-template <typename T>
-__device__ __forceinline__ void k2_point_loads(const EulerParams<T>& P, bool active, size_t o, size_t fs, PointIn<T>& S) {
+template <typename T, bool G>
+__device__ __forceinline__ void k2_point_loads(const EulerParams<T, G>& P, bool active, size_t o, size_t fs, PointIn<T>& S) {
     k2_point_loads<T, false>(P, active, o, fs, S, o, fs);
 }
 
 // forcing of the three momentum rows, all but the gravity filter (pde_euler_cubesphere.py:12-25, 203-290), from the 27
 // (18 on a non-rotating planet) Christoffel fields, all loads in flight together; gcoef = inv_dzdeta * g
-template <typename T, bool CACHED = false>
-__device__ __forceinline__ void k2_forcing(const EulerParams<T>& P, bool active, size_t o, size_t fs, const PointIn<T>& S, T u1,
+template <typename T, bool CACHED = false, bool WITH_IDZ = true, bool G>
+__device__ __forceinline__ void k2_forcing(const EulerParams<T, G>& P, bool active, size_t o, size_t fs, const PointIn<T>& S, T u1,
                                            T u2, T u3, T p, T& fc0, T& fc1, T& fc2, double& gcoef, size_t om, size_t fsm) {
     double cg[27], idzv = 0.0;
     if (active && P.rot_zero) {   // non-rotating planet: the 9 rotation symbols are identically zero
 #pragma unroll
         for (int i = 0; i < 27; ++i) cg[i] = (i % 9) < 3 ? 0.0 : ldm_if<CACHED>(P.chr + (size_t)i * fsm + om);
-        idzv = ldm_if<CACHED>(P.idz + om);
+        if (WITH_IDZ) idzv = ldm_if<CACHED>(P.idz + om);
     } else if (active) {
 #pragma unroll
         for (int i = 0; i < 27; ++i) cg[i] = ldm_if<CACHED>(P.chr + (size_t)i * fsm + om);
-        idzv = ldm_if<CACHED>(P.idz + om);
+        if (WITH_IDZ) idzv = ldm_if<CACHED>(P.idz + om);
     } else {
 #pragma unroll
         for (int i = 0; i < 27; ++i) cg[i] = 0.0;
@@ -289,14 +289,14 @@ __device__ __forceinline__ void k2_forcing(const EulerParams<T>& P, bool active,
         gcoef = idzv * kGravity;
     }
 }
-template <typename T>
-__device__ __forceinline__ void k2_forcing(const EulerParams<T>& P, bool active, size_t o, size_t fs, const PointIn<T>& S, T u1,
+template <typename T, bool G>
+__device__ __forceinline__ void k2_forcing(const EulerParams<T, G>& P, bool active, size_t o, size_t fs, const PointIn<T>& S, T u1,
                                            T u2, T u3, T p, T& fc0, T& fc1, T& fc2, double& gcoef) {
     k2_forcing<T, false>(P, active, o, fs, S, u1, u2, u3, p, fc0, fc1, fc2, gcoef, o, fs);
 }
 
-template <int N, typename T, bool PIPE, bool COLM = false, bool G3 = false>
-__device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
+template <int N, typename T, bool PIPE, bool COLM = false, bool G3 = false, bool G>
+__device__ __forceinline__ void euler_rhs_body(const EulerParams<T, G>& P) {
     using C = Cfg<N>;
     static_assert(!COLM || std::is_same<T, double>::value, "the column form: float64");
     const int bx = COLM ? xcd_slab_block(blockIdx.x, gridDim.x >> 3) : (int)blockIdx.x;
@@ -417,7 +417,9 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
     // ---- forcing
     T fc0, fc1, fc2;
     double gcoef;
-    k2_forcing<T, COLM>(P, active, o, fs, S, u1, u2, u3, p, fc0, fc1, fc2, gcoef, om, fsm);
+    // (matrix-core path: inv_dzdeta, wanted by the epilogue only, is loaded at the top of the third pass - a value that lives
+    // from the forcing to the epilogue was the one the stage-pipeline instantiation spilled, behind a full vector-memory wait)
+    k2_forcing<T, COLM, !MF>(P, active, o, fs, S, u1, u2, u3, p, fc0, fc1, fc2, gcoef, om, fsm);
     WX_STAMP(2);
 
     // accumulators of sum_d dF^d; the forcing is folded in as sqrtG*f so that the final
@@ -444,6 +446,7 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T>& P) {
                 const MfOps4 hf = mf4_load_ops(P.K->D, nullptr, nullptr, P.K->HF, tid & 63);
                 mops4.h0 = hf.h0; mops4.h1 = hf.h1;
             }
+            if (d == 2 && active) gcoef = ldm_if<COLM>(P.idz + om) * kGravity;
             // matrix-core pass (mf4_dir_pass): each thread stages its own node, the 8 waves contract all lines in place -
             // D | cm | cp with the two common face values as a third k-step -, each thread picks its own node up again:
             // no barrier between a thread's read and its next write
@@ -627,17 +630,18 @@ __global__ __launch_bounds__(Cfg<N>::BS, (k2_waves<N, T>())) void euler_rhs_kern
 template <int N, typename T>
 __global__ __launch_bounds__(Cfg<N>::BS, (k2_waves<N, T>())) void euler_rhs_batch_kernel(const EulerParams<T>* table,
                                                                                          const EulerBatchDyn<T> dyn) {
-    auto patch = [&](EulerParams<T>& P) {
+    auto patch = [&](auto& P) {
         const size_t off = (size_t)blockIdx.y * dyn.stride;
         batch_state<T>(P, dyn);
-        P.rhs = dyn.rhs ? dyn.rhs + off : nullptr;
-        P.y = dyn.y ? dyn.y + off : nullptr;
-        P.z = dyn.z ? dyn.z + off : nullptr;
+        P.rhs = dyn.rhs ? dyn.rhs + off : (T*)nullptr;
+        P.y = dyn.y ? dyn.y + off : (const T*)nullptr;
+        P.z = dyn.z ? dyn.z + off : (const T*)nullptr;
         P.region = dyn.region; P.count = dyn.count;
         P.axpy = dyn.axpy; P.ca = dyn.ca; P.cb = dyn.cb; P.cc = dyn.cc; P.cd = dyn.cd;
     };
     if constexpr (std::is_same<T, double>::value) {   // (float64: the register copy fits and is faster; 16-byte dtypes spilled)
-        EulerParams<T> P = table[blockIdx.y];
+        // the block comes out of memory: typed so that every access through its pointers is a global one (wx_common.h: gp)
+        EulerParams<T, true> P = *reinterpret_cast<const EulerParams<T, true>*>(table + blockIdx.y);
         patch(P);
         euler_rhs_body<N, T, false>(P);
     } else {

@@ -93,6 +93,9 @@ struct gp {
 // a qualified address space without per-member loads - those keep plain (generic) pointers, their metric loads are global
 template <typename T, typename X>
 using tp = typename std::conditional<std::is_same<T, double>::value, gp<X>, X*>::type;
+// ... and switchable per instantiation: G = true for kernels whose parameter block comes out of a device table
+template <typename T, typename X, bool G>
+using pp = typename std::conditional<G && std::is_same<T, double>::value, gp<X>, X*>::type;
 static_assert(sizeof(gp<const double>) == sizeof(const double*), "a gp is a pointer");
 
 }  // namespace wx

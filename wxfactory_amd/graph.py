@@ -34,7 +34,10 @@ class GraphedFunction:
             for _ in range(warmup):  # lazy state (complex twins, batches, exchange buffers) is built here
                 fn(*self.inputs)
             side.synchronize()
-            with torch.cuda.graph(self.graph, stream=side):
+            # thread-local capture mode: with a process group alive, torch's communication watchdog thread polls events
+            # while this thread captures; in the default (global) mode such a call from ANOTHER thread is an error there, and
+            # the watchdog answers an error by aborting the process (seen twice in 12 runs of the GPU suite, round 4)
+            with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
                 self.output = fn(*self.inputs)
         torch.cuda.current_stream().wait_stream(side)
 

@@ -727,7 +727,7 @@ class KiopsWorkspace:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            with torch.cuda.graph(g, stream=side):
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):   # (see graph.py: the watchdog thread)
                 for j in range(j0 + 1, m + 1):
                     build(j)
         torch.cuda.current_stream().wait_stream(side)
