@@ -253,9 +253,9 @@ class RhsShallowWater(PanelRhs):
     overlapped_entry = "wx_sw_rhs_overlapped"
     supports_pipeline = True
     # the direct form (no interface buffer: ring-only pack, then ONE launch; wx_sw_rhs_direct): bit-identical to the two-kernel
-    # form; "auto": taken for float64 tiles of 65 536 points and more, where it is the faster one since its loads are global
-    # ones (S7: 54.4 against 57-60 us per whole-sphere R(Q), profiles/r04_flat_to_global_ab.txt); True / False: forced
-    direct = "auto"
+    # form and, at S7, within the +-3 % the boxes of the pool differ by - ahead on one, behind on the next (alternating rounds,
+    # profiles/r04_flat_to_global_ab.txt) - so the two-kernel form stays the default; True: forced
+    direct = False
 
     def _pipe_state(self, dtype):
         """The stage pipeline's ping-pong state of one dtype: slot in use, the tensor whose faces are prepared, the two
@@ -345,10 +345,7 @@ class RhsShallowWater(PanelRhs):
             self._batches[dt] = SwBatch(plans, ex)
         b = self._batches[dt]
         out = torch.empty_like(q)
-        direct = self.direct
-        if direct == "auto":
-            direct = dt == torch.float64 and self.panel_shape[1] ** 2 * self.panel_shape[3] >= 65536
-        if direct:
+        if self.direct:
             b.extrap_pack_ring(q)
             self._phases(ex, lambda region: b.rhs_direct(q, out, region, y, coef))
             return out
