@@ -683,8 +683,8 @@ def decomposition(world, H, tiles_per_side=0, whole_panels=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)    # >= 50 calls ...
+    ap.add_argument("--warmup", type=int, default=10)   # ... after >= 5 warm-ups
     ap.add_argument("--n", type=int, default=8, help="num_solpts (p = n-1)")
     ap.add_argument("--H", type=int, default=60, help="elements per panel side")
     ap.add_argument("--V", type=int, default=8, help="vertical elements")
