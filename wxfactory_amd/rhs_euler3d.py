@@ -438,6 +438,12 @@ class RhsEuler3D(PanelRhs):
             return self._run_batched(qs, ys, zs, coef)
         return super()._run(qs, ys, coef, dtype, zs)
 
+    # tiles of this many points and more take the PREPARED per-tile Jacobian-vector product in a Krylov solve even where an
+    # evaluation would share launches: face values cached once per solve, tangent-only extrapolation, the matrix-core JVP
+    # kernel - against the batched unprepared product 0.382 / 0.374 ms at 0.46 M points per tile (equal), 0.591 / 0.628 at
+    # 0.82 M, 1.25 / 1.36 at 1.8 M, 2.46 / 2.77 at 3.7 M (tools: a V = 1, 2 sweep of the E7 tile, round 4)
+    jvp_prepare_min_points = 600_000
+
     def _small_tiles(self) -> bool:
         return (self.batched and len(self.panels) > 1 and self.panel_shape is not None and not self.timed
                 and math.prod(self.panel_shape) // 5 <= self.batch_max_points)
@@ -632,7 +638,8 @@ class RhsEuler3D(PanelRhs):
         dev = torch.device(self.device) if self.device is not None else Q.device
         can = 1   # a rank that owns no tile goes along with the others
         if self.panels:
-            can = int(not self._small_tiles() and Q.device.type == dev.type and Q.dtype == torch.float64 and Q.is_contiguous())
+            big = math.prod(self.panel_shape) // 5 >= self.jvp_prepare_min_points if self.panel_shape is not None else False
+            can = int((big or not self._small_tiles()) and Q.device.type == dev.type and Q.dtype == torch.float64 and Q.is_contiguous())
         if self.world > 1:   # one decision for all ranks: the value exchange below is collective
             import torch.distributed as dist
 
