@@ -630,7 +630,8 @@ wx_status wx_kiops_finish(double* V, size_t ldv, int j, size_t n, int p, int iop
                           double* hcol, double* workspace, wx_stream stream);
 /* The same Krylov vector for LONG vectors (the E7 sphere: 442 M doubles), in three streaming stages whose reductions the
  * caller completes in between - over ranks (all-reduce: BASELINE config 5 runs KIOPS on 6 GPUs) and with the p replicated
- * augmented components - 11 vector sweeps per Krylov vector instead of 14 and a tall-skinny gemv:
+ * augmented components - 11 vector sweeps per Krylov vector instead of 14 and a tall-skinny gemv (9 with the lazy
+ * normalisation of the *_scaled forms below):
  *   wx_kiops_long_a  V[j][:n] = aw + uflip @ V[j-1][n:];  V[j][n:] = V[j-1][n+1:], 0;
  *                    dots[r - ilow] = <V[r][:n], V[j][:n]>,  ilow = max(0, j - iop) <= r < j      (dots: device, iop doubles)
  *   wx_kiops_long_b  V[j][:] -= sum_r h[r - ilow] V[r][:]  (h: device, the completed products);  *nrm2 = |V[j][:n]|^2
@@ -642,6 +643,17 @@ wx_status wx_kiops_long_a(double* V, size_t ldv, int j, size_t n, int p, int iop
 wx_status wx_kiops_long_b(double* V, size_t ldv, int j, size_t n, int p, int iop, const double* h, double* nrm2,
                           double* workspace, wx_stream stream);
 wx_status wx_kiops_long_c(double* V, size_t ldv, int j, size_t n, int p, const double* nrm2, double* hcol, wx_stream stream);
+/* The same three stages with LAZY normalisation: the n-long part of a basis row is never rewritten for its norm - row r stays
+ * unscaled, scales[r] = 1 / |V[r]| (device, one double per row; the caller sets scales[0] = 1 for the normalised start row) is
+ * applied wherever the row is used, and `aw` is A applied to the UNSCALED row j-1.  The p augmented components are kept
+ * scaled.  9 vector sweeps per Krylov vector instead of 11.  A linear combination of rows must carry the scales:
+ * sum_r c[r] scales[r] V[r][:n]. */
+wx_status wx_kiops_long_a_scaled(double* V, size_t ldv, int j, size_t n, int p, int iop, const double* aw, const double* uflip,
+                                 double* dots, double* workspace, const double* scales, wx_stream stream);
+wx_status wx_kiops_long_b_scaled(double* V, size_t ldv, int j, size_t n, int p, int iop, const double* h, double* nrm2,
+                                 double* workspace, const double* scales, wx_stream stream);
+wx_status wx_kiops_long_c_lazy(double* V, size_t ldv, int j, size_t n, int p, const double* nrm2, double* hcol, double* scales,
+                               wx_stream stream);
 wx_status wx_multi_dot2(const double* V, size_t ldv, int m, const double* a, const double* b, size_t n, double* out,
                         double* workspace, wx_stream stream);
 wx_status wx_pair_update(double* a, double* b, const double* V, size_t ldv, int m, const double* ha, const double* hb,

@@ -473,7 +473,7 @@ def test_stiffness_resilient_epi(built_lib, order):
 
 @pytest.mark.parametrize("p,taus", [(1, [1.0]), (3, [0.4, 1.0])])
 def test_kiops_long_vector_build(built_lib, p, taus, monkeypatch):
-    """Vectors too long for the one-workgroup finish take the three streaming stages (wx_kiops_long_a/b/c): same
+    """Vectors too long for the one-workgroup finish take the three streaming stages (wx_kiops_long_a/b_scaled + _c_lazy): same
     phi-vectors and the same adaptive decisions as the array-expression recurrence they replace (WXHIP_KIOPS_LONG=0),
     and the exact result for a diagonal operator."""
     from wxfactory_amd import solvers
@@ -497,6 +497,13 @@ def test_kiops_long_vector_build(built_lib, p, taus, monkeypatch):
     monkeypatch.delenv("WXHIP_KIOPS_LONG")
     w_split, st_split = kiops(taus, A, u, _force_split=True, **args)
     assert st_split[:4] == st_long[:4] and float((w_split - w_long).abs().max()) <= 1e-12 * scale
+    # the stages above carry the rows' norms as scale factors (lazy normalisation, 9 sweeps per vector); with every row
+    # rewritten for its norm (wx_kiops_long_c, 11 sweeps): the same decisions, the same vectors to rounding
+    monkeypatch.setenv("WXHIP_KIOPS_LAZY", "0")
+    w_eager, st_eager = kiops(taus, A, u, **args)
+    monkeypatch.delenv("WXHIP_KIOPS_LAZY")
+    assert st_eager[:4] == st_long[:4] and st_eager[5] == st_long[5], (st_eager, st_long)
+    assert float((w_eager - w_long).abs().max()) <= 1e-12 * scale
     # exact: w(tau) = sum_k tau^k phi_k(tau lam) u_k
     import math
 

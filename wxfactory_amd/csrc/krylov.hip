@@ -269,9 +269,13 @@ __global__ __launch_bounds__(kFinishThreads) void kiops_finish_c(double* __restr
 // for the array-expression form; deterministic two-stage reductions (multi_dot_finish_kernel sums the partials).
 constexpr int kLongBlocks = 2048;
 
+// scales (nullable): lazy normalisation - row r of the basis holds its n-long part UNSCALED, scales[r] = 1 / |V[r]| is
+// applied where the row is used (its augmented components ARE kept scaled: p values); aw is then A applied to the unscaled
+// row j-1.  One multiply per use instead of a read-modify-write sweep per Krylov vector (kiops_long_c).
 __global__ __launch_bounds__(kFinishThreads) void kiops_long_a(double* __restrict__ V, size_t ldv, int j, size_t n, int p,
                                                                int iop, const double* __restrict__ aw,
-                                                               const double* __restrict__ uflip, double* __restrict__ part) {
+                                                               const double* __restrict__ uflip, double* __restrict__ part,
+                                                               const double* __restrict__ scales) {
     __shared__ double red[4];
     __shared__ double aug[kFinishMaxP];
     double* vj = V + (size_t)j * ldv;
@@ -279,38 +283,59 @@ __global__ __launch_bounds__(kFinishThreads) void kiops_long_a(double* __restric
     if (threadIdx.x < p) aug[threadIdx.x] = vp[n + threadIdx.x];
     __syncthreads();
     const int ilow = j - iop > 0 ? j - iop : 0, nr = j - ilow;
+    const double sa = scales ? scales[j - 1] : 1.0;
     double acc[kFinishMaxIop] = {0.0, 0.0, 0.0, 0.0};
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        double w = aw[i];
+        double w = scales ? sa * aw[i] : aw[i];
         for (int k = 0; k < p; ++k) w += uflip[i * p + k] * aug[k];
         vj[i] = w;
         for (int r = 0; r < nr; ++r) acc[r] += V[(size_t)(ilow + r) * ldv + i] * w;
     }
     if (blockIdx.x == 0 && (int)threadIdx.x < p) vj[n + threadIdx.x] = (int)threadIdx.x + 1 < p ? aug[threadIdx.x + 1] : 0.0;
     for (int r = 0; r < kFinishMaxIop; ++r) {
-        const double t = wg_sum256(r < nr ? acc[r] : 0.0, red);
+        double t = wg_sum256(r < nr ? acc[r] : 0.0, red);
+        if (scales && r < nr) t *= scales[ilow + r];
         if (threadIdx.x == 0) part[(size_t)blockIdx.x * kFinishMaxIop + r] = t;
     }
 }
 
 __global__ __launch_bounds__(kFinishThreads) void kiops_long_b(double* __restrict__ V, size_t ldv, int j, size_t n, int p,
-                                                               int iop, const double* __restrict__ h, double* __restrict__ part) {
+                                                               int iop, const double* __restrict__ h, double* __restrict__ part,
+                                                               const double* __restrict__ scales) {
     __shared__ double red[4];
     double* vj = V + (size_t)j * ldv;
     const int ilow = j - iop > 0 ? j - iop : 0, nr = j - ilow;
-    double c[kFinishMaxIop] = {0.0, 0.0, 0.0, 0.0};
-    for (int r = 0; r < nr; ++r) c[r] = h[r];
+    double c[kFinishMaxIop] = {0.0, 0.0, 0.0, 0.0}, cs[kFinishMaxIop] = {0.0, 0.0, 0.0, 0.0};
+    for (int r = 0; r < nr; ++r) {
+        c[r] = h[r];
+        cs[r] = scales ? h[r] * scales[ilow + r] : h[r];   // on the n-long (unscaled) part of row r
+    }
     const size_t len = n + (size_t)p, stride = (size_t)gridDim.x * blockDim.x;
     double nn = 0.0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) {
         double w = vj[i];
-        for (int r = 0; r < nr; ++r) w -= c[r] * V[(size_t)(ilow + r) * ldv + i];
+        if (i < n) {
+            for (int r = 0; r < nr; ++r) w -= cs[r] * V[(size_t)(ilow + r) * ldv + i];
+        } else {
+            for (int r = 0; r < nr; ++r) w -= c[r] * V[(size_t)(ilow + r) * ldv + i];
+        }
         vj[i] = w;
         if (i < n) nn += w * w;
     }
     const double t = wg_sum256(nn, red);
     if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// lazy normalisation: the augmented components of row j scaled, hcol[j] = |V[j]|, scales[j] = 1 / |V[j]|; the n-long part stays
+__global__ void kiops_long_c_lazy(double* __restrict__ V, size_t ldv, int j, size_t n, int p, const double* __restrict__ nrm2,
+                                  double* __restrict__ hcol, double* __restrict__ scales) {
+    const double nrm = sqrt(*nrm2);
+    if ((int)threadIdx.x < p) V[(size_t)j * ldv + n + threadIdx.x] /= nrm;
+    if (threadIdx.x == 0) {
+        hcol[j] = nrm;
+        scales[j] = 1.0 / nrm;
+    }
 }
 
 __global__ __launch_bounds__(kFinishThreads) void kiops_long_c(double* __restrict__ V, size_t ldv, int j, size_t len,
@@ -564,11 +589,16 @@ static wx_status kiops_long_check(const void* V, int j, int p, int iop, size_t l
 
 wx_status wx_kiops_long_a(double* V, size_t ldv, int j, size_t n, int p, int iop, const double* aw, const double* uflip,
                           double* dots, double* workspace, wx_stream stream) {
+    return wx_kiops_long_a_scaled(V, ldv, j, n, p, iop, aw, uflip, dots, workspace, nullptr, stream);
+}
+
+wx_status wx_kiops_long_a_scaled(double* V, size_t ldv, int j, size_t n, int p, int iop, const double* aw, const double* uflip,
+                                 double* dots, double* workspace, const double* scales, wx_stream stream) {
     wx_status s = kiops_long_check(V, j, p, iop, ldv, n, "wx_kiops_long_a");
     if (s != WX_OK) return s;
     if (!aw || !uflip || !dots || !workspace) return fail(WX_ERR_INVALID, "wx_kiops_long_a: null argument");
     WX_STREAM(st, stream);
-    hipLaunchKernelGGL(kiops_long_a, dim3(kLongBlocks), dim3(kFinishThreads), 0, st, V, ldv, j, n, p, iop, aw, uflip, workspace);
+    hipLaunchKernelGGL(kiops_long_a, dim3(kLongBlocks), dim3(kFinishThreads), 0, st, V, ldv, j, n, p, iop, aw, uflip, workspace, scales);
     const int nr = j - (j - iop > 0 ? j - iop : 0);
     hipLaunchKernelGGL(multi_dot_finish_kernel, dim3(nr), dim3(64), 0, st, workspace, kLongBlocks, kFinishMaxIop, dots);
     WX_HIP_TRY(hipGetLastError());
@@ -577,11 +607,16 @@ wx_status wx_kiops_long_a(double* V, size_t ldv, int j, size_t n, int p, int iop
 
 wx_status wx_kiops_long_b(double* V, size_t ldv, int j, size_t n, int p, int iop, const double* h, double* nrm2,
                           double* workspace, wx_stream stream) {
+    return wx_kiops_long_b_scaled(V, ldv, j, n, p, iop, h, nrm2, workspace, nullptr, stream);
+}
+
+wx_status wx_kiops_long_b_scaled(double* V, size_t ldv, int j, size_t n, int p, int iop, const double* h, double* nrm2,
+                                 double* workspace, const double* scales, wx_stream stream) {
     wx_status s = kiops_long_check(V, j, p, iop, ldv, n, "wx_kiops_long_b");
     if (s != WX_OK) return s;
     if (!h || !nrm2 || !workspace) return fail(WX_ERR_INVALID, "wx_kiops_long_b: null argument");
     WX_STREAM(st, stream);
-    hipLaunchKernelGGL(kiops_long_b, dim3(kLongBlocks), dim3(kFinishThreads), 0, st, V, ldv, j, n, p, iop, h, workspace);
+    hipLaunchKernelGGL(kiops_long_b, dim3(kLongBlocks), dim3(kFinishThreads), 0, st, V, ldv, j, n, p, iop, h, workspace, scales);
     hipLaunchKernelGGL(multi_dot_finish_kernel, dim3(1), dim3(64), 0, st, workspace, kLongBlocks, 1, nrm2);
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
@@ -591,6 +626,16 @@ wx_status wx_kiops_long_c(double* V, size_t ldv, int j, size_t n, int p, const d
     if (!V || !nrm2 || !hcol || j < 1 || p < 1 || ldv < n + (size_t)p) return fail(WX_ERR_INVALID, "wx_kiops_long_c: bad argument");
     WX_STREAM(st, stream);
     hipLaunchKernelGGL(kiops_long_c, dim3(kLongBlocks), dim3(kFinishThreads), 0, st, V, ldv, j, n + (size_t)p, nrm2, hcol);
+    WX_HIP_TRY(hipGetLastError());
+    return WX_OK;
+}
+
+wx_status wx_kiops_long_c_lazy(double* V, size_t ldv, int j, size_t n, int p, const double* nrm2, double* hcol, double* scales,
+                               wx_stream stream) {
+    if (!V || !nrm2 || !hcol || !scales || j < 1 || p < 1 || p > kFinishMaxP || ldv < n + (size_t)p)
+        return fail(WX_ERR_INVALID, "wx_kiops_long_c_lazy: bad argument");
+    WX_STREAM(st, stream);
+    hipLaunchKernelGGL(kiops_long_c_lazy, dim3(1), dim3(64), 0, st, V, ldv, j, n, p, nrm2, hcol, scales);
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
 }

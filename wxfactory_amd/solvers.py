@@ -688,6 +688,7 @@ class KiopsWorkspace:
             self.basis = _Basis(self.Vd)
             self.Ht = torch.empty((mmax + 1, mmax + 1), dtype=dtype, device=dev)  # Ht[c, r] = H[r, c], written entries only
             self.nrm2 = torch.empty(1, dtype=dtype, device=dev)
+            self.scales = torch.ones(mmax + 1, dtype=dtype, device=dev)   # lazy normalisation of the long-vector build: 1 / |V[r]|
             self.u_flip_t = torch.empty((n, p), dtype=dtype, device=dev)
             self.shift = torch.diag(torch.ones(p - 1, dtype=dtype, device=dev), 1)
             self.finish_work = None
@@ -802,6 +803,10 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
     # long vectors: three streaming kernels per Krylov vector; their reductions are completed here in between (all-reduce
     # over the ranks, the replicated augmented components)
     long_build = (basis.gpu and not fused_finish and p <= 16 and iop <= 4 and os.environ.get("WXHIP_KIOPS_LONG", "1") != "0")
+    # ... with LAZY normalisation: a basis row's n-long part is never rewritten for its norm (wx_kiops_long_*_scaled): the
+    # scale 1 / |V[r]| sits in ws.scales and is applied where the row is used - 9 sweeps per Krylov vector instead of 11
+    lazy = long_build and os.environ.get("WXHIP_KIOPS_LAZY", "1") != "0"
+    row_scale = [1.0] * (mmax + 2)   # the host's copy of the scales (from the norms it reads with the Hessenberg columns)
 
     def products(lo: int, hi: int, j: int, out: torch.Tensor):
         """out[k - lo] = <V[k], V[j]> over the n + p components, lo <= k < hi"""
@@ -837,6 +842,9 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
             Vd[0, n:] = torch.as_tensor(va0, dtype=dtype, device=dev)
             beta = math.sqrt(float(global_dotprod(Vd[0, :n], Vd[0, :n], group)) + float(va0 @ va0))
             Vd[0] /= beta
+            if lazy:
+                ws.scales[0] = 1.0
+                row_scale[0] = 1.0
         j0 = j
 
         def build(j):
@@ -856,17 +864,22 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
                     aw = aw.contiguous()
                 ilow = max(0, j - iop)
                 hcol = Ht[j - 1]
-                basis.check(lib.wx_kiops_long_a(Vd.data_ptr(), Vd.stride(0), j, n, p, iop, aw.data_ptr(), u_flip_t.data_ptr(),
-                                                ws.dots.data_ptr(), ws.finish_work.data_ptr(), st), "wx_kiops_long_a")
+                sc = ws.scales.data_ptr() if lazy else None
+                basis.check(lib.wx_kiops_long_a_scaled(Vd.data_ptr(), Vd.stride(0), j, n, p, iop, aw.data_ptr(), u_flip_t.data_ptr(),
+                                                       ws.dots.data_ptr(), ws.finish_work.data_ptr(), sc, st), "wx_kiops_long_a")
                 t = ws.dots[: j - ilow]
                 if split:
                     t = _allreduce(t, group)
                 torch.addmv(t, Vd[ilow:j, n:], Vd[j, n:], out=hcol[ilow:j])   # + the augmented components, once
-                basis.check(lib.wx_kiops_long_b(Vd.data_ptr(), Vd.stride(0), j, n, p, iop, hcol[ilow:j].data_ptr(),
-                                                nrm2.data_ptr(), ws.finish_work.data_ptr(), st), "wx_kiops_long_b")
+                basis.check(lib.wx_kiops_long_b_scaled(Vd.data_ptr(), Vd.stride(0), j, n, p, iop, hcol[ilow:j].data_ptr(),
+                                                       nrm2.data_ptr(), ws.finish_work.data_ptr(), sc, st), "wx_kiops_long_b")
                 if split:
                     _allreduce(nrm2, group)
                 nrm2.add_(torch.dot(Vd[j, n:], Vd[j, n:]))
+                if lazy:
+                    basis.check(lib.wx_kiops_long_c_lazy(Vd.data_ptr(), Vd.stride(0), j, n, p, nrm2.data_ptr(), hcol.data_ptr(),
+                                                         ws.scales.data_ptr(), st), "wx_kiops_long_c_lazy")
+                    return
                 basis.check(lib.wx_kiops_long_c(Vd.data_ptr(), Vd.stride(0), j, n, p, nrm2.data_ptr(), hcol.data_ptr(), st),
                             "wx_kiops_long_c")
                 return
@@ -893,6 +906,7 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
                     j = c + 1
                     break
                 H[c + 1, c] = Hh[c - j0, c + 1]
+                row_scale[c + 1] = 1.0 / float(Hh[c - j0, c + 1])
                 krystep += 1
         H[0, j] = 1.0
         nrm = H[j, j - 1]
@@ -926,9 +940,9 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
                 w[l + blown] = w[l]
                 for k in range(blown):
                     F2 = _expm(sgn * (tau_out[l + k] - tau_now) * H[:j, :j])
-                    w[l + k] = _combine_rows(basis, Vd, j, n, beta * F2[:j, 0])
+                    w[l + k] = _combine_rows(basis, Vd, j, n, beta * F2[:j, 0] * (np.asarray(row_scale[:j]) if lazy else 1.0))
                 l += blown
-            w[l] = _combine_rows(basis, Vd, j, n, beta * F[:j, 0])
+            w[l] = _combine_rows(basis, Vd, j, n, beta * F[:j, 0] * (np.asarray(row_scale[:j]) if lazy else 1.0))
             tau_now += tau
             j = 0
             conv += err
