@@ -248,12 +248,13 @@ def test_generic_dual_jvp_kernel_in_a_subprocess():
 
 @pytest.mark.parametrize("m,n", [(1, 1000), (7, 4097), (8, 65536), (21, 100003)])
 def test_krylov_vector_kernels(built_lib, m, n):
-    """wx_multi_dot / wx_multi_axpy (the Gram-Schmidt sweeps of fgmres) against torch, on a padded basis."""
+    """wx_multi_dot / wx_multi_axpy (the Gram-Schmidt sweeps of fgmres) against torch, on a dense basis and on a padded one
+    (a view with a longer row stride - what solvers._basis_rows hands out for long vectors): the same bits."""
     from wxfactory_amd.solvers import _Basis
 
     gen = torch.Generator(device=DEV).manual_seed(m * 1000 + n)
     Vfull = torch.randn((m + 2, n + 5), generator=gen, device=DEV, dtype=torch.float64)
-    V = Vfull[:, :n]  # row stride n + 5: not contiguous -> torch path
+    V = Vfull[:, :n]  # row stride n + 5: the kernels take it as ldv
     Vc = V.contiguous()
     w = torch.randn(n, generator=gen, device=DEV, dtype=torch.float64)
     basis = _Basis(Vc)
@@ -267,7 +268,13 @@ def test_krylov_vector_kernels(built_lib, m, n):
     assert out is w2
     ref2 = w - h @ Vc[1:1 + m]
     assert torch.allclose(w2, ref2, rtol=1e-12, atol=1e-12 * float(ref2.abs().max()))
-    assert not _Basis(V).gpu
+    padded = _Basis(V)
+    assert padded.gpu and not V.is_contiguous()
+    assert torch.equal(padded.dots(1, 1 + m, w), h)
+    w3 = w.clone()
+    padded.subtract(w3, 1, 1 + m, h)
+    assert torch.equal(w3, w2)
+    assert not _Basis(Vfull.t()[:n]).gpu   # rows that are not contiguous: the torch expressions
 
 
 @pytest.mark.parametrize("m,n", [(0, 513), (1, 1000), (5, 4097), (16, 65536), (17, 30011), (35, 100003)])

@@ -44,13 +44,24 @@ def global_inf_norm(a: torch.Tensor, group=None) -> torch.Tensor:
     return m[0]
 
 
+def _basis_rows(rows: int, length: int, dtype, dev) -> torch.Tensor:
+    """An uninitialised (rows, length) Krylov basis whose LONG rows start on 256-byte boundaries (a view of a padded
+    allocation; every kernel takes the row stride).  The augmented vectors have n + p components, usually an odd number:
+    every other row then sat 8 bytes off its cache lines and the streaming kernels of the long-vector build lost up to a
+    fifth of their rate (wx_kiops_long_b on the whole E7 sphere 3.18 -> 2.69 ms, profiles/r04_kiops_row_alignment.txt)."""
+    # (up to KiopsWorkspace.max_fused_len the short-vector kernels keep their dense rows)
+    ld = length if length <= KiopsWorkspace.max_fused_len else -(-length // 32) * 32
+    return torch.empty((rows, ld), dtype=dtype, device=dev)[:, :length]
+
+
 class _Basis:
     """Gram-Schmidt passes over the rows of a basis matrix V (m, n) against a vector w: on the GPU the two
     single-pass kernels of csrc/krylov.hip (no temporaries of Krylov-vector size), elsewhere torch expressions."""
 
     def __init__(self, V: torch.Tensor):
         self.V = V
-        self.gpu = V.is_cuda and V.dtype == torch.float64 and V.is_contiguous()
+        # (rows contiguous; the row stride may be padded - every kernel takes it as ldv)
+        self.gpu = V.is_cuda and V.dtype == torch.float64 and V.dim() == 2 and V.stride(1) == 1
         if self.gpu:
             from . import _lib
 
@@ -257,7 +268,7 @@ def fgmres(A: Callable, b: torch.Tensor, x0: Optional[torch.Tensor] = None, tol:
     norm_r = float(global_norm(r, group))
     residuals = [(norm_r / norm_b, time() - t0, 0.0)]
     niter = 0
-    V = torch.empty((restart + 1, n), dtype=b.dtype, device=b.device)
+    V = _basis_rows(restart + 1, n, b.dtype, b.device)
     Z = torch.empty((restart, n), dtype=b.dtype, device=b.device) if preconditioner is not None else V  # Z[j] = V[j]
     basis = _Basis(V)
     for _outer in range(maxiter):
@@ -352,7 +363,7 @@ def _fgmres_low_sync(A, b, x0, tol, restart, maxiter, preconditioner, verbose, g
     norm_r = float(global_norm(r, group))
     residuals = [(norm_r / norm_b, time() - t0, 0.0)]
     niter = 0
-    V = torch.empty((restart + 2, n), dtype=b.dtype, device=b.device)
+    V = _basis_rows(restart + 2, n, b.dtype, b.device)
     Z = torch.empty((restart + 1, n), dtype=b.dtype, device=b.device) if preconditioner is not None else None
     basis = _Basis(V)
     scaled = getattr(A, "scaled", None)
@@ -684,7 +695,8 @@ class KiopsWorkspace:
         key = (n, p, mmax, str(dev), dtype)
         if key != self.key:
             self.key = key
-            self.Vd = torch.empty((mmax + 1, n + p), dtype=dtype, device=dev)  # (every row is written before it is read)
+            # (every row is written before it is read)
+            self.Vd = _basis_rows(mmax + 1, n + p, dtype, dev)
             self.basis = _Basis(self.Vd)
             self.Ht = torch.empty((mmax + 1, mmax + 1), dtype=dtype, device=dev)  # Ht[c, r] = H[r, c], written entries only
             self.nrm2 = torch.empty(1, dtype=dtype, device=dev)
@@ -1031,7 +1043,7 @@ def pmex(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, delta: float 
         split = True   # (tests: the several-rank code paths - reductions completed after an all-reduce - on one rank)
     mmax = _affordable_mmax(n, p, mmax, mmin, dev, dtype, group, "pmex")
     m = max(mmin, min(m_init, mmax))
-    Vd = torch.empty((mmax + 1, n + p), dtype=dtype, device=dev)   # (every row is written before it is read)
+    Vd = _basis_rows(mmax + 1, n + p, dtype, dev)   # (every row is written before it is read)
     basis = _Basis(Vd)
     H = np.zeros((mmax + 1, mmax + 1))
     proj = _GaussSeidelProjector(mmax)
