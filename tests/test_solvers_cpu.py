@@ -461,3 +461,26 @@ def test_low_sync_gram_schmidt_breakdown_is_resolved(seed):
     V[j - 2] = torch.from_numpy(Qm[:, : j - 2] @ rng.standard_normal(j - 2) + 1e-7 * Qm[:, j - 2])
     gs = S._LowSyncGramSchmidt(S._Basis(V.clone()), 8)
     assert abs(gs.step(j) - 1e-7) < 1e-12
+
+
+@pytest.mark.parametrize("solver", ["kiops", "pmex"])
+def test_padded_basis_rows_change_nothing(solver, monkeypatch):
+    """Long Krylov bases are handed out with their rows on 256-byte boundaries (solvers._basis_rows: a view of a padded
+    allocation, the row stride is not the row length).  With the threshold lowered so that this small problem counts as long:
+    the same phi-vectors and statistics, bit for bit, as on dense rows."""
+    from wxfactory_amd import solvers
+
+    rows = solvers._basis_rows(5, 300_001, torch.float64, "cpu")
+    assert rows.shape == (5, 300_001) and rows.stride() == (300_032, 1) and not rows.is_contiguous()
+    assert all(rows[r].data_ptr() % 256 == rows[0].data_ptr() % 256 for r in range(5))
+    dense = solvers._basis_rows(5, 1000, torch.float64, "cpu")
+    assert dense.is_contiguous()
+
+    A, u = _problem(p=1)
+    fn = getattr(solvers, solver)
+    args = dict(tol=1e-10, m_init=8, mmin=8, mmax=48)
+    w0, st0 = fn([0.4, 1.0], lambda v: torch.from_numpy(A) @ v, torch.from_numpy(u), **args)
+    monkeypatch.setattr(solvers.KiopsWorkspace, "max_fused_len", 16)   # (n + p = 61 is "long" now: rows of 64)
+    assert not solvers._basis_rows(3, A.shape[0] + 1, torch.float64, "cpu").is_contiguous()
+    w1, st1 = fn([0.4, 1.0], lambda v: torch.from_numpy(A) @ v, torch.from_numpy(u), **args)
+    assert torch.equal(w0, w1) and tuple(st0) == tuple(st1)
