@@ -773,10 +773,14 @@ wx_status wx_euler3d_batch_create(wx_euler3d_batch** out, wx_euler3d_plan* const
     b->n = plans[0]->n; b->H = plans[0]->H; b->V = plans[0]->V; b->count = count; b->nelem = (int)plans[0]->nelem;
     b->dtype = plans[0]->dtype;
     wx_status s = WX_ERR_INVALID;
-    switch (b->dtype) {
-        case WX_F64: s = batch_upload<double>(b, plans, send, halo); break;
-        case WX_C128: s = batch_upload<cplx>(b, plans, send, halo); break;
-        case WX_DUAL128: s = batch_upload<dual>(b, plans, send, halo); break;
+    try {   // (the host copy of the table is a std::vector: no exception crosses the C boundary)
+        switch (b->dtype) {
+            case WX_F64: s = batch_upload<double>(b, plans, send, halo); break;
+            case WX_C128: s = batch_upload<cplx>(b, plans, send, halo); break;
+            case WX_DUAL128: s = batch_upload<dual>(b, plans, send, halo); break;
+        }
+    } catch (...) {
+        s = fail(WX_ERR_NOMEM, "wx_euler3d_batch_create: out of host memory");
     }
     if (s != WX_OK) {
         if (b->table) (void)hipFree(b->table);

@@ -186,7 +186,12 @@ wx_status wx_exchange_create(wx_exchange** out, wx_comm* comm, int rank, int wor
     if (!ex) return fail(WX_ERR_NOMEM, "out of host memory");
     ex->comm = comm; ex->rank = rank; ex->world = world; ex->k = tiles_per_side; ex->ec = edge_doubles;
     ex->loopback = loopback != 0;
-    wx_status st = build_layout(ex);
+    wx_status st;
+    try {   // (the layout lives in standard containers: no exception crosses the C boundary)
+        st = build_layout(ex);
+    } catch (...) {
+        st = fail(WX_ERR_NOMEM, "wx_exchange_create: out of host memory");
+    }
     if (st != WX_OK) { delete ex; return st; }
     *out = ex;
     return WX_OK;

@@ -175,7 +175,8 @@ extern "C" {
 wx_status wx_expfilter_create(wx_expfilter** out, int n, const double* filter) {
     if (!out || !filter) return fail(WX_ERR_INVALID, "wx_expfilter_create: null argument");
     if (n < 2 || n > 8) return fail(WX_ERR_UNSUPPORTED, "num_solpts %d not in 2..8", n);
-    wx_expfilter* h = new wx_expfilter{n, nullptr};
+    wx_expfilter* h = new (std::nothrow) wx_expfilter{n, nullptr};
+    if (!h) return fail(WX_ERR_NOMEM, "wx_expfilter_create: out of host memory");
     hipError_t e = hipMalloc((void**)&h->filter, sizeof(double) * n * n);
     if (e == hipSuccess) e = hipMemcpy(h->filter, filter, sizeof(double) * n * n, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
