@@ -321,6 +321,14 @@ wx_status wx_euler3d_jvp_tangent_extrap_pack(wx_euler3d_plan* pl, const double* 
 wx_status wx_euler3d_jvp_prepared(wx_euler3d_plan* pl, const double* q, const double* v, double eps,
                                   const void* const halo_val[4], const void* const halo_tan[4], double* out, double scale,
                                   wx_region region, wx_stream stream);
+/* ... with the store  out = *z_scale * (scale * Im R) + *z_coef * z  (z_scale null: 1; z null: the plain product).  The two
+ * coefficients are read from DEVICE memory by the kernel.  KIOPS (solvers/kiops.py:170-176: V[j] = A V[j-1] + u a) forms the
+ * n-long part of its next Krylov vector here, in the product's own store, instead of in a sweep of its own
+ * (wx_kiops_long_a_formed then only takes the products). */
+wx_status wx_euler3d_jvp_prepared_axpy(wx_euler3d_plan* pl, const double* q, const double* v, double eps,
+                                       const void* const halo_val[4], const void* const halo_tan[4], double* out, double scale,
+                                       const double* z, const double* z_scale, const double* z_coef, wx_region region,
+                                       wx_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Shallow water on a cubed-sphere tile.
@@ -650,6 +658,10 @@ wx_status wx_kiops_long_c(double* V, size_t ldv, int j, size_t n, int p, const d
  * sum_r c[r] scales[r] V[r][:n]. */
 wx_status wx_kiops_long_a_scaled(double* V, size_t ldv, int j, size_t n, int p, int iop, const double* aw, const double* uflip,
                                  double* dots, double* workspace, const double* scales, wx_stream stream);
+/* ... when V[j][:n] = scales[j-1] * aw + uflip @ V[j-1][n:] has been formed already (by the matvec's own store,
+ * wx_euler3d_jvp_prepared_axpy): the augmented components and the products only - 3 sweeps instead of 5 at iop = 2 */
+wx_status wx_kiops_long_a_formed(double* V, size_t ldv, int j, size_t n, int p, int iop, double* dots, double* workspace,
+                                 const double* scales, wx_stream stream);
 wx_status wx_kiops_long_b_scaled(double* V, size_t ldv, int j, size_t n, int p, int iop, const double* h, double* nrm2,
                                  double* workspace, const double* scales, wx_stream stream);
 wx_status wx_kiops_long_c_lazy(double* V, size_t ldv, int j, size_t n, int p, const double* nrm2, double* hcol, double* scales,

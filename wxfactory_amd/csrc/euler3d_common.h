@@ -105,6 +105,11 @@ struct EulerParams {
     pp<T, const double, G> sgi, sgj, sgk, hi, hj, hk;
     pp<T, const double, G> dcoef, duref, bsn, bwe;
     pp<T, const EulerConsts, G> K;  // device memory
+    // JVP mode, optional (KIOPS: the n-long part of the next Krylov vector formed in the product's epilogue instead of in a sweep
+    // of its own): out_tan = *jzs * (jvp_scale * tangent) + *jza * jz, both coefficients read from DEVICE memory (jzs null: 1)
+    pp<T, const double, G> jz;
+    const double* jzs;
+    const double* jza;
     unsigned long long* stamps;  // WX_K2_DIAG == 1 only, else null
 };
 

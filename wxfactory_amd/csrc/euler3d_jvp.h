@@ -188,11 +188,20 @@ __device__ __forceinline__ void euler_jvp_body(const EulerParams<dual>& P) {
     if (active) {
         const double s = P.advection_only ? 0.0 : -P.jvp_scale / sg;
         accw += gcoef * hf;  // gravity: inv_dzdeta * g * 1/sqrtG * HF_k(sqrtG rho)
-        P.out_tan[o] = s * acc0;
-        P.out_tan[fs + o] = s * acc1;
-        P.out_tan[2 * fs + o] = s * acc2;
-        P.out_tan[3 * fs + o] = s * accw;
-        P.out_tan[4 * fs + o] = s * acc4;
+        if (P.jz != nullptr) {
+            const double sa = P.jzs ? *P.jzs : 1.0, zc = *P.jza;
+            P.out_tan[o] = sa * (s * acc0) + zc * P.jz[o];
+            P.out_tan[fs + o] = sa * (s * acc1) + zc * P.jz[fs + o];
+            P.out_tan[2 * fs + o] = sa * (s * acc2) + zc * P.jz[2 * fs + o];
+            P.out_tan[3 * fs + o] = sa * (s * accw) + zc * P.jz[3 * fs + o];
+            P.out_tan[4 * fs + o] = sa * (s * acc4) + zc * P.jz[4 * fs + o];
+        } else {
+            P.out_tan[o] = s * acc0;
+            P.out_tan[fs + o] = s * acc1;
+            P.out_tan[2 * fs + o] = s * acc2;
+            P.out_tan[3 * fs + o] = s * accw;
+            P.out_tan[4 * fs + o] = s * acc4;
+        }
     }
 }
 
@@ -308,11 +317,20 @@ __device__ __forceinline__ void euler_jvp_body_mf(const EulerParams<dual>& P) {
     if (active) {
         const double sc = P.advection_only ? 0.0 : -P.jvp_scale / sg;
         accw += gcoef * hf;  // gravity: inv_dzdeta * g * 1/sqrtG * HF_k(sqrtG rho)
-        P.out_tan[o] = sc * acc0;
-        P.out_tan[fs + o] = sc * acc1;
-        P.out_tan[2 * fs + o] = sc * acc2;
-        P.out_tan[3 * fs + o] = sc * accw;
-        P.out_tan[4 * fs + o] = sc * acc4;
+        if (P.jz != nullptr) {
+            const double sa = P.jzs ? *P.jzs : 1.0, zc = *P.jza;
+            P.out_tan[o] = sa * (sc * acc0) + zc * P.jz[o];
+            P.out_tan[fs + o] = sa * (sc * acc1) + zc * P.jz[fs + o];
+            P.out_tan[2 * fs + o] = sa * (sc * acc2) + zc * P.jz[2 * fs + o];
+            P.out_tan[3 * fs + o] = sa * (sc * accw) + zc * P.jz[3 * fs + o];
+            P.out_tan[4 * fs + o] = sa * (sc * acc4) + zc * P.jz[4 * fs + o];
+        } else {
+            P.out_tan[o] = sc * acc0;
+            P.out_tan[fs + o] = sc * acc1;
+            P.out_tan[2 * fs + o] = sc * acc2;
+            P.out_tan[3 * fs + o] = sc * accw;
+            P.out_tan[4 * fs + o] = sc * acc4;
+        }
     }
 }
 

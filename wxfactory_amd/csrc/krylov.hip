@@ -287,9 +287,14 @@ __global__ __launch_bounds__(kFinishThreads) void kiops_long_a(double* __restric
     double acc[kFinishMaxIop] = {0.0, 0.0, 0.0, 0.0};
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        double w = scales ? sa * aw[i] : aw[i];
-        for (int k = 0; k < p; ++k) w += uflip[i * p + k] * aug[k];
-        vj[i] = w;
+        double w;
+        if (aw) {   // (null: the n-long part has been formed by the matvec's own store, wx_kiops_long_a_formed)
+            w = scales ? sa * aw[i] : aw[i];
+            for (int k = 0; k < p; ++k) w += uflip[i * p + k] * aug[k];
+            vj[i] = w;
+        } else {
+            w = vj[i];
+        }
         for (int r = 0; r < nr; ++r) acc[r] += V[(size_t)(ilow + r) * ldv + i] * w;
     }
     if (blockIdx.x == 0 && (int)threadIdx.x < p) vj[n + threadIdx.x] = (int)threadIdx.x + 1 < p ? aug[threadIdx.x + 1] : 0.0;
@@ -599,6 +604,20 @@ wx_status wx_kiops_long_a_scaled(double* V, size_t ldv, int j, size_t n, int p, 
     if (!aw || !uflip || !dots || !workspace) return fail(WX_ERR_INVALID, "wx_kiops_long_a: null argument");
     WX_STREAM(st, stream);
     hipLaunchKernelGGL(kiops_long_a, dim3(kLongBlocks), dim3(kFinishThreads), 0, st, V, ldv, j, n, p, iop, aw, uflip, workspace, scales);
+    const int nr = j - (j - iop > 0 ? j - iop : 0);
+    hipLaunchKernelGGL(multi_dot_finish_kernel, dim3(nr), dim3(64), 0, st, workspace, kLongBlocks, kFinishMaxIop, dots);
+    WX_HIP_TRY(hipGetLastError());
+    return WX_OK;
+}
+
+wx_status wx_kiops_long_a_formed(double* V, size_t ldv, int j, size_t n, int p, int iop, double* dots, double* workspace,
+                                 const double* scales, wx_stream stream) {
+    wx_status s = kiops_long_check(V, j, p, iop, ldv, n, "wx_kiops_long_a_formed");
+    if (s != WX_OK) return s;
+    if (!dots || !workspace) return fail(WX_ERR_INVALID, "wx_kiops_long_a_formed: null argument");
+    WX_STREAM(st, stream);
+    hipLaunchKernelGGL(kiops_long_a, dim3(kLongBlocks), dim3(kFinishThreads), 0, st, V, ldv, j, n, p, iop,
+                       static_cast<const double*>(nullptr), static_cast<const double*>(nullptr), workspace, scales);
     const int nr = j - (j - iop > 0 ? j - iop : 0);
     hipLaunchKernelGGL(multi_dot_finish_kernel, dim3(nr), dim3(64), 0, st, workspace, kLongBlocks, kFinishMaxIop, dots);
     WX_HIP_TRY(hipGetLastError());

@@ -307,10 +307,19 @@ class Euler3DPlan:
         check(self.lib.wx_euler3d_jvp_tangent_extrap_pack(self._h, q.data_ptr(), v.data_ptr(), eps, _ptr_array(send_tan), st),
               "wx_euler3d_jvp_tangent_extrap_pack")
 
-    def jvp_prepared(self, q, v, eps: float, halo_val, halo_tan, out, scale: float, region: int = _lib.WX_REGION_ALL):
+    def jvp_prepared(self, q, v, eps: float, halo_val, halo_tan, out, scale: float, region: int = _lib.WX_REGION_ALL,
+                     z=None, z_scale: int = 0, z_coef: int = 0):
+        """z (a real tensor like out; z_scale / z_coef: DEVICE addresses of one double each, z_scale 0 = 1):
+        out = *z_scale * (scale * Im R) + *z_coef * z formed in the product's own store"""
         for t in (q, v, out):
             self._check_real(t)
         st = torch.cuda.current_stream(self.device).cuda_stream
+        if z is not None:
+            self._check_real(z)
+            check(self.lib.wx_euler3d_jvp_prepared_axpy(self._h, q.data_ptr(), v.data_ptr(), eps, _ptr_array(halo_val),
+                                                        _ptr_array(halo_tan), out.data_ptr(), scale, z.data_ptr(),
+                                                        z_scale or None, z_coef, region, st), "wx_euler3d_jvp_prepared_axpy")
+            return
         check(self.lib.wx_euler3d_jvp_prepared(self._h, q.data_ptr(), v.data_ptr(), eps, _ptr_array(halo_val),
                                                _ptr_array(halo_tan), out.data_ptr(), scale, region, st),
               "wx_euler3d_jvp_prepared")
@@ -624,6 +633,10 @@ class RhsEuler3D(PanelRhs):
         build.pmex = build_pmex
         return build
 
+    def jvp_fuses_store(self, Q) -> bool:
+        """True when a product about Q takes the prepared per-tile kernels, whose store can form a x + b z (jvp(out=, z=))."""
+        return bool(self.panels) and self._jvp_is_prepared(Q) and Q.dtype == torch.float64
+
     def _jvp_plans(self):
         if "jvp" not in self._plans:
             self._plans["jvp"] = {p: pl.twin(torch.complex128, dual=True) for p, pl in self.plans.items()}
@@ -673,10 +686,13 @@ class RhsEuler3D(PanelRhs):
             return True
         return lin[0]() is Q and lin[1:] == (Q.data_ptr(), Q._version)
 
-    def jvp(self, Q: torch.Tensor, v: torch.Tensor, eps: float, scale: float) -> torch.Tensor:
+    def jvp(self, Q: torch.Tensor, v: torch.Tensor, eps: float, scale: float, out=None, z=None, z_scale: int = 0,
+            z_coef: int = 0) -> torch.Tensor:
         """scale * Im R(Q + i eps v) for stacked real Q, v -> real tensor shaped like Q.  The dual state is
         formed inside the kernels and only the tangent is stored: the complex-step JVP of
-        solvers/matvec.py:56-61 without a complex array in HBM."""
+        solvers/matvec.py:56-61 without a complex array in HBM.
+        PREPARED products only (the caller checks jvp_fuses_store): `out` = a contiguous tensor of Q's size to write into;
+        `z` (like out) with the device addresses z_scale / z_coef: out = *z_scale * product + *z_coef * z in the same store."""
         np_ = len(self.panels)
         prepared = self._jvp_is_prepared(Q)
         if self.world > 1:
@@ -703,12 +719,16 @@ class RhsEuler3D(PanelRhs):
             vs = v.reshape((np_,) + tuple(self.panel_shape))
         if prepared:
             exv, ext = self._ex_val, self._ex_tan
-            out = torch.empty_like(Qs)
+            out = torch.empty_like(Qs) if out is None else out.reshape(Qs.shape)
+            zs = None if z is None else z.reshape(Qs.shape)
             for i, p in enumerate(self.panels):
                 plans[p].jvp_tangent_pack(Qs[i], vs[i], eps, ext.send_views(p))
             self._exchange_and_launch(ext, lambda i, p, halo, region: plans[p].jvp_prepared(
-                Qs[i], vs[i], eps, exv.halo_views(p) if halo is not None else None, halo, out[i], scale, region))
+                Qs[i], vs[i], eps, exv.halo_views(p) if halo is not None else None, halo, out[i], scale, region,
+                *(() if zs is None else (zs[i], z_scale, z_coef))))
             return out.reshape(Q.shape)
+        if out is not None or z is not None:
+            raise RuntimeError("jvp(out=, z=): only the prepared product stores into a caller's buffer (jvp_fuses_store)")
         ex = self.exchange_for(torch.complex128)
         out = torch.empty_like(Qs)
         if self._small_tiles() and Q.is_contiguous() and v.is_contiguous() and Q.dtype == torch.float64 \

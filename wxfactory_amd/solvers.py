@@ -819,6 +819,8 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
     # scale 1 / |V[r]| sits in ws.scales and is applied where the row is used - 9 sweeps per Krylov vector instead of 11
     lazy = long_build and os.environ.get("WXHIP_KIOPS_LAZY", "1") != "0"
     row_scale = [1.0] * (mmax + 2)   # the host's copy of the scales (from the norms it reads with the Hessenberg columns)
+    store_axpy = (getattr(A, "axpy_into", None)
+                  if long_build and p == 1 and os.environ.get("WXHIP_KIOPS_STORE_AXPY", "1") != "0" else None)
 
     def products(lo: int, hi: int, j: int, out: torch.Tensor):
         """out[k - lo] = <V[k], V[j]> over the n + p components, lo <= k < hi"""
@@ -871,14 +873,23 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
                 return
             if long_build:
                 lib, st = basis.lib, torch.cuda.current_stream(dev).cuda_stream
-                aw = A(Vd[j - 1, :n])
-                if not aw.is_contiguous():
-                    aw = aw.contiguous()
                 ilow = max(0, j - iop)
                 hcol = Ht[j - 1]
                 sc = ws.scales.data_ptr() if lazy else None
-                basis.check(lib.wx_kiops_long_a_scaled(Vd.data_ptr(), Vd.stride(0), j, n, p, iop, aw.data_ptr(), u_flip_t.data_ptr(),
-                                                       ws.dots.data_ptr(), ws.finish_work.data_ptr(), sc, st), "wx_kiops_long_a")
+                # one augmented component, an operator whose product can store a x + b z: the n-long part of row j is formed
+                # by the matvec itself (scale of row j-1 and the augmented component read on the device), one sweep fewer
+                if store_axpy is not None and store_axpy(Vd[j - 1, :n], Vd[j, :n], u_flip_t,
+                                                         ws.scales[j - 1: j].data_ptr() if lazy else 0,
+                                                         Vd[j - 1, n:].data_ptr()):
+                    basis.check(lib.wx_kiops_long_a_formed(Vd.data_ptr(), Vd.stride(0), j, n, p, iop, ws.dots.data_ptr(),
+                                                           ws.finish_work.data_ptr(), sc, st), "wx_kiops_long_a_formed")
+                else:
+                    aw = A(Vd[j - 1, :n])
+                    if not aw.is_contiguous():
+                        aw = aw.contiguous()
+                    basis.check(lib.wx_kiops_long_a_scaled(Vd.data_ptr(), Vd.stride(0), j, n, p, iop, aw.data_ptr(),
+                                                           u_flip_t.data_ptr(), ws.dots.data_ptr(), ws.finish_work.data_ptr(),
+                                                           sc, st), "wx_kiops_long_a")
                 t = ws.dots[: j - ilow]
                 if split:
                     t = _allreduce(t, group)
