@@ -149,6 +149,24 @@ def test_stage_pipeline_and_jvp_over_the_native_exchange(comm):
     torch.cuda.synchronize()
     assert torch.equal(j_plain, j_coll)
     assert piped._ex_tan.backend == "rccl" and piped._ex_tan._native is not None
+    # the store that forms a * (A v) + b * z in the product itself (KIOPS' next Krylov vector), over the INTERIOR / BOUNDARY
+    # launches of the overlapped evaluation: the same bits as from one launch per tile, coefficients read from device memory
+    from wxfactory_amd.matvec import ComplexStepOperator
+
+    coef = torch.tensor([0.75, -1.5], dtype=torch.float64, device=DEV)
+    z = torch.randn(Q.numel(), dtype=torch.float64, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+    outs = []
+    for r_ in (plain, piped):
+        op = ComplexStepOperator(1.0, Q, R, r_)
+        assert r_.jvp_fuses_store(Q)
+        out = torch.full_like(z, float("nan"))
+        assert op.axpy_into(v.flatten().contiguous(), out, z, coef[0:1].data_ptr(), coef[1:2].data_ptr())
+        outs.append(out)
+        r_.jvp_release()
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    want = 0.75 * j_plain - 1.5 * z
+    assert float((outs[0] - want).abs().max()) <= 1e-14 * float(want.abs().max())
 
 
 def test_shallow_water_over_the_native_exchange(comm):
