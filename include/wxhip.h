@@ -325,10 +325,15 @@ wx_status wx_euler3d_jvp_prepared(wx_euler3d_plan* pl, const double* q, const do
  * coefficients are read from DEVICE memory by the kernel.  KIOPS (solvers/kiops.py:170-176: V[j] = A V[j-1] + u a) forms the
  * n-long part of its next Krylov vector here, in the product's own store, instead of in a sweep of its own
  * (wx_kiops_long_a_formed then only takes the products). */
+/* With row0 (row1 nullable) and partials, the launch also leaves the products <row_r, out> of the vector it stored, as one
+ * pair of partial sums per workgroup: partials[2 * w + r], w < wx_euler3d_jvp_workgroups(pl, region) - the iop = 2 products
+ * of KIOPS' incomplete orthogonalisation (solvers/kiops.py:178-186) without a sweep of their own; wx_kiops_long_a_finish
+ * sums the partials of all launches of a product. */
 wx_status wx_euler3d_jvp_prepared_axpy(wx_euler3d_plan* pl, const double* q, const double* v, double eps,
                                        const void* const halo_val[4], const void* const halo_tan[4], double* out, double scale,
-                                       const double* z, const double* z_scale, const double* z_coef, wx_region region,
-                                       wx_stream stream);
+                                       const double* z, const double* z_scale, const double* z_coef, const double* row0,
+                                       const double* row1, double* partials, wx_region region, wx_stream stream);
+size_t wx_euler3d_jvp_workgroups(const wx_euler3d_plan* pl, wx_region region);
 
 /* ------------------------------------------------------------------------------------------
  * Shallow water on a cubed-sphere tile.
@@ -662,6 +667,10 @@ wx_status wx_kiops_long_a_scaled(double* V, size_t ldv, int j, size_t n, int p, 
  * wx_euler3d_jvp_prepared_axpy): the augmented components and the products only - 3 sweeps instead of 5 at iop = 2 */
 wx_status wx_kiops_long_a_formed(double* V, size_t ldv, int j, size_t n, int p, int iop, double* dots, double* workspace,
                                  const double* scales, wx_stream stream);
+/* ... and when the matvec has left the products too (partials: nblocks pairs, wx_euler3d_jvp_prepared_axpy): the augmented
+ * components of row j and dots[r] = scales[ilow + r] * sum_b partials[2 b + r], r < min(iop, j) <= 2 - no sweep at all */
+wx_status wx_kiops_long_a_finish(double* V, size_t ldv, int j, size_t n, int p, int iop, const double* partials, size_t nblocks,
+                                 double* dots, const double* scales, wx_stream stream);
 wx_status wx_kiops_long_b_scaled(double* V, size_t ldv, int j, size_t n, int p, int iop, const double* h, double* nrm2,
                                  double* workspace, const double* scales, wx_stream stream);
 wx_status wx_kiops_long_c_lazy(double* V, size_t ldv, int j, size_t n, int p, const double* nrm2, double* hcol, double* scales,

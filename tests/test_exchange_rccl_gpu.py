@@ -167,6 +167,23 @@ def test_stage_pipeline_and_jvp_over_the_native_exchange(comm):
     assert torch.equal(outs[0], outs[1])
     want = 0.75 * j_plain - 1.5 * z
     assert float((outs[0] - want).abs().max()) <= 1e-14 * float(want.abs().max())
+    # ... and the products of the stored vector with two other vectors, as pairs of partial sums per workgroup
+    rows = [torch.randn(Q.numel(), dtype=torch.float64, device=DEV, generator=torch.Generator(device=DEV).manual_seed(s_))
+            for s_ in (6, 7)]
+    for r_ in (plain, piped):
+        for nrows in (1, 2):
+            op = ComplexStepOperator(1.0, Q, R, r_)
+            out = torch.full_like(z, float("nan"))
+            part, count = op.axpy_into(v.flatten().contiguous(), out, z, coef[0:1].data_ptr(), coef[1:2].data_ptr(), rows[:nrows])
+            torch.cuda.synchronize()
+            assert torch.equal(out, outs[0]) and 0 < 2 * count <= part.numel()
+            got = part[: 2 * count].view(count, 2).sum(dim=0)
+            for k in range(nrows):
+                ref = float(torch.dot(rows[k], out))
+                assert abs(float(got[k]) - ref) <= 1e-12 * float(rows[k].norm() * out.norm()), (nrows, k)
+            if nrows == 1:
+                assert float(got[1]) == 0.0
+            r_.jvp_release()
 
 
 def test_shallow_water_over_the_native_exchange(comm):

@@ -351,8 +351,9 @@ def test_n8_kiops_and_epi2_step(callers8):
 
 def test_n8_kiops_long_build_lets_the_matvec_form_the_vector(callers8, monkeypatch):
     """Long vectors, one augmented component, the prepared matrix-core JVP (what EPI2 + KIOPS runs at E7): the n-long part of
-    the next Krylov vector, A V[j-1] + u a, is formed in the product's own store (wx_euler3d_jvp_prepared_axpy) and the first
-    streaming stage only takes the products (wx_kiops_long_a_formed).  The reference's statistics exactly, its phi-vector to
+    the next Krylov vector, A V[j-1] + u a, is formed in the product's own store (wx_euler3d_jvp_prepared_axpy) together with
+    its products with the two rows it is orthogonalised against (partial sums per workgroup, wx_kiops_long_a_finish) - or,
+    WXHIP_KIOPS_STORE_DOTS=0, the first streaming stage takes the products (wx_kiops_long_a_formed).  The reference's statistics exactly, its phi-vector to
     1e-8, and the vectors of the unfused stages to rounding."""
     from wxfactory_amd import solvers
     from wxfactory_amd.matvec import ComplexStepOperator
@@ -364,12 +365,13 @@ def test_n8_kiops_long_build_lets_the_matvec_form_the_vector(callers8, monkeypat
     vec = torch.zeros((2, R.numel()), dtype=torch.float64, device=DEV)
     vec[1] = R.flatten()
     monkeypatch.setattr(solvers.KiopsWorkspace, "max_fused_len", 4096)   # (make this length count as long)
-    stored = [0]
+    stored, with_products = [0], [0]
     plain = ComplexStepOperator.axpy_into
 
     def counting(self, *a):
         done = plain(self, *a)
-        stored[0] += int(done)
+        stored[0] += 1 if done else 0
+        with_products[0] += isinstance(done, tuple)
         return done
 
     monkeypatch.setattr(ComplexStepOperator, "axpy_into", counting)
@@ -378,22 +380,26 @@ def test_n8_kiops_long_build_lets_the_matvec_form_the_vector(callers8, monkeypat
         op = ComplexStepOperator(dt, Q, R, rhs)
         assert rhs._jvp_is_prepared(Q) and rhs.jvp_fuses_store(Q)
         phiv, stats = kiops([1], op, vec, tol=1e-7, m_init=1, mmin=16, mmax=64)
-        assert stored[0] == int(stats[2]), (stored, stats)   # every Krylov vector of the solve
-        monkeypatch.setenv("WXHIP_KIOPS_STORE_AXPY", "0")
+        assert stored[0] == with_products[0] == int(stats[2]), (stored, with_products, stats)   # every Krylov vector of the solve
+        monkeypatch.setenv("WXHIP_KIOPS_STORE_DOTS", "0")      # the vector from the store, its products from a sweep
+        phiv1, stats1 = kiops([1], op, vec, tol=1e-7, m_init=1, mmin=16, mmax=64)
+        assert stored[0] == 2 * int(stats[2]) and with_products[0] == int(stats[2])
+        monkeypatch.setenv("WXHIP_KIOPS_STORE_AXPY", "0")      # neither
         phiv0, stats0 = kiops([1], op, vec, tol=1e-7, m_init=1, mmin=16, mmax=64)
-        assert stored[0] == int(stats[2])                      # (none of these)
+        assert stored[0] == 2 * int(stats[2])
         rhs.jvp_release()
     finally:
         rhs.jvp_release()
         rhs.batched = True
     ref_stats = g["p0/kiops_stats"]
-    for st in (stats, stats0):
+    for st in (stats, stats1, stats0):
         assert [int(st[i]) for i in (0, 1, 2, 3, 5)] == [int(ref_stats[i]) for i in (0, 1, 2, 3, 5)], (st, ref_stats)
     ref = stack("kiops_phiv").cpu().numpy()
     err = np.abs(phiv.cpu().numpy().reshape(ref.shape) - ref).max(axis=AX) / np.abs(ref).max(axis=AX)
     assert (err < 1e-8).all(), err
     # (384 Krylov vectors, 6 substeps: the one rounding that differs - a x + b z in one store - has grown to 2e-10 by the end)
     assert float((phiv - phiv0).abs().max()) <= 1e-8 * float(phiv0.abs().max())
+    assert float((phiv1 - phiv0).abs().max()) <= 1e-8 * float(phiv0.abs().max())
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -110,6 +110,7 @@ SIGNATURES = {
     "wx_kiops_long_a_scaled": (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p]),
     "wx_kiops_long_a_formed": (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wx_kiops_long_a_finish": (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "wx_kiops_long_b_scaled": (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p]),
     "wx_kiops_long_c_lazy": (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -137,7 +138,8 @@ SIGNATURES = {
     "wx_euler3d_jvp_prepared": (c_int, [c_void_p, c_void_p, c_void_p, c_double, POINTER(c_void_p), POINTER(c_void_p), c_void_p,
                                         c_double, c_int, c_void_p]),
     "wx_euler3d_jvp_prepared_axpy": (c_int, [c_void_p, c_void_p, c_void_p, c_double, POINTER(c_void_p), POINTER(c_void_p), c_void_p,
-                                             c_double, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+                                             c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "wx_euler3d_jvp_workgroups": (c_size_t, [c_void_p, c_int]),
     "wx_euler3d_jvp_extrap_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_double, POINTER(c_void_p), c_void_p]),
     "wx_euler3d_jvp": (c_int, [c_void_p, c_void_p, c_void_p, c_double, POINTER(c_void_p), c_void_p, c_double, c_int,
                                c_void_p]),

@@ -92,7 +92,7 @@ EulerParams<T> make_params(const wx_euler3d_plan* pl) {
     P.send_s = P.send_n = P.send_w = P.send_e = nullptr;
     P.K = pl->consts;
     P.stamps = pl->stamps;
-    P.jz = nullptr; P.jzs = nullptr; P.jza = nullptr;
+    P.jz = nullptr; P.jzs = nullptr; P.jza = nullptr; P.jr0 = nullptr; P.jr1 = nullptr; P.jpart = nullptr;
     P.sg = b.sg; P.h = b.h; P.chr = b.chr; P.idz = b.idz;
     P.sgi = b.sgi; P.sgj = b.sgj; P.sgk = b.sgk; P.hi = b.hi; P.hj = b.hj; P.hk = b.hk;
     P.dcoef = b.dcoef; P.duref = b.duref; P.bsn = b.bsn; P.bwe = b.bwe;
@@ -511,17 +511,34 @@ wx_status wx_euler3d_jvp_tangent_extrap_pack(wx_euler3d_plan* pl, const double* 
 wx_status wx_euler3d_jvp_prepared(wx_euler3d_plan* pl, const double* q, const double* v, double eps,
                                   const void* const halo_val[4], const void* const halo_tan[4], double* out, double scale,
                                   wx_region region, wx_stream stream) {
-    return wx_euler3d_jvp_prepared_axpy(pl, q, v, eps, halo_val, halo_tan, out, scale, nullptr, nullptr, nullptr, region, stream);
+    return wx_euler3d_jvp_prepared_axpy(pl, q, v, eps, halo_val, halo_tan, out, scale, nullptr, nullptr, nullptr, nullptr,
+                                        nullptr, nullptr, region, stream);
+}
+
+// workgroups of one wx_euler3d_jvp_prepared* launch over `region` (= the pairs of partial products such a launch writes)
+size_t wx_euler3d_jvp_workgroups(const wx_euler3d_plan* pl, wx_region region) {
+    if (!pl || (region != WX_REGION_ALL && region != WX_REGION_INTERIOR && region != WX_REGION_BOUNDARY)) return 0;
+    const int count = region_count(region, pl->H, pl->V);
+    if (count == 0) return 0;
+    const int n3 = pl->n * pl->n * pl->n, epb = n3 >= 216 ? 1 : 256 / n3;   // (Cfg<N>::EPB)
+    const size_t grid = ((size_t)count + epb - 1) / epb;
+    if (pl->column) return 8 * ((grid + 7) / 8);                          // (launch_jvp_column)
+    if (epb == 1) { const dim3 g = region_grid(region, pl->H, pl->V); return (size_t)g.x * g.y * g.z; }
+    return grid;
 }
 
 // ... with the store  out = *z_scale * (scale * Im R) + *z_coef * z  (z null: the plain product; the two coefficients are
 // read from device memory by the kernel: a Krylov solver that keeps them there needs no host synchronisation)
+// ... and, with row0 (row1 nullable) and partials: the products <row_r, out> of the stored vector as one pair of partial sums per
+// workgroup, partials[2 * w + r], w < wx_euler3d_jvp_workgroups(pl, region) (the caller sums them: wx_kiops_long_a_finish)
 wx_status wx_euler3d_jvp_prepared_axpy(wx_euler3d_plan* pl, const double* q, const double* v, double eps,
                                        const void* const halo_val[4], const void* const halo_tan[4], double* out, double scale,
-                                       const double* z, const double* z_scale, const double* z_coef, wx_region region,
-                                       wx_stream stream) {
+                                       const double* z, const double* z_scale, const double* z_coef, const double* row0,
+                                       const double* row1, double* partials, wx_region region, wx_stream stream) {
     if (!pl || !q || !v || !out) return fail(WX_ERR_INVALID, "wx_euler3d_jvp_prepared: null argument");
     if (z && !z_coef) return fail(WX_ERR_INVALID, "wx_euler3d_jvp_prepared_axpy: z without its coefficient");
+    if ((row0 || row1 || partials) && !(z && row0 && partials))
+        return fail(WX_ERR_INVALID, "wx_euler3d_jvp_prepared_axpy: products need z, row0 and the partials buffer");
     if (pl->dtype != WX_DUAL128) return fail(WX_ERR_INVALID, "wx_euler3d_jvp_*: the plan must be WX_DUAL128");
     if (!pl->face_val) return fail(WX_ERR_INVALID, "wx_euler3d_jvp_prepared: call wx_euler3d_jvp_prepare first");
     if (region != WX_REGION_ALL && region != WX_REGION_INTERIOR && region != WX_REGION_BOUNDARY)
@@ -535,6 +552,7 @@ wx_status wx_euler3d_jvp_prepared_axpy(wx_euler3d_plan* pl, const double* q, con
     P.jvp = 1; P.q_re = q; P.q_tan = v; P.jvp_eps = eps; P.out_tan = out; P.jvp_scale = scale;
     P.split = 1; P.ft = static_cast<double*>(pl->itf); P.fv = pl->face_val;
     P.jz = z; P.jzs = z ? z_scale : nullptr; P.jza = z ? z_coef : nullptr;
+    P.jr0 = row0; P.jr1 = row0 ? row1 : nullptr; P.jpart = row0 ? partials : nullptr;
     P.region = region; P.count = region_count(region, pl->H, pl->V);
     if (halo_val && halo_tan) {
         P.halo_s = static_cast<const dual*>(halo_tan[0]); P.halo_n = static_cast<const dual*>(halo_tan[1]);

@@ -110,6 +110,10 @@ struct EulerParams {
     pp<T, const double, G> jz;
     const double* jzs;
     const double* jza;
+    // ... and, with it, the products of that stored vector with up to two other vectors (the basis rows KIOPS orthogonalises
+    // against; jr1 nullable), summed over the workgroup: jpart[2 * w + r], w = the workgroup's linear index in the launch
+    pp<T, const double, G> jr0, jr1;
+    double* jpart;
     unsigned long long* stamps;  // WX_K2_DIAG == 1 only, else null
 };
 

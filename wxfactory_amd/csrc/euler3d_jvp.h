@@ -43,6 +43,59 @@ __device__ __forceinline__ JvpForcing jvp_forcing(const EulerParams<dual>& P, si
     return r;
 }
 
+// The product's store when P.jz is set (t = jvp_scale * tangent, what the plain store writes): KIOPS' next Krylov vector
+// out = *jzs * t + *jza * z  (solvers/kiops.py:170-176) in the same store, and with P.jr0 that vector's products with one or two
+// basis rows on top, summed over the workgroup (wave shuffles, then one value per wave through LDS): the first streaming stage
+// of the long-vector build (csrc/krylov.hip: kiops_long_a) has then nothing left to read.
+template <int BS>
+__device__ __forceinline__ void jvp_store_axpy(const EulerParams<dual>& P, bool active, size_t o, size_t fs, double t0, double t1,
+                                          double t2, double t3, double t4) {
+    double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0, w4 = 0.0;
+    if (active) {
+        const double sa = P.jzs ? *P.jzs : 1.0, zc = *P.jza;
+        w0 = sa * t0 + zc * P.jz[o];
+        w1 = sa * t1 + zc * P.jz[fs + o];
+        w2 = sa * t2 + zc * P.jz[2 * fs + o];
+        w3 = sa * t3 + zc * P.jz[3 * fs + o];
+        w4 = sa * t4 + zc * P.jz[4 * fs + o];
+        P.out_tan[o] = w0;
+        P.out_tan[fs + o] = w1;
+        P.out_tan[2 * fs + o] = w2;
+        P.out_tan[3 * fs + o] = w3;
+        P.out_tan[4 * fs + o] = w4;
+    }
+    if (P.jr0 == nullptr) return;   // (uniform over the launch: every thread of the workgroup reaches the barriers below)
+    __shared__ double jred[2 * (BS / 64)];
+    double d0 = 0.0, d1 = 0.0;
+    if (active) {
+        d0 = P.jr0[o] * w0 + P.jr0[fs + o] * w1 + P.jr0[2 * fs + o] * w2 + P.jr0[3 * fs + o] * w3 + P.jr0[4 * fs + o] * w4;
+        if (P.jr1 != nullptr)
+            d1 = P.jr1[o] * w0 + P.jr1[fs + o] * w1 + P.jr1[2 * fs + o] * w2 + P.jr1[3 * fs + o] * w3 + P.jr1[4 * fs + o] * w4;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        d0 += __shfl_down(d0, off, 64);
+        d1 += __shfl_down(d1, off, 64);
+    }
+    const int tid = threadIdx.x;
+    if ((tid & 63) == 0) {
+        jred[tid >> 6] = d0;
+        jred[BS / 64 + (tid >> 6)] = d1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int w = 0; w < BS / 64; ++w) {
+            s0 += jred[w];
+            s1 += jred[BS / 64 + w];
+        }
+        const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        P.jpart[2 * wg] = s0;
+        P.jpart[2 * wg + 1] = s1;
+    }
+}
+
 template <int N, bool COLM = false, bool G3 = false>
 __device__ __forceinline__ void euler_jvp_body(const EulerParams<dual>& P) {
     using C = Cfg<N>;
@@ -185,23 +238,20 @@ __device__ __forceinline__ void euler_jvp_body(const EulerParams<dual>& P) {
         }
     }
 
-    if (active) {
-        const double s = P.advection_only ? 0.0 : -P.jvp_scale / sg;
-        accw += gcoef * hf;  // gravity: inv_dzdeta * g * 1/sqrtG * HF_k(sqrtG rho)
-        if (P.jz != nullptr) {
-            const double sa = P.jzs ? *P.jzs : 1.0, zc = *P.jza;
-            P.out_tan[o] = sa * (s * acc0) + zc * P.jz[o];
-            P.out_tan[fs + o] = sa * (s * acc1) + zc * P.jz[fs + o];
-            P.out_tan[2 * fs + o] = sa * (s * acc2) + zc * P.jz[2 * fs + o];
-            P.out_tan[3 * fs + o] = sa * (s * accw) + zc * P.jz[3 * fs + o];
-            P.out_tan[4 * fs + o] = sa * (s * acc4) + zc * P.jz[4 * fs + o];
-        } else {
+    if (P.jz == nullptr) {
+        if (active) {
+            const double s = P.advection_only ? 0.0 : -P.jvp_scale / sg;
+            accw += gcoef * hf;  // gravity: inv_dzdeta * g * 1/sqrtG * HF_k(sqrtG rho)
             P.out_tan[o] = s * acc0;
             P.out_tan[fs + o] = s * acc1;
             P.out_tan[2 * fs + o] = s * acc2;
             P.out_tan[3 * fs + o] = s * accw;
             P.out_tan[4 * fs + o] = s * acc4;
         }
+    } else {   // (uniform over the launch)
+        const double s = (!active || P.advection_only) ? 0.0 : -P.jvp_scale / sg;
+        accw += gcoef * hf;
+        jvp_store_axpy<Cfg<N>::BS>(P, active, o, fs, s * acc0, s * acc1, s * acc2, s * accw, s * acc4);
     }
 }
 
@@ -314,23 +364,20 @@ __device__ __forceinline__ void euler_jvp_body_mf(const EulerParams<dual>& P) {
         if (d == 2) hf = pl[8 * kMfLE + lptm];
     }
 
-    if (active) {
-        const double sc = P.advection_only ? 0.0 : -P.jvp_scale / sg;
-        accw += gcoef * hf;  // gravity: inv_dzdeta * g * 1/sqrtG * HF_k(sqrtG rho)
-        if (P.jz != nullptr) {
-            const double sa = P.jzs ? *P.jzs : 1.0, zc = *P.jza;
-            P.out_tan[o] = sa * (sc * acc0) + zc * P.jz[o];
-            P.out_tan[fs + o] = sa * (sc * acc1) + zc * P.jz[fs + o];
-            P.out_tan[2 * fs + o] = sa * (sc * acc2) + zc * P.jz[2 * fs + o];
-            P.out_tan[3 * fs + o] = sa * (sc * accw) + zc * P.jz[3 * fs + o];
-            P.out_tan[4 * fs + o] = sa * (sc * acc4) + zc * P.jz[4 * fs + o];
-        } else {
+    if (P.jz == nullptr) {
+        if (active) {
+            const double sc = P.advection_only ? 0.0 : -P.jvp_scale / sg;
+            accw += gcoef * hf;  // gravity: inv_dzdeta * g * 1/sqrtG * HF_k(sqrtG rho)
             P.out_tan[o] = sc * acc0;
             P.out_tan[fs + o] = sc * acc1;
             P.out_tan[2 * fs + o] = sc * acc2;
             P.out_tan[3 * fs + o] = sc * accw;
             P.out_tan[4 * fs + o] = sc * acc4;
         }
+    } else {   // (uniform over the launch)
+        const double sc = (!active || P.advection_only) ? 0.0 : -P.jvp_scale / sg;
+        accw += gcoef * hf;
+        jvp_store_axpy<Cfg<N>::BS>(P, active, o, fs, sc * acc0, sc * acc1, sc * acc2, sc * accw, sc * acc4);
     }
 }
 

@@ -332,6 +332,23 @@ __global__ __launch_bounds__(kFinishThreads) void kiops_long_b(double* __restric
     if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
 
+// the products arrive as pairs of partial sums (from the matvec's own store): sum them in a fixed order, apply the rows' scales,
+// shift the augmented components of row j
+__global__ __launch_bounds__(256) void kiops_long_a_finish_kernel(double* __restrict__ V, size_t ldv, int j, size_t n, int p,
+                                                                   int ilow, const double* __restrict__ part, size_t nblocks,
+                                                                   double* __restrict__ dots, const double* __restrict__ scales) {
+    __shared__ double red[4];
+    const int r = blockIdx.x;
+    double v = 0.0;
+    for (size_t b = threadIdx.x; b < nblocks; b += 256) v += part[2 * b + r];
+    const double t = wg_sum256(v, red);
+    if (threadIdx.x == 0) dots[r] = scales ? t * scales[ilow + r] : t;
+    if (r == 0 && (int)threadIdx.x < p) {
+        const double* vp = V + (size_t)(j - 1) * ldv;
+        V[(size_t)j * ldv + n + threadIdx.x] = (int)threadIdx.x + 1 < p ? vp[n + threadIdx.x + 1] : 0.0;
+    }
+}
+
 // lazy normalisation: the augmented components of row j scaled, hcol[j] = |V[j]|, scales[j] = 1 / |V[j]|; the n-long part stays
 __global__ void kiops_long_c_lazy(double* __restrict__ V, size_t ldv, int j, size_t n, int p, const double* __restrict__ nrm2,
                                   double* __restrict__ hcol, double* __restrict__ scales) {
@@ -620,6 +637,19 @@ wx_status wx_kiops_long_a_formed(double* V, size_t ldv, int j, size_t n, int p, 
                        static_cast<const double*>(nullptr), static_cast<const double*>(nullptr), workspace, scales);
     const int nr = j - (j - iop > 0 ? j - iop : 0);
     hipLaunchKernelGGL(multi_dot_finish_kernel, dim3(nr), dim3(64), 0, st, workspace, kLongBlocks, kFinishMaxIop, dots);
+    WX_HIP_TRY(hipGetLastError());
+    return WX_OK;
+}
+
+wx_status wx_kiops_long_a_finish(double* V, size_t ldv, int j, size_t n, int p, int iop, const double* partials, size_t nblocks,
+                                 double* dots, const double* scales, wx_stream stream) {
+    wx_status s = kiops_long_check(V, j, p, iop, ldv, n, "wx_kiops_long_a_finish");
+    if (s != WX_OK) return s;
+    if (!partials || !dots) return fail(WX_ERR_INVALID, "wx_kiops_long_a_finish: null argument");
+    const int ilow = j - iop > 0 ? j - iop : 0, nr = j - ilow;
+    if (nr > 2) return fail(WX_ERR_INVALID, "wx_kiops_long_a_finish: %d products (the matvec's store leaves two at most)", nr);
+    WX_STREAM(st, stream);
+    hipLaunchKernelGGL(kiops_long_a_finish_kernel, dim3(nr), dim3(256), 0, st, V, ldv, j, n, p, ilow, partials, nblocks, dots, scales);
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
 }

@@ -99,16 +99,24 @@ class ComplexStepOperator:
     def __call__(self, vec: torch.Tensor) -> torch.Tensor:
         return matvec_fun(vec, self.dt, self.Q, self.rhs, self.rhs_handle, self.method)
 
-    def axpy_into(self, vec: torch.Tensor, out: torch.Tensor, z: torch.Tensor, z_scale: int, z_coef: int) -> bool:
+    def axpy_into(self, vec: torch.Tensor, out: torch.Tensor, z: torch.Tensor, z_scale: int, z_coef: int, rows=None):
         """out = *z_scale * (A vec) + *z_coef * z formed in the product's own store (the two coefficients: device addresses of
         one double each, z_scale 0 = 1) - KIOPS' V[j] = A V[j-1] + u a (solvers/kiops.py:170-176) without a sweep of its own.
-        False (nothing done) when this product does not run on the kernels that offer the store."""
+        False (nothing done) when this product does not run on the kernels that offer the store; True when it is done;
+        with `rows` (one or two contiguous vectors like out): (partials, count) - the launches have left the products
+        <row, out> as `count` pairs of partial sums in the device tensor `partials` (wx_kiops_long_a_finish sums them)."""
         h = self.rhs_handle
         fuses = getattr(h, "jvp_fuses_store", None)
         if (self.method != "complex" or fuses is None or not getattr(h, "supports_jvp", False) or not getattr(h, "fused_jvp", True)
                 or not isinstance(self.Q, torch.Tensor) or not self.Q.is_contiguous()
                 or not vec.is_contiguous() or not out.is_contiguous() or not z.is_contiguous() or not fuses(self.Q)):
             return False
+        if rows and len(rows) <= 2 and all(r.is_contiguous() for r in rows) and hasattr(h, "jvp_partials_capacity"):
+            if getattr(self, "_partials", None) is None:
+                self._partials = torch.empty(h.jvp_partials_capacity(), dtype=torch.float64, device=out.device)
+            h.jvp(self.Q, vec.reshape(self.Q.shape), EPS_COMPLEX, self.dt / EPS_COMPLEX, out=out, z=z, z_scale=z_scale,
+                  z_coef=z_coef, rows=rows, partials=self._partials)
+            return self._partials, h.jvp_partials_written
         h.jvp(self.Q, vec.reshape(self.Q.shape), EPS_COMPLEX, self.dt / EPS_COMPLEX, out=out, z=z, z_scale=z_scale, z_coef=z_coef)
         return True
 

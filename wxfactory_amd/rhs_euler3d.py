@@ -307,18 +307,26 @@ class Euler3DPlan:
         check(self.lib.wx_euler3d_jvp_tangent_extrap_pack(self._h, q.data_ptr(), v.data_ptr(), eps, _ptr_array(send_tan), st),
               "wx_euler3d_jvp_tangent_extrap_pack")
 
+    def jvp_workgroups(self, region: int = _lib.WX_REGION_ALL) -> int:
+        """workgroups of one jvp_prepared launch over `region` (= pairs of partial products it writes when asked to)"""
+        return int(self.lib.wx_euler3d_jvp_workgroups(self._h, region))
+
     def jvp_prepared(self, q, v, eps: float, halo_val, halo_tan, out, scale: float, region: int = _lib.WX_REGION_ALL,
-                     z=None, z_scale: int = 0, z_coef: int = 0):
+                     z=None, z_scale: int = 0, z_coef: int = 0, rows=None, partials: int = 0):
         """z (a real tensor like out; z_scale / z_coef: DEVICE addresses of one double each, z_scale 0 = 1):
-        out = *z_scale * (scale * Im R) + *z_coef * z formed in the product's own store"""
+        out = *z_scale * (scale * Im R) + *z_coef * z formed in the product's own store; rows (one or two tensors like out)
+        with `partials` (a device address, 2 * jvp_workgroups(region) doubles): the products <row, out> as partial sums"""
         for t in (q, v, out):
             self._check_real(t)
         st = torch.cuda.current_stream(self.device).cuda_stream
         if z is not None:
             self._check_real(z)
+            r0 = rows[0].data_ptr() if rows else None
+            r1 = rows[1].data_ptr() if rows and len(rows) > 1 else None
             check(self.lib.wx_euler3d_jvp_prepared_axpy(self._h, q.data_ptr(), v.data_ptr(), eps, _ptr_array(halo_val),
                                                         _ptr_array(halo_tan), out.data_ptr(), scale, z.data_ptr(),
-                                                        z_scale or None, z_coef, region, st), "wx_euler3d_jvp_prepared_axpy")
+                                                        z_scale or None, z_coef, r0, r1, (partials or None) if rows else None,
+                                                        region, st), "wx_euler3d_jvp_prepared_axpy")
             return
         check(self.lib.wx_euler3d_jvp_prepared(self._h, q.data_ptr(), v.data_ptr(), eps, _ptr_array(halo_val),
                                                _ptr_array(halo_tan), out.data_ptr(), scale, region, st),
@@ -637,6 +645,13 @@ class RhsEuler3D(PanelRhs):
         """True when a product about Q takes the prepared per-tile kernels, whose store can form a x + b z (jvp(out=, z=))."""
         return bool(self.panels) and self._jvp_is_prepared(Q) and Q.dtype == torch.float64
 
+    def jvp_partials_capacity(self) -> int:
+        """doubles that hold the pairs of partial products of one product's launches, whichever way it is split"""
+        plans = self._jvp_plans()
+        return 2 * sum(max(plans[p].jvp_workgroups(_lib.WX_REGION_ALL),
+                           plans[p].jvp_workgroups(_lib.WX_REGION_INTERIOR) + plans[p].jvp_workgroups(_lib.WX_REGION_BOUNDARY))
+                       for p in self.panels)
+
     def _jvp_plans(self):
         if "jvp" not in self._plans:
             self._plans["jvp"] = {p: pl.twin(torch.complex128, dual=True) for p, pl in self.plans.items()}
@@ -687,12 +702,14 @@ class RhsEuler3D(PanelRhs):
         return lin[0]() is Q and lin[1:] == (Q.data_ptr(), Q._version)
 
     def jvp(self, Q: torch.Tensor, v: torch.Tensor, eps: float, scale: float, out=None, z=None, z_scale: int = 0,
-            z_coef: int = 0) -> torch.Tensor:
+            z_coef: int = 0, rows=None, partials=None) -> torch.Tensor:
         """scale * Im R(Q + i eps v) for stacked real Q, v -> real tensor shaped like Q.  The dual state is
         formed inside the kernels and only the tangent is stored: the complex-step JVP of
         solvers/matvec.py:56-61 without a complex array in HBM.
         PREPARED products only (the caller checks jvp_fuses_store): `out` = a contiguous tensor of Q's size to write into;
-        `z` (like out) with the device addresses z_scale / z_coef: out = *z_scale * product + *z_coef * z in the same store."""
+        `z` (like out) with the device addresses z_scale / z_coef: out = *z_scale * product + *z_coef * z in the same store;
+        `rows` (one or two tensors like out) with `partials` (a float64 device tensor of jvp_partials_capacity() doubles): the
+        launches also leave the products <row, out> as pairs of partial sums, self.jvp_partials_written of them."""
         np_ = len(self.panels)
         prepared = self._jvp_is_prepared(Q)
         if self.world > 1:
@@ -721,11 +738,25 @@ class RhsEuler3D(PanelRhs):
             exv, ext = self._ex_val, self._ex_tan
             out = torch.empty_like(Qs) if out is None else out.reshape(Qs.shape)
             zs = None if z is None else z.reshape(Qs.shape)
+            rs = None if not rows or zs is None else [r.reshape(Qs.shape) for r in rows]
+            written = [0]
+
+            def extra(i, p, region):
+                if zs is None:
+                    return ()   # (the plain call: stand-in plans of the CPU tests know no more)
+                if rs is None:
+                    return (zs[i], z_scale, z_coef)
+                at = partials.data_ptr() + 16 * written[0]
+                written[0] += plans[p].jvp_workgroups(region)
+                assert 2 * written[0] <= partials.numel()
+                return (zs[i], z_scale, z_coef, [r[i] for r in rs], at)
+
             for i, p in enumerate(self.panels):
                 plans[p].jvp_tangent_pack(Qs[i], vs[i], eps, ext.send_views(p))
             self._exchange_and_launch(ext, lambda i, p, halo, region: plans[p].jvp_prepared(
                 Qs[i], vs[i], eps, exv.halo_views(p) if halo is not None else None, halo, out[i], scale, region,
-                *(() if zs is None else (zs[i], z_scale, z_coef))))
+                *extra(i, p, region)))
+            self.jvp_partials_written = written[0]
             return out.reshape(Q.shape)
         if out is not None or z is not None:
             raise RuntimeError("jvp(out=, z=): only the prepared product stores into a caller's buffer (jvp_fuses_store)")

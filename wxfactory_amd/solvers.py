@@ -821,6 +821,7 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
     row_scale = [1.0] * (mmax + 2)   # the host's copy of the scales (from the norms it reads with the Hessenberg columns)
     store_axpy = (getattr(A, "axpy_into", None)
                   if long_build and p == 1 and os.environ.get("WXHIP_KIOPS_STORE_AXPY", "1") != "0" else None)
+    store_dots = os.environ.get("WXHIP_KIOPS_STORE_DOTS", "1") != "0"   # ... and its products with the rows it is orthogonalised against
 
     def products(lo: int, hi: int, j: int, out: torch.Tensor):
         """out[k - lo] = <V[k], V[j]> over the n + p components, lo <= k < hi"""
@@ -878,9 +879,16 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
                 sc = ws.scales.data_ptr() if lazy else None
                 # one augmented component, an operator whose product can store a x + b z: the n-long part of row j is formed
                 # by the matvec itself (scale of row j-1 and the augmented component read on the device), one sweep fewer
-                if store_axpy is not None and store_axpy(Vd[j - 1, :n], Vd[j, :n], u_flip_t,
-                                                         ws.scales[j - 1: j].data_ptr() if lazy else 0,
-                                                         Vd[j - 1, n:].data_ptr()):
+                stored = False
+                if store_axpy is not None:
+                    rows = [Vd[r, :n] for r in range(ilow, j)] if store_dots and j - ilow <= 2 else None
+                    stored = store_axpy(Vd[j - 1, :n], Vd[j, :n], u_flip_t, ws.scales[j - 1: j].data_ptr() if lazy else 0,
+                                        Vd[j - 1, n:].data_ptr(), rows)
+                if isinstance(stored, tuple):   # ... and the products too: nothing left to sweep for this stage
+                    part, count = stored
+                    basis.check(lib.wx_kiops_long_a_finish(Vd.data_ptr(), Vd.stride(0), j, n, p, iop, part.data_ptr(), count,
+                                                           ws.dots.data_ptr(), sc, st), "wx_kiops_long_a_finish")
+                elif stored:
                     basis.check(lib.wx_kiops_long_a_formed(Vd.data_ptr(), Vd.stride(0), j, n, p, iop, ws.dots.data_ptr(),
                                                            ws.finish_work.data_ptr(), sc, st), "wx_kiops_long_a_formed")
                 else:
