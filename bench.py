@@ -350,7 +350,7 @@ def extras(dev, seed):
                                    "algorithmic_bytes_per_point": 156.0, "achieved": round(156.0 * 6 * H * H * n * n / te / 1e9, 1),
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(156.0 * 6 * H * H * n * n / te / 1e9 / HBM_PEAK_GBS, 4),
-                                   "profile": "profiles/r04_v6_swbench_kernel_stats.csv, profiles/r04_pmc_sw_summary.json"},
+                                   "profile": "profiles/r04_v7_swbench_kernel_stats.csv, profiles/r04_pmc_sw_summary.json"},
                       "note": "all six panels in one launch per phase (wx_sw_batch_*): 2 launches per R(Q); launch-latency "
                               "bound (5.5 MB of state per panel)"}}
 
