@@ -112,11 +112,12 @@ class ComplexStepOperator:
                 or not vec.is_contiguous() or not out.is_contiguous() or not z.is_contiguous() or not fuses(self.Q)):
             return False
         if rows and len(rows) <= 2 and all(r.is_contiguous() for r in rows) and hasattr(h, "jvp_partials_capacity"):
-            if getattr(self, "_partials", None) is None:
-                self._partials = torch.empty(h.jvp_partials_capacity(), dtype=torch.float64, device=out.device)
+            part = getattr(h, "_jvp_partials_buf", None)   # (kept by the RHS object: one address from solve to solve)
+            if part is None or part.device != out.device or part.numel() < h.jvp_partials_capacity():
+                part = h._jvp_partials_buf = torch.empty(h.jvp_partials_capacity(), dtype=torch.float64, device=out.device)
             h.jvp(self.Q, vec.reshape(self.Q.shape), EPS_COMPLEX, self.dt / EPS_COMPLEX, out=out, z=z, z_scale=z_scale,
-                  z_coef=z_coef, rows=rows, partials=self._partials)
-            return self._partials, h.jvp_partials_written
+                  z_coef=z_coef, rows=rows, partials=part)
+            return part, h.jvp_partials_written
         h.jvp(self.Q, vec.reshape(self.Q.shape), EPS_COMPLEX, self.dt / EPS_COMPLEX, out=out, z=z, z_scale=z_scale, z_coef=z_coef)
         return True
 
