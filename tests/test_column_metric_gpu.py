@@ -137,6 +137,18 @@ def test_column_plans_under_the_rhs_object_and_the_matvec(built_lib):
         errj = (jv - ref).abs().amax(dim=ax) / ref.abs().amax(dim=ax)
         assert (errj < 1e-9).all(), (batched, errj)
         outs[batched] = (r, jv)
+        if not batched:   # the store that forms a (A v) + b z and leaves the vector's products (KIOPS), column kernels
+            op = ComplexStepOperator(float(g["meta/dt_jvp"]), Q, R, rhs)
+            coef = torch.tensor([1.25, 0.5], dtype=torch.float64, device=DEV)
+            z, row = R.flatten().contiguous(), Q.flatten().contiguous()
+            out = torch.full_like(z, float("nan"))
+            part, count = op.axpy_into(V.flatten().contiguous(), out, z, coef[0:1].data_ptr(), coef[1:2].data_ptr(), [row])
+            torch.cuda.synchronize()
+            want = 1.25 * jv.flatten() + 0.5 * z
+            assert float((out - want).abs().max()) <= 1e-14 * float(want.abs().max())
+            got = float(part[: 2 * count].view(count, 2).sum(dim=0)[0])
+            assert abs(got - float(torch.dot(row, out))) <= 1e-12 * float(row.norm() * out.norm())
+            rhs.jvp_release()
     assert all(pl.column_metric for pl in rhs._jvp_plans().values())   # the dual twins took the slabs
     assert float((outs[True][0] - outs[False][0]).abs().max()) <= 1e-12 * float(R.abs().max())
 
