@@ -668,9 +668,10 @@ wx_status wx_kiops_long_a_scaled(double* V, size_t ldv, int j, size_t n, int p, 
 wx_status wx_kiops_long_a_formed(double* V, size_t ldv, int j, size_t n, int p, int iop, double* dots, double* workspace,
                                  const double* scales, wx_stream stream);
 /* ... and when the matvec has left the products too (partials: nblocks pairs, wx_euler3d_jvp_prepared_axpy): the augmented
- * components of row j and dots[r] = scales[ilow + r] * sum_b partials[2 b + r], r < min(iop, j) <= 2 - no sweep at all */
+ * components of row j and dots[r] = scales[ilow + r] * sum_b partials[2 b + r], r < min(iop, j) <= 2 - no sweep at all
+ * (workspace: wx_kiops_long_workspace() doubles, as for the other stages) */
 wx_status wx_kiops_long_a_finish(double* V, size_t ldv, int j, size_t n, int p, int iop, const double* partials, size_t nblocks,
-                                 double* dots, const double* scales, wx_stream stream);
+                                 double* dots, double* workspace, const double* scales, wx_stream stream);
 wx_status wx_kiops_long_b_scaled(double* V, size_t ldv, int j, size_t n, int p, int iop, const double* h, double* nrm2,
                                  double* workspace, const double* scales, wx_stream stream);
 wx_status wx_kiops_long_c_lazy(double* V, size_t ldv, int j, size_t n, int p, const double* nrm2, double* hcol, double* scales,

@@ -110,7 +110,8 @@ SIGNATURES = {
     "wx_kiops_long_a_scaled": (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p]),
     "wx_kiops_long_a_formed": (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "wx_kiops_long_a_finish": (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "wx_kiops_long_a_finish": (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
+                                       c_void_p]),
     "wx_kiops_long_b_scaled": (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p]),
     "wx_kiops_long_c_lazy": (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -332,16 +332,26 @@ __global__ __launch_bounds__(kFinishThreads) void kiops_long_b(double* __restric
     if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
 
-// the products arrive as pairs of partial sums (from the matvec's own store): sum them in a fixed order, apply the rows' scales,
-// shift the augmented components of row j
+// the products arrive as pairs of partial sums (from the matvec's own store: 172 800 pairs for the E7 sphere): summed in a fixed
+// order in two steps - kFinishStage1 workgroups per product over contiguous chunks, then one workgroup over their results, which
+// also applies the rows' scales and shifts the augmented components of row j  (one workgroup alone took 0.28 ms)
+constexpr int kFinishStage1 = 128;
+__global__ __launch_bounds__(256) void kiops_long_a_finish1(const double* __restrict__ part, size_t nblocks, double* __restrict__ tmp) {
+    __shared__ double red[4];
+    const int r = blockIdx.y;
+    const size_t chunk = (nblocks + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * chunk;
+    const size_t hi = lo + chunk < nblocks ? lo + chunk : nblocks;
+    double v = 0.0;
+    for (size_t b = lo + threadIdx.x; b < hi; b += 256) v += part[2 * b + r];
+    const double t = wg_sum256(v, red);
+    if (threadIdx.x == 0) tmp[(size_t)r * gridDim.x + blockIdx.x] = t;
+}
 __global__ __launch_bounds__(256) void kiops_long_a_finish_kernel(double* __restrict__ V, size_t ldv, int j, size_t n, int p,
-                                                                   int ilow, const double* __restrict__ part, size_t nblocks,
+                                                                   int ilow, const double* __restrict__ tmp,
                                                                    double* __restrict__ dots, const double* __restrict__ scales) {
     __shared__ double red[4];
     const int r = blockIdx.x;
-    double v = 0.0;
-    for (size_t b = threadIdx.x; b < nblocks; b += 256) v += part[2 * b + r];
-    const double t = wg_sum256(v, red);
+    const double t = wg_sum256((int)threadIdx.x < kFinishStage1 ? tmp[(size_t)r * kFinishStage1 + threadIdx.x] : 0.0, red);
     if (threadIdx.x == 0) dots[r] = scales ? t * scales[ilow + r] : t;
     if (r == 0 && (int)threadIdx.x < p) {
         const double* vp = V + (size_t)(j - 1) * ldv;
@@ -642,14 +652,16 @@ wx_status wx_kiops_long_a_formed(double* V, size_t ldv, int j, size_t n, int p, 
 }
 
 wx_status wx_kiops_long_a_finish(double* V, size_t ldv, int j, size_t n, int p, int iop, const double* partials, size_t nblocks,
-                                 double* dots, const double* scales, wx_stream stream) {
+                                 double* dots, double* workspace, const double* scales, wx_stream stream) {
     wx_status s = kiops_long_check(V, j, p, iop, ldv, n, "wx_kiops_long_a_finish");
     if (s != WX_OK) return s;
-    if (!partials || !dots) return fail(WX_ERR_INVALID, "wx_kiops_long_a_finish: null argument");
+    if (!partials || !dots || !workspace) return fail(WX_ERR_INVALID, "wx_kiops_long_a_finish: null argument");
     const int ilow = j - iop > 0 ? j - iop : 0, nr = j - ilow;
     if (nr > 2) return fail(WX_ERR_INVALID, "wx_kiops_long_a_finish: %d products (the matvec's store leaves two at most)", nr);
+    static_assert(2 * kFinishStage1 <= kLongBlocks * kFinishMaxIop, "the long-vector workspace holds the first step's results");
     WX_STREAM(st, stream);
-    hipLaunchKernelGGL(kiops_long_a_finish_kernel, dim3(nr), dim3(256), 0, st, V, ldv, j, n, p, ilow, partials, nblocks, dots, scales);
+    hipLaunchKernelGGL(kiops_long_a_finish1, dim3(kFinishStage1, nr), dim3(256), 0, st, partials, nblocks, workspace);
+    hipLaunchKernelGGL(kiops_long_a_finish_kernel, dim3(nr), dim3(256), 0, st, V, ldv, j, n, p, ilow, workspace, dots, scales);
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
 }

@@ -887,7 +887,8 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
                 if isinstance(stored, tuple):   # ... and the products too: nothing left to sweep for this stage
                     part, count = stored
                     basis.check(lib.wx_kiops_long_a_finish(Vd.data_ptr(), Vd.stride(0), j, n, p, iop, part.data_ptr(), count,
-                                                           ws.dots.data_ptr(), sc, st), "wx_kiops_long_a_finish")
+                                                           ws.dots.data_ptr(), ws.finish_work.data_ptr(), sc, st),
+                                "wx_kiops_long_a_finish")
                 elif stored:
                     basis.check(lib.wx_kiops_long_a_formed(Vd.data_ptr(), Vd.stride(0), j, n, p, iop, ws.dots.data_ptr(),
                                                            ws.finish_work.data_ptr(), sc, st), "wx_kiops_long_a_formed")
