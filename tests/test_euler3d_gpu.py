@@ -189,21 +189,7 @@ def test_rccl_exchange_path_on_one_gpu():
     import socket
 
     if os.environ.get("WX_RCCL_TEST_CHILD") != "1":
-        # In an interpreter of its own, as a rank of a several-GPU run is: this is the one test of the suite that creates a torch
-        # process group (watchdog and heartbeat threads) and captures graphs under it.  About once in ten runs of the WHOLE
-        # suite the process ended here with SIGABRT and nothing on the captured stderr (profiles/r04_capture_crash.md, second
-        # part; ten runs of the test alone under rocgdb: none): in a child the rest of the suite is out of its reach, and its
-        # output - torch's own message included - is in the assertion below if it happens again.
-        import subprocess
-        import sys
-
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        r = subprocess.run([sys.executable, "-X", "faulthandler", "-m", "pytest", "-q", "-x", "-s", "-m", "gpu",
-                            "tests/test_euler3d_gpu.py", "-k", "test_rccl_exchange_path_on_one_gpu"], cwd=root,
-                           env=dict(os.environ, WX_RCCL_TEST_CHILD="1", NCCL_DEBUG="WARN", TORCH_SHOW_CPP_STACKTRACES="1"),
-                           capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0 and "1 passed" in r.stdout, f"rc={r.returncode}\n{r.stdout[-6000:]}\n{r.stderr[-6000:]}"
-        return
+        pytest.skip("runs in an interpreter of its own: tests/test_zz_process_group_gpu.py")
 
     import torch.distributed as dist
 
