@@ -3,7 +3,7 @@
 # in ten runs.  Run it alone under rocgdb a few times, stop at the first signal, keep every thread's backtrace.
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/abort_hunt; mkdir -p "$OUT"
-export LD_LIBRARY_PATH=$ROOT/wxfactory_amd/lib:/opt/rocm/lib:$LD_LIBRARY_PATH NCCL_DEBUG=WARN
+export LD_LIBRARY_PATH=$ROOT/wxfactory_amd/lib:/opt/rocm/lib:$LD_LIBRARY_PATH NCCL_DEBUG=WARN WX_RCCL_TEST_CHILD=1
 cd "$ROOT"
 for i in $(seq 1 ${1:-8}); do
   timeout -k 10 180 rocgdb -batch -ex "set pagination off" -ex "handle SIGUSR1 SIGUSR2 SIGCHLD nostop noprint pass" -ex run \
