@@ -237,6 +237,72 @@ def test_prepared_jvp_on_ragged_tiles(n, H, V):
     assert torch.equal(plain, prepared)
 
 
+@pytest.fixture(scope="module")
+def one_rank_comm():
+    """one communicator for the module (a one-rank RCCL communicator needs no process group)"""
+    from wxfactory_amd.exchange import RcclComm
+
+    c = RcclComm(0, 1, device="cuda:0")
+    yield c
+    torch.cuda.synchronize()
+    c.close()
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("n,H,V,column", [(2, 5, 3, False), (3, 4, 2, False), (4, 3, 2, False), (5, 3, 1, False), (6, 3, 2, False),
+                                          (7, 3, 1, False), (8, 3, 2, False), (8, 3, 2, True), (5, 2, 2, True), (8, 1, 2, False)])
+def test_partial_products_of_the_jvp_store_fill_exactly_their_slots(n, H, V, column, overlap, one_rank_comm):
+    """The a x + b z store of the prepared JVP with the stored vector's products (KIOPS on long vectors): every launch writes
+    one pair of partial sums per workgroup, wx_euler3d_jvp_workgroups of them - for every order (one or several elements per
+    workgroup, 1-D and 3-D grids), whole-tile and INTERIOR / BOUNDARY launches, general and column kernels: exactly the
+    counted slots are written (a wrong count would write past the buffer), and they sum to the products."""
+    from wxfactory_amd.geometry3d import CubedSphere3DTile, metric3d_torch
+    from wxfactory_amd.initial import initial_state
+    from wxfactory_amd.matvec import ComplexStepOperator
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D
+    from wxfactory_amd.synthetic import dfr_ops
+
+    dev = "cuda:0"
+    plans, qs = {}, []
+    gen = torch.Generator(device=dev).manual_seed(11)
+    for p in range(6):
+        t = CubedSphere3DTile(n, H, V, p, 10000.0, 31)
+        plans[p] = Euler3DPlan(n, H, V, 31, p, dfr_ops(n), metric3d_torch(t, dev), column_metric="auto" if column else False)
+        assert plans[p].column_metric == column
+        q = torch.from_numpy(np.array(initial_state(t))).to(dev)
+        qs.append(q * (1.0 + 0.01 * (torch.rand(q.shape, generator=gen, device=dev, dtype=q.dtype) - 0.5)))
+    Q = torch.stack(qs)
+    if overlap:   # every edge message through a one-rank RCCL communicator: INTERIOR / BOUNDARY launches, as on several GPUs
+        from wxfactory_amd.exchange import PanelExchange
+
+        ex = PanelExchange(plans[0].edge_count, dev, rank=0, world_size=1, loopback=True, backend="rccl", comm=one_rank_comm)
+        rhs = RhsEuler3D(plans, ex, overlap=True)
+    else:
+        rhs = RhsEuler3D(plans)
+    rhs.batched = False
+    R = rhs(Q)
+    v = ((torch.rand(Q.shape, generator=gen, device=dev, dtype=Q.dtype) - 0.5) * Q.abs().amax(dim=(0, 2, 3, 4, 5), keepdim=True)).flatten()
+    op = ComplexStepOperator(2.0, Q, R, rhs)
+    assert rhs.jvp_fuses_store(Q)
+    plain = op(v)
+    z = R.flatten().contiguous()
+    rows = [Q.flatten().contiguous(), v.contiguous()]
+    coef = torch.tensor([0.5, 2.0], dtype=torch.float64, device=dev)
+    out = torch.empty_like(z)
+    part, count = op.axpy_into(v, out, z, coef[0:1].data_ptr(), coef[1:2].data_ptr(), rows)   # (allocates the buffer)
+    part.fill_(float("nan"))
+    part2, count2 = op.axpy_into(v, out, z, coef[0:1].data_ptr(), coef[1:2].data_ptr(), rows)
+    torch.cuda.synchronize()
+    rhs.jvp_release()
+    assert part2 is part and count2 == count and 0 < 2 * count <= part.numel()
+    assert torch.isfinite(part[: 2 * count]).all() and torch.isnan(part[2 * count:]).all()
+    want = 0.5 * plain + 2.0 * z
+    assert float((out - want).abs().max()) <= 1e-14 * float(want.abs().max())
+    got = part[: 2 * count].view(count, 2).sum(dim=0)
+    for k in range(2):
+        assert abs(float(got[k]) - float(torch.dot(rows[k], out))) <= 1e-12 * float(rows[k].norm() * out.norm()), k
+
+
 @pytest.mark.parametrize("n,Htot,V", [(4, 4, 2), (8, 4, 1)])
 def test_result_does_not_depend_on_the_decomposition(n, Htot, V):
     """The reference's restart tests require a 6-rank and a 24-rank run of the same case to agree to 1e-15
