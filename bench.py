@@ -722,25 +722,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
+    # before the first call that initialises the GPU runtime (the host driver supports dmabuf IPC only: without this RCCL's
+    # peer mapping fails with hipIpcGetMemHandle: invalid argument); ranks started by an external torchrun land here too
+    if world > 1 or args.loopback:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")   # a communicator that cannot connect says why on stderr
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1 or args.loopback:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("NCCL_DEBUG", "WARN")   # a communicator that cannot connect says why on stderr
-    if world > 1 or args.loopback:   # (loopback: a one-rank group, so that the exchange self-check below is rehearsed too)
-        if world == 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            if "MASTER_PORT" not in os.environ:   # a free port, as the tests pick theirs
-                import socket
-
-                with socket.socket() as sk:
-                    sk.bind(("127.0.0.1", 0))
-                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+    if world > 1:
+        # a HOST-side process group (gloo) for what happens around the measurement: the 128-byte id of the library's
+        # communicator, barriers, the max over ranks, the independent route of the exchange self-check.  NO NCCL process group:
+        # the halo exchange and every reduction of the data path run on the library's own communicator (wx_comm_*), and a
+        # torch NCCL group would add a watchdog thread issuing HIP calls beside the captures (profiles/r05_process_group_abort.md)
+        dist.init_process_group("gloo")
 
     from wxfactory_amd import _lib, synthetic
     from wxfactory_amd.exchange import PanelExchange
@@ -778,13 +774,14 @@ def main():
         """True when `flag` holds on every rank (one all-reduce of the process group; the decision is the same everywhere)."""
         if world == 1 or not dist.is_initialized():
             return flag
-        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)   # (gloo: host tensors)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(t.item())
 
     def torch_exchange():
-        return PanelExchange(edge_doubles, dev, rank=rank, world_size=world, tiles_per_side=k, loopback=args.loopback,
-                             backend="torch")
+        # torch.distributed.all_to_all_single on the gloo group, staged through host copies (exchange.py): the independent
+        # second route of the self-check and the fallback - slow, correct, pinned by tests/test_exchange_gloo.py
+        return PanelExchange(edge_doubles, dev, rank=rank, world_size=world, tiles_per_side=k, backend="torch")
 
     ex = None
     dog = None
@@ -796,7 +793,7 @@ def main():
 
         def hung():
             sys.stderr.write(f"bench.py rank {rank}: the RCCL exchange (communicator set-up / first grouped ncclSend + ncclRecv) "
-                             "did not finish in 300 s; rerun with --exchange torch\n")
+                             "did not finish in 300 s; rerun with --exchange torch (host-staged gloo)\n")
             sys.stderr.flush()
             os._exit(4)
 
@@ -804,13 +801,13 @@ def main():
         dog.daemon = True
         dog.start()
         # the library's own exchange (wx_comm_*, wx_exchange_*).  Its first run on several GPUs is the driver's: if the
-        # communicator or the buffers cannot be set up on some rank, every rank falls back to all_to_all_single and the
-        # line says so, instead of the whole scaling run being lost
+        # communicator or the buffers cannot be set up on some rank, every rank falls back to the host-staged gloo route and
+        # the line says so, instead of the whole scaling run being lost
         from wxfactory_amd.exchange import RcclComm
 
         why = None
         try:
-            comm = RcclComm(rank, world, device=dev)   # (the unique id travels through the process group; one rank needs none)
+            comm = RcclComm(rank, world, device=dev)   # (the unique id travels through the gloo group; one rank needs none)
             ex = PanelExchange(edge_doubles, dev, rank=rank, world_size=world, tiles_per_side=k, loopback=args.loopback,
                                backend="rccl", comm=comm)
         except Exception as e:   # noqa: BLE001 - reported in the line
@@ -819,29 +816,37 @@ def main():
             exchange_report = {"backend": "rccl behind the C ABI (wx_exchange_*: grouped ncclSend / ncclRecv, event fork / join)"}
         else:
             ex, comm = None, None
-            exchange_report = {"backend": "torch.distributed.all_to_all_single", "fell_back_from": "rccl behind the C ABI",
+            exchange_report = {"backend": "gloo all_to_all_single through host copies", "fell_back_from": "rccl behind the C ABI",
                                "reason": why or "set-up failed on another rank"}
-    elif world > 1 or args.loopback:
-        exchange_report = {"backend": "torch.distributed.all_to_all_single"}
+    elif world > 1:
+        exchange_report = {"backend": "gloo all_to_all_single through host copies (--exchange torch)"}
+    elif args.loopback:
+        raise SystemExit("--loopback rehearses the library's exchange on one GPU: it needs --exchange rccl")
     if ex is None:
         ex = torch_exchange()
     rhs = RhsEuler3D(plans, ex, overlap=not args.no_overlap)
 
-    if getattr(ex, "_native", None) is not None and dist.is_initialized():
-        # self-check before anything is timed: the same state through the library's exchange and through
-        # all_to_all_single must give the same R bit for bit on every rank (the second path is the one the gloo tests pin
-        # against the reference's halos)
+    if getattr(ex, "_native", None) is not None:
+        # self-check before anything is timed: the same state through the library's exchange and through an independent
+        # route must give the same R bit for bit on every rank.  Several ranks: gloo's all_to_all_single through host copies
+        # (the route tests/test_exchange_gloo.py pins against the reference's halos).  One rank in loopback mode: the
+        # aliasing exchange (no message moves).
         probe = torch.stack([qs[t] for t in mine]) if mine else qs
         got = rhs(probe)
         torch.cuda.synchronize()
-        rhs_t = RhsEuler3D(plans, torch_exchange(), overlap=not args.no_overlap)
+        if world > 1:
+            rhs_t = RhsEuler3D(plans, torch_exchange(), overlap=not args.no_overlap)
+            route = "gloo all_to_all_single through host copies"
+        else:
+            rhs_t = RhsEuler3D(plans, PanelExchange(edge_doubles, dev, rank=0, world_size=1, tiles_per_side=k))
+            route = "aliasing exchange of one rank"
         want = rhs_t(probe)
         torch.cuda.synchronize()
         same = all_ranks(bool(torch.equal(got, want)) if mine else True)
-        exchange_report["selfcheck"] = ("R(Q) bit-identical to the all_to_all_single exchange on every rank" if same else
-                                        "MISMATCH against the all_to_all_single exchange: timed on all_to_all_single instead")
+        exchange_report["selfcheck"] = (f"R(Q) bit-identical to the {route} on every rank" if same else
+                                        f"MISMATCH against the {route}: timed on that route instead")
         if not same:
-            exchange_report["backend"] = "torch.distributed.all_to_all_single"
+            exchange_report["backend"] = route
             exchange_report["fell_back_from"] = "rccl behind the C ABI"
             rhs, ex = rhs_t, rhs_t.ex
         del got, want, probe
@@ -956,7 +961,7 @@ def main():
         if not (chk == chk and chk < float("inf")):
             raise SystemExit("non-finite RHS in the benchmark")
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64)   # (gloo: host tensors)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
@@ -973,6 +978,7 @@ def main():
         local[0] = out.sum(dim=(0, 2, 3, 4, 5))
         local[1] = out.abs().sum(dim=(0, 2, 3, 4, 5))
         local[2] = out.abs().amax(dim=(0, 2, 3, 4, 5))
+    local = local.cpu()
     if world > 1:
         sums = local[:2].clone()
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
@@ -1085,6 +1091,9 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "rhs_evals_per_s": evals_per_s, "ranks_seen": ranks_seen, "per_rank": per_rank, "checksum": checksum,
             "rccl_version": _lib.load().wx_comm_rccl_version(),
+            "hip_runtime_version": _lib.load().wx_hip_runtime_version(),   # what the process BOUND (inside torch: the wheel's)
+            "process_group": "gloo (host side only: id bootstrap, barriers, max over ranks); no NCCL process group" if world > 1
+                             else "none",
             "config": {"workload": f"E7: 3-D Euler RHS, n={n} (p={n-1}), H={H}x{H} elem/panel, V={V}, 6 panels "
                                    f"({5*pts_panel*6} DOF), halo exchange included",
                        "n": n, "H": H, "V": V, "tiles": topo.ntiles, "tile_H": Ht, "tiles_per_gpu": len(mine),
@@ -1119,7 +1128,7 @@ def main():
     except Exception:   # noqa: BLE001
         pass
     if comm is not None:
-        comm.close()
+        comm.close()   # (closes every exchange made on it first: twins, value / tangent sets, the stage pipeline's)
     if dist.is_initialized():
         dist.destroy_process_group()
 

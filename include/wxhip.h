@@ -381,6 +381,7 @@ wx_status wx_sw_plan_destroy(wx_sw_plan* plan);
 /* Elements of dtype per edge message: 3*H*n, layout [var][along][n]: exactly what the reference's
  * exchange delivers (rhs_sw.py:103-117, 138-150): h (+ surface height), then the rotated (hu1, hu2). */
 size_t wx_sw_edge_count(const wx_sw_plan* plan);
+wx_dtype wx_sw_plan_dtype(const wx_sw_plan* plan);
 /* rhs_sw.py:76-117 sender side: extrapolate (h+hsurf, hu1, hu2) to the element faces into the plan's
  * interface buffer; rotate + flip the four tile-edge lines into send[e] (e = S,N,W,E). */
 wx_status wx_sw_extrap_pack(wx_sw_plan* plan, const void* q, void* const send[4], wx_stream stream);
@@ -499,7 +500,24 @@ int wx_comm_rccl_version(void);
 wx_status wx_comm_unique_id(unsigned char id[WX_COMM_ID_BYTES]);
 wx_status wx_comm_init_rank(wx_comm** comm, int nranks, const unsigned char id[WX_COMM_ID_BYTES], int rank);
 wx_status wx_comm_adopt(wx_comm** comm, void* nccl_comm /* ncclComm_t */, int nranks, int rank);
+/* WX_ERR_INVALID while an exchange made on it is alive (wx_exchange_destroy them first: an exchange keeps its communicator
+ * and a later wx_exchange_start on a destroyed one would use freed memory) */
 wx_status wx_comm_destroy(wx_comm* comm);
+/* exchanges alive on this communicator (wx_exchange_create counts up, wx_exchange_destroy down); < 0: null */
+int wx_comm_users(const wx_comm* comm);
+/* The small reductions of the Krylov callers on the SAME communicator as the halo exchange - reference
+ * solvers/global_operations.py:14-36 (global_norm / global_dotprod / global_inf_norm: MPI allreduce), solvers/kiops.py:165-200
+ * and solvers/pmex.py:150-173 (the products of a new Krylov vector with the basis), solvers/fgmres.py:41 (the one
+ * reduction of the low-synchronisation Gram-Schmidt), simulation.py:399-408 (the NaN flag, MAX).  In place on `count`
+ * doubles of device memory, ncclAllReduce enqueued on `stream` - the caller's compute stream, so inside a HIP-graph capture
+ * the reduction becomes a node of the graph on the capture's origin stream (see STREAM CAPTURE above) and a whole Krylov
+ * pass - matvec, exchange, both reductions per vector - replays from one graph on every rank.  No host synchronisation. */
+typedef enum wx_reduce_op { WX_REDUCE_SUM = 0, WX_REDUCE_MAX = 1, WX_REDUCE_MIN = 2 } wx_reduce_op;
+wx_status wx_comm_allreduce(wx_comm* comm, double* buf, size_t count, wx_reduce_op op, wx_stream stream);
+/* versions this process actually BOUND to (the library is built with the image's hipcc but runs on whatever libamdhip64 /
+ * librccl the process loaded first - inside torch: the wheel's): hipRuntimeGetVersion, hipDriverGetVersion; < 0 on error */
+int wx_hip_runtime_version(void);
+int wx_hip_driver_version(void);
 
 wx_status wx_exchange_create(wx_exchange** exchange, wx_comm* comm, int rank, int world, int tiles_per_side,
                              size_t edge_doubles, int loopback);

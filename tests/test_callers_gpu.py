@@ -491,7 +491,13 @@ def test_kiops_long_vector_build(built_lib, p, taus, monkeypatch):
     gen = torch.Generator(device=DEV).manual_seed(17 + p)
     lam = -(0.2 + 2.5 * torch.rand(n, generator=gen, device=DEV, dtype=torch.float64))
     u = torch.randn((p + 1, n), generator=gen, device=DEV, dtype=torch.float64)
-    A = lambda v: lam * v  # noqa: E731
+    class Diagonal:
+        linear = True   # exactly linear in v: may be handed un-normalised rows (lazy normalisation)
+
+        def __call__(self, v):
+            return lam * v
+
+    A = Diagonal()
     args = dict(tol=1e-10, m_init=12, mmin=10, mmax=40)
     w_long, st_long = kiops(taus, A, u, **args)
     monkeypatch.setenv("WXHIP_KIOPS_LONG", "0")
@@ -522,6 +528,18 @@ def test_kiops_long_vector_build(built_lib, p, taus, monkeypatch):
     for i, tau in enumerate(taus):
         ref = sum((tau ** k) * phi(k, tau * lam) * u[k] for k in range(p + 1))
         assert float((w_long[i] - ref).abs().max()) <= 1e-8 * float(ref.abs().max())
+    # An operator that does NOT declare itself linear - a finite-difference product: truncation term quadratic in v - is
+    # always applied to normalised rows, as the reference does (solvers/kiops.py:170): the long-vector stages then rewrite
+    # every row for its norm (wx_kiops_long_c) and reproduce the array-expression recurrence, decisions and vectors.
+    fd = lambda v: lam * v + 1e-3 * lam * v * v  # noqa: E731
+    ws = solvers.KiopsWorkspace()
+    w_fd, st_fd = kiops(taus, fd, u, workspace=ws, **args)
+    assert float((ws.scales - 1.0).abs().max()) == 0.0          # no row was left un-normalised
+    monkeypatch.setenv("WXHIP_KIOPS_LONG", "0")
+    w_fd_expr, st_fd_expr = kiops(taus, fd, u, **args)
+    monkeypatch.delenv("WXHIP_KIOPS_LONG")
+    assert st_fd[:4] == st_fd_expr[:4] and st_fd[5] == st_fd_expr[5], (st_fd, st_fd_expr)
+    assert float((w_fd - w_fd_expr).abs().max()) <= 1e-11 * float(w_fd_expr.abs().max())
     # a NaN in the operator ends the solve with an error instead of an endless loop of rejections
     bad = lambda v: lam * v * float("nan")  # noqa: E731
     with pytest.raises(ValueError, match="NaN"):

@@ -153,128 +153,6 @@ def test_whole_sphere_on_one_gpu():
         assert Rs[p].shape == qs[p].shape and Rs[p].dtype == qs[p].dtype
 
 
-def _graphs_over_rccl(plans, Q, R, v, plain):
-    """BASELINE config 5 over RCCL ("hipGraph-captured matvec" on several GPUs): whole evaluations INCLUDING the
-    collective - R(Q), and the Krylov matvec "tangent extrapolation -> exchange -> JVP kernels" - captured into ONE HIP
-    graph each and replayed; the exchange runs in its stream-ordered form (PanelRhs.set_inline_exchange).  Graphs that
-    hold RCCL nodes must be gone before the process group is."""
-    from wxfactory_amd.exchange import PanelExchange
-    from wxfactory_amd.graph import GraphedFunction
-    from wxfactory_amd.matvec import ComplexStepOperator, matvec_fun
-    from wxfactory_amd.rhs_euler3d import RhsEuler3D
-
-    for batched in (True, False):
-        gr = RhsEuler3D(plans, PanelExchange(plans[0].edge_count, DEV, rank=0, world_size=1, loopback=True), overlap=True)
-        gr.batched = batched
-        g_rhs = GraphedFunction(gr, Q, rhs=gr)
-        ok = gr.ex.is_inline and gr.ex.needs_comm
-        for scale in (1.0, 1.01):
-            ok = ok and bool(torch.equal(g_rhs(Q * scale), plain(Q * scale)))
-        op = ComplexStepOperator(1.0, Q, R, gr)    # (prepares the linearisation state when the tiles are large)
-        ok = ok and gr._jvp_is_prepared(Q) == (not batched)
-        g_mv = GraphedFunction(op, v.flatten(), rhs=gr)
-        for scale in (1.0, -0.37):
-            ok = ok and bool(torch.equal(g_mv((scale * v).flatten()), matvec_fun((scale * v).flatten(), 1.0, Q, R, plain, "complex")))
-        gr.jvp_release()
-        del g_rhs, g_mv, op, gr
-        torch.cuda.synchronize()
-        assert ok, batched
-
-
-def test_rccl_exchange_path_on_one_gpu():
-    """The N>1 code path end to end on one GPU: a 1-rank RCCL process group with the exchange in
-    loopback mode, so every edge message goes through all_to_all_single on device buffers,
-    asynchronously, while the INTERIOR launch runs, then BOUNDARY - and must equal the aliasing path."""
-    import os
-    import socket
-
-    if os.environ.get("WX_RCCL_TEST_CHILD") != "1":
-        pytest.skip("runs in an interpreter of its own: tests/test_zz_process_group_gpu.py")
-
-    import torch.distributed as dist
-
-    from tests.gpu_util import make_plan, to_dev
-    from wxfactory_amd.exchange import PanelExchange
-    from wxfactory_amd.rhs_euler3d import RhsEuler3D
-
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
-    try:
-        g = golden("euler3d_c31p_n3_h4_v2")
-        plans = {p: make_plan(g, p) for p in range(6)}
-        ex = PanelExchange(plans[0].edge_count, DEV, rank=0, world_size=1, loopback=True)
-        assert ex.needs_comm and ex.n_remote_out == 24 and ex.n_remote_in == 24
-        rhs = RhsEuler3D(plans, ex, overlap=True)
-        qs = {p: to_dev(g.q(p)) for p in range(6)}
-        a = rhs(qs)
-        b = RhsEuler3D(plans)(qs)
-        torch.cuda.synchronize()
-        for p in range(6):
-            assert torch.equal(a[p], b[p]), p
-            ref = g.r(p)
-            err = var_err(a[p].cpu().numpy(), ref)
-            assert (err <= TOL * np.maximum(var_max(ref), _scale(g, p, False))).all()
-        # stage pipeline over the collective: INTERIOR / BOUNDARY launches each write the faces and the
-        # edge messages of their part of the next state into the second buffer set
-        Q = torch.stack([qs[p] for p in range(6)])
-        dt = 1e-3
-        piped, plain = RhsEuler3D(plans, ex, overlap=True), RhsEuler3D(plans)
-        Q1 = piped.stage(Q, None, 0.0, 1.0, dt)
-        Q2 = piped.stage(Q1, Q, 0.75, 0.25, 0.25 * dt)
-        Q3 = piped.stage(Q2, Q, 1.0 / 3.0, 2.0 / 3.0, (2.0 / 3.0) * dt)
-        P1 = plain.axpy(Q, None, 0.0, 1.0, dt)
-        P2 = plain.axpy(P1, Q, 0.75, 0.25, 0.25 * dt)
-        P3 = plain.axpy(P2, Q, 1.0 / 3.0, 2.0 / 3.0, (2.0 / 3.0) * dt)
-        torch.cuda.synchronize()
-        scale = P3.abs().amax(dim=(0, 2, 3, 4, 5), keepdim=True)
-        assert ((Q3 - P3).abs() <= 1e-14 * scale).all()
-        # a rank's tiles stacked in one tensor: ONE launch per phase for all of them (what the ranks of a 4- or 8-GPU run
-        # do with their 24-tile layout), the collective between the INTERIOR and the BOUNDARY launch
-        shared = RhsEuler3D(plans, ex, overlap=True)
-        assert shared._small_tiles()
-        c = shared(Q)
-        torch.cuda.synchronize()
-        assert all(torch.equal(c[i], b[p]) for i, p in enumerate(range(6)))
-        # the prepared complex-step JVP over the collective: value halos once, tangent halos per product
-        from wxfactory_amd.matvec import matvec_fun
-
-        R = plain(Q)
-        v = to_dev(np.stack([g[f"p{p}/V"] for p in range(6)]))
-        for r_ in (piped, plain):
-            r_.batched = False
-        j_plain = matvec_fun(v.flatten(), 1.0, Q, R, plain, "complex")
-        assert piped.jvp_prepare(Q)
-        j_coll = matvec_fun(v.flatten(), 1.0, Q, R, piped, "complex")
-        piped.jvp_release()
-        torch.cuda.synchronize()
-        assert torch.equal(j_plain, j_coll)
-        assert piped._ex_tan.needs_comm and piped._ex_tan.loopback   # (the tangent halos did travel through RCCL)
-
-        _graphs_over_rccl(plans, Q, R, v, plain)   # (in a function of its own: nothing of a graph outlives the call)
-        import gc
-
-        gc.collect()
-        torch.cuda.synchronize()
-    except BaseException as exc:
-        # a failure above leaves graphs with RCCL nodes alive in the failed frames, and destroying the communicator under
-        # them aborts the process (profiles/r04_capture_crash.md): say what failed, then drop those frames' locals
-        import traceback
-
-        traceback.print_exc()
-        traceback.clear_frames(exc.__traceback__)
-        raise
-    finally:
-        import gc
-
-        gc.collect()
-        torch.cuda.synchronize()
-        dist.destroy_process_group()
-
-
 @pytest.mark.parametrize("name", ["euler3d_c31p_n3_h4_v2", "euler3d_c31p_n8_h2_v2", "euler3d_c21_n4_h3_v4", "euler3d_c21p_n4_h3_v4",
                                   "euler3d_c21p_n8_h2_v2"])
 def test_dual_number_arithmetic_equals_complex_step(name):

@@ -463,3 +463,91 @@ def test_inline_exchange_is_capture_safe_by_construction(monkeypatch):
     assert kinds == ["pack"] * len(ex.local) + ["wait"] + ["rhs"] * len(ex.local)
     assert all(o[2] == 0 and o[3] for o in order if o[0] == "rhs")                     # region ALL, halos given
     assert rhs.exchange_for(torch.complex128).is_inline                                # a later-created exchange too
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The bootstrap of the library's communicator and the callers' reductions WITHOUT an NCCL process group
+# ---------------------------------------------------------------------------------------------------------
+def _id_worker(rank, world, port, store_port, q):
+    try:
+        from wxfactory_amd import reduce
+        from wxfactory_amd.exchange import share_comm_id
+
+        mine = bytes([rank + 1]) * 128          # (what wx_comm_unique_id would have produced on this rank)
+        # (a) no process group at all: a TCPStore carries rank 0's id
+        store = dist.TCPStore("127.0.0.1", store_port, world, is_master=(rank == 0), timeout=__import__("datetime").timedelta(seconds=60))
+        assert not dist.is_initialized() and reduce.world_size(None) == 1
+        got = share_comm_id(mine, rank, world, store=store)
+        assert got == bytes([1]) * 128 and len(got) == 128, rank
+        # (b) a gloo group: broadcast; then the reductions of reduce.py over the same group (the CPU twin of RcclComm.allreduce)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        assert share_comm_id(mine, rank, world) == bytes([1]) * 128
+        assert reduce.world_size(None) == world and not reduce.is_comm(None)
+        assert reduce.capturable(None) == (world == 1)
+        t = torch.tensor([float(rank + 1), -float(rank)], dtype=torch.float64)
+        assert reduce.allreduce(t.clone(), None, "sum").tolist() == [world * (world + 1) / 2, -world * (world - 1) / 2]
+        assert reduce.allreduce(t.clone(), None, "max").tolist() == [float(world), 0.0]
+        assert reduce.allreduce(t.clone(), None, "min").tolist() == [1.0, -float(world - 1)]
+
+        class Comm:     # the duck type reduce.py accepts for the library's communicator
+            calls = 0
+
+            def allreduce(self, x, op):
+                Comm.calls += 1
+                dist.all_reduce(x, op={"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op])
+                return x
+
+        c = Comm()
+        c.world = world
+        assert reduce.is_comm(c) and reduce.world_size(c) == world and reduce.capturable(c)
+        assert reduce.allreduce(t.clone(), c, "sum")[0] == world * (world + 1) / 2 and Comm.calls == 1
+        from wxfactory_amd.filters import NanFlag
+
+        flag = NanFlag("cpu", group=c)
+        flag.flag[0] = 1 if rank == world - 1 else 0
+        try:
+            flag.raise_if_set()
+            raised = False
+        except ValueError:
+            raised = True
+        assert raised and Comm.calls == 2      # every rank raises (simulation.py:399-408), through the communicator
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, traceback.format_exc()))
+        raise
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_id_bootstrap_over_a_store(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port, store_port = _free_port(), _free_port()
+    procs = [ctx.Process(target=_id_worker, args=(r, world, port, store_port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=180) for _ in range(world)]
+    [p.join(timeout=60) for p in procs]
+    assert all(r[1] == "ok" for r in res), [r for r in res if r[1] != "ok"]
+
+
+def test_device_buffers_never_travel_on_a_torch_nccl_group(monkeypatch):
+    """backend "torch" with device buffers: gloo = staged through host copies (bench.py's independent route), anything else
+    is refused - the data path of several GPUs is the library's own communicator."""
+    import inspect
+
+    from wxfactory_amd import exchange
+
+    src = inspect.getsource(exchange.PanelExchange.start)
+    assert 'dist.get_backend(self.group) != "gloo"' in src and "backend='rccl'" in src
+    import re
+
+    pkg = os.path.dirname(exchange.__file__)
+    bench = open(os.path.join(os.path.dirname(pkg), "bench.py")).read()
+    assert not re.search(r"init_process_group\(\s*[\"']nccl", bench)
+    for name in os.listdir(pkg):
+        if name.endswith(".py"):
+            assert not re.search(r"init_process_group\(\s*[\"']nccl", open(os.path.join(pkg, name)).read()), name

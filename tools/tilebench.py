@@ -8,19 +8,16 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
 from wxfactory_amd import synthetic  # noqa: E402
-from wxfactory_amd.exchange import PanelExchange  # noqa: E402
+from wxfactory_amd.exchange import PanelExchange, RcclComm  # noqa: E402
 from wxfactory_amd.geometry3d import CubedSphere3DTile, metric3d_torch  # noqa: E402
 from wxfactory_amd.panels import CubeTopology  # noqa: E402
 from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D  # noqa: E402
 
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
-os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-os.environ.setdefault("MASTER_PORT", "29534")
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+comm = RcclComm(0, 1, device=dev)   # the library's own communicator: no torch.distributed process group
 n, H, V, k = 8, 60, 8, int(os.environ.get("K", "2"))
 topo, Ht = CubeTopology(k), H // k
 ops = synthetic.dfr_ops(n)
@@ -32,7 +29,8 @@ for t in range(topo.ntiles):
     qs.append(synthetic.euler3d_state(n, Ht, V, t, dev))
 Q = torch.stack(qs)
 for loop in (False, True):
-    ex = PanelExchange(5 * V * Ht * n * n, dev, rank=0, world_size=1, tiles_per_side=k, loopback=loop)
+    ex = PanelExchange(5 * V * Ht * n * n, dev, rank=0, world_size=1, tiles_per_side=k, loopback=loop,
+                       backend="rccl" if loop else "torch", comm=comm if loop else None)
     rhs = RhsEuler3D(plans, ex)
     outs = {}
     for label, maxpts in (("per-tile launches", 0), ("one launch per phase", 10**9)):
@@ -47,4 +45,5 @@ for loop in (False, True):
         outs[label] = out
         print(f"{topo.ntiles} tiles, split={loop!s:5} {label:22s}: {(time.perf_counter() - t0) / 20 * 1e3:7.3f} ms per whole-sphere R(Q)", flush=True)
     print("   identical:", bool(torch.equal(*outs.values())))
-dist.destroy_process_group()
+torch.cuda.synchronize()
+comm.close()

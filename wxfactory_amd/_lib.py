@@ -16,6 +16,7 @@ WX_COMM_ID_BYTES = 128
 WX_RESERVE_STAGE, WX_RESERVE_JVP = 1, 2
 WX_F64, WX_C128, WX_DUAL128 = 0, 1, 2
 WX_REGION_ALL, WX_REGION_INTERIOR, WX_REGION_BOUNDARY = 0, 1, 2
+WX_REDUCE_SUM, WX_REDUCE_MAX, WX_REDUCE_MIN = 0, 1, 2
 WX_KERNEL_RHS, WX_KERNEL_STAGE, WX_KERNEL_JVP, WX_KERNEL_BATCH_RHS, WX_KERNEL_BATCH_JVP = 0, 1, 2, 3, 4
 
 
@@ -149,6 +150,7 @@ SIGNATURES = {
                                        POINTER(SwMetric)]),
     "wx_sw_plan_destroy": (c_int, [c_void_p]),
     "wx_sw_edge_count": (c_size_t, [c_void_p]),
+    "wx_sw_plan_dtype": (c_int, [c_void_p]),
     "wx_sw_extrap_pack": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p]),
     "wx_sw_rhs": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_int, c_void_p]),
     "wx_sw_rhs_axpy": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_double, c_double, c_double,
@@ -190,6 +192,10 @@ SIGNATURES = {
     "wx_comm_init_rank": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_int]),
     "wx_comm_adopt": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_int]),
     "wx_comm_destroy": (c_int, [c_void_p]),
+    "wx_comm_users": (c_int, [c_void_p]),
+    "wx_comm_allreduce": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "wx_hip_runtime_version": (c_int, []),
+    "wx_hip_driver_version": (c_int, []),
     "wx_exchange_create": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_int, c_int, c_size_t, c_int]),
     "wx_exchange_destroy": (c_int, [c_void_p]),
     "wx_exchange_local_tiles": (c_int, [c_void_p, POINTER(c_int), c_int]),

@@ -37,15 +37,25 @@ def build(force: bool = False, verbose: bool = False, defines=(), out: str = LIB
         hipcc = "hipcc"
     objs = []
     procs = []
+    # an object is rebuilt when its own source, any header, or the switches (defines / extra flags) changed
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(PKG, "..", "include", "wxhip.h")]
+    newest_header = max(os.path.getmtime(h) for h in headers)
+    switches = " ".join(list(defines) + os.environ.get("WX_HIPCC_EXTRA", "").split())
     for src in SOURCES:
         obj = os.path.join(LIBDIR, tag + "_" + src.replace(".hip", ".o"))
+        objs.append(obj)
+        stamp = obj + ".switches"
+        fresh = (not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == switches
+                 and os.path.getmtime(obj) > max(newest_header, os.path.getmtime(os.path.join(CSRC, src))))
+        if fresh:
+            continue
+        open(stamp, "w").write(switches)
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
         cmd += ["-D" + d for d in defines]
         cmd += os.environ.get("WX_HIPCC_EXTRA", "").split()   # development: extra compiler flags for an experiment variant
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))
-        objs.append(obj)
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))

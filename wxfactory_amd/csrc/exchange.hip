@@ -35,6 +35,7 @@ struct wx_comm {
     ncclComm_t comm = nullptr;
     int nranks = 0, rank = 0;
     bool owned = false;
+    int users = 0;   // exchanges alive on this communicator: wx_comm_destroy refuses while there are any
 };
 
 struct wx_exchange {
@@ -108,6 +109,10 @@ wx_status build_layout(wx_exchange* ex) {
 
 bool needs_comm(const wx_exchange* ex) { return ex->world > 1 || ex->loopback; }
 
+// hipRuntimeGetVersion of the first runtime whose Stream::EndCapture survives RCCL on a forked stream of a capture
+// (HIP_VERSION = major * 10^7 + minor * 10^5 + patch: 7.0.2 in torch 2.10 wheels reports 70051831, ROCm 7.2 70226015)
+constexpr int kForkedCaptureMinRuntime = 70200000;
+
 hipError_t make_events(wx_exchange* ex) {
     hipError_t e = hipSuccess;
     if (!ex->fork) e = hipEventCreateWithFlags(&ex->fork, hipEventDisableTiming);
@@ -165,11 +170,46 @@ wx_status wx_comm_adopt(wx_comm** out, void* nccl_comm, int nranks, int rank) {
 
 wx_status wx_comm_destroy(wx_comm* c) {
     if (!c) return WX_OK;
+    if (c->users > 0)
+        return fail(WX_ERR_INVALID, "wx_comm_destroy: %d exchange(s) made on this communicator are alive (wx_exchange_destroy them "
+                    "first; HIP graphs that hold its RCCL nodes too)", c->users);
     ncclResult_t r = ncclSuccess;
     if (c->owned && c->comm) r = ncclCommDestroy(c->comm);
     delete c;
     if (r != ncclSuccess) return fail(WX_ERR_COMM, "ncclCommDestroy failed: %s", ncclGetErrorString(r));
     return WX_OK;
+}
+
+int wx_comm_users(const wx_comm* c) { return c ? c->users : -1; }
+
+// solvers/global_operations.py:14-36, kiops.py:165-200, pmex.py:150-173, fgmres.py:41, simulation.py:399-408: the small
+// reductions of the Krylov callers, in place, on the caller's stream (a graph node under capture: origin stream)
+wx_status wx_comm_allreduce(wx_comm* c, double* buf, size_t count, wx_reduce_op op, wx_stream stream) {
+    if (!c || !c->comm) return fail(WX_ERR_INVALID, "wx_comm_allreduce: null communicator");
+    if (count == 0) return WX_OK;
+    if (!buf) return fail(WX_ERR_INVALID, "wx_comm_allreduce: null buffer");
+    ncclRedOp_t o;
+    switch (op) {
+        case WX_REDUCE_SUM: o = ncclSum; break;
+        case WX_REDUCE_MAX: o = ncclMax; break;
+        case WX_REDUCE_MIN: o = ncclMin; break;
+        default: return fail(WX_ERR_INVALID, "wx_comm_allreduce: unknown reduction %d", (int)op);
+    }
+    WX_STREAM(st, stream);
+    WX_NCCL_TRY(ncclAllReduce(buf, buf, count, ncclDouble, o, c->comm, st));
+    return WX_OK;
+}
+
+int wx_hip_runtime_version(void) {
+    int v = 0;
+    if (hipRuntimeGetVersion(&v) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return v;
+}
+
+int wx_hip_driver_version(void) {
+    int v = 0;
+    if (hipDriverGetVersion(&v) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return v;
 }
 
 wx_status wx_exchange_create(wx_exchange** out, wx_comm* comm, int rank, int world, int tiles_per_side, size_t edge_doubles,
@@ -193,6 +233,7 @@ wx_status wx_exchange_create(wx_exchange** out, wx_comm* comm, int rank, int wor
         st = fail(WX_ERR_NOMEM, "wx_exchange_create: out of host memory");
     }
     if (st != WX_OK) { delete ex; return st; }
+    if (comm) ++comm->users;
     *out = ex;
     return WX_OK;
 }
@@ -206,6 +247,7 @@ wx_status wx_exchange_destroy(wx_exchange* ex) {
         if (ex->send_buf) (void)hipFree(ex->send_buf);
         if (ex->recv_buf) (void)hipFree(ex->recv_buf);
     }
+    if (ex->comm && ex->comm->users > 0) --ex->comm->users;
     delete ex;
     if (e != hipSuccess) return fail(WX_ERR_HIP, "hipEventDestroy failed: %s", hipGetErrorString(e));
     return WX_OK;
@@ -295,6 +337,23 @@ wx_status wx_exchange_start(wx_exchange* ex, wx_stream compute, wx_stream comm_s
     WX_STREAM(cs, compute);
     hipStream_t ms = static_cast<hipStream_t>(comm_stream);
     const bool forked = ms != nullptr && ms != cs;
+    if (forked) {
+        // RCCL on a NON-origin stream of a capture: hip::Stream::EndCapture of HIP runtimes before 7.2 (the 7.0.2 inside
+        // torch 2.10 wheels) then recurses over a cycle of parallel-capture lists until the stack is gone - a SIGSEGV at
+        // hipStreamEndCapture, no error code (profiles/r04_capture_crash.md).  Refused here, where it can still be said.
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        WX_HIP_TRY(hipStreamIsCapturing(cs, &cap));
+        if (cap != hipStreamCaptureStatusNone) {
+            int ver = 0;
+            WX_HIP_TRY(hipRuntimeGetVersion(&ver));
+            if (ver < kForkedCaptureMinRuntime)
+                return fail(WX_ERR_INVALID, "wx_exchange_start: `compute` is being captured and the exchange is forked to another "
+                            "stream; the HIP runtime this process bound (%d) ends such a capture with a stack overflow in "
+                            "hip::Stream::EndCapture (fixed in 7.2 = %d).  Capture the exchange on the capture's origin stream: "
+                            "wx_exchange_start(ex, compute, compute) with the INTERIOR launches forked instead "
+                            "(wx_exchange_fork / _join, wx_*_rhs_overlapped)", ver, kForkedCaptureMinRuntime);
+        }
+    }
     if (forked) {   // the messages were packed on the compute stream: the communication stream starts behind them
         if (!ex->fork || !ex->join) WX_HIP_TRY(make_events(ex));
         WX_HIP_TRY(hipEventRecord(ex->fork, cs));
@@ -354,112 +413,114 @@ wx_status wx_exchange_set_timer(wx_exchange* ex, wx_phase_timer* timer) {
     return WX_OK;
 }
 
-#define WX_STAMP_SLOT(slot)                                                                     \
-    do {                                                                                        \
-        if (ex->timer && (st = wx_phase_timer_stamp(ex->timer, slot, compute)) != WX_OK) return st; \
-    } while (0)
+}  // extern "C" (the shared body of the two *_rhs_overlapped entry points is a template)
+
+namespace {
 
 // The evaluation of a rank's tiles with the exchange in flight beside the interior elements (rhs/rhs.py:88-118 with
 // process_topology.py:269-386, 564-606 in between): pack on `compute`; fork `side` off it for the INTERIOR launches; the
 // grouped sends / receives and then the BOUNDARY launches on `compute`; join.  One launch for ALL elements of each tile when
 // nothing travels; side == NULL or == compute: everything in stream order on `compute`.
-wx_status wx_euler3d_rhs_overlapped(wx_euler3d_plan* const plans[], int count, wx_exchange* ex, const void* const q[],
-                                    void* const rhs[], wx_stream compute, wx_stream side) {
-    if (!plans || !ex || !q || !rhs) return fail(WX_ERR_INVALID, "wx_euler3d_rhs_overlapped: null argument");
-    if (count != (int)ex->local.size())
-        return fail(WX_ERR_INVALID, "wx_euler3d_rhs_overlapped: %d plans for the %d tiles of this rank", count, (int)ex->local.size());
-    if (!ex->bound) return fail(WX_ERR_INVALID, "wx_euler3d_rhs_overlapped: call wx_exchange_bind first");
-    for (int i = 0; i < count; ++i) {
-        if (!plans[i] || !q[i] || !rhs[i]) return fail(WX_ERR_INVALID, "wx_euler3d_rhs_overlapped: null entry %d", i);
-        const size_t words = wx_euler3d_edge_count(plans[i]) * (wx_euler3d_plan_dtype(plans[i]) == WX_F64 ? 1 : 2);
-        if (words != ex->ec)
-            return fail(WX_ERR_INVALID, "wx_euler3d_rhs_overlapped: plan %d packs %zu doubles per edge, the exchange moves %zu", i, words, ex->ec);
-    }
+// pack(plan, q, send[4], stream), eval(plan, q, halo[4] | nullptr, rhs, region, stream): the Euler or shallow-water calls.
+template <typename Plan, typename Pack, typename Eval>
+wx_status overlapped_body(Plan* const plans[], int count, wx_exchange* ex, const void* const q[], void* const rhs[],
+                          wx_stream compute, wx_stream side, bool& forked_open, Pack pack, Eval eval) {
     wx_status st;
-    WX_STAMP_SLOT(0);
+    auto stamp = [&](int slot, wx_stream s) -> wx_status {
+        return ex->timer ? wx_phase_timer_stamp(ex->timer, slot, s) : WX_OK;
+    };
+    if ((st = stamp(0, compute)) != WX_OK) return st;
     for (int i = 0; i < count; ++i) {
         void* send[4];
         for (int e = 0; e < 4; ++e) send[e] = wx_exchange_send_ptr(ex, ex->local[i], e);
-        if ((st = wx_euler3d_extrap_pack(plans[i], q[i], send, compute)) != WX_OK) return st;
+        if ((st = pack(plans[i], q[i], send, compute)) != WX_OK) return st;
     }
-    WX_STAMP_SLOT(1);
+    if ((st = stamp(1, compute)) != WX_OK) return st;
     const bool split = needs_comm(ex);
     // the second stream takes the INTERIOR launches; the exchange stays on `compute` (see the header: on the HIP runtime
     // that ships inside torch 2.10 a capture survives RCCL launches only on its origin stream)
     const bool forked = split && side != nullptr && side != compute;
-    wx_stream interior_stream = forked ? side : compute;
-    if (forked && (st = wx_exchange_fork(ex, compute, side)) != WX_OK) return st;
     if (forked) {   // INTERIOR first: enqueued before the exchange occupies the host thread; stamps 2, 3 bracket it on ITS stream
-        if (ex->timer && (st = wx_phase_timer_stamp(ex->timer, 2, side)) != WX_OK) return st;
+        if ((st = wx_exchange_fork(ex, compute, side)) != WX_OK) return st;
+        forked_open = true;   // from here on an error return must still join `side` (the caller of this body does)
+        if ((st = stamp(2, side)) != WX_OK) return st;
         for (int i = 0; i < count; ++i)
-            if ((st = wx_euler3d_rhs(plans[i], q[i], nullptr, rhs[i], WX_REGION_INTERIOR, interior_stream)) != WX_OK) return st;
-        if (ex->timer && (st = wx_phase_timer_stamp(ex->timer, 3, side)) != WX_OK) return st;
+            if ((st = eval(plans[i], q[i], nullptr, rhs[i], WX_REGION_INTERIOR, side)) != WX_OK) return st;
+        if ((st = stamp(3, side)) != WX_OK) return st;
     }
     if ((st = wx_exchange_start(ex, compute, compute)) != WX_OK) return st;
     if (!forked) {
-        WX_STAMP_SLOT(2);
+        if ((st = stamp(2, compute)) != WX_OK) return st;
         if (split)
             for (int i = 0; i < count; ++i)
-                if ((st = wx_euler3d_rhs(plans[i], q[i], nullptr, rhs[i], WX_REGION_INTERIOR, compute)) != WX_OK) return st;
-        WX_STAMP_SLOT(3);
+                if ((st = eval(plans[i], q[i], nullptr, rhs[i], WX_REGION_INTERIOR, compute)) != WX_OK) return st;
+        if ((st = stamp(3, compute)) != WX_OK) return st;
     }
-    WX_STAMP_SLOT(5);   // the halos are there (in stream order on `compute`)
+    if ((st = stamp(5, compute)) != WX_OK) return st;   // the halos are there (in stream order on `compute`)
     for (int i = 0; i < count; ++i) {
         const void* halo[4];
         for (int e = 0; e < 4; ++e) halo[e] = wx_exchange_halo_ptr(ex, ex->local[i], e);
-        if ((st = wx_euler3d_rhs(plans[i], q[i], halo, rhs[i], split ? WX_REGION_BOUNDARY : WX_REGION_ALL, compute)) != WX_OK) return st;
+        if ((st = eval(plans[i], q[i], halo, rhs[i], split ? WX_REGION_BOUNDARY : WX_REGION_ALL, compute)) != WX_OK) return st;
     }
-    if (forked && (st = wx_exchange_join(ex, compute, side)) != WX_OK) return st;
-    WX_STAMP_SLOT(8);
-    return WX_OK;
+    if (forked) {
+        forked_open = false;
+        if ((st = wx_exchange_join(ex, compute, side)) != WX_OK) return st;
+    }
+    return stamp(8, compute);
+}
+
+template <typename Plan, typename Pack, typename Eval, typename Words>
+wx_status rhs_overlapped(const char* who, Plan* const plans[], int count, wx_exchange* ex, const void* const q[],
+                         void* const rhs[], wx_stream compute, wx_stream side, Pack pack, Eval eval, Words words_of) {
+    if (!plans || !ex || !q || !rhs) return fail(WX_ERR_INVALID, "%s: null argument", who);
+    if (count != (int)ex->local.size())
+        return fail(WX_ERR_INVALID, "%s: %d plans for the %d tiles of this rank", who, count, (int)ex->local.size());
+    if (!ex->bound) return fail(WX_ERR_INVALID, "%s: call wx_exchange_bind first", who);
+    for (int i = 0; i < count; ++i) {
+        if (!plans[i] || !q[i] || !rhs[i]) return fail(WX_ERR_INVALID, "%s: null entry %d", who, i);
+        const size_t words = words_of(plans[i]);   // a mismatch would let the pack kernels write past their send slots
+        if (words != ex->ec)
+            return fail(WX_ERR_INVALID, "%s: plan %d packs %zu doubles per edge, the exchange moves %zu", who, i, words, ex->ec);
+    }
+    bool forked_open = false;
+    const wx_status st = overlapped_body(plans, count, ex, q, rhs, compute, side, forked_open, pack, eval);
+    if (st != WX_OK) {
+        // leave the object usable and the streams joined: `side` rejoins `compute` (a capture of `compute` could not end
+        // with a forked stream still open), no exchange is left marked in flight; the FIRST error is the one reported
+        char first[512];
+        snprintf(first, sizeof first, "%s", wx_last_error());
+        if (forked_open) (void)wx_exchange_join(ex, compute, side);
+        ex->pending = false;
+        snprintf(last_error_buf(), 512, "%s", first);
+    }
+    return st;
+}
+
+}  // namespace
+
+extern "C" {
+
+wx_status wx_euler3d_rhs_overlapped(wx_euler3d_plan* const plans[], int count, wx_exchange* ex, const void* const q[],
+                                    void* const rhs[], wx_stream compute, wx_stream side) {
+    return rhs_overlapped(
+        "wx_euler3d_rhs_overlapped", plans, count, ex, q, rhs, compute, side,
+        [](wx_euler3d_plan* pl, const void* qq, void* const send[4], wx_stream s) { return wx_euler3d_extrap_pack(pl, qq, send, s); },
+        [](wx_euler3d_plan* pl, const void* qq, const void* const halo[4], void* r, wx_region reg, wx_stream s) {
+            return wx_euler3d_rhs(pl, qq, halo, r, reg, s);
+        },
+        [](const wx_euler3d_plan* pl) { return wx_euler3d_edge_count(pl) * (wx_euler3d_plan_dtype(pl) == WX_F64 ? 1 : 2); });
 }
 
 // the shallow-water twin (rhs/rhs_sw.py:76-150)
 wx_status wx_sw_rhs_overlapped(wx_sw_plan* const plans[], int count, wx_exchange* ex, const void* const q[], void* const rhs[],
                                wx_stream compute, wx_stream side) {
-    if (!plans || !ex || !q || !rhs) return fail(WX_ERR_INVALID, "wx_sw_rhs_overlapped: null argument");
-    if (count != (int)ex->local.size())
-        return fail(WX_ERR_INVALID, "wx_sw_rhs_overlapped: %d plans for the %d tiles of this rank", count, (int)ex->local.size());
-    if (!ex->bound) return fail(WX_ERR_INVALID, "wx_sw_rhs_overlapped: call wx_exchange_bind first");
-    for (int i = 0; i < count; ++i)
-        if (!plans[i] || !q[i] || !rhs[i]) return fail(WX_ERR_INVALID, "wx_sw_rhs_overlapped: null entry %d", i);
-    wx_status st;
-    WX_STAMP_SLOT(0);
-    for (int i = 0; i < count; ++i) {
-        void* send[4];
-        for (int e = 0; e < 4; ++e) send[e] = wx_exchange_send_ptr(ex, ex->local[i], e);
-        if ((st = wx_sw_extrap_pack(plans[i], q[i], send, compute)) != WX_OK) return st;
-    }
-    WX_STAMP_SLOT(1);
-    const bool split = needs_comm(ex);
-    // the second stream takes the INTERIOR launches; the exchange stays on `compute` (see the header: on the HIP runtime
-    // that ships inside torch 2.10 a capture survives RCCL launches only on its origin stream)
-    const bool forked = split && side != nullptr && side != compute;
-    wx_stream interior_stream = forked ? side : compute;
-    if (forked && (st = wx_exchange_fork(ex, compute, side)) != WX_OK) return st;
-    if (forked) {   // INTERIOR first: enqueued before the exchange occupies the host thread; stamps 2, 3 bracket it on ITS stream
-        if (ex->timer && (st = wx_phase_timer_stamp(ex->timer, 2, side)) != WX_OK) return st;
-        for (int i = 0; i < count; ++i)
-            if ((st = wx_sw_rhs(plans[i], q[i], nullptr, rhs[i], WX_REGION_INTERIOR, interior_stream)) != WX_OK) return st;
-        if (ex->timer && (st = wx_phase_timer_stamp(ex->timer, 3, side)) != WX_OK) return st;
-    }
-    if ((st = wx_exchange_start(ex, compute, compute)) != WX_OK) return st;
-    if (!forked) {
-        WX_STAMP_SLOT(2);
-        if (split)
-            for (int i = 0; i < count; ++i)
-                if ((st = wx_sw_rhs(plans[i], q[i], nullptr, rhs[i], WX_REGION_INTERIOR, compute)) != WX_OK) return st;
-        WX_STAMP_SLOT(3);
-    }
-    WX_STAMP_SLOT(5);   // the halos are there (in stream order on `compute`)
-    for (int i = 0; i < count; ++i) {
-        const void* halo[4];
-        for (int e = 0; e < 4; ++e) halo[e] = wx_exchange_halo_ptr(ex, ex->local[i], e);
-        if ((st = wx_sw_rhs(plans[i], q[i], halo, rhs[i], split ? WX_REGION_BOUNDARY : WX_REGION_ALL, compute)) != WX_OK) return st;
-    }
-    if (forked && (st = wx_exchange_join(ex, compute, side)) != WX_OK) return st;
-    WX_STAMP_SLOT(8);
-    return WX_OK;
+    return rhs_overlapped(
+        "wx_sw_rhs_overlapped", plans, count, ex, q, rhs, compute, side,
+        [](wx_sw_plan* pl, const void* qq, void* const send[4], wx_stream s) { return wx_sw_extrap_pack(pl, qq, send, s); },
+        [](wx_sw_plan* pl, const void* qq, const void* const halo[4], void* r, wx_region reg, wx_stream s) {
+            return wx_sw_rhs(pl, qq, halo, r, reg, s);
+        },
+        [](const wx_sw_plan* pl) { return wx_sw_edge_count(pl) * (wx_sw_plan_dtype(pl) == WX_F64 ? 1 : 2); });
 }
 
 }  // extern "C"

@@ -809,6 +809,7 @@ wx_status wx_sw_plan_destroy(wx_sw_plan* pl) {
 }
 
 size_t wx_sw_edge_count(const wx_sw_plan* pl) { return pl ? (size_t)3 * pl->H * pl->n : 0; }
+wx_dtype wx_sw_plan_dtype(const wx_sw_plan* pl) { return pl ? pl->dtype : WX_F64; }
 
 wx_status wx_sw_extrap_pack(wx_sw_plan* pl, const void* q, void* const send[4], wx_stream stream) {
     if (!pl || !q) return fail(WX_ERR_INVALID, "wx_sw_extrap_pack: null argument");

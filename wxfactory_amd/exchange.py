@@ -5,26 +5,20 @@ start_exchange_vectors / ExchangeRequest.wait): there, three Ineighbor_alltoall 
 RHS carry (rho), (rho u1, rho u2, rho w), (rho theta); here ONE message per panel edge carries
 all five variables, already rotated and flipped by the pack kernel (wx_euler3d_extrap_pack).
 
-* neighbours on the same rank: zero copy - the receiver's halo pointer aliases the sender's
-  send slot;
-* neighbours on other ranks: one torch.distributed.all_to_all_single (RCCL grouped
-  send/recv over xGMI on GPUs, gloo on CPU) issued asynchronously so the interior elements
-  are computed while it is in flight;
-* `inline` mode (HIP-graph capture, BASELINE config 5): the same collective enqueued in stream order with no
-  work handle kept - between the pack and the evaluation launches - on buffers that never move, so that a
-  whole Krylov matvec (tangent extrapolation -> exchange -> JVP kernels) records into ONE graph.
-* backend "rccl": the library's own exchange behind the C ABI (csrc/exchange.hip, wx_exchange_* of include/wxhip.h:
-  grouped ncclSend / ncclRecv on a communicator made by wx_comm_init_rank) over the same two buffers, with no
-  torch.distributed call on the data path.  Overlap there = the exchange on the compute stream and the INTERIOR
-  launches forked to a second stream (PanelRhs._phases), which also records into a HIP graph.
-
-Why torch's async collective cannot be captured on this stack (profiles/r04_capture_crash.md): the HIP 7.0.2 runtime
-inside the torch wheel lets a non-origin stream that waits on a captured event join the capture AGAIN, RCCL forks /
-joins an internal stream around every launch, and ProcessGroupNCCL launches async work on an internal (non-origin)
-stream - the two streams end up in each other's parallel-capture lists and hip::Stream::EndCapture recurses until the
-stack is gone.  RCCL launched on the capture's origin stream (the inline form, and backend "rccl") records.
+* neighbours on the same rank: zero copy - the receiver's halo pointer aliases the sender's send slot;
+* backend "rccl" - THE data path over several GPUs: the library's own exchange behind the C ABI (csrc/exchange.hip,
+  wx_exchange_* of include/wxhip.h: grouped ncclSend / ncclRecv on a communicator made by wx_comm_init_rank, RcclComm
+  below) with no torch.distributed call.  Overlap = the exchange on the compute stream and the INTERIOR launches forked
+  to a second stream (PanelRhs._phases); that shape also records into a HIP graph (RCCL on the capture's origin stream).
+  The callers' small reductions run on the same communicator (RcclComm.allreduce, reduce.py);
+* backend "torch" - host logic and checks: torch.distributed.all_to_all_single on a gloo group, for CPU buffers (the
+  world_size > 1 tests that pin the slot layout against the halos the reference delivered) or, staged through host
+  copies, for device buffers (the independent route bench.py checks the library's exchange against).  Device buffers on a
+  torch NCCL group are refused: no NCCL process group exists anywhere in this package's processes
+  (profiles/r05_process_group_abort.md, profiles/r04_capture_crash.md).
 """
 import ctypes
+import weakref
 from typing import Dict, List, Tuple
 
 import torch
@@ -33,13 +27,38 @@ import torch.distributed as dist
 from .panels import CubeTopology, owner_of_tiles
 
 
+_REDUCE_OPS = {"sum": 0, "max": 1, "min": 2}   # wx_reduce_op
+
+
+def share_comm_id(ident: bytes, rank: int, world_size: int, group=None, store=None, key: str = "wx_comm_id") -> bytes:
+    """Rank 0's communicator id on every rank - the only thing the library's communicator needs from the outside
+    (the reference gets its communicator from MPI, process_topology.py:259-261).  Through `store` (a torch.distributed
+    Store, e.g. TCPStore: no process group at all) or through `group` (any torch.distributed group - gloo; None = the
+    default group).  One rank: returned as is."""
+    if world_size <= 1:
+        return ident
+    if store is not None:
+        if rank == 0:
+            store.set(key, ident)
+        return bytes(store.get(key))   # (get blocks until the key is there)
+    box = [ident]
+    dist.broadcast_object_list(box, src=0, group=group)
+    return bytes(box[0])
+
+
 class RcclComm:
     """An RCCL communicator of this library's own (wx_comm_unique_id / wx_comm_init_rank, include/wxhip.h): the halo
-    exchange of backend "rccl" runs on it through the C ABI, with no torch.distributed call on the data path.  The 128-byte
-    unique id travels from rank 0 to the others through `group` (any torch.distributed backend; not needed on one rank).
+    exchange of backend "rccl" AND the small reductions of the Krylov callers (allreduce below) run on it through the C
+    ABI, with no torch.distributed call on the data path - the one communicator the reference builds from MPI
+    (process_topology.py:259-261, solvers/global_operations.py:14-36).
+
+    Bootstrap: only the 128-byte unique id has to travel from rank 0 to the others, once.  Give either `group` - any
+    torch.distributed group, normally gloo: NO NCCL process group is needed or wanted (its watchdog thread issues HIP event
+    calls beside this process's graph captures, profiles/r05_process_group_abort.md) - or `store` - a torch.distributed
+    Store such as TCPStore, for processes that have no process group at all; one rank needs neither.
     Collective; the calling process must have its GPU current (torch.cuda.set_device)."""
 
-    def __init__(self, rank: int = 0, world_size: int = 1, group=None, device=None):
+    def __init__(self, rank: int = 0, world_size: int = 1, group=None, device=None, store=None, key: str = "wx_comm_id"):
         from . import _lib
 
         self.lib = _lib.load()
@@ -47,24 +66,70 @@ class RcclComm:
         ident = (ctypes.c_ubyte * _lib.WX_COMM_ID_BYTES)()
         if rank == 0:
             _lib.check(self.lib.wx_comm_unique_id(ident), "wx_comm_unique_id")
-        if world_size > 1:
-            box = [bytes(ident)]
-            dist.broadcast_object_list(box, src=0, group=group)
-            ident = (ctypes.c_ubyte * _lib.WX_COMM_ID_BYTES)(*box[0])
+        ident = (ctypes.c_ubyte * _lib.WX_COMM_ID_BYTES)(*share_comm_id(bytes(ident), rank, world_size, group, store, key))
         self._h = ctypes.c_void_p()
         dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         with torch.cuda.device(dev):
             _lib.check(self.lib.wx_comm_init_rank(ctypes.byref(self._h), world_size, ident, rank), "wx_comm_init_rank")
         self.device = dev
+        # what lives on this communicator and has to go before it: exchanges (they keep the wx_comm*), and HIP graphs that
+        # hold RCCL nodes (ncclCommDestroy under such a graph does not return, profiles/r04_capture_crash.md)
+        self.always = False   # tests: issue the reductions on one rank too (reduce.allreduce skips them otherwise)
+        self._exchanges = weakref.WeakSet()
+        self._graphs = weakref.WeakSet()
 
     @property
     def version(self) -> int:
         return int(self.lib.wx_comm_rccl_version())
 
+    @property
+    def hip_runtime_version(self) -> int:
+        """The HIP runtime this process bound (inside torch: the wheel's, not the one libwxhip.so was compiled with)."""
+        return int(self.lib.wx_hip_runtime_version())
+
+    def allreduce(self, t: torch.Tensor, op: str = "sum") -> torch.Tensor:
+        """In-place all-reduce of a device tensor on torch's current stream (ncclAllReduce behind wx_comm_allreduce): a node
+        of the graph when that stream is being captured.  float64 tensors are reduced where they are; anything else
+        (an int32 NaN flag, an int64 length) goes through a float64 copy - exact for integers below 2^53."""
+        from . import _lib
+
+        if not t.is_cuda:
+            raise ValueError("RcclComm.allreduce reduces device tensors")
+        if t.numel() == 0:
+            return t
+        st = torch.cuda.current_stream(t.device).cuda_stream
+        if t.dtype == torch.float64 and t.is_contiguous():
+            _lib.check(self.lib.wx_comm_allreduce(self._h, t.data_ptr(), t.numel(), _REDUCE_OPS[op], st), "wx_comm_allreduce")
+            return t
+        if t.dtype.is_complex:
+            if op != "sum":
+                raise ValueError("complex tensors can only be summed")
+            buf = torch.view_as_real(t.contiguous()).contiguous()
+        else:
+            buf = t.to(torch.float64).contiguous()
+        _lib.check(self.lib.wx_comm_allreduce(self._h, buf.data_ptr(), buf.numel(), _REDUCE_OPS[op], st), "wx_comm_allreduce")
+        t.copy_(torch.view_as_complex(buf).reshape(t.shape) if t.dtype.is_complex else buf.reshape(t.shape).to(t.dtype))
+        return t
+
+    def register_graph(self, graph):
+        """A HIP graph that holds RCCL nodes of this communicator: close() resets it before the communicator goes."""
+        self._graphs.add(graph)
+
     def close(self):
-        if self._h:
-            self.lib.wx_comm_destroy(self._h)
-            self._h = ctypes.c_void_p()
+        """Graphs with RCCL nodes first, then the exchanges, then the communicator (wx_comm_destroy refuses otherwise)."""
+        if not self._h:
+            return
+        for g in list(self._graphs):
+            try:
+                g.reset()
+            except Exception:   # noqa: BLE001 - a graph that is gone already
+                pass
+        for ex in list(self._exchanges):
+            ex.close()
+        from . import _lib
+
+        h, self._h = self._h, ctypes.c_void_p()
+        _lib.check(self.lib.wx_comm_destroy(h), "wx_comm_destroy")
 
     def __del__(self):
         try:
@@ -164,6 +229,8 @@ class PanelExchange:
         _lib.check(self.lib.wx_exchange_create(ctypes.byref(h), comm._h if comm is not None else None, self.rank, self.world,
                                                k, self.edge_count, int(self.loopback)), "wx_exchange_create")
         self._native = h
+        if comm is not None:
+            comm._exchanges.add(self)   # (RcclComm.close() closes us first: the library keeps the wx_comm* in the exchange)
         if self.send_buf.numel() != self.lib.wx_exchange_send_doubles(h) or self.recv_buf.numel() != self.lib.wx_exchange_recv_doubles(h):
             raise RuntimeError("the library's edge-buffer sizes differ from the host mirror's")
         _lib.check(self.lib.wx_exchange_bind(h, self.send_buf.data_ptr() if self.send_buf.numel() else None,
@@ -253,6 +320,25 @@ class PanelExchange:
         ec = self.edge_count
         send = self.send_buf[: self.n_remote_out * ec]
         recv = self.recv_buf[: self.n_remote_in * ec]
+        if send.is_cuda and dist.get_backend(self.group) != "gloo":
+            # (a torch NCCL process group brings a watchdog thread that issues HIP event calls beside this process's graph
+            # captures - an intermittent SIGABRT in round 4, profiles/r05_process_group_abort.md - and an internal stream
+            # that the bundled HIP runtime cannot capture; the library's own communicator has neither)
+            raise RuntimeError("device buffers travel on the library's own communicator: PanelExchange(backend='rccl', "
+                               "comm=RcclComm(...)); a torch.distributed NCCL group is not used on the data path")
+        if send.is_cuda:
+            # device buffers and a host-only process group: staged through host copies, synchronously.  NOT a data path -
+            # it is the independent second route bench.py checks the library's exchange against before it times anything
+            # (the gloo route is the one tests/test_exchange_gloo.py pins against the halos the reference delivered), with
+            # no NCCL process group in the process.
+            if self.is_inline:
+                raise RuntimeError("the host-staged exchange cannot be captured; use backend='rccl'")
+            send_h, recv_h = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_to_all_single(recv_h, send_h, output_split_sizes=self.recv_splits, input_split_sizes=self.send_splits,
+                                   group=self.group)
+            recv.copy_(recv_h)
+            self._work = None
+            return
         inline = self.is_inline
         work = dist.all_to_all_single(
             recv, send, output_split_sizes=self.recv_splits, input_split_sizes=self.send_splits,

@@ -54,12 +54,11 @@ class NanFlag:
         check(_lib.load().wx_check_nan(Q.data_ptr(), Q.numel(), _DT[Q.dtype], self.ptr(), st), "wx_check_nan")
 
     def raise_if_set(self):
-        import torch.distributed as dist
+        """simulation.py:399-408: Allreduce MAX of the flag over `group` (a torch.distributed group, or the library's
+        communicator - reduce.py), then ValueError("NaN") on every rank."""
+        from . import reduce as _reduce
 
-        flag = self.flag
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
-        bad = int(flag.item())
+        bad = int(_reduce.allreduce(self.flag, self.group, "max").item())
         self.flag.zero_()
         if bad > 0:
             raise ValueError("NaN")

@@ -9,6 +9,7 @@ from typing import Callable
 
 import torch
 
+from . import reduce as _reduce
 from .matvec import ComplexStepOperator, MatvecOpRat
 from .solvers import fgmres
 
@@ -57,8 +58,11 @@ class Tvdrk3:
 
 class Ros2:
     def __init__(self, rhs_handle: Callable, tol: float = 1e-7, gmres_restart: int = 20, verbose: int = 0,
-                 ortho: str = "igs"):
+                 ortho: str = "igs", group=None):
         self.rhs_handle, self.tol, self.gmres_restart, self.verbose = rhs_handle, tol, gmres_restart, verbose
+        # who the solver's reductions run over (reduce.py): by default what the RHS object exchanges its halos on - the
+        # library's communicator (backend "rccl") or its torch.distributed group
+        self.group = group if group is not None else getattr(rhs_handle, "reduce_group", None)
         self.ortho = ortho   # fgmres orthogonalisation: "igs" = the reference's one-synchronisation variant, "cgs"
         self.solver_info = None
         self.failure_flag = 0
@@ -71,7 +75,7 @@ class Ros2:
         t0 = time()
         Qnew, norm_r, norm_b, num_iter, flag, residuals = fgmres(
             A, b, x0=Q_flat, tol=self.tol, restart=self.gmres_restart, maxiter=20000 // self.gmres_restart,
-            verbose=self.verbose, ortho=self.ortho)
+            verbose=self.verbose, ortho=self.ortho, group=self.group)
         self.solver_info = dict(flag=flag, time=time() - t0, iterations=num_iter, residuals=residuals,
                                 rel_residual=norm_r / norm_b)
         self.failure_flag = flag
@@ -93,8 +97,11 @@ class Epi:
     }
 
     def __init__(self, order: int, rhs: Callable, tol: float = 1e-7, jacobian_method: str = "complex",
-                 init_substeps: int = 1, init_method=None, exponential_solver: str = "kiops"):
+                 init_substeps: int = 1, init_method=None, exponential_solver: str = "kiops", group=None):
         from collections import deque
+
+        # who the solver's reductions run over (reduce.py): by default what the RHS object exchanges its halos on
+        self.group = group if group is not None else getattr(rhs, "reduce_group", None)
 
         if exponential_solver not in ("kiops", "pmex"):   # (the two the shipped configurations name, epi.py:314-348)
             raise ValueError(f"Unrecognized exponential solver {exponential_solver}")
@@ -110,6 +117,7 @@ class Epi:
         # more often than replayed, and with a Krylov vector built from ONE host call (wx_euler3d_batch_kiops_vector) the
         # eager pass is GPU-bound already (tools/kiopsgraph.py).
         self.graph_passes = False
+        self._force_split = False   # tests: the several-rank code paths of the phi solvers on one rank
         self._static = None
         self._ws = None
         self.krylov_size = 1
@@ -162,7 +170,8 @@ class Epi:
             from .solvers import pmex
 
             phiv, stats = pmex([1.0], ComplexStepOperator(dt, Q, rhs, self.rhs, self.jacobian_method), vec, tol=self.tol,
-                               mmax=64, task1=False, restart_powers=self.restart_powers)
+                               mmax=64, task1=False, restart_powers=self.restart_powers, group=self.group,
+                               _force_split=self._force_split)
             self.solver_info = dict(substeps=stats[0], rejected=stats[1], iterations=stats[2], exps=stats[3],
                                     error=stats[4], krylov_size=stats[5], own_norms=stats[6])
             return phiv
@@ -176,7 +185,7 @@ class Epi:
                 self._ws = KiopsWorkspace()   # basis, Hessenberg columns and scratch survive from step to step
             ws = self._ws
             if self.graph_passes and bool(getattr(self.rhs, "_small_tiles", lambda: False)()) \
-                    and getattr(self.rhs, "world", 1) == 1:
+                    and (getattr(self.rhs, "world", 1) == 1 or _reduce.capturable(self.group)):
                 # replay whole Krylov passes as HIP graphs: the matvec then has to read the linearisation state from
                 # fixed addresses (static copies of Q and R(Q)); a pass is re-captured whenever (j0, m) is new
                 if self._static is None or self._static[0].shape != Q.shape:
@@ -187,7 +196,8 @@ class Epi:
                 token = (Qm.data_ptr(), Rm.data_ptr(), float(dt), self.jacobian_method)
         phiv, stats = kiops([1], ComplexStepOperator(dt, Qm, Rm, self.rhs, self.jacobian_method), vec,
                             tol=self.tol, m_init=self.krylov_size, mmin=16, mmax=64, task1=False, workspace=ws,
-                            graph_token=token, restart_powers=self.restart_powers)
+                            graph_token=token, restart_powers=self.restart_powers, group=self.group,
+                            _force_split=self._force_split)
         self.krylov_size = math.floor(0.7 * stats[5] + 0.3 * self.krylov_size)
         self.solver_info = dict(substeps=stats[0], rejected=stats[1], iterations=stats[2], exps=stats[3],
                                 error=stats[4], krylov_size=stats[5])

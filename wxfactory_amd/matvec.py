@@ -87,6 +87,11 @@ class ComplexStepOperator:
     def __init__(self, dt: float, Q: torch.Tensor, rhs: torch.Tensor, rhs_handle: Callable, method: str = "complex"):
         self.dt, self.Q, self.rhs, self.rhs_handle, self.method = dt, Q, rhs, rhs_handle, method
         self.kiops_vector = None
+        # EXACTLY linear in v: the dual-number kernels carry the tangent to first order, with no truncation term.  (A
+        # finite difference has one that is quadratic in v, and the true complex step one of order eps^2 |v|^2: a solver
+        # that feeds such an operator un-normalised vectors changes its results - solvers.kiops `lazy`.)
+        self.linear = bool(method == "complex" and getattr(rhs_handle, "supports_jvp", False)
+                           and getattr(rhs_handle, "fused_jvp", True))
         prep = getattr(rhs_handle, "jvp_prepare", None)
         if method == "complex" and prep is not None and getattr(rhs_handle, "fused_jvp", True) and isinstance(Q, torch.Tensor):
             prep(Q)   # every product of this operator linearises about Q: cache its face values once

@@ -47,6 +47,15 @@ class PanelRhs:
         self.edge_count = first.edge_count if first is not None else edge_count
         self.panel_shape = first.shape if first is not None else None
 
+    @property
+    def reduce_group(self):
+        """Who the callers' reductions run over (reduce.py): the library's communicator when the exchange is its own
+        (backend "rccl": halo exchange and reductions on ONE communicator, as the reference has it), else the
+        torch.distributed group of the exchange."""
+        first = next(iter(self._ex.values()), None)
+        comm = getattr(first, "comm", None) if first is not None and first.backend == "rccl" else None
+        return comm if comm is not None else self.group
+
     # -- per-dtype resources
     def plans_for(self, dtype):
         if dtype not in self._plans:

@@ -669,11 +669,10 @@ class RhsEuler3D(PanelRhs):
             big = math.prod(self.panel_shape) // 5 >= self.jvp_prepare_min_points if self.panel_shape is not None else False
             can = int((big or not self._small_tiles()) and Q.device.type == dev.type and Q.dtype == torch.float64 and Q.is_contiguous())
         if self.world > 1:   # one decision for all ranks: the value exchange below is collective
-            import torch.distributed as dist
+            from . import reduce as _reduce
 
             flag = torch.tensor([can], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-            can = int(flag.item())
+            can = int(_reduce.allreduce(flag, self.reduce_group, "min").item())
         if not can:
             self._jvp_lin = None
             return False

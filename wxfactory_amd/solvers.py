@@ -18,13 +18,12 @@ from time import time
 from typing import Callable, List, Optional, Tuple
 
 import torch
-import torch.distributed as dist
+
+from . import reduce as _reduce
 
 
 def _allreduce(t: torch.Tensor, group=None) -> torch.Tensor:
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    return t
+    return _reduce.allreduce(t, group, "sum")
 
 
 def global_dotprod(a: torch.Tensor, b: torch.Tensor, group=None) -> torch.Tensor:
@@ -39,9 +38,7 @@ def global_norm(a: torch.Tensor, group=None) -> torch.Tensor:
 
 def global_inf_norm(a: torch.Tensor, group=None) -> torch.Tensor:
     m = a.abs().max().reshape(1) if a.numel() else torch.zeros(1, dtype=a.real.dtype, device=a.device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
-    return m[0]
+    return _reduce.allreduce(m, group, "max")[0]
 
 
 def _basis_rows(rows: int, length: int, dtype, dev) -> torch.Tensor:
@@ -633,7 +630,7 @@ def _affordable_mmax(n: int, p: int, mmax: int, mmin: int, dev, dtype, group=Non
     dev = torch.device(dev)
     limit = mmax
     row_bytes = (n + p) * 8
-    several = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    several = _reduce.world_size(group) > 1
     # n is the RANK-LOCAL length: ranks own different numbers of tiles (an idle rank has n = 0), so "is my basis small" is
     # not a decision every rank takes alike - and the all-reduce below is collective.  Over several ranks every rank
     # enters it, a rank with a small basis contributing mmax; one rank alone skips the query for small bases.
@@ -649,8 +646,7 @@ def _affordable_mmax(n: int, p: int, mmax: int, mmin: int, dev, dtype, group=Non
         limit = int(min(mmax, rows - 1))
     if several:
         t = torch.tensor([limit], dtype=torch.int64, device=dev if dev.type == "cuda" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
-        limit = int(t.item())
+        limit = int(_reduce.allreduce(t, group, "min").item())
     if limit < mmax:
         if limit < max(mmin, 2):
             raise MemoryError(f"{what}: not even a Krylov basis of mmin = {mmin} vectors of {n + p} values fits in the free "
@@ -719,8 +715,9 @@ class KiopsWorkspace:
             self.graphs.clear()
             self.seen.clear()
 
-    def run_pass(self, j0: int, m: int, build, use_graphs: bool):
-        """build(j) enqueues the construction of vector j."""
+    def run_pass(self, j0: int, m: int, build, use_graphs: bool, comm=None):
+        """build(j) enqueues the construction of vector j.  comm: the library's communicator when the pass holds its
+        reductions / halo exchange (the graph is registered with it: RCCL nodes must go before their communicator)."""
         if not use_graphs:
             for j in range(j0 + 1, m + 1):
                 build(j)
@@ -745,6 +742,8 @@ class KiopsWorkspace:
                     build(j)
         torch.cuda.current_stream().wait_stream(side)
         self.graphs[key] = g
+        if comm is not None and hasattr(comm, "register_graph"):
+            comm.register_graph(g)
         self.captures += 1
         g.replay()   # (capture records, it does not execute)
         self.replays += 1
@@ -801,12 +800,14 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
     ws.request, ws.granted = request, mmax
     Vd, basis, Ht, nrm2 = ws.Vd, ws.basis, ws.Ht, ws.nrm2
     H = np.zeros((mmax + 1, mmax + 1))
-    split = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    split = _reduce.world_size(group) > 1
     if _force_split:
         split = True   # (tests: take the several-rank code paths - reductions completed after an all-reduce - on one rank)
-    # HIP graphs of whole passes: single rank (no collective inside), launch-bound sizes, an operator the caller vouches for
-    use_graphs = (workspace is not None and graph_token is not None and not split and Vd.is_cuda
-                  and n <= KiopsWorkspace.max_graph_points)
+    # HIP graphs of whole passes: launch-bound sizes, an operator the caller vouches for, and - over several ranks - the
+    # reductions on the library's own communicator (wx_comm_allreduce on the capture's origin stream: two graph nodes per
+    # Krylov vector, solvers/kiops.py:176-200; the matvec's halo exchange records the same way)
+    use_graphs = (workspace is not None and graph_token is not None and Vd.is_cuda and n <= KiopsWorkspace.max_graph_points
+                  and (not split or _reduce.capturable(group)))
     if workspace is not None:
         ws.set_token(graph_token)
     fused_finish = (basis.gpu and not split and n + p <= KiopsWorkspace.max_fused_len and p <= 16 and iop <= 4
@@ -817,7 +818,11 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
     long_build = (basis.gpu and not fused_finish and p <= 16 and iop <= 4 and os.environ.get("WXHIP_KIOPS_LONG", "1") != "0")
     # ... with LAZY normalisation: a basis row's n-long part is never rewritten for its norm (wx_kiops_long_*_scaled): the
     # scale 1 / |V[r]| sits in ws.scales and is applied where the row is used - 9 sweeps per Krylov vector instead of 11
-    lazy = long_build and os.environ.get("WXHIP_KIOPS_LAZY", "1") != "0"
+    # Lazy rows hand the operator the UN-normalised row V[j-1] and rescale the product: exact only for an operator that is
+    # linear in v and says so (matvec.ComplexStepOperator.linear: the dual-number kernels).  A finite-difference product has
+    # a truncation term quadratic in v, which |V[j-1]| = h_{j,j-1} >> 1 would amplify - the reference always applies A to
+    # unit vectors (solvers/kiops.py:170) - so every other operator takes the normalising path (wx_kiops_long_c).
+    lazy = long_build and bool(getattr(A, "linear", False)) and os.environ.get("WXHIP_KIOPS_LAZY", "1") != "0"
     row_scale = [1.0] * (mmax + 2)   # the host's copy of the scales (from the norms it reads with the Hessenberg columns)
     store_axpy = (getattr(A, "axpy_into", None)
                   if long_build and p == 1 and os.environ.get("WXHIP_KIOPS_STORE_AXPY", "1") != "0" else None)
@@ -926,7 +931,7 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
             Vd[j] /= hcol[j]
 
         if m > j:
-            ws.run_pass(j, m, build, use_graphs)
+            ws.run_pass(j, m, build, use_graphs, group if _reduce.is_comm(group) else None)
             j = m
         if j > j0:
             Hh = Ht[j0:j, : j + 1].cpu().numpy()  # the one synchronisation of the pass
@@ -1058,7 +1063,7 @@ def pmex(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, delta: float 
     if p == 0:
         p = 1
         u = torch.cat((u, torch.zeros((1, n), dtype=dtype, device=dev)))
-    split = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    split = _reduce.world_size(group) > 1
     if _force_split:
         split = True   # (tests: the several-rank code paths - reductions completed after an all-reduce - on one rank)
     mmax = _affordable_mmax(n, p, mmax, mmin, dev, dtype, group, "pmex")
