@@ -118,9 +118,14 @@ def cpu_baseline(n, V, seed, H=60):
     from oracle import c_port
 
     c_port.load()   # (re)build the C++ port for THIS host once, before six workers would each try to
-    cpp = cpu_baseline_run("cpp", n, H, V, 5, threads, seed)
+    # three repeats of the timed sample: `value` is their median, `range` their min-max (the figure swings with what else
+    # the host runs: 531-866 M between boxes in round 4)
+    runs = sorted((cpu_baseline_run("cpp", n, H, V, 5, threads, seed) for _ in range(3)), key=lambda r: r["dof_updates_per_s"])
+    cpp = runs[1]
     dense = cpu_baseline_run("dense", n, H, 1, 3, threads, seed)
     return {"value": cpp["dof_updates_per_s"], "unit": "DOF-updates/s", "cores": 6 * threads, "kind": "port",
+            "range": {"min": runs[0]["dof_updates_per_s"], "max": runs[-1]["dof_updates_per_s"], "repeats": len(runs),
+                      "value_is": "median"},
             "cpu_model": model, "physical_cores": phys, "logical_cpus": logical, "processes": 6,
             "threads_per_process": threads, "usable_cores": usable,
             "cpu_quota": {"cores": quota, "source": quota_src} if quota else None,
@@ -726,7 +731,8 @@ def main():
     # peer mapping fails with hipIpcGetMemHandle: invalid argument); ranks started by an external torchrun land here too
     if world > 1 or args.loopback:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("NCCL_DEBUG", "WARN")   # a communicator that cannot connect says why on stderr
+        os.environ.setdefault("NCCL_DEBUG", "WARN")   # a communicator that cannot connect says why ...
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")   # ... on stderr (RCCL's default is stdout: the ONE line's stream)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)

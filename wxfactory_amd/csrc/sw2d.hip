@@ -18,6 +18,19 @@
 namespace wx {
 
 constexpr int kMaxN2 = 8;
+// min waves per SIMD requested for the RHS kernels (an element is one wave at n = 8; the evaluation is short, a workgroup's
+// life is one memory round trip after the other: the more of them a CU holds, the more round trips overlap)
+#ifndef WX_SW_WAVES
+#define WX_SW_WAVES 1
+#endif
+constexpr int kSwWaves = WX_SW_WAVES;
+#ifndef WX_SW_LEAN
+#define WX_SW_LEAN 1       // 0: the round-4 schedule everywhere (A/B builds)
+#endif
+#ifndef WX_SW_LEAN_WAVES
+#define WX_SW_LEAN_WAVES 1
+#endif
+constexpr int kSwLeanWaves = WX_SW_LEAN_WAVES;
 
 template <int N>
 struct Cfg2 {
@@ -212,11 +225,17 @@ __device__ __forceinline__ void sw_extrap_body(const SwParams<T> P, const SwDyn<
 // what the extrapolation kernel + the RHS kernel do (the tile-edge lines alone are packed by a ring-only extrapolation
 // launch in front of the exchange): no 12 + 24 B/point round trip of the face values, one launch boundary less in a
 // 60 us evaluation.  Same arithmetic term by term (the face sums run in the extrapolation kernel's order).
-template <int N, typename T, bool PIPE = false, bool DIRECT = false>
+// LEAN (float64, one face pass, interface buffer): the same arithmetic, expression for expression, scheduled for REGISTERS
+// instead of for loads in flight per wave - the eight Christoffel fields are loaded behind the first directional pass instead
+// of with the state, and the compiler is fenced from hoisting them back - so that the kernel fits 64 registers and a CU
+// holds eight workgroups (32 elements) instead of four: the evaluation is a chain of memory round trips per workgroup,
+// and what hides them is other workgroups (107 registers: 16 elements per CU, 50 us at S7; see profiles/r05_sw_lean_ab.txt)
+template <int N, typename T, bool PIPE = false, bool DIRECT = false, bool LEAN = false>
 __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> D) {
     using C = Cfg2<N>;
     constexpr int N2 = C::N2, EPB = C::EPB, BS = C::BS;
     static_assert(!(PIPE && DIRECT), "the stage pipeline prepares an interface buffer: not for the direct form");
+    static_assert(!LEAN || (std::is_same<T, double>::value && !DIRECT && EPB * 4 * N <= BS), "the lean schedule: float64, one face pass");
     const SwSlot<T> S = sw_slot<T>(P, PIPE ? D.slot : 0);   // (the plain kernel reads slot 0: its schedule is untouched)
     __shared__ T fld[3][EPB * C::LE];
     __shared__ T fr[EPB][4][3][N];
@@ -267,7 +286,7 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
         size_t nstride = N;
         long nelem_nbr = -1;   // DIRECT: the neighbour element inside the tile (-1: the face lies on the tile edge)
         size_t o_own, o_nbr;  // slots in the halo-padded interface arrays (own side, neighbour side)
-        gp<const double> sgp, hddp, hodp, hsp;
+        gp<const double> sgp, hddp, hodp;
         if (d == 0) {
             const int ne = el.ei + (plus ? 1 : -1);
             if (ne >= 0 && ne < H) { nbr = S.itf + ((size_t)(el.e + (plus ? 1 : -1)) * 4 + (f ^ 1)) * 3 * N + k; nelem_nbr = el.e + (plus ? 1 : -1); }
@@ -275,14 +294,14 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
             const size_t row = (size_t)el.ej * (H + 2);
             o_own = (row + el.ei + 1) * 2 * N + plus * N + k;
             o_nbr = (row + el.ei + 1 + (plus ? 1 : -1)) * 2 * N + (1 - plus) * N + k;
-            sgp = P.sgi; hddp = P.h11i; hodp = P.h21i; hsp = P.hsi;
+            sgp = P.sgi; hddp = P.h11i; hodp = P.h21i;
         } else {
             const int ne = el.ej + (plus ? 1 : -1);
             if (ne >= 0 && ne < H) { nbr = S.itf + ((size_t)(el.e + (plus ? H : -H)) * 4 + (f ^ 1)) * 3 * N + k; nelem_nbr = el.e + (plus ? H : -H); }
             else { nbr = (plus ? S.halo_n : S.halo_s) + (size_t)el.ei * N + k; nstride = (size_t)H * N; }
             o_own = ((size_t)(el.ej + 1) * H + el.ei) * 2 * N + plus * N + k;
             o_nbr = ((size_t)(el.ej + 1 + (plus ? 1 : -1)) * H + el.ei) * 2 * N + (1 - plus) * N + k;
-            sgp = P.sgj; hddp = P.h22j; hodp = P.h12j; hsp = P.hsj;
+            sgp = P.sgj; hddp = P.h22j; hodp = P.h12j;
         }
         T qo[3], qn[3];
         if constexpr (DIRECT) {
@@ -322,8 +341,11 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
             }
         }
         if (P.has_topo) {  // "substract topo after extrapolation" (rhs_sw.py:153-155), slot by slot
-            qo[0] = qo[0] - hsp[o_own];
-            qn[0] = qn[0] - hsp[o_nbr];
+            // (a branch per direction, not a selected pointer: the compiler kept {hsi, hsj} as an ARRAY IN SCRATCH indexed by
+            // d - 16 bytes stored by every thread of every workgroup at the top of the kernel, 22 MB of writes per S7
+            // evaluation next to 33 MB of results, and a dependent scratch load in front of the face arithmetic)
+            if (d == 0) { qo[0] = qo[0] - P.hsi[o_own]; qn[0] = qn[0] - P.hsi[o_nbr]; }
+            else { qo[0] = qo[0] - P.hsj[o_own]; qn[0] = qn[0] - P.hsj[o_nbr]; }
         }
         in.sg = sgp[o_own]; in.hdd = hddp[o_own]; in.hod = hodp[o_own];
 #pragma unroll
@@ -390,26 +412,40 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
     T q0 = T(1.0), q1 = T(0.0), q2 = T(0.0);
     double sg = 1.0, h11 = 0, h12 = 0, h21 = 0, h22 = 0;
     double c101 = 0, c102 = 0, c111 = 0, c112 = 0, c201 = 0, c202 = 0, c212 = 0, c222 = 0, dz1 = 0.0, dz2 = 0.0;
-    if (active) {   // every load of the point stage, issued together
+    auto load_forcing_fields = [&]() {
+        c101 = P.c101[o]; c102 = P.c102[o]; c111 = P.c111[o]; c112 = P.c112[o];
+        c201 = P.c201[o]; c202 = P.c202[o]; c212 = P.c212[o]; c222 = P.c222[o];
+        if (P.has_topo) { dz1 = P.dz1[o]; dz2 = P.dz2[o]; }
+    };
+    if (active) {   // every load of the point stage, issued together (LEAN: the state and the metric tensor only)
         if constexpr (DIRECT) { q0 = dq0; q1 = dq1; q2 = dq2; }
         else { q0 = D.q[o]; q1 = D.q[fs + o]; q2 = D.q[2 * fs + o]; }
         sg = P.sg[o];
         h11 = P.h11[o]; h12 = P.h12[o]; h21 = P.h21[o]; h22 = P.h22[o];
-        c101 = P.c101[o]; c102 = P.c102[o]; c111 = P.c111[o]; c112 = P.c112[o];
-        c201 = P.c201[o]; c202 = P.c202[o]; c212 = P.c212[o]; c222 = P.c222[o];
-        if (P.has_topo) { dz1 = P.dz1[o]; dz2 = P.dz2[o]; }
+        if constexpr (!LEAN) load_forcing_fields();
     }
+    if constexpr (LEAN) __builtin_amdgcn_sched_barrier(0);
     if constexpr (ONE_PASS) face_flux(fin);   // the face values were issued first and are here first; the point loads fly on
     const T u1 = q1 / q0, u2 = q2 / q0;
     const T hsq = q0 * q0;
     T forc1 = T(0.0), forc2 = T(0.0);
-    if (active) {
+    auto forcing = [&]() {
         forc1 = 2.0 * (c101 * q1 + c102 * q2) + c111 * q1 * u1 + 2.0 * c112 * q1 * u2 + kGravity * q0 * (h11 * dz1 + h12 * dz2);
         forc2 = 2.0 * (c201 * q1 + c202 * q2) + 2.0 * c212 * q1 * u2 + c222 * q2 * u2 + kGravity * q0 * (h21 * dz1 + h22 * dz2);
+    };
+    if constexpr (!LEAN) {
+        if (active) forcing();
     }
     T acc0 = T(0.0), acc1 = T(0.0), acc2 = T(0.0);
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
+        if constexpr (LEAN) {
+            if (d == 1) {   // the forcing fields: in flight under the second pass, consumed behind it
+                __builtin_amdgcn_sched_barrier(0);
+                if (active) load_forcing_fields();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         const T ud = w_sel(d == 0, u1, u2);
         const double ha = d == 0 ? h11 : h12, hb = d == 0 ? h21 : h22;
         if (d > 0 || DIRECT) __syncthreads();   // (DIRECT: the face stage has read the nodal values out of fld)
@@ -425,19 +461,41 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
         const int fp = d == 0 ? jl : il;
         const double cm = sCm[idx], cp = sCp[idx];
         T dv[3];
+        if constexpr (LEAN) {
+            // one variable after the other in a ROLLED loop (the same sums in the same order): eight LDS reads in flight
+            // instead of the 24 + 8 the unrolled form clusters (80 registers at its peak)
+            double dm[N];
 #pragma unroll
-        for (int v = 0; v < 3; ++v) dv[v] = cm * fr[lf][2 * d][v][fp] + cp * fr[lf][2 * d + 1][v][fp];
+            for (int m = 0; m < N; ++m) dm[m] = sD[idx * N + m];
+            dv[0] = dv[1] = dv[2] = 0.0;
+#pragma unroll 1
+            for (int v = 0; v < 3; ++v) {
+                double a = cm * fr[lf][2 * d][v][fp] + cp * fr[lf][2 * d + 1][v][fp];
 #pragma unroll
-        for (int m = 0; m < N; ++m) {
-            const double dm = sD[idx * N + m];
+                for (int m = 0; m < N; ++m) a += dm[m] * fld[v][base + m * stride];
+                if (v == 0) dv[0] = a;
+                else if (v == 1) dv[1] = a;
+                else dv[2] = a;
+            }
+        } else {
 #pragma unroll
-            for (int v = 0; v < 3; ++v) dv[v] += dm * fld[v][base + m * stride];
+            for (int v = 0; v < 3; ++v) dv[v] = cm * fr[lf][2 * d][v][fp] + cp * fr[lf][2 * d + 1][v][fp];
+#pragma unroll
+            for (int m = 0; m < N; ++m) {
+                const double dm = sD[idx * N + m];
+#pragma unroll
+                for (int v = 0; v < 3; ++v) dv[v] += dm * fld[v][base + m * stride];
+            }
         }
         acc0 += dv[0];
         acc1 += dv[1];
         acc2 += dv[2];
     }
     if (!PIPE && !active) return;
+    if constexpr (LEAN) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (active) forcing();
+    }
     const double inv_sg = 1.0 / sg;
     T r0 = inv_sg * (-acc0), r1 = inv_sg * (-acc1) - forc1, r2 = inv_sg * (-acc2) - forc2;
     if (active) {
@@ -470,12 +528,18 @@ template <int N, typename T>
 __global__ __launch_bounds__(Cfg2<N>::BS) void sw_extrap_kernel(const SwParams<T> P, const SwDyn<T> D) {
     sw_extrap_body<N, T>(P, D);
 }
+// which instantiations take the lean schedule (and the occupancy it is made for)
 template <int N, typename T, bool PIPE>
-__global__ __launch_bounds__(Cfg2<N>::BS) void sw_rhs_kernel(const SwParams<T> P, const SwDyn<T> D) {
-    sw_rhs_body<N, T, PIPE>(P, D);
+constexpr bool sw_lean() { return WX_SW_LEAN && std::is_same<T, double>::value && !PIPE && Cfg2<N>::EPB * 4 * N <= Cfg2<N>::BS && N >= 6; }
+template <int N, typename T, bool PIPE>
+constexpr int sw_waves() { return sw_lean<N, T, PIPE>() ? kSwLeanWaves : kSwWaves; }
+
+template <int N, typename T, bool PIPE>
+__global__ __launch_bounds__(Cfg2<N>::BS, (sw_waves<N, T, PIPE>())) void sw_rhs_kernel(const SwParams<T> P, const SwDyn<T> D) {
+    sw_rhs_body<N, T, PIPE, false, sw_lean<N, T, PIPE>()>(P, D);
 }
 template <int N, typename T>
-__global__ __launch_bounds__(Cfg2<N>::BS) void sw_rhs_direct_kernel(const SwParams<T> P, const SwDyn<T> D) {
+__global__ __launch_bounds__(Cfg2<N>::BS, kSwWaves) void sw_rhs_direct_kernel(const SwParams<T> P, const SwDyn<T> D) {
     sw_rhs_body<N, T, false, true>(P, D);
 }
 // the tile-edge lines alone (the ring of elements on the four tile edges): what the direct form still has to exchange
@@ -515,7 +579,7 @@ __global__ __launch_bounds__(Cfg2<N>::BS) void sw_extrap_ring_batch_kernel(const
     sw_extrap_ring_body<N, T>(PB[blockIdx.y], D);
 }
 template <int N, typename T>
-__global__ __launch_bounds__(Cfg2<N>::BS) void sw_rhs_direct_batch_kernel(const SwParams<T>* __restrict__ PB, const T* q, T* rhs,
+__global__ __launch_bounds__(Cfg2<N>::BS, kSwWaves) void sw_rhs_direct_batch_kernel(const SwParams<T>* __restrict__ PB, const T* q, T* rhs,
                                                                          size_t stride, int count, int region, int axpy,
                                                                          const T* y, double ca, double cb, double cc) {
     SwDyn<T> D{q + (size_t)blockIdx.y * stride, rhs + (size_t)blockIdx.y * stride, count, region, axpy,
@@ -531,13 +595,13 @@ __global__ __launch_bounds__(Cfg2<N>::BS) void sw_extrap_batch_kernel(const SwPa
     sw_extrap_body<N, T>(PB[blockIdx.y], D);
 }
 template <int N, typename T, bool PIPE>
-__global__ __launch_bounds__(Cfg2<N>::BS) void sw_rhs_batch_kernel(const SwParams<T>* __restrict__ PB, const T* q, T* rhs,
+__global__ __launch_bounds__(Cfg2<N>::BS, (sw_waves<N, T, PIPE>())) void sw_rhs_batch_kernel(const SwParams<T>* __restrict__ PB, const T* q, T* rhs,
                                                                   size_t stride, int count, int region, int axpy,
                                                                   const T* y, double ca, double cb, double cc, int slot,
                                                                   int prepare) {
     SwDyn<T> D{q + (size_t)blockIdx.y * stride, rhs + (size_t)blockIdx.y * stride, count, region, axpy,
                y ? y + (size_t)blockIdx.y * stride : nullptr, ca, cb, cc, slot, prepare};
-    sw_rhs_body<N, T, PIPE>(PB[blockIdx.y], D);
+    sw_rhs_body<N, T, PIPE, false, sw_lean<N, T, PIPE>()>(PB[blockIdx.y], D);
 }
 
 }  // namespace wx
