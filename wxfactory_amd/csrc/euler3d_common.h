@@ -22,6 +22,12 @@ constexpr bool kSkelDirs = WX_K2_DIAG == 2 || WX_K2_DIAG == 4;
 // to the next element through LDS): the extrapolation kernel neither computes nor stores them, the fused kernel never loads
 // them (wrong results) - what such a design could gain before it pays for its own work (profiles/r04_vertical_faces_ceiling.txt)
 constexpr bool kNoVertFaces = WX_K2_DIAG == 5;
+// 6: the ceiling of every scheme that hides the latency of the fused kernel's state-dependent loads (a workgroup prefetching its
+// next element's face and state values under this element's passes): those loads are folded onto the first 64 elements - they
+// hit the L2 instead of HBM (wrong results).  7: the static fields too - what the kernel's own structure (barriers, LDS, the
+// vector pipe) costs with every load served from cache.  profiles/r05_k2_latency_ceiling.txt
+constexpr bool kDiagCacheState = WX_K2_DIAG == 6 || WX_K2_DIAG == 7;
+constexpr bool kDiagCacheAll = WX_K2_DIAG == 7;
 
 // the streamed-once static fields go through non-temporal loads
 __device__ __forceinline__ double ldm(const double* p) { return __builtin_nontemporal_load(p); }

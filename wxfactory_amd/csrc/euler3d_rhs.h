@@ -75,6 +75,10 @@ struct FaceIn {
     bool mirror;
 };
 
+// (diagnostic build 7: the interface metric from a window too)
+template <int N, bool COLM>
+__device__ __forceinline__ size_t diag_fold(size_t o) { return (kDiagCacheAll && !COLM) ? o % (size_t)(128 * N * N) : o; }
+
 // The loads of one face point of one element: own slot of the interface buffer; the neighbour element's slot,
 // the received halo on a lateral tile edge, or the own state again (mirrored later) at ground / top; the
 // interface metric.  Separate from the arithmetic so that a kernel can issue them early.
@@ -85,7 +89,7 @@ __device__ __forceinline__ void face_load(const EulerParams<T, G>& P, const Elem
     const int d = f >> 1, plus = f & 1;
     const size_t vsh = (size_t)V * H * N2;  // var stride in a halo edge message
 
-    pp<T, const T, G> own = P.itf + ((size_t)el.e * 6 + f) * NQ * N2 + fp;
+    pp<T, const T, G> own = P.itf + ((size_t)(kDiagCacheState ? el.e & 63 : el.e) * 6 + f) * NQ * N2 + fp;
     pp<T, const T, G> nbr;
     size_t nstride = N2;
     bool mirror = false, from_halo = false;
@@ -93,30 +97,30 @@ __device__ __forceinline__ void face_load(const EulerParams<T, G>& P, const Elem
     size_t hfs;  // field stride of the h_contra_itf array
     if (d == 0) {
         const int ne = el.ei + (plus ? 1 : -1);
-        if (ne >= 0 && ne < H) nbr = P.itf + ((size_t)(el.e + (plus ? 1 : -1)) * 6 + (f ^ 1)) * NQ * N2 + fp;
+        if (ne >= 0 && ne < H) nbr = P.itf + ((size_t)(kDiagCacheState ? (el.e + 1) & 63 : el.e + (plus ? 1 : -1)) * 6 + (f ^ 1)) * NQ * N2 + fp;
         else { nbr = (plus ? P.halo_e : P.halo_w) + ((size_t)el.ek * H + el.ej) * N2 + fp; nstride = vsh; from_halo = true; }
         // (column form: the interface metric of a lateral face does not depend on the level - one row of n values per
         // face side instead of V n of them; that of a horizontal face neither on the level nor on the side)
-        const size_t o = COLM ? (((size_t)el.ej * (H + 2) + el.ei + 1) * 2 + plus) * N + fp % N
-                              : (((size_t)el.ek * H + el.ej) * (H + 2) + el.ei + 1) * 2 * N2 + plus * N2 + fp;
+        const size_t o = diag_fold<N, COLM>(COLM ? (((size_t)el.ej * (H + 2) + el.ei + 1) * 2 + plus) * N + fp % N
+                              : (((size_t)el.ek * H + el.ej) * (H + 2) + el.ei + 1) * 2 * N2 + plus * N2 + fp);
         hfs = COLM ? (size_t)H * (H + 2) * 2 * N : (size_t)V * H * (H + 2) * 2 * N2;
         sgp = P.sgi + o;
         hp = P.hi + 0 * 3 * hfs + o;
     } else if (d == 1) {
         const int ne = el.ej + (plus ? 1 : -1);
-        if (ne >= 0 && ne < H) nbr = P.itf + ((size_t)(el.e + (plus ? H : -H)) * 6 + (f ^ 1)) * NQ * N2 + fp;
+        if (ne >= 0 && ne < H) nbr = P.itf + ((size_t)(kDiagCacheState ? (el.e + 2) & 63 : el.e + (plus ? H : -H)) * 6 + (f ^ 1)) * NQ * N2 + fp;
         else { nbr = (plus ? P.halo_n : P.halo_s) + ((size_t)el.ek * H + el.ei) * N2 + fp; nstride = vsh; from_halo = true; }
-        const size_t o = COLM ? ((((size_t)el.ej + 1) * H + el.ei) * 2 + plus) * N + fp % N
-                              : (((size_t)el.ek * (H + 2) + el.ej + 1) * H + el.ei) * 2 * N2 + plus * N2 + fp;
+        const size_t o = diag_fold<N, COLM>(COLM ? ((((size_t)el.ej + 1) * H + el.ei) * 2 + plus) * N + fp % N
+                              : (((size_t)el.ek * (H + 2) + el.ej + 1) * H + el.ei) * 2 * N2 + plus * N2 + fp);
         hfs = COLM ? (size_t)(H + 2) * H * 2 * N : (size_t)V * (H + 2) * H * 2 * N2;
         sgp = P.sgj + o;
         hp = P.hj + 1 * 3 * hfs + o;
     } else {
         const int ne = el.ek + (plus ? 1 : -1);
-        if (ne >= 0 && ne < V) nbr = P.itf + ((size_t)(el.e + (plus ? H * H : -H * H)) * 6 + (f ^ 1)) * NQ * N2 + fp;
+        if (ne >= 0 && ne < V) nbr = P.itf + ((size_t)(kDiagCacheState ? (el.e + 3) & 63 : el.e + (plus ? H * H : -H * H)) * 6 + (f ^ 1)) * NQ * N2 + fp;
         else { nbr = own; mirror = true; }
-        const size_t o = COLM ? ((size_t)el.ej * H + el.ei) * N2 + fp
-                              : ((((size_t)el.ek + 1) * H + el.ej) * H + el.ei) * 2 * N2 + plus * N2 + fp;
+        const size_t o = diag_fold<N, COLM>(COLM ? ((size_t)el.ej * H + el.ei) * N2 + fp
+                              : ((((size_t)el.ek + 1) * H + el.ej) * H + el.ei) * 2 * N2 + plus * N2 + fp);
         hfs = COLM ? (size_t)H * H * N2 : (size_t)(V + 2) * H * H * 2 * N2;
         sgp = P.sgk + o;
         hp = P.hk + 2 * 3 * hfs + o;
@@ -370,7 +374,10 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T, G>& P) {
     // metric offsets: the point's own, or - column form - its place in the column's (n x n) slab
     const size_t om = COLM ? ((size_t)el.ej * H + el.ei) * N2 + pt % N2 : o;
     const size_t fsm = COLM ? (size_t)H * H * N2 : fs;
-    k2_point_loads<T, COLM>(P, active, o, fs, S, om, fsm);   // in flight while the face stage computes
+    // (diagnostic builds 6 / 7: the loads come from a window of 64 elements; the stores go where they belong)
+    const size_t o_ld = kDiagCacheState ? (size_t)(el.e & 63) * N3 + pt : o;
+    const size_t om_ld = (kDiagCacheAll && !COLM) ? o_ld : om;
+    k2_point_loads<T, COLM>(P, active, o_ld, fs, S, om_ld, fsm);   // in flight while the face stage computes
     const T q0 = S.q0, q1 = S.q1, q2 = S.q2, q3 = S.q3, q4 = S.q4;
     const double sg = S.sg;
 
@@ -419,7 +426,7 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T, G>& P) {
     double gcoef;
     // (matrix-core path: inv_dzdeta, wanted by the epilogue only, is loaded at the top of the third pass - a value that lives
     // from the forcing to the epilogue was the one the stage-pipeline instantiation spilled, behind a full vector-memory wait)
-    k2_forcing<T, COLM, !MF>(P, active, o, fs, S, u1, u2, u3, p, fc0, fc1, fc2, gcoef, om, fsm);
+    k2_forcing<T, COLM, !MF>(P, active, o, fs, S, u1, u2, u3, p, fc0, fc1, fc2, gcoef, om_ld, fsm);
     WX_STAMP(2);
 
     // accumulators of sum_d dF^d; the forcing is folded in as sqrtG*f so that the final
@@ -446,7 +453,7 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T, G>& P) {
                 const MfOps4 hf = mf4_load_ops(P.K->D, nullptr, nullptr, P.K->HF, tid & 63);
                 mops4.h0 = hf.h0; mops4.h1 = hf.h1;
             }
-            if (d == 2 && active) gcoef = ldm_if<COLM>(P.idz + om) * kGravity;
+            if (d == 2 && active) gcoef = ldm_if<COLM>(P.idz + om_ld) * kGravity;
             // matrix-core pass (mf4_dir_pass): each thread stages its own node, the 8 waves contract all lines in place -
             // D | cm | cp with the two common face values as a third k-step -, each thread picks its own node up again:
             // no barrier between a thread's read and its next write
