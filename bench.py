@@ -159,7 +159,7 @@ def kernel_source_hash():
     return h.hexdigest()
 
 
-PMC_SUMMARIES = {384.0: "r04_pmc_full_summary.json", 312.0: "r04_pmc_rotzero_summary.json"}
+PMC_SUMMARIES = {384.0: "r05_pmc_full_summary.json", 312.0: "r05_pmc_rotzero_summary.json"}
 
 
 def pmc_traffic(region, n, H, V, bpp=ALGO_BYTES_PER_POINT):
