@@ -644,6 +644,13 @@ wx_status wx_euler3d_batch_pmex_vector(const wx_euler3d_batch* b, const double* 
 wx_status wx_pmex_vector(double* V, size_t ldv, int j, size_t n, int p, const double* aw, const double* uflip, double* LT,
                          double* Linv, int ld, double tol, double* hcol, double* own, double* workspace, int mmax,
                          wx_stream stream);
+/* ... with the vectors split over ranks (solvers/pmex.py:150-173, 194-218): this rank holds n of the components, the p
+ * augmented ones are replicated.  The (j+1) x 2 block of products and the vector's own norm are formed over the n-long parts
+ * and completed by wx_comm_allreduce on `comm` in stream order - two graph nodes under capture, no host round trip -, the
+ * augmented components enter once afterwards.  comm NULL: no reduction (one rank taking the several-rank code path). */
+wx_status wx_pmex_vector_split(double* V, size_t ldv, int j, size_t n, int p, const double* aw, const double* uflip, double* LT,
+                               double* Linv, int ld, double tol, double* hcol, double* own, double* workspace, int mmax,
+                               wx_comm* comm, wx_stream stream);
 /* The low-synchronisation Gram-Schmidt step of solvers/fgmres.py:16-73 (_ortho_1_sync_igs: all rows against the last
  * two in ONE fused reduction, then both rows corrected, scaled and orthogonalised against each other):
  *   wx_multi_dot2   out[k] = <V[k], a>, out[m + k] = <V[k], b>, k < m, one pass over the rows

@@ -265,3 +265,36 @@ def test_config5_kiops_passes_with_exchange_and_reductions_replay_from_one_graph
     del gepi, epi, rhs
     torch.cuda.synchronize()
     ex.close()
+
+
+@pytest.mark.parametrize("p,taus", [(1, [1.0]), (3, [0.4, 1.0])])
+def test_pmex_vectors_split_over_ranks_reduce_in_stream_order(comm, p, taus):
+    """solvers/pmex.py:150-173, 194-218 with the vectors split over ranks: the (j+1) x 2 block of products and the vector's own
+    norm are completed by wx_comm_allreduce inside wx_pmex_vector_split, in stream order - the host reads the Hessenberg
+    columns once per pass, as on one rank.  Same decisions and vectors as the unsplit build."""
+    from wxfactory_amd.solvers import pmex
+
+    n = 50_000
+    gen = torch.Generator(device=DEV).manual_seed(23 + p)
+    lam = -(0.2 + 2.5 * torch.rand(n, generator=gen, device=DEV, dtype=torch.float64))
+    u = torch.randn((p + 1, n), generator=gen, device=DEV, dtype=torch.float64)
+    A = lambda v: lam * v  # noqa: E731
+    args = dict(tol=1e-10, m_init=12, mmin=10, mmax=40)
+    w_one, st_one = pmex(taus, A, u, **args)
+    calls = {"n": 0}
+    inner = comm.allreduce
+
+    def counting(t, op="sum"):
+        calls["n"] += 1
+        return inner(t, op)
+
+    comm.allreduce = counting
+    try:
+        w_split, st_split = pmex(taus, A, u, group=comm, _force_split=True, **args)
+    finally:
+        comm.allreduce = inner
+    assert st_split[:4] == st_one[:4], (st_split, st_one)
+    assert float((w_split - w_one).abs().max()) <= 1e-12 * float(w_one.abs().max())
+    # the per-vector reductions never came back to Python (they are ncclAllReduce calls inside the C function): what Python
+    # reduced is the start of each sub-step only (|u|, the first vector's norm)
+    assert calls["n"] <= 2 + 2 * st_split[0] + 2 * st_split[1], (calls, st_split)

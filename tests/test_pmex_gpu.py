@@ -132,7 +132,9 @@ def test_pmex_device_kernels_split_form_and_exact_result(built_lib, p, taus, mon
     # against the default, whose vectors are built by wx_pmex_vector with none
     monkeypatch.setenv("WXHIP_PMEX_DEVICE", "0")
     w_host, st_host = pmex(taus, A, u, **args)
+    w_hsplit, st_hsplit = pmex(taus, A, u, _force_split=True, **args)   # the several-rank form with the host in between
     monkeypatch.delenv("WXHIP_PMEX_DEVICE")
+    assert st_hsplit[:4] == st_dev[:4] and float((w_hsplit - w_split).abs().max()) <= 1e-12 * scale
     assert st_host[:4] == st_dev[:4] and st_host[5:] == st_dev[5:], (st_host, st_dev)
     assert float((w_host - w_dev).abs().max()) <= 1e-12 * scale
 

@@ -100,6 +100,8 @@ SIGNATURES = {
                                              c_void_p, c_int, c_size_t, c_void_p]),
     "wx_pmex_vector": (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                c_double, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "wx_pmex_vector_split": (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                     c_double, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "wx_kiops_finish_workspace": (c_size_t, [c_size_t]),
     "wx_kiops_finish": (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p]),

@@ -507,10 +507,13 @@ __global__ __launch_bounds__(256) void pmex_project_kernel(const double* __restr
 }
 
 // w = (w - sum_k h[k] V[row0 + k]) * (*scale or 1);  when `part` is given, the squared norm of what was written, per workgroup
+// (nnorm: the squared norm covers the first nnorm components only - the rank-local n-long part when the vectors are split
+// over ranks, whose p replicated augmented components enter once, after the all-reduce)
 template <int R>
 __global__ __launch_bounds__(256) void multi_axpy_dev_kernel(double* __restrict__ w, const double* __restrict__ V, size_t ldv,
                                                              int row0, const double* __restrict__ h, size_t n,
-                                                             const double* __restrict__ scale, double* __restrict__ part) {
+                                                             const double* __restrict__ scale, double* __restrict__ part,
+                                                             size_t nnorm) {
     __shared__ double red[4];
     double cf[R];
 #pragma unroll
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(256) void multi_axpy_dev_kernel(double* __restrict_
         for (int r = 0; r < R; ++r) s -= cf[r] * V[(size_t)(row0 + r) * ldv + i];
         s *= sc;
         w[i] = s;
-        nn += s * s;
+        if (i < nnorm) nn += s * s;
     }
     if (part) {
         const double tsum = wg_sum256(nn, red);
@@ -535,19 +538,53 @@ __global__ __launch_bounds__(256) void multi_axpy_dev_kernel(double* __restrict_
 // hcol[j] = the vector's norm - the estimate, or the root of the summed partials where the estimate fell;  scal[3] = the
 // factor still to be applied (1 when the correction pass normalised the vector already or at a breakdown);  own[0] = 1 when
 // the vector's own norm was needed (pmex's `reg_comm_nrm`)
+// (part == null: the squared norm is complete in *total_in already - the several-rank form, pmex_split_norm_kernel + all-reduce)
 __global__ __launch_bounds__(256) void pmex_finish_kernel(const double* __restrict__ part, int nblocks, double tol,
                                                           double* __restrict__ scal, double* __restrict__ hnorm,
-                                                          double* __restrict__ own) {
+                                                          double* __restrict__ own, const double* __restrict__ total_in) {
     __shared__ double red[4];
     double v = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) v += part[b];
-    const double total = wg_sum256(v, red);
+    if (part)
+        for (int b = threadIdx.x; b < nblocks; b += blockDim.x) v += part[b];
+    double total = wg_sum256(v, red);
+    if (!part) total = *total_in;
     if (threadIdx.x == 0) {
         const bool stands = scal[2] != 0.0;
         const double nrm = stands ? scal[1] : sqrt(total);
         *hnorm = nrm;
         *own = stands ? 0.0 : 1.0;
         scal[3] = (!stands && nrm >= tol) ? 1.0 / nrm : 1.0;
+    }
+}
+
+// several ranks: the products of the rank-local n-long parts have been all-reduced into G; the p augmented components are
+// replicated on every rank and enter once, here:  G[k] += <V[k, n:], V[j-1, n:]>,  G[m + k] += <V[k, n:], V[j, n:]>,  k < m = j+1
+__global__ __launch_bounds__(256) void pmex_split_aug_kernel(const double* __restrict__ V, size_t ldv, int j, size_t n, int p,
+                                                             double* __restrict__ G) {
+    const int m = j + 1;
+    for (int t = threadIdx.x; t < 2 * m; t += blockDim.x) {
+        const int k = t < m ? t : t - m;
+        const double* other = V + (size_t)(t < m ? j - 1 : j) * ldv + n;
+        const double* vk = V + (size_t)k * ldv + n;
+        double a = 0.0;
+        for (int c = 0; c < p; ++c) a += vk[c] * other[c];
+        G[t] += a;
+    }
+}
+// the rank-local squared norm of the corrected vector: the sum of the correction pass's partials, ready for the all-reduce ...
+__global__ __launch_bounds__(256) void pmex_split_norm_kernel(const double* __restrict__ part, int nblocks, double* __restrict__ total) {
+    __shared__ double red[4];
+    double v = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) v += part[b];
+    const double t = wg_sum256(v, red);
+    if (threadIdx.x == 0) *total = t;
+}
+// ... and, after it, the replicated augmented components' share
+__global__ void pmex_split_norm_aug_kernel(const double* __restrict__ vj_aug, int p, double* __restrict__ total) {
+    if (threadIdx.x == 0) {
+        double a = 0.0;
+        for (int c = 0; c < p; ++c) a += vj_aug[c] * vj_aug[c];
+        *total += a;
     }
 }
 
@@ -560,14 +597,14 @@ __global__ __launch_bounds__(256) void scale_if_kernel(double* __restrict__ w, s
 
 template <int R>
 static void launch_axpy_dev(double* w, const double* V, size_t ldv, int row0, const double* h, size_t n, const double* scale,
-                            double* part, unsigned grid, hipStream_t st) {
-    hipLaunchKernelGGL((multi_axpy_dev_kernel<R>), dim3(grid), dim3(256), 0, st, w, V, ldv, row0, h, n, scale, part);
+                            double* part, unsigned grid, hipStream_t st, size_t nnorm) {
+    hipLaunchKernelGGL((multi_axpy_dev_kernel<R>), dim3(grid), dim3(256), 0, st, w, V, ldv, row0, h, n, scale, part, nnorm);
 }
 template <int R>
 static void dispatch_axpy_dev(int rem, double* w, const double* V, size_t ldv, int row0, const double* h, size_t n,
-                              const double* scale, double* part, unsigned grid, hipStream_t st) {
-    if (rem == R) launch_axpy_dev<R>(w, V, ldv, row0, h, n, scale, part, grid, st);
-    else if constexpr (R > 1) dispatch_axpy_dev<R - 1>(rem, w, V, ldv, row0, h, n, scale, part, grid, st);
+                              const double* scale, double* part, unsigned grid, hipStream_t st, size_t nnorm) {
+    if (rem == R) launch_axpy_dev<R>(w, V, ldv, row0, h, n, scale, part, grid, st, nnorm);
+    else if constexpr (R > 1) dispatch_axpy_dev<R - 1>(rem, w, V, ldv, row0, h, n, scale, part, grid, st, nnorm);
 }
 
 constexpr unsigned kPmexAxpyBlocks = 2048;
@@ -765,14 +802,18 @@ size_t wx_pmex_workspace(int mmax) {
     return (size_t)kDotBlocks * 2 * (m + 1) + 2 * (size_t)(m + 1) + (size_t)m + 8 + kPmexAxpyBlocks;
 }
 
-wx_status wx_pmex_vector(double* V, size_t ldv, int j, size_t n, int p, const double* aw, const double* uflip, double* LT,
-                         double* Linv, int ld, double tol, double* hcol, double* own, double* workspace, int mmax,
-                         wx_stream stream) {
+// split: the vectors are cut over ranks (this rank holds n of the components, the p augmented ones are replicated): the
+// products and the own norm are taken over the n-long parts, all-reduced on `comm` (nullable: one rank taking the several-rank
+// code path) on the caller's stream - graph nodes under capture -, the augmented components added once afterwards
+// (solvers/pmex.py:150-173, 194-218)
+static wx_status pmex_vector_impl(double* V, size_t ldv, int j, size_t n, int p, const double* aw, const double* uflip, double* LT,
+                                  double* Linv, int ld, double tol, double* hcol, double* own, double* workspace, int mmax,
+                                  bool split, wx_comm* comm, wx_stream stream, const char* who) {
     if (!V || !aw || !uflip || !LT || !Linv || !hcol || !own || !workspace)
-        return fail(WX_ERR_INVALID, "wx_pmex_vector: null argument");
+        return fail(WX_ERR_INVALID, "%s: null argument", who);
     if (j < 1 || j > mmax || mmax > kPmexMaxM || ld < mmax || p < 1 || p > 16 || ldv < n + (size_t)p)
-        return fail(WX_ERR_INVALID, "wx_pmex_vector: j = %d, mmax = %d (<= %d), ld = %d, p = %d (1..16), row stride %zu, n = %zu",
-                    j, mmax, kPmexMaxM, ld, p, ldv, n);
+        return fail(WX_ERR_INVALID, "%s: j = %d, mmax = %d (<= %d), ld = %d, p = %d (1..16), row stride %zu, n = %zu",
+                    who, j, mmax, kPmexMaxM, ld, p, ldv, n);
     WX_STREAM(st, stream);
     double* dotw = workspace;
     double* G = dotw + (size_t)kDotBlocks * 2 * (mmax + 1);
@@ -787,22 +828,58 @@ wx_status wx_pmex_vector(double* V, size_t ldv, int j, size_t n, int p, const do
         hipLaunchKernelGGL(aug_update_kernel, dim3(grid), dim3(256), 0, st, V, ldv, j, n, p, aw, uflip);
     }
     const int m = j + 1;
+    const size_t dlen = split ? n : len;   // what the products run over
     for (int r = 0; r < m; r += kRowsPerPass2)
-        dispatch_dot2<kRowsPerPass2>(m - r < kRowsPerPass2 ? m - r : kRowsPerPass2, V, ldv, r, V + (size_t)(j - 1) * ldv, vj, len,
+        dispatch_dot2<kRowsPerPass2>(m - r < kRowsPerPass2 ? m - r : kRowsPerPass2, V, ldv, r, V + (size_t)(j - 1) * ldv, vj, dlen,
                                      dotw, m, st);
     hipLaunchKernelGGL(multi_dot_finish_kernel, dim3(2 * m), dim3(64), 0, st, dotw, kDotBlocks, 2 * m, G);
+    if (split) {
+        WX_HIP_TRY(hipGetLastError());
+        if (comm) {
+            const wx_status cs = wx_comm_allreduce(comm, G, (size_t)(2 * m), WX_REDUCE_SUM, stream);
+            if (cs != WX_OK) return cs;
+        }
+        hipLaunchKernelGGL(pmex_split_aug_kernel, dim3(1), dim3(256), 0, st, V, ldv, j, n, p, G);
+    }
     hipLaunchKernelGGL(pmex_project_kernel, dim3(1), dim3(256), 0, st, G, j, LT, Linv, ld, tol, sol, hcol, scal);
     const size_t want = (len + 255) / 256;
     const unsigned grid = (unsigned)(want < kPmexAxpyBlocks ? (want ? want : 1) : kPmexAxpyBlocks);
     for (int r = 0; r < j; r += kRowsPerPass) {
         const bool last = r + kRowsPerPass >= j;
         dispatch_axpy_dev<kRowsPerPass>(j - r < kRowsPerPass ? j - r : kRowsPerPass, vj, V, ldv, r, sol, len,
-                                        last ? scal : nullptr, last ? part : nullptr, grid, st);
+                                        last ? scal : nullptr, last ? part : nullptr, grid, st, split ? n : len);
     }
-    hipLaunchKernelGGL(pmex_finish_kernel, dim3(1), dim3(256), 0, st, part, (int)grid, tol, scal, hcol + j, own);
+    if (split) {
+        double* total = scal + 4;
+        hipLaunchKernelGGL(pmex_split_norm_kernel, dim3(1), dim3(256), 0, st, part, (int)grid, total);
+        WX_HIP_TRY(hipGetLastError());
+        if (comm) {
+            const wx_status cs = wx_comm_allreduce(comm, total, 1, WX_REDUCE_SUM, stream);
+            if (cs != WX_OK) return cs;
+        }
+        hipLaunchKernelGGL(pmex_split_norm_aug_kernel, dim3(1), dim3(64), 0, st, vj + n, p, total);
+        hipLaunchKernelGGL(pmex_finish_kernel, dim3(1), dim3(256), 0, st, (const double*)nullptr, 0, tol, scal, hcol + j, own, total);
+    } else {
+        hipLaunchKernelGGL(pmex_finish_kernel, dim3(1), dim3(256), 0, st, part, (int)grid, tol, scal, hcol + j, own,
+                           (const double*)nullptr);
+    }
     hipLaunchKernelGGL(scale_if_kernel, dim3(grid), dim3(256), 0, st, vj, len, scal + 3);
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
+}
+
+wx_status wx_pmex_vector(double* V, size_t ldv, int j, size_t n, int p, const double* aw, const double* uflip, double* LT,
+                         double* Linv, int ld, double tol, double* hcol, double* own, double* workspace, int mmax,
+                         wx_stream stream) {
+    return pmex_vector_impl(V, ldv, j, n, p, aw, uflip, LT, Linv, ld, tol, hcol, own, workspace, mmax, false, nullptr, stream,
+                            "wx_pmex_vector");
+}
+
+wx_status wx_pmex_vector_split(double* V, size_t ldv, int j, size_t n, int p, const double* aw, const double* uflip, double* LT,
+                               double* Linv, int ld, double tol, double* hcol, double* own, double* workspace, int mmax,
+                               wx_comm* comm, wx_stream stream) {
+    return pmex_vector_impl(V, ldv, j, n, p, aw, uflip, LT, Linv, ld, tol, hcol, own, workspace, mmax, true, comm, stream,
+                            "wx_pmex_vector_split");
 }
 
 // wx_pmex_vector with the complex-step matvec in front (wx_euler3d_batch_extrap_pack + wx_euler3d_batch_jvp on the previous

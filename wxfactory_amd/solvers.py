@@ -1102,11 +1102,14 @@ def pmex(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, delta: float 
         g = _allreduce(basis.dots2(j + 1, Vd[j - 1, :n], Vd[j, :n]), group).reshape(2, j + 1).t()
         return (g + Vd[: j + 1, n:] @ Vd[j - 1: j + 1, n:].t()).cpu().numpy()
 
-    # One GPU, vectors not split over ranks: a Krylov vector is built by ONE host call with no round trip
-    # (wx_pmex_vector: the projector and the norm estimate run in a one-workgroup kernel), the host reads the Hessenberg
-    # columns of a whole pass afterwards and sees a happy breakdown then - the vectors built past it are discarded -, as
-    # kiops does.  (Several ranks: the all-reduce of the block of products needs the host between the two halves.)
-    device_pass = (basis.gpu and not split and p <= 16 and mmax <= 128 and os.environ.get("WXHIP_PMEX_DEVICE", "1") != "0")
+    # A Krylov vector is built by ONE host call with no round trip (wx_pmex_vector: the projector and the norm estimate run
+    # in a one-workgroup kernel), the host reads the Hessenberg columns of a whole pass afterwards and sees a happy breakdown
+    # then - the vectors built past it are discarded -, as kiops does.  Vectors split over ranks: the same with the block of
+    # products and the own norm all-reduced IN STREAM ORDER on the library's communicator (wx_pmex_vector_split); a
+    # torch.distributed group (gloo, CPU tests) keeps the host between the two halves, as the reference does.
+    comm_h = group._h if _reduce.is_comm(group) and (_reduce.world_size(group) > 1 or getattr(group, "always", False)) else None
+    device_pass = (basis.gpu and (not split or _reduce.is_comm(group) or _reduce.world_size(group) == 1) and p <= 16
+                   and mmax <= 128 and os.environ.get("WXHIP_PMEX_DEVICE", "1") != "0")
     if device_pass:
         lib = basis.lib
         LT = torch.zeros((mmax, mmax), dtype=dtype, device=dev)
@@ -1114,7 +1117,7 @@ def pmex(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, delta: float 
         Ht = torch.zeros((mmax + 1, mmax + 1), dtype=dtype, device=dev)   # Ht[c] = column c of H: coefficients, then the norm
         own = torch.zeros(mmax + 1, dtype=dtype, device=dev)
         work = torch.empty(int(lib.wx_pmex_workspace(mmax)), dtype=dtype, device=dev)
-        fused_vector = getattr(A, "pmex_vector", None)   # ... and the matvec too, from the same host call
+        fused_vector = getattr(A, "pmex_vector", None) if not split else None   # ... and the matvec too, from the same host call
         aw_buf = torch.empty(n, dtype=dtype, device=dev) if fused_vector is not None else None
         ht_ptr, ht_row, own_ptr = Ht.data_ptr(), Ht.stride(0) * Ht.element_size(), own.data_ptr()
     l = 0
@@ -1138,6 +1141,11 @@ def pmex(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, delta: float 
                     continue
                 aw = A(Vd[jj - 1, :n]).reshape(-1)
                 aw = aw if aw.is_contiguous() else aw.contiguous()
+                if split:
+                    basis.check(lib.wx_pmex_vector_split(Vd.data_ptr(), Vd.stride(0), jj, n, p, aw.data_ptr(),
+                                                         u_flip_t.data_ptr(), LT.data_ptr(), Linv.data_ptr(), mmax, tol, hcol_ptr,
+                                                         flag_ptr, work.data_ptr(), mmax, comm_h, st), "wx_pmex_vector_split")
+                    continue
                 basis.check(lib.wx_pmex_vector(Vd.data_ptr(), Vd.stride(0), jj, n, p, aw.data_ptr(), u_flip_t.data_ptr(),
                                                LT.data_ptr(), Linv.data_ptr(), mmax, tol, hcol_ptr, flag_ptr, work.data_ptr(),
                                                mmax, st), "wx_pmex_vector")
