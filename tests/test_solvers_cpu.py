@@ -135,11 +135,44 @@ def _free_port():
     return port
 
 
-def _split_worker(rank, world, port, q):
+class _CommOverGloo:
+    """The duck type reduce.py takes for the library's communicator (RcclComm: `world`, `allreduce(tensor, op)`), carried by
+    gloo here: with it as `group`, EVERY reduction of a solver must arrive at allreduce() - a reduction that went to
+    torch.distributed's default group directly would be a call the several-GPU data path does not have."""
+
+    def __init__(self, world):
+        self.world, self.calls = world, 0
+
+    def allreduce(self, t, op="sum"):
+        self.calls += 1
+        dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op])
+        return t
+
+
+def _split_worker(rank, world, port, q, through_comm=False):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        from wxfactory_amd.solvers import fgmres, kiops, pmex
+        from wxfactory_amd import solvers as _solvers
+        from wxfactory_amd.solvers import fgmres as _fgmres, kiops as _kiops, pmex as _pmex
+
+        comm = _CommOverGloo(world) if through_comm else None
+        if through_comm:
+            # no solver code may reach the default group behind the communicator's back: every torch.distributed collective
+            # that is not issued by _CommOverGloo.allreduce (or by this test's own gather) raises
+            real_all_reduce = dist.all_reduce
+
+            def guarded(t, *a, **k):
+                import inspect
+
+                if inspect.stack()[1].function != "allreduce":
+                    raise AssertionError("a reduction went to torch.distributed directly, not through the communicator")
+                return real_all_reduce(t, *a, **k)
+
+            dist.all_reduce = guarded
+        fgmres = lambda *a, **k: _fgmres(*a, group=comm, **k)  # noqa: E731
+        kiops = lambda *a, **k: _kiops(*a, group=comm, **k)  # noqa: E731
+        pmex = lambda *a, **k: _pmex(*a, group=comm, **k)  # noqa: E731
 
         A, u = _problem(p=2)
         n = A.shape[0]
@@ -169,6 +202,8 @@ def _split_worker(rank, world, port, q):
                                                    tol=1e-11, restart=25, maxiter=20)
         ref = np.linalg.solve(np.eye(n) - 0.3 * A, u[0])
         assert flag == 0 and np.abs(x.numpy() - ref[lo:hi]).max() < 1e-8 * np.abs(ref).max()
+        if through_comm:
+            assert comm.calls > 50, comm.calls   # (two per Krylov vector of kiops, one per vector of pmex / fgmres, ...)
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok", stats))
@@ -179,12 +214,15 @@ def _split_worker(rank, world, port, q):
         raise
 
 
-def test_solvers_with_vectors_split_over_gloo_ranks():
+@pytest.mark.parametrize("through_comm", [False, True])
+def test_solvers_with_vectors_split_over_gloo_ranks(through_comm):
+    """through_comm: the reductions over a communicator object (the library's RcclComm on GPUs; a gloo-backed stand-in here)
+    instead of torch.distributed's default group - the same adaptive decisions on every rank either way."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_split_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_split_worker, args=(r, world, port, q, through_comm)) for r in range(world)]
     [p.start() for p in procs]
     res = [q.get(timeout=180) for _ in range(world)]
     [p.join(timeout=60) for p in procs]

@@ -1107,8 +1107,9 @@ def pmex(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, delta: float 
     # then - the vectors built past it are discarded -, as kiops does.  Vectors split over ranks: the same with the block of
     # products and the own norm all-reduced IN STREAM ORDER on the library's communicator (wx_pmex_vector_split); a
     # torch.distributed group (gloo, CPU tests) keeps the host between the two halves, as the reference does.
-    comm_h = group._h if _reduce.is_comm(group) and (_reduce.world_size(group) > 1 or getattr(group, "always", False)) else None
-    device_pass = (basis.gpu and (not split or _reduce.is_comm(group) or _reduce.world_size(group) == 1) and p <= 16
+    reduces = _reduce.world_size(group) > 1 or (_reduce.is_comm(group) and getattr(group, "always", False))
+    comm_h = getattr(group, "_h", None) if _reduce.is_comm(group) and reduces else None   # (the library's wx_comm*)
+    device_pass = (basis.gpu and (not split or comm_h is not None or not reduces) and p <= 16
                    and mmax <= 128 and os.environ.get("WXHIP_PMEX_DEVICE", "1") != "0")
     if device_pass:
         lib = basis.lib
