@@ -355,7 +355,7 @@ def extras(dev, seed):
                                    "algorithmic_bytes_per_point": 156.0, "achieved": round(156.0 * 6 * H * H * n * n / te / 1e9, 1),
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(156.0 * 6 * H * H * n * n / te / 1e9 / HBM_PEAK_GBS, 4),
-                                   "profile": "profiles/r04_v7_swbench_kernel_stats.csv, profiles/r04_pmc_sw_summary.json"},
+                                   "profile": "profiles/r05_v1_swbench_kernel_stats.csv, profiles/r05_pmc_sw_summary.json"},
                       "note": "all six panels in one launch per phase (wx_sw_batch_*): 2 launches per R(Q); launch-latency "
                               "bound (5.5 MB of state per panel)"}}
 
@@ -483,7 +483,7 @@ def column_roofline(col, mine, state, dev, reps=10):
             "algorithmic_bytes_per_point": round(bpp, 2), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
             "note": "vector-pipe bound at this traffic: 62 % of the issue slots, 17 % of the instructions are f64 FMAs "
-                    "(profiles/r03_column_k2_sq_counters.json); the fraction of the HBM peak is reported for scale only"}
+                    "(profiles/r03_column_k2_sq_counters.json; with every load served from cache it still takes 0.65 ms: profiles/r05_k2_latency_ceiling.txt); the fraction of the HBM peak is reported for scale only"}
 
 
 def epi2_kiops_e7_extras(dev, seed, n=8, H=60, V=2, dt=0.5, steps=3):
