@@ -288,6 +288,7 @@ def test_stage_pipeline_equals_the_fused_stages(built_lib, topo):
                                comm=comm if loop else None)
             piped = RhsShallowWater(plans, ex)
             piped.batched = batched
+            piped.direct = False   # (the automatic choice at n = 8 is the direct form, whose fused stage is one launch already)
             Q1 = piped.stage(Q, None, 0.0, 1.0, dt)
             Q2 = piped.stage(Q1, Q, 0.75, 0.25, 0.25 * dt)
             Q3 = piped.stage(Q2, Q, 1.0 / 3.0, 2.0 / 3.0, (2.0 / 3.0) * dt)
@@ -305,7 +306,7 @@ def test_stage_pipeline_equals_the_fused_stages(built_lib, topo):
 
 
 @pytest.mark.parametrize("name", ["sw_rk3_c6_n5_h4", "sw_rk3_c6_n8_h3"])
-@pytest.mark.parametrize("fused,batched", [(True, True), (True, False), (False, True)])
+@pytest.mark.parametrize("fused,batched", [(True, True), (True, False), (False, True), ("auto", True)])
 def test_rk3_time_loop_matches_reference(name, fused, batched, built_lib):
     """The explicit time loop of BASELINE configs 2 / 3 - Tvdrk3.step + apply_filters, simulation.py:147-155 with
     integrators/tvdrk3.py:12-19 on rhs/rhs_sw.py - against the reference's own run of it: the state after one and after
@@ -316,8 +317,15 @@ def test_rk3_time_loop_matches_reference(name, fused, batched, built_lib):
     g = golden_sw(name)
     rhs = RhsShallowWater({p: _plan(g, p) for p in range(6)})
     rhs.batched = batched
-    stepper = Tvdrk3(rhs, fused=fused)   # (fused: the stage pipeline - wx_sw_stage / wx_sw_batch_stage)
-    assert stepper.pipeline == fused
+    if fused == "auto":
+        # the default: float64 at n = 8 takes the direct form (one launch per fused stage, no interface buffer), every other
+        # order the stage pipeline of the two-kernel form
+        stepper = Tvdrk3(rhs)
+        assert rhs._use_direct(torch.float64) == (g.n == 8) and stepper.pipeline == (g.n != 8) and stepper.fused
+    else:
+        rhs.direct = False
+        stepper = Tvdrk3(rhs, fused=fused)   # (fused: the stage pipeline - wx_sw_stage / wx_sw_batch_stage)
+        assert stepper.pipeline == fused
     Q0 = torch.stack([_dev(g.q(p)) for p in range(6)])
     dt, nsteps = float(g["meta/rk3_dt"]), int(g["meta/rk3_steps"])
     stack = lambda key: np.stack([g[f"p{p}/{key}"] for p in range(6)])  # noqa: E731

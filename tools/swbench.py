@@ -79,11 +79,17 @@ def step_us(stepper, reps=100):
     return a.elapsed_time(b) / reps * 1e3
 
 
-fused, piped = Tvdrk3(RhsShallowWater(plans), pipeline=False), Tvdrk3(RhsShallowWater(plans))
+two_f, two_p = RhsShallowWater(plans), RhsShallowWater(plans)
+two_f.direct = two_p.direct = False   # the two-kernel form: fused stages with an extrapolation launch each, and its stage pipeline
+fused, piped = Tvdrk3(two_f, pipeline=False), Tvdrk3(two_p)
 assert piped.pipeline and not fused.pipeline
-tf, tp = step_us(fused), step_us(piped)
+auto = Tvdrk3(RhsShallowWater(plans))   # the default: the direct form at this size, one launch (+ the ring pack) per fused stage
+assert not auto.pipeline and auto.fused
+tf, tp, ta = step_us(fused), step_us(piped), step_us(auto)
 print(f"S7 SSP-RK3 step: fused stages {tf:.1f} us, stage pipeline {tp:.1f} us ({tf / tp:.2f} x)  -> per stage {tp / 3:.1f} us = "
       f"{156.0 * 6 * H * H * n * n / (tp / 3 * 1e-6) / 1e9:.1f} GB/s on 156 B/point")
+print(f"S7 SSP-RK3 step, default (direct form, fused stages): {ta:.1f} us  -> per stage {ta / 3:.1f} us = "
+      f"{156.0 * 6 * H * H * n * n / (ta / 3 * 1e-6) / 1e9:.1f} GB/s on 156 B/point")
 
 # ... and the same two steps replayed from HIP graphs (the host out of the way: what the kernels themselves take)
 for name, stepper in (("fused stages", fused), ("stage pipeline", piped)):

@@ -15,6 +15,15 @@
 #include <cstring>
 #include <new>
 
+// No fused multiply-adds formed BY THE COMPILER in this file: which products and sums it fuses depends on how an expression
+// is spread over basic blocks, so the same source line gave different last bits in the two-kernel and in the direct form as
+// soon as one of them moved a load (and a balanced state - Williamson 2 - turns an ulp of the cancelling terms into 1e-7 of
+// R).  With contraction off every form of the evaluation - extrapolation kernel + RHS kernel, stage pipeline, direct,
+// per tile or batched, whole tile or INTERIOR + BOUNDARY - performs the same IEEE operations in source order and agrees to
+// the last bit by construction; it is also what the reference's NumPy expressions do.  (The kernels are bound by memory
+// round trips, not by the vector pipe: the unfused multiplies cost nothing measurable - profiles/r05_sw_s7_ab.txt.)
+#pragma clang fp contract(off)
+
 namespace wx {
 
 constexpr int kMaxN2 = 8;
@@ -235,11 +244,17 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
     using C = Cfg2<N>;
     constexpr int N2 = C::N2, EPB = C::EPB, BS = C::BS;
     static_assert(!(PIPE && DIRECT), "the stage pipeline prepares an interface buffer: not for the direct form");
-    static_assert(!LEAN || (std::is_same<T, double>::value && !DIRECT && EPB * 4 * N <= BS), "the lean schedule: float64, one face pass");
+    static_assert(!LEAN || (std::is_same<T, double>::value && EPB * 4 * N <= BS), "the lean schedule: float64, one face pass");
     const SwSlot<T> S = sw_slot<T>(P, PIPE ? D.slot : 0);   // (the plain kernel reads slot 0: its schedule is untouched)
     __shared__ T fld[3][EPB * C::LE];
     __shared__ T fr[EPB][4][3][N];
     __shared__ double sD[N * N], sCm[N], sCp[N];
+    // DIRECT: the extrapolated states of both sides of every face point (own side from LDS, neighbour side from the neighbour
+    // element's nodal values), formed by ALL threads - one side of one face point each - before the flux stage reads them:
+    // half the loads in flight per thread of the one-thread-per-face-point form (160 registers, 3 waves per SIMD)
+    __shared__ T fside[DIRECT ? 2 * EPB * 4 * 3 * N : 1];
+    __shared__ double sEm[DIRECT ? N : 1], sEp[DIRECT ? N : 1];
+#define WX_FSIDE(side_, le_, f_, v_, k_) fside[((((side_) * EPB + (le_)) * 4 + (f_)) * 3 + (v_)) * N + (k_)]
     const int tid = threadIdx.x;
     const int H = P.H;
     const size_t fs = (size_t)P.nelem * N2;
@@ -248,18 +263,128 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
     if (tid < N) {
         sCm[tid] = P.K->cm[tid];
         sCp[tid] = P.K->cp[tid];
+        if constexpr (DIRECT) { sEm[tid] = P.K->em[tid]; sEp[tid] = P.K->ep[tid]; }
     }
-    T dq0 = T(1.0), dq1 = T(0.0), dq2 = T(0.0);   // DIRECT: the thread's own nodal state, loaded before the face stage
+    // ---- DIRECT: every load that depends on nothing is issued HERE, before the first barrier - the point's state, metric
+    // tensor and Christoffel fields, the neighbour elements' nodal values of the face sides, the interface metric of the face
+    // points - so that a workgroup's life is ONE memory round trip and not a chain of five (nodal values | neighbour values |
+    // interface metric | point metric | Christoffel fields: each behind a barrier or a dependent stage, with four or five
+    // workgroups per CU to hide them - the direct form then ran at 4.6 TB/s on its 239 MB where the rate allows 5.5)
+    T dq0 = T(1.0), dq1 = T(0.0), dq2 = T(0.0);
+    double e_sg = 1.0, e_h11 = 0, e_h12 = 0, e_h21 = 0, e_h22 = 0;
+    double e_c[8] = {0, 0, 0, 0, 0, 0, 0, 0}, e_dz1 = 0.0, e_dz2 = 0.0;
+    struct FaceInSw {
+        T qo[3], qn[3];
+        double sg, hdd, hod;
+        T hs_o, hs_n;      // DIRECT: the interface topography of the two sides (subtracted once the sides are there)
+        int le, f, k, d, plus;
+        bool valid;
+    };
+    constexpr bool DIRECT_ONE = DIRECT && EPB * 4 * N <= BS;   // one flux task per thread: its interface metric is prefetched
+    FaceInSw fin_d;
+    fin_d.valid = false;
+    // (the interface metric of face point fi; defined here because the direct form calls it before its barriers)
+    auto face_meta = [&](int fi, FaceInSw& in) {
+        in.valid = false;
+        const int le = fi / (4 * N), r = fi % (4 * N), f = r / N, k = r % N;
+        const Elem2 el = decode_elem2(bx * EPB + le, D.count, D.region, H, P.md_h, P.md_w);
+        if (!el.valid) return;
+        const int d = f >> 1, plus = f & 1;
+        size_t o_own, o_nbr;
+        if (d == 0) {
+            const size_t row = (size_t)el.ej * (H + 2);
+            o_own = (row + el.ei + 1) * 2 * N + plus * N + k;
+            o_nbr = (row + el.ei + 1 + (plus ? 1 : -1)) * 2 * N + (1 - plus) * N + k;
+            in.sg = P.sgi[o_own]; in.hdd = P.h11i[o_own]; in.hod = P.h21i[o_own];
+            if (P.has_topo) { in.hs_o = T(P.hsi[o_own]); in.hs_n = T(P.hsi[o_nbr]); }
+        } else {
+            o_own = ((size_t)(el.ej + 1) * H + el.ei) * 2 * N + plus * N + k;
+            o_nbr = ((size_t)(el.ej + 1 + (plus ? 1 : -1)) * H + el.ei) * 2 * N + (1 - plus) * N + k;
+            in.sg = P.sgj[o_own]; in.hdd = P.h22j[o_own]; in.hod = P.h12j[o_own];
+            if (P.has_topo) { in.hs_o = T(P.hsj[o_own]); in.hs_n = T(P.hsj[o_nbr]); }
+        }
+        in.le = le; in.f = f; in.k = k; in.d = d; in.plus = plus;
+        in.valid = true;
+    };
     if constexpr (DIRECT) {
         const int le0 = tid / N2, pt0 = tid % N2;
         const Elem2 el0 = decode_elem2(bx * EPB + le0, D.count, D.region, H, P.md_h, P.md_w);
-        if (le0 < EPB && el0.valid) {
-            const size_t o0 = (size_t)el0.e * N2 + pt0;
-            const int lp = le0 * C::LE + C::lidx(pt0 / N, pt0 % N);
+        const bool act0 = le0 < EPB && el0.valid;
+        const size_t o0 = (size_t)el0.e * N2 + pt0;
+        T hs0 = T(0.0);
+        if (act0) {
             dq0 = D.q[o0]; dq1 = D.q[fs + o0]; dq2 = D.q[2 * fs + o0];
+            if (P.has_topo) hs0 = T(P.hsurf[o0]);
+            e_sg = P.sg[o0];
+            e_h11 = P.h11[o0]; e_h12 = P.h12[o0]; e_h21 = P.h21[o0]; e_h22 = P.h22[o0];
+            if constexpr (!LEAN) {   // (lean schedule: the forcing fields follow under the second pass, as in the two-kernel form)
+                e_c[0] = P.c101[o0]; e_c[1] = P.c102[o0]; e_c[2] = P.c111[o0]; e_c[3] = P.c112[o0];
+                e_c[4] = P.c201[o0]; e_c[5] = P.c202[o0]; e_c[6] = P.c212[o0]; e_c[7] = P.c222[o0];
+                if (P.has_topo) { e_dz1 = P.dz1[o0]; e_dz2 = P.dz2[o0]; }
+            }
+        }
+        if constexpr (DIRECT_ONE) {
+            if (tid < EPB * 4 * N) face_meta(tid, fin_d);
+        }
+        // the NEIGHBOUR side of every face point: global loads only, nothing to wait for
+        // (the sums run in the extrapolation kernel's order: m ascending, per variable)
+        for (int t = tid; t < 2 * EPB * 4 * N; t += BS) {
+            const int side = t / (EPB * 4 * N), fi = t % (EPB * 4 * N);
+            if (side == 0) continue;
+            const int le = fi / (4 * N), r = fi % (4 * N), f = r / N, k = r % N;
+            const Elem2 el = decode_elem2(bx * EPB + le, D.count, D.region, H, P.md_h, P.md_w);
+            if (!el.valid) continue;
+            const int d = f >> 1, plus = f & 1;
+            T sv[3] = {T(0.0), T(0.0), T(0.0)};
+            const int ne = d == 0 ? el.ei + (plus ? 1 : -1) : el.ej + (plus ? 1 : -1);
+            if (ne >= 0 && ne < H) {   // the neighbour element of the same tile: its opposite face, from its nodal values
+                const long nelem_nbr = el.e + (d == 0 ? (plus ? 1 : -1) : (plus ? H : -H));
+                const size_t nb = (size_t)nelem_nbr * N2 + (d == 0 ? k * N : k);
+                const int ns = d == 0 ? 1 : N;
+                gp<const double> wn = plus ? P.K->em : P.K->ep;   // (from memory: the LDS copies are not there yet)
+#pragma unroll
+                for (int m = 0; m < N; ++m) {
+                    const double wm = wn[m];
+                    T h = D.q[nb + m * ns];
+                    if (P.has_topo) h = h + P.hsurf[nb + m * ns];
+                    sv[0] += wm * h;
+                    sv[1] += wm * D.q[fs + nb + m * ns];
+                    sv[2] += wm * D.q[2 * fs + nb + m * ns];
+                }
+            } else {   // a tile edge: the received halo line
+                tp<T, const T> nbr = d == 0 ? (plus ? S.halo_e : S.halo_w) + (size_t)el.ej * N + k
+                                            : (plus ? S.halo_n : S.halo_s) + (size_t)el.ei * N + k;
+                const size_t nstride = (size_t)H * N;
+#pragma unroll
+                for (int v = 0; v < 3; ++v) sv[v] = nbr[v * nstride];
+            }
+#pragma unroll
+            for (int v = 0; v < 3; ++v) WX_FSIDE(1, le, f, v, k) = sv[v];
+        }
+        if (act0) {
+            const int lp = le0 * C::LE + C::lidx(pt0 / N, pt0 % N);
             T h = dq0;
-            if (P.has_topo) h = h + P.hsurf[o0];
+            if (P.has_topo) h = h + hs0;
             fld[0][lp] = h; fld[1][lp] = dq1; fld[2][lp] = dq2;
+        }
+        __syncthreads();
+        // the OWN side, from the staged nodal values
+        for (int t = tid; t < EPB * 4 * N; t += BS) {
+            const int le = t / (4 * N), r = t % (4 * N), f = r / N, k = r % N;
+            const Elem2 el = decode_elem2(bx * EPB + le, D.count, D.region, H, P.md_h, P.md_w);
+            if (!el.valid) continue;
+            const int d = f >> 1, plus = f & 1;
+            T sv[3] = {T(0.0), T(0.0), T(0.0)};
+            const int base = d == 0 ? C::lidx(k, 0) : C::lidx(0, k);
+            const int stride = d == 0 ? 1 : C::NP;
+#pragma unroll
+            for (int m = 0; m < N; ++m) {
+                const double wm = plus ? sEp[m] : sEm[m];
+#pragma unroll
+                for (int v = 0; v < 3; ++v) sv[v] += wm * fld[v][le * C::LE + base + m * stride];
+            }
+#pragma unroll
+            for (int v = 0; v < 3; ++v) WX_FSIDE(0, le, f, v, k) = sv[v];
         }
         __syncthreads();
     }
@@ -267,12 +392,6 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
     // ---- face stage: AUSM common flux of the 4 faces (rhs_sw.py:157-207), as a load part and a flux part: when one pass of the
     // workgroup covers every face point (n >= 3) the point loads are issued between the two, so that they are in flight
     // under the face arithmetic instead of after it (vector-memory results return in issue order: the faces come first)
-    struct FaceInSw {
-        T qo[3], qn[3];
-        double sg, hdd, hod;
-        int le, f, k, d, plus;
-        bool valid;
-    };
     auto face_load = [&](int fi, FaceInSw& in) {
         in.valid = false;
         const int le = fi / (4 * N);
@@ -305,34 +424,7 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
         }
         T qo[3], qn[3];
         if constexpr (DIRECT) {
-            const int base = d == 0 ? C::lidx(k, 0) : C::lidx(0, k);
-            const int stride = d == 0 ? 1 : C::NP;
-            gp<const double> wo = plus ? P.K->ep : P.K->em;   // the own face ...
-            gp<const double> wn = plus ? P.K->em : P.K->ep;   // ... is the neighbour's opposite one
-#pragma unroll
-            for (int v = 0; v < 3; ++v) { qo[v] = T(0.0); qn[v] = T(0.0); }
-#pragma unroll
-            for (int m = 0; m < N; ++m) {
-                const double wm = wo[m];
-#pragma unroll
-                for (int v = 0; v < 3; ++v) qo[v] += wm * fld[v][le * C::LE + base + m * stride];
-            }
-            if (nelem_nbr >= 0) {
-                const size_t nb = (size_t)nelem_nbr * N2 + (d == 0 ? k * N : k);
-                const int ns = d == 0 ? 1 : N;
-#pragma unroll
-                for (int m = 0; m < N; ++m) {
-                    const double wm = wn[m];
-                    T h = D.q[nb + m * ns];
-                    if (P.has_topo) h = h + P.hsurf[nb + m * ns];
-                    qn[0] += wm * h;
-                    qn[1] += wm * D.q[fs + nb + m * ns];
-                    qn[2] += wm * D.q[2 * fs + nb + m * ns];
-                }
-            } else {
-#pragma unroll
-                for (int v = 0; v < 3; ++v) qn[v] = nbr[v * nstride];
-            }
+            // (never taken: the direct form goes through face_meta + the staged sides)
         } else {
 #pragma unroll
             for (int v = 0; v < 3; ++v) {
@@ -357,8 +449,16 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
         if (!in.valid) return;
         const int le = in.le, f = in.f, k = in.k, d = in.d, plus = in.plus;
         const double sg = in.sg, hdd = in.hdd, hod = in.hod;
-        const T qo[3] = {in.qo[0], in.qo[1], in.qo[2]};
-        const T qn[3] = {in.qn[0], in.qn[1], in.qn[2]};
+        T qo[3] = {in.qo[0], in.qo[1], in.qo[2]};
+        T qn[3] = {in.qn[0], in.qn[1], in.qn[2]};
+        if constexpr (DIRECT) {
+#pragma unroll
+            for (int v = 0; v < 3; ++v) { qo[v] = WX_FSIDE(0, le, f, v, k); qn[v] = WX_FSIDE(1, le, f, v, k); }
+            if (P.has_topo) {  // "substract topo after extrapolation" (rhs_sw.py:153-155), slot by slot
+                qo[0] = qo[0] - in.hs_o;
+                qn[0] = qn[0] - in.hs_n;
+            }
+        }
         T qL[3], qR[3];
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
@@ -391,10 +491,13 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
     fin.valid = false;
     if constexpr (ONE_PASS) {
         if (tid < EPB * 4 * N) face_load(tid, fin);
+    } else if constexpr (DIRECT_ONE) {
+        face_flux(fin_d);
     } else {
         for (int fi = tid; fi < EPB * 4 * N; fi += BS) {
             FaceInSw in;
-            face_load(fi, in);
+            if constexpr (DIRECT) face_meta(fi, in);
+            else face_load(fi, in);
             face_flux(in);
         }
     }
@@ -417,9 +520,18 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
         c201 = P.c201[o]; c202 = P.c202[o]; c212 = P.c212[o]; c222 = P.c222[o];
         if (P.has_topo) { dz1 = P.dz1[o]; dz2 = P.dz2[o]; }
     };
-    if (active) {   // every load of the point stage, issued together (LEAN: the state and the metric tensor only)
-        if constexpr (DIRECT) { q0 = dq0; q1 = dq1; q2 = dq2; }
-        else { q0 = D.q[o]; q1 = D.q[fs + o]; q2 = D.q[2 * fs + o]; }
+    if constexpr (DIRECT) {   // (everything was loaded at the top of the kernel)
+        if (active) {
+            q0 = dq0; q1 = dq1; q2 = dq2;
+            sg = e_sg; h11 = e_h11; h12 = e_h12; h21 = e_h21; h22 = e_h22;
+            if constexpr (!LEAN) {
+                c101 = e_c[0]; c102 = e_c[1]; c111 = e_c[2]; c112 = e_c[3];
+                c201 = e_c[4]; c202 = e_c[5]; c212 = e_c[6]; c222 = e_c[7];
+                dz1 = e_dz1; dz2 = e_dz2;
+            }
+        }
+    } else if (active) {   // every load of the point stage, issued together (LEAN: the state and the metric tensor only)
+        q0 = D.q[o]; q1 = D.q[fs + o]; q2 = D.q[2 * fs + o];
         sg = P.sg[o];
         h11 = P.h11[o]; h12 = P.h12[o]; h21 = P.h21[o]; h22 = P.h22[o];
         if constexpr (!LEAN) load_forcing_fields();
@@ -521,26 +633,27 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
         __syncthreads();
         sw_extrap_faces<N, T>(P, fld, bx * EPB, D.count, D.region, sw_slot<T>(P, 1 - D.slot));
     }
+#undef WX_FSIDE
 }
 
-// one tile per launch: parameters by value
-template <int N, typename T>
-__global__ __launch_bounds__(Cfg2<N>::BS) void sw_extrap_kernel(const SwParams<T> P, const SwDyn<T> D) {
-    sw_extrap_body<N, T>(P, D);
-}
 // which instantiations take the lean schedule (and the occupancy it is made for)
 template <int N, typename T, bool PIPE>
 constexpr bool sw_lean() { return WX_SW_LEAN && std::is_same<T, double>::value && !PIPE && Cfg2<N>::EPB * 4 * N <= Cfg2<N>::BS && N >= 6; }
 template <int N, typename T, bool PIPE>
 constexpr int sw_waves() { return sw_lean<N, T, PIPE>() ? kSwLeanWaves : kSwWaves; }
 
+// one tile per launch: parameters by value
+template <int N, typename T>
+__global__ __launch_bounds__(Cfg2<N>::BS) void sw_extrap_kernel(const SwParams<T> P, const SwDyn<T> D) {
+    sw_extrap_body<N, T>(P, D);
+}
 template <int N, typename T, bool PIPE>
 __global__ __launch_bounds__(Cfg2<N>::BS, (sw_waves<N, T, PIPE>())) void sw_rhs_kernel(const SwParams<T> P, const SwDyn<T> D) {
     sw_rhs_body<N, T, PIPE, false, sw_lean<N, T, PIPE>()>(P, D);
 }
 template <int N, typename T>
-__global__ __launch_bounds__(Cfg2<N>::BS, kSwWaves) void sw_rhs_direct_kernel(const SwParams<T> P, const SwDyn<T> D) {
-    sw_rhs_body<N, T, false, true>(P, D);
+__global__ __launch_bounds__(Cfg2<N>::BS, (sw_waves<N, T, false>())) void sw_rhs_direct_kernel(const SwParams<T> P, const SwDyn<T> D) {
+    sw_rhs_body<N, T, false, true, sw_lean<N, T, false>()>(P, D);
 }
 // the tile-edge lines alone (the ring of elements on the four tile edges): what the direct form still has to exchange
 template <int N, typename T>
@@ -579,12 +692,12 @@ __global__ __launch_bounds__(Cfg2<N>::BS) void sw_extrap_ring_batch_kernel(const
     sw_extrap_ring_body<N, T>(PB[blockIdx.y], D);
 }
 template <int N, typename T>
-__global__ __launch_bounds__(Cfg2<N>::BS, kSwWaves) void sw_rhs_direct_batch_kernel(const SwParams<T>* __restrict__ PB, const T* q, T* rhs,
+__global__ __launch_bounds__(Cfg2<N>::BS, (sw_waves<N, T, false>())) void sw_rhs_direct_batch_kernel(const SwParams<T>* __restrict__ PB, const T* q, T* rhs,
                                                                          size_t stride, int count, int region, int axpy,
                                                                          const T* y, double ca, double cb, double cc) {
     SwDyn<T> D{q + (size_t)blockIdx.y * stride, rhs + (size_t)blockIdx.y * stride, count, region, axpy,
                y ? y + (size_t)blockIdx.y * stride : nullptr, ca, cb, cc, 0, 0};
-    sw_rhs_body<N, T, false, true>(PB[blockIdx.y], D);
+    sw_rhs_body<N, T, false, true, sw_lean<N, T, false>()>(PB[blockIdx.y], D);
 }
 // several tiles (the panels one rank owns) per launch: blockIdx.y selects the tile's static parameters
 // from a device-resident table; states/results are slices of one stacked array

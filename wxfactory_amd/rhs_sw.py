@@ -251,11 +251,22 @@ class RhsShallowWater(PanelRhs):
 
     batched = True
     overlapped_entry = "wx_sw_rhs_overlapped"
-    supports_pipeline = True
+
+    @property
+    def supports_pipeline(self) -> bool:
+        """The stage pipeline (wx_sw_stage: the stage's kernel extrapolates its own output) pays where an evaluation takes two
+        launches; where the direct form is taken a fused stage is one launch already, and faster (S7: 49 against 54 us)."""
+        return not self._use_direct(torch.float64)
     # the direct form (no interface buffer: ring-only pack, then ONE launch; wx_sw_rhs_direct): bit-identical to the two-kernel
-    # form and, at S7, within the +-3 % the boxes of the pool differ by - ahead on one, behind on the next (alternating rounds,
-    # profiles/r04_flat_to_global_ab.txt) - so the two-kernel form stays the default; True: forced
-    direct = False
+    # form.  None = automatic: taken for float64 states at n = 8, where it is measured ahead since its face stage is spread
+    # over all threads and its independent loads are issued before the first barrier (S7: 49 against 53-58 us,
+    # profiles/r05_sw_s7_ab.txt); True / False: forced
+    direct = None
+
+    def _use_direct(self, dtype) -> bool:
+        if self.direct is not None:
+            return bool(self.direct)
+        return dtype == torch.float64 and self.panel_shape is not None and self.panel_shape[3] == 64
 
     def _pipe_state(self, dtype):
         """The stage pipeline's ping-pong state of one dtype: slot in use, the tensor whose faces are prepared, the two
@@ -345,7 +356,7 @@ class RhsShallowWater(PanelRhs):
             self._batches[dt] = SwBatch(plans, ex)
         b = self._batches[dt]
         out = torch.empty_like(q)
-        if self.direct:
+        if self._use_direct(dt):
             b.extrap_pack_ring(q)
             self._phases(ex, lambda region: b.rhs_direct(q, out, region, y, coef))
             return out
