@@ -318,6 +318,14 @@ wx_status wx_euler3d_jvp(wx_euler3d_plan* plan, const double* q, const double* v
 wx_status wx_euler3d_jvp_prepare(wx_euler3d_plan* pl, const double* q, void* const send_val[4], wx_stream stream);
 wx_status wx_euler3d_jvp_tangent_extrap_pack(wx_euler3d_plan* pl, const double* q, const double* v, double eps,
                                              void* const send_tan[4], wx_stream stream);
+/* ... with the tangent CORRECTED IN PLACE first (KIOPS on long vectors: the subtraction and the norm of the previous Krylov
+ * vector's incomplete orthogonalisation, solvers/kiops.py:176-207, folded into the kernel that reads the whole vector anyway):
+ * v <- v - h[0] s[0] row0 [- h[1] s[1] row1]  (h, s: device memory, s NULL = 1; row1 NULL: one row; the order of
+ * wx_kiops_long_b), then extrapolated; |v|^2 is left as wx_euler3d_jvp_workgroups(plan, WX_REGION_ALL) partial sums in
+ * `partials` (wx_kiops_long_b_fold_finish sums them).  row0 NULL: the plain call. */
+wx_status wx_euler3d_jvp_tangent_extrap_pack_fix(wx_euler3d_plan* pl, const double* q, double* v, double eps,
+                                                 void* const send_tan[4], const double* row0, const double* row1,
+                                                 const double* h, const double* s, double* partials, wx_stream stream);
 wx_status wx_euler3d_jvp_prepared(wx_euler3d_plan* pl, const double* q, const double* v, double eps,
                                   const void* const halo_val[4], const void* const halo_tan[4], double* out, double scale,
                                   wx_region region, wx_stream stream);
@@ -699,6 +707,12 @@ wx_status wx_kiops_long_a_finish(double* V, size_t ldv, int j, size_t n, int p, 
                                  double* dots, double* workspace, const double* scales, wx_stream stream);
 wx_status wx_kiops_long_b_scaled(double* V, size_t ldv, int j, size_t n, int p, int iop, const double* h, double* nrm2,
                                  double* workspace, const double* scales, wx_stream stream);
+/* ... when the subtraction and the norm of row j were done by the NEXT product's tangent extrapolation
+ * (wx_euler3d_jvp_tangent_extrap_pack_fix: `nblocks` partial squared norms in `partials`): *nrm2 = their sum over the n-long part,
+ * the p augmented components of row j corrected with the same coefficients h[0 .. nr-1]; the caller all-reduces nrm2, adds
+ * the augmented components' share and calls wx_kiops_long_c_lazy, as after wx_kiops_long_b_scaled. */
+wx_status wx_kiops_long_b_fold_finish(double* V, size_t ldv, int j, size_t n, int p, int iop, const double* h,
+                                      const double* partials, size_t nblocks, double* nrm2, double* workspace, wx_stream stream);
 wx_status wx_kiops_long_c_lazy(double* V, size_t ldv, int j, size_t n, int p, const double* nrm2, double* hcol, double* scales,
                                wx_stream stream);
 wx_status wx_multi_dot2(const double* V, size_t ldv, int m, const double* a, const double* b, size_t n, double* out,

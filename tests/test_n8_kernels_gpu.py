@@ -365,13 +365,14 @@ def test_n8_kiops_long_build_lets_the_matvec_form_the_vector(callers8, monkeypat
     vec = torch.zeros((2, R.numel()), dtype=torch.float64, device=DEV)
     vec[1] = R.flatten()
     monkeypatch.setattr(solvers.KiopsWorkspace, "max_fused_len", 4096)   # (make this length count as long)
-    stored, with_products = [0], [0]
+    stored, with_products, folded = [0], [0], [0]
     plain = ComplexStepOperator.axpy_into
 
-    def counting(self, *a):
-        done = plain(self, *a)
+    def counting(self, *a, **k):
+        done = plain(self, *a, **k)
         stored[0] += 1 if done else 0
         with_products[0] += isinstance(done, tuple)
+        folded[0] += "fix" in k
         return done
 
     monkeypatch.setattr(ComplexStepOperator, "axpy_into", counting)
@@ -379,8 +380,21 @@ def test_n8_kiops_long_build_lets_the_matvec_form_the_vector(callers8, monkeypat
     try:
         op = ComplexStepOperator(dt, Q, R, rhs)
         assert rhs._jvp_is_prepared(Q) and rhs.jvp_fuses_store(Q)
+        assert op.fold_ready()
         phiv, stats = kiops([1], op, vec, tol=1e-7, m_init=1, mmin=16, mmax=64)
         assert stored[0] == with_products[0] == int(stats[2]), (stored, with_products, stats)   # every Krylov vector of the solve
+        # ... and the last stage of every vector but the last of a pass - the subtraction of its projections and its norm - rode
+        # on the NEXT product's tangent extrapolation (wx_euler3d_jvp_tangent_extrap_pack_fix): no sweep of its own
+        passes = int(stats[3])   # (at most one pass of new vectors per matrix exponential; its last vector completes itself)
+        assert int(stats[2]) - passes <= folded[0] < int(stats[2]), (folded, stats)
+        monkeypatch.setenv("WXHIP_KIOPS_FOLD", "0")            # every vector completes its own last stage (wx_kiops_long_b_scaled)
+        before = folded[0]
+        phivf, statsf = kiops([1], op, vec, tol=1e-7, m_init=1, mmin=16, mmax=64)
+        monkeypatch.delenv("WXHIP_KIOPS_FOLD")
+        assert folded[0] == before and stored[0] == with_products[0] == 2 * int(stats[2])
+        assert [int(statsf[i]) for i in (0, 1, 2, 3, 5)] == [int(stats[i]) for i in (0, 1, 2, 3, 5)], (statsf, stats)
+        assert float((phivf - phiv).abs().max()) <= 1e-9 * float(phiv.abs().max())
+        stored[0] = with_products[0] = int(stats[2])
         monkeypatch.setenv("WXHIP_KIOPS_STORE_DOTS", "0")      # the vector from the store, its products from a sweep
         phiv1, stats1 = kiops([1], op, vec, tol=1e-7, m_init=1, mmin=16, mmax=64)
         assert stored[0] == 2 * int(stats[2]) and with_products[0] == int(stats[2])

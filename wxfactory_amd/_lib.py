@@ -118,6 +118,8 @@ SIGNATURES = {
     "wx_kiops_long_b_scaled": (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p]),
     "wx_kiops_long_c_lazy": (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wx_kiops_long_b_fold_finish": (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p,
+                                            c_void_p, c_void_p]),
     "wx_multi_dot2": (c_int, [c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "wx_pair_update": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_size_t, c_double,
                                c_double, c_double, c_void_p]),
@@ -139,6 +141,8 @@ SIGNATURES = {
                                               c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wx_euler3d_jvp_prepare": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p]),
     "wx_euler3d_jvp_tangent_extrap_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_double, POINTER(c_void_p), c_void_p]),
+    "wx_euler3d_jvp_tangent_extrap_pack_fix": (c_int, [c_void_p, c_void_p, c_void_p, c_double, POINTER(c_void_p), c_void_p,
+                                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wx_euler3d_jvp_prepared": (c_int, [c_void_p, c_void_p, c_void_p, c_double, POINTER(c_void_p), POINTER(c_void_p), c_void_p,
                                         c_double, c_int, c_void_p]),
     "wx_euler3d_jvp_prepared_axpy": (c_int, [c_void_p, c_void_p, c_void_p, c_double, POINTER(c_void_p), POINTER(c_void_p), c_void_p,

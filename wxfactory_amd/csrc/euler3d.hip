@@ -93,6 +93,7 @@ EulerParams<T> make_params(const wx_euler3d_plan* pl) {
     P.K = pl->consts;
     P.stamps = pl->stamps;
     P.jz = nullptr; P.jzs = nullptr; P.jza = nullptr; P.jr0 = nullptr; P.jr1 = nullptr; P.jpart = nullptr;
+    P.tc_r0 = nullptr; P.tc_r1 = nullptr; P.tch = nullptr; P.tcs = nullptr; P.tc_out = nullptr; P.tc_part = nullptr;
     P.sg = b.sg; P.h = b.h; P.chr = b.chr; P.idz = b.idz;
     P.sgi = b.sgi; P.sgj = b.sgj; P.sgk = b.sgk; P.hi = b.hi; P.hj = b.hj; P.hk = b.hk;
     P.dcoef = b.dcoef; P.duref = b.duref; P.bsn = b.bsn; P.bwe = b.bwe;
@@ -478,7 +479,17 @@ wx_status wx_euler3d_jvp_prepare(wx_euler3d_plan* pl, const double* q, void* con
 // extrapolated in log space.
 wx_status wx_euler3d_jvp_tangent_extrap_pack(wx_euler3d_plan* pl, const double* q, const double* v, double eps,
                                              void* const send_tan[4], wx_stream stream) {
+    return wx_euler3d_jvp_tangent_extrap_pack_fix(pl, q, const_cast<double*>(v), eps, send_tan, nullptr, nullptr, nullptr, nullptr,
+                                                  nullptr, stream);
+}
+
+// ... with the tangent corrected in place first: v <- v - h[0] s[0] row0 [- h[1] s[1] row1] (h, s: device memory; s null: 1;
+// row1 null: one row), |v|^2 left as wx_euler3d_jvp_workgroups(plan, WX_REGION_ALL) partial sums in `partials`.
+wx_status wx_euler3d_jvp_tangent_extrap_pack_fix(wx_euler3d_plan* pl, const double* q, double* v, double eps,
+                                                 void* const send_tan[4], const double* row0, const double* row1,
+                                                 const double* h, const double* s, double* partials, wx_stream stream) {
     if (!pl || !q || !v) return fail(WX_ERR_INVALID, "wx_euler3d_jvp_tangent_extrap_pack: null argument");
+    if (row0 && (!h || !partials)) return fail(WX_ERR_INVALID, "wx_euler3d_jvp_tangent_extrap_pack_fix: rows without coefficients / partials");
     if (pl->dtype != WX_DUAL128) return fail(WX_ERR_INVALID, "wx_euler3d_jvp_*: the plan must be WX_DUAL128");
     if (!pl->face_val) return fail(WX_ERR_INVALID, "wx_euler3d_jvp_tangent_extrap_pack: call wx_euler3d_jvp_prepare first");
     EulerParams<dual> P = make_params<dual>(pl);
@@ -488,15 +499,18 @@ wx_status wx_euler3d_jvp_tangent_extrap_pack(wx_euler3d_plan* pl, const double* 
         P.send_s = static_cast<dual*>(send_tan[0]); P.send_n = static_cast<dual*>(send_tan[1]);
         P.send_w = static_cast<dual*>(send_tan[2]); P.send_e = static_cast<dual*>(send_tan[3]);
     }
+    const bool fix = row0 != nullptr;
+    if (fix) { P.tc_r0 = row0; P.tc_r1 = row1; P.tch = h; P.tcs = s; P.tc_out = v; P.tc_part = partials; }
     WX_STREAM(st, stream);
     const int nelem = (int)pl->nelem;
 #define WX_TAN_CASE(NN)                                                                                                \
-    case NN:                                                                                                           \
-        hipLaunchKernelGGL((euler_tan_extrap_kernel<NN>),                                                              \
-                           grid3_for<NN>() ? region_grid(WX_REGION_ALL, pl->H, pl->V)                                   \
-                                             : dim3((nelem + Cfg<NN>::EPB - 1) / Cfg<NN>::EPB),                        \
-                           dim3(Cfg<NN>::BS), 0, st, P);                                                               \
-        break;
+    case NN: {                                                                                                         \
+        const dim3 grid = grid3_for<NN>() ? region_grid(WX_REGION_ALL, pl->H, pl->V)                                    \
+                                          : dim3((nelem + Cfg<NN>::EPB - 1) / Cfg<NN>::EPB);                           \
+        if (fix) hipLaunchKernelGGL((euler_tan_extrap_kernel<NN, true>), grid, dim3(Cfg<NN>::BS), 0, st, P);            \
+        else hipLaunchKernelGGL((euler_tan_extrap_kernel<NN, false>), grid, dim3(Cfg<NN>::BS), 0, st, P);              \
+        break;                                                                                                         \
+    }
     switch (pl->n) {
         WX_TAN_CASE(2) WX_TAN_CASE(3) WX_TAN_CASE(4) WX_TAN_CASE(5) WX_TAN_CASE(6) WX_TAN_CASE(7) WX_TAN_CASE(8)
         default: return fail(WX_ERR_UNSUPPORTED, "num_solpts %d not in 2..8", pl->n);

@@ -120,6 +120,15 @@ struct EulerParams {
     // against; jr1 nullable), summed over the workgroup: jpart[2 * w + r], w = the workgroup's linear index in the launch
     pp<T, const double, G> jr0, jr1;
     double* jpart;
+    // tangent extrapolation with the input CORRECTED IN PLACE first (KIOPS: the subtraction and the norm of the previous Krylov
+    // vector's orthogonalisation, solvers/kiops.py:176-207, done by the kernel that reads the whole vector anyway):
+    // t <- t - tch[0] * tcs[0] * tc_r0 [- tch[1] * tcs[1] * tc_r1], written back to tc_out (= q_tan's buffer), |t|^2 summed per
+    // workgroup into tc_part[linear workgroup index].  tc_r0 null: off.  tcs null: scales 1.
+    pp<T, const double, G> tc_r0, tc_r1;
+    const double* tch;
+    const double* tcs;
+    double* tc_out;
+    double* tc_part;
     unsigned long long* stamps;  // WX_K2_DIAG == 1 only, else null
 };
 

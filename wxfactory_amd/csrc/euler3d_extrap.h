@@ -121,11 +121,14 @@ __global__ __launch_bounds__(Cfg<N>::BS, kK1Waves) void euler_extrap_kernel(cons
 // five 16-byte ones: 32 KB of LDS instead of 46 (n = 8), no value parts carried for the momentum rows - 0.283 -> 0.235 ms per
 // E7 panel (5.4 TB/s, the float64 K1's rate), bit-identical tangents (the prepared and unprepared products still agree to
 // the last bit: tests/test_n8_kernels_gpu.py).
-template <int N>
+// FIX: the tangent is corrected in place before it is used (EulerParams: tc_*): w = t - cs0 r0 - cs1 r1 in kiops_long_b's order
+// (csrc/krylov.hip), written back, its squared norm left as one partial sum per workgroup
+template <int N, bool FIX>
 __global__ __launch_bounds__(Cfg<N>::BS, kK1Waves) void euler_tan_extrap_kernel(const EulerParams<dual> P) {
     using C = Cfg<N>;
     constexpr int N2 = C::N2, N3 = C::N3, EPB = C::EPB, BS = C::BS;
     __shared__ double pl[7][EPB * C::LE];
+    __shared__ double red[FIX ? BS / 64 : 1];
     const int tid = threadIdx.x;
     __builtin_assume(tid < (int)Cfg<N>::BS);   // (the launch bounds: lets one-element workgroups drop their `le < EPB` guards)
     const int H = P.H, V = P.V;
@@ -133,22 +136,51 @@ __global__ __launch_bounds__(Cfg<N>::BS, kK1Waves) void euler_tan_extrap_kernel(
     {
         const int le = tid / N3, pt = tid % N3;
         const Elem el = decode_blk<EPB, grid3_for<N>()>(P, blockIdx.x * EPB + le, P.nelem, WX_REGION_ALL);
+        double nn = 0.0;
         if (le < EPB && el.valid) {
             const size_t o = (size_t)el.e * N3 + pt;
             const int lp = le * C::LE + C::lidx(pt / N2, (pt / N) % N, pt % N);
             const auto r = P.q_re, t = P.q_tan;
             const double e = P.jvp_eps;
             const double r0 = r[o], r4 = r[4 * fs + o];
+            double tv[5] = {t[o], t[fs + o], t[2 * fs + o], t[3 * fs + o], t[4 * fs + o]};
+            if constexpr (FIX) {
+                const auto a0 = P.tc_r0, a1 = P.tc_r1;
+                const double cs0 = P.tcs ? P.tch[0] * P.tcs[0] : P.tch[0];
+                const double cs1 = a1 != nullptr ? (P.tcs ? P.tch[1] * P.tcs[1] : P.tch[1]) : 0.0;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    double w = tv[k];
+                    w -= cs0 * a0[k * fs + o];
+                    if (a1 != nullptr) w -= cs1 * a1[k * fs + o];
+                    P.tc_out[k * fs + o] = w;
+                    nn += w * w;
+                    tv[k] = w;
+                }
+            }
             pl[0][lp] = log(r0);
-            pl[1][lp] = (e * t[o]) / r0;
-            pl[2][lp] = e * t[fs + o];
-            pl[3][lp] = e * t[2 * fs + o];
-            pl[4][lp] = e * t[3 * fs + o];
+            pl[1][lp] = (e * tv[0]) / r0;
+            pl[2][lp] = e * tv[1];
+            pl[3][lp] = e * tv[2];
+            pl[4][lp] = e * tv[3];
             pl[5][lp] = log(r4);
-            pl[6][lp] = (e * t[4 * fs + o]) / r4;
+            pl[6][lp] = (e * tv[4]) / r4;
+        }
+        if constexpr (FIX) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) nn += __shfl_down(nn, off, 64);
+            if ((tid & 63) == 0) red[tid >> 6] = nn;
         }
     }
     __syncthreads();
+    if constexpr (FIX) {
+        if (tid == 0) {
+            double tsum = 0.0;
+#pragma unroll
+            for (int w = 0; w < BS / 64; ++w) tsum += red[w];
+            P.tc_part[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = tsum;
+        }
+    }
     for (int fi = tid; fi < EPB * 6 * N2; fi += BS) {
         const int le = fi / (6 * N2);
         const int r = fi % (6 * N2);

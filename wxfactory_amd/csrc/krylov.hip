@@ -359,6 +359,31 @@ __global__ __launch_bounds__(256) void kiops_long_a_finish_kernel(double* __rest
     }
 }
 
+// the subtraction and the norm of row j done by the NEXT product's tangent-extrapolation kernel (euler_tan_extrap_kernel<N, true>:
+// one partial squared norm per workgroup): summed here in a fixed order in two steps, and the p augmented components of the
+// row corrected with the same coefficients (kiops_long_b's order)
+__global__ __launch_bounds__(256) void kiops_fold_sum1(const double* __restrict__ part, size_t nblocks, double* __restrict__ tmp) {
+    __shared__ double red[4];
+    const size_t chunk = (nblocks + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * chunk;
+    const size_t hi = lo + chunk < nblocks ? lo + chunk : nblocks;
+    double v = 0.0;
+    for (size_t b = lo + threadIdx.x; b < hi; b += 256) v += part[b];
+    const double t = wg_sum256(v, red);
+    if (threadIdx.x == 0) tmp[blockIdx.x] = t;
+}
+__global__ __launch_bounds__(256) void kiops_fold_finish_kernel(double* __restrict__ V, size_t ldv, int j, size_t n, int p, int ilow,
+                                                                 int nr, const double* __restrict__ h, const double* __restrict__ tmp,
+                                                                 double* __restrict__ nrm2) {
+    __shared__ double red[4];
+    const double t = wg_sum256((int)threadIdx.x < kFinishStage1 ? tmp[threadIdx.x] : 0.0, red);
+    if (threadIdx.x == 0) *nrm2 = t;
+    if ((int)threadIdx.x < p) {
+        double w = V[(size_t)j * ldv + n + threadIdx.x];
+        for (int r = 0; r < nr; ++r) w -= h[r] * V[(size_t)(ilow + r) * ldv + n + threadIdx.x];
+        V[(size_t)j * ldv + n + threadIdx.x] = w;
+    }
+}
+
 // lazy normalisation: the augmented components of row j scaled, hcol[j] = |V[j]|, scales[j] = 1 / |V[j]|; the n-long part stays
 __global__ void kiops_long_c_lazy(double* __restrict__ V, size_t ldv, int j, size_t n, int p, const double* __restrict__ nrm2,
                                   double* __restrict__ hcol, double* __restrict__ scales) {
@@ -699,6 +724,19 @@ wx_status wx_kiops_long_a_finish(double* V, size_t ldv, int j, size_t n, int p, 
     WX_STREAM(st, stream);
     hipLaunchKernelGGL(kiops_long_a_finish1, dim3(kFinishStage1, nr), dim3(256), 0, st, partials, nblocks, workspace);
     hipLaunchKernelGGL(kiops_long_a_finish_kernel, dim3(nr), dim3(256), 0, st, V, ldv, j, n, p, ilow, workspace, dots, scales);
+    WX_HIP_TRY(hipGetLastError());
+    return WX_OK;
+}
+
+wx_status wx_kiops_long_b_fold_finish(double* V, size_t ldv, int j, size_t n, int p, int iop, const double* h,
+                                      const double* partials, size_t nblocks, double* nrm2, double* workspace, wx_stream stream) {
+    wx_status s = kiops_long_check(V, j, p, iop, ldv, n, "wx_kiops_long_b_fold_finish");
+    if (s != WX_OK) return s;
+    if (!h || !partials || !nrm2 || !workspace || nblocks == 0) return fail(WX_ERR_INVALID, "wx_kiops_long_b_fold_finish: null argument");
+    const int ilow = j - iop > 0 ? j - iop : 0, nr = j - ilow;
+    WX_STREAM(st, stream);
+    hipLaunchKernelGGL(kiops_fold_sum1, dim3(kFinishStage1), dim3(256), 0, st, partials, nblocks, workspace);
+    hipLaunchKernelGGL(kiops_fold_finish_kernel, dim3(1), dim3(256), 0, st, V, ldv, j, n, p, ilow, nr, h, workspace, nrm2);
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
 }

@@ -104,12 +104,26 @@ class ComplexStepOperator:
     def __call__(self, vec: torch.Tensor) -> torch.Tensor:
         return matvec_fun(vec, self.dt, self.Q, self.rhs, self.rhs_handle, self.method)
 
-    def axpy_into(self, vec: torch.Tensor, out: torch.Tensor, z: torch.Tensor, z_scale: int, z_coef: int, rows=None):
+    def fold_ready(self) -> bool:
+        """True when axpy_into(..., rows=, fix=) is available: the product runs on the prepared per-tile kernels, whose
+        tangent-extrapolation launch can first correct its input vector in place (KIOPS on long vectors: the subtraction and
+        the norm of the previous vector's orthogonalisation without a sweep of their own)."""
+        h = self.rhs_handle
+        fuses = getattr(h, "jvp_fuses_store", None)
+        return bool(self.method == "complex" and fuses is not None and getattr(h, "supports_jvp", False)
+                    and getattr(h, "fused_jvp", True) and getattr(h, "jvp_supports_fix", False)
+                    and hasattr(h, "jvp_partials_capacity") and isinstance(self.Q, torch.Tensor) and self.Q.is_contiguous()
+                    and fuses(self.Q))
+
+    def axpy_into(self, vec: torch.Tensor, out: torch.Tensor, z: torch.Tensor, z_scale: int, z_coef: int, rows=None, fix=None):
         """out = *z_scale * (A vec) + *z_coef * z formed in the product's own store (the two coefficients: device addresses of
         one double each, z_scale 0 = 1) - KIOPS' V[j] = A V[j-1] + u a (solvers/kiops.py:170-176) without a sweep of its own.
         False (nothing done) when this product does not run on the kernels that offer the store; True when it is done;
         with `rows` (one or two contiguous vectors like out): (partials, count) - the launches have left the products
-        <row, out> as `count` pairs of partial sums in the device tensor `partials` (wx_kiops_long_a_finish sums them)."""
+        <row, out> as `count` pairs of partial sums in the device tensor `partials` (wx_kiops_long_a_finish sums them).
+        `fix` (only with rows, only when fold_ready()): dict(rows=, h=, s=, between=) - `vec` is corrected in place first,
+        vec -= h[k] s[k] fix_rows[k], and between(partials_tensor, count) is called on the stream between that and the
+        product (RhsEuler3D.jvp(fix=))."""
         h = self.rhs_handle
         fuses = getattr(h, "jvp_fuses_store", None)
         if (self.method != "complex" or fuses is None or not getattr(h, "supports_jvp", False) or not getattr(h, "fused_jvp", True)
@@ -120,9 +134,18 @@ class ComplexStepOperator:
             part = getattr(h, "_jvp_partials_buf", None)   # (kept by the RHS object: one address from solve to solve)
             if part is None or part.device != out.device or part.numel() < h.jvp_partials_capacity():
                 part = h._jvp_partials_buf = torch.empty(h.jvp_partials_capacity(), dtype=torch.float64, device=out.device)
+            jfix = None
+            if fix is not None:
+                fpart = getattr(h, "_jvp_fix_buf", None)
+                if fpart is None or fpart.device != out.device or fpart.numel() < h.jvp_fix_capacity():
+                    fpart = h._jvp_fix_buf = torch.empty(h.jvp_fix_capacity(), dtype=torch.float64, device=out.device)
+                jfix = dict(rows=fix["rows"], h=fix["h"], s=fix["s"], part=fpart,
+                            between=lambda count: fix["between"](fpart, count))
             h.jvp(self.Q, vec.reshape(self.Q.shape), EPS_COMPLEX, self.dt / EPS_COMPLEX, out=out, z=z, z_scale=z_scale,
-                  z_coef=z_coef, rows=rows, partials=part)
+                  z_coef=z_coef, rows=rows, partials=part, **({"fix": jfix} if jfix is not None else {}))
             return part, h.jvp_partials_written
+        if fix is not None:
+            raise RuntimeError("axpy_into(fix=) needs rows= and an operator that is fold_ready()")
         h.jvp(self.Q, vec.reshape(self.Q.shape), EPS_COMPLEX, self.dt / EPS_COMPLEX, out=out, z=z, z_scale=z_scale, z_coef=z_coef)
         return True
 

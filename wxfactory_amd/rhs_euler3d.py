@@ -299,11 +299,22 @@ class Euler3DPlan:
         st = torch.cuda.current_stream(self.device).cuda_stream
         check(self.lib.wx_euler3d_jvp_prepare(self._h, q.data_ptr(), _ptr_array(send_val), st), "wx_euler3d_jvp_prepare")
 
-    def jvp_tangent_pack(self, q, v, eps: float, send_tan):
+    def jvp_tangent_pack(self, q, v, eps: float, send_tan, fix=None):
+        """fix = (rows, h_ptr, s_ptr, partials_ptr): v is first corrected IN PLACE, v -= h[0] s[0] rows[0] [+ the second row],
+        its squared norm left as jvp_workgroups() partial sums (wx_euler3d_jvp_tangent_extrap_pack_fix)."""
         self._check_real(q)
         self._check_real(v)
         self.faces_epoch += 1
         st = torch.cuda.current_stream(self.device).cuda_stream
+        if fix is not None:
+            rows, h_ptr, s_ptr, part_ptr = fix
+            for r in rows:
+                self._check_real(r)
+            check(self.lib.wx_euler3d_jvp_tangent_extrap_pack_fix(
+                self._h, q.data_ptr(), v.data_ptr(), eps, _ptr_array(send_tan), rows[0].data_ptr(),
+                rows[1].data_ptr() if len(rows) > 1 else None, h_ptr, s_ptr or None, part_ptr, st),
+                "wx_euler3d_jvp_tangent_extrap_pack_fix")
+            return
         check(self.lib.wx_euler3d_jvp_tangent_extrap_pack(self._h, q.data_ptr(), v.data_ptr(), eps, _ptr_array(send_tan), st),
               "wx_euler3d_jvp_tangent_extrap_pack")
 
@@ -652,6 +663,13 @@ class RhsEuler3D(PanelRhs):
                            plans[p].jvp_workgroups(_lib.WX_REGION_INTERIOR) + plans[p].jvp_workgroups(_lib.WX_REGION_BOUNDARY))
                        for p in self.panels)
 
+    jvp_supports_fix = True   # jvp(fix=): the tangent extrapolation can correct its input in place (KIOPS' deferred stage)
+
+    def jvp_fix_capacity(self) -> int:
+        """doubles that hold the partial squared norms of one product's tangent-extrapolation launches (jvp(fix=))"""
+        plans = self._jvp_plans()
+        return sum(plans[p].jvp_workgroups(_lib.WX_REGION_ALL) for p in self.panels)
+
     def _jvp_plans(self):
         if "jvp" not in self._plans:
             self._plans["jvp"] = {p: pl.twin(torch.complex128, dual=True) for p, pl in self.plans.items()}
@@ -701,14 +719,19 @@ class RhsEuler3D(PanelRhs):
         return lin[0]() is Q and lin[1:] == (Q.data_ptr(), Q._version)
 
     def jvp(self, Q: torch.Tensor, v: torch.Tensor, eps: float, scale: float, out=None, z=None, z_scale: int = 0,
-            z_coef: int = 0, rows=None, partials=None) -> torch.Tensor:
+            z_coef: int = 0, rows=None, partials=None, fix=None) -> torch.Tensor:
         """scale * Im R(Q + i eps v) for stacked real Q, v -> real tensor shaped like Q.  The dual state is
         formed inside the kernels and only the tangent is stored: the complex-step JVP of
         solvers/matvec.py:56-61 without a complex array in HBM.
         PREPARED products only (the caller checks jvp_fuses_store): `out` = a contiguous tensor of Q's size to write into;
         `z` (like out) with the device addresses z_scale / z_coef: out = *z_scale * product + *z_coef * z in the same store;
         `rows` (one or two tensors like out) with `partials` (a float64 device tensor of jvp_partials_capacity() doubles): the
-        launches also leave the products <row, out> as pairs of partial sums, self.jvp_partials_written of them."""
+        launches also leave the products <row, out> as pairs of partial sums, self.jvp_partials_written of them.
+        `fix` = dict(rows=[one or two tensors like v], h=device address of their coefficients, s=device address of the rows'
+        scales or 0, part=a float64 device tensor of jvp_fix_capacity() doubles, between=callable(count)): v - a contiguous
+        tensor the caller owns - is first CORRECTED IN PLACE by the tangent-extrapolation launches (v -= h[k] s[k] rows[k]),
+        which leave |v|^2 as `count` partial sums in `part`; between(count) then runs on the same stream (the caller completes
+        the norm there: KIOPS' deferred orthogonalisation stage) before the product's own launches."""
         np_ = len(self.panels)
         prepared = self._jvp_is_prepared(Q)
         if self.world > 1:
@@ -750,15 +773,25 @@ class RhsEuler3D(PanelRhs):
                 assert 2 * written[0] <= partials.numel()
                 return (zs[i], z_scale, z_coef, [r[i] for r in rs], at)
 
-            for i, p in enumerate(self.panels):
-                plans[p].jvp_tangent_pack(Qs[i], vs[i], eps, ext.send_views(p))
+            if fix is not None:
+                frows = [r.reshape(Qs.shape) for r in fix["rows"]]
+                at = 0
+                for i, p in enumerate(self.panels):
+                    plans[p].jvp_tangent_pack(Qs[i], vs[i], eps, ext.send_views(p),
+                                              ([r[i] for r in frows], fix["h"], fix["s"], fix["part"].data_ptr() + 8 * at))
+                    at += plans[p].jvp_workgroups(_lib.WX_REGION_ALL)
+                assert at <= fix["part"].numel()
+                fix["between"](at)
+            else:
+                for i, p in enumerate(self.panels):
+                    plans[p].jvp_tangent_pack(Qs[i], vs[i], eps, ext.send_views(p))
             self._exchange_and_launch(ext, lambda i, p, halo, region: plans[p].jvp_prepared(
                 Qs[i], vs[i], eps, exv.halo_views(p) if halo is not None else None, halo, out[i], scale, region,
                 *extra(i, p, region)))
             self.jvp_partials_written = written[0]
             return out.reshape(Q.shape)
-        if out is not None or z is not None:
-            raise RuntimeError("jvp(out=, z=): only the prepared product stores into a caller's buffer (jvp_fuses_store)")
+        if out is not None or z is not None or fix is not None:
+            raise RuntimeError("jvp(out=, z=, fix=): only the prepared product stores into a caller's buffer (jvp_fuses_store)")
         ex = self.exchange_for(torch.complex128)
         out = torch.empty_like(Qs)
         if self._small_tiles() and Q.is_contiguous() and v.is_contiguous() and Q.dtype == torch.float64 \

@@ -827,6 +827,15 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
     store_axpy = (getattr(A, "axpy_into", None)
                   if long_build and p == 1 and os.environ.get("WXHIP_KIOPS_STORE_AXPY", "1") != "0" else None)
     store_dots = os.environ.get("WXHIP_KIOPS_STORE_DOTS", "1") != "0"   # ... and its products with the rows it is orthogonalised against
+    # ... and the LAST stage of a vector (the subtraction of its projections and its norm: 4 sweeps of their own) DEFERRED into
+    # the next product, whose tangent-extrapolation kernel reads the whole vector anyway: it corrects it in place and leaves the
+    # norm as partial sums (wx_euler3d_jvp_tangent_extrap_pack_fix + wx_kiops_long_b_fold_finish): one sweep less per vector.
+    # The Hessenberg column of vector j is then complete when vector j + 1 is under way; the last vector of a pass takes the
+    # stage on its own (wx_kiops_long_b_scaled), so the host finds every column complete when it reads them.
+    fold = (lazy and store_axpy is not None and store_dots and iop <= 2 and os.environ.get("WXHIP_KIOPS_FOLD", "1") != "0"
+            and bool(getattr(A, "fold_ready", lambda: False)()))
+    pending = [None]   # the vector whose last stage is outstanding
+    pass_end = [0]     # the last vector of the pass being built
 
     def products(lo: int, hi: int, j: int, out: torch.Tensor):
         """out[k - lo] = <V[k], V[j]> over the n + p components, lo <= k < hi"""
@@ -882,13 +891,45 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
                 ilow = max(0, j - iop)
                 hcol = Ht[j - 1]
                 sc = ws.scales.data_ptr() if lazy else None
+
+                def last_stage(jv, part=None, count=0):
+                    """vector jv: projections subtracted, norm, scale (solvers/kiops.py:186-207) - from the partial norms the
+                    next product's tangent extrapolation left (part), or as a stage of its own"""
+                    il = max(0, jv - iop)
+                    hc = Ht[jv - 1]
+                    if part is not None:
+                        basis.check(lib.wx_kiops_long_b_fold_finish(Vd.data_ptr(), Vd.stride(0), jv, n, p, iop, hc[il:jv].data_ptr(),
+                                                                    part.data_ptr(), count, nrm2.data_ptr(),
+                                                                    ws.finish_work.data_ptr(), st), "wx_kiops_long_b_fold_finish")
+                    else:
+                        basis.check(lib.wx_kiops_long_b_scaled(Vd.data_ptr(), Vd.stride(0), jv, n, p, iop, hc[il:jv].data_ptr(),
+                                                               nrm2.data_ptr(), ws.finish_work.data_ptr(), sc, st), "wx_kiops_long_b")
+                    if split:
+                        _allreduce(nrm2, group)
+                    nrm2.add_(torch.dot(Vd[jv, n:], Vd[jv, n:]))
+                    if lazy:
+                        basis.check(lib.wx_kiops_long_c_lazy(Vd.data_ptr(), Vd.stride(0), jv, n, p, nrm2.data_ptr(), hc.data_ptr(),
+                                                             ws.scales.data_ptr(), st), "wx_kiops_long_c_lazy")
+                    else:
+                        basis.check(lib.wx_kiops_long_c(Vd.data_ptr(), Vd.stride(0), jv, n, p, nrm2.data_ptr(), hc.data_ptr(), st),
+                                    "wx_kiops_long_c")
+
                 # one augmented component, an operator whose product can store a x + b z: the n-long part of row j is formed
                 # by the matvec itself (scale of row j-1 and the augmented component read on the device), one sweep fewer
                 stored = False
                 if store_axpy is not None:
                     rows = [Vd[r, :n] for r in range(ilow, j)] if store_dots and j - ilow <= 2 else None
+                    fixarg = None
+                    if pending[0] is not None:   # (== j - 1: its last stage rides on this product's tangent extrapolation)
+                        jp = pending[0]
+                        ilp = max(0, jp - iop)
+                        fixarg = dict(rows=[Vd[r, :n] for r in range(ilp, jp)], h=Ht[jp - 1][ilp:jp].data_ptr(),
+                                      s=ws.scales[ilp:].data_ptr(), between=lambda part, count, jp=jp: last_stage(jp, part, count))
+                        pending[0] = None
                     stored = store_axpy(Vd[j - 1, :n], Vd[j, :n], u_flip_t, ws.scales[j - 1: j].data_ptr() if lazy else 0,
-                                        Vd[j - 1, n:].data_ptr(), rows)
+                                        Vd[j - 1, n:].data_ptr(), rows, **({"fix": fixarg} if fixarg is not None else {}))
+                    if fixarg is not None and not isinstance(stored, tuple):
+                        raise RuntimeError("kiops: the operator declared fold_ready() but did not take the deferred stage")
                 if isinstance(stored, tuple):   # ... and the products too: nothing left to sweep for this stage
                     part, count = stored
                     basis.check(lib.wx_kiops_long_a_finish(Vd.data_ptr(), Vd.stride(0), j, n, p, iop, part.data_ptr(), count,
@@ -908,17 +949,10 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
                 if split:
                     t = _allreduce(t, group)
                 torch.addmv(t, Vd[ilow:j, n:], Vd[j, n:], out=hcol[ilow:j])   # + the augmented components, once
-                basis.check(lib.wx_kiops_long_b_scaled(Vd.data_ptr(), Vd.stride(0), j, n, p, iop, hcol[ilow:j].data_ptr(),
-                                                       nrm2.data_ptr(), ws.finish_work.data_ptr(), sc, st), "wx_kiops_long_b")
-                if split:
-                    _allreduce(nrm2, group)
-                nrm2.add_(torch.dot(Vd[j, n:], Vd[j, n:]))
-                if lazy:
-                    basis.check(lib.wx_kiops_long_c_lazy(Vd.data_ptr(), Vd.stride(0), j, n, p, nrm2.data_ptr(), hcol.data_ptr(),
-                                                         ws.scales.data_ptr(), st), "wx_kiops_long_c_lazy")
+                if fold and isinstance(stored, tuple) and j < pass_end[0]:
+                    pending[0] = j   # the next product of this pass takes the last stage along
                     return
-                basis.check(lib.wx_kiops_long_c(Vd.data_ptr(), Vd.stride(0), j, n, p, nrm2.data_ptr(), hcol.data_ptr(), st),
-                            "wx_kiops_long_c")
+                last_stage(j)
                 return
             torch.addmv(A(Vd[j - 1, :n]), u_flip_t, Vd[j - 1, n:], out=Vd[j, :n])
             torch.mv(shift, Vd[j - 1, n:], out=Vd[j, n:])  # augmented components: up by one, zero at the end
@@ -931,7 +965,9 @@ def kiops(tau_out, A: Callable, u: torch.Tensor, tol: float = 1e-7, m_init: int 
             Vd[j] /= hcol[j]
 
         if m > j:
+            pass_end[0] = m   # (the last vector of the pass completes its own last stage: nothing is left pending)
             ws.run_pass(j, m, build, use_graphs, group if _reduce.is_comm(group) else None)
+            assert pending[0] is None
             j = m
         if j > j0:
             Hh = Ht[j0:j, : j + 1].cpu().numpy()  # the one synchronisation of the pass
