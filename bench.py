@@ -815,12 +815,21 @@ def main():
         from wxfactory_amd.exchange import RcclComm
 
         why = None
+        # RCCL prints its version banner on STDOUT when NCCL_DEBUG is set (at the first communicator's creation), whatever
+        # NCCL_DEBUG_FILE says: fd 1 points at fd 2 for the duration of the set-up - this program's stdout is the ONE line
+        sys.stdout.flush()
+        keep_fd1 = os.dup(1)
+        os.dup2(2, 1)
         try:
             comm = RcclComm(rank, world, device=dev)   # (the unique id travels through the gloo group; one rank needs none)
             ex = PanelExchange(edge_doubles, dev, rank=rank, world_size=world, tiles_per_side=k, loopback=args.loopback,
                                backend="rccl", comm=comm)
         except Exception as e:   # noqa: BLE001 - reported in the line
             why = f"{type(e).__name__}: {e}"
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep_fd1, 1)
+            os.close(keep_fd1)
         if all_ranks(why is None):
             exchange_report = {"backend": "rccl behind the C ABI (wx_exchange_*: grouped ncclSend / ncclRecv, event fork / join)"}
         else:

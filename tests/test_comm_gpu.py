@@ -298,3 +298,32 @@ def test_pmex_vectors_split_over_ranks_reduce_in_stream_order(comm, p, taus):
     # the per-vector reductions never came back to Python (they are ncclAllReduce calls inside the C function): what Python
     # reduced is the start of each sub-step only (|u|, the first vector's norm)
     assert calls["n"] <= 2 + 2 * st_split[0] + 2 * st_split[1], (calls, st_split)
+
+
+def test_bench_loopback_rehearsal_prints_one_line_and_checks_its_exchange(built_lib):
+    """bench.py --loopback: the several-GPU path of the benchmark on one GPU - a one-rank communicator of the library's own, every
+    edge message through grouped ncclSend / ncclRecv, INTERIOR beside the exchange, no process group of any kind - at a reduced
+    size.  stdout must be exactly ONE JSON line (RCCL's banner goes to stderr), the exchange self-check must have passed against
+    the aliasing route, and the checksum must equal the unsplit run's."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = [sys.executable, os.path.join(root, "bench.py"), "--H", "6", "--V", "2", "--steps", "3", "--warmup", "1", "--no-extras",
+              "--no-cpu-baseline"]
+    lines = {}
+    for name, extra in (("loopback", ["--loopback"]), ("plain", [])):
+        r = subprocess.run(common + extra, capture_output=True, text=True, timeout=400, cwd=root)
+        assert r.returncode == 0, (name, r.stdout[-2000:], r.stderr[-3000:])
+        out = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(out) == 1, (name, out[:5])
+        lines[name] = json.loads(out[0])
+    lb, pl = lines["loopback"], lines["plain"]
+    assert lb["n_gpus"] == 1 and lb["ranks_seen"] == 1 and lb["process_group"] == "none"
+    assert lb["config"]["exchange"]["backend"].startswith("rccl behind the C ABI"), lb["config"]["exchange"]
+    assert "bit-identical" in lb["config"]["exchange"]["selfcheck"], lb["config"]["exchange"]
+    assert lb["hip_runtime_version"] >= 60000000 and lb["rccl_version"] >= 20000
+    for k in ("sum", "abs_sum", "max_abs"):
+        a, b = np.asarray(lb["checksum"][k]), np.asarray(pl["checksum"][k])
+        assert (np.abs(a - b) <= 1e-12 * np.maximum(np.asarray(pl["checksum"]["abs_sum"]), 1e-300)).all(), (k, a, b)
