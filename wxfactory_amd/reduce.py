@@ -35,7 +35,15 @@ def allreduce(t: torch.Tensor, group=None, op: str = "sum") -> torch.Tensor:
             group.allreduce(t, op)
         return t
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(t, op=getattr(dist.ReduceOp, _TORCH_OPS[op]), group=group)
+        red = getattr(dist.ReduceOp, _TORCH_OPS[op])
+        if t.is_cuda and dist.get_backend(group) == "gloo":
+            # a host-only process group and a device tensor: through a host copy (tests and checks; the data path of several
+            # GPUs is the library's communicator above)
+            h = t.cpu()
+            dist.all_reduce(h, op=red, group=group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=red, group=group)
     return t
 
 
