@@ -714,6 +714,9 @@ def main():
                     help="halo exchange of the several-GPU path: 'rccl' = the library's own behind the C ABI (wx_exchange_*: "
                          "grouped ncclSend / ncclRecv on a communication stream, event fork / join; the whole evaluation of a "
                          "rank is one wx_euler3d_rhs_overlapped call), 'torch' = torch.distributed.all_to_all_single")
+    ap.add_argument("--one-device", action="store_true",
+                    help="rehearsal of the several-rank program flow on ONE GPU: every rank uses device 0 (needs --exchange "
+                         "torch - gloo through host copies -: RCCL refuses two ranks on one device); not a measurement")
     ap.add_argument("--metric", choices=("true", "synthetic"), default="true",
                     help="static metric fields: the cubed-sphere metric of the DCMIP 3-1 planet from wxfactory_amd.geometry3d "
                          "(default, SURVEY 8d) or SURVEY's seeded synthetic fields; values do not affect speed")
@@ -739,6 +742,10 @@ def main():
         os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")   # ... on stderr (RCCL's default is stdout: the ONE line's stream)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if args.one_device:
+        if args.exchange != "torch" and world > 1:
+            raise SystemExit("--one-device: RCCL refuses two ranks on one device, use --exchange torch")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -746,7 +753,16 @@ def main():
         # communicator, barriers, the max over ranks, the independent route of the exchange self-check.  NO NCCL process group:
         # the halo exchange and every reduction of the data path run on the library's own communicator (wx_comm_*), and a
         # torch NCCL group would add a watchdog thread issuing HIP calls beside the captures (profiles/r05_process_group_abort.md)
-        dist.init_process_group("gloo")
+        # (gloo announces its connections on STDOUT: fd 1 points at fd 2 meanwhile - this program's stdout is the ONE line)
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo")
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep, 1)
+            os.close(keep)
 
     from wxfactory_amd import _lib, synthetic
     from wxfactory_amd.exchange import PanelExchange
@@ -1113,6 +1129,8 @@ def main():
             "hip_runtime_version": _lib.load().wx_hip_runtime_version(),   # what the process BOUND (inside torch: the wheel's)
             "process_group": "gloo (host side only: id bootstrap, barriers, max over ranks); no NCCL process group" if world > 1
                              else "none",
+            **({"rehearsal": "--one-device: every rank on GPU 0, halos through gloo and host copies - program flow only, NOT a "
+                             "measurement"} if args.one_device else {}),
             "config": {"workload": f"E7: 3-D Euler RHS, n={n} (p={n-1}), H={H}x{H} elem/panel, V={V}, 6 panels "
                                    f"({5*pts_panel*6} DOF), halo exchange included",
                        "n": n, "H": H, "V": V, "tiles": topo.ntiles, "tile_H": Ht, "tiles_per_gpu": len(mine),

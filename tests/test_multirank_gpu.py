@@ -200,3 +200,35 @@ def test_four_real_ranks_on_the_24_tile_layout(built_lib):
     res = [q.get(timeout=500) for _ in range(world)]
     [p.join(timeout=60) for p in procs]
     assert all(r[1] == "ok" for r in res), [r for r in res if r[1] != "ok"]
+
+
+@pytest.mark.parametrize("gpus", [2, 4])
+def test_bench_program_flow_over_several_ranks(built_lib, gpus):
+    """`python bench.py --gpus N` end to end with N real ranks (started by bench.py itself through torch.distributed.run), on
+    ONE device (--one-device: every rank on GPU 0, halos through gloo and host copies): the gloo process group, the
+    decomposition (whole panels at 2, the 24-tile layout at 4), the timed loop between barriers, the max over ranks, the
+    all-reduced checksum, the gathered per-rank phase rows, ONE line on rank 0's stdout - everything of the several-GPU
+    benchmark but the RCCL transport.  The checksum must equal the one-rank run's."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--H", "6", "--V", "2", "--steps", "3", "--warmup", "1", "--no-extras", "--no-cpu-baseline"]
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=400, cwd=root)
+    assert r1.returncode == 0, (r1.stdout[-1500:], r1.stderr[-3000:])
+    one = json.loads([ln for ln in r1.stdout.splitlines() if ln.strip()][-1])
+    rn = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--one-device", "--exchange", "torch"]
+                        + common, capture_output=True, text=True, timeout=600, cwd=root)
+    assert rn.returncode == 0, (rn.stdout[-1500:], rn.stderr[-4000:])
+    out = [ln for ln in rn.stdout.splitlines() if ln.strip()]
+    assert len(out) == 1, out[:4]
+    line = json.loads(out[0])
+    assert line["n_gpus"] == gpus and line["ranks_seen"] == gpus and line["scaling"] == "strong"
+    assert line["process_group"].startswith("gloo") and "rehearsal" in line
+    assert len(line["per_rank"]) == gpus and sorted(r["rank"] for r in line["per_rank"]) == list(range(gpus))
+    assert line["config"]["tiles"] == (6 if gpus == 2 else 24) and line["config"]["tiles_per_gpu"] == line["config"]["tiles"] // gpus
+    assert all(r["tiles"] == line["config"]["tiles_per_gpu"] for r in line["per_rank"])
+    for k in ("sum", "abs_sum", "max_abs"):
+        a, b = np.asarray(line["checksum"][k]), np.asarray(one["checksum"][k])
+        assert (np.abs(a - b) <= 1e-12 * np.maximum(np.asarray(one["checksum"]["abs_sum"]), 1e-300)).all(), (k, a, b)
