@@ -182,6 +182,22 @@ int main(int argc, char** argv) {
         printf("RCCL %d, loopback exchange + INTERIOR / BOUNDARY launches: %s\n", wx_comm_rccl_version(),
                same ? "bit-identical to the single launch" : "DIFFERENT");
         if (!same) ok = 0;
+        /* a caller's reduction on the same communicator (solvers/global_operations.py:14-36: the Krylov solvers' dot products
+         * and norms), in stream order; one rank: the sum of one contribution.  And the order of teardown: the communicator
+         * refuses to go while an exchange made on it is alive. */
+        {
+            double dots[3] = {1.5, -2.0, 4.0}, back[3];
+            double* ddots = NULL;
+            CHECK_HIP(hipMalloc((void**)&ddots, sizeof dots));
+            CHECK_HIP(hipMemcpy(ddots, dots, sizeof dots, hipMemcpyHostToDevice));
+            CHECK_WX(wx_comm_allreduce(comm, ddots, 3, WX_REDUCE_SUM, stream));
+            CHECK_HIP(hipStreamSynchronize(stream));
+            CHECK_HIP(hipMemcpy(back, ddots, sizeof dots, hipMemcpyDeviceToHost));
+            if (back[0] != 1.5 || back[1] != -2.0 || back[2] != 4.0) ok = 0;
+            CHECK_HIP(hipFree(ddots));
+            if (wx_comm_users(comm) != 1 || wx_comm_destroy(comm) == WX_OK) ok = 0;
+            printf("wx_comm_allreduce on the exchange's communicator: %s; HIP runtime %d\n", ok ? "ok" : "WRONG", wx_hip_runtime_version());
+        }
         CHECK_WX(wx_exchange_destroy(ex));
         CHECK_WX(wx_comm_destroy(comm));
         CHECK_HIP(hipStreamDestroy(comm_stream));
