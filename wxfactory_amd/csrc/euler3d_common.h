@@ -10,7 +10,10 @@ constexpr int NQ = 5;   // values per face point in the interface buffer and in 
 
 // measured optima (A/B on MI355X): compile-time constants, not build knobs
 constexpr int kK1Waves = 1;           // min waves per SIMD requested for the extrapolation kernel
-constexpr int kK2Waves = 4;           // ... for the fused kernel, 8-byte dtypes (n = 8: two workgroups of 8 waves per CU)
+#ifndef WX_K2_WAVES
+#define WX_K2_WAVES 4
+#endif
+constexpr int kK2Waves = WX_K2_WAVES;   // ... for the fused kernel, 8-byte dtypes (n = 8: two workgroups of 8 waves per CU; A/B builds: -DWX_K2_WAVES=6)
 constexpr int kJvpWaves = 4;          // ... for the JVP kernel
 constexpr int kFieldBatch = 3;        // vector-pipe passes: fields contracted per rolled batch (all 7 at once: 241 VGPRs)
 constexpr int kFieldBatchWide = 4;    // ... 16-byte dtypes (one workgroup per CU: a little more ILP pays)

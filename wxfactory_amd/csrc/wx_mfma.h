@@ -27,7 +27,10 @@ namespace wx {
 #define WX_MFMA 1   // 0: the vector-pipe contractions for n = 8 too (A/B builds)
 #endif
 constexpr int kMfLE = 8 * 72;        // doubles per field image
-constexpr int kMfFS = 7 * 64 + 16;   // doubles per face in the face-flux image: faces 2d and 2d+1 land on different banks
+#ifndef WX_MF_FS_PAD
+#define WX_MF_FS_PAD 16
+#endif
+constexpr int kMfFS = 7 * 64 + WX_MF_FS_PAD;   // doubles per face in the face-flux image: faces 2d and 2d+1 land on different banks
 __device__ __forceinline__ int mf_idx(int kl, int jl, int il) { return kl * 72 + jl * 8 + (il ^ jl); }
 
 // Lane maps (found with tools/mfma_f64_4x4_probe.hip): lane l, k = l >> 4, block g = (l >> 2) & 3, x = l & 3:
