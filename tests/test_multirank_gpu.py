@@ -4,7 +4,8 @@ buffers, reduce.py's host-staged reductions), because RCCL refuses two ranks on 
 path except the transport itself runs as it would on N GPUs: tile ownership, the slot layout of the edge buffers, the
 INTERIOR / BOUNDARY launches around a travelling exchange, the batched launches of a rank's tiles, the collective decision of
 jvp_prepare, the split Krylov vectors of KIOPS with their two reductions per vector.  Checked against the REFERENCE's values:
-R of every panel (1e-10), and the KIOPS statistics of config/dcmip21.ini's EPI2 step, decision for decision, on every rank.
+R of every panel (1e-10), the KIOPS statistics of config/dcmip21.ini's EPI2 step decision for decision on every rank (config 5),
+a Rosenbrock-2 + FGMRES step (config 4), SSP-RK3 steps through the stage pipeline, shallow water R(Q) and time loop (configs 2, 3).
 (The transport: tests/test_exchange_rccl_gpu.py and tests/test_comm_gpu.py, one-rank communicator in loopback.)"""
 import os
 import socket
@@ -108,6 +109,76 @@ def _worker(rank, world, port, q):
         dist.all_reduce(updmax, op=dist.ReduceOp.MAX)
         err = np.abs(Qn.cpu().numpy() - ref_u).max(axis=AX)
         assert (err <= 1e-6 * updmax.numpy() + 1e-13 * np.abs(ref_u).max(axis=AX)).all(), (rank, err / updmax.numpy())
+        del epi, rhs5, ex5, plans5
+
+        # ---- (3) BASELINE config 4: one Rosenbrock-2 step, FGMRES with the reference's one-synchronisation Gram-Schmidt
+        # (integrators/ros2.py:24-81, solvers/fgmres.py): one reduction per Krylov vector over the ranks, every decision from
+        # all-reduced numbers; and an SSP-RK3 step through the stage pipeline, whose INTERIOR / BOUNDARY launches each
+        # extrapolate their own elements' output for the next stage
+        from tests.gpu_util import device_metric
+        from tests.util import Golden
+        from wxfactory_amd.integrators import Ros2, Tvdrk3
+
+        cg = Golden("callers_euler3d_n3_h3_v2")
+        plans4 = {p: Euler3DPlan(cg.n, cg.H, cg.V, cg.case, p, cg.ops, device_metric(cg, p, DEV)) for p in mine}
+        ex4 = PanelExchange(plans4[mine[0]].edge_count, DEV, rank=rank, world_size=world)
+        rhs4 = RhsEuler3D(plans4, ex4, overlap=True)
+        st4 = lambda key: torch.from_numpy(np.stack([cg[f"p{p}/{key}"] for p in mine])).to(DEV)  # noqa: E731
+
+        def worst(t):   # the largest value of a per-variable array over all ranks
+            t = torch.from_numpy(np.ascontiguousarray(t))
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return t.numpy()
+
+        ros = Ros2(rhs4, tol=1e-9, gmres_restart=30)
+        Qr = ros.step(st4("Q"), float(cg["meta/dt_jvp"]))
+        info = ros.solver_info
+        assert info["flag"] == 0 and info["rel_residual"] < 1e-9 and abs(info["iterations"] - 151) <= 2, (rank, info["iterations"])
+        ref, q0 = st4("ros2").cpu().numpy(), st4("Q").cpu().numpy()
+        upd = worst(np.abs(ref - q0).max(axis=AX))
+        err = np.abs(Qr.cpu().numpy() - ref).max(axis=AX)
+        assert (err <= 1e-7 * upd).all(), (rank, err / upd)
+        its = [None] * world
+        dist.all_gather_object(its, int(info["iterations"]))
+        assert len(set(its)) == 1
+        stepper = Tvdrk3(rhs4)
+        assert stepper.pipeline
+        Qk = stepper.step(st4("Q"), float(cg["meta/dt_rk"]))
+        ref = st4("rk3").cpu().numpy()
+        upd = worst(np.abs(ref - q0).max(axis=AX))
+        err = np.abs(Qk.cpu().numpy() - ref).max(axis=AX)
+        assert (err <= 1e-9 * upd + 1e-13 * np.abs(ref).max(axis=AX)).all(), (rank, err / upd)
+        del ros, stepper, rhs4, ex4, plans4
+
+        # ---- (4) shallow water (BASELINE configs 2, 3): R(Q) on Williamson 5 (topography) against the reference, panel by panel,
+        # and five SSP-RK3 steps of Williamson 6 at the order of config 3 against the reference's own run
+        from tests.test_sw_gpu import _plan, _scale
+        from tests.util import golden_sw
+        from wxfactory_amd.rhs_sw import RhsShallowWater
+
+        gs = golden_sw("sw_c5_n4_h3")
+        plw = {p: _plan(gs, p) for p in mine}
+        exw = PanelExchange(plw[mine[0]].edge_count, DEV, rank=rank, world_size=world)
+        rw = RhsShallowWater(plw, exw)
+        Rw = rw(torch.stack([to_dev(gs.q(p)) for p in mine]))
+        torch.cuda.synchronize()
+        for i, p in enumerate(mine):
+            ref = gs.r(p)
+            sc = np.maximum(var_max(ref), _scale(gs, p, False))
+            assert (var_err(Rw[i].cpu().numpy(), ref) <= 1e-10 * sc).all(), (rank, p)
+        gk = golden_sw("sw_rk3_c6_n8_h3")
+        plk = {p: _plan(gk, p) for p in mine}
+        exk = PanelExchange(plk[mine[0]].edge_count, DEV, rank=rank, world_size=world)
+        stepper = Tvdrk3(RhsShallowWater(plk, exk))
+        Qw = torch.stack([to_dev(gk.q(p)) for p in mine])
+        dtk, nsteps = float(gk["meta/rk3_dt"]), int(gk["meta/rk3_steps"])
+        for _ in range(nsteps):
+            Qw = stepper.step(Qw, dtk)
+        ref = np.stack([gk[f"p{p}/rk3_n"] for p in mine])
+        moved = worst(np.abs(ref - np.stack([gk[f"p{p}/Q"] for p in mine])).max(axis=(0, 2, 3, 4)))
+        err = np.abs(Qw.cpu().numpy() - ref).max(axis=(0, 2, 3, 4))
+        assert (err <= 1e-8 * moved).all(), (rank, err / moved)
+
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok", got))
