@@ -128,6 +128,13 @@ def test_pmex_device_kernels_split_form_and_exact_result(built_lib, p, taus, mon
     assert float((w_dev.cpu() - w_cpu).abs().max()) <= 1e-11 * scale
     w_split, st_split = pmex(taus, A, u, _force_split=True, **args)
     assert st_split[:4] == st_dev[:4] and float((w_split - w_dev).abs().max()) <= 1e-12 * scale
+    # the default at this length is the vector in four fused launches (pmex_aug_dot2_kernel ...); the row-batched launches that
+    # long vectors take: the same decisions, the same vectors to rounding (the products are summed in other groups)
+    monkeypatch.setenv("WXHIP_PMEX_FUSED", "0")
+    w_rows, st_rows = pmex(taus, A, u, **args)
+    monkeypatch.delenv("WXHIP_PMEX_FUSED")
+    assert st_rows[:4] == st_dev[:4] and st_rows[5:] == st_dev[5:], (st_rows, st_dev)
+    assert float((w_rows - w_dev).abs().max()) <= 1e-12 * scale
     # ... and the one-rank form with a host round trip per vector (the projector on the host, as the reference has it)
     # against the default, whose vectors are built by wx_pmex_vector with none
     monkeypatch.setenv("WXHIP_PMEX_DEVICE", "0")

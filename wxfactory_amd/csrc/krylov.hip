@@ -12,6 +12,8 @@
 
 #include "wx_common.h"
 
+#include <cstdlib>
+
 namespace wx {
 
 constexpr int kDotBlocks = 2048;   // partial sums per row
@@ -474,10 +476,10 @@ __device__ __forceinline__ void two_sum(double a, double b, double& s, double& e
 // solve (LT strictly upper: column c = products of v_c with the older vectors; Linv = (I + LT^T)^{-1}, unit lower).
 // sol[0:j] = g - LT (Linv g);  hcol[0:j] = sol;  scal[0] = factor for the correction pass (1 / norm estimate, or 1),
 // scal[1] = the estimate (-1: the difference came out negative), scal[2] = 1 when the estimate stands.
-__global__ __launch_bounds__(256) void pmex_project_kernel(const double* __restrict__ G, int j, double* __restrict__ LT,
-                                                           double* __restrict__ Linv, int ld, double tol,
-                                                           double* __restrict__ sol, double* __restrict__ hcol,
-                                                           double* __restrict__ scal) {
+__device__ __forceinline__ void pmex_project_body(const double* __restrict__ G, int j, double* __restrict__ LT,
+                                                  double* __restrict__ Linv, int ld, double tol,
+                                                  double* __restrict__ sol, double* __restrict__ hcol,
+                                                  double* __restrict__ scal) {
     __shared__ double g[kPmexMaxM], t[kPmexMaxM], c[kPmexMaxM];
     const int tid = threadIdx.x;
     const double* g0 = G;            // products with v_{j-1}
@@ -529,6 +531,140 @@ __global__ __launch_bounds__(256) void pmex_project_kernel(const double* __restr
         scal[1] = est;
         scal[2] = stands ? 1.0 : 0.0;
     }
+}
+__global__ __launch_bounds__(256) void pmex_project_kernel(const double* __restrict__ G, int j, double* __restrict__ LT,
+                                                           double* __restrict__ Linv, int ld, double tol,
+                                                           double* __restrict__ sol, double* __restrict__ hcol,
+                                                           double* __restrict__ scal) {
+    pmex_project_body(G, j, LT, Linv, ld, tol, sol, hcol, scal);
+}
+
+// ---- the same vector in FOUR launches instead of nine to thirteen (one rank; the sizes of the shipped .ini files, where a
+// Krylov vector is a chain of dependent 5-10 us launches): each kernel below performs exactly the floating-point operations
+// of the kernels it replaces, in their order; the products are summed over fewer, larger groups (one workgroup of partials per
+// 256 components instead of always 2048), so the Hessenberg columns agree with the separate launches' to rounding and PMEX's
+// decisions - checked against the reference's own statistics - are the same (tests/test_pmex_gpu.py, test_sw_gpu.py)
+//   pmex_aug_dot2_kernel        aug_update_kernel + every multi_dot2_kernel pass (the new row is formed on the fly, and dotted)
+//   pmex_finish_project_kernel  multi_dot_finish_kernel + pmex_project_kernel
+//   pmex_axpy_all_kernel        every multi_axpy_dev_kernel pass
+//   pmex_finish_scale_kernel    pmex_finish_kernel + scale_if_kernel
+template <int R>
+__global__ __launch_bounds__(kDotThreads) void pmex_aug_dot2_kernel(double* __restrict__ V, size_t ldv, int j, size_t n, int p,
+                                                                    const double* __restrict__ aw,
+                                                                    const double* __restrict__ uflip,
+                                                                    double* __restrict__ partial) {
+    __shared__ double aug[16];
+    __shared__ double red[2 * R][kDotThreads / 64];
+    const int m = j + 1;
+    double* vj = V + (size_t)j * ldv;
+    const double* vp = V + (size_t)(j - 1) * ldv;
+    if ((int)threadIdx.x < p) aug[threadIdx.x] = vp[n + threadIdx.x];
+    __syncthreads();
+    const size_t len = n + (size_t)p, stride = (size_t)gridDim.x * blockDim.x;
+    for (int row0 = 0; row0 < m; row0 += R) {
+        const int nr = m - row0 < R ? m - row0 : R;
+        double acc[2 * R];
+#pragma unroll
+        for (int r = 0; r < 2 * R; ++r) acc[r] = 0.0;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) {
+            const double ai = vp[i];
+            double bi;
+            if (i < n) {   // (aug_update_kernel's expression)
+                bi = aw[i];
+                for (int k = 0; k < p; ++k) bi += uflip[i * p + k] * aug[k];
+            } else {
+                const int t = (int)(i - n);
+                bi = t + 1 < p ? aug[t + 1] : 0.0;
+            }
+            if (row0 == 0) vj[i] = bi;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (r < nr) {
+                    const double v = row0 + r == j ? bi : V[(size_t)(row0 + r) * ldv + i];
+                    acc[r] += v * ai;
+                    acc[R + r] += v * bi;
+                }
+            }
+        }
+        if (row0 > 0) __syncthreads();   // the previous chunk's partials have been read out of `red`
+#pragma unroll
+        for (int r = 0; r < 2 * R; ++r) {
+            double v = acc[r];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if ((threadIdx.x & 63) == 0) red[r][threadIdx.x >> 6] = v;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < 2 * R) {
+            const int r = threadIdx.x % R, which = threadIdx.x / R;
+            if (r < nr) {
+                double v = 0.0;
+#pragma unroll
+                for (int k = 0; k < kDotThreads / 64; ++k) v += red[threadIdx.x][k];
+                partial[(size_t)blockIdx.x * 2 * m + which * m + row0 + r] = v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pmex_finish_project_kernel(const double* __restrict__ partial, int blocks, int j,
+                                                                  double* __restrict__ LT, double* __restrict__ Linv, int ld,
+                                                                  double tol, double* __restrict__ sol, double* __restrict__ hcol,
+                                                                  double* __restrict__ scal, double* __restrict__ G) {
+    const int m2 = 2 * (j + 1), wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int k = wave; k < m2; k += 4) {   // (multi_dot_finish_kernel: one wave per product, the same order)
+        double v = 0.0;
+        for (int b = lane; b < blocks; b += 64) v += partial[(size_t)b * m2 + k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) G[k] = v;
+    }
+    __threadfence_block();
+    __syncthreads();
+    pmex_project_body(G, j, LT, Linv, ld, tol, sol, hcol, scal);
+}
+
+__global__ __launch_bounds__(256) void pmex_axpy_all_kernel(double* __restrict__ w, const double* __restrict__ V, size_t ldv, int j,
+                                                            const double* __restrict__ h, size_t n,
+                                                            const double* __restrict__ scale, double* __restrict__ part,
+                                                            size_t nnorm) {
+    __shared__ double red[4];
+    __shared__ double cf[kPmexMaxM];
+    for (int r = threadIdx.x; r < j; r += blockDim.x) cf[r] = h[r];
+    __syncthreads();
+    const double sc = *scale;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    double nn = 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double s = w[i];
+#pragma unroll 8
+        for (int r = 0; r < j; ++r) s -= cf[r] * V[(size_t)r * ldv + i];
+        s *= sc;
+        w[i] = s;
+        if (i < nnorm) nn += s * s;
+    }
+    const double tsum = wg_sum256(nn, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = tsum;
+}
+
+__global__ __launch_bounds__(256) void pmex_finish_scale_kernel(double* __restrict__ w, size_t n, const double* __restrict__ part,
+                                                                int nblocks, double tol, double* __restrict__ scal,
+                                                                double* __restrict__ hnorm, double* __restrict__ own) {
+    __shared__ double red[4];
+    double v = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) v += part[b];
+    const double total = wg_sum256(v, red);   // (every workgroup sums the partials itself, in pmex_finish_kernel's order)
+    const bool stands = scal[2] != 0.0;
+    const double nrm = stands ? scal[1] : sqrt(total);
+    const double f = (!stands && nrm >= tol) ? 1.0 / nrm : 1.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *hnorm = nrm;
+        *own = stands ? 0.0 : 1.0;
+        scal[3] = f;
+    }
+    if (f == 1.0) return;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) w[i] *= f;
 }
 
 // w = (w - sum_k h[k] V[row0 + k]) * (*scale or 1);  when `part` is given, the squared norm of what was written, per workgroup
@@ -633,6 +769,9 @@ static void dispatch_axpy_dev(int rem, double* w, const double* V, size_t ldv, i
 }
 
 constexpr unsigned kPmexAxpyBlocks = 2048;
+constexpr unsigned kPmexFusedDotBlocks = 512;
+constexpr size_t kPmexFusedMaxLen = 1u << 21;   // vectors up to this length are built by the four fused launches (longer ones are
+                                                // bound by the sweeps, not by the launches, and keep the row-batched kernels)
 
 }  // namespace wx
 
@@ -860,6 +999,23 @@ static wx_status pmex_vector_impl(double* V, size_t ldv, int j, size_t n, int p,
     double* part = scal + 8;
     const size_t len = n + (size_t)p;
     double* vj = V + (size_t)j * ldv;
+    const char* fused_sw = getenv("WXHIP_PMEX_FUSED");   // (A/B and tests: "0" = the row-batched launches at every size)
+    if (!split && !(fused_sw && fused_sw[0] == '0') && len <= kPmexFusedMaxLen) {   // launch-bound sizes: four launches (see pmex_aug_dot2_kernel)
+        const size_t wantf = (len + 255) / 256;
+        const unsigned gridf = (unsigned)(wantf < kPmexAxpyBlocks ? (wantf ? wantf : 1) : kPmexAxpyBlocks);
+        // one workgroup of partial products per 256 components and no more (the row-batched kernels always leave kDotBlocks =
+        // 2048 partials per product, which ONE finishing workgroup cannot sum in a launch's time): at most 512 here
+        const unsigned gridd = (unsigned)(wantf < kPmexFusedDotBlocks ? (wantf ? wantf : 1) : kPmexFusedDotBlocks);
+        hipLaunchKernelGGL((pmex_aug_dot2_kernel<kRowsPerPass2>), dim3(gridd), dim3(kDotThreads), 0, st, V, ldv, j, n, p, aw,
+                           uflip, dotw);
+        hipLaunchKernelGGL(pmex_finish_project_kernel, dim3(1), dim3(256), 0, st, dotw, (int)gridd, j, LT, Linv, ld, tol, sol, hcol,
+                           scal, G);
+        hipLaunchKernelGGL(pmex_axpy_all_kernel, dim3(gridf), dim3(256), 0, st, vj, V, ldv, j, sol, len, scal, part, len);
+        hipLaunchKernelGGL(pmex_finish_scale_kernel, dim3(gridf), dim3(256), 0, st, vj, len, part, (int)gridf, tol, scal, hcol + j,
+                           own);
+        WX_HIP_TRY(hipGetLastError());
+        return WX_OK;
+    }
     {
         const size_t want = (n + 255) / 256;
         const unsigned grid = (unsigned)(want < 8192 ? (want ? want : 1) : 8192);
