@@ -358,7 +358,7 @@ def extras(dev, seed):
                                    "algorithmic_bytes_per_point": 156.0, "achieved": round(156.0 * 6 * H * H * n * n / te / 1e9, 1),
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(156.0 * 6 * H * H * n * n / te / 1e9 / HBM_PEAK_GBS, 4),
-                                   "profile": "profiles/r05_v2_swbench_kernel_stats.csv, profiles/r05_pmc_sw_summary.json"},
+                                   "profile": "profiles/r05_v3_swbench_kernel_stats.csv, profiles/r05_pmc_sw_summary.json"},
                       "note": "all six panels in one launch per phase (wx_sw_batch_*): the ring of tile-edge lines is packed by a "
                               "5 us launch, then ONE launch evaluates everything (own face states from LDS, the neighbours' from "
                               "the neighbour elements' nodal values); 5.5 MB of state per panel"}}
