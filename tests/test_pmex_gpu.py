@@ -203,10 +203,18 @@ def test_pmex_happy_breakdown_on_the_device(built_lib, monkeypatch):
         # breakdown="exact": the Hessenberg column of the vector that breaks down is kept (the reference stores it only
         # after its test, pmex.py:225-233 - breakdown="reference", the default)
         w, st = pmex([1.0], lambda v: lam * v, u, tol=1e-9, m_init=12, mmin=12, mmax=30, breakdown="exact")
-        assert st[0] == 1 and st[1] == 0 and st[2] in (5, 6) and st[4] == 0.0, st   # (5 or 6: see tests/test_solvers_cpu.py)
         assert float((w[0] - ref).abs().max()) <= 1e-10 * float(ref.abs().max()), (device_pass, st)
         w_ref, st_ref = pmex([1.0], lambda v: lam * v, u, tol=1e-9, m_init=12, mmin=12, mmax=30)
         assert st_ref[:4] == st[:4]
+        if st[2] == 12:
+            # the breakdown was NOT seen: the norm of the sixth vector is estimated as sqrt(<w, w> - sum g_k^2) (pmex.py:194-218),
+            # a difference of two numbers of size |w|^2 whose rounding noise, sqrt(eps) |w| ~ 1e-8 |w|, can land above the
+            # tolerance - then the vector of noise is normalised and the pass runs to its end; every column past the fifth
+            # weighs nothing and both forms are exact.  Which way it falls depends on how the products were summed.
+            assert st[0] == 1 and st[1] == 0, st
+            assert float((w_ref[0] - ref).abs().max()) <= 1e-10 * float(ref.abs().max()), (device_pass, st_ref)
+            continue
+        assert st[0] == 1 and st[1] == 0 and st[2] in (5, 6) and st[4] == 0.0, st   # (5 or 6: see tests/test_solvers_cpu.py)
         err = float((w_ref[0] - ref).abs().max()) / float(ref.abs().max())
         # seen at once (5 vectors): the reference's result misses the last column's projections; seen a vector of noise
         # later (6), that column weighs nothing and both forms are exact

@@ -16,7 +16,15 @@
 
 namespace wx {
 
-constexpr int kDotBlocks = 2048;   // partial sums per row
+constexpr int kDotBlocks = 2048;   // partial sums per row, at most (the workspaces are sized for it)
+// ... and no more workgroups than the vector has work for: each covers at least 256 components (one per thread).  At the sizes
+// of the shipped .ini files (30-100 k values per vector) that is 120-400 partials per product instead of 2048 - the launch of
+// 2048 mostly empty workgroups and the finish over their partials weighed on an FGMRES iteration there
+// (profiles/r05_fgmres_ini.txt); from 0.5 M components on it is the 2048 of before
+static inline int dot_blocks(size_t n) {
+    const size_t want = (n + 255) / 256;
+    return (int)(want < 1 ? 1 : (want < (size_t)kDotBlocks ? want : (size_t)kDotBlocks));
+}
 constexpr int kDotThreads = 256;
 // Rows per pass.  Every pass re-reads the vector(s) the rows are applied to (and the update kernels re-write them), so a
 // basis of j rows costs j + ceil(j / R) (+ writes) vector sweeps: at R = 4 the two-vector kernels of an FGMRES cycle of
@@ -409,7 +417,7 @@ __global__ __launch_bounds__(kFinishThreads) void kiops_long_c(double* __restric
 template <int R>
 static void launch_dot2(const double* V, size_t ldv, int row0, const double* a, const double* b, size_t n, double* partial,
                         int m, hipStream_t st) {
-    hipLaunchKernelGGL((multi_dot2_kernel<R>), dim3(kDotBlocks), dim3(kDotThreads), 0, st, V, ldv, row0, a, b, n, partial, m);
+    hipLaunchKernelGGL((multi_dot2_kernel<R>), dim3(dot_blocks(n)), dim3(kDotThreads), 0, st, V, ldv, row0, a, b, n, partial, m);
 }
 template <int R>
 static void launch_pair(double* a, double* b, const double* V, size_t ldv, int row0, const double* ha, const double* hb,
@@ -422,7 +430,7 @@ static void launch_pair(double* a, double* b, const double* V, size_t ldv, int r
 template <int R>
 static void launch_dot(const double* V, size_t ldv, int row0, const double* w, size_t n, double* partial, int m,
                        hipStream_t st) {
-    hipLaunchKernelGGL((multi_dot_kernel<R>), dim3(kDotBlocks), dim3(kDotThreads), 0, st, V, ldv, row0, w, n, partial, m);
+    hipLaunchKernelGGL((multi_dot_kernel<R>), dim3(dot_blocks(n)), dim3(kDotThreads), 0, st, V, ldv, row0, w, n, partial, m);
 }
 template <int R>
 static void launch_axpy(double* w, const double* V, size_t ldv, int row0, const double* h, size_t n, double scale,
@@ -789,7 +797,7 @@ wx_status wx_multi_dot(const double* V, size_t ldv, int m, const double* w, size
     WX_STREAM(st, stream);
     for (int r = 0; r < m; r += kRowsPerPass)
         dispatch_dot<kRowsPerPass>(m - r < kRowsPerPass ? m - r : kRowsPerPass, V, ldv, r, w, n, workspace, m, st);
-    hipLaunchKernelGGL(multi_dot_finish_kernel, dim3(m), dim3(64), 0, st, workspace, kDotBlocks, m, out);
+    hipLaunchKernelGGL(multi_dot_finish_kernel, dim3(m), dim3(64), 0, st, workspace, dot_blocks(n), m, out);
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
 }
@@ -923,7 +931,7 @@ wx_status wx_multi_dot2(const double* V, size_t ldv, int m, const double* a, con
     WX_STREAM(st, stream);
     for (int r = 0; r < m; r += kRowsPerPass2)
         dispatch_dot2<kRowsPerPass2>(m - r < kRowsPerPass2 ? m - r : kRowsPerPass2, V, ldv, r, a, b, n, workspace, m, st);
-    hipLaunchKernelGGL(multi_dot_finish_kernel, dim3(2 * m), dim3(64), 0, st, workspace, kDotBlocks, 2 * m, out);
+    hipLaunchKernelGGL(multi_dot_finish_kernel, dim3(2 * m), dim3(64), 0, st, workspace, dot_blocks(n), 2 * m, out);
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
 }
@@ -1026,7 +1034,7 @@ static wx_status pmex_vector_impl(double* V, size_t ldv, int j, size_t n, int p,
     for (int r = 0; r < m; r += kRowsPerPass2)
         dispatch_dot2<kRowsPerPass2>(m - r < kRowsPerPass2 ? m - r : kRowsPerPass2, V, ldv, r, V + (size_t)(j - 1) * ldv, vj, dlen,
                                      dotw, m, st);
-    hipLaunchKernelGGL(multi_dot_finish_kernel, dim3(2 * m), dim3(64), 0, st, dotw, kDotBlocks, 2 * m, G);
+    hipLaunchKernelGGL(multi_dot_finish_kernel, dim3(2 * m), dim3(64), 0, st, dotw, dot_blocks(dlen), 2 * m, G);
     if (split) {
         WX_HIP_TRY(hipGetLastError());
         if (comm) {

@@ -65,6 +65,12 @@ class _Basis:
             self.lib = _lib.load()
             self.check = _lib.check
             self.work = torch.empty(int(self.lib.wx_multi_dot_workspace(V.shape[0])), dtype=torch.float64, device=V.device)
+            # the coefficients of pair_update travel through a small ring of PINNED host buffers: an asynchronous copy on the
+            # stream instead of a pageable-memory transfer (which synchronises) per Krylov vector - at the sizes of the shipped
+            # .ini files an FGMRES iteration is a handful of 5-20 us launches and every host stall shows
+            self._coef_dev = torch.empty(2 * V.shape[0], dtype=torch.float64, device=V.device)
+            self._coef_host = [torch.empty(2 * V.shape[0], dtype=torch.float64).pin_memory() for _ in range(4)]
+            self._coef_turn = 0
 
     def dots(self, lo: int, hi: int, w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """<V[k, :len(w)], w> for lo <= k < hi (device tensor; written to `out` when given)."""
@@ -142,7 +148,15 @@ class _Basis:
             b -= cross * a
             b *= scale_b
             return
-        hab = torch.as_tensor(list(ha) + list(hb), dtype=torch.float64).to(V.device, non_blocking=True) if m else None
+        hab = None
+        if m:
+            host = self._coef_host[self._coef_turn % len(self._coef_host)]
+            self._coef_turn += 1
+            hv = host.numpy()
+            hv[:m] = ha
+            hv[m: 2 * m] = hb
+            hab = self._coef_dev[: 2 * m]
+            hab.copy_(host[: 2 * m], non_blocking=True)
         st = torch.cuda.current_stream(V.device).cuda_stream
         self.check(self.lib.wx_pair_update(a.data_ptr(), b.data_ptr(), V.data_ptr(), V.stride(0), m,
                                            hab.data_ptr() if m else None, hab[m:].data_ptr() if m else None, a.numel(),
