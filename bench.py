@@ -352,16 +352,17 @@ def extras(dev, seed):
     return {"euler_k2_all_27_christoffel": k2_full_metric(dev, seed), "sw_s7": {"workload": "shallow water, n=8, H=60, 6 panels on 1 GPU (1244160 DOF), whole-sphere R(Q) of the Galewsky jet + bump",
                       "us_per_eval": te * 1e6, "dof_updates_per_s": dof / te,
                       "algorithmic_GBps": 156.0 * 6 * H * H * n * n / te / 1e9,
-                      "form": "direct (ring pack + one launch, no interface buffer)" if rhs._use_direct(torch.float64)
-                              else "two kernels (extrapolation + RHS)",
-                      "roofline": {"bound": "hbm", "kernels": "sw_extrap_ring_batch_kernel + sw_rhs_direct_batch_kernel (one R(Q) = both)",
+                      "form": ("direct, ONE launch (tile-edge lines pulled from the neighbour tiles' nodal values, no interface buffer)"
+                               if rhs._batches[torch.float64].pulls else "direct (ring pack + one launch, no interface buffer)")
+                              if rhs._use_direct(torch.float64) else "two kernels (extrapolation + RHS)",
+                      "roofline": {"bound": "hbm", "kernels": "sw_rhs_direct_batch_kernel (one R(Q) = one launch)",
                                    "algorithmic_bytes_per_point": 156.0, "achieved": round(156.0 * 6 * H * H * n * n / te / 1e9, 1),
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(156.0 * 6 * H * H * n * n / te / 1e9 / HBM_PEAK_GBS, 4),
                                    "profile": "profiles/r05_v3_swbench_kernel_stats.csv, profiles/r05_pmc_sw_summary.json"},
-                      "note": "all six panels in one launch per phase (wx_sw_batch_*): the ring of tile-edge lines is packed by a "
-                              "5 us launch, then ONE launch evaluates everything (own face states from LDS, the neighbours' from "
-                              "the neighbour elements' nodal values); 5.5 MB of state per panel"}}
+                      "note": "all six panels in ONE launch (wx_sw_batch_rhs_direct, wx_sw_batch_direct_pulls = 1): own face states "
+                              "from LDS, the neighbours' from the neighbour elements' nodal values - across panel edges too (sum, "
+                              "rotation and flip of the neighbour panel's line formed in place); 5.5 MB of state per panel"}}
 
 
 def rhs_benchmark_matrix(dev, seed):

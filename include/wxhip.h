@@ -437,6 +437,12 @@ wx_status wx_sw_rhs_direct(wx_sw_plan* plan, const void* q, const void* const ha
 wx_status wx_sw_batch_extrap_pack_ring(wx_sw_batch* batch, const void* q, size_t panel_stride, wx_stream stream);
 wx_status wx_sw_batch_rhs_direct(wx_sw_batch* batch, const void* q, const void* y, void* out, size_t panel_stride, double a,
                                  double b, double c, int axpy, wx_region region, wx_stream stream);
+/* *pulls = 1: every halo line of every tile of the batch IS the send line of a tile of the batch (same-rank neighbours: found by
+ * the addresses given to wx_sw_batch_create) - wx_sw_batch_rhs_direct then forms the tile-edge lines itself from the neighbour
+ * tiles' nodal values (sum, rotation and flip as the ring pack: rhs_sw.py:76-117, process_topology.py:318-384) and
+ * wx_sw_batch_extrap_pack_ring need not be called; 0: call it (and exchange) first.  The stacked state must then hold the tiles in
+ * the order of `plans`, panel_stride apart. */
+wx_status wx_sw_batch_direct_pulls(const wx_sw_batch* batch, int* pulls);
 wx_status wx_sw_plan_reserve(wx_sw_plan* plan, int what);
 wx_status wx_sw_extrap_pack_slot(wx_sw_plan* plan, const void* q, void* const send[4], int slot, wx_stream stream);
 wx_status wx_sw_stage(wx_sw_plan* plan, const void* q, const void* const halo[4], const void* y, void* out, double a,

@@ -200,15 +200,23 @@ def test_tiles_of_a_24_rank_decomposition(built_lib):
     ex = PanelExchange(plans[0].edge_count, DEV, rank=0, world_size=1, tiles_per_side=k)
     rhs = RhsShallowWater(plans, ex)
     Q = torch.stack([_dev(g.q(t)) for t in range(topo.ntiles)])
-    R = rhs(Q).cpu().numpy()
+    Rd = rhs(Q)
+    R = Rd.cpu().numpy()
     for t in range(topo.ntiles):
         ref = g.r(t)
         scale = np.maximum(var_max(ref), _scale(g, t, False))
         assert (var_err(R[t], ref) <= TOL * scale).all(), t
+    # the direct form on the 24 tiles: tile edges INSIDE a panel (no rotation, no flip) and on panel edges, every line pulled
+    # from the neighbour tile's nodal values - the same bits as the two-kernel form
+    one = RhsShallowWater(plans, PanelExchange(plans[0].edge_count, DEV, rank=0, world_size=1, tiles_per_side=k))
+    one.direct = True
+    got = one(Q)
+    assert one._batches[torch.float64].pulls and not bool(one.ex.send_buf.any())
+    assert ((got - Rd).abs() <= 1e-15 * Rd.abs().amax(dim=(0, 2, 3), keepdim=True)).all()
 
 
 @pytest.mark.parametrize("name", SW_FIXTURES)
-def test_direct_form_equals_the_two_kernel_form(built_lib, name):
+def test_direct_form_equals_the_two_kernel_form(built_lib, name, monkeypatch):
     """wx_sw_rhs_direct / wx_sw_batch_rhs_direct: no interface buffer - the RHS kernel extrapolates its own face states from
     LDS and the neighbours' from the neighbour elements' nodal values; only the ring of tile-edge lines is packed before
     the exchange.  Same arithmetic term by term: the result equals the two-kernel form to the last bits (and with it the
@@ -234,12 +242,25 @@ def test_direct_form_equals_the_two_kernel_form(built_lib, name):
         torch.cuda.synchronize()
         assert ((got - want).abs() <= 1e-15 * scale).all(), (name, loop, float(((got - want).abs() / scale).max()))
         assert ((got_axpy - want_axpy).abs() <= 1e-15 * want_axpy.abs().amax(dim=(0, 2, 3), keepdim=True)).all(), (name, loop)
-        # the ring-only pack wrote the same edge lines as the full extrapolation
-        twoex = RhsShallowWater(plans, PanelExchange(plans[0].edge_count, DEV, rank=0, world_size=1))
-        twoex(Q)
+        # halos that alias the neighbours' send lines: the launch forms the tile-edge lines itself from the neighbour tiles' nodal
+        # values (wx_sw_batch_direct_pulls) and nothing is packed; halos that travel: the ring pack + the exchange
+        assert one._batches[torch.float64].pulls == (not loop)
         if not loop:
+            assert not bool(one.ex.send_buf.any())
+            # ... against the packed lines (WXHIP_SW_PULL=0 when the batch is created): the same bits, and the ring-only pack
+            # wrote the same edge lines as the full extrapolation
+            monkeypatch.setenv("WXHIP_SW_PULL", "0")
+            packed = RhsShallowWater(plans, PanelExchange(plans[0].edge_count, DEV, rank=0, world_size=1))
+            packed.direct = True
+            got_p, got_axpy_p = packed(Q), packed.axpy(Q, Q, 0.75, 0.25, 12.5)
+            monkeypatch.delenv("WXHIP_SW_PULL")
+            assert not packed._batches[torch.float64].pulls
+            twoex = RhsShallowWater(plans, PanelExchange(plans[0].edge_count, DEV, rank=0, world_size=1))
+            twoex.direct = False
+            twoex(Q)
             torch.cuda.synchronize()
-            assert torch.equal(one.ex.send_buf, twoex.ex.send_buf)
+            assert torch.equal(got_p, got) and torch.equal(got_axpy_p, got_axpy), name
+            assert torch.equal(packed.ex.send_buf, twoex.ex.send_buf)
     # one tile through the plan: the per-tile entry points, halos from the fixture
     p = 3
     q = _dev(g.q(p))

@@ -167,6 +167,7 @@ SIGNATURES = {
     "wx_sw_rhs_direct": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_double, c_double, c_double, c_int,
                                  c_int, c_void_p]),
     "wx_sw_batch_extrap_pack_ring": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wx_sw_batch_direct_pulls": (c_int, [c_void_p, POINTER(c_int)]),
     "wx_sw_batch_rhs_direct": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_double, c_double, c_double, c_int,
                                        c_int, c_void_p]),
     "wx_sw_plan_reserve": (c_int, [c_void_p, c_int]),

@@ -12,6 +12,7 @@
 #include "wx_math.h"
 #include "wx_panels.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -72,6 +73,18 @@ struct SwDyn {
     // writes); prepare != 0: the RHS kernel also extrapolates ITS OUTPUT - the next stage's state - to the faces of the
     // OTHER slot and packs its tile-edge lines into the other send set (no separate extrapolation pass for the next stage)
     int slot, prepare;
+    // direct form of a batch whose tiles are all each other's neighbours (SwParams::pull): the stacked state, so that a
+    // tile-edge face can read the NEIGHBOUR TILE's nodal values itself (null: the edge lines come from the halo buffers)
+    const T* q_all = nullptr;
+    size_t q_stride = 0;
+};
+
+// a tile edge as the SOURCE of a neighbour's halo line: its rotation matrix, the tile's topography (null: flat).  (The boundary
+// coordinates along the edge - boundary_we / boundary_sn - are COPIED behind the table, H * N per edge: SwParams::pull_x; a
+// pointer to them here would put a second round trip in front of the rotation.)
+struct SwPullEdge {
+    double rot[8];
+    const double* hs;
 };
 
 template <typename T>
@@ -91,6 +104,13 @@ struct SwParams {
     gp<const double> hsurf, dz1, dz2, hsi, hsj;
     gp<const double> bsn, bwe;
     gp<const SwConsts> K;
+    // batches only: for each edge (S, N, W, E) 4 * s + 2 * (the source has topography) + (its edge flips the line), s = 4 * (index
+    // of the tile in the batch whose send line this halo line is) + that tile's edge, or -1 (sw_batch_build: found by the
+    // addresses - a halo line that IS another tile's send line); pull_tab[s]: what the kernel needs of that tile's edge at one
+    // load's distance
+    int pull[4];
+    gp<const SwPullEdge> pull_tab;
+    gp<const double> pull_x;   // [4 * tiles][H * N]
 };
 
 struct Elem2 {
@@ -337,20 +357,53 @@ __device__ __forceinline__ void sw_rhs_body(const SwParams<T> P, const SwDyn<T> 
             const int d = f >> 1, plus = f & 1;
             T sv[3] = {T(0.0), T(0.0), T(0.0)};
             const int ne = d == 0 ? el.ei + (plus ? 1 : -1) : el.ej + (plus ? 1 : -1);
+            // the line of nodal values the side is extrapolated from (null: a received halo line instead), and - when that line
+            // belongs to ANOTHER TILE of this launch - the rotation into this tile's basis
+            const T* qs = nullptr;
+            gp<const double> wn = nullptr, hs = nullptr, rot = nullptr;
+            size_t nb = 0;
+            int ns = 1;
+            double X = 0.0;
             if (ne >= 0 && ne < H) {   // the neighbour element of the same tile: its opposite face, from its nodal values
                 const long nelem_nbr = el.e + (d == 0 ? (plus ? 1 : -1) : (plus ? H : -H));
-                const size_t nb = (size_t)nelem_nbr * N2 + (d == 0 ? k * N : k);
-                const int ns = d == 0 ? 1 : N;
-                gp<const double> wn = plus ? P.K->em : P.K->ep;   // (from memory: the LDS copies are not there yet)
+                nb = (size_t)nelem_nbr * N2 + (d == 0 ? k * N : k);
+                ns = d == 0 ? 1 : N;
+                wn = plus ? P.K->em : P.K->ep;   // (from memory: the LDS copies are not there yet)
+                qs = D.q;
+                if (P.has_topo) hs = P.hsurf;
+            } else if (D.q_all != nullptr) {
+                // a tile edge whose neighbour tile is in this launch: ITS edge line, formed here from its nodal values exactly
+                // as its ring pack would form it (sw_extrap_faces: the sum, the rotation into this tile's basis, the flip of the
+                // line) - the evaluation is then ONE launch, the 5 us ring launch in front of a 43 us kernel is gone.
+                // (selected values, not a computed index: that would put the whole parameter block into scratch; everything
+                // the line needs comes from THIS tile's parameters - no chain of loads through the neighbour's)
+                const bool e_hi = plus != 0;
+                const int code = d == 0 ? (e_hi ? P.pull[E_E] : P.pull[E_W]) : (e_hi ? P.pull[E_N] : P.pull[E_S]);
+                gp<const SwPullEdge> src = P.pull_tab + (size_t)(code >> 2);
+                const int se = (code >> 2) & 3, sd = se >> 1 ? 0 : 1, splus = se & 1;   // (E_S, E_N: lines along i; E_W, E_E: along j)
+                int pos = (d == 0 ? el.ej : el.ei) * N + k;
+                if (code & 1) pos = H * N - 1 - pos;
+                const int sa = pos / N, sk = pos - sa * N;
+                const int sei = sd == 0 ? (splus ? H - 1 : 0) : sa, sej = sd == 0 ? sa : (splus ? H - 1 : 0);
+                nb = (size_t)(sej * H + sei) * N2 + (sd == 0 ? sk * N : sk);
+                ns = sd == 0 ? 1 : N;
+                wn = splus ? P.K->ep : P.K->em;   // (the tiles of a batch share their operators: sw_batch_build checks)
+                qs = D.q_all + (size_t)(code >> 4) * D.q_stride;
+                if (code & 2) hs = src->hs;
+                rot = src->rot;
+                X = P.pull_x[(size_t)(code >> 2) * (H * N) + sa * N + sk];
+            }
+            if (qs != nullptr) {
 #pragma unroll
                 for (int m = 0; m < N; ++m) {
                     const double wm = wn[m];
-                    T h = D.q[nb + m * ns];
-                    if (P.has_topo) h = h + P.hsurf[nb + m * ns];
+                    T h = qs[nb + m * ns];
+                    if (hs != nullptr) h = h + hs[nb + m * ns];
                     sv[0] += wm * h;
-                    sv[1] += wm * D.q[fs + nb + m * ns];
-                    sv[2] += wm * D.q[2 * fs + nb + m * ns];
+                    sv[1] += wm * qs[fs + nb + m * ns];
+                    sv[2] += wm * qs[2 * fs + nb + m * ns];
                 }
+                if (rot != nullptr) rotate_contra<T>(rot, X, sv[1], sv[2]);
             } else {   // a tile edge: the received halo line
                 tp<T, const T> nbr = d == 0 ? (plus ? S.halo_e : S.halo_w) + (size_t)el.ej * N + k
                                             : (plus ? S.halo_n : S.halo_s) + (size_t)el.ei * N + k;
@@ -694,9 +747,10 @@ __global__ __launch_bounds__(Cfg2<N>::BS) void sw_extrap_ring_batch_kernel(const
 template <int N, typename T>
 __global__ __launch_bounds__(Cfg2<N>::BS, (sw_waves<N, T, false>())) void sw_rhs_direct_batch_kernel(const SwParams<T>* __restrict__ PB, const T* q, T* rhs,
                                                                          size_t stride, int count, int region, int axpy,
-                                                                         const T* y, double ca, double cb, double cc) {
+                                                                         const T* y, double ca, double cb, double cc, int pull) {
     SwDyn<T> D{q + (size_t)blockIdx.y * stride, rhs + (size_t)blockIdx.y * stride, count, region, axpy,
                y ? y + (size_t)blockIdx.y * stride : nullptr, ca, cb, cc, 0, 0};
+    if (pull) { D.q_all = q; D.q_stride = stride; }
     sw_rhs_body<N, T, false, true, sw_lean<N, T, false>()>(PB[blockIdx.y], D);
 }
 // several tiles (the panels one rank owns) per launch: blockIdx.y selects the tile's static parameters
@@ -728,6 +782,7 @@ struct wx_sw_plan {
     void* itf = nullptr;
     void* itf2 = nullptr;   // interface slot 1 (wx_sw_plan_reserve: the stage pipeline)
     SwConsts* consts = nullptr;
+    SwConsts hconsts;       // (the host's copy: what a batch needs to know of its tiles - flips, operators)
     SwParams<double> base;
 };
 
@@ -737,6 +792,8 @@ struct wx_sw_batch {
     wx_dtype dtype;
     void* table = nullptr;  // device: SwParams<T>[count]
     bool pipelined = false; // the table holds both slots (wx_sw_batch_create_pipelined)
+    bool pulls = false;     // every halo line of every tile is the send line of a tile of this batch (SwParams::pull is set)
+    void* pull_tab = nullptr;   // device: SwPullEdge[4 * count] (pulls only)
 };
 
 namespace {
@@ -758,6 +815,9 @@ SwParams<T> make_sw_params(const wx_sw_plan* pl) {
     P.sgi = b.sgi; P.sgj = b.sgj; P.h11i = b.h11i; P.h21i = b.h21i; P.h12j = b.h12j; P.h22j = b.h22j;
     P.hsurf = b.hsurf; P.dz1 = b.dz1; P.dz2 = b.dz2; P.hsi = b.hsi; P.hsj = b.hsj;
     P.bsn = b.bsn; P.bwe = b.bwe; P.K = pl->consts;
+    P.pull[0] = P.pull[1] = P.pull[2] = P.pull[3] = -1;
+    P.pull_tab = nullptr;
+    P.pull_x = nullptr;
     return P;
 }
 
@@ -807,7 +867,7 @@ wx_status sw_launch(int what, const SwParams<T>* P, const SwDyn<T>& D, const SwP
             const int g8 = 8 * ((grid + 7) / 8);   // a multiple of eight workgroups: the surplus finds no element
             if (what == 5) hipLaunchKernelGGL((sw_rhs_direct_kernel<N, T>), dim3(g8), dim3(C::BS), 0, st, *P, D);
             else hipLaunchKernelGGL((sw_rhs_direct_batch_kernel<N, T>), dim3(g8, nb), dim3(C::BS), 0, st, table, D.q, D.rhs, stride,
-                                    D.count, D.region, D.axpy, D.y, D.ca, D.cb, D.cc);
+                                    D.count, D.region, D.axpy, D.y, D.ca, D.cb, D.cc, D.q_all != nullptr ? 1 : 0);
         }
         WX_HIP_TRY(hipGetLastError());
         return WX_OK;
@@ -857,6 +917,12 @@ wx_status sw_run(wx_sw_plan* pl, bool extrap, const void* q, void* const send[4]
     return sw_dispatch<T>(pl->n, extrap ? 0 : 1, &P, D, nullptr, 0, 0, st);
 }
 
+// two tiles extrapolate with the same weights on the same grid (a line of one can be formed with the constants of the other)
+bool sw_same_operators(const wx_sw_plan* a, const wx_sw_plan* b) {
+    return a->n == b->n && a->H == b->H && memcmp(a->hconsts.em, b->hconsts.em, sizeof(a->hconsts.em)) == 0 &&
+           memcmp(a->hconsts.ep, b->hconsts.ep, sizeof(a->hconsts.ep)) == 0;
+}
+
 template <typename T>
 wx_status sw_batch_build(wx_sw_batch* b, wx_sw_plan* const plans[], int count, void* const send[][4],
                          const void* const halo[][4], void* const send2[][4] = nullptr, const void* const halo2[][4] = nullptr) {
@@ -867,7 +933,49 @@ wx_status sw_batch_build(wx_sw_batch* b, wx_sw_plan* const plans[], int count, v
         set_edges<T>(host[i], send[i], halo[i]);
         if (send2 && halo2) set_edges<T>(host[i], send2[i], halo2[i], 1);
     }
-    hipError_t e = hipMalloc(&b->table, sizeof(SwParams<T>) * count);
+    // which tile's send line is this halo line?  (same-rank neighbours: the exchange aliases the two.)  When EVERY halo line of
+    // the batch is one, the direct form needs no ring pack: its tile-edge faces read the neighbour tile's nodal values.
+    // WXHIP_SW_PULL=0: keep the packed lines (the A/B and the test of the two against each other).
+    const char* env = getenv("WXHIP_SW_PULL");
+    bool all = !(env && env[0] == '0') && !(send2 && halo2) && count > 0 && send && halo;
+    for (int i = 0; all && i < count; ++i)
+        for (int e = 0; all && e < 4; ++e) {
+            int found = -1;
+            for (int j = 0; halo[i][e] && found < 0 && j < count; ++j)
+                for (int f = 0; f < 4; ++f)
+                    if (send[j][f] == halo[i][e] && sw_same_operators(plans[j], plans[i])) { found = 4 * j + f; break; }
+            if (found < 0) { all = false; break; }
+            const wx_sw_plan* src = plans[found >> 2];
+            host[i].pull[e] = 4 * found + (src->base.has_topo ? 2 : 0) + (src->hconsts.flip[found & 3] ? 1 : 0);
+        }
+    hipError_t e = hipSuccess;
+    if (all) {   // the tiles' edges as sources
+        SwPullEdge* tab = new (std::nothrow) SwPullEdge[4 * count];
+        if (!tab) { delete[] host; return fail(WX_ERR_NOMEM, "out of host memory"); }
+        for (int j = 0; j < count; ++j)
+            for (int f = 0; f < 4; ++f) {
+                SwPullEdge& t = tab[4 * j + f];
+                memcpy(t.rot, plans[j]->hconsts.rot[f], sizeof(t.rot));
+                t.hs = plans[j]->base.has_topo ? plans[j]->base.hsurf.p : nullptr;
+            }
+        const size_t line = (size_t)plans[0]->H * plans[0]->n, tab_bytes = sizeof(SwPullEdge) * 4 * count;
+        e = hipMalloc(&b->pull_tab, tab_bytes + sizeof(double) * 4 * count * line);
+        if (e == hipSuccess) e = hipMemcpy(b->pull_tab, tab, tab_bytes, hipMemcpyHostToDevice);
+        delete[] tab;
+        double* xs = reinterpret_cast<double*>(static_cast<char*>(b->pull_tab) + tab_bytes);
+        for (int j = 0; e == hipSuccess && j < count; ++j)
+            for (int f = 0; e == hipSuccess && f < 4; ++f)
+                e = hipMemcpy(xs + (size_t)(4 * j + f) * line, f >> 1 ? plans[j]->base.bwe.p : plans[j]->base.bsn.p,
+                              sizeof(double) * line, hipMemcpyDeviceToDevice);
+        for (int i = 0; i < count; ++i) {
+            host[i].pull_tab = static_cast<const SwPullEdge*>(b->pull_tab);
+            host[i].pull_x = xs;
+        }
+    } else {
+        for (int i = 0; i < count; ++i) host[i].pull[0] = host[i].pull[1] = host[i].pull[2] = host[i].pull[3] = -1;
+    }
+    b->pulls = all;
+    if (e == hipSuccess) e = hipMalloc(&b->table, sizeof(SwParams<T>) * count);
     if (e == hipSuccess) e = hipMemcpy(b->table, host, sizeof(SwParams<T>) * count, hipMemcpyHostToDevice);
     delete[] host;
     if (e != hipSuccess) return fail(WX_ERR_HIP, "wx_sw_batch_create: %s", hipGetErrorString(e));
@@ -900,6 +1008,7 @@ static wx_status sw_batch_direct(wx_sw_batch* b, int what, const void* q, void* 
                                  const void* y, double ca, double cb, double cc, hipStream_t st) {
     SwDyn<T> D{static_cast<const T*>(q), static_cast<T*>(out), what == 6 ? b->H : sw_region_count(region, b->H), region, axpy,
                static_cast<const T*>(y), ca, cb, cc, 0, 0};
+    if (what == 7 && b->pulls) D.q_all = D.q;   // (the batch kernel takes the stacked state and its stride from its own arguments)
     return sw_dispatch<T>(b->n, what, nullptr, D, static_cast<const SwParams<T>*>(b->table), b->count, stride, st);
 }
 
@@ -951,6 +1060,7 @@ wx_status wx_sw_plan_create_tile(wx_sw_plan** out, int n, int H, wx_dtype dtype,
         hc.flip[ed] = on_panel_edge[ed] ? kFlip[panel][ed] : 0;
         for (int i = 0; i < 8; ++i) hc.rot[ed][i] = on_panel_edge[ed] ? kRot[panel][ed][i] : identity[i];
     }
+    pl->hconsts = hc;
     if (e == hipSuccess) e = hipMemcpy(pl->consts, &hc, sizeof(hc), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         if (pl->itf) (void)hipFree(pl->itf);
@@ -1081,6 +1191,7 @@ wx_status wx_sw_batch_create(wx_sw_batch** out, wx_sw_plan* const plans[], int c
     }
     if (st != WX_OK) {
         if (b->table) (void)hipFree(b->table);
+        if (b->pull_tab) (void)hipFree(b->pull_tab);
         delete b;
         return st;
     }
@@ -1091,6 +1202,7 @@ wx_status wx_sw_batch_create(wx_sw_batch** out, wx_sw_plan* const plans[], int c
 wx_status wx_sw_batch_destroy(wx_sw_batch* b) {
     if (!b) return WX_OK;
     hipError_t e = hipFree(b->table);
+    if (b->pull_tab) { const hipError_t e2 = hipFree(b->pull_tab); if (e == hipSuccess) e = e2; }
     delete b;
     if (e != hipSuccess) return fail(WX_ERR_HIP, "hipFree failed: %s", hipGetErrorString(e));
     return WX_OK;
@@ -1156,6 +1268,12 @@ wx_status wx_sw_batch_extrap_pack_ring(wx_sw_batch* b, const void* q, size_t pan
         case WX_C128: return sw_batch_direct<cplx>(b, 6, q, nullptr, panel_stride, 0, 0, nullptr, 0.0, 0.0, 1.0, st);
         default: return sw_batch_direct<dual>(b, 6, q, nullptr, panel_stride, 0, 0, nullptr, 0.0, 0.0, 1.0, st);
     }
+}
+
+wx_status wx_sw_batch_direct_pulls(const wx_sw_batch* b, int* pulls) {
+    if (!b || !pulls) return fail(WX_ERR_INVALID, "wx_sw_batch_direct_pulls: null argument");
+    *pulls = b->pulls ? 1 : 0;
+    return WX_OK;
 }
 
 wx_status wx_sw_batch_rhs_direct(wx_sw_batch* bt, const void* q, const void* y, void* out, size_t panel_stride, double a,
@@ -1239,6 +1357,7 @@ wx_status wx_sw_batch_create_pipelined(wx_sw_batch** out, wx_sw_plan* const plan
     }
     if (st != WX_OK) {
         if (b->table) (void)hipFree(b->table);
+        if (b->pull_tab) (void)hipFree(b->pull_tab);
         delete b;
         return st;
     }

@@ -199,6 +199,10 @@ class SwBatch:
                       "wx_sw_batch_create_pipelined")
             else:
                 check(self.lib.wx_sw_batch_create(ctypes.byref(self._h), handles, n, send, halo), "wx_sw_batch_create")
+        # True: every tile's neighbours are in this batch - rhs_direct forms the tile-edge lines itself, no ring pack in front
+        pulls = ctypes.c_int(0)
+        check(self.lib.wx_sw_batch_direct_pulls(self._h, ctypes.byref(pulls)), "wx_sw_batch_direct_pulls")
+        self.pulls = bool(pulls.value)
 
     def extrap_pack_ring(self, q):
         st = torch.cuda.current_stream(self.device).cuda_stream
@@ -257,7 +261,7 @@ class RhsShallowWater(PanelRhs):
         """The stage pipeline (wx_sw_stage: the stage's kernel extrapolates its own output) pays where an evaluation takes two
         launches; where the direct form is taken a fused stage is one launch already, and faster (S7: 49 against 54 us)."""
         return not self._use_direct(torch.float64)
-    # the direct form (no interface buffer: ring-only pack, then ONE launch; wx_sw_rhs_direct): bit-identical to the two-kernel
+    # the direct form (no interface buffer: ring-only pack - none when SwBatch.pulls - then ONE launch; wx_sw_rhs_direct): bit-identical to the two-kernel
     # form.  None = automatic: taken for float64 states at n = 8, where it is measured ahead since its face stage is spread
     # over all threads and its independent loads are issued before the first barrier (S7: 49 against 53-58 us,
     # profiles/r05_sw_s7_ab.txt); True / False: forced
@@ -357,7 +361,8 @@ class RhsShallowWater(PanelRhs):
         b = self._batches[dt]
         out = torch.empty_like(q)
         if self._use_direct(dt):
-            b.extrap_pack_ring(q)
+            if not b.pulls:
+                b.extrap_pack_ring(q)
             self._phases(ex, lambda region: b.rhs_direct(q, out, region, y, coef))
             return out
         b.extrap_pack(q)
