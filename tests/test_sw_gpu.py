@@ -253,6 +253,8 @@ def test_direct_form_equals_the_two_kernel_form(built_lib, name, monkeypatch):
             packed = RhsShallowWater(plans, PanelExchange(plans[0].edge_count, DEV, rank=0, world_size=1))
             packed.direct = True
             got_p, got_axpy_p = packed(Q), packed.axpy(Q, Q, 0.75, 0.25, 12.5)
+            Qc = torch.complex(Q, 1e-3 * torch.roll(Q, 1, dims=0))
+            got_pc = packed(Qc)   # (a batch per dtype, created at its first call: this one too while the switch is set)
             monkeypatch.delenv("WXHIP_SW_PULL")
             assert not packed._batches[torch.float64].pulls
             twoex = RhsShallowWater(plans, PanelExchange(plans[0].edge_count, DEV, rank=0, world_size=1))
@@ -261,6 +263,12 @@ def test_direct_form_equals_the_two_kernel_form(built_lib, name, monkeypatch):
             torch.cuda.synchronize()
             assert torch.equal(got_p, got) and torch.equal(got_axpy_p, got_axpy), name
             assert torch.equal(packed.ex.send_buf, twoex.ex.send_buf)
+            # ... and on complex states (the complex-step matvec's dtype): pulled = packed = two kernels
+            want_c, got_c = two(Qc), one(Qc)
+            assert one._batches[torch.complex128].pulls and not packed._batches[torch.complex128].pulls
+            assert torch.equal(got_c, got_pc), name
+            sc = want_c.abs().amax(dim=(0, 2, 3), keepdim=True)
+            assert ((got_c - want_c).abs() <= 1e-15 * sc).all(), (name, float(((got_c - want_c).abs() / sc).max()))
     # one tile through the plan: the per-tile entry points, halos from the fixture
     p = 3
     q = _dev(g.q(p))
