@@ -191,6 +191,42 @@ def pmc_traffic(region, n, H, V, bpp=ALGO_BYTES_PER_POINT):
         return None, {"reason": f"{type(e).__name__}: {e}"}
 
 
+FP64_MFMA_PEAK_TFLOPS = 78.6    # SURVEY 8d; = 512 flop per 16 issue cycles per SIMD (tools/mfma_f64_probe.hip) x 1024 SIMDs x 2.4 GHz
+SQ_COUNTERS = "r05_v4_k2_sq_counters.json"
+
+
+def mfma_block(plans, n, launch_s, elements):
+    """The element-local contractions of the dominant kernel on the matrix cores (north star: MFMA utilisation against the
+    gfx950 peak).  The flop rate is live: the three directional passes issue 520 `v_mfma_f64_4x4x4_4b_f64` per element at
+    n = 8 (csrc/wx_mfma.h, mf4_dir_pass; four 4 x 4 x 4 products = 512 flop each) over the launch time measured in this run.  The pipe's busy fraction comes from the committed counter pass of the same kernel
+    (tools/collect_profiles.sh: SQ_INSTS_MFMA, SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE) - which also checks the 520."""
+    from wxfactory_amd import _lib
+
+    if n != 8 or not plans:
+        return None
+    pl = next(iter(plans.values()))
+    if not pl.lib.wx_euler3d_uses_matrix_cores(pl._h, _lib.WX_KERNEL_RHS):
+        return {"used": False}
+    insts = 520.0 * elements
+    blk = {"used": True, "instruction": "v_mfma_f64_4x4x4_4b_f64", "instructions_per_launch": insts, "flop_per_instruction": 512,
+           "achieved": round(insts * 512 / launch_s / 1e12, 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": round(insts * 512 / launch_s / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+           "note": "the kernel is bound by HBM (roofline.bound): the contractions are 2.6 flop per byte, the matrix pipe is mostly idle by design"}
+    try:
+        c = json.load(open(os.path.join(ROOT, "profiles", SQ_COUNTERS)))["wx::euler_rhs_kernel<8, double, false>"]
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs; busy cycles over all 1024 SIMDs
+        simd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
+        blk["counters"] = {"profile": "profiles/" + SQ_COUNTERS, "SQ_INSTS_MFMA_per_launch": c["SQ_INSTS_MFMA"],
+                           "SQ_VALU_MFMA_BUSY_CYCLES": c["SQ_VALU_MFMA_BUSY_CYCLES"],
+                           "mfma_util": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles, 4),
+                           "vector_instructions_per_launch": c["SQ_INSTS_VALU"],
+                           "wait_fraction_of_wave_cycles": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3),
+                           "shape": "one E7 panel (tools/kbench.py --rot-zero): the launch shape of the N = 1 line"}
+    except (OSError, KeyError, ValueError) as e:
+        blk["counters"] = {"reason": f"{type(e).__name__}: {e}"}
+    return blk
+
+
 def copy_ceiling(dev, gib=2, reps=10):
     """What this GPU sustains on a read-once / write-once stream, measured in this run (wx_stream_copy: 16 bytes per lane,
     one pass over `gib` GiB, far beyond the 256 MiB Infinity Cache): the achievable side of the 8 TB/s figure."""
@@ -1099,6 +1135,7 @@ def main():
                                    "bytes_per_point": bpp, "frac": roof["sweep"]["frac"],
                                    "dof_updates_per_s_this_rank": 5 * (pts_panel / (k * k)) * len(mine) / (dt / args.steps),
                                    "met": bool(roof["sweep"]["frac"] >= 0.5)}
+        roof["matrix_cores"] = mfma_block(plans, n, tk, (pts_panel / (k * k)) / n**3 * frac_of_panel[region] * tiles_in_launch[region])
         roof["ceiling"] = copy_ceiling(dev)
         if roof["ceiling"] and traffic:
             on_traffic = traffic / tk / 1e9
