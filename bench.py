@@ -385,7 +385,7 @@ def extras(dev, seed):
     torch.cuda.synchronize()
     te = (time.perf_counter() - t0) / reps
     dof = 3 * 6 * H * H * n * n
-    return {"euler_k2_all_27_christoffel": k2_full_metric(dev, seed), "sw_s7": {"workload": "shallow water, n=8, H=60, 6 panels on 1 GPU (1244160 DOF), whole-sphere R(Q) of the Galewsky jet + bump",
+    return {"euler_k2_all_27_christoffel": k2_full_metric(dev, seed), "sw_s7": {"workload": "shallow water, n=8, H=60, 6 panels on 1 GPU (4147200 DOF = 3 x 1382400 points), whole-sphere R(Q) of the Galewsky jet + bump",
                       "us_per_eval": te * 1e6, "dof_updates_per_s": dof / te,
                       "algorithmic_GBps": 156.0 * 6 * H * H * n * n / te / 1e9,
                       "form": ("direct, ONE launch (tile-edge lines pulled from the neighbour tiles' nodal values, no interface buffer)"

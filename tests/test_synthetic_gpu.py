@@ -149,7 +149,7 @@ def test_mass_conservation_at_full_size(n, H, V):
 
 def test_shallow_water_mass_conservation_at_s7():
     """The S7 workload of BASELINE.json's galewsky line at FULL size (shallow water, n = 8, 60 x 60 elements per panel,
-    6 panels, 1.24 M DOF) through its size-independent property: the continuity row is in flux form, so the quadrature
+    6 panels, 4.15 M DOF) through its size-independent property: the continuity row is in flux form, so the quadrature
     of sqrtG * R[h] over the closed sphere telescopes to zero - every AUSM interface flux, across rotated and flipped
     panel edges too, is the same number from both sides.  Own cubed-sphere metric, seeded state; one evaluation with
     all panels in one launch per phase and one through the per-panel launches."""
