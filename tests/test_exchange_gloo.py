@@ -62,7 +62,7 @@ def _worker(rank, world, port, q):
         raise
 
 
-@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("world", [2, 3, 6, 8])
 def test_exchange_over_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -213,7 +213,7 @@ def _jvp_worker(rank, world, port, q):
         raise
 
 
-@pytest.mark.parametrize("world", [2, 8])
+@pytest.mark.parametrize("world", [2, 6, 8])
 def test_prepared_jvp_orchestration_over_gloo(world):
     """RhsEuler3D.jvp_prepare + jvp across ranks (whole panels on 2 ranks; 8 ranks, two of them idle): the value halos
     travel once, the tangent halos once per product through their own exchange, interior before boundary, and the
@@ -262,7 +262,7 @@ def _rhs_worker(rank, world, port, q):
         raise
 
 
-@pytest.mark.parametrize("world", [2, 8])
+@pytest.mark.parametrize("world", [2, 6, 8])
 def test_panel_rhs_orchestration_over_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
