@@ -1010,7 +1010,9 @@ def main():
     for i in range(args.steps):
         # HIP events around every kernel launch of every `event_every`-th timed step (default: every step).  An event pair
         # is two marker packets between kernels that would otherwise follow each other directly and overlap their tails:
-        # 24 pairs per evaluation cost it 0.3-0.4 % (measured, profiles/r03_v12_event_sampling.txt)
+        # 24 pairs per evaluation cost it 1.1 % (6.80-6.82 against 6.73-6.74 ms, profiles/r05_bench_spread.txt); kept at every
+        # step because the rocprofv3 averages of the same command then describe the same launches in the same state - with
+        # events on every fourth step the two differed by 4 % (profiles/r03_v12_event_sampling.txt)
         recording[0] = i % args.event_every == 0
         if one_call:
             lib.wx_exchange_set_timer(ex._native, native_timers[i] if recording[0] else None)
