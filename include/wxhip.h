@@ -207,6 +207,18 @@ typedef enum {
 } wx_kernel;
 int wx_euler3d_uses_matrix_cores(const wx_euler3d_plan* plan, wx_kernel kernel);
 
+/* Low orders (num_solpts 2..4, WX_F64 - the orders of the reference's shipped configurations and of its RHS benchmark,
+ * tests/rhs_benchmark/run.sh:67-71): the evaluation is ONE kernel that keeps the face states on chip (a workgroup owns a
+ * brick of elements, solves every Riemann problem of the brick once, and extrapolates the states beyond the brick's surface
+ * from the neighbour elements' nodal values; csrc/euler3d_brick.h).  On such a plan wx_euler3d_extrap_pack* write the edge
+ * messages only - there is no interface buffer - and every wx_euler3d_rhs* / _stage / _shifted_* call reads q alone; the
+ * calling sequence and the results (to rounding) are those of the two-kernel form.  wx_euler3d_plan_one_kernel: 1 when the
+ * plan takes this form (0 otherwise, < 0 on a null plan); wx_euler3d_plan_set_one_kernel(plan, 0 / 1) switches it at setup
+ * time (0 = the two-kernel form; 1 is refused for plans the form does not serve).  The environment variable
+ * WXHIP_DIRECT=0, read when a plan is created, makes 0 the default. */
+int wx_euler3d_plan_one_kernel(const wx_euler3d_plan* plan);
+wx_status wx_euler3d_plan_set_one_kernel(wx_euler3d_plan* plan, int on);
+
 /* Number of ELEMENTS of dtype in one edge message: 5*V*H*n^2, layout [var][ek][along][n^2] =
  * exactly the reference's q_itf_{s,n,w,e} after ExchangeRequest.wait(). */
 size_t wx_euler3d_edge_count(const wx_euler3d_plan* plan);

@@ -1,0 +1,139 @@
+"""The low-order one-kernel form (csrc/euler3d_brick.h; num_solpts 2..4, float64) against the two-kernel form on the same
+plan, and against the reference's fixtures through every entry point that takes it: whole-tile and INTERIOR + BOUNDARY launches on
+tiles whose sides the bricks do not divide, the batched launch, the fused stage update with its edge messages, the shifted state."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import EDGE_FIELDS, golden, halo7, make_oracle, var_err, var_max
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib_loaded(built_lib):
+    from wxfactory_amd import _lib
+
+    return _lib.load()
+
+
+def _tile(n, H, V, panel=4, seed=3):
+    from wxfactory_amd import synthetic
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan
+
+    m = synthetic.euler3d_metric(n, H, V, panel, DEV, seed=seed)
+    q = synthetic.euler3d_state(n, H, V, panel, DEV, seed=seed)
+    plan = Euler3DPlan(n, H, V, 31, panel, synthetic.dfr_ops(n), m)
+    return plan, q
+
+
+def _halos(plan, q):
+    """A consistent finite halo: the tile's own packed edges, permuted."""
+    send = torch.zeros((4, plan.edge_count), dtype=torch.float64, device=DEV)
+    plan.extrap_pack(q, [send[e].data_ptr() for e in range(4)])
+    torch.cuda.synchronize()
+    return send, [send[e] for e in (1, 0, 3, 2)]
+
+
+def _rel(a, b):
+    ax = tuple(range(1, a.dim()))
+    return float(((a - b).abs().amax(dim=ax) / b.abs().amax(dim=ax).clamp_min(1e-300)).max())
+
+
+@pytest.mark.parametrize("n,H,V", [(2, 5, 3), (2, 8, 2), (2, 3, 1), (3, 5, 3), (3, 4, 2), (4, 5, 2), (4, 3, 1), (2, 1, 1), (4, 2, 3)])
+def test_one_kernel_form_equals_the_two_kernel_form(n, H, V):
+    from wxfactory_amd import _lib
+
+    plan, q = _tile(n, H, V)
+    assert plan.one_kernel
+    send1, halo = _halos(plan, q)
+    hp = [h.data_ptr() for h in halo]
+    out1 = torch.full_like(q, float("nan"))
+    plan.rhs(q, hp, out1)
+    # INTERIOR + BOUNDARY write exactly what ALL writes
+    out1s = torch.full_like(q, float("nan"))
+    plan.rhs(q, None, out1s, _lib.WX_REGION_INTERIOR)
+    plan.rhs(q, hp, out1s, _lib.WX_REGION_BOUNDARY)
+    torch.cuda.synchronize()
+    assert torch.equal(out1, out1s)
+    # the two-kernel form on the same plan
+    plan.set_one_kernel(False)
+    assert not plan.one_kernel
+    send2 = torch.zeros_like(send1)
+    plan.extrap_pack(q, [send2[e].data_ptr() for e in range(4)])
+    out2 = torch.full_like(q, float("nan"))
+    plan.rhs(q, hp, out2)
+    torch.cuda.synchronize()
+    assert torch.equal(send1, send2), "the pack kernel's messages are the extrapolation kernel's, bit for bit"
+    assert torch.isfinite(out1).all()
+    assert _rel(out1, out2) <= 1e-13, _rel(out1, out2)
+    # fused update and shifted state
+    y, v = torch.randn_like(q), q * 1e-3 * torch.rand_like(q)
+    a2 = torch.empty_like(q)
+    plan.shifted_extrap_pack(q, v, 1e-4, None)
+    plan.shifted_rhs_axpy(q, v, 1e-4, hp, y, a2, 0.5, 0.25, -2.0)
+    plan.set_one_kernel(True)
+    a1 = torch.empty_like(q)
+    plan.shifted_extrap_pack(q, v, 1e-4, None)
+    plan.shifted_rhs_axpy(q, v, 1e-4, hp, y, a1, 0.5, 0.25, -2.0)
+    torch.cuda.synchronize()
+    assert _rel(a1, a2) <= 1e-13
+    plan.close()
+
+
+@pytest.mark.parametrize("n", [2, 3, 4])
+@pytest.mark.parametrize("filtered", [False, True])
+def test_stage_update_and_next_messages(n, filtered):
+    """wx_euler3d_stage with prepare_next: the stage's output and the edge messages of that output (the next stage's state) -
+    one-kernel form against the two-kernel form's pipeline epilogue."""
+    from wxfactory_amd import _lib, synthetic
+
+    H, V = 5, 2
+    plan, q = _tile(n, H, V)
+    plan.reserve(_lib.WX_RESERVE_STAGE)
+    if filtered:
+        f = np.eye(n) * 0.97 + 0.03 / n
+        plan.set_exp_filter(f)
+    _, halo = _halos(plan, q)
+    hp = [h.data_ptr() for h in halo]
+    y = torch.randn_like(q) * 1e-3 + q
+    res = {}
+    for form in (True, False):
+        plan.set_one_kernel(form)
+        ns = torch.zeros((4, plan.edge_count), dtype=torch.float64, device=DEV)
+        flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+        out = torch.empty_like(q)
+        plan.extrap_pack_slot(q, None, 0)
+        plan.stage(q, hp, y, None, out, 0.75, 0.25, 1e-3, 0.0, _lib.WX_REGION_ALL, 0, [ns[e].data_ptr() for e in range(4)],
+                   2 if filtered else 1, flag.data_ptr() if filtered else 0)
+        torch.cuda.synchronize()
+        res[form] = (out, ns, int(flag.item()))
+    assert res[True][2] == 0 and res[False][2] == 0
+    assert _rel(res[True][0], res[False][0]) <= 1e-13
+    assert _rel(res[True][1], res[False][1]) <= 1e-12
+    plan.close()
+
+
+@pytest.mark.parametrize("name", ["euler3d_c31p_n2_h4_v3", "euler3d_c31p_n3_h4_v2", "euler3d_c21_n4_h3_v4", "euler3d_c21p_n4_h3_v4"])
+def test_whole_sphere_callable_on_low_order_fixtures(name):
+    """RhsEuler3D (batched launches, exchange by aliasing) on the reference's low-order fixtures: R of every panel at 1e-10."""
+    from tests.gpu_util import make_plan, to_dev
+    from wxfactory_amd.rhs_euler3d import RhsEuler3D
+
+    g = golden(name)
+    panels = g.metric_panels()
+    if len(panels) != 6:
+        pytest.skip("needs all six panels")
+    plans = {p: make_plan(g, p) for p in panels}
+    assert all(pl.one_kernel for pl in plans.values())
+    rhs = RhsEuler3D(plans)
+    Q = torch.stack([to_dev(g.q(p)) for p in panels])
+    R = rhs(Q).cpu().numpy()
+    for i, p in enumerate(panels):
+        o = make_oracle(g, p)
+        want = {}
+        o.rhs(g.q(p), g.halo(p), want=want)
+        scale = np.maximum(var_max(g.r(p)), o.cancel_scale(want))
+        err = var_err(R[i], g.r(p))
+        assert (err <= 1e-10 * scale).all(), (name, p, err / scale)

@@ -76,6 +76,8 @@ SIGNATURES = {
     "wx_euler3d_plan_set_column_metric": (c_int, [c_void_p, c_void_p]),
     "wx_euler3d_plan_has_column_metric": (c_int, [c_void_p]),
     "wx_euler3d_uses_matrix_cores": (c_int, [c_void_p, c_int]),
+    "wx_euler3d_plan_one_kernel": (c_int, [c_void_p]),
+    "wx_euler3d_plan_set_one_kernel": (c_int, [c_void_p, c_int]),
     "wx_euler3d_extrap_pack": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p]),
     "wx_euler3d_rhs": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_int, c_void_p]),
     "wx_euler3d_rhs_axpy": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_double, c_double,

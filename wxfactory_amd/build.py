@@ -49,16 +49,23 @@ def build(force: bool = False, verbose: bool = False, defines=(), out: str = LIB
                  and os.path.getmtime(obj) > max(newest_header, os.path.getmtime(os.path.join(CSRC, src))))
         if fresh:
             continue
-        open(stamp, "w").write(switches)
+        for stale in (stamp, obj):   # (a failed compile must not leave the old object beside a stamp that matches)
+            if os.path.exists(stale):
+                os.remove(stale)
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
         cmd += ["-D" + d for d in defines]
         cmd += os.environ.get("WX_HIPCC_EXTRA", "").split()   # development: extra compiler flags for an experiment variant
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, p in procs:
+        procs.append((cmd, stamp, subprocess.Popen(cmd)))
+    failed = []
+    for cmd, stamp, p in procs:
         if p.wait() != 0:
-            raise RuntimeError("hipcc failed: " + " ".join(cmd))
+            failed.append(" ".join(cmd))
+        else:
+            open(stamp, "w").write(switches)   # the stamp follows a successful compile only
+    if failed:
+        raise RuntimeError("hipcc failed: " + "; ".join(failed))
     # RCCL (the halo exchange, csrc/exchange.hip): librccl.so.1 - inside a torch process the copy torch has loaded already
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs + ["-L/opt/rocm/lib", "-lrccl"]
     if verbose:

@@ -27,7 +27,8 @@
 //
 // This file: the plan, the batch and the C ABI.  The device code is in the headers included below, one per kernel family:
 //   euler3d_common.h (parameter block, launch shapes, value types), euler3d_extrap.h (K1), euler3d_rhs.h (K2),
-//   euler3d_jvp.h (the JVP specialisation), euler3d_launch.h (launchers, the column-form entry points).
+//   euler3d_brick.h (the one-kernel form of the low orders), euler3d_jvp.h (the JVP specialisation), euler3d_launch.h
+//   (launchers, the column-form entry points).
 #include "wx_common.h"
 #include "wx_math.h"
 #include "wx_mfma.h"
@@ -47,6 +48,7 @@
 #include "euler3d_common.h"
 #include "euler3d_extrap.h"
 #include "euler3d_rhs.h"
+#include "euler3d_brick.h"
 #include "euler3d_jvp.h"
 #include "euler3d_launch.h"
 
@@ -67,6 +69,9 @@ struct wx_euler3d_plan {
     double* face_val = nullptr;   // prepared JVP: face values of the linearisation state, [elem][6][5][n^2] doubles
     EulerParams<double> base;  // pointer-free parts + metric pointers (q/rhs/halo/send filled per call)
     // column form (wx_euler3d_plan_set_column_metric): the metric of a column-invariant geometry as (n x n) slabs
+    // low orders, float64: the one-kernel form (euler3d_brick.h) - the pack entry points write the edge messages only,
+    // the evaluation reads no interface buffer.  WXHIP_DIRECT=0 (environment, read at plan creation): the two-kernel form.
+    bool direct = false;
     bool column = false;
     const double *c_sg = nullptr, *c_h = nullptr, *c_chr = nullptr, *c_idz = nullptr, *c_sgi = nullptr, *c_sgj = nullptr,
                  *c_sgk = nullptr, *c_hi = nullptr, *c_hj = nullptr, *c_hk = nullptr;
@@ -130,6 +135,27 @@ wx_status dispatch_rhs(int n, const EulerParams<T>& P, hipStream_t st) {
 
 int region_count(int region, int H, int V);
 
+bool plan_direct(const wx_euler3d_plan* pl) { return pl->direct && !pl->column; }
+
+// the pack half of an evaluation in the one-kernel form (float64)
+wx_status dispatch_pack(int n, const EulerParams<double>& P, hipStream_t st) {
+    switch (n) {
+        case 2: return launch_pack<2, double>(P, st);
+        case 3: return launch_pack<3, double>(P, st);
+        case 4: return launch_pack<4, double>(P, st);
+    }
+    return fail(WX_ERR_UNSUPPORTED, "the one-kernel form serves num_solpts 2..4, not %d", n);
+}
+
+wx_status dispatch_brick(int n, const EulerParams<double>& P, bool epi, hipStream_t st) {
+    switch (n) {
+        case 2: return launch_brick<2>(P, epi, st);
+        case 3: return launch_brick<3>(P, epi, st);
+        case 4: return launch_brick<4>(P, epi, st);
+    }
+    return fail(WX_ERR_UNSUPPORTED, "the one-kernel form serves num_solpts 2..4, not %d", n);
+}
+
 template <typename T>
 wx_status run_extrap(wx_euler3d_plan* pl, const void* q, void* const send[4], hipStream_t st, int slot = 0) {
     EulerParams<T> P = make_params<T>(pl);
@@ -138,6 +164,9 @@ wx_status run_extrap(wx_euler3d_plan* pl, const void* q, void* const send[4], hi
     if (send) {
         P.send_s = static_cast<T*>(send[0]); P.send_n = static_cast<T*>(send[1]);
         P.send_w = static_cast<T*>(send[2]); P.send_e = static_cast<T*>(send[3]);
+    }
+    if constexpr (std::is_same<T, double>::value) {
+        if (plan_direct(pl)) return send ? dispatch_pack(pl->n, P, st) : WX_OK;   // (no interface buffer to fill)
     }
     return dispatch_extrap<T>(pl->n, P, st);
 }
@@ -173,6 +202,7 @@ wx_status run_rhs(wx_euler3d_plan* pl, const void* q, const void* const halo[4],
             P.sgi = pl->c_sgi; P.sgj = pl->c_sgj; P.sgk = pl->c_sgk; P.hi = pl->c_hi; P.hj = pl->c_hj; P.hk = pl->c_hk;
             return dispatch_rhs_column(pl->n, P, st);
         }
+        if (plan_direct(pl)) return dispatch_brick(pl->n, P, epilogue, st);
     }
     return dispatch_rhs<T>(pl->n, P, st);
 }
@@ -234,6 +264,10 @@ wx_status wx_euler3d_plan_create_tile(wx_euler3d_plan** out, int n, int H, int V
         };
         b.md_v = magic(V); b.md_h = magic(H); b.md_w = magic(H - 2);
         b.md_ring = magic(H * H - (H > 2 ? (H - 2) * (H - 2) : 0));
+    }
+    {
+        const char* env = getenv("WXHIP_DIRECT");
+        pl->direct = dtype == WX_F64 && n <= 4 && !(env && env[0] == '0');
     }
     b.advection_only = case_number < 13; b.has_damp = damp;
     b.sg = m->sqrtG; b.h = m->h_contra; b.chr = m->christoffel; b.idz = m->inv_dzdeta;
@@ -327,6 +361,16 @@ wx_status wx_euler3d_plan_set_column_metric(wx_euler3d_plan* pl, const wx_euler3
 }
 
 int wx_euler3d_plan_has_column_metric(const wx_euler3d_plan* pl) { return pl && pl->column ? 1 : 0; }
+
+int wx_euler3d_plan_one_kernel(const wx_euler3d_plan* pl) { return pl ? (plan_direct(pl) ? 1 : 0) : -1; }
+
+wx_status wx_euler3d_plan_set_one_kernel(wx_euler3d_plan* pl, int on) {
+    if (!pl) return fail(WX_ERR_INVALID, "wx_euler3d_plan_set_one_kernel: null plan");
+    if (on && !(pl->dtype == WX_F64 && pl->n <= 4))
+        return fail(WX_ERR_UNSUPPORTED, "the one-kernel form serves WX_F64 plans of num_solpts 2..4");
+    pl->direct = on != 0;
+    return WX_OK;
+}
 
 double wx_euler3d_bytes_per_point(const wx_euler3d_plan* pl) {
     if (!pl) return 0.0;
@@ -610,6 +654,7 @@ wx_status wx_euler3d_shifted_extrap_pack(wx_euler3d_plan* pl, const double* q, c
         P.send_w = static_cast<double*>(send[2]); P.send_e = static_cast<double*>(send[3]);
     }
     WX_STREAM(st, stream);
+    if (plan_direct(pl)) return send ? dispatch_pack(pl->n, P, st) : WX_OK;
     return dispatch_extrap<double>(pl->n, P, st);
 }
 
@@ -635,11 +680,12 @@ wx_status wx_euler3d_shifted_rhs_axpy2(wx_euler3d_plan* pl, const double* q, con
         P.halo_w = static_cast<const double*>(halo[2]); P.halo_e = static_cast<const double*>(halo[3]);
     }
     WX_STREAM(st, stream);
+    if (plan_direct(pl)) return dispatch_brick(pl->n, P, false, st);
     return dispatch_rhs<double>(pl->n, P, st);
 }
 
 static wx_status ensure_slot1(wx_euler3d_plan* pl) {
-    if (pl->itf2) return WX_OK;
+    if (pl->itf2 || plan_direct(pl)) return WX_OK;   // (the one-kernel form has no interface buffer)
     return fail(WX_ERR_INVALID, "the stage pipeline needs the second interface buffer - call wx_euler3d_plan_reserve(plan, "
                                 "WX_RESERVE_STAGE) at setup time (evaluation entry points do not allocate)");
 }
@@ -724,6 +770,7 @@ wx_status wx_euler3d_stage(wx_euler3d_plan* pl, const void* q, const void* const
 struct wx_euler3d_batch {
     int n, H, V, count, nelem;
     wx_dtype dtype;
+    bool direct = false;    // every plan takes the one-kernel form (euler3d_brick.h)
     void* table = nullptr;  // device: EulerParams<T>[count]
 };
 
@@ -760,6 +807,15 @@ wx_status batch_extrap(const wx_euler3d_batch* b, const void* q, const double* v
         dyn.q_tan = v; dyn.eps = eps;  // float64: shifted state q + eps v (null: plain)
     }
     const EulerParams<T>* t = static_cast<const EulerParams<T>*>(b->table);
+    if constexpr (std::is_same<T, double>::value) {
+        if (b->direct) {
+            switch (b->n) {
+                case 2: return launch_pack_batch<2, T>(t, dyn, b->H, b->V, b->count, st);
+                case 3: return launch_pack_batch<3, T>(t, dyn, b->H, b->V, b->count, st);
+                case 4: return launch_pack_batch<4, T>(t, dyn, b->H, b->V, b->count, st);
+            }
+        }
+    }
     switch (b->n) {
         case 2: return launch_extrap_batch<2, T>(t, dyn, b->nelem, b->count, st);
         case 3: return launch_extrap_batch<3, T>(t, dyn, b->nelem, b->count, st);
@@ -785,6 +841,15 @@ wx_status batch_rhs(const wx_euler3d_batch* b, const void* q, const double* v, d
     dyn.region = region; dyn.count = region_count(region, b->H, b->V);
     dyn.axpy = axpy; dyn.ca = ca; dyn.cb = cb; dyn.cc = cc; dyn.cd = cd;
     const EulerParams<T>* t = static_cast<const EulerParams<T>*>(b->table);
+    if constexpr (std::is_same<T, double>::value) {
+        if (b->direct) {
+            switch (b->n) {
+                case 2: return launch_brick_batch<2>(t, dyn, b->H, b->V, b->count, st);
+                case 3: return launch_brick_batch<3>(t, dyn, b->H, b->V, b->count, st);
+                case 4: return launch_brick_batch<4>(t, dyn, b->H, b->V, b->count, st);
+            }
+        }
+    }
     switch (b->n) {
         case 2: return launch_rhs_batch<2, T>(t, dyn, b->count, st);
         case 3: return launch_rhs_batch<3, T>(t, dyn, b->count, st);
@@ -816,6 +881,8 @@ wx_status wx_euler3d_batch_create(wx_euler3d_batch** out, wx_euler3d_plan* const
     if (!b) return fail(WX_ERR_NOMEM, "out of host memory");
     b->n = plans[0]->n; b->H = plans[0]->H; b->V = plans[0]->V; b->count = count; b->nelem = (int)plans[0]->nelem;
     b->dtype = plans[0]->dtype;
+    b->direct = true;
+    for (int i = 0; i < count; ++i) b->direct = b->direct && plan_direct(plans[i]);
     wx_status s = WX_ERR_INVALID;
     try {   // (the host copy of the table is a std::vector: no exception crosses the C boundary)
         switch (b->dtype) {

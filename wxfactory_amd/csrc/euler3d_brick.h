@@ -1,0 +1,592 @@
+// The low-order form of the 3-D Euler evaluation (n = 2, 3, 4: the orders of every shipped .ini and of the reference's own
+// RHS benchmark matrix, tests/rhs_benchmark/run.sh:67-71): ONE kernel per evaluation, no interface buffer.
+//
+// Why: at low order the interface buffer of the two-kernel form is the traffic.  An element of n^3 points has 6 n^2 face
+// points: K1 writes 5 * 6 / n values per solution point (120 B/point at n = 2 beside 40 B/point of state), K2 reads them
+// back twice (own and neighbour side), and both neighbours solve every Riemann problem.  Measured at n = 2 on the
+// reference's benchmark size (profiles/r06_low_order_ceiling.txt): K1 50 us + K2 168 us, of which K2's loads and stores
+// alone take 124 us - the evaluation is bound by the bytes of its own intermediate, not by its arithmetic.
+//
+// Here a workgroup owns a BRICK of elements (4 x 4 x 2 at n = 2, 2 x 2 x 2 at n = 3, 2 x 2 x 1 at n = 4):
+//   * the state of the brick goes to LDS once (log rho, rho u^i, log rho theta: rhs_dfr.py:50-71);
+//   * the face states of both sides of every face INSIDE the brick are extrapolated from LDS, the Riemann problem of such a
+//     face is solved ONCE and its seven results are handed to both elements (fluxes.py:326-403 writes the common flux
+//     to both sides too);
+//   * for a face on the brick's surface the outer state comes from the received halo (tile edge), from the wall rule
+//     (ground / top, pde_euler_cubesphere.py:150-156), or is extrapolated HERE from the neighbour element's nodal values
+//     read from Q - n values per face point and variable out of the L2 / Infinity Cache instead of one out of an
+//     interface buffer that a kernel before this one had to write;
+//   * the rest (pointwise fluxes, forcing, the three directional passes, epilogue) is the fused kernel's (euler3d_rhs.h).
+// The tile-edge messages come from a pack kernel over the ring of boundary elements only (euler3d_extrap.h, PACK_ONLY).
+// Arithmetic is the two-kernel form's, operation for operation (same extrapolation sums, same Rusanov expressions): the two
+// forms agree to rounding (the interface metric of a face inside the brick is read from the lower element's slot for both
+// sides, where the two-kernel form reads each element's own copy of the same number).
+#pragma once
+
+// diagnostic builds of the one-kernel form (wrong results; profiles/r06_brick_breakdown.txt): 1 the states beyond the brick's
+// surface are copies of the own state (no loads of neighbour elements, no logarithms of their values); 2 no Riemann arithmetic;
+// 3 no face stage at all; 4 no Christoffel loads
+#ifndef WX_BRICK_DIAG
+#define WX_BRICK_DIAG 0
+#endif
+
+namespace wx {
+
+template <int N>
+struct BrickCfg {
+    static constexpr bool on = N <= 4;
+    static constexpr int N2 = N * N, N3 = N * N * N;
+    static constexpr int LOG_EPB = N == 2 ? 5 : (N == 3 ? 3 : (N == 4 ? 2 : 0));   // elements per brick: 32, 8, 4
+    static constexpr int EPB = 1 << LOG_EPB;
+    static constexpr int BS = ((EPB * N3 + 63) / 64) * 64;
+    static constexpr int NP = Cfg<N>::NP;
+    static constexpr int LE = N2 * NP;
+    __host__ __device__ static constexpr int lidx(int kl, int jl, int il) { return (kl * N + jl) * NP + il; }
+};
+
+// The elements of one launch: up to four boxes of a tile (ALL: the tile; INTERIOR: the tile without its ring; BOUNDARY: the
+// south and north rows, the west and east columns), every level, each box cut into bricks of its own shape
+// (2^li x 2^lj x 2^lk elements, li + lj + lk = LOG_EPB: a one-element-wide strip takes long bricks).  Bricks start at the
+// box origin; the last brick of a row / column / the top layer may be cut (its surplus threads idle).
+struct BrickBoxes {
+    int nbricks;           // bricks of one tile in this launch = plane * (bricks along k)
+    int plane;             // in-plane bricks, all boxes
+    unsigned md_plane;     // fast_div multiplier for `plane`
+    int lk;                // log2 of the brick's vertical extent (the same for every box)
+    int start1, start2, start3;   // first in-plane brick of boxes 1, 2, 3 (INT_MAX: no such box)
+    int i0[4], j0[4], i1[4], j1[4];   // the boxes' element ranges [i0, i1) x [j0, j1)
+    int li[4], lj[4], nbi[4];         // brick shape and bricks per row
+    unsigned mdi[4];                  // fast_div multiplier for nbi
+};
+// (constant indices only: a run-time index into a by-value kernel argument sends the whole struct to scratch)
+#define WX_BOX(G, field, box) ((box) == 0 ? (G).field[0] : ((box) == 1 ? (G).field[1] : ((box) == 2 ? (G).field[2] : (G).field[3])))
+
+template <typename X>
+__device__ __forceinline__ X* raw_ptr(X* p) { return p; }
+template <typename X>
+__device__ __forceinline__ X* raw_ptr(gp<X> p) { return p.raw(); }
+
+struct BrickAt {
+    int i0, j0, k0, i1, j1, li, lj, lk;
+    bool any;
+};
+
+__device__ __forceinline__ BrickAt brick_at(const BrickBoxes& G, int L) {
+    BrickAt b;
+    b.any = L < G.nbricks;
+    if (!b.any) L = 0;
+    const int kb = fast_div(L, G.plane, G.md_plane);
+    const int bp = L - kb * G.plane;
+    const int box = (bp >= G.start1) + (bp >= G.start2) + (bp >= G.start3);
+    const int r = bp - (box == 0 ? 0 : (box == 1 ? G.start1 : (box == 2 ? G.start2 : G.start3)));
+    const int nbi = WX_BOX(G, nbi, box);
+    const int bj = fast_div(r, nbi, WX_BOX(G, mdi, box)), bi = r - bj * nbi;
+    b.li = WX_BOX(G, li, box); b.lj = WX_BOX(G, lj, box); b.lk = G.lk;
+    b.i0 = WX_BOX(G, i0, box) + (bi << b.li); b.j0 = WX_BOX(G, j0, box) + (bj << b.lj); b.k0 = kb << b.lk;
+    b.i1 = WX_BOX(G, i1, box); b.j1 = WX_BOX(G, j1, box);
+    return b;
+}
+
+struct BElem {
+    int ei, ej, ek, e;
+    int lbi, lbj, lbk;   // position in the brick
+    bool valid;
+};
+
+template <int EPB>
+__device__ __forceinline__ BElem brick_elem(const BrickAt& b, int le, int H, int V) {
+    BElem r;
+    r.lbi = le & ((1 << b.li) - 1);
+    r.lbj = (le >> b.li) & ((1 << b.lj) - 1);
+    r.lbk = le >> (b.li + b.lj);
+    r.ei = b.i0 + r.lbi; r.ej = b.j0 + r.lbj; r.ek = b.k0 + r.lbk;
+    r.valid = b.any && le < EPB && r.ei < b.i1 && r.ej < b.j1 && r.ek < V;
+    if (!r.valid) { r.ei = b.i0; r.ej = b.j0; r.ek = b.k0; }   // (an addressable element: the brick's first)
+    r.e = (r.ek * H + r.ej) * H + r.ei;
+    return r;
+}
+
+// both sides of one Riemann problem (rusanov_face from the left element's point of view + the two right-side values):
+// qL, qR [7]: the five face values in, pressure and log pressure filled here.  wall: 0 none, 1 the RIGHT state is the mirror
+// image of the left one (top of the model: own = left), 2 the LEFT state mirrors the right one (ground)
+template <typename T>
+__device__ __forceinline__ void rusanov_both(T* qL, T* qR, int d, int wall, double sg, double h0, double h1, double h2,
+                                             bool advection_only, T* outL, T& bR, T& lpR) {
+    const T gL = kGamma * w_log(qL[4] * kRdOverP0), gR = kGamma * w_log(qR[4] * kRdOverP0);
+    qL[5] = kP0 * w_exp(gL); qR[5] = kP0 * w_exp(gR);
+    qL[6] = kLogP0 + gL; qR[6] = kLogP0 + gR;
+    const double hdd = d == 0 ? h0 : (d == 1 ? h1 : h2);
+    const T rL = 1.0 / qL[0], rR = 1.0 / qR[0];
+    T uL = w_sel(d == 0, qL[1], w_sel(d == 1, qL[2], qL[3])) * rL;
+    T uR = w_sel(d == 0, qR[1], w_sel(d == 1, qR[2], qR[3])) * rR;
+    if (wall == 1) uR = -uL;   // no-flow wall: odd symmetry of w (pde_euler_cubesphere.py:150-156)
+    if (wall == 2) uL = -uR;
+    rusanov_face<T>(qL, qR, uL, uR, rL, rR, sg, h0, h1, h2, hdd, true, advection_only, outL);
+    const double sgh2 = sg * h2;
+    bR = 0.5 * (sgh2 * qL[5] + sgh2 * qR[5]) / qR[5];
+    lpR = qR[6];
+}
+
+// The face stage of a brick.  img: the five LDS images of the brick's state (log rho, rho u1, rho u2, rho w, log rho theta),
+// element `le` at le * LE.  store(le, f, fp, out[0..4], B, log p) receives the seven results of face f of element le.
+// Work items: the three plus-side faces of every element (the face is solved for both elements when the upper neighbour is
+// in the brick), then the minus-side faces of the elements on the brick's three lower surfaces - every face once, no idle
+// item in a full brick.
+template <int N, typename T, bool G, typename Store>
+__device__ __forceinline__ void brick_face_stage(const EulerParams<T, G>& P, const BrickAt& bk, const T* img, int img_stride,
+                                                 Store store) {
+    using C = BrickCfg<N>;
+    constexpr int N2 = C::N2, N3 = C::N3, EPB = C::EPB, BS = C::BS;
+    const int tid = threadIdx.x;
+    const int H = P.H, V = P.V;
+    const size_t fs = (size_t)P.nelem * N3;
+    const int ni = 1 << bk.li, nj = 1 << bk.lj, nk = 1 << bk.lk;
+    constexpr int nA = 3 * EPB * N2;
+    const int nB0 = nj * nk * N2, nB1 = ni * nk * N2, nB2 = ni * nj * N2;
+    const int total = nA + nB0 + nB1 + nB2;
+    // (the four halo pointers by value, here: a select between MEMBERS of a parameter block that is a local copy - the batched
+    // launch - becomes a select of their addresses and sends the whole block to scratch)
+    const T* const halo_e = raw_ptr(P.halo_e); const T* const halo_w = raw_ptr(P.halo_w);
+    const T* const halo_n = raw_ptr(P.halo_n); const T* const halo_s = raw_ptr(P.halo_s);
+    for (int w = tid; w < total; w += BS) {
+        int d, fle, fp;
+        bool plus;
+        if (w < nA) {
+            d = w / (EPB * N2);
+            const int r = w - d * (EPB * N2);
+            fle = r / N2; fp = r - fle * N2;
+            plus = true;
+        } else {
+            int x = w - nA;
+            plus = false;
+            if (x < nB0) {          // elements with lbi == 0, indexed by (lbk, lbj)
+                d = 0;
+                const int s = x / N2; fp = x - s * N2;
+                fle = s << bk.li;
+            } else if (x < nB0 + nB1) {   // lbj == 0, indexed by (lbk, lbi)
+                d = 1;
+                x -= nB0;
+                const int s = x / N2; fp = x - s * N2;
+                fle = ((s >> bk.li) << (bk.li + bk.lj)) + (s & (ni - 1));
+            } else {                      // lbk == 0, indexed by (lbj, lbi)
+                d = 2;
+                x -= nB0 + nB1;
+                const int s = x / N2; fp = x - s * N2;
+                fle = s;
+            }
+        }
+        const BElem el = brick_elem<EPB>(bk, fle, H, V);
+        if (!el.valid) continue;
+        // the element across the face
+        const int gd = d == 0 ? el.ei : (d == 1 ? el.ej : el.ek);   // own coordinate along d
+        const int nd = d == 0 ? ni : (d == 1 ? nj : nk);            // brick extent along d
+        const int end_d = d == 0 ? bk.i1 : (d == 1 ? bk.j1 : V);    // end of the launch's box along d
+        const int ng = plus ? gd + 1 : gd - 1;
+        const int lbd = d == 0 ? el.lbi : (d == 1 ? el.lbj : el.lbk);   // (selects: a run-time index would go to scratch)
+        const bool in_brick = plus && (lbd + 1 < nd) && (ng < end_d);
+        const int lim = d == 2 ? V : H;
+        const bool outside = ng < 0 || ng >= lim;   // tile edge (halo) or ground / top (wall)
+        const int a = fp / N, b = fp - a * N;
+        // nodal line of face point (a, b) along d: LDS offset and stride, point index and stride
+        int lbase, lstride, pbase, pstride;
+        if (d == 0) { lbase = C::lidx(a, b, 0); lstride = 1; pbase = (a * N + b) * N; pstride = 1; }
+        else if (d == 1) { lbase = C::lidx(a, 0, b); lstride = C::NP; pbase = a * N2 + b; pstride = N; }
+        else { lbase = C::lidx(0, a, b); lstride = N * C::NP; pbase = a * N + b; pstride = N2; }
+
+        // own side: from LDS, the weights of the own face (extrap_faces, term by term)
+        T so[7], sn[7];
+        {
+            const auto wv = plus ? P.K->ep : P.K->em;
+#pragma unroll
+            for (int v = 0; v < 5; ++v) so[v] = T(0.0);
+#pragma unroll
+            for (int m = 0; m < N; ++m) {
+                const double wm = wv[m];
+#pragma unroll
+                for (int v = 0; v < 5; ++v) so[v] += wm * img[v * img_stride + fle * C::LE + lbase + m * lstride];
+            }
+            so[0] = w_exp(so[0]);
+            so[4] = w_exp(so[4]);
+        }
+        int wall = 0;
+        const int nle = fle + (d == 0 ? 1 : (d == 1 ? ni : ni * nj));
+        if (in_brick) {
+            const auto wv = P.K->em;   // the upper element's minus face
+#pragma unroll
+            for (int v = 0; v < 5; ++v) sn[v] = T(0.0);
+#pragma unroll
+            for (int m = 0; m < N; ++m) {
+                const double wm = wv[m];
+#pragma unroll
+                for (int v = 0; v < 5; ++v) sn[v] += wm * img[v * img_stride + nle * C::LE + lbase + m * lstride];
+            }
+            sn[0] = w_exp(sn[0]);
+            sn[4] = w_exp(sn[4]);
+        } else if ((outside && d == 2) || WX_BRICK_DIAG == 1) {
+            wall = plus ? 1 : 2;
+#pragma unroll
+            for (int v = 0; v < 5; ++v) sn[v] = so[v];
+        } else if (outside) {
+            // lateral tile edge: the received message (process_topology.py:595-606), five planes V H n^2 apart
+            const size_t vsh = (size_t)V * H * N2;
+            pp<T, const T, G> hb(d == 0 ? (plus ? halo_e : halo_w) : (plus ? halo_n : halo_s));
+            hb = hb + ((size_t)el.ek * H + (d == 0 ? el.ej : el.ei)) * N2 + fp;
+#pragma unroll
+            for (int v = 0; v < 5; ++v) sn[v] = hb[v * vsh];
+        } else {
+            // a neighbour element of this tile outside the brick: its face state from its nodal values, as its own
+            // extrapolation forms it
+            const size_t eo = (size_t)(el.e + (plus ? 1 : -1) * (d == 0 ? 1 : (d == 1 ? H : H * H))) * N3 + pbase;
+            const auto wv = plus ? P.K->em : P.K->ep;   // its face towards this brick
+            T nv[N][5];
+#pragma unroll
+            for (int m = 0; m < N; ++m) load_state<T>(P, eo + m * pstride, fs, nv[m][0], nv[m][1], nv[m][2], nv[m][3], nv[m][4]);
+#pragma unroll
+            for (int v = 0; v < 5; ++v) sn[v] = T(0.0);
+#pragma unroll
+            for (int m = 0; m < N; ++m) {
+                const double wm = wv[m];
+                sn[0] += wm * w_log(nv[m][0]);
+                sn[1] += wm * nv[m][1];
+                sn[2] += wm * nv[m][2];
+                sn[3] += wm * nv[m][3];
+                sn[4] += wm * w_log(nv[m][4]);
+            }
+            sn[0] = w_exp(sn[0]);
+            sn[4] = w_exp(sn[4]);
+        }
+        // interface metric: the own slot of the face (face_load)
+        double sg, h0, h1, h2;
+        {
+            const int pl = plus ? 1 : 0;
+            pp<T, const double, G> sgp, hp;
+            size_t hfs;
+            if (d == 0) {
+                const size_t o = (((size_t)el.ek * H + el.ej) * (H + 2) + el.ei + 1) * 2 * N2 + pl * N2 + fp;
+                hfs = (size_t)V * H * (H + 2) * 2 * N2;
+                sgp = P.sgi + o; hp = P.hi + 0 * 3 * hfs + o;
+            } else if (d == 1) {
+                const size_t o = (((size_t)el.ek * (H + 2) + el.ej + 1) * H + el.ei) * 2 * N2 + pl * N2 + fp;
+                hfs = (size_t)V * (H + 2) * H * 2 * N2;
+                sgp = P.sgj + o; hp = P.hj + 1 * 3 * hfs + o;
+            } else {
+                const size_t o = ((((size_t)el.ek + 1) * H + el.ej) * H + el.ei) * 2 * N2 + pl * N2 + fp;
+                hfs = (size_t)(V + 2) * H * H * 2 * N2;
+                sgp = P.sgk + o; hp = P.hk + 2 * 3 * hfs + o;
+            }
+            sg = *sgp; h0 = hp[0]; h1 = hp[hfs]; h2 = hp[2 * hfs];
+        }
+        // left = the lower element's plus-side state, right = the upper element's minus-side state
+        T qL[7], qR[7];
+#pragma unroll
+        for (int v = 0; v < 5; ++v) {
+            qL[v] = w_sel(plus, so[v], sn[v]);
+            qR[v] = w_sel(plus, sn[v], so[v]);
+        }
+        T out[7], bR, lpR;
+        if (WX_BRICK_DIAG == 2) {
+            T sum = T(sg + h0 + h1 + h2);
+#pragma unroll
+            for (int v = 0; v < 5; ++v) sum += qL[v] + qR[v];
+#pragma unroll
+            for (int c = 0; c < 7; ++c) out[c] = sum;
+            bR = sum; lpR = sum;
+        } else
+        rusanov_both<T>(qL, qR, d, wall, sg, h0, h1, h2, P.advection_only != 0, out, bR, lpR);
+        if (plus) {
+            store(fle, 2 * d + 1, fp, out, out[5], out[6]);
+            if (in_brick) store(nle, 2 * d, fp, out, bR, lpR);
+        } else {
+            store(fle, 2 * d, fp, out, bR, lpR);
+        }
+    }
+}
+
+// tile-edge messages of the stage's OUTPUT (the next stage's state) from its LDS images (log rho, momenta, log rho theta):
+// what extrap_faces does for the outward faces of the tile edge, on a brick
+template <int N, typename T, bool G>
+__device__ __forceinline__ void brick_pack_edges(const EulerParams<T, G>& P, const BrickAt& bk, const T* img, int img_stride) {
+    using C = BrickCfg<N>;
+    constexpr int N2 = C::N2, EPB = C::EPB, BS = C::BS;
+    const int H = P.H, V = P.V;
+    for (int fi = threadIdx.x; fi < EPB * 4 * N2; fi += BS) {
+        const int le = fi / (4 * N2);
+        const int r = fi - le * (4 * N2);
+        const int f = r / N2, fp = r - f * N2;
+        const BElem el = brick_elem<EPB>(bk, le, H, V);
+        if (!el.valid) continue;
+        const int d = f >> 1, plus = f & 1;
+        const int a = fp / N, b = fp - a * N;
+        int edge = -1, along = 0;
+        double X = 0.0;
+        if (d == 0 && ((plus && el.ei == H - 1) || (!plus && el.ei == 0))) {
+            edge = plus ? E_E : E_W; along = el.ej; X = P.bwe[el.ej * N + b];
+        } else if (d == 1 && ((plus && el.ej == H - 1) || (!plus && el.ej == 0))) {
+            edge = plus ? E_N : E_S; along = el.ei; X = P.bsn[el.ei * N + b];
+        }
+        pp<T, T, G> sendp = edge == E_S ? P.nsend_s : (edge == E_N ? P.nsend_n : (edge == E_W ? P.nsend_w : P.nsend_e));
+        if (edge < 0 || sendp == nullptr) continue;
+        int base, stride;
+        if (d == 0) { base = C::lidx(a, b, 0); stride = 1; }
+        else { base = C::lidx(a, 0, b); stride = C::NP; }
+        const auto w = plus ? P.K->ep : P.K->em;
+        T s[5];
+#pragma unroll
+        for (int v = 0; v < 5; ++v) s[v] = T(0.0);
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+            const double wm = w[m];
+#pragma unroll
+            for (int v = 0; v < 5; ++v) s[v] += wm * img[v * img_stride + le * C::LE + base + m * stride];
+        }
+        s[0] = w_exp(s[0]);
+        s[4] = w_exp(s[4]);
+        rotate_contra<T>(P.K->rot[edge], X, s[1], s[2]);
+        int al = along, bb = b;
+        if (P.K->flip[edge]) { al = H - 1 - along; bb = N - 1 - b; }
+        const size_t eo = ((size_t)el.ek * H + al) * N2 + a * N + bb;
+        const size_t vs = (size_t)V * H * N2;
+        pp<T, T, G> out = sendp + eo;
+#pragma unroll
+        for (int v = 0; v < 5; ++v) out[v * vs] = s[v];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the fused evaluation on a brick (float64).  EPI: the stage pipeline's epilogue (optional exponential filter + NaN flag on the
+// output, the tile-edge messages of the output) - a separate instantiation, the plain kernel keeps its schedule.
+// ------------------------------------------------------------------------------------------------
+template <int N, typename T, bool EPI, bool G>
+__device__ __forceinline__ void euler_brick_body(const EulerParams<T, G>& P, const BrickBoxes& GB) {
+    using C = BrickCfg<N>;
+    static_assert(std::is_same<T, double>::value, "the brick form of the fused kernel: float64");
+    constexpr int N2 = C::N2, N3 = C::N3, EPB = C::EPB, BS = C::BS;
+    constexpr int NF = 8;   // staged fields: 4 F rows, A, B (per direction) + log p + sqrtG*rho
+    constexpr int NC = 7;   // face quantities, see rusanov_face
+    constexpr int FST = NC * N2;
+    __shared__ T smem[NF * EPB * C::LE + EPB * 6 * FST];
+    T(*fld)[EPB * C::LE] = reinterpret_cast<T(*)[EPB * C::LE]>(smem);
+    T* frs = smem + NF * EPB * C::LE;
+#define WX_FR(le_, f_, c_, fp_) frs[((le_) * 6 + (f_)) * FST + (c_) * N2 + (fp_)]
+    __shared__ double sD[N * N], sHF[N * N], sCm[N], sCp[N];
+    __shared__ double sEF[EPI ? N * N : 1];
+
+    const int tid = threadIdx.x;
+    __builtin_assume(tid < BS);
+    const int H = P.H, V = P.V;
+    const size_t fs = (size_t)P.nelem * N3;
+    const BrickAt bk = brick_at(GB, xcd_slab_block(blockIdx.x, gridDim.x >> 3));
+    if (!bk.any) return;   // (uniform over the workgroup: the launch is padded to a multiple of eight workgroups)
+    for (int i = tid; i < N * N; i += BS) {
+        sD[i] = P.K->D[i];
+        sHF[i] = P.K->HF[i];
+        if (EPI) sEF[i] = P.K->EF[i];
+    }
+    if (tid < N) {
+        sCm[tid] = P.K->cm[tid];
+        sCp[tid] = P.K->cp[tid];
+    }
+
+    const int le = tid / N3, pt = tid - le * N3;
+    const BElem el = brick_elem<EPB>(bk, le, H, V);
+    const bool active = el.valid;
+    const int kl = pt / N2, jl = (pt / N) % N, il = pt % N;
+    const int lb = (le < EPB ? le : 0) * C::LE;
+    const int lpt = lb + C::lidx(kl, jl, il);
+    const size_t o = (size_t)el.e * N3 + pt;
+
+    // ---- the state -> registers and, in the form the extrapolation wants, -> LDS; the metric loads follow and stay in flight
+    // under the face stage
+    PointIn<T> S;
+    k2_point_loads<T, false>(P, active, o, fs, S, o, fs);
+    const T q0 = S.q0, q1 = S.q1, q2 = S.q2, q3 = S.q3, q4 = S.q4;
+    const double sg = S.sg;
+    if (le < EPB) {
+        fld[0][lpt] = w_log(q0);
+        fld[1][lpt] = q1;
+        fld[2][lpt] = q2;
+        fld[3][lpt] = q3;
+        fld[4][lpt] = w_log(q4);
+    }
+    __syncthreads();
+
+    // ---- face stage: every Riemann problem of the brick once
+    if (WX_BRICK_DIAG != 3)
+    brick_face_stage<N, T>(P, bk, &fld[0][0], EPB * C::LE, [&](int sle, int f, int fp, const T* out, T bq, T lp) {
+#pragma unroll
+        for (int c = 0; c < 5; ++c) WX_FR(sle, f, c, fp) = out[c];
+        WX_FR(sle, f, 5, fp) = bq;
+        WX_FR(sle, f, 6, fp) = lp;
+    });
+
+    // ---- pointwise quantities
+    const T rinv = 1.0 / q0;
+    const T u1 = q1 * rinv, u2 = q2 * rinv, u3 = q3 * rinv;
+    const T glog = kGamma * w_log(kRdOverP0 * q4);
+    const T p = kP0 * w_exp(glog);
+    const T logp = kLogP0 + glog;
+    if (le < EPB) {
+        fld[6][lpt] = logp;
+        fld[7][lpt] = sg * q0;
+    }
+
+    // ---- forcing
+    T fc0, fc1, fc2;
+    double gcoef;
+    k2_forcing<T, false, true>(P, active, o, fs, S, u1, u2, u3, p, fc0, fc1, fc2, gcoef, o, fs);
+
+    T acc0 = T(0.0), acc1 = sg * fc0, acc2 = sg * fc1, acc4 = T(0.0), accw = sg * fc2;
+    T hf = T(0.0);
+
+    // ---- three directional passes (euler_rhs_body's vector-pipe form)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const T ud = w_sel(d == 0, u1, w_sel(d == 1, u2, u3));
+        const double hd0 = d == 0 ? S.h00 : (d == 1 ? S.h01 : S.h02);
+        const double hd1 = d == 0 ? S.h01 : (d == 1 ? S.h11 : S.h12);
+        const double hd2 = d == 0 ? S.h02 : (d == 1 ? S.h12 : S.h22);
+        const T sgu = sg * ud;
+        const T Bd = T(sg * hd2);
+        __syncthreads();  // the face stage's / the previous direction's reads of the images are done
+        if (le < EPB) {
+            fld[0][lpt] = sgu * q0;
+            fld[1][lpt] = sgu * q1 + (sg * hd0) * p;
+            fld[2][lpt] = sgu * q2 + (sg * hd1) * p;
+            fld[3][lpt] = sgu * q4;
+            fld[4][lpt] = sgu * q3;
+            fld[5][lpt] = Bd;
+        }
+        __syncthreads();
+
+        int idx, fp, base, stride;
+        if (d == 0) { idx = il; fp = kl * N + jl; base = lb + C::lidx(kl, jl, 0); stride = 1; }
+        else if (d == 1) { idx = jl; fp = kl * N + il; base = lb + C::lidx(kl, 0, il); stride = C::NP; }
+        else { idx = kl; fp = jl * N + il; base = lb + C::lidx(0, jl, il); stride = N * C::NP; }
+
+        double dm[N];
+#pragma unroll
+        for (int m = 0; m < N; ++m) dm[m] = sD[idx * N + m];
+        const double cm = sCm[idx], cp = sCp[idx];
+        const int lf = le < EPB ? le : 0;
+        const T pB = p * Bd;
+#pragma unroll 1
+        for (int c0 = 0; c0 < 7; c0 += kFieldBatch) {
+#pragma unroll
+            for (int cc = 0; cc < kFieldBatch; ++cc) {
+                const int c = c0 + cc;
+                if (c < 7) {
+                    T a = cm * WX_FR(lf, 2 * d, c, fp) + cp * WX_FR(lf, 2 * d + 1, c, fp);
+#pragma unroll
+                    for (int m = 0; m < N; ++m) a += dm[m] * fld[c][base + m * stride];
+                    // W^d = [A@D + A*@C] + p [B@D + B*@C] + p B [log p@D + log p^@C]  (rhs_dfr.py:113-136)
+                    if (c == 0) acc0 += a;
+                    else if (c == 1) acc1 += a;
+                    else if (c == 2) acc2 += a;
+                    else if (c == 3) acc4 += a;
+                    else if (c == 4) accw += a;
+                    else if (c == 5) accw += a * p;
+                    else accw += a * pB;
+                }
+            }
+        }
+        if (d == 2) {
+#pragma unroll
+            for (int m = 0; m < N; ++m) hf += sHF[idx * N + m] * fld[7][base + m * stride];
+        }
+    }
+
+    // ---- epilogue
+    const double inv_sg = 1.0 / sg;
+    accw += gcoef * hf;  // gravity: inv_dzdeta * g * 1/sqrtG * HF_k(sqrtG rho)
+    T r0 = -inv_sg * acc0, r1 = -inv_sg * acc1, r2 = -inv_sg * acc2, r3 = -inv_sg * accw, r4 = -inv_sg * acc4;
+    if (P.advection_only) { r0 = r1 = r2 = r3 = r4 = T(0.0); }
+    if (active && P.axpy) {  // fused stage update of an explicit Runge-Kutta scheme (integrators/tvdrk3.py:12-19)
+        r0 = P.cb * q0 + P.cc * r0; r1 = P.cb * q1 + P.cc * r1; r2 = P.cb * q2 + P.cc * r2;
+        r3 = P.cb * q3 + P.cc * r3; r4 = P.cb * q4 + P.cc * r4;
+        if (P.y != nullptr) {
+            r0 += P.ca * P.y[o]; r1 += P.ca * P.y[fs + o]; r2 += P.ca * P.y[2 * fs + o];
+            r3 += P.ca * P.y[3 * fs + o]; r4 += P.ca * P.y[4 * fs + o];
+        }
+        if (P.z != nullptr) {
+            r0 += P.cd * P.z[o]; r1 += P.cd * P.z[fs + o]; r2 += P.cd * P.z[2 * fs + o];
+            r3 += P.cd * P.z[3 * fs + o]; r4 += P.cd * P.z[4 * fs + o];
+        }
+    }
+    if (EPI && P.efilter) {
+        // the per-step exponential filter (operators.py:114-119, 257-261) on the stage's output while it is in registers
+        T t0 = active ? sg * r0 : T(0.0), t1 = active ? sg * r1 : T(0.0), t2 = active ? sg * r2 : T(0.0),
+          t3 = active ? sg * r3 : T(0.0), t4 = active ? sg * r4 : T(0.0);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            __syncthreads();  // previous reads of fld are done
+            if (le < EPB) {
+                fld[0][lpt] = t0; fld[1][lpt] = t1; fld[2][lpt] = t2; fld[3][lpt] = t3; fld[4][lpt] = t4;
+            }
+            __syncthreads();
+            int base, stride, idx;
+            if (d == 0) { base = lb + C::lidx(kl, jl, 0); stride = 1; idx = il; }
+            else if (d == 1) { base = lb + C::lidx(kl, 0, il); stride = C::NP; idx = jl; }
+            else { base = lb + C::lidx(0, jl, il); stride = N * C::NP; idx = kl; }
+            t0 = t1 = t2 = t3 = t4 = T(0.0);
+#pragma unroll
+            for (int m = 0; m < N; ++m) {
+                const double w = sEF[idx * N + m];
+                t0 += w * fld[0][base + m * stride]; t1 += w * fld[1][base + m * stride];
+                t2 += w * fld[2][base + m * stride]; t3 += w * fld[3][base + m * stride];
+                t4 += w * fld[4][base + m * stride];
+            }
+        }
+        r0 = t0 * inv_sg; r1 = t1 * inv_sg; r2 = t2 * inv_sg; r3 = t3 * inv_sg; r4 = t4 * inv_sg;
+        if (active && P.nan_flag != nullptr &&
+            (r0 != r0 || r1 != r1 || r2 != r2 || r3 != r3 || r4 != r4))
+            *P.nan_flag = 1;   // many writers, one value: a plain store is as good as an atomic OR (never cleared here)
+    }
+    if (active) {
+        store_r<T>(P, o, r0);
+        store_r<T>(P, fs + o, r1);
+        store_r<T>(P, 2 * fs + o, r2);
+        store_r<T>(P, 3 * fs + o, r3);
+        store_r<T>(P, 4 * fs + o, r4);
+    }
+    if (EPI) {
+        // the output is the next stage's state: its tile-edge messages now, while it is in registers (no pack launch)
+        const bool any_send = P.nsend_s != nullptr || P.nsend_n != nullptr || P.nsend_w != nullptr || P.nsend_e != nullptr;
+        const bool at_edge = bk.i0 == 0 || bk.j0 == 0 || bk.i0 + (1 << bk.li) >= H || bk.j0 + (1 << bk.lj) >= H;
+        if (any_send && at_edge) {   // (uniform over the workgroup)
+            __syncthreads();
+            if (le < EPB) {
+                fld[0][lpt] = active ? w_log(r0) : T(0.0);
+                fld[1][lpt] = r1;
+                fld[2][lpt] = r2;
+                fld[3][lpt] = r3;
+                fld[4][lpt] = active ? w_log(r4) : T(0.0);
+            }
+            __syncthreads();
+            brick_pack_edges<N, T>(P, bk, &fld[0][0], EPB * C::LE);
+        }
+    }
+#undef WX_FR
+}
+
+template <int N, bool EPI>
+__global__ __launch_bounds__(BrickCfg<N>::BS, kK2Waves) void euler_brick_kernel(const EulerParams<double> P, const BrickBoxes GB) {
+    euler_brick_body<N, double, EPI>(P, GB);
+}
+
+template <int N>
+__global__ __launch_bounds__(BrickCfg<N>::BS, kK2Waves) void euler_brick_batch_kernel(const EulerParams<double>* table,
+                                                                                     const EulerBatchDyn<double> dyn,
+                                                                                     const BrickBoxes GB) {
+    // the block comes out of memory: typed so that every access through its pointers is a global one (wx_common.h: gp)
+    EulerParams<double, true> P = *reinterpret_cast<const EulerParams<double, true>*>(table + blockIdx.y);
+    const size_t off = (size_t)blockIdx.y * dyn.stride;
+    batch_state<double>(P, dyn);
+    P.rhs = dyn.rhs ? dyn.rhs + off : (double*)nullptr;
+    P.y = dyn.y ? dyn.y + off : (const double*)nullptr;
+    P.z = dyn.z ? dyn.z + off : (const double*)nullptr;
+    P.region = dyn.region; P.count = dyn.count;
+    P.axpy = dyn.axpy; P.ca = dyn.ca; P.cb = dyn.cb; P.cc = dyn.cc; P.cd = dyn.cd;
+    euler_brick_body<N, double, false>(P, GB);
+}
+
+}  // namespace wx

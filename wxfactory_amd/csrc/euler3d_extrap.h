@@ -7,7 +7,8 @@ namespace wx {
 // Phase 1-2 on nodal values already staged in LDS (log rho, rho u1, rho u2, rho w, log rho*theta):
 // one thread per face point extrapolates, exponentiates, writes the interface buffer and, on outward
 // tile-edge faces, the rotated / flipped edge message.  Shared by K1 and by K2's stage-pipeline epilogue.
-template <int N, typename T, bool COLM = false, bool G3 = false, bool G>
+// PACK: the edge messages only, nothing to the interface buffer (the pack kernel of the low-order one-kernel form, euler3d_brick.h)
+template <int N, typename T, bool COLM = false, bool G3 = false, bool PACK = false, bool G>
 __device__ __forceinline__ void extrap_faces(const EulerParams<T, G>& P, T (*fld)[Cfg<N>::EPB * Cfg<N>::LE], int slot0,
                                              int count, int region, pp<T, T, G> itf_dst, pp<T, T, G> ss, pp<T, T, G> sn, pp<T, T, G> sw,
                                              pp<T, T, G> se) {
@@ -29,6 +30,7 @@ __device__ __forceinline__ void extrap_faces(const EulerParams<T, G>& P, T (*fld
         if (kNoVertFaces && f >= 4) continue;
         const int d = f >> 1, plus = f & 1;
         const int a = fp / N, b = fp % N;
+        if (PACK && !((d == 0 && (plus ? el.ei == H - 1 : el.ei == 0)) || (d == 1 && (plus ? el.ej == H - 1 : el.ej == 0)))) continue;
         // point index of m-th node on the line normal to the face, and its stride
         int base, stride;
         if (d == 0) { base = C::lidx(a, b, 0); stride = 1; }           // (kl=a, jl=b, il=m)
@@ -46,9 +48,11 @@ __device__ __forceinline__ void extrap_faces(const EulerParams<T, G>& P, T (*fld
         }
         s[0] = w_exp(s[0]);
         s[4] = w_exp(s[4]);
-        pp<T, T, G> dst = itf_dst + ((size_t)el.e * 6 + f) * NQ * N2 + fp;
+        if (!PACK) {
+            pp<T, T, G> dst = itf_dst + ((size_t)el.e * 6 + f) * NQ * N2 + fp;
 #pragma unroll
-        for (int v = 0; v < 5; ++v) dst[v * N2] = s[v];
+            for (int v = 0; v < 5; ++v) dst[v * N2] = s[v];
+        }
 
         // outward faces of the tile edge: rotate into the neighbour's basis, flip, pack
         int edge = -1, along = 0;
@@ -79,7 +83,8 @@ __device__ __forceinline__ void extrap_faces(const EulerParams<T, G>& P, T (*fld
 // ------------------------------------------------------------------------------------------------
 // K1: extrapolation to element faces + tile-edge pack
 // ------------------------------------------------------------------------------------------------
-template <int N, typename T, bool G3 = false, bool G>
+// PACK: the ring of boundary elements only (P.count = its size), edge messages only
+template <int N, typename T, bool G3 = false, bool PACK = false, bool G>
 __device__ __forceinline__ void euler_extrap_body(const EulerParams<T, G>& P) {
     using C = Cfg<N>;
     constexpr int N2 = C::N2, N3 = C::N3, EPB = C::EPB;
@@ -92,7 +97,7 @@ __device__ __forceinline__ void euler_extrap_body(const EulerParams<T, G>& P) {
 
     {
         const int le = tid / N3, pt = tid % N3;
-        const Elem el = decode_blk<EPB, G3>(P, blockIdx.x * EPB + le, P.nelem, WX_REGION_ALL);
+        const Elem el = decode_blk<EPB, G3>(P, blockIdx.x * EPB + le, PACK ? P.count : P.nelem, PACK ? WX_REGION_BOUNDARY : WX_REGION_ALL);
         if (le < EPB && el.valid) {
             const size_t o = (size_t)el.e * N3 + pt;
             const int lp = le * C::LE + C::lidx(pt / N2, (pt / N) % N, pt % N);
@@ -107,12 +112,19 @@ __device__ __forceinline__ void euler_extrap_body(const EulerParams<T, G>& P) {
     }
     __syncthreads();
 
-    extrap_faces<N, T, false, G3>(P, fld, blockIdx.x * EPB, P.nelem, WX_REGION_ALL, P.itf, P.send_s, P.send_n, P.send_w, P.send_e);
+    extrap_faces<N, T, false, G3, PACK>(P, fld, blockIdx.x * EPB, PACK ? P.count : P.nelem, PACK ? WX_REGION_BOUNDARY : WX_REGION_ALL, P.itf,
+                                        P.send_s, P.send_n, P.send_w, P.send_e);
 }
 
 template <int N, typename T>
 __global__ __launch_bounds__(Cfg<N>::BS, kK1Waves) void euler_extrap_kernel(const EulerParams<T> P) {
     euler_extrap_body<N, T, grid3_for<N>()>(P);
+}
+
+// the pack kernel of the one-kernel form: the ring's outward faces -> rotated / flipped edge messages (slots, not the grid form)
+template <int N, typename T>
+__global__ __launch_bounds__(Cfg<N>::BS, kK1Waves) void euler_pack_kernel(const EulerParams<T> P) {
+    euler_extrap_body<N, T, false, true>(P);
 }
 
 // K1 for the prepared complex-step JVP (wx_euler3d_jvp_tangent_extrap_pack): only the TANGENTS of the face states of
@@ -293,6 +305,21 @@ __global__ __launch_bounds__(Cfg<N>::BS, kK1Waves) void euler_extrap_batch_kerne
     } else {
         __shared__ EulerParams<T> sP;
         euler_extrap_body<N, T>(batch_params<T>(sP, table, [&](EulerParams<T>& P) { batch_state<T>(P, dyn); }));
+    }
+}
+
+// ... and the pack kernel of the one-kernel form for all tiles (dyn.count = the ring's size)
+template <int N, typename T>
+__global__ __launch_bounds__(Cfg<N>::BS, kK1Waves) void euler_pack_batch_kernel(const EulerParams<T>* table,
+                                                                                const EulerBatchDyn<T> dyn) {
+    if constexpr (std::is_same<T, double>::value) {
+        EulerParams<T, true> P = *reinterpret_cast<const EulerParams<T, true>*>(table + blockIdx.y);
+        batch_state<T>(P, dyn);
+        P.count = dyn.count;
+        euler_extrap_body<N, T, false, true>(P);
+    } else {
+        __shared__ EulerParams<T> sP;
+        euler_extrap_body<N, T, false, true>(batch_params<T>(sP, table, [&](EulerParams<T>& P) { batch_state<T>(P, dyn); P.count = dyn.count; }));
     }
 }
 

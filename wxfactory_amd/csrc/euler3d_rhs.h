@@ -256,6 +256,9 @@ template <typename T, bool CACHED = false, bool WITH_IDZ = true, bool G>
 __device__ __forceinline__ void k2_forcing(const EulerParams<T, G>& P, bool active, size_t o, size_t fs, const PointIn<T>& S, T u1,
                                            T u2, T u3, T p, T& fc0, T& fc1, T& fc2, double& gcoef, size_t om, size_t fsm) {
     double cg[27], idzv = 0.0;
+#if defined(WX_BRICK_DIAG) && WX_BRICK_DIAG == 4
+    active = false;
+#endif
     if (active && P.rot_zero) {   // non-rotating planet: the 9 rotation symbols are identically zero
 #pragma unroll
         for (int i = 0; i < 27; ++i) cg[i] = (i % 9) < 3 ? 0.0 : ldm_if<CACHED>(P.chr + (size_t)i * fsm + om);

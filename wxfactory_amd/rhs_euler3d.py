@@ -157,6 +157,15 @@ class Euler3DPlan:
 
     axpy_two = True  # rhs_axpy takes a second array (z, d)
 
+    @property
+    def one_kernel(self) -> bool:
+        """True when this plan evaluates in the low-order one-kernel form (csrc/euler3d_brick.h; include/wxhip.h)."""
+        return int(self.lib.wx_euler3d_plan_one_kernel(self._h)) == 1
+
+    def set_one_kernel(self, on: bool):
+        """Setup time (before any Euler3DBatch over this plan is made): choose the two-kernel form (False) for a low-order plan."""
+        check(self.lib.wx_euler3d_plan_set_one_kernel(self._h, 1 if on else 0), "wx_euler3d_plan_set_one_kernel")
+
     def twin(self, dtype, dual: bool = False):
         """Plan of another dtype over the same (borrowed) metric tensors."""
         t = Euler3DPlan(self.n, self.H, self.V, self.case_number, self.panel, self._ops, self._metric, dtype=dtype,
