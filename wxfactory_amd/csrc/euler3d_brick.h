@@ -41,6 +41,11 @@ struct BrickCfg {
     static constexpr int BS = ((EPB * N3 + 63) / 64) * 64;
     static constexpr int NP = Cfg<N>::NP;
     static constexpr int LE = N2 * NP;
+    // waves per SIMD the register allocation aims at: n = 2 holds two workgroups per CU whatever it does (59 KB of LDS each)
+#ifndef WX_BRICK_WAVES
+#define WX_BRICK_WAVES 3
+#endif
+    static constexpr int WAVES = N == 2 ? 2 : WX_BRICK_WAVES;
     __host__ __device__ static constexpr int lidx(int kl, int jl, int il) { return (kl * N + jl) * NP + il; }
 };
 
@@ -66,12 +71,18 @@ __device__ __forceinline__ X* raw_ptr(X* p) { return p; }
 template <typename X>
 __device__ __forceinline__ X* raw_ptr(gp<X> p) { return p.raw(); }
 
+// x / d for the small numbers of a brick's face decode (x < 2048, 1 <= d <= 33): (x * kSmallDiv[d]) >> 16, kSmallDiv[d] = 65536 / d + 1
+__constant__ unsigned kSmallDiv[34] = {0, 65537, 32769, 21846, 16385, 13108, 10923, 9363, 8193, 7282, 6554, 5958, 5462, 5042, 4682, 4370, 4097,
+                                       3856, 3641, 3450, 3277, 3121, 2979, 2850, 2731, 2622, 2521, 2428, 2341, 2260, 2185, 2115, 2049, 1986};
+__device__ __forceinline__ int small_div(int x, unsigned m) { return (int)(((unsigned)x * m) >> 16); }
+
 struct BrickAt {
-    int i0, j0, k0, i1, j1, li, lj, lk;
+    int i0, j0, k0, li, lj, lk;
+    int vi, vj, vk;   // extent of the brick's elements that exist (the last brick of a row / column / the top layer is cut)
     bool any;
 };
 
-__device__ __forceinline__ BrickAt brick_at(const BrickBoxes& G, int L) {
+__device__ __forceinline__ BrickAt brick_at(const BrickBoxes& G, int L, int V) {
     BrickAt b;
     b.any = L < G.nbricks;
     if (!b.any) L = 0;
@@ -83,36 +94,41 @@ __device__ __forceinline__ BrickAt brick_at(const BrickBoxes& G, int L) {
     const int bj = fast_div(r, nbi, WX_BOX(G, mdi, box)), bi = r - bj * nbi;
     b.li = WX_BOX(G, li, box); b.lj = WX_BOX(G, lj, box); b.lk = G.lk;
     b.i0 = WX_BOX(G, i0, box) + (bi << b.li); b.j0 = WX_BOX(G, j0, box) + (bj << b.lj); b.k0 = kb << b.lk;
-    b.i1 = WX_BOX(G, i1, box); b.j1 = WX_BOX(G, j1, box);
+    const int ri = WX_BOX(G, i1, box) - b.i0, rj = WX_BOX(G, j1, box) - b.j0, rk = V - b.k0;
+    b.vi = ri < (1 << b.li) ? ri : (1 << b.li);
+    b.vj = rj < (1 << b.lj) ? rj : (1 << b.lj);
+    b.vk = rk < (1 << b.lk) ? rk : (1 << b.lk);
     return b;
 }
 
 struct BElem {
     int ei, ej, ek, e;
-    int lbi, lbj, lbk;   // position in the brick
     bool valid;
 };
 
+// the element at position (lbi, lbj, lbk) of the brick; le = its slot in the workgroup's LDS images
+__device__ __forceinline__ int brick_slot(const BrickAt& b, int lbi, int lbj, int lbk) { return lbi + (lbj << b.li) + (lbk << (b.li + b.lj)); }
+
 template <int EPB>
-__device__ __forceinline__ BElem brick_elem(const BrickAt& b, int le, int H, int V) {
+__device__ __forceinline__ BElem brick_elem(const BrickAt& b, int le, int H) {
     BElem r;
-    r.lbi = le & ((1 << b.li) - 1);
-    r.lbj = (le >> b.li) & ((1 << b.lj) - 1);
-    r.lbk = le >> (b.li + b.lj);
-    r.ei = b.i0 + r.lbi; r.ej = b.j0 + r.lbj; r.ek = b.k0 + r.lbk;
-    r.valid = b.any && le < EPB && r.ei < b.i1 && r.ej < b.j1 && r.ek < V;
+    const int lbi = le & ((1 << b.li) - 1), lbj = (le >> b.li) & ((1 << b.lj) - 1), lbk = le >> (b.li + b.lj);
+    r.ei = b.i0 + lbi; r.ej = b.j0 + lbj; r.ek = b.k0 + lbk;
+    r.valid = b.any && le < EPB && lbi < b.vi && lbj < b.vj && lbk < b.vk;
     if (!r.valid) { r.ei = b.i0; r.ej = b.j0; r.ek = b.k0; }   // (an addressable element: the brick's first)
     r.e = (r.ek * H + r.ej) * H + r.ei;
     return r;
 }
 
 // both sides of one Riemann problem (rusanov_face from the left element's point of view + the two right-side values):
-// qL, qR [7]: the five face values in, pressure and log pressure filled here.  wall: 0 none, 1 the RIGHT state is the mirror
-// image of the left one (top of the model: own = left), 2 the LEFT state mirrors the right one (ground)
+// qL, qR [7]: the five face values in, pressure and log pressure filled here; lgL, lgR = log(rho theta) of the two states - the
+// sum the extrapolation exponentiated (pde_euler_cubesphere.py:158-160 takes the logarithm of that exponential again: the
+// same number to rounding, two logarithms per face point less).  wall: 0 none, 1 the RIGHT state is the mirror image of the left
+// one (top of the model: own = left), 2 the LEFT state mirrors the right one (ground)
 template <typename T>
-__device__ __forceinline__ void rusanov_both(T* qL, T* qR, int d, int wall, double sg, double h0, double h1, double h2,
+__device__ __forceinline__ void rusanov_both(T* qL, T* qR, T lgL, T lgR, int d, int wall, double sg, double h0, double h1, double h2,
                                              bool advection_only, T* outL, T& bR, T& lpR) {
-    const T gL = kGamma * w_log(qL[4] * kRdOverP0), gR = kGamma * w_log(qR[4] * kRdOverP0);
+    const T gL = kGamma * (lgL + kLogRdOverP0), gR = kGamma * (lgR + kLogRdOverP0);
     qL[5] = kP0 * w_exp(gL); qR[5] = kP0 * w_exp(gR);
     qL[6] = kLogP0 + gL; qR[6] = kLogP0 + gR;
     const double hdd = d == 0 ? h0 : (d == 1 ? h1 : h2);
@@ -127,161 +143,227 @@ __device__ __forceinline__ void rusanov_both(T* qL, T* qR, int d, int wall, doub
     lpR = qR[6];
 }
 
+// The pointers a face item selects between (four halos, six interface-metric arrays), copied OUT of the parameter block into
+// scalars before any select: `d == 0 ? P.sgi : P.sgj` on a block that lives in memory (the batched launch's copy, or any block
+// a by-reference lambda capture has pinned there) becomes a load through a selected ADDRESS and drags the block into scratch.
+// No lambdas and no pointer aggregates in this file for that reason.
+// interface metric of face point fp of face (d, plus) of element (ek, ej, ei): the element's own slot (face_load)
+template <int N, typename T, bool G>
+__device__ __forceinline__ void brick_face_metric(const double* sgi, const double* sgj, const double* sgk, const double* hi,
+                                                  const double* hj, const double* hk, int H, int V, int ek, int ej, int ei, int d, int pl,
+                                                  int fp, double& sg, double& h0, double& h1, double& h2) {
+    constexpr int N2 = N * N;
+    size_t o, hfs;
+    if (d == 0) {
+        o = (((size_t)ek * H + ej) * (H + 2) + ei + 1) * 2 * N2 + pl * N2 + fp;
+        hfs = (size_t)V * H * (H + 2) * 2 * N2;
+    } else if (d == 1) {
+        o = (((size_t)ek * (H + 2) + ej + 1) * H + ei) * 2 * N2 + pl * N2 + fp;
+        hfs = (size_t)V * (H + 2) * H * 2 * N2;
+    } else {
+        o = ((((size_t)ek + 1) * H + ej) * H + ei) * 2 * N2 + pl * N2 + fp;
+        hfs = (size_t)(V + 2) * H * H * 2 * N2;
+    }
+    const pp<T, const double, G> sgp(d == 0 ? sgi : (d == 1 ? sgj : sgk));
+    const pp<T, const double, G> hp = pp<T, const double, G>(d == 0 ? hi : (d == 1 ? hj : hk)) + ((size_t)d * 3 * hfs + o);
+    sg = sgp[o]; h0 = hp[0]; h1 = hp[hfs]; h2 = hp[2 * hfs];
+}
+
+// face state of element slot `le` from the LDS images: s[0..4] the five values, lg = log(rho theta) (the sum before its exponential)
+template <int N, typename T, typename W>
+__device__ __forceinline__ void brick_extrap_lds(const T* img, int img_stride, int off, int lstride, W wv, T* s, T& lg) {
+#pragma unroll
+    for (int v = 0; v < 5; ++v) s[v] = T(0.0);
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+        const double wm = wv[m];
+#pragma unroll
+        for (int v = 0; v < 5; ++v) s[v] += wm * img[v * img_stride + off + m * lstride];
+    }
+    lg = s[4];
+    s[0] = w_exp(s[0]);
+    s[4] = w_exp(s[4]);
+}
+
+// nodal line of face point fp along d: LDS offset and stride, point index and stride
+template <int N>
+__device__ __forceinline__ void brick_line(int d, int fp, int& lbase, int& lstride, int& pbase, int& pstride) {
+    using C = BrickCfg<N>;
+    const int a = fp / N, b = fp - a * N;
+    if (d == 0) { lbase = C::lidx(a, b, 0); lstride = 1; pbase = (a * N + b) * N; pstride = 1; }
+    else if (d == 1) { lbase = C::lidx(a, 0, b); lstride = C::NP; pbase = a * C::N2 + b; pstride = N; }
+    else { lbase = C::lidx(0, a, b); lstride = N * C::NP; pbase = a * N + b; pstride = C::N2; }
+}
+
+// one face point on the brick's surface
+struct Surf { int d, plus, le, fp, ei, ej, ek, kind; };   // kind: 0 a neighbour element of this tile, 1 halo, 2 wall
+
+template <int N>
+__device__ __forceinline__ Surf surf_decode(const BrickAt& bk, int w, int s0, int s1, int s2, unsigned m_vi, unsigned m_vj, int H, int V) {
+    constexpr int N2 = N * N;
+    const int vi = bk.vi, vj = bk.vj, vk = bk.vk;
+    Surf u;
+    int x = w;
+    if (x < 2 * s0) { u.d = 0; u.plus = x < s0; if (!u.plus) x -= s0; }
+    else if (x < 2 * (s0 + s1)) { u.d = 1; x -= 2 * s0; u.plus = x < s1; if (!u.plus) x -= s1; }
+    else { u.d = 2; x -= 2 * (s0 + s1); u.plus = x < s2; if (!u.plus) x -= s2; }
+    const int s = x / N2;
+    u.fp = x - s * N2;
+    int lbi, lbj, lbk;
+    if (u.d == 0) { lbk = small_div(s, m_vj); lbj = s - lbk * vj; lbi = u.plus ? vi - 1 : 0; }
+    else if (u.d == 1) { lbk = small_div(s, m_vi); lbi = s - lbk * vi; lbj = u.plus ? vj - 1 : 0; }
+    else { lbj = small_div(s, m_vi); lbi = s - lbj * vi; lbk = u.plus ? vk - 1 : 0; }
+    u.le = brick_slot(bk, lbi, lbj, lbk);
+    u.ei = bk.i0 + lbi; u.ej = bk.j0 + lbj; u.ek = bk.k0 + lbk;
+    const int gd = u.d == 0 ? u.ei : (u.d == 1 ? u.ej : u.ek);
+    const int ng = u.plus ? gd + 1 : gd - 1;
+    const bool outside = ng < 0 || ng >= (u.d == 2 ? V : H);
+    u.kind = (WX_BRICK_DIAG == 1) ? 2 : (outside ? (u.d == 2 ? 2 : 1) : 0);
+    return u;
+}
+
+// the loads of a surface item: the outer element's nodal line (kind 0: nv[m][0..4]) or the halo values (kind 1: hv[0..4]).
+// (two sets of registers, each written on one path only: one set written on both paths meets in copies behind the branch, and
+// a copy of a loaded value is a wait for it - the loads would not stay in flight)
+template <int N, typename T, bool G>
+__device__ __forceinline__ void surf_load(const EulerParams<T, G>& P, const Surf& u, const T* halo_s, const T* halo_n, const T* halo_w,
+                                          const T* halo_e, T (*nv)[5], T* hv) {
+    constexpr int N2 = N * N, N3 = N2 * N;
+    const int H = P.H, V = P.V;
+    int lbase, lstride, pbase, pstride;
+    brick_line<N>(u.d, u.fp, lbase, lstride, pbase, pstride);
+    if (u.kind == 0) {
+        const size_t fs = (size_t)P.nelem * N3;
+        const int e = (u.ek * H + u.ej) * H + u.ei;
+        const size_t eo = (size_t)(e + (u.plus ? 1 : -1) * (u.d == 0 ? 1 : (u.d == 1 ? H : H * H))) * N3 + pbase;
+#pragma unroll
+        for (int m = 0; m < N; ++m) load_state<T>(P, eo + m * pstride, fs, nv[m][0], nv[m][1], nv[m][2], nv[m][3], nv[m][4]);
+    } else if (u.kind == 1) {
+        // lateral tile edge: the received message (process_topology.py:595-606), five planes V H n^2 apart
+        const size_t vsh = (size_t)V * H * N2;
+        pp<T, const T, G> hb(u.d == 0 ? (u.plus ? halo_e : halo_w) : (u.plus ? halo_n : halo_s));
+        hb = hb + ((size_t)u.ek * H + (u.d == 0 ? u.ej : u.ei)) * N2 + u.fp;
+#pragma unroll
+        for (int v = 0; v < 5; ++v) hv[v] = hb[v * vsh];
+    }
+}
+
 // The face stage of a brick.  img: the five LDS images of the brick's state (log rho, rho u1, rho u2, rho w, log rho theta),
-// element `le` at le * LE.  store(le, f, fp, out[0..4], B, log p) receives the seven results of face f of element le.
-// Work items: the three plus-side faces of every element (the face is solved for both elements when the upper neighbour is
-// in the brick), then the minus-side faces of the elements on the brick's three lower surfaces - every face once, no idle
-// item in a full brick.
+// element slot `le` at le * LE.  store(le, f, fp, out[0..4], B, log p) receives the seven results of face f of element le.
+// Two classes of work items, each a wave-uniform way to the two face states:
+//   1. faces between two elements of the brick: both states from LDS, ONE Riemann problem, results to both elements;
+//   2. faces on the brick's surface: the own state from LDS, the outer one from the neighbour element's nodal values (read
+//      from Q and extrapolated here as that element's own evaluation does), from the received halo (tile edge) or from the wall
+//      rule (ground / top).  The loads of a thread's first surface item are issued BEFORE it works through class 1.
+// Both classes meet in ONE copy of the Riemann arithmetic: a face gives the same bits whichever class a launch's bricks put it
+// in (INTERIOR + BOUNDARY == ALL bit for bit).
+// rot: the wave that starts class 1 (the classes rarely fill whole rounds: the surplus rotates over the SIMDs from brick to brick).
 template <int N, typename T, bool G, typename Store>
-__device__ __forceinline__ void brick_face_stage(const EulerParams<T, G>& P, const BrickAt& bk, const T* img, int img_stride,
+__device__ __forceinline__ void brick_face_stage(const EulerParams<T, G>& P, const BrickAt& bk, const T* img, int img_stride, int rot,
                                                  Store store) {
     using C = BrickCfg<N>;
-    constexpr int N2 = C::N2, N3 = C::N3, EPB = C::EPB, BS = C::BS;
+    constexpr int N2 = C::N2, BS = C::BS;
     const int tid = threadIdx.x;
     const int H = P.H, V = P.V;
-    const size_t fs = (size_t)P.nelem * N3;
-    const int ni = 1 << bk.li, nj = 1 << bk.lj, nk = 1 << bk.lk;
-    constexpr int nA = 3 * EPB * N2;
-    const int nB0 = nj * nk * N2, nB1 = ni * nk * N2, nB2 = ni * nj * N2;
-    const int total = nA + nB0 + nB1 + nB2;
-    // (the four halo pointers by value, here: a select between MEMBERS of a parameter block that is a local copy - the batched
-    // launch - becomes a select of their addresses and sends the whole block to scratch)
+    const int vi = bk.vi, vj = bk.vj, vk = bk.vk;
+    const unsigned m_vi = kSmallDiv[vi], m_vj = kSmallDiv[vj], m_vi1 = kSmallDiv[vi > 1 ? vi - 1 : 1], m_vj1 = kSmallDiv[vj > 1 ? vj - 1 : 1];
+    // class 1: per direction the lower element of each inner face, positions (lbi, lbj, lbk) with lb_d < v_d - 1
+    const int c0 = (vi - 1) * vj * vk * N2, c1 = vi * (vj - 1) * vk * N2, c2 = vi * vj * (vk - 1) * N2;
+    // class 2: per direction the plus faces of the last layer, then the minus faces of the first
+    const int s0 = vj * vk * N2, s1 = vi * vk * N2, s2 = vi * vj * N2;
+    const int nI = c0 + c1 + c2, nS = 2 * (s0 + s1 + s2);
     const T* const halo_e = raw_ptr(P.halo_e); const T* const halo_w = raw_ptr(P.halo_w);
     const T* const halo_n = raw_ptr(P.halo_n); const T* const halo_s = raw_ptr(P.halo_s);
-    for (int w = tid; w < total; w += BS) {
-        int d, fle, fp;
-        bool plus;
-        if (w < nA) {
-            d = w / (EPB * N2);
-            const int r = w - d * (EPB * N2);
-            fle = r / N2; fp = r - fle * N2;
-            plus = true;
-        } else {
-            int x = w - nA;
-            plus = false;
-            if (x < nB0) {          // elements with lbi == 0, indexed by (lbk, lbj)
-                d = 0;
-                const int s = x / N2; fp = x - s * N2;
-                fle = s << bk.li;
-            } else if (x < nB0 + nB1) {   // lbj == 0, indexed by (lbk, lbi)
-                d = 1;
-                x -= nB0;
-                const int s = x / N2; fp = x - s * N2;
-                fle = ((s >> bk.li) << (bk.li + bk.lj)) + (s & (ni - 1));
-            } else {                      // lbk == 0, indexed by (lbj, lbi)
-                d = 2;
-                x -= nB0 + nB1;
-                const int s = x / N2; fp = x - s * N2;
-                fle = s;
-            }
-        }
-        const BElem el = brick_elem<EPB>(bk, fle, H, V);
-        if (!el.valid) continue;
-        // the element across the face
-        const int gd = d == 0 ? el.ei : (d == 1 ? el.ej : el.ek);   // own coordinate along d
-        const int nd = d == 0 ? ni : (d == 1 ? nj : nk);            // brick extent along d
-        const int end_d = d == 0 ? bk.i1 : (d == 1 ? bk.j1 : V);    // end of the launch's box along d
-        const int ng = plus ? gd + 1 : gd - 1;
-        const int lbd = d == 0 ? el.lbi : (d == 1 ? el.lbj : el.lbk);   // (selects: a run-time index would go to scratch)
-        const bool in_brick = plus && (lbd + 1 < nd) && (ng < end_d);
-        const int lim = d == 2 ? V : H;
-        const bool outside = ng < 0 || ng >= lim;   // tile edge (halo) or ground / top (wall)
-        const int a = fp / N, b = fp - a * N;
-        // nodal line of face point (a, b) along d: LDS offset and stride, point index and stride
-        int lbase, lstride, pbase, pstride;
-        if (d == 0) { lbase = C::lidx(a, b, 0); lstride = 1; pbase = (a * N + b) * N; pstride = 1; }
-        else if (d == 1) { lbase = C::lidx(a, 0, b); lstride = C::NP; pbase = a * N2 + b; pstride = N; }
-        else { lbase = C::lidx(0, a, b); lstride = N * C::NP; pbase = a * N + b; pstride = N2; }
+    const double* const sgi = raw_ptr(P.sgi); const double* const sgj = raw_ptr(P.sgj); const double* const sgk = raw_ptr(P.sgk);
+    const double* const hi = raw_ptr(P.hi); const double* const hj = raw_ptr(P.hj); const double* const hk = raw_ptr(P.hk);
 
-        // own side: from LDS, the weights of the own face (extrap_faces, term by term)
-        T so[7], sn[7];
-        {
-            const auto wv = plus ? P.K->ep : P.K->em;
-#pragma unroll
-            for (int v = 0; v < 5; ++v) so[v] = T(0.0);
-#pragma unroll
-            for (int m = 0; m < N; ++m) {
-                const double wm = wv[m];
-#pragma unroll
-                for (int v = 0; v < 5; ++v) so[v] += wm * img[v * img_stride + fle * C::LE + lbase + m * lstride];
-            }
-            so[0] = w_exp(so[0]);
-            so[4] = w_exp(so[4]);
-        }
-        int wall = 0;
-        const int nle = fle + (d == 0 ? 1 : (d == 1 ? ni : ni * nj));
-        if (in_brick) {
-            const auto wv = P.K->em;   // the upper element's minus face
-#pragma unroll
-            for (int v = 0; v < 5; ++v) sn[v] = T(0.0);
-#pragma unroll
-            for (int m = 0; m < N; ++m) {
-                const double wm = wv[m];
-#pragma unroll
-                for (int v = 0; v < 5; ++v) sn[v] += wm * img[v * img_stride + nle * C::LE + lbase + m * lstride];
-            }
-            sn[0] = w_exp(sn[0]);
-            sn[4] = w_exp(sn[4]);
-        } else if ((outside && d == 2) || WX_BRICK_DIAG == 1) {
-            wall = plus ? 1 : 2;
-#pragma unroll
-            for (int v = 0; v < 5; ++v) sn[v] = so[v];
-        } else if (outside) {
-            // lateral tile edge: the received message (process_topology.py:595-606), five planes V H n^2 apart
-            const size_t vsh = (size_t)V * H * N2;
-            pp<T, const T, G> hb(d == 0 ? (plus ? halo_e : halo_w) : (plus ? halo_n : halo_s));
-            hb = hb + ((size_t)el.ek * H + (d == 0 ? el.ej : el.ei)) * N2 + fp;
-#pragma unroll
-            for (int v = 0; v < 5; ++v) sn[v] = hb[v * vsh];
-        } else {
-            // a neighbour element of this tile outside the brick: its face state from its nodal values, as its own
-            // extrapolation forms it
-            const size_t eo = (size_t)(el.e + (plus ? 1 : -1) * (d == 0 ? 1 : (d == 1 ? H : H * H))) * N3 + pbase;
-            const auto wv = plus ? P.K->em : P.K->ep;   // its face towards this brick
-            T nv[N][5];
-#pragma unroll
-            for (int m = 0; m < N; ++m) load_state<T>(P, eo + m * pstride, fs, nv[m][0], nv[m][1], nv[m][2], nv[m][3], nv[m][4]);
-#pragma unroll
-            for (int v = 0; v < 5; ++v) sn[v] = T(0.0);
-#pragma unroll
-            for (int m = 0; m < N; ++m) {
-                const double wm = wv[m];
-                sn[0] += wm * w_log(nv[m][0]);
-                sn[1] += wm * nv[m][1];
-                sn[2] += wm * nv[m][2];
-                sn[3] += wm * nv[m][3];
-                sn[4] += wm * w_log(nv[m][4]);
-            }
-            sn[0] = w_exp(sn[0]);
-            sn[4] = w_exp(sn[4]);
-        }
-        // interface metric: the own slot of the face (face_load)
+    // this thread's items: k1 of class 1 (w = t1 + it BS), then k2 of class 2 (w = tid + it BS)
+    const int t1 = (tid + 64 * rot) & (BS - 1);
+    const int k1 = t1 < nI ? (nI - t1 + BS - 1) / BS : 0;
+    const int k2 = tid < nS ? (nS - tid + BS - 1) / BS : 0;
+
+    // ---- the first surface item: decode and LOADS, now
+    T nv[N][5], hv[5];
+    double g0, g1, g2, g3;
+    Surf u = surf_decode<N>(bk, tid < nS ? tid : 0, s0, s1, s2, m_vi, m_vj, H, V);
+    if (k2 > 0) {
+        brick_face_metric<N, T, G>(sgi, sgj, sgk, hi, hj, hk, H, V, u.ek, u.ej, u.ei, u.d, u.plus, u.fp, g0, g1, g2, g3);
+        surf_load<N, T>(P, u, halo_s, halo_n, halo_w, halo_e, nv, hv);
+    }
+
+    for (int it = 0; it < k1 + k2; ++it) {
+        T qL[7], qR[7], lgL, lgR;
         double sg, h0, h1, h2;
-        {
-            const int pl = plus ? 1 : 0;
-            pp<T, const double, G> sgp, hp;
-            size_t hfs;
-            if (d == 0) {
-                const size_t o = (((size_t)el.ek * H + el.ej) * (H + 2) + el.ei + 1) * 2 * N2 + pl * N2 + fp;
-                hfs = (size_t)V * H * (H + 2) * 2 * N2;
-                sgp = P.sgi + o; hp = P.hi + 0 * 3 * hfs + o;
-            } else if (d == 1) {
-                const size_t o = (((size_t)el.ek * (H + 2) + el.ej + 1) * H + el.ei) * 2 * N2 + pl * N2 + fp;
-                hfs = (size_t)V * (H + 2) * H * 2 * N2;
-                sgp = P.sgj + o; hp = P.hj + 1 * 3 * hfs + o;
-            } else {
-                const size_t o = ((((size_t)el.ek + 1) * H + el.ej) * H + el.ei) * 2 * N2 + pl * N2 + fp;
-                hfs = (size_t)(V + 2) * H * H * 2 * N2;
-                sgp = P.sgk + o; hp = P.hk + 2 * 3 * hfs + o;
+        int d, fp, le, nle = 0, wall = 0;
+        bool both, own_is_L = true;
+        if (it < k1) {
+            int x = t1 + it * BS;
+            if (x < c0) d = 0;
+            else if (x < c0 + c1) { d = 1; x -= c0; }
+            else { d = 2; x -= c0 + c1; }
+            const int s = x / N2;
+            fp = x - s * N2;
+            // the lower element: s = (lbk * B + lbj) * A + lbi over the box (A, B, .) = (vi, vj, vk) with side d one shorter
+            const int A = d == 0 ? vi - 1 : vi, B = d == 1 ? vj - 1 : vj;
+            const int r = small_div(s, d == 0 ? m_vi1 : m_vi), lbi = s - r * A;
+            const int lbk = small_div(r, d == 1 ? m_vj1 : m_vj), lbj = r - lbk * B;
+            le = brick_slot(bk, lbi, lbj, lbk);
+            nle = le + (d == 0 ? 1 : (d == 1 ? (1 << bk.li) : (1 << (bk.li + bk.lj))));
+            brick_face_metric<N, T, G>(sgi, sgj, sgk, hi, hj, hk, H, V, bk.k0 + lbk, bk.j0 + lbj, bk.i0 + lbi, d, 1, fp, sg, h0, h1, h2);
+            int lbase, lstride, pbase, pstride;
+            brick_line<N>(d, fp, lbase, lstride, pbase, pstride);
+            brick_extrap_lds<N, T>(img, img_stride, le * C::LE + lbase, lstride, P.K->ep, qL, lgL);
+            brick_extrap_lds<N, T>(img, img_stride, nle * C::LE + lbase, lstride, P.K->em, qR, lgR);
+            both = true;
+        } else {
+            if (it > k1) {   // (a later surface item of this thread: its loads here)
+                u = surf_decode<N>(bk, tid + (it - k1) * BS, s0, s1, s2, m_vi, m_vj, H, V);
+                brick_face_metric<N, T, G>(sgi, sgj, sgk, hi, hj, hk, H, V, u.ek, u.ej, u.ei, u.d, u.plus, u.fp, g0, g1, g2, g3);
+                surf_load<N, T>(P, u, halo_s, halo_n, halo_w, halo_e, nv, hv);
             }
-            sg = *sgp; h0 = hp[0]; h1 = hp[hfs]; h2 = hp[2 * hfs];
-        }
-        // left = the lower element's plus-side state, right = the upper element's minus-side state
-        T qL[7], qR[7];
+            d = u.d; fp = u.fp; le = u.le;
+            sg = g0; h0 = g1; h1 = g2; h2 = g3;
+            int lbase, lstride, pbase, pstride;
+            brick_line<N>(d, fp, lbase, lstride, pbase, pstride);
+            T so[5], sn[5], lgo, lgn;
+            if (u.plus) brick_extrap_lds<N, T>(img, img_stride, le * C::LE + lbase, lstride, P.K->ep, so, lgo);
+            else brick_extrap_lds<N, T>(img, img_stride, le * C::LE + lbase, lstride, P.K->em, so, lgo);
+            if (u.kind == 0) {
+                // the neighbour's face state from its nodal values, as its own extrapolation forms it (its face towards this brick)
 #pragma unroll
-        for (int v = 0; v < 5; ++v) {
-            qL[v] = w_sel(plus, so[v], sn[v]);
-            qR[v] = w_sel(plus, sn[v], so[v]);
+                for (int v = 0; v < 5; ++v) sn[v] = T(0.0);
+#pragma unroll
+                for (int m = 0; m < N; ++m) {
+                    const double wm = u.plus ? P.K->em[m] : P.K->ep[m];
+                    sn[0] += wm * w_log(nv[m][0]);
+                    sn[1] += wm * nv[m][1];
+                    sn[2] += wm * nv[m][2];
+                    sn[3] += wm * nv[m][3];
+                    sn[4] += wm * w_log(nv[m][4]);
+                }
+                lgn = sn[4];
+                sn[0] = w_exp(sn[0]);
+                sn[4] = w_exp(sn[4]);
+            } else if (u.kind == 1) {
+#pragma unroll
+                for (int v = 0; v < 5; ++v) sn[v] = hv[v];
+                lgn = w_log(sn[4]);
+            } else {
+                wall = u.plus ? 1 : 2;
+#pragma unroll
+                for (int v = 0; v < 5; ++v) sn[v] = so[v];
+                lgn = lgo;
+            }
+            // left = the lower element's plus-side state, right = the upper element's minus-side state
+            own_is_L = u.plus != 0;
+#pragma unroll
+            for (int v = 0; v < 5; ++v) {
+                qL[v] = w_sel(own_is_L, so[v], sn[v]);
+                qR[v] = w_sel(own_is_L, sn[v], so[v]);
+            }
+            lgL = w_sel(own_is_L, lgo, lgn);
+            lgR = w_sel(own_is_L, lgn, lgo);
+            both = false;
         }
         T out[7], bR, lpR;
         if (WX_BRICK_DIAG == 2) {
@@ -291,13 +373,16 @@ __device__ __forceinline__ void brick_face_stage(const EulerParams<T, G>& P, con
 #pragma unroll
             for (int c = 0; c < 7; ++c) out[c] = sum;
             bR = sum; lpR = sum;
-        } else
-        rusanov_both<T>(qL, qR, d, wall, sg, h0, h1, h2, P.advection_only != 0, out, bR, lpR);
-        if (plus) {
-            store(fle, 2 * d + 1, fp, out, out[5], out[6]);
-            if (in_brick) store(nle, 2 * d, fp, out, bR, lpR);
         } else {
-            store(fle, 2 * d, fp, out, bR, lpR);
+            rusanov_both<T>(qL, qR, lgL, lgR, d, wall, sg, h0, h1, h2, P.advection_only != 0, out, bR, lpR);
+        }
+        if (both) {
+            store(le, 2 * d + 1, fp, out, out[5], out[6]);
+            store(nle, 2 * d, fp, out, bR, lpR);
+        } else if (own_is_L) {
+            store(le, 2 * d + 1, fp, out, out[5], out[6]);
+        } else {
+            store(le, 2 * d, fp, out, bR, lpR);
         }
     }
 }
@@ -313,7 +398,7 @@ __device__ __forceinline__ void brick_pack_edges(const EulerParams<T, G>& P, con
         const int le = fi / (4 * N2);
         const int r = fi - le * (4 * N2);
         const int f = r / N2, fp = r - f * N2;
-        const BElem el = brick_elem<EPB>(bk, le, H, V);
+        const BElem el = brick_elem<EPB>(bk, le, H);
         if (!el.valid) continue;
         const int d = f >> 1, plus = f & 1;
         const int a = fp / N, b = fp - a * N;
@@ -352,6 +437,20 @@ __device__ __forceinline__ void brick_pack_edges(const EulerParams<T, G>& P, con
     }
 }
 
+// where the fused kernel keeps the seven results of face f of element slot le (euler_rhs_body's face-flux image)
+template <int N, typename T>
+struct BrickFaceStore {
+    T* frs;
+    __device__ __forceinline__ void operator()(int le, int f, int fp, const T* out, T bq, T lp) const {
+        constexpr int N2 = N * N;
+        T* q = frs + (le * 6 + f) * (7 * N2) + fp;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) q[c * N2] = out[c];
+        q[5 * N2] = bq;
+        q[6 * N2] = lp;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // the fused evaluation on a brick (float64).  EPI: the stage pipeline's epilogue (optional exponential filter + NaN flag on the
 // output, the tile-edge messages of the output) - a separate instantiation, the plain kernel keeps its schedule.
@@ -375,7 +474,8 @@ __device__ __forceinline__ void euler_brick_body(const EulerParams<T, G>& P, con
     __builtin_assume(tid < BS);
     const int H = P.H, V = P.V;
     const size_t fs = (size_t)P.nelem * N3;
-    const BrickAt bk = brick_at(GB, xcd_slab_block(blockIdx.x, gridDim.x >> 3));
+    const int brick_id = xcd_slab_block(blockIdx.x, gridDim.x >> 3);
+    const BrickAt bk = brick_at(GB, brick_id, V);
     if (!bk.any) return;   // (uniform over the workgroup: the launch is padded to a multiple of eight workgroups)
     for (int i = tid; i < N * N; i += BS) {
         sD[i] = P.K->D[i];
@@ -388,41 +488,56 @@ __device__ __forceinline__ void euler_brick_body(const EulerParams<T, G>& P, con
     }
 
     const int le = tid / N3, pt = tid - le * N3;
-    const BElem el = brick_elem<EPB>(bk, le, H, V);
+    const BElem el = brick_elem<EPB>(bk, le, H);
     const bool active = el.valid;
     const int kl = pt / N2, jl = (pt / N) % N, il = pt % N;
     const int lb = (le < EPB ? le : 0) * C::LE;
     const int lpt = lb + C::lidx(kl, jl, il);
     const size_t o = (size_t)el.e * N3 + pt;
 
-    // ---- the state -> registers and, in the form the extrapolation wants, -> LDS; the metric loads follow and stay in flight
-    // under the face stage
+    // ---- every load of the point stage goes out first, in the order of use: state, Christoffel symbols, the rest of the metric.
+    // The face stage issues the loads of its surface items behind them and works on LDS meanwhile.
     PointIn<T> S;
     k2_point_loads<T, false>(P, active, o, fs, S, o, fs);
+    double cg[27], idzv = 0.0, dco = 0.0, dur0 = 0.0, dur1 = 0.0, dur2 = 0.0;
+    {
+        const bool ld = active && WX_BRICK_DIAG != 4;
+        // (two batches of unconditional loads: a condition per load is a branch and a full wait per load)
+        if (ld && P.rot_zero) {   // non-rotating planet: the 9 rotation symbols are identically zero
+#pragma unroll
+            for (int i = 0; i < 27; ++i) cg[i] = (i % 9) < 3 ? 0.0 : ldm(P.chr + (size_t)i * fs + o);
+        } else if (ld) {
+#pragma unroll
+            for (int i = 0; i < 27; ++i) cg[i] = ldm(P.chr + (size_t)i * fs + o);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 27; ++i) cg[i] = 0.0;
+        }
+        if (ld) idzv = ldm(P.idz + o);
+        if (ld && P.has_damp) { dco = P.dcoef[o]; dur0 = P.duref[o]; dur1 = P.duref[fs + o]; dur2 = P.duref[2 * fs + o]; }
+    }
     const T q0 = S.q0, q1 = S.q1, q2 = S.q2, q3 = S.q3, q4 = S.q4;
     const double sg = S.sg;
+    const T lq4 = w_log(q4);
     if (le < EPB) {
         fld[0][lpt] = w_log(q0);
         fld[1][lpt] = q1;
         fld[2][lpt] = q2;
         fld[3][lpt] = q3;
-        fld[4][lpt] = w_log(q4);
+        fld[4][lpt] = lq4;
     }
     __syncthreads();
 
-    // ---- face stage: every Riemann problem of the brick once
-    if (WX_BRICK_DIAG != 3)
-    brick_face_stage<N, T>(P, bk, &fld[0][0], EPB * C::LE, [&](int sle, int f, int fp, const T* out, T bq, T lp) {
+    // (the values loaded for the forcing are first USED here: without this the compiler pulls the forcing's first operations -
+    // 2 c, g / dz - up to the loads, and the wait for all of them in front of the barrier)
 #pragma unroll
-        for (int c = 0; c < 5; ++c) WX_FR(sle, f, c, fp) = out[c];
-        WX_FR(sle, f, 5, fp) = bq;
-        WX_FR(sle, f, 6, fp) = lp;
-    });
+    for (int i = 0; i < 27; ++i) asm volatile("" : "+v"(cg[i]));
+    asm volatile("" : "+v"(idzv));
 
-    // ---- pointwise quantities
+    // ---- pointwise quantities (the logarithm of rho theta is the one the extrapolation took)
     const T rinv = 1.0 / q0;
     const T u1 = q1 * rinv, u2 = q2 * rinv, u3 = q3 * rinv;
-    const T glog = kGamma * w_log(kRdOverP0 * q4);
+    const T glog = kGamma * (lq4 + kLogRdOverP0);
     const T p = kP0 * w_exp(glog);
     const T logp = kLogP0 + glog;
     if (le < EPB) {
@@ -430,10 +545,33 @@ __device__ __forceinline__ void euler_brick_body(const EulerParams<T, G>& P, con
         fld[7][lpt] = sg * q0;
     }
 
-    // ---- forcing
-    T fc0, fc1, fc2;
-    double gcoef;
-    k2_forcing<T, false, true>(P, active, o, fs, S, u1, u2, u3, p, fc0, fc1, fc2, gcoef, o, fs);
+    // ---- forcing (k2_forcing's arithmetic on the values loaded above)
+    T fc0 = T(0.0), fc1 = T(0.0), fc2 = T(0.0);
+    double gcoef = 0.0;
+    if (active) {
+        T fc[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double* c = cg + i * 9;
+            const double c01 = c[0], c02 = c[1], c03 = c[2], c11 = c[3], c12 = c[4], c13 = c[5], c22 = c[6], c23 = c[7], c33 = c[8];
+            fc[i] = 2.0 * q0 * (c01 * u1 + c02 * u2 + c03 * u3) + c11 * (q0 * u1 * u1 + S.h00 * p) +
+                    2.0 * c12 * (q0 * u1 * u2 + S.h01 * p) + 2.0 * c13 * (q0 * u1 * u3 + S.h02 * p) +
+                    c22 * (q0 * u2 * u2 + S.h11 * p) + 2.0 * c23 * (q0 * u2 * u3 + S.h12 * p) +
+                    c33 * (q0 * u3 * u3 + S.h22 * p);
+        }
+        if (P.has_damp) {
+            const T dw = dco * q0;
+            fc[0] += dw * (u1 - dur0);
+            fc[1] += dw * (u2 - dur1);
+            fc[2] += dw * (u3 - dur2);
+        }
+        fc0 = fc[0]; fc1 = fc[1]; fc2 = fc[2];
+        gcoef = idzv * kGravity;
+    }
+
+    // ---- face stage: every Riemann problem of the brick once
+    if (WX_BRICK_DIAG != 3)
+    brick_face_stage<N, T>(P, bk, &fld[0][0], EPB * C::LE, brick_id & (BS / 64 - 1), BrickFaceStore<N, T>{frs});
 
     T acc0 = T(0.0), acc1 = sg * fc0, acc2 = sg * fc1, acc4 = T(0.0), accw = sg * fc2;
     T hf = T(0.0);
@@ -569,12 +707,12 @@ __device__ __forceinline__ void euler_brick_body(const EulerParams<T, G>& P, con
 }
 
 template <int N, bool EPI>
-__global__ __launch_bounds__(BrickCfg<N>::BS, kK2Waves) void euler_brick_kernel(const EulerParams<double> P, const BrickBoxes GB) {
+__global__ __launch_bounds__(BrickCfg<N>::BS, BrickCfg<N>::WAVES) void euler_brick_kernel(const EulerParams<double> P, const BrickBoxes GB) {
     euler_brick_body<N, double, EPI>(P, GB);
 }
 
 template <int N>
-__global__ __launch_bounds__(BrickCfg<N>::BS, kK2Waves) void euler_brick_batch_kernel(const EulerParams<double>* table,
+__global__ __launch_bounds__(BrickCfg<N>::BS, BrickCfg<N>::WAVES) void euler_brick_batch_kernel(const EulerParams<double>* table,
                                                                                      const EulerBatchDyn<double> dyn,
                                                                                      const BrickBoxes GB) {
     // the block comes out of memory: typed so that every access through its pointers is a global one (wx_common.h: gp)
