@@ -207,8 +207,8 @@ typedef enum {
 } wx_kernel;
 int wx_euler3d_uses_matrix_cores(const wx_euler3d_plan* plan, wx_kernel kernel);
 
-/* Low orders (num_solpts 2..4, WX_F64 - the orders of the reference's shipped configurations and of its RHS benchmark,
- * tests/rhs_benchmark/run.sh:67-71): the evaluation is ONE kernel that keeps the face states on chip (a workgroup owns a
+/* Low orders (WX_F64; default at num_solpts 2, available for 3 and 4 - the orders of the reference's shipped configurations
+ * and of its RHS benchmark, tests/rhs_benchmark/run.sh:67-71): the evaluation is ONE kernel that keeps the face states on chip (a workgroup owns a
  * brick of elements, solves every Riemann problem of the brick once, and extrapolates the states beyond the brick's surface
  * from the neighbour elements' nodal values; csrc/euler3d_brick.h).  On such a plan wx_euler3d_extrap_pack* write the edge
  * messages only - there is no interface buffer - and every wx_euler3d_rhs* / _stage / _shifted_* call reads q alone; the

@@ -25,6 +25,8 @@ def _tile(n, H, V, panel=4, seed=3):
     m = synthetic.euler3d_metric(n, H, V, panel, DEV, seed=seed)
     q = synthetic.euler3d_state(n, H, V, panel, DEV, seed=seed)
     plan = Euler3DPlan(n, H, V, 31, panel, synthetic.dfr_ops(n), m)
+    assert plan.one_kernel == (n == 2)   # the default: where the form wins
+    plan.set_one_kernel(True)
     return plan, q
 
 
@@ -126,6 +128,8 @@ def test_whole_sphere_callable_on_low_order_fixtures(name):
     if len(panels) != 6:
         pytest.skip("needs all six panels")
     plans = {p: make_plan(g, p) for p in panels}
+    for pl in plans.values():
+        pl.set_one_kernel(True)
     assert all(pl.one_kernel for pl in plans.values())
     rhs = RhsEuler3D(plans)
     Q = torch.stack([to_dev(g.q(p)) for p in panels])

@@ -267,7 +267,8 @@ wx_status wx_euler3d_plan_create_tile(wx_euler3d_plan** out, int n, int H, int V
     }
     {
         const char* env = getenv("WXHIP_DIRECT");
-        pl->direct = dtype == WX_F64 && n <= 4 && !(env && env[0] == '0');
+        // default at num_solpts 2, where it wins (profiles/r06_low_order_forms.txt); 3 and 4 on request (set_one_kernel)
+        pl->direct = dtype == WX_F64 && n == 2 && !(env && env[0] == '0');
     }
     b.advection_only = case_number < 13; b.has_damp = damp;
     b.sg = m->sqrtG; b.h = m->h_contra; b.chr = m->christoffel; b.idz = m->inv_dzdeta;

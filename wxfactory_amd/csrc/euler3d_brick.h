@@ -43,7 +43,7 @@ struct BrickCfg {
     static constexpr int LE = N2 * NP;
     // waves per SIMD the register allocation aims at: n = 2 holds two workgroups per CU whatever it does (59 KB of LDS each)
 #ifndef WX_BRICK_WAVES
-#define WX_BRICK_WAVES 3
+#define WX_BRICK_WAVES 2
 #endif
     static constexpr int WAVES = N == 2 ? 2 : WX_BRICK_WAVES;
     __host__ __device__ static constexpr int lidx(int kl, int jl, int il) { return (kl * N + jl) * NP + il; }
