@@ -106,6 +106,20 @@ wx_status wx_phase_timer_create(wx_phase_timer** timer);
 wx_status wx_phase_timer_destroy(wx_phase_timer* timer);
 wx_status wx_phase_timer_stamp(wx_phase_timer* timer, int slot, wx_stream stream);
 wx_status wx_phase_timer_elapsed(wx_phase_timer* timer, double seconds[9]);
+/* seconds from stamp 0 to every stamped slot (a slot without a stamp: -1): where two streams' phases lie against each other -
+ * did the exchange on the compute stream (slot 5) complete before the INTERIOR launches on the second stream ended (slot 3)? */
+wx_status wx_phase_timer_since_start(wx_phase_timer* timer, double seconds[9]);
+
+/* Streams with a scheduling priority, for the overlapped evaluation (wx_*_rhs_overlapped, wx_exchange_fork): the INTERIOR launches
+ * fill every CU, and the grouped ncclSend / ncclRecv that should run beside them are a handful of workgroups on the compute stream.
+ * REQUIREMENT for overlap at N > 1: `side` (INTERIOR) at the LOWEST priority the device offers, the compute stream at normal or
+ * higher - the dispatcher then gives the exchange's workgroups the next free slots instead of queueing them behind INTERIOR's
+ * (torch.cuda.Stream offers normal and high only, no low: PanelExchange takes its second stream from here).
+ * priority_class: +1 lowest, 0 normal, -1 highest (mapped onto hipDeviceGetStreamPriorityRange).  Non-blocking streams of the
+ * current device; wx_stream_destroy synchronises the stream first. */
+wx_status wx_stream_priority_range(int* least, int* greatest);
+wx_status wx_stream_create(wx_stream* stream, int priority_class);
+wx_status wx_stream_destroy(wx_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * 3-D Euler on a cubed-sphere tile.

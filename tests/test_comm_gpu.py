@@ -300,6 +300,39 @@ def test_pmex_vectors_split_over_ranks_reduce_in_stream_order(comm, p, taus):
     assert calls["n"] <= 2 + 2 * st_split[0] + 2 * st_split[1], (calls, st_split)
 
 
+@pytest.mark.parametrize("p", [1, 3])
+def test_pmex_on_a_rank_that_owns_nothing_still_takes_part(comm, p):
+    """ranks beyond the tile count (6, 7 of an 8-GPU node) hold the p augmented components of every Krylov vector
+    and NO nodal part: A(V[:0]) and the flipped u are empty tensors, whose address is null.  wx_pmex_vector_split must accept
+    them (it refused, and the other ranks - already inside ncclAllReduce - would have hung), issue both reductions and build
+    the augmented part: the whole solver on an empty nodal part, device pass, against the host pass on the same input."""
+    from wxfactory_amd.solvers import pmex
+
+    u = torch.zeros((p + 1, 0), device=DEV, dtype=torch.float64)
+    A = lambda v: v  # noqa: E731  (never sees a component)
+    args = dict(tol=1e-10, m_init=6, mmin=4, mmax=20)
+    calls = {"n": 0}
+    inner = comm.allreduce
+
+    def counting(t, op="sum"):
+        calls["n"] += 1
+        return inner(t, op)
+
+    comm.allreduce = counting
+    try:
+        w_dev, st_dev = pmex([1.0], A, u, group=comm, _force_split=True, **args)
+    finally:
+        comm.allreduce = inner
+    assert calls["n"] > 0    # the collective decisions still went through the communicator
+    os.environ["WXHIP_PMEX_DEVICE"] = "0"
+    try:
+        w_host, st_host = pmex([1.0], A, u, group=comm, _force_split=True, **args)
+    finally:
+        del os.environ["WXHIP_PMEX_DEVICE"]
+    assert w_dev.shape == w_host.shape and w_dev.shape[-1] == 0
+    assert st_dev[:4] == st_host[:4], (st_dev, st_host)
+
+
 def test_bench_loopback_rehearsal_prints_one_line_and_checks_its_exchange(built_lib):
     """bench.py --loopback: the several-GPU path of the benchmark on one GPU - a one-rank communicator of the library's own, every
     edge message through grouped ncclSend / ncclRecv, INTERIOR beside the exchange, no process group of any kind - at a reduced

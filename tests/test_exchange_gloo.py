@@ -546,8 +546,9 @@ def test_device_buffers_never_travel_on_a_torch_nccl_group(monkeypatch):
     import re
 
     pkg = os.path.dirname(exchange.__file__)
-    bench = open(os.path.join(os.path.dirname(pkg), "bench.py")).read()
-    assert not re.search(r"init_process_group\(\s*[\"']nccl", bench)
+    root = os.path.dirname(pkg)
+    for name in ["bench.py"] + [os.path.join("benchlib", f) for f in os.listdir(os.path.join(root, "benchlib")) if f.endswith(".py")]:
+        assert not re.search(r"init_process_group\(\s*[\"']nccl", open(os.path.join(root, name)).read()), name
     for name in os.listdir(pkg):
         if name.endswith(".py"):
             assert not re.search(r"init_process_group\(\s*[\"']nccl", open(os.path.join(pkg, name)).read()), name

@@ -17,42 +17,59 @@ import torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-N, H, V, CASE = 8, 60, 8, 31
-CHECK = 4          # the panel compared (panel 4: its N and W edges are flipped, all four rotated)
+N, H, V = 8, 60, 8
+CHECKS = {31: 4, 21: 0}   # the panel compared (panel 4: its N and W edges are flipped, all four rotated; panel 0: the mountain's)
+# case 31: DCMIP 3-1 (config 4's physics; a shallow atmosphere without topography, non-rotating: 18 Christoffel fields);
+# case 21: DCMIP 2-1 (config 5's physics: the Schaer mountain - a metric that depends on the level - and the Rayleigh sponge above
+# 20 km, pde_euler_cubesphere.py:285-288 + init/dcmip.py:676-757: the has_damp loads, +32 B/point)
+CASES = {31: 10000.0, 21: 30000.0}
 
 
 def _ref_metric(m):
     """geometry3d's device metric of one panel -> the reference's names on the host (what the oracle takes)."""
     om = {"sqrtG_new": m["sqrtG"], "h_contra_new": m["h_contra"], "christoffel": m["christoffel"],
           "inv_dzdeta_new": m["inv_dzdeta"]}
+    for k in ("damp_coef", "damp_uref"):
+        if k in m:
+            om[k] = m[k]
     for d in "ijk":
         om[f"sqrtG_itf_{d}_new"] = m[f"sqrtG_itf_{d}"]
         om[f"h_contra_itf_{d}_new"] = m[f"h_contra_itf_{d}"]
     return {k: v.cpu().numpy() for k, v in om.items()}
 
 
-def test_e7_panel_all_rows_against_the_c_port(built_lib):
+@pytest.mark.parametrize("CASE", sorted(CASES, reverse=True))
+def test_e7_panel_all_rows_against_the_c_port(built_lib, CASE):
     from oracle import cubed_sphere as cs
     from oracle.c_port import Euler3DPortC
     from wxfactory_amd import _lib
-    from wxfactory_amd.geometry3d import CubedSphere3DTile, metric3d_torch
+    from wxfactory_amd.geometry3d import CubedSphere3DTile, metric3d_torch, planet_for_case, topography_for_case
     from wxfactory_amd.initial import initial_state
     from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D
     from wxfactory_amd.synthetic import dfr_ops
 
+    CHECK = CHECKS[CASE]
     threads = max(1, min(16, len(os.sched_getaffinity(0))))
     ops = dfr_ops(N)
     plans, metrics, qs, bnd = {}, {}, [], {}
     gen = torch.Generator(device=DEV).manual_seed(2025)
+    topo = topography_for_case(CASE, planet_for_case(CASE)[0])
     for p in range(6):
-        t = CubedSphere3DTile(N, H, V, p, 10000.0, CASE)
+        t = CubedSphere3DTile(N, H, V, p, CASES[CASE], CASE, topo=topo)
         metrics[p] = metric3d_torch(t, DEV)
+        assert ("damp_coef" in metrics[p]) == (CASE == 21)
         plans[p] = Euler3DPlan(N, H, V, CASE, p, ops, metrics[p])
         q = torch.from_numpy(np.array(initial_state(t))).to(DEV)
         qs.append(q * (1.0 + 0.01 * (torch.rand(q.shape, generator=gen, device=DEV, dtype=q.dtype) - 0.5)))
         b = metrics[p]["boundary_sn"].cpu().numpy().reshape(H, 1, N)
         bnd[p] = (np.tile(b, (1, N, 1)), np.tile(metrics[p]["boundary_we"].cpu().numpy().reshape(H, 1, N), (1, N, 1)))
     assert int(plans[0].lib.wx_euler3d_uses_matrix_cores(plans[0]._h, _lib.WX_KERNEL_RHS)) == 1
+    # compulsory bytes per point of this plan: 312 (case 31, no rotation symbols) / 344 (case 21: + the four sponge fields)
+    assert plans[0].bytes_per_point == (312.0 if CASE == 31 else 344.0)
+    if CASE == 21:   # the mountain makes the metric depend on the level: the general kernel's case, not the column form's
+        h13 = metrics[CHECK]["h_contra"][0, 2]   # (terrain-following levels: dz/dx at fixed eta fades with height)
+        assert float((h13[0] - h13[-1]).abs().max()) > 1e-3 * float(h13.abs().max()) > 0.0
+        assert float(metrics[CHECK]["damp_coef"].abs().max()) > 0.0
     Q = torch.stack(qs)
     del qs
     rhs = RhsEuler3D(plans)

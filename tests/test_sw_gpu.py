@@ -443,6 +443,20 @@ def test_own_geometry_and_initial_states_against_the_oracle(built_lib, case):
     full = torch.stack([_dev(initial_sw.galewsky(t, True, h0)) for t in tiles])
     Rj, Rf = rhs(jet), rhs(full)
     torch.cuda.synchronize()
+    # S7 itself (BASELINE config 3's size: 6 x 60 x 60 elements, 1.38 M points) against the NumPy oracle, all six panels, every
+    # row, at 1e-10 - through the default form of the evaluation at this size (one launch, tile-edge lines pulled by the kernel)
+    assert rhs._use_direct(torch.float64)
+    metrics7 = [metric2d(t) for t in tiles]
+    oracles7 = [SW2DOracle(n, H, ops, m, None, t.boundary_sn, t.boundary_we, panel=p) for p, (t, m) in enumerate(zip(tiles, metrics7))]
+    q7 = [initial_sw.galewsky(t, True, h0) for t in tiles]
+    itf7 = [o.extrapolate(q) for o, q in zip(oracles7, q7)]
+    recv7 = cs.route([o.pack_edges(itf) for o, itf in zip(oracles7, itf7)])
+    for p, o in enumerate(oracles7):
+        terms7 = {}
+        ref = o.rhs(q7[p], recv7[p], itf=itf7[p], want=terms7)
+        scale = np.maximum(var_max(ref), SW2DOracle.cancel_scale(terms7))
+        err = var_err(Rf[p].cpu().numpy(), ref)
+        assert (err <= TOL * scale).all(), ("S7", p, err / scale)
     assert float(Rj[:, 0].abs().max()) < 1e-7                   # m/s of depth (1.3e-3 at 8 x 8 elements per panel)
     assert 1e-3 < float(Rf[:, 0].abs().max()) < 1e-1            # the bump's gravity waves set off
     assert float((Rj[:, 1:].abs().amax(dim=(0, 2, 3, 4)) / jet[:, 1:].abs().amax(dim=(0, 2, 3, 4))).max()) < 1e-9   # 1/s

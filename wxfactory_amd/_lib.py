@@ -66,6 +66,10 @@ SIGNATURES = {
     "wx_phase_timer_destroy": (c_int, [c_void_p]),
     "wx_phase_timer_stamp": (c_int, [c_void_p, c_int, c_void_p]),
     "wx_phase_timer_elapsed": (c_int, [c_void_p, POINTER(c_double)]),
+    "wx_phase_timer_since_start": (c_int, [c_void_p, POINTER(c_double)]),
+    "wx_stream_priority_range": (c_int, [POINTER(c_int), POINTER(c_int)]),
+    "wx_stream_create": (c_int, [POINTER(c_void_p), c_int]),
+    "wx_stream_destroy": (c_int, [c_void_p]),
     "wx_euler3d_plan_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int,
                                        POINTER(DfrOps), POINTER(Euler3DMetric)]),
     "wx_euler3d_plan_create_tile": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_int),

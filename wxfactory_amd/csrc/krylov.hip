@@ -994,7 +994,10 @@ size_t wx_pmex_workspace(int mmax) {
 static wx_status pmex_vector_impl(double* V, size_t ldv, int j, size_t n, int p, const double* aw, const double* uflip, double* LT,
                                   double* Linv, int ld, double tol, double* hcol, double* own, double* workspace, int mmax,
                                   bool split, wx_comm* comm, wx_stream stream, const char* who) {
-    if (!V || !aw || !uflip || !LT || !Linv || !hcol || !own || !workspace)
+    // (n == 0: a rank that owns no tile - ranks 6, 7 of an 8-GPU node - holds the p augmented components only; its n-long
+    // operands are empty tensors, whose address is null.  It still takes part in both reductions and runs every kernel of the
+    // augmented part: none of them touches aw / uflip when n == 0.)
+    if (!V || (n > 0 && (!aw || !uflip)) || !LT || !Linv || !hcol || !own || !workspace)
         return fail(WX_ERR_INVALID, "%s: null argument", who);
     if (j < 1 || j > mmax || mmax > kPmexMaxM || ld < mmax || p < 1 || p > 16 || ldv < n + (size_t)p)
         return fail(WX_ERR_INVALID, "%s: j = %d, mmax = %d (<= %d), ld = %d, p = %d (1..16), row stride %zu, n = %zu",

@@ -197,4 +197,48 @@ wx_status wx_phase_timer_elapsed(wx_phase_timer* t, double seconds[9]) {
     return WX_OK;
 }
 
+wx_status wx_phase_timer_since_start(wx_phase_timer* t, double seconds[9]) {
+    if (!t || !seconds) return wx::fail(WX_ERR_INVALID, "wx_phase_timer_since_start: null argument");
+    if (!t->set[0]) return wx::fail(WX_ERR_INVALID, "wx_phase_timer_since_start: slot 0 must be stamped");
+    for (int i = 0; i <= 8; ++i)
+        if (t->set[i]) WX_HIP_TRY(hipEventSynchronize(t->ev[i]));
+    seconds[0] = 0.0;
+    for (int i = 1; i <= 8; ++i) {
+        seconds[i] = -1.0;
+        if (!t->set[i]) continue;
+        float ms = 0.0f;
+        WX_HIP_TRY(hipEventElapsedTime(&ms, t->ev[0], t->ev[i]));
+        seconds[i] = 1e-3 * ms;
+    }
+    return WX_OK;
+}
+
+wx_status wx_stream_priority_range(int* least, int* greatest) {
+    int lo = 0, hi = 0;
+    WX_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    if (least) *least = lo;
+    if (greatest) *greatest = hi;
+    return WX_OK;
+}
+
+wx_status wx_stream_create(wx_stream* out, int priority_class) {
+    if (!out) return wx::fail(WX_ERR_INVALID, "wx_stream_create: null argument");
+    *out = nullptr;
+    int lo = 0, hi = 0;   // numerically: least >= greatest
+    WX_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    const int prio = priority_class > 0 ? lo : (priority_class < 0 ? hi : (lo + hi) / 2);
+    hipStream_t st = nullptr;
+    WX_HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio));
+    *out = st;
+    return WX_OK;
+}
+
+wx_status wx_stream_destroy(wx_stream stream) {
+    if (!stream) return WX_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    (void)hipStreamSynchronize(st);
+    WX_HIP_TRY(hipStreamDestroy(st));
+    return WX_OK;
+}
+
 }  // extern "C"

@@ -18,6 +18,7 @@ all five variables, already rotated and flipped by the pack kernel (wx_euler3d_e
   (profiles/r05_process_group_abort.md, profiles/r04_capture_crash.md).
 """
 import ctypes
+import os
 import weakref
 from typing import Dict, List, Tuple
 
@@ -63,6 +64,7 @@ class RcclComm:
 
         self.lib = _lib.load()
         self.rank, self.world = rank, world_size
+        refuse_nccl_process_group("RcclComm")
         ident = (ctypes.c_ubyte * _lib.WX_COMM_ID_BYTES)()
         if rank == 0:
             _lib.check(self.lib.wx_comm_unique_id(ident), "wx_comm_unique_id")
@@ -136,6 +138,27 @@ class RcclComm:
             self.close()
         except Exception:
             pass
+
+
+def refuse_nccl_process_group(who: str):
+    """A torch.distributed NCCL process group in this process brings a watchdog thread that polls HIP events beside this
+    package's graph captures; the HIP runtime inside the torch wheel answers such a call by invalidating the capture and failing
+    the query, and the watchdog answers an error by aborting the process (profiles/r05_process_group_abort.md).  The library's
+    communicator and a NCCL group do not share a process: refused here, before any capture starts, not at the first exchange."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    backends = set()
+    try:
+        backends.add(str(dist.get_backend()))
+        pg_map = getattr(dist.distributed_c10d, "_world", None)
+        for pg in list(getattr(pg_map, "pg_map", {}) or {}):
+            backends.add(str(dist.get_backend(pg)))
+    except Exception:   # noqa: BLE001 - a group this rank is not part of
+        pass
+    if any("nccl" in b.lower() for b in backends):
+        raise RuntimeError(f"{who}: a torch.distributed NCCL process group is initialised in this process; its watchdog thread's "
+                           "HIP event queries abort the process under this package's graph captures - use a gloo group (or a "
+                           "TCPStore) for the host side, the library's communicator carries the device data")
 
 
 class PanelExchange:
@@ -240,13 +263,30 @@ class PanelExchange:
                 if (self.lib.wx_exchange_send_ptr(h, p, e) != self.send_view(p, e).data_ptr()
                         or self.lib.wx_exchange_halo_ptr(h, p, e) != self.halo_view(p, e).data_ptr()):
                     raise RuntimeError(f"the library's slot of tile {p}, edge {e} differs from the host mirror's")
-        # the communication stream the exchange is forked to (one per exchange object; the join is an event wait)
-        self.comm_stream = torch.cuda.Stream(device=device) if self.needs_comm else None
+        # the second stream of the overlapped evaluation (one per exchange object; the join is an event wait): it carries the
+        # INTERIOR launches, which fill every CU - at the LOWEST priority the device offers, so that the workgroups of the grouped
+        # sends / receives on the compute stream get the next free slots instead of queueing behind them (include/wxhip.h:
+        # wx_stream_create; torch's own streams know normal and high only).  WXHIP_SIDE_PRIORITY=normal: the A/B without.
+        self.comm_stream, self._side = None, None
+        if self.needs_comm:
+            if os.environ.get("WXHIP_SIDE_PRIORITY", "low") == "low":
+                side = ctypes.c_void_p()
+                with torch.cuda.device(device):
+                    _lib.check(self.lib.wx_stream_create(ctypes.byref(side), 1), "wx_stream_create")
+                self._side = side
+                self.comm_stream = torch.cuda.ExternalStream(side.value, device=device)
+            else:
+                self.comm_stream = torch.cuda.Stream(device=device)
+        self.side_priority = "lowest" if self._side is not None else "normal"
 
     def close(self):
         if self._native:
             self.lib.wx_exchange_destroy(self._native)
             self._native = None
+        if getattr(self, "_side", None) is not None:
+            self.comm_stream = None
+            self.lib.wx_stream_destroy(self._side)
+            self._side = None
 
     def __del__(self):
         try:
@@ -314,7 +354,9 @@ class PanelExchange:
             from . import _lib
 
             cs = torch.cuda.current_stream(self.send_buf.device).cuda_stream
-            ms = cs if (self.is_inline or on_compute) else self.comm_stream.cuda_stream
+            # (the second stream is a LOW-priority one, made for the INTERIOR launches: the exchange itself never goes there - a
+            # caller that asks for it, the timed evaluation's stamps, gets the exchange in stream order on the compute stream)
+            ms = cs if (self.is_inline or on_compute or self._side is not None) else self.comm_stream.cuda_stream
             _lib.check(self.lib.wx_exchange_start(self._native, cs, ms), "wx_exchange_start")
             return
         ec = self.edge_count

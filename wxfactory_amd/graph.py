@@ -40,6 +40,17 @@ class GraphedFunction:
             with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
                 self.output = fn(*self.inputs)
         torch.cuda.current_stream().wait_stream(side)
+        # a graph that holds RCCL nodes (R(Q) or a matvec over the library's exchange) must go before its communicator:
+        # ncclCommDestroy under such a graph does not return (profiles/r04_capture_crash.md).  RcclComm.close() resets
+        # what is registered with it.
+        holders = []
+        try:
+            holders = [getattr(rhs, "reduce_group", None), getattr(getattr(rhs, "ex", None), "comm", None)]
+        except Exception:   # noqa: BLE001 - an RHS object without plans yet
+            pass
+        for holder in holders:
+            if holder is not None and hasattr(holder, "register_graph"):
+                holder.register_graph(self.graph)
 
     def __call__(self, *inputs: torch.Tensor) -> torch.Tensor:
         for dst, src in zip(self.inputs, inputs):

@@ -72,6 +72,33 @@ def column_metric_slabs(metric: Dict[str, torch.Tensor], n: int, H: int, V: int,
     return out
 
 
+class LaunchEvents:
+    """Opt-in instrumentation of the two launches of an evaluation (bench.py's live kernel timing): while `on`, every
+    extrapolation / pack launch and every fused-kernel launch of Euler3DPlan and Euler3DBatch is bracketed by a pair of HIP
+    events on the launch stream.  `rhs`: (start, end, region, tiles in the launch); `pack`: (start, end).  Off: one attribute
+    test per launch."""
+
+    def __init__(self):
+        self.on = False
+        self.rhs, self.pack = [], []
+
+    def clear(self):
+        self.rhs, self.pack = [], []
+
+    def around(self, launch, kind, region=0, tiles=1):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        launch()
+        b.record()
+        if kind == "rhs":
+            self.rhs.append((a, b, region, tiles))
+        else:
+            self.pack.append((a, b))
+
+
+LAUNCH_EVENTS = LaunchEvents()
+
+
 class Euler3DPlan:
     """One tile (= one cube panel).  Owns the native plan; borrows the metric tensors
     (kept alive here) exactly as the reference's pde module borrows NumPy/CuPy buffers."""
@@ -189,6 +216,9 @@ class Euler3DPlan:
         self.faces_epoch += 1
         arr = _ptr_array(send_ptrs)
         st = torch.cuda.current_stream(self.device).cuda_stream
+        if LAUNCH_EVENTS.on:
+            return LAUNCH_EVENTS.around(lambda: check(self.lib.wx_euler3d_extrap_pack(self._h, q.data_ptr(), arr, st),
+                                                      "wx_euler3d_extrap_pack"), "pack")
         check(self.lib.wx_euler3d_extrap_pack(self._h, q.data_ptr(), arr, st), "wx_euler3d_extrap_pack")
 
     def rhs(self, q: torch.Tensor, halo_ptrs: Optional[Sequence[int]], out: torch.Tensor, region: int = _lib.WX_REGION_ALL):
@@ -196,6 +226,9 @@ class Euler3DPlan:
         self._check_q(out)
         arr = _ptr_array(halo_ptrs)
         st = torch.cuda.current_stream(self.device).cuda_stream
+        if LAUNCH_EVENTS.on:
+            return LAUNCH_EVENTS.around(lambda: check(self.lib.wx_euler3d_rhs(self._h, q.data_ptr(), arr, out.data_ptr(), region, st),
+                                                      "wx_euler3d_rhs"), "rhs", region, 1)
         check(self.lib.wx_euler3d_rhs(self._h, q.data_ptr(), arr, out.data_ptr(), region, st), "wx_euler3d_rhs")
 
     def rhs_axpy(self, q, halo_ptrs, y, out, a: float, b: float, c: float, region: int = _lib.WX_REGION_ALL,
@@ -393,17 +426,22 @@ class Euler3DBatch:
         for pl in self._keep[0].values():
             pl.faces_epoch += 1
         st = torch.cuda.current_stream(self.device).cuda_stream
-        check(self.lib.wx_euler3d_batch_extrap_pack(self._h, q.data_ptr(), v.data_ptr() if v is not None else None, eps,
-                                                    self.stride, st), "wx_euler3d_batch_extrap_pack")
+        launch = lambda: check(self.lib.wx_euler3d_batch_extrap_pack(self._h, q.data_ptr(), v.data_ptr() if v is not None else None,  # noqa: E731
+                                                                     eps, self.stride, st), "wx_euler3d_batch_extrap_pack")
+        if LAUNCH_EVENTS.on:
+            return LAUNCH_EVENTS.around(launch, "pack")
+        launch()
 
     def rhs(self, q, out, region, y=None, z=None, coef=None, v=None, eps: float = 0.0):
         st = torch.cuda.current_stream(self.device).cuda_stream
         a, b, c, d = coef if coef is not None else (0.0, 0.0, 1.0, 0.0)
-        check(self.lib.wx_euler3d_batch_rhs_axpy2(self._h, q.data_ptr(), v.data_ptr() if v is not None else None, eps,
-                                                  y.data_ptr() if y is not None else None,
-                                                  z.data_ptr() if z is not None else None, out.data_ptr(), self.stride,
-                                                  0 if coef is None else 1, a, b, c, d, region, st),
-              "wx_euler3d_batch_rhs_axpy2")
+        launch = lambda: check(self.lib.wx_euler3d_batch_rhs_axpy2(  # noqa: E731
+            self._h, q.data_ptr(), v.data_ptr() if v is not None else None, eps, y.data_ptr() if y is not None else None,
+            z.data_ptr() if z is not None else None, out.data_ptr(), self.stride, 0 if coef is None else 1, a, b, c, d, region, st),
+            "wx_euler3d_batch_rhs_axpy2")
+        if LAUNCH_EVENTS.on:
+            return LAUNCH_EVENTS.around(launch, "rhs", region, len(self.panels))
+        launch()
 
     def jvp(self, q, v, eps: float, out, scale: float, region):
         """dual batches: out (real) = scale * Im R(q + i eps v) for all tiles."""

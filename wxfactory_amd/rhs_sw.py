@@ -259,8 +259,10 @@ class RhsShallowWater(PanelRhs):
     @property
     def supports_pipeline(self) -> bool:
         """The stage pipeline (wx_sw_stage: the stage's kernel extrapolates its own output) pays where an evaluation takes two
-        launches; where the direct form is taken a fused stage is one launch already, and faster (S7: 49 against 54 us)."""
-        return not self._use_direct(torch.float64)
+        launches; where the direct form is taken a fused stage is one launch already, and faster (S7: 49 against 54 us).  The
+        direct form is only taken by the batched evaluation of several local tiles (_run_batched): a rank with one tile - the
+        six-GPU decomposition - evaluates in two launches and keeps the pipeline."""
+        return not (self._use_direct(torch.float64) and self.batched and len(self.panels) > 1)
     # the direct form (no interface buffer: ring-only pack - none when SwBatch.pulls - then ONE launch; wx_sw_rhs_direct): bit-identical to the two-kernel
     # form.  None = automatic: taken for float64 states at n = 8, where it is measured ahead since its face stage is spread
     # over all threads and its independent loads are issued before the first barrier (S7: 49 against 53-58 us,
