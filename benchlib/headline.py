@@ -47,6 +47,9 @@ def main():
                          "roofline block; the two passes' step times are both in the line).  K > 0: one pass, events around "
                          "the launches of every K-th timed step (K = 1 costs the headline ~1 %: two marker packets between "
                          "kernels that would otherwise overlap their tails)")
+    ap.add_argument("--compute-priority", choices=("normal", "high"), default="normal",
+                    help="priority of the stream the evaluation is enqueued on (pack, exchange, BOUNDARY); the INTERIOR launches of "
+                         "the overlapped evaluation go to the exchange's second stream (WXHIP_SIDE_PRIORITY=low: lowest priority)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary (shallow-water S7) measurement")
     ap.add_argument("--loopback", action="store_true",
                     help="rehearsal on one GPU: route every edge message through the RCCL collective (1-rank group) and split "
@@ -252,6 +255,11 @@ def main():
             h = ctypes.c_void_p()
             _lib.check(lib.wx_phase_timer_create(ctypes.byref(h)), "wx_phase_timer_create")
             native_timers.append(h)
+
+    if args.compute_priority == "high":   # everything below is enqueued on a high-priority stream (an A/B of the overlap)
+        hp = torch.cuda.Stream(device=dev, priority=-1)
+        hp.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.set_stream(hp)
 
     def timed_pass(events_every):
         """K steps between barriers; events_every: 0 none, K > 0 around the launches of every K-th step."""

@@ -112,9 +112,12 @@ wx_status wx_phase_timer_since_start(wx_phase_timer* timer, double seconds[9]);
 
 /* Streams with a scheduling priority, for the overlapped evaluation (wx_*_rhs_overlapped, wx_exchange_fork): the INTERIOR launches
  * fill every CU, and the grouped ncclSend / ncclRecv that should run beside them are a handful of workgroups on the compute stream.
- * REQUIREMENT for overlap at N > 1: `side` (INTERIOR) at the LOWEST priority the device offers, the compute stream at normal or
- * higher - the dispatcher then gives the exchange's workgroups the next free slots instead of queueing them behind INTERIOR's
- * (torch.cuda.Stream offers normal and high only, no low: PanelExchange takes its second stream from here).
+ * MEASURED on MI355X (profiles/r06_overlap_priority_ab.txt, the loopback rehearsal of bench.py with the stamps of
+ * wx_phase_timer_since_start): with both streams at normal priority the exchange enqueued BEHIND the INTERIOR launches completes
+ * 50 us after INTERIOR starts - the dispatcher serves the hardware queues in turn and a workgroup of the fused kernel lives a few
+ * microseconds, so the exchange's workgroups are not starved -, while INTERIOR on a lowest-priority stream runs 23 % slower even
+ * alone on the device.  No priority is required; these entry points let a caller choose one (torch.cuda.Stream offers normal
+ * and high only, no low).
  * priority_class: +1 lowest, 0 normal, -1 highest (mapped onto hipDeviceGetStreamPriorityRange).  Non-blocking streams of the
  * current device; wx_stream_destroy synchronises the stream first. */
 wx_status wx_stream_priority_range(int* least, int* greatest);

@@ -969,7 +969,7 @@ wx_status wx_multi_axpy(double* w, const double* V, size_t ldv, int m, const dou
 
 wx_status wx_krylov_aug_update(double* V, size_t ldv, int j, size_t n, int p, const double* aw, const double* uflip,
                                wx_stream stream) {
-    if (!V || !aw || !uflip) return fail(WX_ERR_INVALID, "wx_krylov_aug_update: null argument");
+    if (!V || (n > 0 && (!aw || !uflip))) return fail(WX_ERR_INVALID, "wx_krylov_aug_update: null argument");   // (n == 0: an idle rank's empty operands)
     if (j < 1 || p < 1 || p > 16 || ldv < n + (size_t)p)
         return fail(WX_ERR_INVALID, "wx_krylov_aug_update: j = %d, p = %d (1..16), row stride %zu, n = %zu", j, p, ldv, n);
     WX_STREAM(st, stream);

@@ -264,12 +264,14 @@ class PanelExchange:
                         or self.lib.wx_exchange_halo_ptr(h, p, e) != self.halo_view(p, e).data_ptr()):
                     raise RuntimeError(f"the library's slot of tile {p}, edge {e} differs from the host mirror's")
         # the second stream of the overlapped evaluation (one per exchange object; the join is an event wait): it carries the
-        # INTERIOR launches, which fill every CU - at the LOWEST priority the device offers, so that the workgroups of the grouped
-        # sends / receives on the compute stream get the next free slots instead of queueing behind them (include/wxhip.h:
-        # wx_stream_create; torch's own streams know normal and high only).  WXHIP_SIDE_PRIORITY=normal: the A/B without.
+        # INTERIOR launches, which fill every CU.  Its priority was MEASURED (profiles/r06_overlap_priority_ab.txt): at normal
+        # priority the grouped sends / receives enqueued behind INTERIOR complete 50 us after INTERIOR's start - the dispatcher
+        # serves the queues in turn, a workgroup of the fused kernel lives a few microseconds -, while on a lowest-priority stream
+        # (include/wxhip.h: wx_stream_create) INTERIOR itself runs 23 % slower with nothing beside it.  Default: normal;
+        # WXHIP_SIDE_PRIORITY=low selects the low-priority stream.
         self.comm_stream, self._side = None, None
         if self.needs_comm:
-            if os.environ.get("WXHIP_SIDE_PRIORITY", "low") == "low":
+            if os.environ.get("WXHIP_SIDE_PRIORITY", "normal") == "low":
                 side = ctypes.c_void_p()
                 with torch.cuda.device(device):
                     _lib.check(self.lib.wx_stream_create(ctypes.byref(side), 1), "wx_stream_create")
