@@ -754,6 +754,25 @@ wx_status wx_multi_dot2(const double* V, size_t ldv, int m, const double* a, con
                         double* workspace, wx_stream stream);
 wx_status wx_pair_update(double* a, double* b, const double* V, size_t ldv, int m, const double* ha, const double* hb,
                          size_t n, double scale_a, double cross, double scale_b, wx_stream stream);
+/* fgmres without a host round trip per Krylov vector (solvers/fgmres.py:16-73, 160-210: the lagged one-synchronisation
+ * Gram-Schmidt).  wx_fgmres_vector = step J of that scheme on rows a = V[J-2], b = V[J-1]: the 2 J products <V[k], a>, <V[k], b>
+ * (all-reduced over `comm` when given), the step's small algebra in a one-wave kernel - Hessenberg column J-2 finished, column
+ * J-1 started, the second-pass corrections T, the lagged products K, all (ld x ld) row-major in DEVICE memory - and the update
+ * of the two rows with the coefficients that kernel left at `coef` (3 ld doubles).  vn[J-2] = the norm of row J-2 (the scale of
+ * the next operator application).  *flag (device int, zeroed by the caller before a pass) becomes J at the first step whose norm
+ * estimate falls under the host algorithm's thresholds (a breakdown, a suspect cancellation, a NaN): that step and the later
+ * ones of the pass leave the rows untouched, and the caller redoes them on the host.  The host reads R once per PASS of
+ * several vectors and finds the iteration the reference would have stopped at from its columns; vectors built past it are
+ * discarded.  workspace: wx_fgmres_workspace(ld) doubles.
+ * wx_euler3d_batch_fgmres_vector: the same with the finite-difference Rosenbrock operator in front (integrators/ros2.py:27-30,
+ * solvers/matvec.py:76-88): row J-1 = A(row J-2 / s) s with s = vn[J-3] read by the kernels from device memory. */
+size_t wx_fgmres_workspace(int rows);
+wx_status wx_fgmres_vector(double* V, size_t ldv, int J, size_t n, double* R, double* T, double* K, int ld, double* coef,
+                           double* vn, int* flag, double* workspace, wx_comm* comm, wx_stream stream);
+wx_status wx_euler3d_batch_fgmres_vector(const wx_euler3d_batch* batch, const double* q, const double* rq, double* V, size_t ldv,
+                                         int J, size_t n, double eps, double half_dt_over_eps, double* R, double* T, double* K,
+                                         int ld, double* coef, double* vn, int* flag, double* workspace, size_t panel_stride,
+                                         wx_stream stream);
 
 #ifdef __cplusplus
 }

@@ -151,6 +151,29 @@ def test_ros2_fgmres_step(setup, ortho):
     assert (err <= 1e-7 * upd).all(), (err / upd)
 
 
+def test_fgmres_device_passes_take_the_host_loop_decisions(setup, monkeypatch):
+    """fgmres with the Gram-Schmidt step on the device and one read-back per pass of several Krylov vectors (wx_fgmres_vector,
+    wx_euler3d_batch_fgmres_vector: the operator's scale read from device memory) against the one-vector-at-a-time loop on the
+    same step: the same iteration count, the same solution, the reference's 151 iterations; vectors built past the end of a
+    cycle are counted."""
+    from wxfactory_amd.integrators import Ros2
+
+    g, rhs, stack = setup
+    dt = float(g["meta/dt_jvp"])
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("WXHIP_FGMRES_VECTOR", mode)
+        ros = Ros2(rhs, tol=1e-9, gmres_restart=30)
+        res[mode] = (ros.step(stack("Q"), dt), ros.solver_info)
+    dev, host = res["1"][1], res["0"][1]
+    assert dev["device_passes"] > 0 and dev["vectors_built"] >= dev["iterations"] - 12 and host["device_passes"] == 0, (dev, host)
+    assert dev["flag"] == 0 and dev["iterations"] == host["iterations"] and abs(dev["iterations"] - 151) <= 2, (dev["iterations"], host["iterations"])
+    assert dev["wasted_vectors"] <= 20 * (1 + dev["iterations"] // 30), dev
+    ax = (0, 2, 3, 4, 5)
+    upd = (res["0"][0] - stack("Q")).abs().amax(dim=ax)
+    assert (((res["1"][0] - res["0"][0]).abs().amax(dim=ax)) <= 1e-8 * upd).all()
+
+
 def test_kiops_and_epi2_step(setup):
     """phi_1(dt J) R through KIOPS with the complex-step JVP, and the EPI2 step built on it
     (the integrator config/dcmip31.ini actually ships with), against the reference's kiops.py/epi.py."""

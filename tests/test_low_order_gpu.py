@@ -141,3 +141,35 @@ def test_whole_sphere_callable_on_low_order_fixtures(name):
         scale = np.maximum(var_max(g.r(p)), o.cancel_scale(want))
         err = var_err(R[i], g.r(p))
         assert (err <= 1e-10 * scale).all(), (name, p, err / scale)
+
+
+def test_ros2_step_at_order_2_with_device_passes(monkeypatch):
+    """config/dcmip31.ini's order (num_solpts 2) on a small sphere of own geometry: the Rosenbrock-2 + fgmres step with the
+    device passes - whose operator is the ONE-KERNEL form here, its shifted state scaled from device memory - against the host
+    loop: same iterations, same solution."""
+    from wxfactory_amd import synthetic
+    from wxfactory_amd.geometry3d import CubedSphere3DTile, metric3d_torch
+    from wxfactory_amd.initial import initial_state
+    from wxfactory_amd.integrators import Ros2
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D
+
+    n, H, V = 2, 6, 3
+    plans, q = {}, []
+    for p in range(6):
+        t = CubedSphere3DTile(n, H, V, p, 10000.0, 31)
+        plans[p] = Euler3DPlan(n, H, V, 31, p, synthetic.dfr_ops(n), metric3d_torch(t, DEV))
+        q.append(torch.from_numpy(initial_state(t)).to(DEV))
+    assert all(pl.one_kernel for pl in plans.values())
+    rhs = RhsEuler3D(plans)
+    Q = torch.stack(q)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("WXHIP_FGMRES_VECTOR", mode)
+        ros = Ros2(rhs, tol=1e-10)
+        res[mode] = (ros.step(Q, 30.0), ros.solver_info)
+    dev, host = res["1"][1], res["0"][1]
+    assert dev["device_passes"] > 0 and host["device_passes"] == 0
+    assert dev["flag"] == 0 and dev["iterations"] == host["iterations"], (dev["iterations"], host["iterations"])
+    ax = (0, 2, 3, 4, 5)
+    upd = (res["0"][0] - Q).abs().amax(dim=ax)
+    assert (((res["1"][0] - res["0"][0]).abs().amax(dim=ax)) <= 1e-7 * upd).all()   # (both solved to 1e-10 of |b|)

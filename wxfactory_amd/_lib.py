@@ -129,6 +129,12 @@ SIGNATURES = {
     "wx_multi_dot2": (c_int, [c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "wx_pair_update": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_size_t, c_double,
                                c_double, c_double, c_void_p]),
+    "wx_fgmres_workspace": (c_size_t, [c_int]),
+    "wx_fgmres_vector": (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wx_euler3d_batch_fgmres_vector": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_size_t, c_double,
+                                               c_double, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_size_t, c_void_p]),
     "wx_expfilter_create": (c_int, [POINTER(c_void_p), c_int, POINTER(c_double)]),
     "wx_expfilter_destroy": (c_int, [c_void_p]),
     "wx_expfilter_uses_matrix_cores": (c_int, [c_void_p, c_int]),

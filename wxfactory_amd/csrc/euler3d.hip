@@ -92,6 +92,7 @@ EulerParams<T> make_params(const wx_euler3d_plan* pl) {
     P.itf_out = nullptr; P.nsend_s = P.nsend_n = P.nsend_w = P.nsend_e = nullptr;
     P.efilter = 0; P.nan_flag = nullptr;
     P.jvp = 0; P.q_re = P.q_tan = nullptr; P.out_tan = nullptr; P.jvp_eps = 0.0; P.jvp_scale = 1.0;
+    P.dscale = nullptr;
     P.split = 0; P.ft = nullptr; P.fv = nullptr; P.hv_s = P.hv_n = P.hv_w = P.hv_e = nullptr;
     P.halo_s = P.halo_n = P.halo_w = P.halo_e = nullptr;
     P.send_s = P.send_n = P.send_w = P.send_e = nullptr;
@@ -797,8 +798,10 @@ wx_status batch_upload(wx_euler3d_batch* b, wx_euler3d_plan* const* plans, void*
 }
 
 template <typename T>
-wx_status batch_extrap(const wx_euler3d_batch* b, const void* q, const double* v, double eps, size_t stride, hipStream_t st) {
+wx_status batch_extrap(const wx_euler3d_batch* b, const void* q, const double* v, double eps, size_t stride, hipStream_t st,
+                       const double* dscale = nullptr) {
     EulerBatchDyn<T> dyn{};
+    dyn.dscale = dscale;
     dyn.stride = stride;
     dyn.stride_re = stride;
     if (v != nullptr && std::is_same<T, dual>::value) {  // dual state (q, eps v) from two real arrays
@@ -832,8 +835,9 @@ wx_status batch_extrap(const wx_euler3d_batch* b, const void* q, const double* v
 template <typename T>
 wx_status batch_rhs(const wx_euler3d_batch* b, const void* q, const double* v, double eps, const void* y, const void* z,
                     void* out, size_t stride, int axpy, double ca, double cb, double cc, double cd, wx_region region,
-                    hipStream_t st) {
+                    hipStream_t st, const double* dscale = nullptr) {
     EulerBatchDyn<T> dyn{};
+    dyn.dscale = dscale;
     dyn.q = static_cast<const T*>(q); dyn.y = static_cast<const T*>(y); dyn.z = static_cast<const T*>(z);
     dyn.rhs = static_cast<T*>(out);
     dyn.stride = stride;
@@ -966,6 +970,31 @@ wx_status wx_euler3d_batch_kiops_vector(const wx_euler3d_batch* b, const double*
     s = wx_euler3d_batch_jvp(b, q, v, eps, aw, scale, panel_stride, WX_REGION_ALL, stream);
     if (s != WX_OK) return s;
     return wx_kiops_finish(V, ldv, j, n, p, iop, aw, uflip, hcol, workspace, stream);
+}
+
+// One Krylov vector of fgmres with the finite-difference Rosenbrock operator (integrators/ros2.py:27-30 + solvers/matvec.py:76-88
+// + solvers/fgmres.py:160-210) from ONE host call and with no host round trip: row J-1 = A(row J-2 / s) s, A v = v - dt/2
+// (R(q + eps v) - R(q)) / eps, s = the lagged norm vn[J-3] read from device memory by the kernels (EulerParams::dscale), then
+// wx_fgmres_vector's products, step and update.  For a rank that owns the whole sphere at launch-bound sizes (the shipped .ini
+// files).  rq = R(q); half_dt_over_eps = dt / (2 eps).
+wx_status wx_euler3d_batch_fgmres_vector(const wx_euler3d_batch* b, const double* q, const double* rq, double* V, size_t ldv, int J,
+                                         size_t n, double eps, double half_dt_over_eps, double* R, double* T, double* K, int ld,
+                                         double* coef, double* vn, int* flag, double* workspace, size_t panel_stride,
+                                         wx_stream stream) {
+    if (!b || !q || !rq || !V || !vn) return fail(WX_ERR_INVALID, "wx_euler3d_batch_fgmres_vector: null argument");
+    if (b->dtype != WX_F64) return fail(WX_ERR_INVALID, "wx_euler3d_batch_fgmres_vector: the batch must be WX_F64");
+    if (J < 3 || n != (size_t)b->count * panel_stride)
+        return fail(WX_ERR_INVALID, "wx_euler3d_batch_fgmres_vector: J = %d, vector length %zu != %d tiles x %zu", J, n, b->count, panel_stride);
+    WX_STREAM(st, stream);
+    const double* z = V + (size_t)(J - 2) * ldv;
+    double* w = V + (size_t)(J - 1) * ldv;
+    const double* s = vn + (J - 3);
+    wx_status st1 = batch_extrap<double>(b, q, z, eps, panel_stride, st, s);
+    if (st1 != WX_OK) return st1;
+    // out = 1 * z + 0 * (q + eps z / s) - c s R(q + eps z / s) + c s R(q)
+    st1 = batch_rhs<double>(b, q, z, eps, z, rq, w, panel_stride, 1, 1.0, 0.0, -half_dt_over_eps, half_dt_over_eps, WX_REGION_ALL, st, s);
+    if (st1 != WX_OK) return st1;
+    return wx_fgmres_vector(V, ldv, J, n, R, T, K, ld, coef, vn, flag, workspace, nullptr, stream);
 }
 
 wx_status wx_euler3d_batch_rhs_axpy2(const wx_euler3d_batch* b, const void* q, const double* v, double eps, const void* y,

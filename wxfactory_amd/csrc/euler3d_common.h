@@ -95,6 +95,10 @@ struct EulerParams {
     pp<T, const double, G> q_re, q_tan;
     pp<T, double, G> out_tan;
     double jvp_eps, jvp_scale;
+    // shifted float64 state with a scale read from DEVICE memory (fgmres' device pass: `A(z / s) * s` of solvers/fgmres.py:172
+    // with s = the lagged norm the Gram-Schmidt kernel left on the device): the state is q + (jvp_eps / *dscale) q_tan and the
+    // store coefficients cc, cd are multiplied by *dscale.  Null: off.
+    const double* dscale;
     // prepared JVP (wx_euler3d_jvp_prepare): the face VALUES of the linearisation state stay in fv (real,
     // [elem][6][5][n^2]) and in the value halos hv_* for a whole Krylov solve; per product only the face TANGENTS are
     // extrapolated (ft, real, same layout; tangent edge messages through send_* / halo_* as REAL arrays)
@@ -266,7 +270,7 @@ __device__ __forceinline__ int xcd_slab_block(int b, int nblocks8) { return (b &
 template <typename T, bool G>
 __device__ __forceinline__ T load_q(const EulerParams<T, G>& P, size_t i) {
     if constexpr (std::is_same<T, double>::value) {
-        if (P.q_tan != nullptr) return P.q[i] + P.jvp_eps * P.q_tan[i];  // (same expression as load_state)
+        if (P.q_tan != nullptr) return P.q[i] + (P.dscale ? P.jvp_eps / *P.dscale : P.jvp_eps) * P.q_tan[i];  // (same expression as load_state)
         return P.q[i];
     } else if constexpr (std::is_same<T, dual>::value) {
         if (P.jvp) return dual(P.q_re[i], P.jvp_eps * P.q_tan[i]);
@@ -284,7 +288,7 @@ __device__ __forceinline__ void load_state(const EulerParams<T, G>& P, size_t o,
         a0 = q[o]; a1 = q[fs + o]; a2 = q[2 * fs + o]; a3 = q[3 * fs + o]; a4 = q[4 * fs + o];
         if (P.q_tan != nullptr) {
             const auto v = P.q_tan;
-            const double e = P.jvp_eps;
+            const double e = P.dscale ? P.jvp_eps / *P.dscale : P.jvp_eps;
             a0 += e * v[o]; a1 += e * v[fs + o]; a2 += e * v[2 * fs + o]; a3 += e * v[3 * fs + o]; a4 += e * v[4 * fs + o];
         }
     } else if constexpr (std::is_same<T, dual>::value) {

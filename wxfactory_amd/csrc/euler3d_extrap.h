@@ -264,6 +264,7 @@ struct EulerBatchDyn {
     size_t stride_re;
     double eps, scale;
     int jvp;
+    const double* dscale;   // EulerParams::dscale (fgmres' device pass), nullable
 };
 
 template <typename T, bool G>
@@ -274,6 +275,7 @@ __device__ __forceinline__ void batch_state(EulerParams<T, G>& P, const EulerBat
     P.q_tan = dyn.q_tan ? dyn.q_tan + offr : (const double*)nullptr;
     P.out_tan = dyn.out_tan ? dyn.out_tan + offr : (double*)nullptr;
     P.jvp = dyn.jvp; P.jvp_eps = dyn.eps; P.jvp_scale = dyn.scale;
+    P.dscale = dyn.dscale;
 }
 
 // The parameters of tile blockIdx.y for a batched launch: the table entry goes to LDS (one 8-byte word per thread), one

@@ -544,15 +544,17 @@ __device__ __forceinline__ void euler_rhs_body(const EulerParams<T, G>& P) {
     T r0 = -inv_sg * acc0, r1 = -inv_sg * acc1, r2 = -inv_sg * acc2, r3 = -inv_sg * accw, r4 = -inv_sg * acc4;
     if (P.advection_only) { r0 = r1 = r2 = r3 = r4 = T(0.0); }
     if (active && P.axpy) {  // fused stage update of an explicit Runge-Kutta scheme (integrators/tvdrk3.py:12-19)
-        r0 = P.cb * q0 + P.cc * r0; r1 = P.cb * q1 + P.cc * r1; r2 = P.cb * q2 + P.cc * r2;
-        r3 = P.cb * q3 + P.cc * r3; r4 = P.cb * q4 + P.cc * r4;
+        const double sdev = P.dscale ? *P.dscale : 1.0;   // (fgmres' device pass: see EulerParams::dscale)
+        const double cc = P.cc * sdev, cd = P.cd * sdev;
+        r0 = P.cb * q0 + cc * r0; r1 = P.cb * q1 + cc * r1; r2 = P.cb * q2 + cc * r2;
+        r3 = P.cb * q3 + cc * r3; r4 = P.cb * q4 + cc * r4;
         if (P.y != nullptr) {
             r0 += P.ca * P.y[o]; r1 += P.ca * P.y[fs + o]; r2 += P.ca * P.y[2 * fs + o];
             r3 += P.ca * P.y[3 * fs + o]; r4 += P.ca * P.y[4 * fs + o];
         }
         if (P.z != nullptr) {
-            r0 += P.cd * P.z[o]; r1 += P.cd * P.z[fs + o]; r2 += P.cd * P.z[2 * fs + o];
-            r3 += P.cd * P.z[3 * fs + o]; r4 += P.cd * P.z[4 * fs + o];
+            r0 += cd * P.z[o]; r1 += cd * P.z[fs + o]; r2 += cd * P.z[2 * fs + o];
+            r3 += cd * P.z[3 * fs + o]; r4 += cd * P.z[4 * fs + o];
         }
     }
     if (PIPE && P.efilter) {

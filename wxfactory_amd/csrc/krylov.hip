@@ -150,7 +150,9 @@ template <int R>
 __global__ __launch_bounds__(256) void pair_update_kernel(double* __restrict__ a, double* __restrict__ b,
                                                           const double* __restrict__ V, size_t ldv, int row0,
                                                           const double* __restrict__ ha, const double* __restrict__ hb,
-                                                          size_t n, int last, double sa, double cross, double sb) {
+                                                          size_t n, int last, double sa, double cross, double sb,
+                                                          const double* __restrict__ dsc) {
+    if (dsc != nullptr) { sa = dsc[0]; cross = dsc[1]; sb = dsc[2]; }   // (the device pass of fgmres: scalings left by the step kernel)
     double ca[R > 0 ? R : 1], cb[R > 0 ? R : 1];
 #pragma unroll
     for (int r = 0; r < R; ++r) { ca[r] = ha[row0 + r]; cb[r] = hb[row0 + r]; }
@@ -416,15 +418,16 @@ __global__ __launch_bounds__(kFinishThreads) void kiops_long_c(double* __restric
 
 template <int R>
 static void launch_dot2(const double* V, size_t ldv, int row0, const double* a, const double* b, size_t n, double* partial,
-                        int m, hipStream_t st) {
-    hipLaunchKernelGGL((multi_dot2_kernel<R>), dim3(dot_blocks(n)), dim3(kDotThreads), 0, st, V, ldv, row0, a, b, n, partial, m);
+                        int m, hipStream_t st, int blocks = 0) {
+    hipLaunchKernelGGL((multi_dot2_kernel<R>), dim3(blocks > 0 ? blocks : dot_blocks(n)), dim3(kDotThreads), 0, st, V, ldv, row0, a, b, n,
+                       partial, m);
 }
 template <int R>
 static void launch_pair(double* a, double* b, const double* V, size_t ldv, int row0, const double* ha, const double* hb,
-                        size_t n, int last, double sa, double cross, double sb, hipStream_t st) {
+                        size_t n, int last, double sa, double cross, double sb, hipStream_t st, const double* dsc = nullptr) {
     const size_t want = (n + 255) / 256;
     const unsigned grid = (unsigned)(want < 8192 ? (want ? want : 1) : 8192);
-    hipLaunchKernelGGL((pair_update_kernel<R>), dim3(grid), dim3(256), 0, st, a, b, V, ldv, row0, ha, hb, n, last, sa, cross, sb);
+    hipLaunchKernelGGL((pair_update_kernel<R>), dim3(grid), dim3(256), 0, st, a, b, V, ldv, row0, ha, hb, n, last, sa, cross, sb, dsc);
 }
 
 template <int R>
@@ -455,15 +458,16 @@ static void dispatch_axpy(int rem, double* w, const double* V, size_t ldv, int r
 }
 template <int R>
 static void dispatch_dot2(int rem, const double* V, size_t ldv, int row0, const double* a, const double* b, size_t n,
-                          double* partial, int m, hipStream_t st) {
-    if (rem == R) launch_dot2<R>(V, ldv, row0, a, b, n, partial, m, st);
-    else if constexpr (R > 1) dispatch_dot2<R - 1>(rem, V, ldv, row0, a, b, n, partial, m, st);
+                          double* partial, int m, hipStream_t st, int blocks = 0) {
+    if (rem == R) launch_dot2<R>(V, ldv, row0, a, b, n, partial, m, st, blocks);
+    else if constexpr (R > 1) dispatch_dot2<R - 1>(rem, V, ldv, row0, a, b, n, partial, m, st, blocks);
 }
 template <int R>
 static void dispatch_pair(int rem, double* a, double* b, const double* V, size_t ldv, int row0, const double* ha,
-                          const double* hb, size_t n, int last, double sa, double cross, double sb, hipStream_t st) {
-    if (rem == R) launch_pair<R>(a, b, V, ldv, row0, ha, hb, n, last, sa, cross, sb, st);
-    else if constexpr (R > 0) dispatch_pair<R - 1>(rem, a, b, V, ldv, row0, ha, hb, n, last, sa, cross, sb, st);
+                          const double* hb, size_t n, int last, double sa, double cross, double sb, hipStream_t st,
+                          const double* dsc = nullptr) {
+    if (rem == R) launch_pair<R>(a, b, V, ldv, row0, ha, hb, n, last, sa, cross, sb, st, dsc);
+    else if constexpr (R > 0) dispatch_pair<R - 1>(rem, a, b, V, ldv, row0, ha, hb, n, last, sa, cross, sb, st, dsc);
 }
 
 
@@ -785,6 +789,160 @@ constexpr size_t kPmexFusedMaxLen = 1u << 21;   // vectors up to this length are
 
 using namespace wx;
 
+// ---- the two vector kernels of a Krylov step at LAUNCH-BOUND lengths (fgmres' device pass at the sizes of the shipped .ini files:
+// 30 k - 100 k components): any number of basis rows in ONE launch each, where the row-batched kernels above take a launch per
+// 16 rows - the time of such a step is the number of its launches.
+//   multi_dot2_small   partial[block][2 J]: <V[r], a>, <V[r], b>, r < J; a thread keeps its (at most kSmallEpt) components of a and
+//                      b in registers and walks the rows; needs n <= gridDim.x * 256 * kSmallEpt
+//   pair_update_small  a -= sum_r ha[r] V[r]; b -= sum_r hb[r] V[r]; a *= dsc[0]; b = (b - dsc[1] a) dsc[2]   (m <= 64 rows)
+constexpr int kSmallEpt = 8;
+constexpr int kSmallMaxLen = 64 * 256 * kSmallEpt;   // with kGsFusedBlocks = 64 workgroups
+
+__global__ __launch_bounds__(256) void multi_dot2_small_kernel(const double* __restrict__ V, size_t ldv, int J,
+                                                               const double* __restrict__ a, const double* __restrict__ b, size_t n,
+                                                               double* __restrict__ partial) {
+    __shared__ double red[4][128];
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double av[kSmallEpt], bv[kSmallEpt];
+#pragma unroll
+    for (int e = 0; e < kSmallEpt; ++e) {
+        const size_t i = i0 + e * stride;
+        av[e] = i < n ? a[i] : 0.0;
+        bv[e] = i < n ? b[i] : 0.0;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = 0; r < J; ++r) {
+        const double* row = V + (size_t)r * ldv;
+        double pa = 0.0, pb = 0.0;
+#pragma unroll
+        for (int e = 0; e < kSmallEpt; ++e) {
+            const size_t i = i0 + e * stride;
+            const double v = i < n ? row[i] : 0.0;
+            pa += v * av[e];
+            pb += v * bv[e];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            pa += __shfl_down(pa, off, 64);
+            pb += __shfl_down(pb, off, 64);
+        }
+        if (lane == 0) { red[wave][r] = pa; red[wave][64 + r] = pb; }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * J) {
+        const int k = threadIdx.x < J ? threadIdx.x : 64 + ((int)threadIdx.x - J);
+        partial[(size_t)blockIdx.x * 2 * J + threadIdx.x] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    }
+}
+
+__global__ __launch_bounds__(256) void pair_update_small_kernel(double* __restrict__ a, double* __restrict__ b,
+                                                                const double* __restrict__ V, size_t ldv, int m,
+                                                                const double* __restrict__ ha, const double* __restrict__ hb, size_t n,
+                                                                const double* __restrict__ dsc) {
+    __shared__ double ca[64], cb[64];
+    if ((int)threadIdx.x < m) { ca[threadIdx.x] = ha[threadIdx.x]; cb[threadIdx.x] = hb[threadIdx.x]; }
+    __syncthreads();
+    const double sa = dsc[0], cross = dsc[1], sb = dsc[2];
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double x = a[i], y = b[i];
+        for (int r = 0; r < m; ++r) {
+            const double v = V[(size_t)r * ldv + i];
+            x -= ca[r] * v;
+            y -= cb[r] * v;
+        }
+        x *= sa;
+        a[i] = x;
+        b[i] = (y - cross * x) * sb;
+    }
+}
+
+// ---- fgmres' lagged one-synchronisation Gram-Schmidt step on the device (solvers/fgmres.py:16-73; the host form:
+// solvers.py _LowSyncGramSchmidt.step, statement for statement).  A Krylov vector then costs no host round trip: the host
+// enqueues several vectors (operator, products, this kernel, the update of the two rows) and reads the Hessenberg columns
+// once per pass - the iteration at which the reference would have stopped is found from those columns, vectors built past it
+// are discarded.  One wave; lane i = row i (rows <= 64).
+//   G: the 2 J products <V[k], a>, <V[k], b> (a = row J-2, b = row J-1);  R, T, K: (ld x ld) row-major, device
+//   coef: ha at 0, hb at ld, (1/norm, cross, 1/norm) at 2 ld;  vn[J-2] = the norm of row J-2 (the operator's next scale)
+//   flag: 0, or the first step whose norm estimate fell below the host form's thresholds (_SUSPECT, _BREAKDOWN) - that step and
+//   every later one of the pass leave the rows untouched (zero coefficients, unit scalings) and the host redoes them.
+constexpr double kGsSuspect = 1e-12, kGsBreakdown = 1e-14;
+constexpr int kGsFusedBlocks = 64;            // workgroups of the products where the step kernel sums their partials itself
+constexpr int kGsFusedMaxLen = 2 * 1024 * 1024;   // ... for vectors up to this length (beyond: 2048 blocks and the finish launch)
+
+__global__ __launch_bounds__(256) void fgmres_gs_step_kernel(const double* __restrict__ G, const double* __restrict__ partial,
+                                                             int blocks, int J, double* __restrict__ R, double* __restrict__ T,
+                                                             double* __restrict__ K, int ld, double* __restrict__ coef,
+                                                             double* __restrict__ vn, int* __restrict__ flag) {
+    const int i = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m2 = J - 2;
+    double ga = 0.0, gb = 0.0;
+    if (partial != nullptr) {
+        // the products' partial sums (multi_dot2_kernel: [block][2 J]) summed here, four waves over the blocks: no finish launch
+        __shared__ double red[4][128];
+        double xa = 0.0, xb = 0.0;
+        if (i < J)
+            for (int blk = wave; blk < blocks; blk += 4) {
+                xa += partial[(size_t)blk * 2 * J + i];
+                xb += partial[(size_t)blk * 2 * J + J + i];
+            }
+        red[wave][i] = xa;
+        red[wave][64 + i] = xb;
+        __syncthreads();
+        if (wave != 0) return;
+        ga = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+        gb = (red[0][64 + i] + red[1][64 + i]) + (red[2][64 + i] + red[3][64 + i]);
+    } else {
+        if (wave != 0) return;
+        ga = i < J ? G[i] : 0.0;
+        gb = i < J ? G[J + i] : 0.0;
+    }
+    const bool dead = *flag != 0;
+    const double s = i < m2 ? ga : 0.0;
+    double ss = s * s, sR = s * gb;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        ss += __shfl_xor(ss, off, 64);
+        sR += __shfl_xor(sR, off, 64);
+    }
+    const double gaa = __shfl(ga, m2, 64), gbb = __shfl(gb, m2, 64);   // <a, a>, <a, b>
+    const double d = gaa - ss;
+    const bool bad = dead || !(d == d) || d <= kGsSuspect * gaa;        // (suspect, breakdown, NaN: the host form's branches)
+    if (bad) {
+        if (i == 0 && !dead) *flag = J;
+        if (i < m2) { coef[i] = 0.0; coef[ld + i] = 0.0; }
+        if (i == 0) { coef[2 * ld] = 1.0; coef[2 * ld + 1] = 0.0; coef[2 * ld + 2] = 1.0; vn[m2] = 1.0; }
+        return;
+    }
+    const double norm = sqrt(d);
+    const double cross = (gbb - sR) / norm;
+    const double colJ1 = i == m2 ? cross : gb;                          // column J-1, rows 0 .. J-2
+    if (i < J - 1) R[i * ld + J - 1] = colJ1;
+    if (i == 0) { R[m2 * ld + m2] = norm; vn[m2] = norm; coef[2 * ld] = 1.0 / norm; coef[2 * ld + 1] = cross; coef[2 * ld + 2] = 1.0 / norm; }
+    if (i < m2) { T[i * ld + m2] = s / norm; coef[i] = s; coef[ld + i] = gb; }
+    if (m2 > 0) {
+        // L r3 = s, L = I + strict lower part of T[:m2, :m2]^T: forward substitution, column by column
+        double acc = s;
+        for (int k = 0; k < m2; ++k) {
+            const double rk = __shfl(acc, k, 64);
+            if (i > k && i < m2) acc -= T[k * ld + i] * rk;
+        }
+        // column J-2 finished (the lagged correction); kept in a register for the product below: rows < J-2, then the norm
+        const double colJ2 = i < m2 ? K[i * ld + (J - 3)] + acc : (i == m2 ? norm : 0.0);
+        if (i < m2) R[i * ld + m2] = colJ2;
+        // K[:J-1, J-2] = (R[:J-1, J-1] - R[:J-1, 1:J-1] @ r3) / norm   (columns 1 .. J-3 from memory, column J-2 from the register)
+        double dot = 0.0;
+        for (int c = 0; c < m2; ++c) {
+            const double rc = __shfl(acc, c, 64);
+            if (i < J - 1) dot += (c == m2 - 1 ? colJ2 : R[i * ld + 1 + c]) * rc;
+        }
+        if (i < J - 1) K[i * ld + m2] = (colJ1 - dot) / norm;
+    } else if (i == 0) {
+        K[0] = cross / norm;
+    }
+}
+
 extern "C" {
 
 size_t wx_multi_dot_workspace(int m) { return (size_t)kDotBlocks * (m > 0 ? m : 1); }   // (wx_multi_dot2: pass 2 m)
@@ -946,6 +1104,66 @@ wx_status wx_pair_update(double* a, double* b, const double* V, size_t ldv, int 
     for (; r + kRowsPerPass2 < m; r += kRowsPerPass2)   // (strictly less: the last batch carries the scalings)
         launch_pair<kRowsPerPass2>(a, b, V, ldv, r, ha, hb, n, 0, 1.0, 0.0, 1.0, st);
     dispatch_pair<kRowsPerPass2>(m - r, a, b, V, ldv, r, ha, hb, n, 1, scale_a, cross, scale_b, st);
+    WX_HIP_TRY(hipGetLastError());
+    return WX_OK;
+}
+
+size_t wx_fgmres_workspace(int rows) {   // products' partial sums + the 2 rows products themselves
+    const int r = rows > 0 ? rows : 1;
+    return wx_multi_dot_workspace(2 * r) + 2 * (size_t)r;
+}
+
+// One Krylov vector of fgmres' low-synchronisation Gram-Schmidt (step J: rows a = V[J-2], b = V[J-1]) without a host round trip:
+// the 2 J products, their reduction over the ranks (comm nullable), the step's small algebra (fgmres_gs_step_kernel), the update
+// of the two rows with the coefficients that kernel left on the device.
+wx_status wx_fgmres_vector(double* V, size_t ldv, int J, size_t n, double* R, double* T, double* K, int ld, double* coef,
+                           double* vn, int* flag, double* workspace, wx_comm* comm, wx_stream stream) {
+    if (!V || !R || !T || !K || !coef || !vn || !flag || !workspace) return fail(WX_ERR_INVALID, "wx_fgmres_vector: null argument");
+    if (J < 2 || J > 64 || J > ld || ldv < n) return fail(WX_ERR_INVALID, "wx_fgmres_vector: J = %d (2..64, <= ld = %d), row stride %zu, n = %zu", J, ld, ldv, n);
+    WX_STREAM(st, stream);
+    double* a = V + (size_t)(J - 2) * ldv;
+    double* b = V + (size_t)(J - 1) * ldv;
+    double* G = workspace + wx_multi_dot_workspace(2 * ld);
+    if (comm) {
+        wx_status s = wx_multi_dot2(V, ldv, J, a, b, n, G, workspace, stream);
+        if (s != WX_OK) return s;
+        s = wx_comm_allreduce(comm, G, (size_t)(2 * J), WX_REDUCE_SUM, stream);
+        if (s != WX_OK) return s;
+        hipLaunchKernelGGL(fgmres_gs_step_kernel, dim3(1), dim3(256), 0, st, G, (const double*)nullptr, 0, J, R, T, K, ld, coef, vn, flag);
+    } else if (n <= (size_t)kSmallMaxLen && J <= 64) {
+        // one rank, launch-bound lengths: the products of ALL rows in one launch, their partial sums summed by the step kernel, the
+        // update of both rows over ALL rows in one launch: three launches per Krylov vector beside the operator's
+        const int want = dot_blocks(n), blocks = want < kGsFusedBlocks ? want : kGsFusedBlocks;
+        hipLaunchKernelGGL(multi_dot2_small_kernel, dim3(blocks), dim3(256), 0, st, V, ldv, J, a, b, n, workspace);
+        hipLaunchKernelGGL(fgmres_gs_step_kernel, dim3(1), dim3(256), 0, st, (const double*)nullptr, workspace, blocks, J, R, T, K, ld,
+                           coef, vn, flag);
+        if (n > 0) {
+            const size_t wantp = (n + 255) / 256;
+            hipLaunchKernelGGL(pair_update_small_kernel, dim3((unsigned)(wantp ? wantp : 1)), dim3(256), 0, st, a, b, V, ldv, J - 2, coef,
+                               coef + ld, n, coef + 2 * ld);
+        }
+        WX_HIP_TRY(hipGetLastError());
+        return WX_OK;
+    } else if (n <= (size_t)kGsFusedMaxLen) {
+        // one rank, launch-bound lengths: the products over at most kGsFusedBlocks workgroups, their partial sums summed by the
+        // step kernel itself (four waves over <= 64 blocks: a dozen loads per lane) - one launch less per Krylov vector
+        const int want = dot_blocks(n), blocks = want < kGsFusedBlocks ? want : kGsFusedBlocks;
+        for (int r = 0; r < J; r += kRowsPerPass2)
+            dispatch_dot2<kRowsPerPass2>(J - r < kRowsPerPass2 ? J - r : kRowsPerPass2, V, ldv, r, a, b, n, workspace, J, st, blocks);
+        hipLaunchKernelGGL(fgmres_gs_step_kernel, dim3(1), dim3(256), 0, st, (const double*)nullptr, workspace, blocks, J, R, T, K, ld,
+                           coef, vn, flag);
+    } else {
+        const wx_status s = wx_multi_dot2(V, ldv, J, a, b, n, G, workspace, stream);
+        if (s != WX_OK) return s;
+        hipLaunchKernelGGL(fgmres_gs_step_kernel, dim3(1), dim3(256), 0, st, G, (const double*)nullptr, 0, J, R, T, K, ld, coef, vn, flag);
+    }
+    const int m = J - 2;
+    if (n > 0) {
+        int r = 0;
+        for (; r + kRowsPerPass2 < m; r += kRowsPerPass2)   // (strictly less: the last batch carries the scalings)
+            launch_pair<kRowsPerPass2>(a, b, V, ldv, r, coef, coef + ld, n, 0, 1.0, 0.0, 1.0, st);
+        dispatch_pair<kRowsPerPass2>(m - r, a, b, V, ldv, r, coef, coef + ld, n, 1, 1.0, 0.0, 1.0, st, coef + 2 * ld);
+    }
     WX_HIP_TRY(hipGetLastError());
     return WX_OK;
 }

@@ -77,7 +77,7 @@ class Ros2:
             A, b, x0=Q_flat, tol=self.tol, restart=self.gmres_restart, maxiter=20000 // self.gmres_restart,
             verbose=self.verbose, ortho=self.ortho, group=self.group)
         self.solver_info = dict(flag=flag, time=time() - t0, iterations=num_iter, residuals=residuals,
-                                rel_residual=norm_r / norm_b)
+                                rel_residual=norm_r / norm_b, **(getattr(fgmres, "last_stats", None) or {}))
         self.failure_flag = flag
         return Qnew.reshape(Q.shape)
 

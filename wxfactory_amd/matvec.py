@@ -157,6 +157,10 @@ class MatvecOpRat(MatvecOp):
         super().__init__(lambda vec: matvec_rat(vec, dt, Q, rhs_vec, rhs_handle), Q.dtype, Q.shape)
         # A(vec / s) * s without passes over the vector for the scalings (used by fgmres' lagged normalisation)
         self.scaled = lambda vec, s, out=None: matvec_rat(vec, dt, Q, rhs_vec, rhs_handle, scale=s, out=out)
+        # ... and a whole Krylov vector of fgmres - this operator applied with the scale read from device memory, the products, the
+        # Gram-Schmidt step, the update of the rows - from one host call with no host round trip (RhsEuler3D.fgmres_vector_fn)
+        fn = getattr(rhs_handle, "fgmres_vector_fn", None)
+        self.fgmres_vector = fn(Q, rhs_vec, dt, EPS_FD) if fn is not None and _can_shift(rhs_handle, Q) else None
 
 
 class MatvecOpBasic(MatvecOp):

@@ -449,6 +449,15 @@ class Euler3DBatch:
         check(self.lib.wx_euler3d_batch_jvp(self._h, q.data_ptr(), v.data_ptr(), eps, out.data_ptr(), scale, self.stride,
                                             region, st), "wx_euler3d_batch_jvp")
 
+    def fgmres_vector(self, q, rq, V, J: int, n: int, eps: float, half_dt_over_eps: float, R, T, K, ld: int, coef, vn, flag, work):
+        """float64 batches on a rank that owns the whole sphere: Krylov vector of fgmres (step J of the lagged Gram-Schmidt) with
+        the finite-difference Rosenbrock operator in front, one host call, no host round trip (wx_euler3d_batch_fgmres_vector)."""
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.wx_euler3d_batch_fgmres_vector(self._h, q.data_ptr(), rq.data_ptr(), V.data_ptr(), V.stride(0), J, n, eps,
+                                                      half_dt_over_eps, R.data_ptr(), T.data_ptr(), K.data_ptr(), ld,
+                                                      coef.data_ptr(), vn.data_ptr(), flag.data_ptr(), work.data_ptr(), self.stride,
+                                                      st), "wx_euler3d_batch_fgmres_vector")
+
     def kiops_vector(self, q, V, j: int, n: int, p: int, iop: int, eps: float, scale: float, uflip, hcol, aw, work):
         """dual batches on a rank that owns the whole sphere: Krylov vector j of KIOPS from one host call
         (wx_euler3d_batch_kiops_vector)."""
@@ -697,6 +706,28 @@ class RhsEuler3D(PanelRhs):
             bt.pmex_vector(Q, V, j, n, p, eps, scale, uflip, LT, Linv, tol, hcol_ptr, own_ptr, aw, work, mmax)
 
         build.pmex = build_pmex
+        return build
+
+    def fgmres_vector_fn(self, Q: torch.Tensor, Rq: torch.Tensor, dt: float, eps: float):
+        """A callable (V, J, n, R, T, K, ld, coef, vn, flag, work) that builds a Krylov vector of fgmres for the finite-difference
+        Rosenbrock operator v - dt/2 (R(Q + eps v) - R(Q)) / eps (solvers/matvec.py:76-88) from one host call and with no host
+        round trip, or None when that does not apply (several ranks, large tiles, another dtype)."""
+        if not (self._small_tiles() and self.world == 1 and isinstance(Q, torch.Tensor) and Q.is_cuda and Q.is_contiguous()
+                and Q.dtype == torch.float64 and Rq.is_contiguous() and getattr(self, "fused_shift", True)
+                and os.environ.get("WXHIP_FGMRES_VECTOR", "1") != "0"):
+            return None
+        plans, ex = self.plans_for(torch.float64), self.exchange_for(torch.float64)
+        if ex.needs_comm:
+            return None
+        bt = self._batch_for(torch.float64, plans, ex)
+        Rq = Rq.reshape(Q.shape)
+        c = 0.5 * dt / eps
+
+        def build(V, J, n, R, T, K, ld, coef, vn, flag, work):
+            for pl in plans.values():
+                pl.faces_epoch += 1
+            bt.fgmres_vector(Q, Rq, V, J, n, eps, c, R, T, K, ld, coef, vn, flag, work)
+
         return build
 
     def jvp_fuses_store(self, Q) -> bool:

@@ -378,6 +378,25 @@ def _fgmres_low_sync(A, b, x0, tol, restart, maxiter, preconditioner, verbose, g
     Z = torch.empty((restart + 1, n), dtype=b.dtype, device=b.device) if preconditioner is not None else None
     basis = _Basis(V)
     scaled = getattr(A, "scaled", None)
+    # Device passes (include/wxhip.h: wx_fgmres_vector): where the operator offers a whole Krylov vector from one host call
+    # (A.fgmres_vector: the launch-bound sizes of the shipped .ini files on one GPU) the Gram-Schmidt step runs on the device
+    # and the host reads the Hessenberg columns once per PASS of several vectors.  The rotations, the residual test and the
+    # solution are formed from those columns exactly as below, column by column: the iterates and the iteration count are
+    # those of the one-vector-at-a-time loop (to the rounding of the step's small algebra); vectors built past the iteration
+    # that ends a cycle are discarded (`wasted`).
+    vector = getattr(A, "fgmres_vector", None) if (Z is None and basis.gpu and _reduce.world_size(group) == 1) else None
+    dev = None
+    if vector is not None:
+        rows = restart + 2
+        # R, T, K, the norms and the flag in ONE buffer: a pass ends with one copy to the host (the flag: an int32 in the last slot)
+        state = torch.zeros(3 * rows * rows + rows + 1, dtype=torch.float64, device=b.device)
+        mats = state[: 3 * rows * rows].view(3, rows, rows)
+        dev = dict(state=state, R=mats[0], T=mats[1], K=mats[2], vn=state[3 * rows * rows: 3 * rows * rows + rows],
+                   flag=state[3 * rows * rows + rows:].view(torch.int32)[:1], coef=torch.zeros(3 * rows, dtype=torch.float64, device=b.device),
+                   work=torch.empty(int(basis.lib.wx_fgmres_workspace(rows)), dtype=torch.float64, device=b.device),
+                   host=torch.empty(3 * rows * rows + rows + 1, dtype=torch.float64).pin_memory(), rows=rows)
+    stats = fgmres.last_stats = {"device_passes": 0, "vectors_built": 0, "wasted_vectors": 0, "host_redone_steps": 0}
+    chunk = max(1, int(os.environ.get("WXHIP_FGMRES_CHUNK", "20")))
     for _outer in range(maxiter):
         gs = _LowSyncGramSchmidt(basis, restart + 2, group)
         Hm = [[0.0] * (restart + 2) for _ in range(restart)]   # Hm[j][i] = h_{i,j} after the rotations
@@ -392,21 +411,60 @@ def _fgmres_low_sync(A, b, x0, tol, restart, maxiter, preconditioner, verbose, g
             V[1] = A(V[0])
         v_norm = gs.step(2)
         k = 0
+        ahead = 0          # Krylov steps J = j + 3 already done on the device: columns up to `ahead` are in gs.R
+        on_device = dev is not None and v_norm != 0.0
+        if on_device:
+            hv, rr = dev["host"].numpy(), dev["rows"]
+            hm = hv[: 3 * rr * rr].reshape(3, rr, rr)
+            hm[0], hm[1], hm[2] = gs.R, gs.T, gs.K
+            hv[3 * rr * rr:] = 0.0
+            hv[3 * rr * rr] = v_norm
+            dev["state"].copy_(dev["host"], non_blocking=True)
+        rate = None
         for j in range(restart):
             niter += 1
-            zj = preconditioner(V[j + 1]) if Z is not None else V[j + 1]
-            if Z is not None:
-                Z[j + 1] = zj
-            if scaled is not None:
-                w = scaled(zj, v_norm, out=V[j + 2])   # A(zj / v_norm) * v_norm, scalings folded into the kernels,
-                if w.data_ptr() != V[j + 2].data_ptr():  # written straight into the basis row when the operator can
-                    V[j + 2] = w
-            else:
-                w = A(zj / v_norm)
-                torch.mul(w, v_norm, out=V[j + 2])
-            v_norm = gs.step(j + 3)
-            if Z is not None and v_norm != 0.0:
-                Z[j + 1] /= v_norm
+            if on_device:
+                if j >= ahead:
+                    # how many vectors to build before the next read-back: a chunk, or what the residual's decay says is left
+                    want = chunk
+                    if rate is not None and 0.0 < rate < 1.0 and abs(g[j]) > tol_abs:
+                        want = max(1, min(chunk, int(math.ceil(math.log(tol_abs / abs(g[j])) / math.log(rate)))))
+                    upto = min(restart, j + want)
+                    for jj in range(j, upto):
+                        vector(V, jj + 3, n, dev["R"], dev["T"], dev["K"], restart + 2, dev["coef"], dev["vn"], dev["flag"], dev["work"])
+                    stats["device_passes"] += 1
+                    stats["vectors_built"] += upto - j
+                    dev["host"].copy_(dev["state"], non_blocking=True)
+                    torch.cuda.current_stream(b.device).synchronize()          # the pass's one synchronisation
+                    hv, rr = dev["host"].numpy(), dev["rows"]
+                    bad = int(dev["host"][3 * rr * rr + rr:].view(torch.int32)[0])
+                    good_upto = upto if bad == 0 else bad - 3    # steps J < bad are sound
+                    if good_upto > j:
+                        hm = hv[: 3 * rr * rr].reshape(3, rr, rr)
+                        gs.R[:, :], gs.T[:, :], gs.K[:, :] = hm[0], hm[1], hm[2]
+                        vns = hv[3 * rr * rr: 3 * rr * rr + rr].copy()
+                    ahead = good_upto
+                    if bad != 0:
+                        on_device = False     # a breakdown / suspect cancellation at step `bad`: the host's branches take over
+                        stats["wasted_vectors"] += upto - good_upto
+                if j < ahead:
+                    v_norm = float(vns[j + 1])
+            if not (j < ahead):
+                if dev is not None and not on_device:
+                    stats["host_redone_steps"] += 1
+                zj = preconditioner(V[j + 1]) if Z is not None else V[j + 1]
+                if Z is not None:
+                    Z[j + 1] = zj
+                if scaled is not None:
+                    w = scaled(zj, v_norm, out=V[j + 2])   # A(zj / v_norm) * v_norm, scalings folded into the kernels,
+                    if w.data_ptr() != V[j + 2].data_ptr():  # written straight into the basis row when the operator can
+                        V[j + 2] = w
+                else:
+                    w = A(zj / v_norm)
+                    torch.mul(w, v_norm, out=V[j + 2])
+                v_norm = gs.step(j + 3)
+                if Z is not None and v_norm != 0.0:
+                    Z[j + 1] /= v_norm
             hj = gs.R[: j + 2, j + 1].tolist()
             for i in range(j):  # previous rotations
                 t = cs[i] * hj[i] + sn[i] * hj[i + 1]
@@ -422,11 +480,15 @@ def _fgmres_low_sync(A, b, x0, tol, restart, maxiter, preconditioner, verbose, g
             sn.append(s_)
             Hm[j][: j + 2] = hj
             k = j + 1
+            if g[j] != 0.0 and abs(g[j + 1]) > 0.0:
+                rate = abs(g[j + 1]) / abs(g[j]) if j == 0 or rate is None else 0.5 * (rate + abs(g[j + 1]) / abs(g[j]))
             if j < restart - 1 or v_norm == 0.0:
                 norm_r = abs(g[j + 1])
                 residuals.append((norm_r / norm_b, time() - t0, 0.0))
                 if norm_r < tol_abs or norm_r != norm_r or v_norm == 0.0:
                     break   # converged, NaN, or breakdown (row j+1 vanished: h_{j+1,j} = 0, the least-squares residual is exact)
+        if ahead > k:
+            stats["wasted_vectors"] += ahead - k
         y = [0.0] * k
         for i in range(k - 1, -1, -1):
             acc = g[i]
