@@ -31,7 +31,7 @@ def kernel_source_hash():
     return h.hexdigest()
 
 
-PMC_SUMMARIES = {384.0: "r05_pmc_full_summary.json", 312.0: "r05_pmc_rotzero_summary.json"}
+PMC_SUMMARIES = {384.0: "r06_pmc_full_summary.json", 312.0: "r06_pmc_rotzero_summary.json"}
 
 
 def pmc_traffic(region, n, H, V, bpp=ALGO_BYTES_PER_POINT):
@@ -64,7 +64,8 @@ def pmc_traffic(region, n, H, V, bpp=ALGO_BYTES_PER_POINT):
 
 
 FP64_MFMA_PEAK_TFLOPS = 78.6    # SURVEY 8d; = 512 flop per 16 issue cycles per SIMD (tools/mfma_f64_probe.hip) x 1024 SIMDs x 2.4 GHz
-SQ_COUNTERS = "r05_v4_k2_sq_counters.json"
+SQ_COUNTERS = "r06_v1_k2_sq_counters.json"   # (falls back to round 5's pass of the same kernel until this round's is installed)
+SQ_COUNTERS_FALLBACK = "r05_v4_k2_sq_counters.json"
 
 
 def mfma_block(plans, n, launch_s, elements):
@@ -85,10 +86,11 @@ def mfma_block(plans, n, launch_s, elements):
            "frac": round(insts * 512 / launch_s / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
            "note": "the kernel is bound by HBM (roofline.bound): the contractions are 2.6 flop per byte, the matrix pipe is mostly idle by design"}
     try:
-        c = json.load(open(os.path.join(ROOT, "profiles", SQ_COUNTERS)))["wx::euler_rhs_kernel<8, double, false>"]
+        name = SQ_COUNTERS if os.path.exists(os.path.join(ROOT, "profiles", SQ_COUNTERS)) else SQ_COUNTERS_FALLBACK
+        c = json.load(open(os.path.join(ROOT, "profiles", name)))["wx::euler_rhs_kernel<8, double, false>"]
         # GRBM_GUI_ACTIVE is summed over the 8 XCDs; busy cycles over all 1024 SIMDs
         simd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
-        blk["counters"] = {"profile": "profiles/" + SQ_COUNTERS, "SQ_INSTS_MFMA_per_launch": c["SQ_INSTS_MFMA"],
+        blk["counters"] = {"profile": "profiles/" + name, "SQ_INSTS_MFMA_per_launch": c["SQ_INSTS_MFMA"],
                            "SQ_VALU_MFMA_BUSY_CYCLES": c["SQ_VALU_MFMA_BUSY_CYCLES"],
                            "mfma_util": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles, 4),
                            "vector_instructions_per_launch": c["SQ_INSTS_VALU"],

@@ -35,7 +35,7 @@ if __name__ == "__main__":
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
-    from bench import kernel_source_hash  # the hash bench.py checks before it quotes these bytes
+    from benchlib.roofline import kernel_source_hash  # the hash bench.py checks before it quotes these bytes
 
     try:
         commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
