@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""End-to-end run of a DCMIP case on one GPU from nothing but its parameters (development tool / demo):
+"""End-to-end run of a DCMIP case on one GPU from nothing but its parameters (development tool / demo; OUTSIDE the coverage
+contract of SURVEY.md section 8 - a driver is out of scope, this is the smallest one that lets the kernels be watched on a real case):
 geometry3d -> metric (+ mountain, sponge) -> initial.py state -> SSP-RK3 (pipelined stages) + exponential filter +
 NaN flag, with conservation diagnostics.  Mirrors what `Simulation` does for config/dcmip31.ini / dcmip21_rk3.ini
 minus configuration parsing and output.

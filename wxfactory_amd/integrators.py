@@ -213,7 +213,8 @@ class Epi:
 
 
 class EpiStiff(Epi):
-    """Stiffness-resilient EPI of order >= 2 (integrators/epi_stiff.py:14-132; `time_integrator = epi_stiff<order>`,
+    """(OUTSIDE the coverage contract, SURVEY.md section 8 / section 2 #14: config/dcmip20.ini is not a BASELINE configuration; kept because it
+    exercises the fused kernels' second code path through the exponential solvers, no effort goes here.)  Stiffness-resilient EPI of order >= 2 (integrators/epi_stiff.py:14-132; `time_integrator = epi_stiff<order>`,
     config/dcmip20.ini): the remainders of the order - 2 previous states enter from phi_3 on, with the weights of
     integrators/integrator.py:135-146 for the nodes 1, 2, ..., order - 2.  Start-up by EPI2 steps; simulation.py:336-340
     builds it with init_substeps = 10."""
