@@ -233,6 +233,11 @@ int wx_euler3d_uses_matrix_cores(const wx_euler3d_plan* plan, wx_kernel kernel);
  * plan takes this form (0 otherwise, < 0 on a null plan); wx_euler3d_plan_set_one_kernel(plan, 0 / 1) switches it at setup
  * time (0 = the two-kernel form; 1 is refused for plans the form does not serve).  The environment variable
  * WXHIP_DIRECT=0, read when a plan is created, makes 0 the default. */
+/* The one-kernel form takes its float64 logarithms (log rho, log rho theta of rhs_dfr.py:50-71) from a 38-instruction form
+ * (x = 2^k m; s = (m - 1) / (m + 1); the classical degree-7 series in s^2; error < 1 ulp for positive normal arguments) instead of
+ * the device library's 84-instruction one: its face stage is bound by its instruction count.  wx_lean_log applies that function to
+ * an array (device pointers): the accuracy claim is a test (tests/test_low_order_gpu.py). */
+wx_status wx_lean_log(const double* x, double* y, size_t n, wx_stream stream);
 int wx_euler3d_plan_one_kernel(const wx_euler3d_plan* plan);
 wx_status wx_euler3d_plan_set_one_kernel(wx_euler3d_plan* plan, int on);
 
@@ -308,6 +313,13 @@ wx_status wx_euler3d_stage(wx_euler3d_plan* plan, const void* q, const void* con
 typedef struct wx_euler3d_batch wx_euler3d_batch;
 wx_status wx_euler3d_batch_create(wx_euler3d_batch** out, wx_euler3d_plan* const* plans, int count, void* const (*send)[4],
                                   const void* const (*halo)[4]);
+/* 1 when the batch evaluates in the one-kernel form AND every tile's four neighbours are tiles of this batch (one rank owns the
+ * sphere: each halo line handed to wx_euler3d_batch_create IS another tile's send line): wx_euler3d_batch_extrap_pack then launches
+ * nothing - the evaluation forms a tile-edge state from the neighbour tile's nodal values itself, the sender's extrapolation,
+ * rotation and flip (process_topology.py:269-386) - and R(Q) of the whole sphere is ONE launch.  Taken by default for spheres of
+ * at most 262 144 points (launch-bound: the sizes of the shipped .ini files); WXHIP_BRICK_PULLS=1 / 0 (read at batch creation)
+ * forces it on / off. */
+int wx_euler3d_batch_pulls(const wx_euler3d_batch* batch);
 wx_status wx_euler3d_batch_destroy(wx_euler3d_batch* batch);
 wx_status wx_euler3d_batch_extrap_pack(const wx_euler3d_batch* batch, const void* q, const double* v, double eps,
                                        size_t panel_stride, wx_stream stream);

@@ -67,9 +67,10 @@ def test_one_kernel_form_equals_the_two_kernel_form(n, H, V):
     out2 = torch.full_like(q, float("nan"))
     plan.rhs(q, hp, out2)
     torch.cuda.synchronize()
-    assert torch.equal(send1, send2), "the pack kernel's messages are the extrapolation kernel's, bit for bit"
+    # (the one-kernel form and its pack kernel take their logarithms from the lean form of wx_math.h: an ulp apart from the library's)
+    assert _rel(send1, send2) <= 4e-15, _rel(send1, send2)
     assert torch.isfinite(out1).all()
-    assert _rel(out1, out2) <= 1e-13, _rel(out1, out2)
+    assert _rel(out1, out2) <= 1e-12, _rel(out1, out2)
     # fused update and shifted state
     y, v = torch.randn_like(q), q * 1e-3 * torch.rand_like(q)
     a2 = torch.empty_like(q)
@@ -80,7 +81,7 @@ def test_one_kernel_form_equals_the_two_kernel_form(n, H, V):
     plan.shifted_extrap_pack(q, v, 1e-4, None)
     plan.shifted_rhs_axpy(q, v, 1e-4, hp, y, a1, 0.5, 0.25, -2.0)
     torch.cuda.synchronize()
-    assert _rel(a1, a2) <= 1e-13
+    assert _rel(a1, a2) <= 1e-12
     plan.close()
 
 
@@ -112,7 +113,7 @@ def test_stage_update_and_next_messages(n, filtered):
         torch.cuda.synchronize()
         res[form] = (out, ns, int(flag.item()))
     assert res[True][2] == 0 and res[False][2] == 0
-    assert _rel(res[True][0], res[False][0]) <= 1e-13
+    assert _rel(res[True][0], res[False][0]) <= 1e-12
     assert _rel(res[True][1], res[False][1]) <= 1e-12
     plan.close()
 
@@ -173,3 +174,75 @@ def test_ros2_step_at_order_2_with_device_passes(monkeypatch):
     ax = (0, 2, 3, 4, 5)
     upd = (res["0"][0] - Q).abs().amax(dim=ax)
     assert (((res["1"][0] - res["0"][0]).abs().amax(dim=ax)) <= 1e-7 * upd).all()   # (both solved to 1e-10 of |b|)
+
+
+def test_the_lean_logarithm_is_good_to_an_ulp():
+    """wx_math.h: lean_log (the logarithm of the one-kernel form) against numpy's over the range the path feeds it - densities,
+    rho theta, 1e-8 ... 1e9: within 1 ulp of the correctly rounded value wherever |log x| is not tiny, 2e-16 absolute near 1."""
+    from wxfactory_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    x = np.concatenate([10.0 ** rng.uniform(-8, 9, 400_000), 1.0 + rng.uniform(-0.3, 0.45, 100_000), np.array([1.0, 2.0, 0.5, 1e5, 287.05])])
+    xd = torch.from_numpy(x).to(DEV)
+    yd = torch.empty_like(xd)
+    _lib.check(lib.wx_lean_log(xd.data_ptr(), yd.data_ptr(), x.size, torch.cuda.current_stream().cuda_stream), "wx_lean_log")
+    torch.cuda.synchronize()
+    y = yd.cpu().numpy()
+    ref = np.log(x.astype(np.longdouble))
+    err = np.abs(y.astype(np.longdouble) - ref)
+    ulp = np.spacing(np.abs(np.asarray(ref, dtype=np.float64)))
+    assert float(np.max(err / np.maximum(ulp, 2.2e-16))) <= 1.0, float(np.max(err / np.maximum(ulp, 2.2e-16)))
+    assert y[-5] == 0.0
+
+
+def test_tile_edge_states_pulled_from_the_neighbour_tiles(monkeypatch):
+    """One rank owns the sphere: the one-kernel form forms the tile-edge states itself from the neighbour tiles' nodal values
+    (the sender's extrapolation, rotation, flip) - no pack launch.  On the reference's all-panel fixture (order 3, the form
+    selected by hand) against the reference's R of every panel - every panel edge's rotation and flip - and against the same
+    evaluation through packed edge messages, plain and on the shifted state of the finite-difference products; and at order 2 (the
+    default form) on a sphere of own geometry."""
+    from tests.gpu_util import make_plan, to_dev
+    from wxfactory_amd import synthetic
+    from wxfactory_amd.geometry3d import CubedSphere3DTile, metric3d_torch
+    from wxfactory_amd.initial import initial_state
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D
+
+    g = golden("euler3d_c31p_n3_h4_v2")
+    panels = g.metric_panels()
+    assert len(panels) == 6
+    Q = torch.stack([to_dev(g.q(p)) for p in panels])
+    v = Q * 1e-3 * torch.rand_like(Q)
+
+    def both_ways(make_plans, Q, v):
+        res = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("WXHIP_BRICK_PULLS", mode)
+            plans = make_plans()
+            for pl in plans.values():
+                pl.set_one_kernel(True)
+            rhs = RhsEuler3D(plans)
+            R = rhs(Q)
+            bt = rhs._batch_for(torch.float64, rhs.plans_for(torch.float64), rhs.exchange_for(torch.float64))
+            assert bt.pulls == (mode == "1")
+            S = rhs.shifted_axpy(Q, v, 1e-4, v, 1.0, 0.0, -2.0, R, 2.0)
+            torch.cuda.synchronize()
+            res[mode] = (R, S)
+        assert _rel(res["1"][0], res["0"][0]) <= 1e-12 and _rel(res["1"][1], res["0"][1]) <= 1e-12
+        return res["1"][0]
+
+    R = both_ways(lambda: {p: make_plan(g, p) for p in panels}, Q, v).cpu().numpy()
+    for i, p in enumerate(panels):
+        o = make_oracle(g, p)
+        want = {}
+        o.rhs(g.q(p), g.halo(p), want=want)
+        scale = np.maximum(var_max(g.r(p)), o.cancel_scale(want))
+        err = var_err(R[i], g.r(p))
+        assert (err <= 1e-10 * scale).all(), (p, err / scale)
+
+    n, H, V = 2, 5, 3
+    tiles = [CubedSphere3DTile(n, H, V, p, 10000.0, 31) for p in range(6)]
+    metrics = [metric3d_torch(t, DEV) for t in tiles]
+    Q2 = torch.stack([torch.from_numpy(initial_state(t)).to(DEV) for t in tiles])
+    Q2 = Q2 * (1.0 + 0.01 * (torch.rand_like(Q2) - 0.5))
+    both_ways(lambda: {p: Euler3DPlan(n, H, V, 31, p, synthetic.dfr_ops(n), metrics[p]) for p in range(6)}, Q2, Q2 * 1e-3)

@@ -80,6 +80,7 @@ SIGNATURES = {
     "wx_euler3d_plan_set_column_metric": (c_int, [c_void_p, c_void_p]),
     "wx_euler3d_plan_has_column_metric": (c_int, [c_void_p]),
     "wx_euler3d_uses_matrix_cores": (c_int, [c_void_p, c_int]),
+    "wx_lean_log": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "wx_euler3d_plan_one_kernel": (c_int, [c_void_p]),
     "wx_euler3d_plan_set_one_kernel": (c_int, [c_void_p, c_int]),
     "wx_euler3d_extrap_pack": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), c_void_p]),
@@ -144,6 +145,7 @@ SIGNATURES = {
     "wx_check_nan": (c_int, [c_void_p, c_size_t, c_int, c_void_p, c_void_p]),
     "wx_cart2d_sponge": (c_int, [c_void_p, c_void_p, c_double, c_size_t, c_int, c_void_p]),
     "wx_euler3d_batch_create": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_int, c_void_p, c_void_p]),
+    "wx_euler3d_batch_pulls": (c_int, [c_void_p]),
     "wx_euler3d_batch_destroy": (c_int, [c_void_p]),
     "wx_euler3d_batch_extrap_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_size_t, c_void_p]),
     "wx_euler3d_batch_rhs_axpy2": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_size_t,

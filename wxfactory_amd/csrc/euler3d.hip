@@ -72,6 +72,8 @@ struct wx_euler3d_plan {
     // low orders, float64: the one-kernel form (euler3d_brick.h) - the pack entry points write the edge messages only,
     // the evaluation reads no interface buffer.  WXHIP_DIRECT=0 (environment, read at plan creation): the two-kernel form.
     bool direct = false;
+    int flip[4] = {0, 0, 0, 0};   // what the pack of edge e does to its line (the device constants' flip[e]) ...
+    double rot[4][8];             // ... and its rotation table (the device constants' rot[e])
     bool column = false;
     const double *c_sg = nullptr, *c_h = nullptr, *c_chr = nullptr, *c_idz = nullptr, *c_sgi = nullptr, *c_sgj = nullptr,
                  *c_sgk = nullptr, *c_hi = nullptr, *c_hj = nullptr, *c_hk = nullptr;
@@ -93,6 +95,7 @@ EulerParams<T> make_params(const wx_euler3d_plan* pl) {
     P.efilter = 0; P.nan_flag = nullptr;
     P.jvp = 0; P.q_re = P.q_tan = nullptr; P.out_tan = nullptr; P.jvp_eps = 0.0; P.jvp_scale = 1.0;
     P.dscale = nullptr;
+    for (int e = 0; e < 4; ++e) { P.pull_tile[e] = -1; P.pull_edge[e] = 0; P.pull_flip[e] = 0; }
     P.split = 0; P.ft = nullptr; P.fv = nullptr; P.hv_s = P.hv_n = P.hv_w = P.hv_e = nullptr;
     P.halo_s = P.halo_n = P.halo_w = P.halo_e = nullptr;
     P.send_s = P.send_n = P.send_w = P.send_e = nullptr;
@@ -312,7 +315,8 @@ wx_status wx_euler3d_plan_create_tile(wx_euler3d_plan** out, int n, int H, int V
     static const double identity[8] = {1, 0, 0, 0, 0, 1, 0, 0};
     for (int ed = 0; ed < 4; ++ed) {  // interior tile edges: no flip, no rotation (process_topology.py:219-228)
         hc.flip[ed] = on_panel_edge[ed] ? kFlip[panel][ed] : 0;
-        for (int i = 0; i < 8; ++i) hc.rot[ed][i] = on_panel_edge[ed] ? kRot[panel][ed][i] : identity[i];
+        pl->flip[ed] = hc.flip[ed];
+        for (int i = 0; i < 8; ++i) pl->rot[ed][i] = hc.rot[ed][i] = on_panel_edge[ed] ? kRot[panel][ed][i] : identity[i];
     }
     e = hipMalloc((void**)&pl->consts, sizeof(EulerConsts));
     if (e == hipSuccess) e = hipMemcpy(pl->consts, &hc, sizeof(hc), hipMemcpyHostToDevice);
@@ -773,6 +777,7 @@ struct wx_euler3d_batch {
     int n, H, V, count, nelem;
     wx_dtype dtype;
     bool direct = false;    // every plan takes the one-kernel form (euler3d_brick.h)
+    bool pulls = false;     // ... and every tile's neighbours are tiles of this batch: no pack launch (EulerParams::pull_tile)
     void* table = nullptr;  // device: EulerParams<T>[count]
 };
 
@@ -788,6 +793,22 @@ wx_status batch_upload(wx_euler3d_batch* b, wx_euler3d_plan* const* plans, void*
         P.send_w = static_cast<T*>(send[i][2]); P.send_e = static_cast<T*>(send[i][3]);
         P.halo_s = static_cast<const T*>(halo[i][0]); P.halo_n = static_cast<const T*>(halo[i][1]);
         P.halo_w = static_cast<const T*>(halo[i][2]); P.halo_e = static_cast<const T*>(halo[i][3]);
+        if (b->pulls) {
+            double prot[4][8];
+            const double* px[4];
+            for (int e = 0; e < 4; ++e)
+                for (int j = 0; j < b->count; ++j)
+                    for (int e2 = 0; e2 < 4; ++e2)
+                        if (send[j][e2] == halo[i][e]) {
+                            P.pull_tile[e] = j; P.pull_edge[e] = e2; P.pull_flip[e] = plans[j]->flip[e2];
+                            for (int k = 0; k < 8; ++k) prot[e][k] = plans[j]->rot[e2][k];
+                            px[e] = e2 >= E_W ? plans[j]->base.bwe : plans[j]->base.bsn;
+                        }
+            // (setup time: the plan's device constants learn what its four neighbours do to their lines)
+            hipError_t e1 = hipMemcpy(&plans[i]->consts->prot, prot, sizeof(prot), hipMemcpyHostToDevice);
+            if (e1 == hipSuccess) e1 = hipMemcpy(&plans[i]->consts->pull_x, px, sizeof(px), hipMemcpyHostToDevice);
+            if (e1 != hipSuccess) return fail(WX_ERR_HIP, "batch neighbour tables: %s", hipGetErrorString(e1));
+        }
         host[i] = P;
     }
     const size_t bytes = sizeof(EulerParams<T>) * b->count;
@@ -812,6 +833,7 @@ wx_status batch_extrap(const wx_euler3d_batch* b, const void* q, const double* v
     }
     const EulerParams<T>* t = static_cast<const EulerParams<T>*>(b->table);
     if constexpr (std::is_same<T, double>::value) {
+        if (b->direct && b->pulls) return WX_OK;   // (the evaluation forms the tile-edge states itself: nothing to pack)
         if (b->direct) {
             switch (b->n) {
                 case 2: return launch_pack_batch<2, T>(t, dyn, b->H, b->V, b->count, st);
@@ -838,6 +860,7 @@ wx_status batch_rhs(const wx_euler3d_batch* b, const void* q, const double* v, d
                     hipStream_t st, const double* dscale = nullptr) {
     EulerBatchDyn<T> dyn{};
     dyn.dscale = dscale;
+    dyn.pulls = (b->direct && b->pulls) ? 1 : 0;
     dyn.q = static_cast<const T*>(q); dyn.y = static_cast<const T*>(y); dyn.z = static_cast<const T*>(z);
     dyn.rhs = static_cast<T*>(out);
     dyn.stride = stride;
@@ -888,6 +911,23 @@ wx_status wx_euler3d_batch_create(wx_euler3d_batch** out, wx_euler3d_plan* const
     b->dtype = plans[0]->dtype;
     b->direct = true;
     for (int i = 0; i < count; ++i) b->direct = b->direct && plan_direct(plans[i]);
+    {   // every halo line IS the send line of a tile of this batch (one rank owns the sphere: the exchange aliases): pulls
+        // Taken at LAUNCH-BOUND sizes only (the shipped .ini files: the pack launch is a fifth of an evaluation there); at the
+        // reference's benchmark size the tile-edge items cost the kernel more (+12 us) than the pack launch it saves (8 us):
+        // profiles/r06_low_order_forms.txt.  WXHIP_BRICK_PULLS=1 / 0 forces it on / off.
+        const char* env = getenv("WXHIP_BRICK_PULLS");
+        const size_t points = (size_t)count * plans[0]->nelem * (size_t)(b->n * b->n * b->n);
+        const bool wanted = env ? env[0] != '0' : points <= 262144;
+        bool all = b->direct && b->dtype == WX_F64 && count <= 30 && wanted;   // (30: a tile index + 1 in five bits)
+        for (int i = 0; i < count && all; ++i)
+            for (int e = 0; e < 4 && all; ++e) {
+                bool found = false;
+                for (int j = 0; j < count && !found; ++j)
+                    for (int e2 = 0; e2 < 4 && !found; ++e2) found = send[j][e2] == halo[i][e];
+                all = found;
+            }
+        b->pulls = all;
+    }
     wx_status s = WX_ERR_INVALID;
     try {   // (the host copy of the table is a std::vector: no exception crosses the C boundary)
         switch (b->dtype) {
@@ -906,6 +946,8 @@ wx_status wx_euler3d_batch_create(wx_euler3d_batch** out, wx_euler3d_plan* const
     *out = b;
     return WX_OK;
 }
+
+int wx_euler3d_batch_pulls(const wx_euler3d_batch* b) { return b ? ((b->direct && b->pulls) ? 1 : 0) : -1; }
 
 wx_status wx_euler3d_batch_destroy(wx_euler3d_batch* b) {
     if (!b) return WX_OK;

@@ -66,6 +66,11 @@ struct BrickBoxes {
 // (constant indices only: a run-time index into a by-value kernel argument sends the whole struct to scratch)
 #define WX_BOX(G, field, box) ((box) == 0 ? (G).field[0] : ((box) == 1 ? (G).field[1] : ((box) == 2 ? (G).field[2] : (G).field[3])))
 
+// the logarithms of this file (float64): the lean form of wx_math.h - the face stage is bound by its instruction count, and the
+// library's log is 84 of them against 38.  The pack kernel of the one-kernel form takes the same function (euler3d_extrap.h,
+// PACK), so a tile-edge state is the same number whether a brick extrapolates it or the neighbour tile packs it.
+__device__ __forceinline__ double b_log(double x) { return lean_log(x); }
+
 template <typename X>
 __device__ __forceinline__ X* raw_ptr(X* p) { return p; }
 template <typename X>
@@ -196,10 +201,31 @@ __device__ __forceinline__ void brick_line(int d, int fp, int& lbase, int& lstri
 }
 
 // one face point on the brick's surface
-struct Surf { int d, plus, le, fp, ei, ej, ek, kind; };   // kind: 0 a neighbour element of this tile, 1 halo, 2 wall
+// kind: 0 a neighbour element of this tile, 1 halo (the received message), 2 wall, 3 a tile of the same batch across the tile edge
+// (its nodal line: element `pes` of tile `pt2`, face point `pfp` of its edge `pe2` - see EulerParams::pull_tile)
+struct Surf { int d, plus, le, fp, ei, ej, ek, kind, pt2, pe2, pes, pfp; };
 
-template <int N>
-__device__ __forceinline__ Surf surf_decode(const BrickAt& bk, int w, int s0, int s1, int s2, unsigned m_vi, unsigned m_vj, int H, int V) {
+// the other tiles of a batched launch, for kind 3 (null table: a single-tile launch, or no pulls)
+// (the four neighbour tiles packed into ONE word, a byte per edge S, N, W, E: tile + 1 in bits 0-4, its edge in bits 5-6, its flip
+// in bit 7 - picked out by a shift.  Not four members picked out by a select: a select between members of a block that lives in
+// memory becomes a load through a selected address and pins the block in scratch, see the note above brick_face_metric.)
+struct BrickBatchCtx {
+    const EulerParams<double>* table;
+    long long stride;   // doubles between consecutive tiles' states
+    int self;
+    unsigned packed;
+};
+__device__ __forceinline__ unsigned brick_pack_pulls(const EulerParams<double>* me) {
+    unsigned w = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        w |= ((unsigned)((me->pull_tile[e] + 1) & 31) | ((unsigned)(me->pull_edge[e] & 3) << 5) | ((unsigned)(me->pull_flip[e] & 1) << 7)) << (8 * e);
+    return w;
+}
+
+template <int N, typename T, bool G>
+__device__ __forceinline__ Surf surf_decode(const EulerParams<T, G>& P, const BrickBatchCtx& ctx, const BrickAt& bk, int w, int s0, int s1,
+                                            int s2, unsigned m_vi, unsigned m_vj, int H, int V) {
     constexpr int N2 = N * N;
     const int vi = bk.vi, vj = bk.vj, vk = bk.vk;
     Surf u;
@@ -219,6 +245,26 @@ __device__ __forceinline__ Surf surf_decode(const BrickAt& bk, int w, int s0, in
     const int ng = u.plus ? gd + 1 : gd - 1;
     const bool outside = ng < 0 || ng >= (u.d == 2 ? V : H);
     u.kind = (WX_BRICK_DIAG == 1) ? 2 : (outside ? (u.d == 2 ? 2 : 1) : 0);
+    u.pt2 = -1; u.pe2 = 0; u.pes = 0; u.pfp = 0;
+    if (u.kind == 1 && ctx.table != nullptr) {
+        // the tile edge this face lies on, and who is behind it (constant indices: see WX_BOX)
+        const unsigned inf = (ctx.packed >> (8 * ((u.d == 0 ? E_W : E_S) + u.plus))) & 0xffu;   // (E_S, E_N, E_W, E_E = 0, 1, 2, 3)
+        const int t2 = (int)(inf & 31u) - 1;
+        if (t2 >= 0) {
+            const int e2 = (int)((inf >> 5) & 3u);
+            const int fl = (int)(inf >> 7);
+            // our slot of its message is (ek, along, a, b): it wrote that slot from its element along_s, face point (a, b_s)
+            // (extrap_faces: al = flip ? H - 1 - along : along, bb = flip ? N - 1 - b : b)
+            const int along = u.d == 0 ? u.ej : u.ei;
+            const int a = u.fp / N, b = u.fp - a * N;
+            const int along_s = fl ? H - 1 - along : along, b_s = fl ? N - 1 - b : b;
+            const int ei_s = e2 == E_W ? 0 : (e2 == E_E ? H - 1 : along_s);
+            const int ej_s = e2 == E_S ? 0 : (e2 == E_N ? H - 1 : along_s);
+            u.kind = 3; u.pt2 = t2; u.pe2 = e2;
+            u.pes = (u.ek * H + ej_s) * H + ei_s;
+            u.pfp = a * N + b_s;
+        }
+    }
     return u;
 }
 
@@ -226,18 +272,33 @@ __device__ __forceinline__ Surf surf_decode(const BrickAt& bk, int w, int s0, in
 // (two sets of registers, each written on one path only: one set written on both paths meets in copies behind the branch, and
 // a copy of a loaded value is a wait for it - the loads would not stay in flight)
 template <int N, typename T, bool G>
-__device__ __forceinline__ void surf_load(const EulerParams<T, G>& P, const Surf& u, const T* halo_s, const T* halo_n, const T* halo_w,
-                                          const T* halo_e, T (*nv)[5], T* hv) {
+__device__ __forceinline__ void surf_load(const EulerParams<T, G>& P, const BrickBatchCtx& ctx, const Surf& u, const T* halo_s,
+                                          const T* halo_n, const T* halo_w, const T* halo_e, T (*nv)[5], T* hv, double& px) {
     constexpr int N2 = N * N, N3 = N2 * N;
     const int H = P.H, V = P.V;
     int lbase, lstride, pbase, pstride;
     brick_line<N>(u.d, u.fp, lbase, lstride, pbase, pstride);
-    if (u.kind == 0) {
+    if (u.kind == 0 || u.kind == 3) {
+        // the nodal line of the element behind the face: of this tile, or (kind 3) of the tile across the tile edge - the
+        // same loads at another tile's distance (load_state adds the offset to every array of the state: q, and the shift's v)
         const size_t fs = (size_t)P.nelem * N3;
-        const int e = (u.ek * H + u.ej) * H + u.ei;
-        const size_t eo = (size_t)(e + (u.plus ? 1 : -1) * (u.d == 0 ? 1 : (u.d == 1 ? H : H * H))) * N3 + pbase;
+        size_t eo;
+        int ps = pstride;
+        if (u.kind == 0) {
+            const int e = (u.ek * H + u.ej) * H + u.ei;
+            eo = (size_t)(e + (u.plus ? 1 : -1) * (u.d == 0 ? 1 : (u.d == 1 ? H : H * H))) * N3 + pbase;
+        } else {
+            int lb2, ls2, pb2, ps2;
+            brick_line<N>(u.pe2 >= E_W ? 0 : 1, u.pfp, lb2, ls2, pb2, ps2);
+            eo = (size_t)((long long)(u.pt2 - ctx.self) * ctx.stride + (long long)u.pes * N3 + pb2);
+            ps = ps2;
+            // the sender's edge coordinate of this line (its boundary_we / boundary_sn, reached through this plan's constants)
+            const int edge = (u.d == 0 ? E_W : E_S) + u.plus;
+            const int along_s = u.pe2 >= E_W ? (u.pes / H) % H : u.pes % H;
+            px = P.K->pull_x[edge][along_s * N + u.pfp % N];
+        }
 #pragma unroll
-        for (int m = 0; m < N; ++m) load_state<T>(P, eo + m * pstride, fs, nv[m][0], nv[m][1], nv[m][2], nv[m][3], nv[m][4]);
+        for (int m = 0; m < N; ++m) load_state<T>(P, eo + (size_t)(m * ps), fs, nv[m][0], nv[m][1], nv[m][2], nv[m][3], nv[m][4]);
     } else if (u.kind == 1) {
         // lateral tile edge: the received message (process_topology.py:595-606), five planes V H n^2 apart
         const size_t vsh = (size_t)V * H * N2;
@@ -259,8 +320,8 @@ __device__ __forceinline__ void surf_load(const EulerParams<T, G>& P, const Surf
 // in (INTERIOR + BOUNDARY == ALL bit for bit).
 // rot: the wave that starts class 1 (the classes rarely fill whole rounds: the surplus rotates over the SIMDs from brick to brick).
 template <int N, typename T, bool G, typename Store>
-__device__ __forceinline__ void brick_face_stage(const EulerParams<T, G>& P, const BrickAt& bk, const T* img, int img_stride, int rot,
-                                                 Store store) {
+__device__ __forceinline__ void brick_face_stage(const EulerParams<T, G>& P, const BrickBatchCtx& ctx, const BrickAt& bk, const T* img,
+                                                 int img_stride, int rot, Store store) {
     using C = BrickCfg<N>;
     constexpr int N2 = C::N2, BS = C::BS;
     const int tid = threadIdx.x;
@@ -284,11 +345,11 @@ __device__ __forceinline__ void brick_face_stage(const EulerParams<T, G>& P, con
 
     // ---- the first surface item: decode and LOADS, now
     T nv[N][5], hv[5];
-    double g0, g1, g2, g3;
-    Surf u = surf_decode<N>(bk, tid < nS ? tid : 0, s0, s1, s2, m_vi, m_vj, H, V);
+    double g0, g1, g2, g3, px;
+    Surf u = surf_decode<N, T, G>(P, ctx, bk, tid < nS ? tid : 0, s0, s1, s2, m_vi, m_vj, H, V);
     if (k2 > 0) {
         brick_face_metric<N, T, G>(sgi, sgj, sgk, hi, hj, hk, H, V, u.ek, u.ej, u.ei, u.d, u.plus, u.fp, g0, g1, g2, g3);
-        surf_load<N, T>(P, u, halo_s, halo_n, halo_w, halo_e, nv, hv);
+        surf_load<N, T>(P, ctx, u, halo_s, halo_n, halo_w, halo_e, nv, hv, px);
     }
 
     for (int it = 0; it < k1 + k2; ++it) {
@@ -317,9 +378,9 @@ __device__ __forceinline__ void brick_face_stage(const EulerParams<T, G>& P, con
             both = true;
         } else {
             if (it > k1) {   // (a later surface item of this thread: its loads here)
-                u = surf_decode<N>(bk, tid + (it - k1) * BS, s0, s1, s2, m_vi, m_vj, H, V);
+                u = surf_decode<N, T, G>(P, ctx, bk, tid + (it - k1) * BS, s0, s1, s2, m_vi, m_vj, H, V);
                 brick_face_metric<N, T, G>(sgi, sgj, sgk, hi, hj, hk, H, V, u.ek, u.ej, u.ei, u.d, u.plus, u.fp, g0, g1, g2, g3);
-                surf_load<N, T>(P, u, halo_s, halo_n, halo_w, halo_e, nv, hv);
+                surf_load<N, T>(P, ctx, u, halo_s, halo_n, halo_w, halo_e, nv, hv, px);
             }
             d = u.d; fp = u.fp; le = u.le;
             sg = g0; h0 = g1; h1 = g2; h2 = g3;
@@ -328,26 +389,33 @@ __device__ __forceinline__ void brick_face_stage(const EulerParams<T, G>& P, con
             T so[5], sn[5], lgo, lgn;
             if (u.plus) brick_extrap_lds<N, T>(img, img_stride, le * C::LE + lbase, lstride, P.K->ep, so, lgo);
             else brick_extrap_lds<N, T>(img, img_stride, le * C::LE + lbase, lstride, P.K->em, so, lgo);
-            if (u.kind == 0) {
-                // the neighbour's face state from its nodal values, as its own extrapolation forms it (its face towards this brick)
+            if (u.kind == 0 || u.kind == 3) {
+                // the neighbour's face state from its nodal values, as its own extrapolation forms it (its face towards this brick;
+                // kind 3: the outward face of the tile across the tile edge, its edge pe2: N and E are plus faces)
+                const bool nplus = u.kind == 3 ? (u.pe2 == E_N || u.pe2 == E_E) : !u.plus;
 #pragma unroll
                 for (int v = 0; v < 5; ++v) sn[v] = T(0.0);
 #pragma unroll
                 for (int m = 0; m < N; ++m) {
-                    const double wm = u.plus ? P.K->em[m] : P.K->ep[m];
-                    sn[0] += wm * w_log(nv[m][0]);
+                    const double wm = nplus ? P.K->ep[m] : P.K->em[m];
+                    sn[0] += wm * b_log(nv[m][0]);
                     sn[1] += wm * nv[m][1];
                     sn[2] += wm * nv[m][2];
                     sn[3] += wm * nv[m][3];
-                    sn[4] += wm * w_log(nv[m][4]);
+                    sn[4] += wm * b_log(nv[m][4]);
                 }
                 lgn = sn[4];
                 sn[0] = w_exp(sn[0]);
                 sn[4] = w_exp(sn[4]);
+                if (u.kind == 3) {
+                    // ... then what its pack does before sending (process_topology.py:322-386): the horizontal contravariant pair
+                    // rotated into THIS panel's basis with ITS table and ITS edge coordinate (EulerConsts::prot, pull_x)
+                    rotate_contra<T>(P.K->prot[(u.d == 0 ? E_W : E_S) + u.plus], px, sn[1], sn[2]);
+                }
             } else if (u.kind == 1) {
 #pragma unroll
                 for (int v = 0; v < 5; ++v) sn[v] = hv[v];
-                lgn = w_log(sn[4]);
+                lgn = b_log(sn[4]);
             } else {
                 wall = u.plus ? 1 : 2;
 #pragma unroll
@@ -456,7 +524,7 @@ struct BrickFaceStore {
 // output, the tile-edge messages of the output) - a separate instantiation, the plain kernel keeps its schedule.
 // ------------------------------------------------------------------------------------------------
 template <int N, typename T, bool EPI, bool G>
-__device__ __forceinline__ void euler_brick_body(const EulerParams<T, G>& P, const BrickBoxes& GB) {
+__device__ __forceinline__ void euler_brick_body(const EulerParams<T, G>& P, const BrickBoxes& GB, const BrickBatchCtx& ctx) {
     using C = BrickCfg<N>;
     static_assert(std::is_same<T, double>::value, "the brick form of the fused kernel: float64");
     constexpr int N2 = C::N2, N3 = C::N3, EPB = C::EPB, BS = C::BS;
@@ -518,9 +586,9 @@ __device__ __forceinline__ void euler_brick_body(const EulerParams<T, G>& P, con
     }
     const T q0 = S.q0, q1 = S.q1, q2 = S.q2, q3 = S.q3, q4 = S.q4;
     const double sg = S.sg;
-    const T lq4 = w_log(q4);
+    const T lq4 = b_log(q4);
     if (le < EPB) {
-        fld[0][lpt] = w_log(q0);
+        fld[0][lpt] = b_log(q0);
         fld[1][lpt] = q1;
         fld[2][lpt] = q2;
         fld[3][lpt] = q3;
@@ -571,7 +639,7 @@ __device__ __forceinline__ void euler_brick_body(const EulerParams<T, G>& P, con
 
     // ---- face stage: every Riemann problem of the brick once
     if (WX_BRICK_DIAG != 3)
-    brick_face_stage<N, T>(P, bk, &fld[0][0], EPB * C::LE, brick_id & (BS / 64 - 1), BrickFaceStore<N, T>{frs});
+    brick_face_stage<N, T>(P, ctx, bk, &fld[0][0], EPB * C::LE, brick_id & (BS / 64 - 1), BrickFaceStore<N, T>{frs});
 
     T acc0 = T(0.0), acc1 = sg * fc0, acc2 = sg * fc1, acc4 = T(0.0), accw = sg * fc2;
     T hf = T(0.0);
@@ -695,11 +763,11 @@ __device__ __forceinline__ void euler_brick_body(const EulerParams<T, G>& P, con
         if (any_send && at_edge) {   // (uniform over the workgroup)
             __syncthreads();
             if (le < EPB) {
-                fld[0][lpt] = active ? w_log(r0) : T(0.0);
+                fld[0][lpt] = active ? b_log(r0) : T(0.0);
                 fld[1][lpt] = r1;
                 fld[2][lpt] = r2;
                 fld[3][lpt] = r3;
-                fld[4][lpt] = active ? w_log(r4) : T(0.0);
+                fld[4][lpt] = active ? b_log(r4) : T(0.0);
             }
             __syncthreads();
             brick_pack_edges<N, T>(P, bk, &fld[0][0], EPB * C::LE);
@@ -710,7 +778,7 @@ __device__ __forceinline__ void euler_brick_body(const EulerParams<T, G>& P, con
 
 template <int N, bool EPI>
 __global__ __launch_bounds__(BrickCfg<N>::BS, BrickCfg<N>::WAVES) void euler_brick_kernel(const EulerParams<double> P, const BrickBoxes GB) {
-    euler_brick_body<N, double, EPI>(P, GB);
+    euler_brick_body<N, double, EPI>(P, GB, BrickBatchCtx{nullptr, 0, 0, 0u});
 }
 
 template <int N>
@@ -726,7 +794,9 @@ __global__ __launch_bounds__(BrickCfg<N>::BS, BrickCfg<N>::WAVES) void euler_bri
     P.z = dyn.z ? dyn.z + off : (const double*)nullptr;
     P.region = dyn.region; P.count = dyn.count;
     P.axpy = dyn.axpy; P.ca = dyn.ca; P.cb = dyn.cb; P.cc = dyn.cc; P.cd = dyn.cd;
-    euler_brick_body<N, double, false>(P, GB);
+    // (tile-edge states from the other tiles of this launch when the batch holds every tile's neighbours: EulerParams::pull_tile)
+    const BrickBatchCtx ctx{dyn.pulls ? table : nullptr, (long long)dyn.stride, (int)blockIdx.y, brick_pack_pulls(table + blockIdx.y)};
+    euler_brick_body<N, double, false>(P, GB, ctx);
 }
 
 }  // namespace wx

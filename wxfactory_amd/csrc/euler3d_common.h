@@ -68,6 +68,10 @@ struct EulerConsts {
     double EF[kMaxN * kMaxN];  // nodal exponential filter (wx_euler3d_set_exp_filter), identity until set
     double rot[4][8];
     int flip[4];
+    // one-kernel form with pulls (EulerParams::pull_tile): what the tile ACROSS edge e does to the line it would send through its
+    // edge towards this tile - its rotation table for that edge and its array of edge coordinates (boundary_sn / _we)
+    double prot[4][8];
+    const double* pull_x[4];
 };
 
 // G: the pointers carry the global address space in device code (wx_common.h: gp) - the batched float64 kernels, whose
@@ -99,6 +103,10 @@ struct EulerParams {
     // with s = the lagged norm the Gram-Schmidt kernel left on the device): the state is q + (jvp_eps / *dscale) q_tan and the
     // store coefficients cc, cd are multiplied by *dscale.  Null: off.
     const double* dscale;
+    // one-kernel form, all tiles of a sphere in one batch (euler3d_brick.h): the tile across edge e is tile pull_tile[e] of the
+    // same batch, reached through ITS edge pull_edge[e], which it flips or not (pull_flip[e]) - the launch then forms a tile-edge
+    // state from that tile's nodal values itself (the sender's sum, rotation and flip) and no pack launch runs.  -1: no such tile.
+    int pull_tile[4], pull_edge[4], pull_flip[4];
     // prepared JVP (wx_euler3d_jvp_prepare): the face VALUES of the linearisation state stay in fv (real,
     // [elem][6][5][n^2]) and in the value halos hv_* for a whole Krylov solve; per product only the face TANGENTS are
     // extrapolated (ft, real, same layout; tangent edge messages through send_* / halo_* as REAL arrays)

@@ -103,11 +103,16 @@ __device__ __forceinline__ void euler_extrap_body(const EulerParams<T, G>& P) {
             const int lp = le * C::LE + C::lidx(pt / N2, (pt / N) % N, pt % N);
             T a0, a1, a2, a3, a4;
             load_state<T>(P, o, fs, a0, a1, a2, a3, a4);
-            fld[0][lp] = w_log(a0);
+            if constexpr (PACK && std::is_same<T, double>::value) {   // (the one-kernel form's logarithm: euler3d_brick.h, b_log)
+                fld[0][lp] = lean_log(a0);
+                fld[4][lp] = lean_log(a4);
+            } else {
+                fld[0][lp] = w_log(a0);
+                fld[4][lp] = w_log(a4);
+            }
             fld[1][lp] = a1;
             fld[2][lp] = a2;
             fld[3][lp] = a3;
-            fld[4][lp] = w_log(a4);
         }
     }
     __syncthreads();
@@ -265,6 +270,7 @@ struct EulerBatchDyn {
     double eps, scale;
     int jvp;
     const double* dscale;   // EulerParams::dscale (fgmres' device pass), nullable
+    int pulls;              // one-kernel form: tile-edge states pulled from the other tiles of the launch (EulerParams::pull_tile)
 };
 
 template <typename T, bool G>

@@ -1,5 +1,6 @@
 // libwxhip.so: error string, version, device probe.
 #include "wx_common.h"
+#include "wx_math.h"
 #include "wx_mfma.h"
 
 #include <new>
@@ -238,6 +239,21 @@ wx_status wx_stream_destroy(wx_stream stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     (void)hipStreamSynchronize(st);
     WX_HIP_TRY(hipStreamDestroy(st));
+    return WX_OK;
+}
+
+// the float64 logarithm of the one-kernel form (wx_math.h: lean_log) on an array - so that its accuracy is a tested statement
+__global__ __launch_bounds__(256) void wx_lean_log_kernel(const double* __restrict__ x, double* __restrict__ y, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = wx::lean_log(x[i]);
+}
+
+wx_status wx_lean_log(const double* x, double* y, size_t n, wx_stream stream) {
+    if (n == 0) return WX_OK;
+    if (!x || !y) return wx::fail(WX_ERR_INVALID, "wx_lean_log: null argument");
+    WX_STREAM(st, stream);
+    hipLaunchKernelGGL(wx_lean_log_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, n);
+    WX_HIP_TRY(hipGetLastError());
     return WX_OK;
 }
 

@@ -61,6 +61,51 @@ __device__ __forceinline__ double w_max(double a, double b) { return (a > b || a
 __device__ __forceinline__ double w_min(double a, double b) { return (a < b || a != a) ? a : b; }
 __device__ __forceinline__ double w_real(double x) { return x; }
 
+// Lean float64 logarithm and exponential for the one-kernel form of the low orders (csrc/euler3d_brick.h), whose face stage is
+// bound by the instruction count of its transcendentals: the library's log is 98 vector instructions (double-double
+// arithmetic, special cases), its exp 42.  Arguments here are densities, rho theta and their extrapolated logarithms: positive,
+// finite, normal; |x| < 700 for the exponential - no special cases.  Error < 1 ulp (the classical fdlibm forms).
+//   lean_log: x = 2^k m, m in [sqrt(1/2), sqrt(2)); f = m - 1, s = f / (2 + f); log m = f - f^2/2 + s (f^2/2 + R(s^2))   ~40 instructions
+//   lean_exp: x = k ln2 + r, |r| <= ln2 / 2; exp r by its Taylor polynomial of degree 13 (truncation 4e-18)          ~20 instructions
+__device__ __forceinline__ double lean_log(double x) {
+    double f = __builtin_amdgcn_frexp_mant(x);            // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool lo = f < 0.70710678118654752440;
+    f = lo ? f + f : f;
+    e = lo ? e - 1 : e;
+    f -= 1.0;                                              // [-0.2929, 0.4142)
+    const double s = f / (2.0 + f);
+    const double dk = (double)e;
+    const double z = s * s, w = z * z;
+    const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
+    const double t2 = z * (6.666666666666735130e-01 + w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
+__device__ __forceinline__ double lean_exp(double x) {
+    const double k = __builtin_rint(x * 1.44269504088896338700e+00);
+    const double r = __builtin_fma(-k, 1.90821492927058770002e-10, __builtin_fma(-k, 6.93147180369123816490e-01, x));
+    double p = 1.0 / 6227020800.0;                          // 1/13!
+    p = __builtin_fma(p, r, 1.0 / 479001600.0);
+    p = __builtin_fma(p, r, 1.0 / 39916800.0);
+    p = __builtin_fma(p, r, 1.0 / 3628800.0);
+    p = __builtin_fma(p, r, 1.0 / 362880.0);
+    p = __builtin_fma(p, r, 1.0 / 40320.0);
+    p = __builtin_fma(p, r, 1.0 / 5040.0);
+    p = __builtin_fma(p, r, 1.0 / 720.0);
+    p = __builtin_fma(p, r, 1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_amdgcn_ldexp(p, (int)k);
+}
+// value-type dispatch: LEAN selects the forms above for float64 and for the value part of a dual number
+template <bool LEAN> __device__ __forceinline__ double w_logx(double x) { return LEAN ? lean_log(x) : log(x); }
+template <bool LEAN> __device__ __forceinline__ double w_expx(double x) { return LEAN ? lean_exp(x) : exp(x); }
+
 __device__ __forceinline__ cplx w_log(cplx z) { return {log(hypot(z.re, z.im)), atan2(z.im, z.re)}; }
 __device__ __forceinline__ cplx w_exp(cplx z) {
     const double e = exp(z.re);

@@ -420,6 +420,11 @@ class Euler3DBatch:
         with torch.cuda.device(self.device):
             check(self.lib.wx_euler3d_batch_create(ctypes.byref(self._h), handles, n, send, halo), "wx_euler3d_batch_create")
 
+    @property
+    def pulls(self) -> bool:
+        """One-kernel form with every neighbour tile in the batch: no pack launch, R(Q) is one launch (wx_euler3d_batch_pulls)."""
+        return int(self.lib.wx_euler3d_batch_pulls(self._h)) == 1
+
     def extrap_pack(self, q, v=None, eps: float = 0.0):
         """Phase 1-2 of all tiles; with v: on q + eps v (float64 batch) or on the dual state (q, eps v) formed from
         the two real arrays (dual batch)."""
