@@ -1,5 +1,6 @@
 """The headline of bench.py: whole-sphere 3-D Euler R(Q), timed between barriers, ONE JSON line on rank 0."""
 import argparse
+import math
 import json
 import os
 import sys
@@ -287,15 +288,24 @@ def main():
     # W = 10 steps (67 ms) ended inside that ramp on one box of round 6 and the FIRST timed pass read 8.5 ms per step where the
     # second read 6.7 (profiles/r06_v1_bench.json.log against r06_v1_bench_profiled.json.log) - so evaluations run for half a
     # second first, then the W warm-up steps of the contract, then EXACTLY K timed steps
+    # (an evaluation is a COLLECTIVE at N > 1: every rank must run the same number of them - the count comes from rank-wide numbers)
     out = None
-    spin = 0
+    torch.cuda.synchronize()
+    barrier()
     t_spin = time.perf_counter()
-    while spin < 5 or time.perf_counter() - t_spin < args.spinup:
+    for _ in range(5):
         out = rhs(state)
-        spin += 1
-        if spin % 8 == 0:
+    torch.cuda.synchronize()
+    per_eval = torch.tensor([(time.perf_counter() - t_spin) / 5.0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(per_eval, op=dist.ReduceOp.MAX)
+    more = int(min(5000, max(0, math.ceil(args.spinup / max(float(per_eval.item()), 1e-6)) - 5)))
+    for i in range(more):
+        out = rhs(state)
+        if i % 8 == 7:
             torch.cuda.synchronize()
     torch.cuda.synchronize()
+    spin = 5 + more
     for _ in range(args.warmup):
         out = rhs(state)
     # the headline: EXACTLY K steps between barriers, nothing but the evaluation inside

@@ -246,3 +246,43 @@ def test_tile_edge_states_pulled_from_the_neighbour_tiles(monkeypatch):
     Q2 = torch.stack([torch.from_numpy(initial_state(t)).to(DEV) for t in tiles])
     Q2 = Q2 * (1.0 + 0.01 * (torch.rand_like(Q2) - 0.5))
     both_ways(lambda: {p: Euler3DPlan(n, H, V, 31, p, synthetic.dfr_ops(n), metrics[p]) for p in range(6)}, Q2, Q2 * 1e-3)
+
+
+@pytest.mark.parametrize("pulls", ["1", "0"])
+def test_one_kernel_form_on_the_24_tile_decomposition(pulls, monkeypatch):
+    """The layout of 4 and 8 GPUs - k x k tiles per panel, interior tile edges unrotated and unflipped, panel edges as ever - on
+    one rank in the one-kernel form (order 3: selected by hand), tile-edge states pulled from the neighbour tiles or read from
+    packed messages: R of every tile against what the reference computed on 24 MPI ranks (1e-10); per-tile launches agree with
+    the batched one."""
+    from tests.gpu_util import to_dev
+    from tests.test_euler3d_gpu import _scale_tile
+    from wxfactory_amd.exchange import PanelExchange
+    from wxfactory_amd.geometry3d import CubedSphere3DTile, metric3d_torch
+    from wxfactory_amd.panels import CubeTopology
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D
+    from wxfactory_amd.synthetic import dfr_ops
+
+    monkeypatch.setenv("WXHIP_BRICK_PULLS", pulls)
+    g = golden("euler3d_tiles24_n3_h2_v2")
+    k = int(g["meta/k"])
+    topo = CubeTopology(k)
+    plans = {}
+    for t in range(topo.ntiles):
+        p, row, col = topo.locate(t)
+        tile = CubedSphere3DTile(g.n, g.H, g.V, p, 10000.0, g.case, row=row, col=col, k=k)
+        plans[t] = Euler3DPlan(g.n, g.H, g.V, g.case, p, dfr_ops(g.n), metric3d_torch(tile, DEV), on_panel_edge=topo.on_panel_edge(t))
+        plans[t].set_one_kernel(True)
+    ex = PanelExchange(plans[0].edge_count, DEV, rank=0, world_size=1, tiles_per_side=k)
+    rhs = RhsEuler3D(plans, ex)
+    assert rhs._small_tiles()
+    Q = torch.stack([to_dev(g.q(t)) for t in range(topo.ntiles)])
+    Rd = rhs(Q)
+    assert rhs._batch_for(torch.float64, rhs.plans_for(torch.float64), ex).pulls == (pulls == "1")
+    R = Rd.cpu().numpy()
+    rhs.batched = False
+    assert _rel(rhs(Q), Rd) <= 1e-12
+    scales = {t: _scale_tile(g, t, topo) for t in g.metric_panels()}
+    floor = np.max(np.stack(list(scales.values())), axis=0)
+    for t in range(topo.ntiles):
+        ref = g.r(t)
+        assert (var_err(R[t], ref) <= 1e-10 * np.maximum(var_max(ref), scales.get(t, floor))).all(), t
