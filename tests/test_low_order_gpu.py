@@ -119,29 +119,47 @@ def test_stage_update_and_next_messages(n, filtered):
 
 
 @pytest.mark.parametrize("name", ["euler3d_c31p_n2_h4_v3", "euler3d_c31p_n3_h4_v2", "euler3d_c21_n4_h3_v4", "euler3d_c21p_n4_h3_v4"])
-def test_whole_sphere_callable_on_low_order_fixtures(name):
-    """RhsEuler3D (batched launches, exchange by aliasing) on the reference's low-order fixtures: R of every panel at 1e-10."""
+def test_one_kernel_form_on_the_low_order_fixtures(name):
+    """Every low-order fixture of the reference (orders 2, 3, 4; DCMIP 3-1 and 2-1 with its mountain and sponge) through the
+    one-kernel form: per panel with the halos the reference delivered (whole-tile and INTERIOR + BOUNDARY launches), and - where
+    the fixture holds all six panels - the whole sphere through RhsEuler3D (batched launch, exchange by aliasing); R at 1e-10."""
     from tests.gpu_util import make_plan, to_dev
+    from wxfactory_amd import _lib
     from wxfactory_amd.rhs_euler3d import RhsEuler3D
 
     g = golden(name)
     panels = g.metric_panels()
-    if len(panels) != 6:
-        pytest.skip("needs all six panels")
     plans = {p: make_plan(g, p) for p in panels}
     for pl in plans.values():
         pl.set_one_kernel(True)
     assert all(pl.one_kernel for pl in plans.values())
-    rhs = RhsEuler3D(plans)
-    Q = torch.stack([to_dev(g.q(p)) for p in panels])
-    R = rhs(Q).cpu().numpy()
-    for i, p in enumerate(panels):
+
+    def check(R, p, what):
         o = make_oracle(g, p)
         want = {}
         o.rhs(g.q(p), g.halo(p), want=want)
         scale = np.maximum(var_max(g.r(p)), o.cancel_scale(want))
-        err = var_err(R[i], g.r(p))
-        assert (err <= 1e-10 * scale).all(), (name, p, err / scale)
+        err = var_err(R, g.r(p))
+        assert (err <= 1e-10 * scale).all(), (name, what, p, err / scale)
+
+    for p in panels:
+        q = to_dev(g.q(p))
+        halo = [to_dev(halo7(h)) for h in g.halo(p)]
+        hp = [h.data_ptr() for h in halo]
+        out = torch.full_like(q, float("nan"))
+        plans[p].extrap_pack(q, None)
+        plans[p].rhs(q, hp, out)
+        split = torch.full_like(q, float("nan"))
+        plans[p].rhs(q, None, split, _lib.WX_REGION_INTERIOR)
+        plans[p].rhs(q, hp, split, _lib.WX_REGION_BOUNDARY)
+        torch.cuda.synchronize()
+        assert torch.equal(out, split)
+        check(out.cpu().numpy(), p, "tile")
+    if len(panels) == 6:
+        rhs = RhsEuler3D(plans)
+        R = rhs(torch.stack([to_dev(g.q(p)) for p in panels])).cpu().numpy()
+        for i, p in enumerate(panels):
+            check(R[i], p, "sphere")
 
 
 def test_ros2_step_at_order_2_with_device_passes(monkeypatch):
@@ -286,3 +304,76 @@ def test_one_kernel_form_on_the_24_tile_decomposition(pulls, monkeypatch):
     for t in range(topo.ntiles):
         ref = g.r(t)
         assert (var_err(R[t], ref) <= 1e-10 * np.maximum(var_max(ref), scales.get(t, floor))).all(), t
+
+
+@pytest.mark.parametrize("n,H,V", [(2, 5, 3), (2, 4, 2), (3, 4, 2), (4, 3, 2)])
+def test_one_kernel_form_of_the_complex_step_product(n, H, V):
+    """wx_euler3d_jvp on a dual plan in the one-kernel form (csrc/euler3d_brick_jvp.h) against the two-kernel form on the same plan:
+    whole tile and INTERIOR + BOUNDARY, dual edge messages from the pack kernel."""
+    from wxfactory_amd import _lib, synthetic
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan
+
+    m = synthetic.euler3d_metric(n, H, V, 4, DEV, seed=5)
+    q = synthetic.euler3d_state(n, H, V, 4, DEV, seed=5)
+    v = q * 1e-2 * (torch.rand_like(q) - 0.5)
+    plan = Euler3DPlan(n, H, V, 31, 4, synthetic.dfr_ops(n), m, dtype=torch.complex128, dual=True)
+    assert plan.one_kernel == (n == 2)
+    eps = 1.4901161193847656e-08
+    res = {}
+    for form in (True, False):
+        plan.set_one_kernel(form)
+        send = torch.zeros((4, plan.edge_count), dtype=torch.complex128, device=DEV)
+        plan.jvp_extrap_pack(q, v, eps, [send[e].data_ptr() for e in range(4)])
+        halo = [send[e] for e in (1, 0, 3, 2)]
+        hp = [h.data_ptr() for h in halo]
+        out = torch.full_like(q, float("nan"))
+        plan.jvp(q, v, eps, hp, out, 1.0 / eps)
+        split = torch.full_like(q, float("nan"))
+        plan.jvp(q, v, eps, None, split, 1.0 / eps, _lib.WX_REGION_INTERIOR)
+        plan.jvp(q, v, eps, hp, split, 1.0 / eps, _lib.WX_REGION_BOUNDARY)
+        torch.cuda.synchronize()
+        assert torch.equal(out, split)
+        res[form] = (out, torch.view_as_real(send).clone())
+    assert torch.isfinite(res[True][0]).all()
+    assert _rel(res[True][1], res[False][1]) <= 1e-13
+    assert _rel(res[True][0], res[False][0]) <= 1e-11, _rel(res[True][0], res[False][0])
+    plan.close()
+
+
+def test_complex_step_matvec_and_kiops_on_an_order_2_sphere(monkeypatch):
+    """Order 2 (config/dcmip31.ini's) on a small sphere of own geometry: matvec_fun's complex step through the one-kernel dual form
+    (batched, tile-edge states pulled or packed) against the two-kernel dual kernels, and KIOPS over it (the one-call Krylov
+    vector of wx_euler3d_batch_kiops_vector): the same adaptive decisions."""
+    from wxfactory_amd import synthetic
+    from wxfactory_amd.geometry3d import CubedSphere3DTile, metric3d_torch
+    from wxfactory_amd.initial import initial_state
+    from wxfactory_amd.matvec import ComplexStepOperator, matvec_fun
+    from wxfactory_amd.rhs_euler3d import Euler3DPlan, RhsEuler3D
+    from wxfactory_amd.solvers import kiops
+
+    n, H, V = 2, 6, 3
+    tiles = [CubedSphere3DTile(n, H, V, p, 10000.0, 31) for p in range(6)]
+    metrics = [metric3d_torch(t, DEV) for t in tiles]
+    Q = torch.stack([torch.from_numpy(initial_state(t)).to(DEV) for t in tiles])
+    Q = Q * (1.0 + 0.01 * (torch.rand_like(Q) - 0.5))
+    v = (torch.rand_like(Q) - 0.5).flatten()
+    res = {}
+    for mode in ("pull", "pack", "two"):
+        monkeypatch.setenv("WXHIP_BRICK_PULLS", "1" if mode == "pull" else "0")
+        monkeypatch.setenv("WXHIP_DIRECT", "0" if mode == "two" else "1")
+        plans = {p: Euler3DPlan(n, H, V, 31, p, synthetic.dfr_ops(n), metrics[p]) for p in range(6)}
+        rhs = RhsEuler3D(plans)
+        R = rhs(Q)
+        jv = matvec_fun(v, 30.0, Q, R, rhs, "complex")
+        dualplans = rhs._jvp_plans()
+        assert all(pl.one_kernel == (mode != "two") for pl in dualplans.values())
+        vec = torch.zeros((2, R.numel()), dtype=torch.float64, device=DEV)
+        vec[1] = R.flatten()
+        op = ComplexStepOperator(30.0, Q, R, rhs)
+        phiv, stats = kiops([1], op, vec, tol=1e-7, m_init=1, mmin=10, mmax=64)
+        torch.cuda.synchronize()
+        res[mode] = (jv, phiv, [int(stats[i]) for i in (0, 1, 2, 3, 5)])
+    for mode in ("pull", "pack"):
+        assert _rel(res[mode][0].reshape(Q.shape), res["two"][0].reshape(Q.shape)) <= 1e-10, mode
+        assert res[mode][2] == res["two"][2], (mode, res[mode][2], res["two"][2])
+        assert _rel(res[mode][1].reshape(-1, 1), res["two"][1].reshape(-1, 1)) <= 1e-6

@@ -50,6 +50,7 @@
 #include "euler3d_rhs.h"
 #include "euler3d_brick.h"
 #include "euler3d_jvp.h"
+#include "euler3d_brick_jvp.h"
 #include "euler3d_launch.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -272,7 +273,7 @@ wx_status wx_euler3d_plan_create_tile(wx_euler3d_plan** out, int n, int H, int V
     {
         const char* env = getenv("WXHIP_DIRECT");
         // default at num_solpts 2, where it wins (profiles/r06_low_order_forms.txt); 3 and 4 on request (set_one_kernel)
-        pl->direct = dtype == WX_F64 && n == 2 && !(env && env[0] == '0');
+        pl->direct = (dtype == WX_F64 || dtype == WX_DUAL128) && n == 2 && !(env && env[0] == '0');   // (dual plans: the JVP entry points)
     }
     b.advection_only = case_number < 13; b.has_damp = damp;
     b.sg = m->sqrtG; b.h = m->h_contra; b.chr = m->christoffel; b.idz = m->inv_dzdeta;
@@ -372,8 +373,8 @@ int wx_euler3d_plan_one_kernel(const wx_euler3d_plan* pl) { return pl ? (plan_di
 
 wx_status wx_euler3d_plan_set_one_kernel(wx_euler3d_plan* pl, int on) {
     if (!pl) return fail(WX_ERR_INVALID, "wx_euler3d_plan_set_one_kernel: null plan");
-    if (on && !(pl->dtype == WX_F64 && pl->n <= 4))
-        return fail(WX_ERR_UNSUPPORTED, "the one-kernel form serves WX_F64 plans of num_solpts 2..4");
+    if (on && !((pl->dtype == WX_F64 || pl->dtype == WX_DUAL128) && pl->n <= 4))
+        return fail(WX_ERR_UNSUPPORTED, "the one-kernel form serves WX_F64 and WX_DUAL128 plans of num_solpts 2..4");
     pl->direct = on != 0;
     return WX_OK;
 }
@@ -462,6 +463,14 @@ wx_status wx_euler3d_jvp_extrap_pack(wx_euler3d_plan* pl, const double* q, const
         P.send_w = static_cast<dual*>(send[2]); P.send_e = static_cast<dual*>(send[3]);
     }
     WX_STREAM(st, stream);
+    if (plan_direct(pl) && jvp_lean()) {   // one-kernel form: the edge messages only (no interface buffer)
+        if (!send) return WX_OK;
+        switch (pl->n) {
+            case 2: return launch_pack<2, dual>(P, st);
+            case 3: return launch_pack<3, dual>(P, st);
+            case 4: return launch_pack<4, dual>(P, st);
+        }
+    }
     return dispatch_extrap<dual>(pl->n, P, st);
 }
 
@@ -485,6 +494,13 @@ wx_status wx_euler3d_jvp(wx_euler3d_plan* pl, const double* q, const double* v, 
     }
     WX_STREAM(st, stream);
     if (!jvp_lean()) return dispatch_rhs<dual>(pl->n, P, st);
+    if (plan_direct(pl)) {
+        switch (pl->n) {
+            case 2: return launch_jvp_brick<2>(P, st);
+            case 3: return launch_jvp_brick<3>(P, st);
+            case 4: return launch_jvp_brick<4>(P, st);
+        }
+    }
     if (pl->column) {   // column form of the metric: the launch reads the slabs
         P.sg = pl->c_sg; P.h = pl->c_h; P.chr = pl->c_chr; P.idz = pl->c_idz;
         P.sgi = pl->c_sgi; P.sgj = pl->c_sgj; P.sgk = pl->c_sgk; P.hi = pl->c_hi; P.hj = pl->c_hj; P.hk = pl->c_hk;
@@ -832,6 +848,16 @@ wx_status batch_extrap(const wx_euler3d_batch* b, const void* q, const double* v
         dyn.q_tan = v; dyn.eps = eps;  // float64: shifted state q + eps v (null: plain)
     }
     const EulerParams<T>* t = static_cast<const EulerParams<T>*>(b->table);
+    if constexpr (std::is_same<T, dual>::value) {
+        if (b->direct && dyn.jvp && jvp_lean()) {   // the one-kernel form of the complex-step product: edge messages only, or nothing
+            if (b->pulls) return WX_OK;
+            switch (b->n) {
+                case 2: return launch_pack_batch<2, T>(t, dyn, b->H, b->V, b->count, st);
+                case 3: return launch_pack_batch<3, T>(t, dyn, b->H, b->V, b->count, st);
+                case 4: return launch_pack_batch<4, T>(t, dyn, b->H, b->V, b->count, st);
+            }
+        }
+    }
     if constexpr (std::is_same<T, double>::value) {
         if (b->direct && b->pulls) return WX_OK;   // (the evaluation forms the tile-edge states itself: nothing to pack)
         if (b->direct) {
@@ -918,7 +944,7 @@ wx_status wx_euler3d_batch_create(wx_euler3d_batch** out, wx_euler3d_plan* const
         const char* env = getenv("WXHIP_BRICK_PULLS");
         const size_t points = (size_t)count * plans[0]->nelem * (size_t)(b->n * b->n * b->n);
         const bool wanted = env ? env[0] != '0' : points <= 262144;
-        bool all = b->direct && b->dtype == WX_F64 && count <= 30 && wanted;   // (30: a tile index + 1 in five bits)
+        bool all = b->direct && (b->dtype == WX_F64 || b->dtype == WX_DUAL128) && count <= 30 && wanted;   // (30: a tile index + 1 in five bits)
         for (int i = 0; i < count && all; ++i)
             for (int e = 0; e < 4 && all; ++e) {
                 bool found = false;
@@ -982,6 +1008,14 @@ wx_status wx_euler3d_batch_jvp(const wx_euler3d_batch* b, const double* q, const
     dyn.region = region; dyn.count = region_count(region, b->H, b->V);
     const EulerParams<dual>* t = static_cast<const EulerParams<dual>*>(b->table);
     WX_STREAM(st, stream);
+    if (b->direct && jvp_lean()) {
+        dyn.pulls = b->pulls ? 1 : 0;
+        switch (b->n) {
+            case 2: return launch_jvp_brick_batch<2>(t, dyn, b->H, b->V, b->count, st);
+            case 3: return launch_jvp_brick_batch<3>(t, dyn, b->H, b->V, b->count, st);
+            case 4: return launch_jvp_brick_batch<4>(t, dyn, b->H, b->V, b->count, st);
+        }
+    }
     switch (b->n) {
         case 2: return launch_jvp_batch<2>(t, dyn, b->count, st);
         case 3: return launch_jvp_batch<3>(t, dyn, b->count, st);

@@ -70,6 +70,7 @@ struct BrickBoxes {
 // library's log is 84 of them against 38.  The pack kernel of the one-kernel form takes the same function (euler3d_extrap.h,
 // PACK), so a tile-edge state is the same number whether a brick extrapolates it or the neighbour tile packs it.
 __device__ __forceinline__ double b_log(double x) { return lean_log(x); }
+__device__ __forceinline__ dual b_log(dual x) { return lean_log(x); }
 
 template <typename X>
 __device__ __forceinline__ X* raw_ptr(X* p) { return p; }
@@ -210,12 +211,13 @@ struct Surf { int d, plus, le, fp, ei, ej, ek, kind, pt2, pe2, pes, pfp; };
 // in bit 7 - picked out by a shift.  Not four members picked out by a select: a select between members of a block that lives in
 // memory becomes a load through a selected address and pins the block in scratch, see the note above brick_face_metric.)
 struct BrickBatchCtx {
-    const EulerParams<double>* table;
+    const void* table;  // the launch's parameter table, or null: no pulls
     long long stride;   // doubles between consecutive tiles' states
     int self;
     unsigned packed;
 };
-__device__ __forceinline__ unsigned brick_pack_pulls(const EulerParams<double>* me) {
+template <typename T>
+__device__ __forceinline__ unsigned brick_pack_pulls(const EulerParams<T>* me) {
     unsigned w = 0;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -346,8 +348,10 @@ __device__ __forceinline__ void brick_face_stage(const EulerParams<T, G>& P, con
     // ---- the first surface item: decode and LOADS, now
     T nv[N][5], hv[5];
     double g0, g1, g2, g3, px;
+    // (dual numbers: twice the registers per value - the first surface item's loads are issued where they are used)
+    constexpr bool PREFETCH = std::is_same<T, double>::value;
     Surf u = surf_decode<N, T, G>(P, ctx, bk, tid < nS ? tid : 0, s0, s1, s2, m_vi, m_vj, H, V);
-    if (k2 > 0) {
+    if (PREFETCH && k2 > 0) {
         brick_face_metric<N, T, G>(sgi, sgj, sgk, hi, hj, hk, H, V, u.ek, u.ej, u.ei, u.d, u.plus, u.fp, g0, g1, g2, g3);
         surf_load<N, T>(P, ctx, u, halo_s, halo_n, halo_w, halo_e, nv, hv, px);
     }
@@ -377,7 +381,7 @@ __device__ __forceinline__ void brick_face_stage(const EulerParams<T, G>& P, con
             brick_extrap_lds<N, T>(img, img_stride, nle * C::LE + lbase, lstride, P.K->em, qR, lgR);
             both = true;
         } else {
-            if (it > k1) {   // (a later surface item of this thread: its loads here)
+            if (it > k1 || !PREFETCH) {   // (a later surface item of this thread: its loads here)
                 u = surf_decode<N, T, G>(P, ctx, bk, tid + (it - k1) * BS, s0, s1, s2, m_vi, m_vj, H, V);
                 brick_face_metric<N, T, G>(sgi, sgj, sgk, hi, hj, hk, H, V, u.ek, u.ej, u.ei, u.d, u.plus, u.fp, g0, g1, g2, g3);
                 surf_load<N, T>(P, ctx, u, halo_s, halo_n, halo_w, halo_e, nv, hv, px);
@@ -526,7 +530,7 @@ struct BrickFaceStore {
 template <int N, typename T, bool EPI, bool G>
 __device__ __forceinline__ void euler_brick_body(const EulerParams<T, G>& P, const BrickBoxes& GB, const BrickBatchCtx& ctx) {
     using C = BrickCfg<N>;
-    static_assert(std::is_same<T, double>::value, "the brick form of the fused kernel: float64");
+    static_assert(std::is_same<T, double>::value, "the brick form of the fused kernel: float64 (the dual form: euler3d_brick_jvp.h)");
     constexpr int N2 = C::N2, N3 = C::N3, EPB = C::EPB, BS = C::BS;
     constexpr int NF = 8;   // staged fields: 4 F rows, A, B (per direction) + log p + sqrtG*rho
     constexpr int NC = 7;   // face quantities, see rusanov_face

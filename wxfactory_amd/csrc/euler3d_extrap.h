@@ -103,7 +103,7 @@ __device__ __forceinline__ void euler_extrap_body(const EulerParams<T, G>& P) {
             const int lp = le * C::LE + C::lidx(pt / N2, (pt / N) % N, pt % N);
             T a0, a1, a2, a3, a4;
             load_state<T>(P, o, fs, a0, a1, a2, a3, a4);
-            if constexpr (PACK && std::is_same<T, double>::value) {   // (the one-kernel form's logarithm: euler3d_brick.h, b_log)
+            if constexpr (PACK && !std::is_same<T, cplx>::value) {   // (the one-kernel form's logarithm: euler3d_brick.h, b_log)
                 fld[0][lp] = lean_log(a0);
                 fld[4][lp] = lean_log(a4);
             } else {

@@ -119,6 +119,35 @@ static wx_status launch_brick_batch(const EulerParams<double>* table, const Eule
     }
 }
 
+template <int N>
+static wx_status launch_jvp_brick(const EulerParams<dual>& P, hipStream_t st) {
+    if constexpr (BrickCfg<N>::on) {
+        using C = BrickCfg<N>;
+        if (P.count == 0) return WX_OK;
+        const BrickBoxes GB = brick_boxes(C::LOG_EPB, brick_lk_default<N>(), P.region, P.H, P.V);
+        hipLaunchKernelGGL((euler_jvp_brick_kernel<N>), dim3(8 * ((GB.nbricks + 7) / 8)), dim3(C::BS), 0, st, P, GB);
+        WX_HIP_TRY(hipGetLastError());
+        return WX_OK;
+    } else {
+        return fail(WX_ERR_UNSUPPORTED, "the one-kernel form serves num_solpts 2..4, not %d", N);
+    }
+}
+
+template <int N>
+static wx_status launch_jvp_brick_batch(const EulerParams<dual>* table, const EulerBatchDyn<dual>& dyn, int H, int V, int ntiles,
+                                        hipStream_t st) {
+    if constexpr (BrickCfg<N>::on) {
+        using C = BrickCfg<N>;
+        if (dyn.count == 0) return WX_OK;
+        const BrickBoxes GB = brick_boxes(C::LOG_EPB, brick_lk_default<N>(), dyn.region, H, V);
+        hipLaunchKernelGGL((euler_jvp_brick_batch_kernel<N>), dim3(8 * ((GB.nbricks + 7) / 8), ntiles), dim3(C::BS), 0, st, table, dyn, GB);
+        WX_HIP_TRY(hipGetLastError());
+        return WX_OK;
+    } else {
+        return fail(WX_ERR_UNSUPPORTED, "the one-kernel form serves num_solpts 2..4, not %d", N);
+    }
+}
+
 // the pack kernel of the one-kernel form: the ring's outward faces -> edge messages
 template <int N, typename T>
 static wx_status launch_pack(EulerParams<T> P, hipStream_t st) {

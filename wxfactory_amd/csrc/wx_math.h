@@ -185,6 +185,8 @@ __device__ __forceinline__ dual w_min(dual a, dual b) {
 }
 __device__ __forceinline__ double w_real(dual z) { return z.re; }
 
+__device__ __forceinline__ dual lean_log(dual z) { return {lean_log(z.re), z.im / z.re}; }   // (w_log(dual) with the lean value part)
+
 // select between values: component-wise for the two-double types (a ternary on the aggregate makes
 // the compiler route register arrays of them through scratch memory)
 __device__ __forceinline__ double w_sel(bool c, double a, double b) { return c ? a : b; }
