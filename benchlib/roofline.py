@@ -15,7 +15,7 @@ ALGO_BYTES_PER_POINT = 384.0  # 360 B/point fields + 24 B/
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 KERNEL_SOURCES = ("wxfactory_amd/csrc/euler3d.hip", "wxfactory_amd/csrc/euler3d_common.h", "wxfactory_amd/csrc/euler3d_extrap.h",
-                  "wxfactory_amd/csrc/euler3d_rhs.h", "wxfactory_amd/csrc/euler3d_brick.h", "wxfactory_amd/csrc/euler3d_jvp.h", "wxfactory_amd/csrc/euler3d_launch.h",
+                  "wxfactory_amd/csrc/euler3d_rhs.h", "wxfactory_amd/csrc/euler3d_brick.h", "wxfactory_amd/csrc/euler3d_brick_jvp.h", "wxfactory_amd/csrc/euler3d_jvp.h", "wxfactory_amd/csrc/euler3d_launch.h",
                   "wxfactory_amd/csrc/wx_math.h", "wxfactory_amd/csrc/wx_mfma.h", "wxfactory_amd/csrc/wx_common.h",
                   "wxfactory_amd/csrc/wx_panels.h")
 
@@ -64,7 +64,7 @@ def pmc_traffic(region, n, H, V, bpp=ALGO_BYTES_PER_POINT):
 
 
 FP64_MFMA_PEAK_TFLOPS = 78.6    # SURVEY 8d; = 512 flop per 16 issue cycles per SIMD (tools/mfma_f64_probe.hip) x 1024 SIMDs x 2.4 GHz
-SQ_COUNTERS = "r06_v1_k2_sq_counters.json"   # (falls back to round 5's pass of the same kernel until this round's is installed)
+SQ_COUNTERS = "r06_v2_k2_sq_counters.json"   # (falls back to round 5's pass of the same kernel until this round's is installed)
 SQ_COUNTERS_FALLBACK = "r05_v4_k2_sq_counters.json"
 
 

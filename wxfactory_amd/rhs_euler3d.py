@@ -199,6 +199,9 @@ class Euler3DPlan:
                         dual=dual, on_panel_edge=self.on_panel_edge)
         if self.column_metric:
             t.enable_column_metric("auto", slabs=self._column_slabs)   # (the same slabs: no second check, no second copy)
+        # the form chosen for this plan (set_one_kernel) goes with the twin, where the twin's dtype offers it
+        if (dtype == torch.float64 or dual) and self.n <= 4 and self.dtype == torch.float64 and t.one_kernel != self.one_kernel:
+            t.set_one_kernel(self.one_kernel)
         return t
 
     def _check_q(self, q):
