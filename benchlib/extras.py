@@ -129,6 +129,23 @@ def ini_size_extras(dev, seed):
             ts.append(time.perf_counter() - t0)
         out[label].update(epi2_dt_s=dt_ini, epi2_step_ms=round(sorted(ts[3:])[2] * 1e3, 2),
                           epi2_krylov_vectors=int(epi.solver_info["iterations"]))
+        # BASELINE config 4's integrator at this size: Rosenbrock-2 + FGMRES (integrators/ros2.py:24-81), the Gram-Schmidt step on
+        # the device and one read-back per pass of Krylov vectors (include/wxhip.h: wx_fgmres_vector)
+        from wxfactory_amd.integrators import Ros2
+
+        ros, Qr, tr = Ros2(rhs, tol=1e-7, gmres_restart=30), Q, []
+        for i in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            Qr = ros.step(Qr, dt_ini)
+            torch.cuda.synchronize()
+            tr.append(time.perf_counter() - t0)
+        si = ros.solver_info
+        med = sorted(tr[1:])[1]
+        out[label].update(ros2_fgmres_step_ms=round(med * 1e3, 2), ros2_fgmres_iterations=int(si["iterations"]),
+                          ros2_fgmres_us_per_iteration=round(med / max(1, si["iterations"]) * 1e6, 1),
+                          ros2_fgmres_device_passes=si.get("device_passes"), ros2_fgmres_wasted_vectors=si.get("wasted_vectors"),
+                          one_kernel_form=bool(plans[0].one_kernel))
     return out
 
 
