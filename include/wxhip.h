@@ -775,7 +775,11 @@ wx_status wx_pair_update(double* a, double* b, const double* V, size_t ldv, int 
  * estimate falls under the host algorithm's thresholds (a breakdown, a suspect cancellation, a NaN): that step and the later
  * ones of the pass leave the rows untouched, and the caller redoes them on the host.  The host reads R once per PASS of
  * several vectors and finds the iteration the reference would have stopped at from its columns; vectors built past it are
- * discarded.  workspace: wx_fgmres_workspace(ld) doubles.
+ * discarded.  workspace: wx_fgmres_workspace(ld) doubles.  On one rank and up to 262 144 components the step is three launches
+ * (products of all rows, algebra, update of both rows); with WXHIP_FGMRES_ONE_LAUNCH=1 in the environment ONE, its <= 128
+ * workgroups meeting at a barrier inside it (never under stream capture): the same bits, the same time - and a launch that needs
+ * all its workgroups resident at once, which a GPU shared with other processes does not promise; a workgroup that waits in vain
+ * sets *flag = -1.
  * wx_euler3d_batch_fgmres_vector: the same with the finite-difference Rosenbrock operator in front (integrators/ros2.py:27-30,
  * solvers/matvec.py:76-88): row J-1 = A(row J-2 / s) s with s = vn[J-3] read by the kernels from device memory. */
 size_t wx_fgmres_workspace(int rows);

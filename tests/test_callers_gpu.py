@@ -174,6 +174,44 @@ def test_fgmres_device_passes_take_the_host_loop_decisions(setup, monkeypatch):
     assert (((res["1"][0] - res["0"][0]).abs().amax(dim=ax)) <= 1e-8 * upd).all()
 
 
+@pytest.mark.parametrize("n", [3000, 29160, 103680, 131072, 200000, 262144])
+def test_fgmres_step_in_one_launch_is_the_three_launch_step(built_lib, monkeypatch, n):
+    """wx_fgmres_vector at launch-bound lengths: products, the step's algebra and the update of the two rows from ONE launch (the
+    workgroups meet at a barrier inside it) against the three launches it replaces - the same bits in every row, in R, T, K, the
+    norms and the coefficients, over a run of steps on one workspace (the barrier's sequence numbers), flag clear."""
+    from wxfactory_amd import _lib
+
+    lib = _lib.load()
+    rows, steps = 14, 10
+    gen = torch.Generator(device=DEV).manual_seed(7 + n)
+    V0 = torch.randn((rows, n), generator=gen, device=DEV, dtype=torch.float64)
+    q, _ = torch.linalg.qr(V0[:2].T)
+    V0[:2] = q.T.contiguous()
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("WXHIP_FGMRES_ONE_LAUNCH", mode)
+        V = V0.clone()
+        st = torch.zeros(3 * rows * rows + rows + 1, dtype=torch.float64, device=DEV)
+        R, T, K = (st[i * rows * rows: (i + 1) * rows * rows] for i in range(3))
+        vn = st[3 * rows * rows: 3 * rows * rows + rows]
+        flag = st[3 * rows * rows + rows:].view(torch.int32)[:1]
+        coef = torch.zeros(3 * rows, dtype=torch.float64, device=DEV)
+        work = torch.full((int(lib.wx_fgmres_workspace(rows)),), float("nan"), dtype=torch.float64, device=DEV)   # (nothing to zero)
+        stream = torch.cuda.current_stream().cuda_stream
+        for J in range(3, 3 + steps):
+            _lib.check(lib.wx_fgmres_vector(V.data_ptr(), V.stride(0), J, n, R.data_ptr(), T.data_ptr(), K.data_ptr(), rows,
+                                            coef.data_ptr(), vn.data_ptr(), flag.data_ptr(), work.data_ptr(), None, stream),
+                       "wx_fgmres_vector")
+        torch.cuda.synchronize()
+        out[mode] = (V, st.clone(), coef)
+    assert int(out["1"][1][3 * rows * rows + rows:].view(torch.int32)[0]) == 0
+    for a, b in zip(out["1"], out["0"]):
+        assert torch.equal(a, b)
+    # and the steps did something: the rows the steps finished are orthonormal
+    G = out["1"][0][: steps + 1] @ out["1"][0][: steps + 1].T
+    assert float((G - torch.eye(steps + 1, device=DEV, dtype=torch.float64)).abs().max()) < 1e-10
+
+
 def test_kiops_and_epi2_step(setup):
     """phi_1(dt J) R through KIOPS with the complex-step JVP, and the EPI2 step built on it
     (the integrator config/dcmip31.ini actually ships with), against the reference's kiops.py/epi.py."""

@@ -36,8 +36,9 @@ for label, case, n, H, V, ztop, dt in (("dcmip31.ini", 31, 2, 12, 3, 10000.0, 30
         matvec_rat(v, dt, Q, R, rhs)
     torch.cuda.synchronize()
     mv = (time.perf_counter() - t0) / 200
-    for ortho, vec in (("igs", "1"), ("igs", "0"), ("cgs", "0")):
+    for ortho, vec, one in (("igs", "1", "1"), ("igs", "1", "0"), ("igs", "0", "1"), ("cgs", "0", "1")):
         os.environ["WXHIP_FGMRES_VECTOR"] = vec   # 1: device passes (one read-back per pass of several vectors), 0: one per vector
+        os.environ["WXHIP_FGMRES_ONE_LAUNCH"] = one   # 1: the step's products, algebra and update from one launch, 0: three
         ros, Qs, ts = Ros2(rhs, tol=1e-7, gmres_restart=30, ortho=ortho), Q, []
         for i in range(4):
             torch.cuda.synchronize()
@@ -48,7 +49,8 @@ for label, case, n, H, V, ztop, dt in (("dcmip31.ini", 31, 2, 12, 3, 10000.0, 30
         it = ros.solver_info["iterations"]
         med = sorted(ts[1:])[1]
         si = ros.solver_info
-        print(f"{label} ros2 + fgmres({ortho}, device passes {'on' if vec == '1' else 'off'}): step {med*1e3:.2f} ms, {it} iterations, "
+        print(f"{label} ros2 + fgmres({ortho}, device passes {'on' if vec == '1' else 'off'}{', one-launch step' if vec == '1' and one == '1' else ''}): step {med*1e3:.2f} ms, {it} iterations, "
               f"{med/it*1e6:.1f} us per iteration; operator {mv*1e6:.1f} us; flag {si['flag']}; passes {si.get('device_passes')}, "
-              f"vectors built {si.get('vectors_built')}, wasted {si.get('wasted_vectors')}, redone on the host {si.get('host_redone_steps')}",
+              f"vectors built {si.get('vectors_built')}, wasted {si.get('wasted_vectors')}, redone on the host {si.get('host_redone_steps')}; "
+              f"host: enqueue {si.get('enqueue_s', 0)*1e3:.2f} ms, wait {si.get('wait_s', 0)*1e3:.2f} ms, cycle ends {si.get('cycle_end_s', 0)*1e3:.2f} ms",
               flush=True)

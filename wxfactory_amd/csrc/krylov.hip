@@ -9,10 +9,11 @@
 // Deterministic: multi_dot reduces per workgroup into a partial buffer, a second tiny kernel sums the partials in
 // a fixed order (no floating-point atomics).
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <cstdlib>
 
 #include "wx_common.h"
 
-#include <cstdlib>
 
 namespace wx {
 
@@ -792,47 +793,78 @@ using namespace wx;
 // ---- the two vector kernels of a Krylov step at LAUNCH-BOUND lengths (fgmres' device pass at the sizes of the shipped .ini files:
 // 30 k - 100 k components): any number of basis rows in ONE launch each, where the row-batched kernels above take a launch per
 // 16 rows - the time of such a step is the number of its launches.
-//   multi_dot2_small   partial[block][2 J]: <V[r], a>, <V[r], b>, r < J; a thread keeps its (at most kSmallEpt) components of a and
-//                      b in registers and walks the rows; needs n <= gridDim.x * 256 * kSmallEpt
+//   multi_dot2_small   partial[block][2 J]: <V[r], a>, <V[r], b>, r < J over the workgroup's chunk of 256 ept components
+//                      (small_products); needs n <= gridDim.x * kSmallThreads * ept, ept <= kSmallEpt
 //   pair_update_small  a -= sum_r ha[r] V[r]; b -= sum_r hb[r] V[r]; a *= dsc[0]; b = (b - dsc[1] a) dsc[2]   (m <= 64 rows)
-constexpr int kSmallEpt = 8;
-constexpr int kSmallMaxLen = 64 * 256 * kSmallEpt;   // with kGsFusedBlocks = 64 workgroups
 
-__global__ __launch_bounds__(256) void multi_dot2_small_kernel(const double* __restrict__ V, size_t ldv, int J,
-                                                               const double* __restrict__ a, const double* __restrict__ b, size_t n,
-                                                               double* __restrict__ partial) {
-    __shared__ double red[4][128];
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    double av[kSmallEpt], bv[kSmallEpt];
-#pragma unroll
-    for (int e = 0; e < kSmallEpt; ++e) {
-        const size_t i = i0 + e * stride;
-        av[e] = i < n ? a[i] : 0.0;
-        bv[e] = i < n ? b[i] : 0.0;
+// The products of a workgroup's chunk (kSmallThreads ept components from c0; ept <= kSmallEpt): a and b of the chunk staged in LDS,
+// the ROWS dealt over the sixteen waves, a wave's row components all in flight before the first product - one wave reduction per
+// row and workgroup (each wave walking every row over its own lanes' components took four, six dependent cross-lane steps each),
+// and 16 loads per lane in flight (four waves with 8 each moved 1 TB/s at 100 k components: 14 us).
+// red[r] = <V[r], a>, red[64 + r] = <V[r], b> over the chunk, valid after the barrier.
+constexpr int kSmallThreads = 1024;
+constexpr int kSmallEpt = 2;
+constexpr int kSmallBlocks = 128;    // at most (the one-launch step's barrier: two words per lane of the waiting wave)
+constexpr int kSmallMaxLen = kSmallBlocks * kSmallThreads * kSmallEpt;
+
+__device__ __forceinline__ void small_products(const double* __restrict__ V, size_t ldv, int J, const double* a, const double* b,
+                                               size_t n, int ept, double* sa, double* sb, double* red) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t c0 = (size_t)blockIdx.x * kSmallThreads * ept;
+    for (int e = 0; e < ept; ++e) {
+        const int k = tid + kSmallThreads * e;
+        const size_t i = c0 + k;
+        sa[k] = i < n ? a[i] : 0.0;
+        sb[k] = i < n ? b[i] : 0.0;
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int r = 0; r < J; ++r) {
-        const double* row = V + (size_t)r * ldv;
+    __syncthreads();
+    for (int r = wave; r < J; r += kSmallThreads / 64) {
+        const double* row = V + (size_t)r * ldv + c0;
         double pa = 0.0, pb = 0.0;
+        for (int e0 = 0; e0 < ept; ++e0) {   // (a batch: 16 components per lane)
+            double v[16];
 #pragma unroll
-        for (int e = 0; e < kSmallEpt; ++e) {
-            const size_t i = i0 + e * stride;
-            const double v = i < n ? row[i] : 0.0;
-            pa += v * av[e];
-            pb += v * bv[e];
+            for (int e = 0; e < 16; ++e) {
+                const int k = lane + 64 * (16 * e0 + e);
+                v[e] = c0 + k < n ? row[k] : 0.0;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = lane + 64 * (16 * e0 + e);
+                pa += v[e] * sa[k];
+                pb += v[e] * sb[k];
+            }
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             pa += __shfl_down(pa, off, 64);
             pb += __shfl_down(pb, off, 64);
         }
-        if (lane == 0) { red[wave][r] = pa; red[wave][64 + r] = pb; }
+        if (lane == 0) { red[r] = pa; red[64 + r] = pb; }
     }
     __syncthreads();
+}
+
+// components per thread such that kSmallBlocks workgroups cover n
+static inline int small_ept(size_t n) {
+    const size_t per = (size_t)kSmallBlocks * kSmallThreads;
+    const size_t e = (n + per - 1) / per;
+    return (int)(e < 1 ? 1 : e);
+}
+static inline int small_blocks(size_t n, int ept) {
+    const size_t per = (size_t)kSmallThreads * ept;
+    const size_t g = (n + per - 1) / per;
+    return (int)(g < 1 ? 1 : g);
+}
+
+__global__ __launch_bounds__(kSmallThreads) void multi_dot2_small_kernel(const double* __restrict__ V, size_t ldv, int J,
+                                                                         const double* __restrict__ a, const double* __restrict__ b,
+                                                                         size_t n, int ept, double* __restrict__ partial) {
+    __shared__ double sa[kSmallThreads * kSmallEpt], sb[kSmallThreads * kSmallEpt], red[128];
+    small_products(V, ldv, J, a, b, n, ept, sa, sb, red);
     if ((int)threadIdx.x < 2 * J) {
-        const int k = threadIdx.x < J ? threadIdx.x : 64 + ((int)threadIdx.x - J);
-        partial[(size_t)blockIdx.x * 2 * J + threadIdx.x] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+        const int k = (int)threadIdx.x < J ? (int)threadIdx.x : 64 + ((int)threadIdx.x - J);
+        partial[(size_t)blockIdx.x * 2 * J + threadIdx.x] = red[k];
     }
 }
 
@@ -871,34 +903,63 @@ constexpr double kGsSuspect = 1e-12, kGsBreakdown = 1e-14;
 constexpr int kGsFusedBlocks = 64;            // workgroups of the products where the step kernel sums their partials itself
 constexpr int kGsFusedMaxLen = 2 * 1024 * 1024;   // ... for vectors up to this length (beyond: 2048 blocks and the finish launch)
 
-__global__ __launch_bounds__(256) void fgmres_gs_step_kernel(const double* __restrict__ G, const double* __restrict__ partial,
-                                                             int blocks, int J, double* __restrict__ R, double* __restrict__ T,
-                                                             double* __restrict__ K, int ld, double* __restrict__ coef,
-                                                             double* __restrict__ vn, int* __restrict__ flag) {
-    const int i = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m2 = J - 2;
-    double ga = 0.0, gb = 0.0;
-    if (partial != nullptr) {
-        // the products' partial sums (multi_dot2_kernel: [block][2 J]) summed here, four waves over the blocks: no finish launch
-        __shared__ double red[4][128];
-        double xa = 0.0, xb = 0.0;
-        if (i < J)
-            for (int blk = wave; blk < blocks; blk += 4) {
-                xa += partial[(size_t)blk * 2 * J + i];
-                xb += partial[(size_t)blk * 2 * J + J + i];
-            }
-        red[wave][i] = xa;
-        red[wave][64 + i] = xb;
-        __syncthreads();
-        if (wave != 0) return;
-        ga = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
-        gb = (red[0][64 + i] + red[1][64 + i]) + (red[2][64 + i] + red[3][64 + i]);
-    } else {
-        if (wave != 0) return;
-        ga = i < J ? G[i] : 0.0;
-        gb = i < J ? G[J + i] : 0.0;
+// the step's small algebra, one wave (lane i = row i); ga, gb: the lane's two products
+// Values one workgroup of the one-launch step leaves for the others (partial sums, update coefficients) travel as agent-scope
+// relaxed atomics: stores written through, loads served from the coherent level - with whole fences (__threadfence: write back and
+// invalidate the XCD's L2) around the barrier the launch took 85 us more, at any size.
+// lane k's value in every lane, k uniform: two v_readlane (the general shuffle goes through the LDS crossbar, ~100 cycles on the
+// dependent chain of the substitutions below)
+__device__ __forceinline__ double lane_bcast(double v, int k) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), k), __builtin_amdgcn_readlane(__double2loint(v), k));
+}
+__device__ __forceinline__ void gs_put(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double gs_get(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// sT[k * 64 + i] = T[k][i] (k, i < J-2) and sRt[c * 65 + i] = R[i][1 + c] (i < J-1, c < J-3): what the two dependent chains below
+// read, staged by the whole workgroup (gs_stage) - from global memory each of their ~2 (J-2) steps was a round trip
+// sRt[63 * 65 + i] = K[i][J-3] (the lagged products' column, i < J-2) and sRt[64 * 65 - 1] = the flag (as a double): no global load
+// is left on the algebra's chain
+constexpr int kGsStageT = 64 * 64, kGsStageR = 64 * 65;
+__device__ __forceinline__ void gs_stage(const double* T, const double* R, const double* K, const int* flag, int J, int ld, double* sT,
+                                         double* sRt) {
+    const int m2 = J - 2, m3 = J - 3;
+    if ((int)threadIdx.x < m2 && m3 >= 0) sRt[63 * 65 + threadIdx.x] = K[threadIdx.x * ld + (m3 > 0 ? m3 : 0)];
+    if (threadIdx.x == 64) sRt[64 * 65 - 1] = (double)*flag;
+    // (batches of eight loads in flight: one element per trip of the loop was a memory round trip per element)
+    const int bs = blockDim.x;
+    for (int base = threadIdx.x; base < m2 * m2; base += 8 * bs) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * bs, k = idx / m2, i = idx - k * m2;
+            t[u] = idx < m2 * m2 ? T[k * ld + i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * bs, k = idx / m2, i = idx - k * m2;
+            if (idx < m2 * m2) sT[k * 64 + i] = t[u];
+        }
     }
-    const bool dead = *flag != 0;
+    if (m3 > 0)
+        for (int base = threadIdx.x; base < (J - 1) * m3; base += 8 * bs) {
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * bs, i = idx / m3, c = idx - i * m3;
+                t[u] = idx < (J - 1) * m3 ? R[i * ld + 1 + c] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * bs, i = idx / m3, c = idx - i * m3;
+                if (idx < (J - 1) * m3) sRt[c * 65 + i] = t[u];
+            }
+        }
+}
+
+__device__ __forceinline__ void gs_step_algebra(int i, double ga, double gb, int J, double* R, double* T, double* K, int ld, double* coef,
+                                                double* vn, int* flag, const double* sT, const double* sRt) {
+    const int m2 = J - 2;
+    const bool dead = sRt[64 * 65 - 1] != 0.0;
     const double s = i < m2 ? ga : 0.0;
     double ss = s * s, sR = s * gb;
 #pragma unroll
@@ -906,40 +967,202 @@ __global__ __launch_bounds__(256) void fgmres_gs_step_kernel(const double* __res
         ss += __shfl_xor(ss, off, 64);
         sR += __shfl_xor(sR, off, 64);
     }
-    const double gaa = __shfl(ga, m2, 64), gbb = __shfl(gb, m2, 64);   // <a, a>, <a, b>
+    const double gaa = lane_bcast(ga, m2), gbb = lane_bcast(gb, m2);   // <a, a>, <a, b>
     const double d = gaa - ss;
     const bool bad = dead || !(d == d) || d <= kGsSuspect * gaa;        // (suspect, breakdown, NaN: the host form's branches)
     if (bad) {
         if (i == 0 && !dead) *flag = J;
-        if (i < m2) { coef[i] = 0.0; coef[ld + i] = 0.0; }
-        if (i == 0) { coef[2 * ld] = 1.0; coef[2 * ld + 1] = 0.0; coef[2 * ld + 2] = 1.0; vn[m2] = 1.0; }
+        if (i < m2) { gs_put(coef + i, 0.0); gs_put(coef + ld + i, 0.0); }
+        if (i == 0) { gs_put(coef + 2 * ld, 1.0); gs_put(coef + 2 * ld + 1, 0.0); gs_put(coef + 2 * ld + 2, 1.0); vn[m2] = 1.0; }
         return;
     }
     const double norm = sqrt(d);
     const double cross = (gbb - sR) / norm;
     const double colJ1 = i == m2 ? cross : gb;                          // column J-1, rows 0 .. J-2
     if (i < J - 1) R[i * ld + J - 1] = colJ1;
-    if (i == 0) { R[m2 * ld + m2] = norm; vn[m2] = norm; coef[2 * ld] = 1.0 / norm; coef[2 * ld + 1] = cross; coef[2 * ld + 2] = 1.0 / norm; }
-    if (i < m2) { T[i * ld + m2] = s / norm; coef[i] = s; coef[ld + i] = gb; }
+    if (i == 0) { R[m2 * ld + m2] = norm; vn[m2] = norm; gs_put(coef + 2 * ld, 1.0 / norm); gs_put(coef + 2 * ld + 1, cross); gs_put(coef + 2 * ld + 2, 1.0 / norm); }
+    if (i < m2) { T[i * ld + m2] = s / norm; gs_put(coef + i, s); gs_put(coef + ld + i, gb); }
     if (m2 > 0) {
         // L r3 = s, L = I + strict lower part of T[:m2, :m2]^T: forward substitution, column by column
         double acc = s;
         for (int k = 0; k < m2; ++k) {
-            const double rk = __shfl(acc, k, 64);
-            if (i > k && i < m2) acc -= T[k * ld + i] * rk;
+            const double rk = lane_bcast(acc, k);
+            if (i > k && i < m2) acc -= sT[k * 64 + i] * rk;
         }
         // column J-2 finished (the lagged correction); kept in a register for the product below: rows < J-2, then the norm
-        const double colJ2 = i < m2 ? K[i * ld + (J - 3)] + acc : (i == m2 ? norm : 0.0);
+        const double colJ2 = i < m2 ? sRt[63 * 65 + i] + acc : (i == m2 ? norm : 0.0);
         if (i < m2) R[i * ld + m2] = colJ2;
         // K[:J-1, J-2] = (R[:J-1, J-1] - R[:J-1, 1:J-1] @ r3) / norm   (columns 1 .. J-3 from memory, column J-2 from the register)
         double dot = 0.0;
         for (int c = 0; c < m2; ++c) {
-            const double rc = __shfl(acc, c, 64);
-            if (i < J - 1) dot += (c == m2 - 1 ? colJ2 : R[i * ld + 1 + c]) * rc;
+            const double rc = lane_bcast(acc, c);
+            if (i < J - 1) dot += (c == m2 - 1 ? colJ2 : sRt[c * 65 + i]) * rc;
         }
         if (i < J - 1) K[i * ld + m2] = (colJ1 - dot) / norm;
     } else if (i == 0) {
         K[0] = cross / norm;
+    }
+}
+
+// the products' partial sums ([block][2 J]) summed by four waves over the blocks -> wave 0's lanes hold <V[i], a>, <V[i], b>
+// (returns false on the other three waves)
+__device__ __forceinline__ bool gs_sum_partials(const double* partial, int blocks, int J, double (*red)[128], double& ga, double& gb) {
+    const int i = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double xa = 0.0, xb = 0.0;
+    if (i < J && wave < 4)
+        for (int blk0 = wave; blk0 < blocks; blk0 += 32) {   // (eight blocks' pairs in flight, summed in the order of the blocks)
+            double ta[8], tb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int blk = blk0 + 4 * u;
+                ta[u] = blk < blocks ? gs_get(partial + (size_t)blk * 2 * J + i) : 0.0;
+                tb[u] = blk < blocks ? gs_get(partial + (size_t)blk * 2 * J + J + i) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                xa += ta[u];
+                xb += tb[u];
+            }
+        }
+    if (wave < 4) {   // (the one-launch step runs it with sixteen waves)
+        red[wave][i] = xa;
+        red[wave][64 + i] = xb;
+    }
+    __syncthreads();
+    if (wave != 0) return false;
+    ga = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+    gb = (red[0][64 + i] + red[1][64 + i]) + (red[2][64 + i] + red[3][64 + i]);
+    return true;
+}
+
+__global__ __launch_bounds__(256) void fgmres_gs_step_kernel(const double* __restrict__ G, const double* __restrict__ partial,
+                                                             int blocks, int J, double* R, double* T, double* K, int ld, double* coef,
+                                                             double* vn, int* flag) {
+    __shared__ double sT[kGsStageT], sRt[kGsStageR];
+    __shared__ double red[4][128];
+    const int i = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    gs_stage(T, R, K, flag, J, ld, sT, sRt);
+    double ga = 0.0, gb = 0.0;
+    if (partial != nullptr) {   // (multi_dot2_kernel's partial sums summed here: no finish launch)
+        if (!gs_sum_partials(partial, blocks, J, red, ga, gb)) return;
+    } else {
+        __syncthreads();
+        if (wave != 0) return;
+        ga = i < J ? G[i] : 0.0;
+        gb = i < J ? G[J + i] : 0.0;
+    }
+    gs_step_algebra(i, ga, gb, J, R, T, K, ld, coef, vn, flag, sT, sRt);
+}
+
+// ---- a whole Gram-Schmidt step of fgmres' device pass in ONE launch at launch-bound lengths: the products of all rows with the
+// two newest (multi_dot2_small), the step's algebra (by the workgroup that arrives last), the update of the two rows
+// (pair_update_small) - three dependent launches of ~10 us each otherwise.  The <= kSmallBlocks workgroups are all resident
+// (256 CUs); they meet at a barrier through 1 + kSmallBlocks words of the workspace, each set to (kGsMagic << 32) | sequence
+// number: sync[1 + g] by workgroup g when its products are written, sync[0] by workgroup 0 when the coefficients are
+// (the sequence number is the library's, one per launch: nothing has to be zeroed, an aborted launch leaves nothing behind).  A
+// workgroup's components of a and b stay in its registers from the products to the update.  The wait is bounded: a workgroup that
+// does not see the release within kGsSpinLimit polls sets flag = -1 and leaves its rows untouched (the host raises).
+constexpr unsigned long long kGsMagic = 0x57584753ull;
+constexpr unsigned kGsSpinLimit = 1u << 22;
+
+__global__ __launch_bounds__(kSmallThreads) void fgmres_vector_small_kernel(double* __restrict__ V, size_t ldv, int J, size_t n, int ept,
+                                                                  double* partial, double* R, double* T, double* K, int ld,
+                                                                  double* coef, double* vn, int* flag, unsigned long long* sync,
+                                                                  unsigned seq) {
+    __shared__ double sT[kGsStageT], sRt[kGsStageR];
+    __shared__ double sa[kSmallThreads * kSmallEpt], sb[kSmallThreads * kSmallEpt];
+    __shared__ double red[4][128];
+    __shared__ double ca[64], cb[64], sc[3];
+    __shared__ int s_lost;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double* a = V + (size_t)(J - 2) * ldv;
+    double* b = V + (size_t)(J - 1) * ldv;
+    // ---- products (multi_dot2_small_kernel's arithmetic); this workgroup's components of a and b stay in LDS for the update
+    small_products(V, ldv, J, a, b, n, ept, sa, sb, red[0]);
+    if (tid < 2 * J) {
+        const int k = tid < J ? tid : 64 + (tid - J);
+        gs_put(partial + (size_t)blockIdx.x * 2 * J + tid, red[0][k]);
+    }
+    __syncthreads();   // (waits for this workgroup's stores as well)
+    // ---- arrive: a word per workgroup; workgroup 0 waits for all of them, does the step's algebra and releases the others
+    // (no read-modify-write: sixty-four workgroups retrying a compare-and-swap on one word took 80 us)
+    const unsigned long long released = (kGsMagic << 32) | (unsigned long long)seq;
+    if (tid == 0) {
+        s_lost = 0;
+        __hip_atomic_store(&sync[1 + blockIdx.x], released, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (blockIdx.x == 0) {
+        gs_stage(T, R, K, flag, J, ld, sT, sRt);
+        if (wave == 0) {
+            unsigned polls = 0;
+            for (;;) {
+                const bool here = (lane >= (int)gridDim.x ||
+                                   __hip_atomic_load(&sync[1 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == released) &&
+                                  (lane + 64 >= (int)gridDim.x ||
+                                   __hip_atomic_load(&sync[1 + 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == released);
+                if (__all(here)) break;
+                if (++polls > kGsSpinLimit) {
+                    if (lane == 0) s_lost = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __syncthreads();
+        if (!s_lost) {   // (uniform over the workgroup)
+            double ga = 0.0, gb = 0.0;
+            if (gs_sum_partials(partial, (int)gridDim.x, J, red, ga, gb)) gs_step_algebra(lane, ga, gb, J, R, T, K, ld, coef, vn, flag, sT, sRt);
+            __syncthreads();   // (wave 0's stores of the coefficients are complete)
+            if (tid == 0) __hip_atomic_store(&sync[0], released, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else if (tid == 0) {
+        unsigned polls = 0;
+        while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != released) {
+            if (++polls > kGsSpinLimit) { s_lost = 1; break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+    __syncthreads();
+    if (s_lost) {   // the release never came: say so, leave the rows as they are
+        if (tid == 0) atomicExch(flag, -1);
+        return;
+    }
+    // ---- the update of this workgroup's components (pair_update_small_kernel's arithmetic) with the coefficients just left
+    const int m = J - 2;
+    if (tid < m) {
+        ca[tid] = gs_get(coef + tid);
+        cb[tid] = gs_get(coef + ld + tid);
+    }
+    if (tid < 3) sc[tid] = gs_get(coef + 2 * ld + tid);
+    __syncthreads();
+    const double scale_a = sc[0], cross = sc[1], scale_b = sc[2];
+    const size_t c0 = (size_t)blockIdx.x * kSmallThreads * ept;
+    double x[kSmallEpt], y[kSmallEpt];
+#pragma unroll
+    for (int e = 0; e < kSmallEpt; ++e) {
+        x[e] = e < ept ? sa[tid + kSmallThreads * e] : 0.0;
+        y[e] = e < ept ? sb[tid + kSmallThreads * e] : 0.0;
+    }
+#pragma unroll 8
+    for (int r = 0; r < m; ++r) {
+        const double* row = V + (size_t)r * ldv + c0;
+        const double car = ca[r], cbr = cb[r];
+#pragma unroll
+        for (int e = 0; e < kSmallEpt; ++e) {
+            const int k = tid + kSmallThreads * e;
+            const double v = (e < ept && c0 + k < n) ? row[k] : 0.0;
+            x[e] -= car * v;
+            y[e] -= cbr * v;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < kSmallEpt; ++e) {
+        const size_t i = c0 + tid + kSmallThreads * e;
+        if (e < ept && i < n) {
+            const double xs = x[e] * scale_a;
+            a[i] = xs;
+            b[i] = (y[e] - cross * xs) * scale_b;
+        }
     }
 }
 
@@ -1110,7 +1333,7 @@ wx_status wx_pair_update(double* a, double* b, const double* V, size_t ldv, int 
 
 size_t wx_fgmres_workspace(int rows) {   // products' partial sums + the 2 rows products themselves
     const int r = rows > 0 ? rows : 1;
-    return wx_multi_dot_workspace(2 * r) + 2 * (size_t)r;
+    return wx_multi_dot_workspace(2 * r) + 2 * (size_t)r + 2 + kSmallBlocks;   // (+ the barrier words of the one-launch step)
 }
 
 // One Krylov vector of fgmres' low-synchronisation Gram-Schmidt (step J: rows a = V[J-2], b = V[J-1]) without a host round trip:
@@ -1132,9 +1355,25 @@ wx_status wx_fgmres_vector(double* V, size_t ldv, int J, size_t n, double* R, do
         hipLaunchKernelGGL(fgmres_gs_step_kernel, dim3(1), dim3(256), 0, st, G, (const double*)nullptr, 0, J, R, T, K, ld, coef, vn, flag);
     } else if (n <= (size_t)kSmallMaxLen && J <= 64) {
         // one rank, launch-bound lengths: the products of ALL rows in one launch, their partial sums summed by the step kernel, the
-        // update of both rows over ALL rows in one launch: three launches per Krylov vector beside the operator's
-        const int want = dot_blocks(n), blocks = want < kGsFusedBlocks ? want : kGsFusedBlocks;
-        hipLaunchKernelGGL(multi_dot2_small_kernel, dim3(blocks), dim3(256), 0, st, V, ldv, J, a, b, n, workspace);
+        // update of both rows over ALL rows in one launch: three launches per Krylov vector beside the operator's - or, on request,
+        // ONE, the workgroups meeting at a barrier inside it (not under stream capture: a replay would meet its own old sequence number)
+        const int ept = small_ept(n);
+        const int blocks = small_blocks(n, ept);
+        // (opt-in: measured equal to the three launches - the GPU runs dependent launches 0.1 us apart - and a barrier inside a launch
+        // needs every workgroup resident, which a GPU shared with other processes does not promise; profiles/r06_fgmres_device_passes.txt)
+        const char* sw = getenv("WXHIP_FGMRES_ONE_LAUNCH");   // (read per call: the A/B of tests/test_callers_gpu.py)
+        const bool one_launch = sw && sw[0] == '1';
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (one_launch && n > 0 && hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
+            static std::atomic<unsigned> sequence{0};
+            const unsigned seq = sequence.fetch_add(1u) + 1u;
+            unsigned long long* sync = reinterpret_cast<unsigned long long*>(G + 2 * (size_t)ld);
+            hipLaunchKernelGGL(fgmres_vector_small_kernel, dim3(blocks), dim3(kSmallThreads), 0, st, V, ldv, J, n, ept, workspace, R, T, K, ld, coef,
+                               vn, flag, sync, seq);
+            WX_HIP_TRY(hipGetLastError());
+            return WX_OK;
+        }
+        hipLaunchKernelGGL(multi_dot2_small_kernel, dim3(blocks), dim3(kSmallThreads), 0, st, V, ldv, J, a, b, n, ept, workspace);
         hipLaunchKernelGGL(fgmres_gs_step_kernel, dim3(1), dim3(256), 0, st, (const double*)nullptr, workspace, blocks, J, R, T, K, ld,
                            coef, vn, flag);
         if (n > 0) {

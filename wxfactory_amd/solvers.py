@@ -254,6 +254,15 @@ def _stagnated(update: torch.Tensor, x: torch.Tensor, group=None) -> bool:
     return any_nz > 0.0 and change < 1e-12
 
 
+def _cycle_end_stats(r: torch.Tensor, update: torch.Tensor, x: torch.Tensor):
+    """(||r||, stagnated) of a restart cycle's end on ONE rank from one read-back: global_norm + _stagnated are some twenty
+    launches and two synchronisations, which at the sizes of the shipped .ini files weigh as much as five Krylov vectors."""
+    nz = x != 0
+    rel = torch.where(nz, (update / x).abs(), 0.0)   # (x = 0: inf / nan, masked)
+    rr, change, any_nz = torch.stack((torch.dot(r, r), rel.max(), nz.any().to(r.dtype))).tolist()
+    return math.sqrt(rr) if rr >= 0.0 else rr, any_nz > 0.0 and change < 1e-12
+
+
 def fgmres(A: Callable, b: torch.Tensor, x0: Optional[torch.Tensor] = None, tol: float = 1e-5, restart: int = 20,
            maxiter: Optional[int] = None, preconditioner: Optional[Callable] = None, verbose: int = 0, group=None,
            ortho: str = "igs") -> Tuple[torch.Tensor, float, float, int, int, List[Tuple[float, float, float]]]:
@@ -395,7 +404,8 @@ def _fgmres_low_sync(A, b, x0, tol, restart, maxiter, preconditioner, verbose, g
                    flag=state[3 * rows * rows + rows:].view(torch.int32)[:1], coef=torch.zeros(3 * rows, dtype=torch.float64, device=b.device),
                    work=torch.empty(int(basis.lib.wx_fgmres_workspace(rows)), dtype=torch.float64, device=b.device),
                    host=torch.empty(3 * rows * rows + rows + 1, dtype=torch.float64).pin_memory(), rows=rows)
-    stats = fgmres.last_stats = {"device_passes": 0, "vectors_built": 0, "wasted_vectors": 0, "host_redone_steps": 0}
+    stats = fgmres.last_stats = {"device_passes": 0, "vectors_built": 0, "wasted_vectors": 0, "host_redone_steps": 0,
+                                 "enqueue_s": 0.0, "wait_s": 0.0, "cycle_end_s": 0.0}   # (where a device pass's host time goes)
     chunk = max(1, int(os.environ.get("WXHIP_FGMRES_CHUNK", "20")))
     for _outer in range(maxiter):
         gs = _LowSyncGramSchmidt(basis, restart + 2, group)
@@ -430,14 +440,20 @@ def _fgmres_low_sync(A, b, x0, tol, restart, maxiter, preconditioner, verbose, g
                     if rate is not None and 0.0 < rate < 1.0 and abs(g[j]) > tol_abs:
                         want = max(1, min(chunk, int(math.ceil(math.log(tol_abs / abs(g[j])) / math.log(rate)))))
                     upto = min(restart, j + want)
+                    t_a = time()
                     for jj in range(j, upto):
                         vector(V, jj + 3, n, dev["R"], dev["T"], dev["K"], restart + 2, dev["coef"], dev["vn"], dev["flag"], dev["work"])
                     stats["device_passes"] += 1
                     stats["vectors_built"] += upto - j
                     dev["host"].copy_(dev["state"], non_blocking=True)
+                    t_b = time()
                     torch.cuda.current_stream(b.device).synchronize()          # the pass's one synchronisation
+                    stats["enqueue_s"] += t_b - t_a
+                    stats["wait_s"] += time() - t_b
                     hv, rr = dev["host"].numpy(), dev["rows"]
                     bad = int(dev["host"][3 * rr * rr + rr:].view(torch.int32)[0])
+                    if bad < 0:   # (the one-launch step's barrier was never released: wx_fgmres_vector)
+                        raise RuntimeError("fgmres: a workgroup of the device step gave up waiting for the others (flag -1)")
                     good_upto = upto if bad == 0 else bad - 3    # steps J < bad are sound
                     if good_upto > j:
                         hm = hv[: 3 * rr * rr].reshape(3, rr, rr)
@@ -489,6 +505,7 @@ def _fgmres_low_sync(A, b, x0, tol, restart, maxiter, preconditioner, verbose, g
                     break   # converged, NaN, or breakdown (row j+1 vanished: h_{j+1,j} = 0, the least-squares residual is exact)
         if ahead > k:
             stats["wasted_vectors"] += ahead - k
+        t_c = time()
         y = [0.0] * k
         for i in range(k - 1, -1, -1):
             acc = g[i]
@@ -506,11 +523,17 @@ def _fgmres_low_sync(A, b, x0, tol, restart, maxiter, preconditioner, verbose, g
             update = basis.combine(k, yh)
         x += update
         r = b - A(x)
-        norm_r = float(global_norm(r, group))
+        if dev is not None and x.numel() > 0:   # (one rank, on the GPU)
+            norm_r, stagnated = _cycle_end_stats(r, update, x)
+        else:
+            norm_r, stagnated = float(global_norm(r, group)), None
         residuals.append((norm_r / norm_b, time() - t0, 0.0))
         if verbose > 0:
             print(f"res: {norm_r/norm_b:.2e} (iter {niter})", flush=True)
-        if _stagnated(update, x, group):
+        if stagnated is None:
+            stagnated = _stagnated(update, x, group)
+        stats["cycle_end_s"] += time() - t_c
+        if stagnated:
             return x, norm_r, norm_b, niter, -1, residuals
         if norm_r < tol_abs:
             return x, norm_r, norm_b, niter, 0, residuals
