@@ -39,6 +39,8 @@ __global__ void k_code(double* p, int sel) {   // a long straight-line body (~60
     p[threadIdx.x + blockIdx.x * blockDim.x] = x + 1.0;
 }
 
+__global__ void k_grid2(double* p) { linger(); p[threadIdx.x + (blockIdx.x + blockIdx.y * gridDim.x) * blockDim.x] += 1.0; }
+
 int main() {
     double* p;
     hipMalloc(&p, 1 << 20);
@@ -56,6 +58,8 @@ int main() {
         hipLaunchKernelGGL(k_vgpr, dim3(81), dim3(256), 0, st, p);
         hipLaunchKernelGGL(k_small, dim3(81), dim3(256), 0, st, p);
         hipLaunchKernelGGL(k_code, dim3(81), dim3(256), 0, st, p, it);
+        hipLaunchKernelGGL(k_small, dim3(81), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(k_grid2, dim3(16, 6), dim3(256), 0, st, p);
     }
     hipStreamSynchronize(st);
     printf("done\n");
