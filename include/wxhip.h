@@ -783,6 +783,17 @@ wx_status wx_pair_update(double* a, double* b, const double* V, size_t ldv, int 
  * wx_euler3d_batch_fgmres_vector: the same with the finite-difference Rosenbrock operator in front (integrators/ros2.py:27-30,
  * solvers/matvec.py:76-88): row J-1 = A(row J-2 / s) s with s = vn[J-3] read by the kernels from device memory. */
 size_t wx_fgmres_workspace(int rows);
+/* fgmres' host side of the same scheme (solvers/fgmres.py:75-94, 202-262), plain host code on HOST arrays - the reference does it in
+ * the interpreter, which at the shipped .ini sizes was a sixth of a Rosenbrock step once the vectors came from device passes.
+ * wx_fgmres_rotate_columns: Hessenberg columns j0 .. j1-1 (column j = R[0 .. j+1][j+1], R row-major ld x ld) through the stored
+ * rotations cs / sn[0 .. j), a new rotation each (fgmres.py's _rotg), g updated, Hm[j][0 .. j+1] = the rotated column, res[j - j0]
+ * = |g[j+1]|, *rate = the running decay of that estimate (NaN on entry: none yet); stops behind the first column whose estimate is
+ * below tol_abs or NaN or whose row norm vn[j+1] is zero (*stopped = 1).  Returns the number of columns taken, -1 on bad arguments.
+ * wx_fgmres_back_substitute: y[0 .. k) from the rotated columns and g.  Same IEEE operations in the same order as the interpreted
+ * loops (tests/test_solvers.py holds them bit for bit). */
+int wx_fgmres_rotate_columns(const double* R, int ld, int j0, int j1, int restart, const double* vn, double* cs, double* sn, double* g,
+                             double* Hm, double tol_abs, double* rate, double* res, int* stopped);
+int wx_fgmres_back_substitute(const double* Hm, int ld, int k, const double* g, double* y);
 wx_status wx_fgmres_vector(double* V, size_t ldv, int J, size_t n, double* R, double* T, double* K, int ld, double* coef,
                            double* vn, int* flag, double* workspace, wx_comm* comm, wx_stream stream);
 wx_status wx_euler3d_batch_fgmres_vector(const wx_euler3d_batch* batch, const double* q, const double* rq, double* V, size_t ldv,

@@ -13,6 +13,12 @@ import torch.multiprocessing as mp
 from scipy.linalg import expm
 
 
+@pytest.fixture(autouse=True, scope="module")
+def _library(built_lib):
+    """fgmres' host-side loops are the library's (wx_fgmres_rotate_columns: plain host C, no GPU needed): build it first."""
+    return built_lib
+
+
 def _problem(n=96, p=3, seed=3):
     rng = np.random.default_rng(seed)
     A = -np.diag(rng.uniform(0.1, 6.0, n)) + 0.4 * rng.standard_normal((n, n)) / np.sqrt(n)
@@ -522,3 +528,96 @@ def test_padded_basis_rows_change_nothing(solver, monkeypatch):
     assert not solvers._basis_rows(3, A.shape[0] + 1, torch.float64, "cpu").is_contiguous()
     w1, st1 = fn([0.4, 1.0], lambda v: torch.from_numpy(A) @ v, torch.from_numpy(u), **args)
     assert torch.equal(w0, w1) and tuple(st0) == tuple(st1)
+
+
+def _interpreted_columns(R, j0, j1, restart, vn, cs, sn, g, Hm, tol_abs, rate):
+    """fgmres.py:75-94, 202-246 as the interpreter runs it (the checker of wx_fgmres_rotate_columns: Python floats, ** 2)."""
+    import math
+
+    def rotg(a, b):
+        if b == 0.0:
+            return 1.0, 0.0
+        if a == 0.0:
+            return 0.0, 1.0
+        scl = min(abs(a), abs(b))
+        sigma = math.copysign(1.0, a) if abs(a) > abs(b) else math.copysign(1.0, b)
+        r = sigma * (scl * math.sqrt((a / scl) ** 2 + (b / scl) ** 2))
+        return a / r, b / r
+
+    res, stopped = [], False
+    for j in range(j0, j1):
+        hj = R[: j + 2, j + 1].tolist()
+        for i in range(j):
+            t = cs[i] * hj[i] + sn[i] * hj[i + 1]
+            hj[i + 1] = -sn[i] * hj[i] + cs[i] * hj[i + 1]
+            hj[i] = t
+        if hj[j + 1] != 0.0:
+            c, s = rotg(hj[j], hj[j + 1])
+            hj[j], hj[j + 1] = c * hj[j] + s * hj[j + 1], 0.0
+            g[j], g[j + 1] = c * g[j] + s * g[j + 1], -s * g[j] + c * g[j + 1]
+        else:
+            c, s = 1.0, 0.0
+        cs[j], sn[j] = c, s
+        Hm[j][: j + 2] = hj
+        if g[j] != 0.0 and abs(g[j + 1]) > 0.0:
+            q = abs(g[j + 1]) / abs(g[j])
+            rate = q if j == 0 or rate is None else 0.5 * (rate + q)
+        res.append(abs(g[j + 1]))
+        if j < restart - 1 or vn[j + 1] == 0.0:
+            if res[-1] < tol_abs or res[-1] != res[-1] or vn[j + 1] == 0.0:
+                stopped = True
+                break
+    return len(res), stopped, rate, res
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_host_side_of_fgmres_in_c_is_the_interpreted_loop(built_lib, seed):
+    """wx_fgmres_rotate_columns / wx_fgmres_back_substitute (plain host C behind the C ABI) against the reference's interpreted
+    loops: the same bits in the rotations, g, the rotated columns, the estimates, the decay rate, the stopping column and y -
+    whole cycles at once and in ragged chunks (what device passes hand over), zeros in the subdiagonal, a vanished row, NaN."""
+    from wxfactory_amd.solvers import _host_lib, _rotate_columns
+
+    rng = np.random.default_rng(seed)
+    restart = 30
+    ld = restart + 2
+    R = np.triu(rng.standard_normal((ld, ld)), -1) * np.exp(rng.uniform(-8, 2, (ld, ld)))
+    R[np.arange(1, ld), np.arange(0, ld - 1)] = 0.0        # column j of the Hessenberg matrix is R[: j + 2, j + 1]
+    vn = np.abs(rng.standard_normal(ld)) + 0.1
+    if seed == 1:
+        R[7, 7] = 0.0                                      # h_{j+1,j} = 0: the identity rotation
+    if seed == 2:
+        vn[12] = 0.0                                       # a vanished row: breakdown, the estimate is exact
+    if seed == 3:
+        R[5, 9] = float("nan")
+    tol_abs = 1e-9 if seed != 4 else 1e-2                  # (seed 4: converges inside the cycle)
+    g0 = float(np.abs(rng.standard_normal()) + 1.0)
+    # the interpreted loop, one cycle
+    cs_p, sn_p, g_p = [0.0] * (restart + 1), [0.0] * (restart + 1), [0.0] * ld
+    g_p[0] = g0
+    Hm_p = [[0.0] * ld for _ in range(restart)]
+    n_p, stop_p, rate_p, res_p = _interpreted_columns(R, 0, restart, restart, vn.tolist(), cs_p, sn_p, g_p, Hm_p, tol_abs, None)
+    # the C helper, in ragged chunks
+    cs, sn, g, Hm = np.zeros(restart + 1), np.zeros(restart + 1), np.zeros(ld), np.zeros((restart, ld))
+    g[0] = g0
+    rate, stopped, res = np.full(1, np.nan), np.zeros(1, dtype=np.int32), np.zeros(restart + 1)
+    j, got_res = 0, []
+    while j < restart and not stopped[0]:
+        j1 = min(restart, j + int(rng.integers(1, 9)))
+        took = _rotate_columns(R, j, j1, restart, vn, cs, sn, g, Hm, tol_abs, rate, res, stopped)
+        got_res += res[:took].tolist()
+        j += took
+    assert (j, bool(stopped[0])) == (n_p, stop_p)
+    same = lambda a, b: np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+    assert same(cs[:j], cs_p[:j]) and same(sn[:j], sn_p[:j]) and same(g, g_p) and same(got_res, res_p)
+    assert same(Hm[:j], np.asarray(Hm_p)[:j])
+    assert (rate_p is None and np.isnan(rate[0])) or same(rate[0], rate_p)
+    # the back substitution
+    y_p = [0.0] * j
+    for i in range(j - 1, -1, -1):
+        acc = g_p[i]
+        for l in range(i + 1, j):
+            acc -= Hm_p[l][i] * y_p[l]
+        y_p[i] = acc / Hm_p[i][i]
+    y = np.zeros(j)
+    assert _host_lib().wx_fgmres_back_substitute(Hm.ctypes.data, ld, j, g.ctypes.data, y.ctypes.data) == 0
+    assert same(y, y_p)

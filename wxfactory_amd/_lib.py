@@ -131,6 +131,9 @@ SIGNATURES = {
     "wx_pair_update": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_size_t, c_double,
                                c_double, c_double, c_void_p]),
     "wx_fgmres_workspace": (c_size_t, [c_int]),
+    "wx_fgmres_rotate_columns": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double,
+                                         c_void_p, c_void_p, c_void_p]),
+    "wx_fgmres_back_substitute": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "wx_fgmres_vector": (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p]),
     "wx_euler3d_batch_fgmres_vector": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_size_t, c_double,

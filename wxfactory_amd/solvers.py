@@ -15,6 +15,8 @@ slice (ranks 6, 7 of an 8-GPU node with whole panels): all ranks make the same c
 import math
 import os
 from time import time
+
+import numpy
 from typing import Callable, List, Optional, Tuple
 
 import torch
@@ -254,6 +256,24 @@ def _stagnated(update: torch.Tensor, x: torch.Tensor, group=None) -> bool:
     return any_nz > 0.0 and change < 1e-12
 
 
+def _host_lib():
+    """The library's host-side helpers (plain C on host arrays: no GPU needed to call them)."""
+    from . import _lib
+
+    return _lib.load()
+
+
+def _rotate_columns(R, j0: int, j1: int, restart: int, vn, cs, sn, g, Hm, tol_abs: float, rate_box, res, stopped_box) -> int:
+    """fgmres.py:202-246 for the Hessenberg columns j0 .. j1-1 of R in one call (include/wxhip.h: wx_fgmres_rotate_columns): the
+    stored rotations applied, a new one formed (_rotg), g updated, the stopping test - returns how many columns were taken."""
+    took = int(_host_lib().wx_fgmres_rotate_columns(R.ctypes.data, R.shape[1], j0, j1, restart, vn.ctypes.data, cs.ctypes.data,
+                                                    sn.ctypes.data, g.ctypes.data, Hm.ctypes.data, float(tol_abs),
+                                                    rate_box.ctypes.data, res.ctypes.data, stopped_box.ctypes.data))
+    if took < 0 or Hm.shape[1] != R.shape[1]:
+        raise ValueError("wx_fgmres_rotate_columns: bad arguments")
+    return took
+
+
 def _cycle_end_stats(r: torch.Tensor, update: torch.Tensor, x: torch.Tensor):
     """(||r||, stagnated) of a restart cycle's end on ONE rank from one read-back: global_norm + _stagnated are some twenty
     launches and two synchronisations, which at the sizes of the shipped .ini files weigh as much as five Krylov vectors."""
@@ -409,10 +429,15 @@ def _fgmres_low_sync(A, b, x0, tol, restart, maxiter, preconditioner, verbose, g
     chunk = max(1, int(os.environ.get("WXHIP_FGMRES_CHUNK", "20")))
     for _outer in range(maxiter):
         gs = _LowSyncGramSchmidt(basis, restart + 2, group)
-        Hm = [[0.0] * (restart + 2) for _ in range(restart)]   # Hm[j][i] = h_{i,j} after the rotations
-        cs, sn = [], []
-        g = [0.0] * (restart + 2)
+        ldh = restart + 2
+        Hm = numpy.zeros((restart, ldh))   # Hm[j][i] = h_{i,j} after the rotations
+        cs, sn = numpy.zeros(restart + 1), numpy.zeros(restart + 1)
+        g = numpy.zeros(ldh)
         g[0] = norm_r
+        vn_host = numpy.zeros(ldh)         # vn_host[j + 1] = the norm that came with column j
+        res = numpy.zeros(restart + 1)
+        rate_box = numpy.full(1, numpy.nan)
+        stopped_box = numpy.zeros(1, dtype=numpy.int32)
         torch.div(r, norm_r, out=V[0])
         if Z is not None:
             Z[0] = preconditioner(V[0])
@@ -430,42 +455,39 @@ def _fgmres_low_sync(A, b, x0, tol, restart, maxiter, preconditioner, verbose, g
             hv[3 * rr * rr:] = 0.0
             hv[3 * rr * rr] = v_norm
             dev["state"].copy_(dev["host"], non_blocking=True)
-        rate = None
-        for j in range(restart):
-            niter += 1
-            if on_device:
-                if j >= ahead:
-                    # how many vectors to build before the next read-back: a chunk, or what the residual's decay says is left
-                    want = chunk
-                    if rate is not None and 0.0 < rate < 1.0 and abs(g[j]) > tol_abs:
-                        want = max(1, min(chunk, int(math.ceil(math.log(tol_abs / abs(g[j])) / math.log(rate)))))
-                    upto = min(restart, j + want)
-                    t_a = time()
-                    for jj in range(j, upto):
-                        vector(V, jj + 3, n, dev["R"], dev["T"], dev["K"], restart + 2, dev["coef"], dev["vn"], dev["flag"], dev["work"])
-                    stats["device_passes"] += 1
-                    stats["vectors_built"] += upto - j
-                    dev["host"].copy_(dev["state"], non_blocking=True)
-                    t_b = time()
-                    torch.cuda.current_stream(b.device).synchronize()          # the pass's one synchronisation
-                    stats["enqueue_s"] += t_b - t_a
-                    stats["wait_s"] += time() - t_b
-                    hv, rr = dev["host"].numpy(), dev["rows"]
-                    bad = int(dev["host"][3 * rr * rr + rr:].view(torch.int32)[0])
-                    if bad < 0:   # (the one-launch step's barrier was never released: wx_fgmres_vector)
-                        raise RuntimeError("fgmres: a workgroup of the device step gave up waiting for the others (flag -1)")
-                    good_upto = upto if bad == 0 else bad - 3    # steps J < bad are sound
-                    if good_upto > j:
-                        hm = hv[: 3 * rr * rr].reshape(3, rr, rr)
-                        gs.R[:, :], gs.T[:, :], gs.K[:, :] = hm[0], hm[1], hm[2]
-                        vns = hv[3 * rr * rr: 3 * rr * rr + rr].copy()
-                    ahead = good_upto
-                    if bad != 0:
-                        on_device = False     # a breakdown / suspect cancellation at step `bad`: the host's branches take over
-                        stats["wasted_vectors"] += upto - good_upto
-                if j < ahead:
-                    v_norm = float(vns[j + 1])
-            if not (j < ahead):
+        j = 0
+        while j < restart:
+            if on_device and j >= ahead:
+                # how many vectors to build before the next read-back: a chunk, or what the residual's decay says is left
+                want = chunk
+                rate = float(rate_box[0])
+                if rate == rate and 0.0 < rate < 1.0 and abs(g[j]) > tol_abs:
+                    want = max(1, min(chunk, int(math.ceil(math.log(tol_abs / abs(g[j])) / math.log(rate)))))
+                upto = min(restart, j + want)
+                t_a = time()
+                for jj in range(j, upto):
+                    vector(V, jj + 3, n, dev["R"], dev["T"], dev["K"], restart + 2, dev["coef"], dev["vn"], dev["flag"], dev["work"])
+                stats["device_passes"] += 1
+                stats["vectors_built"] += upto - j
+                dev["host"].copy_(dev["state"], non_blocking=True)
+                t_b = time()
+                torch.cuda.current_stream(b.device).synchronize()          # the pass's one synchronisation
+                stats["enqueue_s"] += t_b - t_a
+                stats["wait_s"] += time() - t_b
+                hv, rr = dev["host"].numpy(), dev["rows"]
+                bad = int(dev["host"][3 * rr * rr + rr:].view(torch.int32)[0])
+                if bad < 0:   # (the one-launch step's barrier was never released: wx_fgmres_vector)
+                    raise RuntimeError("fgmres: a workgroup of the device step gave up waiting for the others (flag -1)")
+                good_upto = upto if bad == 0 else bad - 3    # steps J < bad are sound
+                if good_upto > j:
+                    hm = hv[: 3 * rr * rr].reshape(3, rr, rr)
+                    gs.R[:, :], gs.T[:, :], gs.K[:, :] = hm[0], hm[1], hm[2]
+                    vn_host[j + 1: good_upto + 1] = hv[3 * rr * rr + j + 1: 3 * rr * rr + good_upto + 1]
+                ahead = good_upto
+                if bad != 0:
+                    on_device = False     # a breakdown / suspect cancellation at step `bad`: the host's branches take over
+                    stats["wasted_vectors"] += upto - good_upto
+            if not (j < ahead):   # one vector the host's way
                 if dev is not None and not on_device:
                     stats["host_redone_steps"] += 1
                 zj = preconditioner(V[j + 1]) if Z is not None else V[j + 1]
@@ -481,43 +503,32 @@ def _fgmres_low_sync(A, b, x0, tol, restart, maxiter, preconditioner, verbose, g
                 v_norm = gs.step(j + 3)
                 if Z is not None and v_norm != 0.0:
                     Z[j + 1] /= v_norm
-            hj = gs.R[: j + 2, j + 1].tolist()
-            for i in range(j):  # previous rotations
-                t = cs[i] * hj[i] + sn[i] * hj[i + 1]
-                hj[i + 1] = -sn[i] * hj[i] + cs[i] * hj[i + 1]
-                hj[i] = t
-            if hj[j + 1] != 0.0:
-                c, s_, rr = _rotg(hj[j], hj[j + 1])
-                hj[j], hj[j + 1] = c * hj[j] + s_ * hj[j + 1], 0.0
-                g[j], g[j + 1] = c * g[j] + s_ * g[j + 1], -s_ * g[j] + c * g[j + 1]
+                vn_host[j + 1] = v_norm
+                upto_cols = j + 1
             else:
-                c, s_ = 1.0, 0.0
-            cs.append(c)
-            sn.append(s_)
-            Hm[j][: j + 2] = hj
-            k = j + 1
-            if g[j] != 0.0 and abs(g[j + 1]) > 0.0:
-                rate = abs(g[j + 1]) / abs(g[j]) if j == 0 or rate is None else 0.5 * (rate + abs(g[j + 1]) / abs(g[j]))
-            if j < restart - 1 or v_norm == 0.0:
-                norm_r = abs(g[j + 1])
-                residuals.append((norm_r / norm_b, time() - t0, 0.0))
-                if norm_r < tol_abs or norm_r != norm_r or v_norm == 0.0:
-                    break   # converged, NaN, or breakdown (row j+1 vanished: h_{j+1,j} = 0, the least-squares residual is exact)
+                upto_cols = ahead
+            # the columns j .. upto_cols - 1 of gs.R through the rotations, the residual estimate and the stopping test
+            # (include/wxhip.h: wx_fgmres_rotate_columns - the reference's interpreted loop, same operations, on the host)
+            took = _rotate_columns(gs.R, j, upto_cols, restart, vn_host, cs, sn, g, Hm, tol_abs, rate_box, res, stopped_box)
+            now = time() - t0
+            for jj in range(j, j + took):
+                if jj < restart - 1 or vn_host[jj + 1] == 0.0:
+                    residuals.append((float(res[jj - j]) / norm_b, now, 0.0))
+            niter += took
+            j += took
+            k = j
+            v_norm = float(vn_host[j])
+            if stopped_box[0]:
+                break   # converged, NaN, or breakdown (row j+1 vanished: h_{j+1,j} = 0, the least-squares residual is exact)
         if ahead > k:
             stats["wasted_vectors"] += ahead - k
         t_c = time()
-        y = [0.0] * k
-        for i in range(k - 1, -1, -1):
-            acc = g[i]
-            for l in range(i + 1, k):
-                acc -= Hm[l][i] * y[l]
-            y[i] = acc / Hm[i][i]
+        yv = numpy.zeros(k)
+        if _host_lib().wx_fgmres_back_substitute(Hm.ctypes.data, ldh, k, g.ctypes.data, yv.ctypes.data) != 0:
+            raise ValueError("wx_fgmres_back_substitute: bad arguments")
         if Z is not None:
-            update = torch.as_tensor(y, dtype=b.dtype, device=b.device) @ Z[:k]
+            update = torch.as_tensor(yv, dtype=b.dtype, device=b.device) @ Z[:k]
         else:
-            import numpy
-
-            yv = numpy.asarray(y)
             yh = yv + gs.T[:k, :k] @ yv
             yh[0] += (gs.R[0, 0] - 1.0) * yv[0]
             update = basis.combine(k, yh)
