@@ -212,6 +212,12 @@ def test_the_lean_logarithm_is_good_to_an_ulp():
     ulp = np.spacing(np.abs(np.asarray(ref, dtype=np.float64)))
     assert float(np.max(err / np.maximum(ulp, 2.2e-16))) <= 1.0, float(np.max(err / np.maximum(ulp, 2.2e-16)))
     assert y[-5] == 0.0
+    # a state that has blown up must show in R (the NaN flag of the integrators): what the library's log returns there
+    bad = torch.tensor([-1.0, -1e-300, 0.0, float("nan"), -float("inf")], dtype=torch.float64, device=DEV)
+    out = torch.empty_like(bad)
+    _lib.check(lib.wx_lean_log(bad.data_ptr(), out.data_ptr(), bad.numel(), torch.cuda.current_stream().cuda_stream), "wx_lean_log")
+    o = out.cpu().numpy()
+    assert np.isnan(o[0]) and np.isnan(o[1]) and o[2] == -np.inf and np.isnan(o[3]) and np.isnan(o[4])
 
 
 def test_tile_edge_states_pulled_from_the_neighbour_tiles(monkeypatch):

@@ -175,12 +175,12 @@ __global__ __launch_bounds__(Cfg<N>::BS, kK1Waves) void euler_tan_extrap_kernel(
                     tv[k] = w;
                 }
             }
-            pl[0][lp] = log(r0);
+            pl[0][lp] = w_log(r0);
             pl[1][lp] = (e * tv[0]) / r0;
             pl[2][lp] = e * tv[1];
             pl[3][lp] = e * tv[2];
             pl[4][lp] = e * tv[3];
-            pl[5][lp] = log(r4);
+            pl[5][lp] = w_log(r4);
             pl[6][lp] = (e * tv[4]) / r4;
         }
         if constexpr (FIX) {

@@ -53,7 +53,6 @@ __device__ __forceinline__ cplx operator/(double a, cplx b) { return cplx(a, 0.0
 __device__ __forceinline__ cplx& operator+=(cplx& a, cplx b) { a.re += b.re; a.im += b.im; return a; }
 __device__ __forceinline__ cplx& operator-=(cplx& a, cplx b) { a.re -= b.re; a.im -= b.im; return a; }
 
-__device__ __forceinline__ double w_log(double x) { return log(x); }
 __device__ __forceinline__ double w_exp(double x) { return exp(x); }
 __device__ __forceinline__ double w_sqrt(double x) { return sqrt(x); }
 __device__ __forceinline__ double w_abs(double x) { return fabs(x); }
@@ -81,8 +80,19 @@ __device__ __forceinline__ double lean_log(double x) {
     const double t2 = z * (6.666666666666735130e-01 + w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
     const double R = t2 + t1;
     const double hfsq = 0.5 * f * f;
-    return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+    const double r = dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+    // a state that has blown up must show: NaN for a negative argument (and NaN), -inf at zero, as the library's log
+    return x > 0.0 ? r : (x == 0.0 ? -__builtin_huge_val() : __builtin_nan(""));
 }
+// The float64 logarithm of EVERY form goes through lean_log (round 6): the two-kernel form takes three per point at n = 8 - the
+// pressure's and two per face point (the interface buffer holds rho theta, as the reference's arrays do) - and the extrapolation
+// kernel two; with the library's 84-instruction log those were a quarter of the fused kernel's vector instructions.  Measured
+// (profiles/r06_lean_log_everywhere.txt): extrapolation kernel -6 %, fused kernel -2 % at n = 8, whole R(Q) -1...-5 % at n = 3...6.
+// -DWX_LEAN_LOG_K2=0 builds the library's log back in (A/B).
+#ifndef WX_LEAN_LOG_K2
+#define WX_LEAN_LOG_K2 1
+#endif
+__device__ __forceinline__ double w_log(double x) { return WX_LEAN_LOG_K2 ? lean_log(x) : log(x); }
 __device__ __forceinline__ double lean_exp(double x) {
     const double k = __builtin_rint(x * 1.44269504088896338700e+00);
     const double r = __builtin_fma(-k, 1.90821492927058770002e-10, __builtin_fma(-k, 6.93147180369123816490e-01, x));
@@ -171,7 +181,7 @@ __device__ __forceinline__ dual operator/(double a, dual b) {
 }
 __device__ __forceinline__ dual& operator+=(dual& a, dual b) { a.re += b.re; a.im += b.im; return a; }
 __device__ __forceinline__ dual& operator-=(dual& a, dual b) { a.re -= b.re; a.im -= b.im; return a; }
-__device__ __forceinline__ dual w_log(dual z) { return {log(z.re), z.im / z.re}; }
+__device__ __forceinline__ dual w_log(dual z) { return {w_log(z.re), z.im / z.re}; }
 __device__ __forceinline__ dual w_exp(dual z) { const double e = exp(z.re); return {e, e * z.im}; }
 __device__ __forceinline__ dual w_sqrt(dual z) { const double s = sqrt(z.re); return {s, z.im / (2.0 * s)}; }
 __device__ __forceinline__ double w_abs(dual z) { return fabs(z.re); }  // modulus to first order; no tangent
