@@ -81,8 +81,11 @@ __device__ __forceinline__ double lean_log(double x) {
     const double R = t2 + t1;
     const double hfsq = 0.5 * f * f;
     const double r = dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
-    // a state that has blown up must show: NaN for a negative argument (and NaN), -inf at zero, as the library's log
-    return x > 0.0 ? r : (x == 0.0 ? -__builtin_huge_val() : __builtin_nan(""));
+    // a state that has blown up must show: NaN for a negative argument (and NaN), -inf at zero, as the library's log - ADDED to the
+    // (finite) value the arithmetic above leaves there, not selected: a select of the result becomes a branch around the whole
+    // computation, which cuts every kernel's schedule at every logarithm
+    const double bad = x > 0.0 ? 0.0 : (x == 0.0 ? -__builtin_huge_val() : __builtin_nan(""));
+    return r + bad;
 }
 // The float64 logarithm of EVERY form goes through lean_log (round 6): the two-kernel form takes three per point at n = 8 - the
 // pressure's and two per face point (the interface buffer holds rho theta, as the reference's arrays do) - and the extrapolation
