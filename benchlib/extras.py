@@ -188,7 +188,7 @@ def extras(dev, seed):
                                    "algorithmic_bytes_per_point": 156.0, "achieved": round(156.0 * 6 * H * H * n * n / te / 1e9, 1),
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(156.0 * 6 * H * H * n * n / te / 1e9 / HBM_PEAK_GBS, 4),
-                                   "profile": "profiles/r06_v2_swbench_kernel_stats.csv, profiles/r06_pmc_sw_summary.json"},
+                                   "profile": "profiles/r06_v3_swbench_kernel_stats.csv, profiles/r06_pmc_sw_summary.json"},
                       "note": "all six panels in ONE launch (wx_sw_batch_rhs_direct, wx_sw_batch_direct_pulls = 1): own face states "
                               "from LDS, the neighbours' from the neighbour elements' nodal values - across panel edges too (sum, "
                               "rotation and flip of the neighbour panel's line formed in place); 5.5 MB of state per panel"}}

@@ -64,7 +64,7 @@ def pmc_traffic(region, n, H, V, bpp=ALGO_BYTES_PER_POINT):
 
 
 FP64_MFMA_PEAK_TFLOPS = 78.6    # SURVEY 8d; = 512 flop per 16 issue cycles per SIMD (tools/mfma_f64_probe.hip) x 1024 SIMDs x 2.4 GHz
-SQ_COUNTERS = "r06_v2_k2_sq_counters.json"   # (falls back to round 5's pass of the same kernel until this round's is installed)
+SQ_COUNTERS = "r06_v3_k2_sq_counters.json"   # (falls back to round 5's pass of the same kernel until this round's is installed)
 SQ_COUNTERS_FALLBACK = "r05_v4_k2_sq_counters.json"
 
 
