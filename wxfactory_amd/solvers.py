@@ -266,10 +266,14 @@ def _host_lib():
 def _rotate_columns(R, j0: int, j1: int, restart: int, vn, cs, sn, g, Hm, tol_abs: float, rate_box, res, stopped_box) -> int:
     """fgmres.py:202-246 for the Hessenberg columns j0 .. j1-1 of R in one call (include/wxhip.h: wx_fgmres_rotate_columns): the
     stored rotations applied, a new one formed (_rotg), g updated, the stopping test - returns how many columns were taken."""
-    took = int(_host_lib().wx_fgmres_rotate_columns(R.ctypes.data, R.shape[1], j0, j1, restart, vn.ctypes.data, cs.ctypes.data,
+    ld = R.shape[1]
+    if (Hm.shape[1] != ld or Hm.shape[0] < j1 or min(vn.size, g.size) < j1 + 1 or min(cs.size, sn.size) < j1 or res.size < j1 - j0
+            or not all(a.flags.c_contiguous and a.dtype == numpy.float64 for a in (R, vn, cs, sn, g, Hm, rate_box, res))):
+        raise ValueError("wx_fgmres_rotate_columns: array shapes")
+    took = int(_host_lib().wx_fgmres_rotate_columns(R.ctypes.data, ld, j0, j1, restart, vn.ctypes.data, cs.ctypes.data,
                                                     sn.ctypes.data, g.ctypes.data, Hm.ctypes.data, float(tol_abs),
                                                     rate_box.ctypes.data, res.ctypes.data, stopped_box.ctypes.data))
-    if took < 0 or Hm.shape[1] != R.shape[1]:
+    if took < 0:
         raise ValueError("wx_fgmres_rotate_columns: bad arguments")
     return took
 
