@@ -192,6 +192,14 @@ def test_ros2_step_at_order_2_with_device_passes(monkeypatch):
     ax = (0, 2, 3, 4, 5)
     upd = (res["0"][0] - Q).abs().amax(dim=ax)
     assert (((res["1"][0] - res["0"][0]).abs().amax(dim=ax)) <= 1e-7 * upd).all()   # (both solved to 1e-10 of |b|)
+    # the same device passes with the Gram-Schmidt step from ONE launch (a barrier of resident workgroups inside it): every step
+    # is the three launches' bit for bit, so the whole solve is
+    monkeypatch.setenv("WXHIP_FGMRES_VECTOR", "1")
+    monkeypatch.setenv("WXHIP_FGMRES_ONE_LAUNCH", "1")
+    ros = Ros2(rhs, tol=1e-10)
+    one = ros.step(Q, 30.0)
+    assert ros.solver_info["flag"] == 0 and ros.solver_info["iterations"] == dev["iterations"]
+    assert torch.equal(one, res["1"][0])
 
 
 def test_the_lean_logarithm_is_good_to_an_ulp():
