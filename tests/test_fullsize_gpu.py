@@ -7,6 +7,8 @@ What the small fixtures cannot show: the index arithmetic at offsets of gigabyte
 panel span 3.2 GB), the element / region decode at H = 60, the halo addressing of 60-element edges, the INTERIOR +
 BOUNDARY split at the launch shape of the multi-GPU runs.  Geometry, metric and initial state are the product's own
 (geometry3d, initial: DCMIP 3-1 + a seeded 1 % perturbation, so that R is O(1) and the bound is not about cancellation).
+The same at the size of the reference's own benchmark matrix (6.48 M DOF; `extra.rhs_benchmark_matrix`) for the forms the low
+orders take: n = 2 in the one-kernel form (bricks cut by the tile edge), n = 4 in the batched two-kernel form.
 Reference: rhs/rhs_dfr.py:48-313, solvers/matvec.py:56-61.
 """
 import os
@@ -17,7 +19,6 @@ import torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-N, H, V = 8, 60, 8
 CHECKS = {31: 4, 21: 0}   # the panel compared (panel 4: its N and W edges are flipped, all four rotated; panel 0: the mountain's)
 # case 31: DCMIP 3-1 (config 4's physics; a shallow atmosphere without topography, non-rotating: 18 Christoffel fields);
 # case 21: DCMIP 2-1 (config 5's physics: the Schaer mountain - a metric that depends on the level - and the Rayleigh sponge above
@@ -38,8 +39,14 @@ def _ref_metric(m):
     return {k: v.cpu().numpy() for k, v in om.items()}
 
 
-@pytest.mark.parametrize("CASE", sorted(CASES, reverse=True))
-def test_e7_panel_all_rows_against_the_c_port(built_lib, CASE):
+# (order, elements per side, levels, case): the E7 panels, and the reference's benchmark matrix (tests/rhs_benchmark/run.sh:67-71,
+# 6.48 M DOF) at two of its orders - n = 2 through the ONE-kernel form on bricks cut by the tile edge (30 = 3 x 8 + 6), n = 4 through
+# the batched two-kernel form: the sizes `extra.rhs_benchmark_matrix` times
+SIZES = [(8, 60, 8, 31), (8, 60, 8, 21), (2, 30, 30, 31), (4, 15, 15, 31)]
+
+
+@pytest.mark.parametrize("N,H,V,CASE", SIZES)
+def test_e7_panel_all_rows_against_the_c_port(built_lib, N, H, V, CASE):
     from oracle import cubed_sphere as cs
     from oracle.c_port import Euler3DPortC
     from wxfactory_amd import _lib
@@ -63,9 +70,11 @@ def test_e7_panel_all_rows_against_the_c_port(built_lib, CASE):
         qs.append(q * (1.0 + 0.01 * (torch.rand(q.shape, generator=gen, device=DEV, dtype=q.dtype) - 0.5)))
         b = metrics[p]["boundary_sn"].cpu().numpy().reshape(H, 1, N)
         bnd[p] = (np.tile(b, (1, N, 1)), np.tile(metrics[p]["boundary_we"].cpu().numpy().reshape(H, 1, N), (1, N, 1)))
-    assert int(plans[0].lib.wx_euler3d_uses_matrix_cores(plans[0]._h, _lib.WX_KERNEL_RHS)) == 1
-    # compulsory bytes per point of this plan: 312 (case 31, no rotation symbols) / 344 (case 21: + the four sponge fields)
-    assert plans[0].bytes_per_point == (312.0 if CASE == 31 else 344.0)
+    assert int(plans[0].lib.wx_euler3d_uses_matrix_cores(plans[0]._h, _lib.WX_KERNEL_RHS)) == (1 if N == 8 else 0)
+    assert bool(plans[0].one_kernel) == (N == 2)
+    # compulsory bytes per point of this plan at n = 8: 312 (case 31, no rotation symbols) / 344 (case 21: + the four sponge fields)
+    if N == 8:
+        assert plans[0].bytes_per_point == (312.0 if CASE == 31 else 344.0)
     if CASE == 21:   # the mountain makes the metric depend on the level: the general kernel's case, not the column form's
         h13 = metrics[CHECK]["h_contra"][0, 2]   # (terrain-following levels: dz/dx at fixed eta fades with height)
         assert float((h13[0] - h13[-1]).abs().max()) > 1e-3 * float(h13.abs().max()) > 0.0
@@ -73,7 +82,7 @@ def test_e7_panel_all_rows_against_the_c_port(built_lib, CASE):
     Q = torch.stack(qs)
     del qs
     rhs = RhsEuler3D(plans)
-    assert not rhs._small_tiles()   # per-panel launches: bench.py's path
+    assert rhs._small_tiles() == (N != 8)   # per-panel launches: bench.py's path; one launch per phase for all panels: the matrix's
     R = rhs(Q)
     torch.cuda.synchronize()
 
@@ -109,14 +118,15 @@ def test_e7_panel_all_rows_against_the_c_port(built_lib, CASE):
     v = (torch.rand(Q.shape, generator=gen, device=DEV, dtype=Q.dtype) - 0.5) * Q.abs().amax(dim=(0, 2, 3, 4, 5), keepdim=True) * 1e-3
     eps = float(np.sqrt(np.finfo(float).eps))
     dual = rhs._jvp_plans()[CHECK]
-    assert int(dual.lib.wx_euler3d_uses_matrix_cores(dual._h, _lib.WX_KERNEL_JVP)) == 1 or os.environ.get("WXHIP_JVP_LEAN") == "0"
+    assert N != 8 or int(dual.lib.wx_euler3d_uses_matrix_cores(dual._h, _lib.WX_KERNEL_JVP)) == 1 or os.environ.get("WXHIP_JVP_LEAN") == "0"
     J = rhs.jvp(Q, v, eps, 1.0 / eps)
-    assert rhs.jvp_prepare(Q)
-    Jp = rhs.jvp(Q, v, eps, 1.0 / eps)
-    rhs.jvp_release()
-    torch.cuda.synchronize()
-    assert torch.equal(J, Jp)
-    del Jp
+    if N == 8:   # (the prepared form is the large tiles')
+        assert rhs.jvp_prepare(Q)
+        Jp = rhs.jvp(Q, v, eps, 1.0 / eps)
+        rhs.jvp_release()
+        torch.cuda.synchronize()
+        assert torch.equal(J, Jp)
+        del Jp
     vh = v.cpu().numpy()
     sends_c = {}
     for p in [CHECK] + [cs.NEIGHBOR[CHECK][e] for e in range(4)]:
