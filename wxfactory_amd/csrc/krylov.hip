@@ -489,38 +489,67 @@ __device__ __forceinline__ void two_sum(double a, double b, double& s, double& e
 // solve (LT strictly upper: column c = products of v_c with the older vectors; Linv = (I + LT^T)^{-1}, unit lower).
 // sol[0:j] = g - LT (Linv g);  hcol[0:j] = sol;  scal[0] = factor for the correction pass (1 / norm estimate, or 1),
 // scal[1] = the estimate (-1: the difference came out negative), scal[2] = 1 when the estimate stands.
-__device__ __forceinline__ void pmex_project_body(const double* __restrict__ G, int j, double* __restrict__ LT,
-                                                  double* __restrict__ Linv, int ld, double tol,
+// ST: the triangles the three products below walk - Linv's lower one, LT's upper one, j x j - staged in LDS by the whole
+// workgroup first (j <= kPmexStage): each product is a thread's OWN sequential sum, whose every term was a dependent round trip
+// to memory (20 us of a 114 us Krylov vector at the shipped .ini sizes); the sums keep their order, the results their bits.
+constexpr int kPmexStage = 64;
+template <bool ST>
+__device__ __forceinline__ void pmex_project_body(const double* __restrict__ G, int j, double* LT, double* Linv, int ld, double tol,
                                                   double* __restrict__ sol, double* __restrict__ hcol,
                                                   double* __restrict__ scal) {
     __shared__ double g[kPmexMaxM], t[kPmexMaxM], c[kPmexMaxM];
-    const int tid = threadIdx.x;
+    __shared__ double sL[ST ? kPmexStage * (kPmexStage + 1) : 1], sU[ST ? kPmexStage * (kPmexStage + 1) : 1];
+    constexpr int SS = kPmexStage + 1;
+    const int tid = threadIdx.x, bs = blockDim.x;
     const double* g0 = G;            // products with v_{j-1}
     const double* g1 = G + (j + 1);  // products with the new vector
-    for (int k = tid; k < j; k += blockDim.x) g[k] = g1[k];
+    for (int k = tid; k < j; k += bs) g[k] = g1[k];
+    if constexpr (ST) {   // (batches of eight loads in flight)
+        for (int base = tid; base < j * j; base += 8 * bs) {
+            double tl[8], tu[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * bs, r = idx / j, k = idx - r * j;
+                const bool in = idx < j * j;
+                // (not what this step itself writes below: row j-1 of Linv left of its diagonal, column j-1 of LT)
+                tl[u] = (in && k <= r && (r < j - 1 || k == r)) ? Linv[(size_t)r * ld + k] : 0.0;
+                tu[u] = (in && k > r && k < j - 1) ? LT[(size_t)r * ld + k] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * bs, r = idx / j, k = idx - r * j;
+                if (idx < j * j) {
+                    if (k <= r) { if (r < j - 1 || k == r) sL[r * SS + k] = tl[u]; }
+                    else if (k < j - 1) sU[r * SS + k] = tu[u];
+                }
+            }
+        }
+    }
     if (j > 1) {
-        for (int k = tid; k < j - 1; k += blockDim.x) {
+        for (int k = tid; k < j - 1; k += bs) {
             c[k] = g0[k];
             LT[(size_t)k * ld + (j - 1)] = g0[k];
+            if constexpr (ST) sU[k * SS + (j - 1)] = g0[k];
         }
         __syncthreads();
         // row j-1 of Linv: -c^T Linv[0:j-1, 0:j-1]  (Linv unit lower triangular: rows i >= k contribute to column k)
-        for (int k = tid; k < j - 1; k += blockDim.x) {
+        for (int k = tid; k < j - 1; k += bs) {
             double a = 0.0;
-            for (int i = k; i < j - 1; ++i) a += c[i] * Linv[(size_t)i * ld + k];
+            for (int i = k; i < j - 1; ++i) a += c[i] * (ST ? sL[i * SS + k] : Linv[(size_t)i * ld + k]);
             Linv[(size_t)(j - 1) * ld + k] = -a;
+            if constexpr (ST) sL[(j - 1) * SS + k] = -a;
         }
     }
     __syncthreads();
-    for (int r = tid; r < j; r += blockDim.x) {
+    for (int r = tid; r < j; r += bs) {
         double a = 0.0;
-        for (int k = 0; k <= r; ++k) a += Linv[(size_t)r * ld + k] * g[k];
+        for (int k = 0; k <= r; ++k) a += (ST ? sL[r * SS + k] : Linv[(size_t)r * ld + k]) * g[k];
         t[r] = a;
     }
     __syncthreads();
-    for (int r = tid; r < j; r += blockDim.x) {
+    for (int r = tid; r < j; r += bs) {
         double a = 0.0;
-        for (int cc = r + 1; cc < j; ++cc) a += LT[(size_t)r * ld + cc] * t[cc];
+        for (int cc = r + 1; cc < j; ++cc) a += (ST ? sU[r * SS + cc] : LT[(size_t)r * ld + cc]) * t[cc];
         const double v = g[r] - a;
         sol[r] = v;
         hcol[r] = v;
@@ -545,11 +574,16 @@ __device__ __forceinline__ void pmex_project_body(const double* __restrict__ G, 
         scal[2] = stands ? 1.0 : 0.0;
     }
 }
+__device__ __forceinline__ void pmex_project(const double* __restrict__ G, int j, double* LT, double* Linv, int ld, double tol,
+                                             double* __restrict__ sol, double* __restrict__ hcol, double* __restrict__ scal) {
+    if (j <= kPmexStage) pmex_project_body<true>(G, j, LT, Linv, ld, tol, sol, hcol, scal);   // (uniform over the launch)
+    else pmex_project_body<false>(G, j, LT, Linv, ld, tol, sol, hcol, scal);
+}
 __global__ __launch_bounds__(256) void pmex_project_kernel(const double* __restrict__ G, int j, double* __restrict__ LT,
                                                            double* __restrict__ Linv, int ld, double tol,
                                                            double* __restrict__ sol, double* __restrict__ hcol,
                                                            double* __restrict__ scal) {
-    pmex_project_body(G, j, LT, Linv, ld, tol, sol, hcol, scal);
+    pmex_project(G, j, LT, Linv, ld, tol, sol, hcol, scal);
 }
 
 // ---- the same vector in FOUR launches instead of nine to thirteen (one rank; the sizes of the shipped .ini files, where a
@@ -634,7 +668,7 @@ __global__ __launch_bounds__(256) void pmex_finish_project_kernel(const double* 
     }
     __threadfence_block();
     __syncthreads();
-    pmex_project_body(G, j, LT, Linv, ld, tol, sol, hcol, scal);
+    pmex_project(G, j, LT, Linv, ld, tol, sol, hcol, scal);
 }
 
 __global__ __launch_bounds__(256) void pmex_axpy_all_kernel(double* __restrict__ w, const double* __restrict__ V, size_t ldv, int j,
@@ -807,26 +841,22 @@ constexpr int kSmallEpt = 2;
 constexpr int kSmallBlocks = 128;    // at most (the one-launch step's barrier: two words per lane of the waiting wave)
 constexpr int kSmallMaxLen = kSmallBlocks * kSmallThreads * kSmallEpt;
 
-__device__ __forceinline__ void small_products(const double* __restrict__ V, size_t ldv, int J, const double* a, const double* b,
-                                               size_t n, int ept, double* sa, double* sb, double* red) {
+// the rows' part: sa, sb = the chunk's components of the two vectors (staged by the caller, barrier included); own_row (or -1): a
+// row that IS the second vector (PMEX forms its new row in the same launch: its chunk is sb, not yet a row in memory)
+__device__ __forceinline__ void small_rows(const double* __restrict__ V, size_t ldv, int J, size_t n, int ept, const double* sa,
+                                           const double* sb, double* red, int own_row) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t c0 = (size_t)blockIdx.x * kSmallThreads * ept;
-    for (int e = 0; e < ept; ++e) {
-        const int k = tid + kSmallThreads * e;
-        const size_t i = c0 + k;
-        sa[k] = i < n ? a[i] : 0.0;
-        sb[k] = i < n ? b[i] : 0.0;
-    }
-    __syncthreads();
     for (int r = wave; r < J; r += kSmallThreads / 64) {
         const double* row = V + (size_t)r * ldv + c0;
+        const bool own = r == own_row;   // (uniform over the wave)
         double pa = 0.0, pb = 0.0;
         for (int e0 = 0; e0 < ept; ++e0) {   // (a batch: 16 components per lane)
             double v[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int k = lane + 64 * (16 * e0 + e);
-                v[e] = c0 + k < n ? row[k] : 0.0;
+                v[e] = own ? sb[k] : (c0 + k < n ? row[k] : 0.0);
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -845,6 +875,20 @@ __device__ __forceinline__ void small_products(const double* __restrict__ V, siz
     __syncthreads();
 }
 
+__device__ __forceinline__ void small_products(const double* __restrict__ V, size_t ldv, int J, const double* a, const double* b,
+                                               size_t n, int ept, double* sa, double* sb, double* red) {
+    const int tid = threadIdx.x;
+    const size_t c0 = (size_t)blockIdx.x * kSmallThreads * ept;
+    for (int e = 0; e < ept; ++e) {
+        const int k = tid + kSmallThreads * e;
+        const size_t i = c0 + k;
+        sa[k] = i < n ? a[i] : 0.0;
+        sb[k] = i < n ? b[i] : 0.0;
+    }
+    __syncthreads();
+    small_rows(V, ldv, J, n, ept, sa, sb, red, -1);
+}
+
 // components per thread such that kSmallBlocks workgroups cover n
 static inline int small_ept(size_t n) {
     const size_t per = (size_t)kSmallBlocks * kSmallThreads;
@@ -855,6 +899,77 @@ static inline int small_blocks(size_t n, int ept) {
     const size_t per = (size_t)kSmallThreads * ept;
     const size_t g = (n + per - 1) / per;
     return (int)(g < 1 ? 1 : g);
+}
+
+// ---- PMEX at launch-bound lengths (one rank, up to kSmallMaxLen components, at most 64 rows): the new row formed and the 2 (j + 1)
+// products taken by the scheme above (pmex_aug_dot2_kernel walks the rows in passes of 16 with 32 accumulators per thread and as
+// many wave reductions per wave: 22 us of a 114 us Krylov vector at the shipped .ini sizes), at most kSmallBlocks partial sums per
+// product, which pmex_finish_project_small_kernel sums with all of them in flight before the projector (pmex_project: staged).
+__global__ __launch_bounds__(kSmallThreads) void pmex_aug_products_small_kernel(double* __restrict__ V, size_t ldv, int j, size_t n,
+                                                                                int p, const double* __restrict__ aw,
+                                                                                const double* __restrict__ uflip, int ept,
+                                                                                double* __restrict__ partial) {
+    __shared__ double sa[kSmallThreads * kSmallEpt], sb[kSmallThreads * kSmallEpt], red[128];
+    __shared__ double aug[16];
+    const int tid = threadIdx.x, m = j + 1;
+    double* vj = V + (size_t)j * ldv;
+    const double* vp = V + (size_t)(j - 1) * ldv;
+    if (tid < p) aug[tid] = vp[n + tid];
+    __syncthreads();
+    const size_t len = n + (size_t)p, c0 = (size_t)blockIdx.x * kSmallThreads * ept;
+    for (int e = 0; e < ept; ++e) {
+        const int k = tid + kSmallThreads * e;
+        const size_t i = c0 + k;
+        double ai = 0.0, bi = 0.0;
+        if (i < len) {
+            ai = vp[i];
+            if (i < n) {   // (aug_update_kernel's expression)
+                bi = aw[i];
+                for (int q = 0; q < p; ++q) bi += uflip[i * p + q] * aug[q];
+            } else {
+                const int t = (int)(i - n);
+                bi = t + 1 < p ? aug[t + 1] : 0.0;
+            }
+            vj[i] = bi;
+        }
+        sa[k] = ai;
+        sb[k] = bi;
+    }
+    __syncthreads();
+    small_rows(V, ldv, m, len, ept, sa, sb, red, j);
+    if (tid < 2 * m) {
+        const int which = tid / m, r = tid - which * m;
+        partial[(size_t)blockIdx.x * 2 * m + tid] = red[64 * which + r];
+    }
+}
+
+__global__ __launch_bounds__(kSmallThreads) void pmex_finish_project_small_kernel(const double* __restrict__ partial, int blocks, int j,
+                                                                                  double* LT, double* Linv, int ld, double tol,
+                                                                                  double* __restrict__ sol, double* __restrict__ hcol,
+                                                                                  double* __restrict__ scal, double* __restrict__ G) {
+    __shared__ double grp[8][128];
+    const int m2 = 2 * (j + 1);   // <= 128
+    const int k = threadIdx.x & 127, g = threadIdx.x >> 7;   // product, group of workgroups (8 groups of <= 16)
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int b = g + 8 * u;
+        v[u] = (k < m2 && b < blocks) ? partial[(size_t)b * m2 + k] : 0.0;
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += v[u];
+    grp[g][k] = acc;
+    __syncthreads();
+    if ((int)threadIdx.x < m2) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += grp[q][threadIdx.x];
+        G[threadIdx.x] = t;
+    }
+    __threadfence_block();
+    __syncthreads();
+    pmex_project(G, j, LT, Linv, ld, tol, sol, hcol, scal);
 }
 
 __global__ __launch_bounds__(kSmallThreads) void multi_dot2_small_kernel(const double* __restrict__ V, size_t ldv, int J,
@@ -1471,6 +1586,19 @@ static wx_status pmex_vector_impl(double* V, size_t ldv, int j, size_t n, int p,
     if (!split && !(fused_sw && fused_sw[0] == '0') && len <= kPmexFusedMaxLen) {   // launch-bound sizes: four launches (see pmex_aug_dot2_kernel)
         const size_t wantf = (len + 255) / 256;
         const unsigned gridf = (unsigned)(wantf < kPmexAxpyBlocks ? (wantf ? wantf : 1) : kPmexAxpyBlocks);
+        const char* small_sw = getenv("WXHIP_PMEX_SMALL");   // (A/B and tests: "0" = the round-5 product and projector launches)
+        if (!(small_sw && small_sw[0] == '0') && len <= (size_t)kSmallMaxLen && j + 1 <= 64) {
+            const int ept = small_ept(len), blocks = small_blocks(len, ept);
+            hipLaunchKernelGGL(pmex_aug_products_small_kernel, dim3(blocks), dim3(kSmallThreads), 0, st, V, ldv, j, n, p, aw, uflip, ept,
+                               dotw);
+            hipLaunchKernelGGL(pmex_finish_project_small_kernel, dim3(1), dim3(kSmallThreads), 0, st, dotw, blocks, j, LT, Linv, ld, tol,
+                               sol, hcol, scal, G);
+            hipLaunchKernelGGL(pmex_axpy_all_kernel, dim3(gridf), dim3(256), 0, st, vj, V, ldv, j, sol, len, scal, part, len);
+            hipLaunchKernelGGL(pmex_finish_scale_kernel, dim3(gridf), dim3(256), 0, st, vj, len, part, (int)gridf, tol, scal, hcol + j,
+                               own);
+            WX_HIP_TRY(hipGetLastError());
+            return WX_OK;
+        }
         // one workgroup of partial products per 256 components and no more (the row-batched kernels always leave kDotBlocks =
         // 2048 partials per product, which ONE finishing workgroup cannot sum in a launch's time): at most 512 here
         const unsigned gridd = (unsigned)(wantf < kPmexFusedDotBlocks ? (wantf ? wantf : 1) : kPmexFusedDotBlocks);
