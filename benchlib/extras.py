@@ -129,6 +129,16 @@ def ini_size_extras(dev, seed):
             ts.append(time.perf_counter() - t0)
         out[label].update(epi2_dt_s=dt_ini, epi2_step_ms=round(sorted(ts[3:])[2] * 1e3, 2),
                           epi2_krylov_vectors=int(epi.solver_info["iterations"]))
+        # ... and with the schema's default exponential solver (config-format.json: exponential_solver = pmex)
+        epx, Qp, tp = Epi(2, rhs, tol=1e-7, exponential_solver="pmex"), Q, []
+        for i in range(6):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            Qp = epx.step(Qp, dt_ini)
+            torch.cuda.synchronize()
+            tp.append(time.perf_counter() - t0)
+        out[label].update(epi2_pmex_step_ms=round(sorted(tp[2:])[2] * 1e3, 2),
+                          epi2_pmex_krylov_vectors=int(epx.solver_info["iterations"]))
         # BASELINE config 4's integrator at this size: Rosenbrock-2 + FGMRES (integrators/ros2.py:24-81), the Gram-Schmidt step on
         # the device and one read-back per pass of Krylov vectors (include/wxhip.h: wx_fgmres_vector)
         from wxfactory_amd.integrators import Ros2
